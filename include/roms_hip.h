@@ -1,0 +1,201 @@
+/*
+ * roms_hip.h -- C ABI of the MI355X-native ROMS nonlinear 3-D time-stepping
+ * hot path (libroms_hip.so).
+ *
+ * The reference has no FFI; its seam is the Fortran module-procedure name
+ * `CALL X(ng, tile)` used by ROMS/Nonlinear/main3d.F:307-814 and
+ * ROMS/Nonlinear/initial.F:337-571.  Each entry point below replaces the body
+ * of one such procedure (the file:line it replaces is cited on the
+ * declaration).  The ISO_C_BINDING interface block a maintainer adds on the
+ * Fortran side is in roms_trunk_mgh_amd/fortran/roms_hip_mod.F90 and
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: ints, doubles, pointers; no C++/torch types.
+ *   - every entry returns int: 0 = ROMS NoError; non-zero = error, mapped by
+ *     the Fortran shim to exit_flag 8 (algorithm) or 2 (communication), the
+ *     codes of ROMS/Modules/mod_scalars.F:523-532.  The library never aborts.
+ *   - host arrays stay owned by the caller (Fortran `allocate`); the library
+ *     owns device mirrors and device scratch (the `_tile` routines' automatic
+ *     IminS:ImaxS work arrays).
+ *   - array layout = the reference's: column-major, i fastest, common
+ *     horizontal extents LBi:UBi,LBj:UBj for every field of a tile.
+ */
+#ifndef ROMS_HIP_H
+#define ROMS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Field identifiers and shapes                                        */
+/* ------------------------------------------------------------------ */
+enum roms_kind {
+  K_2D = 0, K_2D_T2, K_2D_T3, K_2D_NT,
+  K_3DR, K_3DW, K_3DR_T2, K_3DW_T2, K_3DW_NAT, K_4DT
+};
+
+enum roms_field_id {
+#define ROMS_FIELD(name, kind, owner) FID_##name,
+#include "roms_fields.def"
+#undef ROMS_FIELD
+  FID_COUNT
+};
+
+/* All module arrays of one tile (host pointers in the oracle, device pointers
+ * inside the library). */
+typedef struct roms_fields {
+#define ROMS_FIELD(name, kind, owner) double *name;
+#include "roms_fields.def"
+#undef ROMS_FIELD
+} roms_fields_t;
+
+/* ------------------------------------------------------------------ */
+/* Tile bounds: every integer of ROMS/Include/set_bounds.h:20-79 and   */
+/* ROMS/Include/tile.h:21-45, plus DOMAIN(ng)%*_Edge(tile)             */
+/* (ROMS/Modules/mod_param.F:286-323) and the grid sizes.             */
+/* ------------------------------------------------------------------ */
+typedef struct roms_bounds {
+  int Lm, Mm, N, NT, NAT;
+  int ntileI, ntileJ, tile, Itile, Jtile;
+  int NghostPoints, EWperiodic, NSperiodic;
+  int west_edge, east_edge, south_edge, north_edge;
+  int LBi, UBi, LBj, UBj;
+  int Istr, Iend, Jstr, Jend;
+  int IstrB, IendB, IstrM, IstrP, IendP, IstrR, IendR, IstrT, IendT, IstrU;
+  int JstrB, JendB, JstrM, JstrP, JendP, JstrR, JendR, JstrT, JendT, JstrV;
+  int Istrm3, Istrm2, Istrm1, IstrUm2, IstrUm1;
+  int Iendp1, Iendp2, Iendp2i, Iendp3;
+  int Jstrm3, Jstrm2, Jstrm1, JstrVm2, JstrVm1;
+  int Jendp1, Jendp2, Jendp2i, Jendp3;
+} roms_bounds_t;
+
+/* ------------------------------------------------------------------ */
+/* Run-time parameters (mod_scalars.F, mod_param.F)                    */
+/* ------------------------------------------------------------------ */
+#define ROMS_MAXN   64     /* max vertical levels held in the param block   */
+#define ROMS_MAXNT  16     /* max tracers                                   */
+#define ROMS_MAXFAST 256   /* max 2*ndtfast                                 */
+
+/* Tracer advection scheme codes = the logical records of T_ADV
+ * (mod_param.F:382-394). */
+enum roms_adv {
+  ADV_C2 = 0, ADV_C4, ADV_A4, ADV_U3, ADV_SU3, ADV_SPLINES, ADV_MPDATA, ADV_HSIMT
+};
+/* Lateral boundary condition codes actually supported on this path
+ * (T_LBC, mod_param.F:120-160): closed wall or periodic. */
+enum roms_lbc { LBC_PERIODIC = 0, LBC_CLOSED = 1 };
+
+typedef struct roms_params {
+  double dt, dtfast;                 /* mod_scalars.F dt(ng), dtfast(ng)     */
+  double g, rho0;                    /* mod_scalars.F:431-441                */
+  double gamma2;                     /* slipperiness, roms_*.in GAMMA2       */
+  double lambda;                     /* implicit weight, mod_scalars.F:724   */
+  int    ndtfast, nfast;             /* set_weights.F:3-244                  */
+  double weight1[ROMS_MAXFAST];      /* weight(1,1:2*ndtfast,ng)             */
+  double weight2[ROMS_MAXFAST];      /* weight(2,1:2*ndtfast,ng)             */
+  int    Vtransform;                 /* set_depth.F:82                       */
+  double hc;
+  double sc_r[ROMS_MAXN + 1], Cs_r[ROMS_MAXN + 1];   /* index 1..N           */
+  double sc_w[ROMS_MAXN + 1], Cs_w[ROMS_MAXN + 1];   /* index 0..N           */
+  int    Hadv[ROMS_MAXNT], Vadv[ROMS_MAXNT];         /* enum roms_adv        */
+  int    lbc_west, lbc_east, lbc_south, lbc_north;   /* enum roms_lbc        */
+  /* equation of state */
+  int    nonlin_eos;                 /* 1 = NONLIN_EOS (rho_eos.F:111)       */
+  double R0, T0, S0, Tcoef, Scoef;   /* linear EOS (rho_eos.F:576)           */
+  /* CPP-derived option switches of the application header */
+  int    uv_adv, uv_cor, uv_vis2, curvgrid, var_rho_2d;
+  int    ts_dif2, mix_geo_ts, mix_s_ts, salinity, lmd_nonlocal, solar_source;
+  int    splines_vdiff, splines_vvisc;
+  double Akt_bak[ROMS_MAXNT], Akv_bak;
+} roms_params_t;
+
+/* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and
+ * mod_scalars.F (iic, iif, ntfirst, PREDICTOR_2D_STEP); see
+ * main3d.F:189-191 and main3d.F:597-662.  All 1-based as in Fortran. */
+typedef struct roms_step_idx {
+  int iic, ntfirst;
+  int nstp, nnew, nrhs;
+  int kstp, krhs, knew;
+  int iif, predictor_2d_step;
+} roms_step_idx_t;
+
+/* ------------------------------------------------------------------ */
+/* Library life cycle                                                  */
+/* ------------------------------------------------------------------ */
+/* Replaces nothing; called once after ROMS_initialize (nl_roms.h:60-231).
+ * nccl_unique_id: 128-byte ncclUniqueId shared by all ranks, or NULL when
+ * ntileI*ntileJ == 1. */
+int roms_hip_init(int rank, int ntileI, int ntileJ, int device_id,
+                  const void *nccl_unique_id);
+int roms_hip_finalize(void);
+/* 128-byte id for roms_hip_init, generated on rank 0 (ncclGetUniqueId). */
+int roms_hip_get_unique_id(void *out128);
+
+/* BOUNDS(ng)%...(tile): get_bounds.F:738 (get_tile), :1009 (var_bounds). */
+int roms_hip_set_bounds(const roms_bounds_t *b);
+int roms_hip_set_params(const roms_params_t *p);
+
+/* Register the host address (c_loc) of one module array; allocates its
+ * device mirror.  n_doubles is checked against the shape implied by kind. */
+int roms_hip_register_field(int field_id, double *host_ptr, long n_doubles);
+/* Host <-> device copies of one field (whole array). */
+int roms_hip_sync_to_device(int field_id);
+int roms_hip_sync_to_host(int field_id);
+int roms_hip_sync_all_to_device(void);
+int roms_hip_sync_all_to_host(void);
+/* Device address of a field mirror (for zero-copy consumers); NULL if none. */
+double *roms_hip_device_ptr(int field_id);
+int roms_hip_device_synchronize(void);
+const char *roms_hip_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* Hot-path entry points -- one per reference module procedure         */
+/* ------------------------------------------------------------------ */
+/* set_massflux(ng,tile,model)      ROMS/Nonlinear/set_massflux.F:28  */
+int roms_hip_set_massflux(const roms_step_idx_t *s);
+/* rho_eos(ng,tile,model)           ROMS/Nonlinear/rho_eos.F:47       */
+int roms_hip_rho_eos(const roms_step_idx_t *s);
+/* omega(ng,tile,model)             ROMS/Nonlinear/omega.F:28         */
+int roms_hip_omega(const roms_step_idx_t *s);
+/* set_zeta(ng,tile)                ROMS/Nonlinear/set_zeta.F:25      */
+int roms_hip_set_zeta(const roms_step_idx_t *s);
+/* set_depth(ng,tile,model)         ROMS/Nonlinear/set_depth.F:33     */
+int roms_hip_set_depth(const roms_step_idx_t *s);
+/* rhs3d(ng,tile) -> pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2
+ *                                  ROMS/Nonlinear/rhs3d.F:25         */
+int roms_hip_rhs3d(const roms_step_idx_t *s);
+/* the pieces of rhs3d, exported for per-kernel parity tests */
+int roms_hip_pre_step3d(const roms_step_idx_t *s);  /* pre_step3d.F:39   */
+int roms_hip_prsgrd(const roms_step_idx_t *s);      /* prsgrd32.h:40     */
+int roms_hip_t3dmix2(const roms_step_idx_t *s);     /* t3dmix2_geo.h:23  */
+int roms_hip_rhs3d_tile(const roms_step_idx_t *s);  /* rhs3d.F:174       */
+int roms_hip_uv3dmix2(const roms_step_idx_t *s);    /* uv3dmix2_s.h:42   */
+/* step2d(ng,tile)                  ROMS/Nonlinear/step2d_LF_AM3.h:18 */
+int roms_hip_step2d(const roms_step_idx_t *s);
+/* step3d_uv(ng,tile)               ROMS/Nonlinear/step3d_uv.F:27     */
+int roms_hip_step3d_uv(const roms_step_idx_t *s);
+/* step3d_t(ng,tile)                ROMS/Nonlinear/step3d_t.F:40      */
+int roms_hip_step3d_t(const roms_step_idx_t *s);
+
+/* The whole barotropic loop LOOP_2D of main3d.F:592-700 in one call
+ * (predictor/corrector sequencing done inside, optionally replayed from a
+ * hipGraph).  indx1 is mod_stepping's indx1(ng), updated on return. */
+int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1);
+
+/* mp_exchange2d/3d/4d (ROMS/Utility/mp_exchange.F:290/1413/2753) together
+ * with the periodic exchange_*_tile (exchange_2d.F:229, exchange_3d.F:259) on
+ * whole registered fields; level = 1-based trailing index (time level or
+ * tracer) or 0 for all.  Exported for tests. */
+int roms_hip_exchange(int field_id, int level);
+
+/* Timing helper: average device milliseconds of the last call of each entry
+ * measured with hipEvents on the library's stream (bench.py roofline). */
+int roms_hip_timing_enable(int on);
+double roms_hip_timing_last_ms(const char *entry);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROMS_HIP_H */

@@ -1,0 +1,82 @@
+"""CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front end of oracle/_build/liboracle.so, the plain-C restatement of the
+reference's nonlinear 3-D kernels (see oracle/oracle.h for the pinning status).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package; the product path (roms_trunk_mgh_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from roms_trunk_mgh_amd import abi
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KERNELS = ["set_massflux", "omega", "set_zeta", "set_depth", "rho_eos", "pre_step3d",
+           "prsgrd", "t3dmix2", "rhs3d_tile", "uv3dmix2", "rhs3d", "step2d",
+           "step3d_uv", "step3d_t"]
+
+
+def build(force=False):
+    so = os.path.join(_DIR, "_build", "liboracle.so")
+    if force or not os.path.exists(so) or os.path.exists("/usr/bin/make"):
+        if os.path.exists("/usr/bin/make") or force:
+            subprocess.run(["make", "-s", "-C", _DIR], check=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_DIR, "_build", "liboracle.so")
+        if not os.path.exists(so):
+            so = build()
+        _LIB = C.CDLL(so)
+        abi.check_abi(_LIB)
+        for k in KERNELS:
+            fn = getattr(_LIB, "oracle_" + k, None)
+            if fn is None:
+                continue
+            fn.restype = C.c_int
+            fn.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params),
+                           C.POINTER(abi.StepIdx), C.POINTER(abi.Fields)]
+        if hasattr(_LIB, "oracle_step2d_loop"):
+            _LIB.oracle_step2d_loop.restype = C.c_int
+            _LIB.oracle_step2d_loop.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params),
+                                                C.POINTER(abi.StepIdx), C.POINTER(abi.Fields),
+                                                C.POINTER(C.c_int)]
+    return _LIB
+
+
+class Oracle:
+    """Backend with the same method names as roms_trunk_mgh_amd.hip.RomsHip,
+    operating in place on a TileState's host arrays."""
+
+    name = "oracle"
+
+    def __init__(self, state):
+        self.st = state
+        self.l = lib()
+        self.F = state.fields_struct()
+
+    def call(self, kernel, s):
+        fn = getattr(self.l, "oracle_" + kernel)
+        rc = fn(C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))
+        if rc != 0:
+            raise RuntimeError(f"oracle_{kernel} returned {rc}")
+
+    def step2d_loop(self, s, indx1):
+        ii = C.c_int(indx1)
+        rc = self.l.oracle_step2d_loop(C.byref(self.st.b), C.byref(self.st.p), C.byref(s),
+                                       C.byref(self.F), C.byref(ii))
+        if rc != 0:
+            raise RuntimeError(f"oracle_step2d_loop returned {rc}")
+        return ii.value
+
+    def to_host(self):
+        return self.st
+
+    def sync(self):
+        pass

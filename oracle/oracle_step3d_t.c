@@ -1,0 +1,263 @@
+/*
+ * oracle_step3d_t.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ * step3d_t_tile: corrector time-step for tracers
+ * (ROMS/Nonlinear/step3d_t.F:108-1682).  Parity unpinned: the reference file
+ * cannot be compiled here (USE mod_sources -> mod_netcdf).
+ */
+#include "oracle.h"
+
+int oracle_step3d_t(OARGS)
+{
+  ORACLE_PROLOGUE
+  if (o_check_lbc(b, p)) return 8;
+  const int nnew = s->nnew;
+  const double dt = p->dt;
+  const double eps = 1.0E-16;
+  for (int itrc = 1; itrc <= NT; itrc++) {
+    int ha = p->Hadv[itrc - 1], va = p->Vadv[itrc - 1];
+    if (ha == ADV_MPDATA || ha == ADV_HSIMT || ha == ADV_SPLINES) return 8;
+    if (va == ADV_MPDATA || va == ADV_HSIMT || va == ADV_U3) return 8;
+  }
+  double *FX_ = walloc(nis * njs), *FE_ = walloc(nis * njs);
+  double *curv_ = walloc(nis * njs), *grad_ = walloc(nis * njs);
+  double *oHz_ = walloc(nis * njs * N);
+  double *CF_ = walloc(nis * (N + 1)), *BC_ = walloc(nis * (N + 1));
+  double *DC_ = walloc(nis * (N + 1)), *FC_ = walloc(nis * (N + 1));
+#define FX(i,j)    FX_[WS2(i,j)]
+#define FE(i,j)    FE_[WS2(i,j)]
+#define curv(i,j)  curv_[WS2(i,j)]
+#define grad(i,j)  grad_[WS2(i,j)]
+#define oHz(i,j,k) oHz_[WS3(i,j,k)]
+#define CF(i,k)    CF_[WSK(i,k)]
+#define BC(i,k)    BC_[WSK(i,k)]
+#define DC(i,k)    DC_[WSK(i,k)]
+#define FC(i,k)    FC_[WSK(i,k)]
+
+  /* step3d_t.F:340-360 */
+  for (int k = 1; k <= N; k++)
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) oHz(i, j, k) = 1.0 / Hz(i, j, k);
+
+  /* T_LOOP1 / K_LOOP: horizontal advection, step3d_t.F:363-880 */
+  for (int itrc = 1; itrc <= NT; itrc++) {
+    const int ha = p->Hadv[itrc - 1];
+    for (int k = 1; k <= N; k++) {
+      if (ha == ADV_C2) {
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istr; i <= Iend + 1; i++)
+            FX(i, j) = Huon(i, j, k) * 0.5 * (t(i - 1, j, k, 3, itrc) + t(i, j, k, 3, itrc));
+        for (int j = Jstr; j <= Jend + 1; j++)
+          for (int i = Istr; i <= Iend; i++)
+            FE(i, j) = Hvom(i, j, k) * 0.5 * (t(i, j - 1, k, 3, itrc) + t(i, j, k, 3, itrc));
+      } else {
+        /* A4 / C4 / SU3 / U3 -- step3d_t.F:596-828 */
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istrm1; i <= Iendp2; i++)
+            FX(i, j) = t(i, j, k, 3, itrc) - t(i - 1, j, k, 3, itrc);
+        if (!EWperiodic) {
+          if (west_edge) for (int j = Jstr; j <= Jend; j++) FX(Istr - 1, j) = FX(Istr, j);
+          if (east_edge) for (int j = Jstr; j <= Jend; j++) FX(Iend + 2, j) = FX(Iend + 1, j);
+        }
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istr - 1; i <= Iend + 1; i++) {
+            if (ha == ADV_U3) {
+              curv(i, j) = FX(i + 1, j) - FX(i, j);
+            } else if (ha == ADV_A4) {
+              double cff = 2.0 * FX(i + 1, j) * FX(i, j);
+              if (cff > eps) grad(i, j) = cff / (FX(i + 1, j) + FX(i, j));
+              else grad(i, j) = 0.0;
+            } else {
+              grad(i, j) = 0.5 * (FX(i + 1, j) + FX(i, j));
+            }
+          }
+        double cff1 = 1.0 / 6.0, cff2 = 1.0 / 3.0;
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istr; i <= Iend + 1; i++) {
+            if (ha == ADV_U3) {
+              FX(i, j) = Huon(i, j, k) * 0.5 * (t(i - 1, j, k, 3, itrc) + t(i, j, k, 3, itrc)) -
+                         cff1 * (curv(i - 1, j) * MAX(Huon(i, j, k), 0.0) +
+                                 curv(i, j) * MIN(Huon(i, j, k), 0.0));
+            } else {
+              FX(i, j) = Huon(i, j, k) * 0.5 *
+                         (t(i - 1, j, k, 3, itrc) + t(i, j, k, 3, itrc) -
+                          cff2 * (grad(i, j) - grad(i - 1, j)));
+            }
+          }
+        for (int j = Jstrm1; j <= Jendp2; j++)
+          for (int i = Istr; i <= Iend; i++)
+            FE(i, j) = t(i, j, k, 3, itrc) - t(i, j - 1, k, 3, itrc);
+        if (!NSperiodic) {
+          if (south_edge) for (int i = Istr; i <= Iend; i++) FE(i, Jstr - 1) = FE(i, Jstr);
+          if (north_edge) for (int i = Istr; i <= Iend; i++) FE(i, Jend + 2) = FE(i, Jend + 1);
+        }
+        for (int j = Jstr - 1; j <= Jend + 1; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            if (ha == ADV_U3) {
+              curv(i, j) = FE(i, j + 1) - FE(i, j);
+            } else if (ha == ADV_A4) {
+              double cff = 2.0 * FE(i, j + 1) * FE(i, j);
+              if (cff > eps) grad(i, j) = cff / (FE(i, j + 1) + FE(i, j));
+              else grad(i, j) = 0.0;
+            } else {
+              grad(i, j) = 0.5 * (FE(i, j + 1) + FE(i, j));
+            }
+          }
+        for (int j = Jstr; j <= Jend + 1; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            if (ha == ADV_U3) {
+              FE(i, j) = Hvom(i, j, k) * 0.5 * (t(i, j - 1, k, 3, itrc) + t(i, j, k, 3, itrc)) -
+                         cff1 * (curv(i, j - 1) * MAX(Hvom(i, j, k), 0.0) +
+                                 curv(i, j) * MIN(Hvom(i, j, k), 0.0));
+            } else {
+              FE(i, j) = Hvom(i, j, k) * 0.5 *
+                         (t(i, j - 1, k, 3, itrc) + t(i, j, k, 3, itrc) -
+                          cff2 * (grad(i, j) - grad(i, j - 1)));
+            }
+          }
+      }
+      /* HADV_STEPPING, step3d_t.F:831-875 */
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend; i++) {
+          double cff = dt * pm(i, j) * pn(i, j);
+          double cff1 = cff * (FX(i + 1, j) - FX(i, j));
+          double cff2 = cff * (FE(i, j + 1) - FE(i, j));
+          double cff3 = cff1 + cff2;
+          t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) - cff3;
+        }
+    }
+  }
+
+  /* T_LOOP2 / J_LOOP1: vertical advection, step3d_t.F:883-1210 */
+  for (int itrc = 1; itrc <= NT; itrc++) {
+    const int va = p->Vadv[itrc - 1];
+    for (int j = Jstr; j <= Jend; j++) {
+      if (va == ADV_SPLINES) {
+        for (int i = Istr; i <= Iend; i++) {
+          FC(i, 0) = 2.0 * t(i, j, 1, 3, itrc);
+          CF(i, 1) = 1.0;
+        }
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            double cff = 1.0 / (2.0 * Hz(i, j, k) + Hz(i, j, k + 1) * (2.0 - CF(i, k)));
+            CF(i, k + 1) = cff * Hz(i, j, k);
+            FC(i, k) = cff * (3.0 * (Hz(i, j, k) * t(i, j, k + 1, 3, itrc) +
+                                     Hz(i, j, k + 1) * t(i, j, k, 3, itrc)) -
+                              Hz(i, j, k + 1) * FC(i, k - 1));
+          }
+        for (int i = Istr; i <= Iend; i++)
+          FC(i, N) = (2.0 * t(i, j, N, 3, itrc) - FC(i, N - 1)) / (1.0 - CF(i, N));
+        for (int k = N - 1; k >= 0; k--)
+          for (int i = Istr; i <= Iend; i++) {
+            FC(i, k) = FC(i, k) - CF(i, k + 1) * FC(i, k + 1);
+            FC(i, k + 1) = W(i, j, k + 1) * FC(i, k + 1);
+          }
+        for (int i = Istr; i <= Iend; i++) {
+          FC(i, N) = 0.0;
+          FC(i, 0) = 0.0;
+        }
+      } else if (va == ADV_A4) {
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++)
+            FC(i, k) = t(i, j, k + 1, 3, itrc) - t(i, j, k, 3, itrc);
+        for (int i = Istr; i <= Iend; i++) {
+          FC(i, 0) = FC(i, 1);
+          FC(i, N) = FC(i, N - 1);
+        }
+        for (int k = 1; k <= N; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            double cff = 2.0 * FC(i, k) * FC(i, k - 1);
+            if (cff > eps) CF(i, k) = cff / (FC(i, k) + FC(i, k - 1));
+            else CF(i, k) = 0.0;
+          }
+        double cff1 = 1.0 / 3.0;
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++)
+            FC(i, k) = W(i, j, k) * 0.5 *
+                       (t(i, j, k, 3, itrc) + t(i, j, k + 1, 3, itrc) -
+                        cff1 * (CF(i, k + 1) - CF(i, k)));
+        for (int i = Istr; i <= Iend; i++) {
+          FC(i, 0) = 0.0;
+          FC(i, N) = 0.0;
+        }
+      } else if (va == ADV_C2) {
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++)
+            FC(i, k) = W(i, j, k) * 0.5 * (t(i, j, k, 3, itrc) + t(i, j, k + 1, 3, itrc));
+        for (int i = Istr; i <= Iend; i++) {
+          FC(i, 0) = 0.0;
+          FC(i, N) = 0.0;
+        }
+      } else { /* C4 / SU3, step3d_t.F:1094+ */
+        double cff1 = 0.5, cff2 = 7.0 / 12.0, cff3 = 1.0 / 12.0;
+        for (int k = 2; k <= N - 2; k++)
+          for (int i = Istr; i <= Iend; i++)
+            FC(i, k) = W(i, j, k) *
+                       (cff2 * (t(i, j, k, 3, itrc) + t(i, j, k + 1, 3, itrc)) -
+                        cff3 * (t(i, j, k - 1, 3, itrc) + t(i, j, k + 2, 3, itrc)));
+        for (int i = Istr; i <= Iend; i++) {
+          FC(i, 0) = 0.0;
+          FC(i, 1) = W(i, j, 1) *
+                     (cff1 * t(i, j, 1, 3, itrc) + cff2 * t(i, j, 2, 3, itrc) -
+                      cff3 * t(i, j, 3, 3, itrc));
+          FC(i, N - 1) = W(i, j, N - 1) *
+                         (cff1 * t(i, j, N, 3, itrc) + cff2 * t(i, j, N - 1, 3, itrc) -
+                          cff3 * t(i, j, N - 2, 3, itrc));
+          FC(i, N) = 0.0;
+        }
+      }
+      /* VADV_STEPPING, step3d_t.F:1168-1208 */
+      for (int i = Istr; i <= Iend; i++) CF(i, 0) = dt * pm(i, j) * pn(i, j);
+      for (int k = 1; k <= N; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          double cff1 = CF(i, 0) * (FC(i, k) - FC(i, k - 1));
+          t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) - cff1;
+          t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) * oHz(i, j, k);
+        }
+    }
+  }
+
+  /* J_LOOP2: implicit vertical diffusion, spline form, step3d_t.F:1363-1455 */
+  for (int j = Jstr; j <= Jend; j++) {
+    for (int itrc = 1; itrc <= NT; itrc++) {
+      const int ltrc = MIN(NAT, itrc);
+      double cff1 = 1.0 / 6.0;
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          FC(i, k) = cff1 * Hz(i, j, k) - dt * Akt(i, j, k - 1, ltrc) * oHz(i, j, k);
+          CF(i, k) = cff1 * Hz(i, j, k + 1) - dt * Akt(i, j, k + 1, ltrc) * oHz(i, j, k + 1);
+        }
+      for (int i = Istr; i <= Iend; i++) {
+        CF(i, 0) = 0.0;
+        DC(i, 0) = 0.0;
+      }
+      cff1 = 1.0 / 3.0;
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          BC(i, k) = cff1 * (Hz(i, j, k) + Hz(i, j, k + 1)) +
+                     dt * Akt(i, j, k, ltrc) * (oHz(i, j, k) + oHz(i, j, k + 1));
+          double cff = 1.0 / (BC(i, k) - FC(i, k) * CF(i, k - 1));
+          CF(i, k) = cff * CF(i, k);
+          DC(i, k) = cff * (t(i, j, k + 1, nnew, itrc) - t(i, j, k, nnew, itrc) -
+                            FC(i, k) * DC(i, k - 1));
+        }
+      for (int i = Istr; i <= Iend; i++) DC(i, N) = 0.0;
+      for (int k = N - 1; k >= 1; k--)
+        for (int i = Istr; i <= Iend; i++) DC(i, k) = DC(i, k) - CF(i, k) * DC(i, k + 1);
+      for (int k = 1; k <= N; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          DC(i, k) = DC(i, k) * Akt(i, j, k, ltrc);
+          double c1 = dt * oHz(i, j, k) * (DC(i, k) - DC(i, k - 1));
+          t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) + c1;
+        }
+    }
+  }
+
+  /* lateral BCs + periodic wrap, step3d_t.F:1564-1626 */
+  for (int itrc = 1; itrc <= NT; itrc++) {
+    o_t3dbc(b, p, s, F, nnew, itrc);
+    o_exchange3d(b, GT_R, N, &t(LBi, LBj, 1, nnew, itrc));
+  }
+  free(FX_); free(FE_); free(curv_); free(grad_); free(oHz_);
+  free(CF_); free(BC_); free(DC_); free(FC_);
+  return 0;
+}

@@ -1,0 +1,397 @@
+"""Synthetic (analytic) problem set-up for the configurations BASELINE.json
+names: BENCHMARK1/2/3, UPWELLING, SEAMOUNT.  Host-side, runs once -- this is
+the reference's `initial` phase (ROMS/Nonlinear/initial.F:273-571), restated in
+numpy only far enough to give the hot path realistic inputs:
+
+  grid      ROMS/Functionals/ana_grid.h   (BENCHMARK :243-248,459-479,674-689,
+            867-874,920-926; UPWELLING :384-392,1047-1070; SEAMOUNT :345-350,
+            1021-1028) and ROMS/Utility/metrics.F
+  s-coord   ROMS/Utility/set_scoord.F (Vstretching 4)
+  weights   ROMS/Utility/set_weights.F:3-244 (POWER_LAW)
+  IC        ROMS/Functionals/ana_initial.h:523-536, 787-794, 806-825
+
+The per-step physics *outside* the hot path (bulk_flux, lmd_vmix, set_vbc --
+SURVEY.md section 8f-1) is replaced by fixed analytic forcing/mixing fields
+that are inputs to BOTH the oracle and the HIP path.
+"""
+import math
+
+import numpy as np
+
+from . import abi
+from .bounds import make_bounds
+from .state import TileState
+
+# ---------------------------------------------------------------------------
+# configuration table (ROMS/External/roms_*.in)
+# ---------------------------------------------------------------------------
+CONFIGS = {
+    # name: Lm, Mm, N, NAT, dt, ndtfast, tnu2, visc2, gamma2, theta_s, theta_b,
+    #       Tcline, Hadv, Vadv, app
+    "BENCHMARK1": dict(Lm=512, Mm=64, N=30, NAT=2, dt=150.0, ndtfast=20, tnu2=500.0,
+                       visc2=5000.0, gamma2=1.0, theta_s=0.0, theta_b=0.0, Tcline=400.0,
+                       Hadv="U3", Vadv="C4", app="BENCHMARK"),
+    "BENCHMARK2": dict(Lm=1024, Mm=128, N=30, NAT=2, dt=150.0, ndtfast=20, tnu2=500.0,
+                       visc2=5000.0, gamma2=1.0, theta_s=0.0, theta_b=0.0, Tcline=400.0,
+                       Hadv="U3", Vadv="C4", app="BENCHMARK"),
+    "BENCHMARK3": dict(Lm=2048, Mm=256, N=30, NAT=2, dt=150.0, ndtfast=20, tnu2=500.0,
+                       visc2=5000.0, gamma2=1.0, theta_s=0.0, theta_b=0.0, Tcline=400.0,
+                       Hadv="U3", Vadv="C4", app="BENCHMARK"),
+    # shrunken BENCHMARK for CPU-sized parity tests
+    "BENCHMARK_TINY": dict(Lm=64, Mm=32, N=30, NAT=2, dt=150.0, ndtfast=20, tnu2=500.0,
+                           visc2=5000.0, gamma2=1.0, theta_s=0.0, theta_b=0.0, Tcline=400.0,
+                           Hadv="U3", Vadv="C4", app="BENCHMARK"),
+    "UPWELLING": dict(Lm=41, Mm=80, N=16, NAT=2, dt=300.0, ndtfast=30, tnu2=0.0,
+                      visc2=5.0, gamma2=1.0, theta_s=3.0, theta_b=0.0, Tcline=25.0,
+                      Hadv="U3", Vadv="C4", app="UPWELLING"),
+    "SEAMOUNT": dict(Lm=49, Mm=48, N=13, NAT=1, dt=60.0, ndtfast=20, tnu2=0.0,
+                     visc2=0.0, gamma2=-1.0, theta_s=6.5, theta_b=2.0, Tcline=100.0,
+                     Hadv="A4", Vadv="A4", app="SEAMOUNT"),
+}
+
+G = 9.81            # mod_scalars.F:431-441
+RHO0 = 1025.0
+ERADIUS = 6371315.0
+DEG2RAD = math.pi / 180.0
+
+
+def set_weights(ndtfast):
+    """ROMS/Utility/set_weights.F:3-244, POWER_LAW filter.  The reference sums in
+    real(r16); numpy longdouble is used here (differences <= 1 ulp of double)."""
+    LD = np.longdouble
+    Falpha, Fbeta, Fgamma = 2.0, 4.0, 0.284     # mod_scalars.F:310-312
+    n2 = 2 * ndtfast
+    w1 = np.zeros(n2 + 2, dtype=np.float64)     # 1-based
+    w2 = np.zeros(n2 + 2, dtype=np.float64)
+    nfast = 0
+    scale = (Falpha + 1.0) * (Falpha + Fbeta + 1.0) / (
+        (Falpha + 2.0) * (Falpha + Fbeta + 2.0) * float(ndtfast))
+    gamma = Fgamma * max(0.0, 1.0 - 10.0 / float(ndtfast))
+    for _ in range(16):
+        nfast = 0
+        for i in range(1, n2 + 1):
+            cff = LD(scale) * LD(i)
+            w1[i] = float(cff ** LD(Falpha) - cff ** LD(Falpha + Fbeta) - LD(gamma) * cff)
+            if w1[i] > 0.0:
+                nfast = i
+            if nfast > 0 and w1[i] < 0.0:
+                w1[i] = 0.0
+        wsum = LD(0)
+        shift = LD(0)
+        for i in range(1, nfast + 1):
+            wsum += LD(w1[i])
+            shift += LD(w1[i]) * LD(i)
+        scale = float(LD(scale) * shift / (wsum * LD(ndtfast)))
+    for _ in range(ndtfast):
+        wsum = LD(0)
+        shift = LD(0)
+        for i in range(1, nfast + 1):
+            wsum += LD(w1[i])
+            shift += LD(i) * LD(w1[i])
+        shift = shift / wsum
+        cff = LD(ndtfast) - shift
+        if cff > 1:
+            nfast += 1
+            for i in range(nfast, 1, -1):
+                w1[i] = w1[i - 1]
+            w1[1] = 0.0
+        elif cff > 0:
+            wsum = LD(1) - cff
+            for i in range(nfast, 1, -1):
+                w1[i] = float(wsum * LD(w1[i]) + cff * LD(w1[i - 1]))
+            w1[1] = float(wsum * LD(w1[1]))
+        elif cff < -1:
+            nfast -= 1
+            for i in range(1, nfast + 1):
+                w1[i] = w1[i + 1]
+            w1[nfast + 1] = 0.0
+        elif cff < 0:
+            wsum = LD(1) + cff
+            for i in range(1, nfast):
+                w1[i] = float(wsum * LD(w1[i]) - cff * LD(w1[i + 1]))
+            w1[nfast] = float(wsum * LD(w1[nfast]))
+    for j in range(1, nfast + 1):
+        cff = w1[j]
+        for i in range(1, j + 1):
+            w2[i] = w2[i] + cff
+    wsum = LD(0)
+    cff = LD(0)
+    for i in range(1, nfast + 1):
+        wsum += LD(w1[i])
+        cff += LD(w2[i])
+    wsum = LD(1) / wsum
+    cff = LD(1) / cff
+    for i in range(1, nfast + 1):
+        w1[i] = float(wsum * LD(w1[i]))
+        w2[i] = float(cff * LD(w2[i]))
+    return nfast, w1[1:n2 + 1].copy(), w2[1:n2 + 1].copy()
+
+
+def set_scoord(N, theta_s, theta_b):
+    """ROMS/Utility/set_scoord.F, Vstretching == 4 branch."""
+    sc_w = np.zeros(N + 1)
+    Cs_w = np.zeros(N + 1)
+    sc_r = np.zeros(N + 1)      # index 1..N used
+    Cs_r = np.zeros(N + 1)
+    ds = 1.0 / float(N)
+
+    def C(s):
+        if theta_s > 0.0:
+            Csur = (1.0 - math.cosh(theta_s * s)) / (math.cosh(theta_s) - 1.0)
+        else:
+            Csur = -s ** 2
+        if theta_b > 0.0:
+            return (math.exp(theta_b * Csur) - 1.0) / (1.0 - math.exp(-theta_b))
+        return Csur
+
+    sc_w[N] = 0.0
+    Cs_w[N] = 0.0
+    for k in range(N - 1, 0, -1):
+        s = ds * float(k - N)
+        sc_w[k] = s
+        Cs_w[k] = C(s)
+    sc_w[0] = -1.0
+    Cs_w[0] = -1.0
+    for k in range(1, N + 1):
+        s = ds * (float(k - N) - 0.5)
+        sc_r[k] = s
+        Cs_r[k] = C(s)
+    return sc_r, Cs_r, sc_w, Cs_w
+
+
+def make_params(cfg, NT):
+    p = abi.Params()
+    p.dt = cfg["dt"]
+    p.dtfast = cfg["dt"] / float(cfg["ndtfast"])
+    p.g, p.rho0 = G, RHO0
+    p.gamma2 = cfg["gamma2"]
+    p.lambda_ = 1.0                              # mod_scalars.F:724-729
+    p.ndtfast = cfg["ndtfast"]
+    nfast, w1, w2 = set_weights(cfg["ndtfast"])
+    p.nfast = nfast
+    for i in range(2 * cfg["ndtfast"]):
+        p.weight1[i] = w1[i]
+        p.weight2[i] = w2[i]
+    p.Vtransform = 2
+    p.hc = cfg["Tcline"]                          # Vtransform 2: hc = Tcline
+    sc_r, Cs_r, sc_w, Cs_w = set_scoord(cfg["N"], cfg["theta_s"], cfg["theta_b"])
+    for k in range(cfg["N"] + 1):
+        p.sc_r[k], p.Cs_r[k], p.sc_w[k], p.Cs_w[k] = sc_r[k], Cs_r[k], sc_w[k], Cs_w[k]
+    for it in range(NT):
+        p.Hadv[it] = abi.ADV[cfg.get("Hadv_list", [cfg["Hadv"]] * NT)[it]]
+        p.Vadv[it] = abi.ADV[cfg.get("Vadv_list", [cfg["Vadv"]] * NT)[it]]
+    p.lbc_west = p.lbc_east = abi.LBC_PERIODIC
+    p.lbc_south = p.lbc_north = abi.LBC_CLOSED
+    app = cfg["app"]
+    p.R0, p.T0, p.S0 = 1027.0, {"BENCHMARK": 10.0, "UPWELLING": 14.0, "SEAMOUNT": 10.0}[app], \
+        {"BENCHMARK": 35.0, "UPWELLING": 35.0, "SEAMOUNT": 32.0}[app]
+    p.Tcoef = 1.7e-4
+    p.Scoef = {"BENCHMARK": 7.6e-4, "UPWELLING": 0.0, "SEAMOUNT": 7.6e-4}[app]
+    p.nonlin_eos = int(app == "BENCHMARK")
+    # option switches of the application headers (ROMS/Include/{benchmark,upwelling,seamount}.h)
+    p.uv_adv, p.uv_cor = 1, 1
+    p.uv_vis2 = int(app in ("BENCHMARK", "UPWELLING"))
+    p.curvgrid = int(app == "BENCHMARK")
+    p.var_rho_2d = int(app == "BENCHMARK")
+    p.ts_dif2 = 1
+    p.mix_geo_ts = int(app in ("BENCHMARK", "SEAMOUNT"))
+    p.mix_s_ts = int(app == "UPWELLING")
+    p.salinity = int(app in ("BENCHMARK", "UPWELLING"))
+    p.lmd_nonlocal = int(app == "BENCHMARK")
+    p.solar_source = int(app == "BENCHMARK")
+    p.splines_vdiff = p.splines_vvisc = 1
+    for it in range(NT):
+        p.Akt_bak[it] = {"BENCHMARK": 1.0e-5}.get(app, 1.0e-6)
+    p.Akv_bak = {"BENCHMARK": 1.0e-4}.get(app, 1.0e-5)
+    return p
+
+
+def _grid_global(cfg, b, st):
+    """Fill the 2-D grid arrays over the whole allocated range of tile bounds b
+    (analytic functions are evaluated directly at ghost indices, which equals
+    what the reference obtains after its periodic exchanges)."""
+    Lm, Mm = cfg["Lm"], cfg["Mm"]
+    app = cfg["app"]
+    ii = np.arange(b.LBi, b.UBi + 1, dtype=np.float64)[:, None]
+    jj = np.arange(b.LBj, b.UBj + 1, dtype=np.float64)[None, :]
+    ni, nj = st.ni, st.nj
+    ones = np.ones((ni, nj))
+    if app == "BENCHMARK":
+        Xsize, Esize = 360.0, 20.0
+        dx, dy = Xsize / float(Lm), Esize / float(Mm)
+        latr = (-70.0 + dy * (jj - 0.5)) * ones
+        val1 = float(Lm) / (2.0 * math.pi * ERADIUS)
+        val2 = float(Mm) * 360.0 / (2.0 * math.pi * ERADIUS * Esize)
+        pm = val1 * (1.0 / np.cos(latr * DEG2RAD))
+        pn = val2 * ones
+        fval = 2.0 * (2.0 * math.pi * 366.25 / 365.25) / 86400.0
+        f = fval * np.sin(latr * DEG2RAD)
+        h = 500.0 + 1750.0 * (1.0 + np.tanh((68.0 + latr) / dy))
+        st.lonr = dx * (ii - 0.5) * ones
+        st.latr = latr
+    else:
+        if app == "UPWELLING":
+            Xsize, Esize, depth, f0 = 1000.0 * Lm, 1000.0 * Mm, 150.0, -8.26e-5
+        else:  # SEAMOUNT
+            Xsize, Esize, depth, f0 = 320.0e3, 320.0e3, 5000.0, 1.0e-4
+        dx, dy = Xsize / float(Lm), Esize / float(Mm)
+        xr = dx * (ii - 0.5) * ones
+        yr = dy * (jj - 0.5) * ones
+        pm = ones / dx
+        pn = ones / dy
+        f = f0 * ones
+        if app == "UPWELLING":
+            jv = np.where(jj <= Mm // 2, jj, Mm + 1 - jj)
+            h = np.minimum(depth, 84.5 + 66.526 * np.tanh((jv - 10.0) / 7.0)) * ones
+        else:
+            # periodic images of the seamount do not matter: it sits mid-domain
+            xw = np.mod(xr, Xsize)
+            v1 = (xw - 0.5 * Xsize) / 40000.0
+            v2 = (yr - 0.5 * Esize) / 40000.0
+            h = depth - 4500.0 * np.exp(-(v1 * v1 + v2 * v2))
+        st.lonr, st.latr = xr, yr
+    A = st.arr
+    A["pm"][:] = pm
+    A["pn"][:] = pn
+    A["f"][:] = f
+    A["h"][:] = h
+    # ---- metrics.F ----
+    A["om_r"][:] = 1.0 / pm
+    A["on_r"][:] = 1.0 / pn
+    A["omn"][:] = 1.0 / (pm * pn)
+    A["fomn"][:] = f * A["omn"]
+    A["pnom_r"][:] = pn / pm
+    A["pmon_r"][:] = pm / pn
+    s = slice(1, None)
+    m = slice(0, -1)
+    A["pmon_u"][s, :] = (pm[m, :] + pm[s, :]) / (pn[m, :] + pn[s, :])
+    A["pnom_u"][s, :] = (pn[m, :] + pn[s, :]) / (pm[m, :] + pm[s, :])
+    A["om_u"][s, :] = 2.0 / (pm[m, :] + pm[s, :])
+    A["on_u"][s, :] = 2.0 / (pn[m, :] + pn[s, :])
+    A["pmon_v"][:, s] = (pm[:, m] + pm[:, s]) / (pn[:, m] + pn[:, s])
+    A["pnom_v"][:, s] = (pn[:, m] + pn[:, s]) / (pm[:, m] + pm[:, s])
+    A["om_v"][:, s] = 2.0 / (pm[:, m] + pm[:, s])
+    A["on_v"][:, s] = 2.0 / (pn[:, m] + pn[:, s])
+    pm4 = pm[m, m] + pm[m, s] + pm[s, m] + pm[s, s]
+    pn4 = pn[m, m] + pn[m, s] + pn[s, m] + pn[s, s]
+    A["pnom_p"][s, s] = pn4 / pm4
+    A["pmon_p"][s, s] = pm4 / pn4
+    A["om_p"][s, s] = 4.0 / pm4
+    A["on_p"][s, s] = 4.0 / pn4
+    # ana_grid.h:757-770 (CURVGRID && UV_ADV): interior rows only, wall rows stay 0
+    if app == "BENCHMARK":
+        c = slice(1, -1)
+        dndx = np.zeros((ni, nj))
+        dmde = np.zeros((ni, nj))
+        dndx[c, :] = 0.5 * (1.0 / pn[2:, :] - 1.0 / pn[:-2, :])
+        dmde[:, c] = 0.5 * (1.0 / pm[:, 2:] - 1.0 / pm[:, :-2])
+        jlo, jhi = st.J(max(b.LBj, 1)), st.J(min(b.UBj, Mm))
+        A["dndx"][:, jlo:jhi + 1] = dndx[:, jlo:jhi + 1]
+        A["dmde"][:, jlo:jhi + 1] = dmde[:, jlo:jhi + 1]
+    # horizontal mixing coefficients (ini_hmixcoef.F: uniform, not grid-scaled here)
+    A["visc2_r"][:] = cfg["visc2"]
+    A["visc2_p"][:] = cfg["visc2"]
+    A["diff2"][:] = cfg["tnu2"]
+
+
+def z_levels(st, zeta2d):
+    """set_depth.F:82-300, Vtransform == 2 (numpy restatement used for IC only)."""
+    b, p = st.b, st.p
+    N = b.N
+    h = st["h"]
+    hinv = 1.0 / (p.hc + h)
+    z_w = np.zeros((st.ni, st.nj, N + 1), order="F")
+    z_r = np.zeros((st.ni, st.nj, N), order="F")
+    z_w[:, :, 0] = -h
+    for k in range(1, N + 1):
+        cff_w = p.hc * p.sc_w[k]
+        cff_r = p.hc * p.sc_r[k]
+        cff2_r = (cff_r + p.Cs_r[k] * h) * hinv
+        cff2_w = (cff_w + p.Cs_w[k] * h) * hinv
+        z_w[:, :, k] = zeta2d + (zeta2d + h) * cff2_w
+        z_r[:, :, k - 1] = zeta2d + (zeta2d + h) * cff2_r
+    return z_r, z_w
+
+
+def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
+              perturb=0.0, seed=0):
+    """Build bounds, parameters and an initialised TileState for one tile of a
+    named configuration.  `perturb` adds a smooth 2-D (i- and j-dependent)
+    perturbation to the initial temperature and free surface so that
+    x-direction stencil errors cannot hide behind BENCHMARK's zonal symmetry
+    (hard parts)."""
+    cfg = dict(CONFIGS[config])
+    if overrides:
+        cfg.update(overrides)
+    NAT = cfg["NAT"]
+    NT = NT or NAT
+    adv = {cfg["Hadv"], cfg["Vadv"]} | set(cfg.get("Hadv_list", [])) | set(cfg.get("Vadv_list", []))
+    nghost = 3 if adv & {"MPDATA", "HSIMT"} else 2          # inp_par.F:266-278
+    b = make_bounds(cfg["Lm"], cfg["Mm"], cfg["N"], NT, NAT, ntileI, ntileJ, tile,
+                    EWperiodic=True, NSperiodic=False, NghostPoints=nghost)
+    p = make_params(cfg, NT)
+    st = TileState(b, p)
+    st.cfg = cfg
+    _grid_global(cfg, b, st)
+    app = cfg["app"]
+    A = st.arr
+    Lm, Mm, N = cfg["Lm"], cfg["Mm"], cfg["N"]
+    ii = np.arange(b.LBi, b.UBi + 1, dtype=np.float64)[:, None]
+    jj = np.arange(b.LBj, b.UBj + 1, dtype=np.float64)[None, :]
+    # smooth doubly-varying bump, periodic in i
+    bump = np.sin(2.0 * math.pi * (ii - 0.5) / Lm * 3.0) * np.sin(math.pi * (jj - 0.5) / Mm * 2.0)
+    zeta0 = perturb * 0.05 * bump
+    # closed walls: zero-gradient ghost rows for zeta (zetabc.F closed branches)
+    for k in range(3):
+        A["zeta"][:, :, k] = zeta0
+    A["Zt_avg1"][:] = zeta0
+    z_r, z_w = z_levels(st, zeta0)
+    if app == "BENCHMARK":
+        val1 = (44.69 / 39.382) ** 2
+        val2 = val1 * (RHO0 * 800.0 / G) * (5.0e-05 / ((42.689 / 44.69) ** 2))
+        T = val2 * np.exp(z_r / 800.0) * (0.6 - 0.4 * np.tanh(z_r / 800.0))
+        S = 35.0
+    elif app == "UPWELLING":
+        T = p.T0 + 8.0 * np.exp(z_r / 50.0)
+        S = p.S0
+    else:
+        T = p.T0 + 7.5 * np.exp(z_r / 1000.0)
+        S = None
+    T = T + perturb * 0.5 * bump[:, :, None] * np.exp(z_r / 200.0)
+    for lev in range(3):
+        A["t"][:, :, :, lev, 0] = T
+        if NAT > 1:
+            A["t"][:, :, :, lev, 1] = S
+        for it in range(NAT, NT):       # passive tracers: positive definite blobs
+            pbump = 1.0 + np.exp(-(((ii - 0.5) / Lm - (it - NAT + 1) / (NT - NAT + 1.0)) / 0.08) ** 2
+                                 - (((jj - 0.5) / Mm - 0.5) / 0.25) ** 2)
+            A["t"][:, :, :, lev, it] = pbump[:, :, None] * np.exp(z_r / 500.0) + 0.5
+    # ---- fixed forcing / mixing inputs (stand in for bulk_flux, set_vbc, lmd_vmix) ----
+    if app == "BENCHMARK":
+        lat = st.latr
+        uwind = 15.0 * np.exp(-(0.2 * (60.0 + lat)) ** 2)     # ana_winds.h:118-126
+        tau = 1.2 * 1.3e-3 * uwind * uwind / RHO0             # bulk stress magnitude, m2/s2
+        A["sustr"][:] = tau
+        A["svstr"][:] = 0.0
+        A["srflx"][:] = 150.0 / (RHO0 * 3985.0) * (0.5 + 0.5 * np.cos(2 * math.pi * (ii - 0.5) / Lm))
+        A["stflx"][:, :, 0] = A["srflx"] - 100.0 / (RHO0 * 3985.0)
+        Akv = 1.0e-4 + 1.0e-2 * np.exp(z_w / 60.0)
+        Akt = 1.0e-5 + 5.0e-3 * np.exp(z_w / 60.0)
+        A["Akv"][:] = Akv
+        for it in range(NAT):
+            A["Akt"][:, :, :, it] = Akt * (1.0 if it == 0 else 0.8)
+            gh = 2.0e-2 * np.exp(z_w / 30.0) * (z_w / z_w[:, :, :1]) * (1.0 - z_w / z_w[:, :, :1])
+            A["ghats"][:, :, :, it] = gh * (1.0 if it == 0 else 0.0)
+    elif app == "UPWELLING":
+        # ana_smflux.h (UPWELLING): constant along-shore stress; ana_vmix.h:200,327
+        A["sustr"][:] = 0.1 / RHO0
+        A["srflx"][:] = 0.0
+        A["Akv"][:] = 2.0e-3 + 8.0e-3 * np.exp(z_w / 150.0)
+        for it in range(NAT):
+            A["Akt"][:, :, :, it] = 1.0e-6
+    else:
+        A["Akv"][:] = p.Akv_bak
+        for it in range(NAT):
+            A["Akt"][:, :, :, it] = p.Akt_bak[it]
+    st.z_r0, st.z_w0 = z_r, z_w
+    return st

@@ -1,0 +1,267 @@
+// capi.hip -- life cycle, field registry and host<->device copies behind the
+// C ABI of include/roms_hip.h.
+#include "roms_dev.h"
+#include <map>
+#include <vector>
+
+RomsCtx g_ctx;
+
+static const int k_field_kind[FID_COUNT] = {
+#define ROMS_FIELD(name, kind, owner) kind,
+#include "roms_fields.def"
+#undef ROMS_FIELD
+};
+static const char *k_field_name[FID_COUNT] = {
+#define ROMS_FIELD(name, kind, owner) #name,
+#include "roms_fields.def"
+#undef ROMS_FIELD
+};
+
+int roms_fail(const char *where, const char *what)
+{
+  g_ctx.last_error = std::string(where) + ": " + what;
+  return 8;   // ROMS exit_flag 8 = "Fatal algorithm result" (mod_scalars.F:523-532)
+}
+
+long roms_field_count(int kind, const roms_bounds_t &b)
+{
+  const long nij = (long)(b.UBi - b.LBi + 1) * (long)(b.UBj - b.LBj + 1);
+  switch (kind) {
+  case K_2D:      return nij;
+  case K_2D_T2:   return nij * 2;
+  case K_2D_T3:   return nij * 3;
+  case K_2D_NT:   return nij * b.NT;
+  case K_3DR:     return nij * b.N;
+  case K_3DW:     return nij * (b.N + 1);
+  case K_3DR_T2:  return nij * b.N * 2;
+  case K_3DW_T2:  return nij * (b.N + 1) * 2;
+  case K_3DW_NAT: return nij * (b.N + 1) * b.NAT;
+  case K_4DT:     return nij * b.N * 3 * b.NT;
+  }
+  return -1;
+}
+
+// ---------------------------------------------------------------- timing --
+static std::map<std::string, double> g_last_ms;
+
+ScopedTimer::ScopedTimer(const char *n) : name(n)
+{
+  if (!g_ctx.timing) return;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+  hipEventRecord(e0, g_ctx.stream);
+}
+ScopedTimer::~ScopedTimer()
+{
+  if (!e0) return;
+  hipEventRecord(e1, g_ctx.stream);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  g_last_ms[name] = ms;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+}
+
+extern "C" int roms_hip_timing_enable(int on) { g_ctx.timing = on != 0; return 0; }
+extern "C" double roms_hip_timing_last_ms(const char *entry)
+{
+  auto it = g_last_ms.find(entry);
+  return it == g_last_ms.end() ? -1.0 : it->second;
+}
+
+// ------------------------------------------------------------- life cycle --
+extern "C" int roms_abi_sizeof(int which)
+{
+  switch (which) {
+  case 0: return (int)sizeof(roms_bounds_t);
+  case 1: return (int)sizeof(roms_params_t);
+  case 2: return (int)sizeof(roms_step_idx_t);
+  case 3: return (int)sizeof(roms_fields_t);
+  case 4: return (int)FID_COUNT;
+  }
+  return -1;
+}
+
+extern "C" const char *roms_hip_last_error(void) { return g_ctx.last_error.c_str(); }
+
+int halo_init();      // halo.hip
+int halo_finalize();
+
+extern "C" int roms_hip_init(int rank, int ntileI, int ntileJ, int device_id, const void *nccl_unique_id)
+{
+  if (g_ctx.inited) return roms_fail("roms_hip_init", "already initialised");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return roms_fail("roms_hip_init", "no HIP device: the HIP path has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return roms_fail("roms_hip_init", "bad device id");
+  HIP_TRY(hipSetDevice(device_id));
+  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  g_ctx.rank = rank;
+  g_ctx.ntileI = ntileI;
+  g_ctx.ntileJ = ntileJ;
+  g_ctx.device = device_id;
+  g_ctx.have_nccl_id = false;
+  if (nccl_unique_id) {
+    memcpy(g_ctx.nccl_id, nccl_unique_id, 128);
+    g_ctx.have_nccl_id = true;
+  }
+  HIP_TRY(hipMalloc(&g_ctx.devc, sizeof(RomsDev)));
+  memset(&g_ctx.hostc, 0, sizeof(RomsDev));
+  g_ctx.devc_dirty = true;
+  g_ctx.inited = true;
+  if (ntileI * ntileJ > 1) {
+    if (!g_ctx.have_nccl_id) return roms_fail("roms_hip_init", "multi-tile run needs an RCCL unique id");
+    int rc = halo_init();
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int roms_hip_finalize(void)
+{
+  if (!g_ctx.inited) return 0;
+  hipStreamSynchronize(g_ctx.stream);
+  halo_finalize();
+  for (int i = 0; i < FID_COUNT; i++) {
+    if (g_ctx.dev[i]) hipFree(g_ctx.dev[i]);
+    g_ctx.dev[i] = nullptr;
+    g_ctx.host[i] = nullptr;
+    g_ctx.count[i] = 0;
+  }
+  for (auto &w : g_ctx.hostc.ws3) { if (w) hipFree(w); w = nullptr; }
+  for (auto &w : g_ctx.hostc.ws2) { if (w) hipFree(w); w = nullptr; }
+  if (g_ctx.devc) hipFree(g_ctx.devc);
+  g_ctx.devc = nullptr;
+  if (g_ctx.stream) hipStreamDestroy(g_ctx.stream);
+  g_ctx.stream = nullptr;
+  g_ctx.inited = false;
+  g_ctx.have_bounds = g_ctx.have_params = false;
+  return 0;
+}
+
+extern "C" int roms_hip_set_bounds(const roms_bounds_t *b)
+{
+  if (!g_ctx.inited) return roms_fail("roms_hip_set_bounds", "library not initialised");
+  if (b->N > ROMS_MAXN || b->NT > ROMS_MAXNT) return roms_fail("roms_hip_set_bounds", "N or NT too large");
+  if (b->ntileI != g_ctx.ntileI || b->ntileJ != g_ctx.ntileJ)
+    return roms_fail("roms_hip_set_bounds", "tiling differs from roms_hip_init");
+  g_ctx.b = *b;
+  g_ctx.hostc.b = *b;
+  g_ctx.have_bounds = true;
+  g_ctx.devc_dirty = true;
+  // device scratch for the _tile routines' automatic arrays
+  const long nij = (long)(b->UBi - b->LBi + 1) * (long)(b->UBj - b->LBj + 1);
+  for (auto &w : g_ctx.hostc.ws3) {
+    if (w) hipFree(w);
+    HIP_TRY(hipMalloc(&w, sizeof(double) * nij * (b->N + 1)));
+    HIP_TRY(hipMemsetAsync(w, 0, sizeof(double) * nij * (b->N + 1), g_ctx.stream));
+  }
+  for (auto &w : g_ctx.hostc.ws2) {
+    if (w) hipFree(w);
+    HIP_TRY(hipMalloc(&w, sizeof(double) * nij));
+    HIP_TRY(hipMemsetAsync(w, 0, sizeof(double) * nij, g_ctx.stream));
+  }
+  return 0;
+}
+
+extern "C" int roms_hip_set_params(const roms_params_t *p)
+{
+  if (!g_ctx.inited) return roms_fail("roms_hip_set_params", "library not initialised");
+  if (2 * p->ndtfast > ROMS_MAXFAST) return roms_fail("roms_hip_set_params", "ndtfast too large");
+  g_ctx.p = *p;
+  g_ctx.hostc.p = *p;
+  g_ctx.have_params = true;
+  g_ctx.devc_dirty = true;
+  return 0;
+}
+
+int roms_flush_consts()
+{
+  if (!g_ctx.devc_dirty) return 0;
+  HIP_TRY(hipMemcpyAsync(g_ctx.devc, &g_ctx.hostc, sizeof(RomsDev), hipMemcpyHostToDevice, g_ctx.stream));
+  // the host block may change again before the copy runs: make it synchronous
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  g_ctx.devc_dirty = false;
+  return 0;
+}
+
+extern "C" int roms_hip_register_field(int id, double *host_ptr, long n_doubles)
+{
+  if (!g_ctx.inited || !g_ctx.have_bounds) return roms_fail("roms_hip_register_field", "set_bounds first");
+  if (id < 0 || id >= FID_COUNT) return roms_fail("roms_hip_register_field", "bad field id");
+  const long want = roms_field_count(k_field_kind[id], g_ctx.b);
+  if (want != n_doubles) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "field %s: size %ld does not match bounds (%ld)", k_field_name[id], n_doubles, want);
+    return roms_fail("roms_hip_register_field", msg);
+  }
+  if (g_ctx.dev[id]) hipFree(g_ctx.dev[id]);
+  HIP_TRY(hipMalloc(&g_ctx.dev[id], sizeof(double) * want));
+  HIP_TRY(hipMemsetAsync(g_ctx.dev[id], 0, sizeof(double) * want, g_ctx.stream));
+  g_ctx.host[id] = host_ptr;
+  g_ctx.count[id] = want;
+  double **slot = reinterpret_cast<double **>(&g_ctx.hostc.F) + id;
+  *slot = g_ctx.dev[id];
+  g_ctx.devc_dirty = true;
+  return 0;
+}
+
+extern "C" int roms_hip_sync_to_device(int id)
+{
+  if (id < 0 || id >= FID_COUNT || !g_ctx.dev[id]) return roms_fail("roms_hip_sync_to_device", "field not registered");
+  HIP_TRY(hipMemcpyAsync(g_ctx.dev[id], g_ctx.host[id], sizeof(double) * g_ctx.count[id], hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+extern "C" int roms_hip_sync_to_host(int id)
+{
+  if (id < 0 || id >= FID_COUNT || !g_ctx.dev[id]) return roms_fail("roms_hip_sync_to_host", "field not registered");
+  HIP_TRY(hipMemcpyAsync(g_ctx.host[id], g_ctx.dev[id], sizeof(double) * g_ctx.count[id], hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+extern "C" int roms_hip_sync_all_to_device(void)
+{
+  for (int id = 0; id < FID_COUNT; id++)
+    if (g_ctx.dev[id])
+      HIP_TRY(hipMemcpyAsync(g_ctx.dev[id], g_ctx.host[id], sizeof(double) * g_ctx.count[id], hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+extern "C" int roms_hip_sync_all_to_host(void)
+{
+  for (int id = 0; id < FID_COUNT; id++)
+    if (g_ctx.dev[id])
+      HIP_TRY(hipMemcpyAsync(g_ctx.host[id], g_ctx.dev[id], sizeof(double) * g_ctx.count[id], hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+extern "C" double *roms_hip_device_ptr(int id)
+{
+  if (id < 0 || id >= FID_COUNT) return nullptr;
+  return g_ctx.dev[id];
+}
+
+extern "C" int roms_hip_device_synchronize(void)
+{
+  if (!g_ctx.inited) return roms_fail("roms_hip_device_synchronize", "library not initialised");
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+// Every kernel entry calls this first.
+int roms_entry_check(const char *name)
+{
+  if (!g_ctx.inited) return roms_fail(name, "library not initialised");
+  if (!g_ctx.have_bounds || !g_ctx.have_params) return roms_fail(name, "bounds/params not set");
+  for (int id = 0; id < FID_COUNT; id++)
+    if (!g_ctx.dev[id]) {
+      std::string m = std::string("field not registered: ") + k_field_name[id];
+      return roms_fail(name, m.c_str());
+    }
+  return roms_flush_consts();
+}

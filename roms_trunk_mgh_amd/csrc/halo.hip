@@ -1,0 +1,268 @@
+// halo.hip -- ghost-point updates: the reference's exchange_*_tile periodic
+// copies (ROMS/Nonlinear/exchange_2d.F:43-788, exchange_3d.F:43-1108) and
+// mp_exchange2d/3d/4d (ROMS/Utility/mp_exchange.F:290/1413/2753) re-done for
+// one-tile-per-GPU: device pack kernel -> grouped RCCL ncclSend/ncclRecv over
+// xGMI -> device unpack kernel, all on the library stream (no host copy, no
+// host synchronisation).
+//
+// Semantics kept from the reference (mp_exchange.F:73-286, tile_neighbors):
+//   * two dependent phases, W/E first then S/N over the FULL i-range including
+//     the just-received ghost columns, so corners ride along in phase 2;
+//   * rank = Jtile*NtileI + Itile; periodic directions wrap to the far tile;
+//   * with 2 ghost points and periodicity the west-most tile receives
+//     Nghost+1 columns from the east-most tile (which sends Nghost+1).
+// RCCL is resolved at run time (dlsym in the already-loaded process image, then
+// dlopen of librccl.so) so that a Fortran host and a Python host share one build.
+#include "roms_dev.h"
+#include <dlfcn.h>
+
+// ------------------------------------------------------------ RCCL binding --
+typedef struct { char internal[128]; } rccl_uid_t;
+typedef void *rccl_comm_t;
+typedef int (*fn_getuid)(rccl_uid_t *);
+typedef int (*fn_initrank)(rccl_comm_t *, int, rccl_uid_t, int);
+typedef int (*fn_destroy)(rccl_comm_t);
+typedef int (*fn_send)(const void *, size_t, int, int, rccl_comm_t, hipStream_t);
+typedef int (*fn_recv)(void *, size_t, int, int, rccl_comm_t, hipStream_t);
+typedef int (*fn_group)(void);
+typedef const char *(*fn_errstr)(int);
+static struct {
+  bool loaded = false;
+  fn_getuid getuid = nullptr;
+  fn_initrank initrank = nullptr;
+  fn_destroy destroy = nullptr;
+  fn_send send = nullptr;
+  fn_recv recv = nullptr;
+  fn_group gstart = nullptr, gend = nullptr;
+  fn_errstr errstr = nullptr;
+} rccl;
+static const int RCCL_FLOAT64 = 8;   // ncclFloat64 / ncclDouble
+
+static int rccl_load()
+{
+  if (rccl.loaded) return 0;
+  void *h = RTLD_DEFAULT;
+  if (!dlsym(h, "ncclCommInitRank")) {
+    const char *cands[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    h = nullptr;
+    for (const char *c : cands) { h = dlopen(c, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return roms_fail("rccl_load", "librccl.so not found");
+  }
+  rccl.getuid = (fn_getuid)dlsym(h, "ncclGetUniqueId");
+  rccl.initrank = (fn_initrank)dlsym(h, "ncclCommInitRank");
+  rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
+  rccl.send = (fn_send)dlsym(h, "ncclSend");
+  rccl.recv = (fn_recv)dlsym(h, "ncclRecv");
+  rccl.gstart = (fn_group)dlsym(h, "ncclGroupStart");
+  rccl.gend = (fn_group)dlsym(h, "ncclGroupEnd");
+  rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+  if (!rccl.getuid || !rccl.initrank || !rccl.send || !rccl.recv || !rccl.gstart || !rccl.gend)
+    return roms_fail("rccl_load", "RCCL symbols missing");
+  rccl.loaded = true;
+  return 0;
+}
+
+static int rccl_fail(const char *where, int code)
+{
+  g_ctx.last_error = std::string(where) + ": " + (rccl.errstr ? rccl.errstr(code) : "RCCL error");
+  return 2;   // ROMS exit_flag 2, as mp_exchange.F:551
+}
+#define RCCL_TRY(expr) do { int r_ = (expr); if (r_ != 0) return rccl_fail(#expr, r_); } while (0)
+
+extern "C" int roms_hip_get_unique_id(void *out128)
+{
+  int rc = rccl_load();
+  if (rc) return rc;
+  rccl_uid_t id;
+  RCCL_TRY(rccl.getuid(&id));
+  memcpy(out128, &id, 128);
+  return 0;
+}
+
+// ---------------------------------------------------------- neighbour table --
+struct Neigh {
+  int Wtile, Etile, Stile, Ntile;              // -1 = none
+  int GsendW, GsendE, GrecvW, GrecvE;
+  int GsendS, GsendN, GrecvS, GrecvN;
+};
+
+// mp_exchange.F:73-286 (tile_neighbors).  Pure host function, exported so the
+// CPU tests can check it against the Python mirror without a GPU.
+extern "C" int roms_hip_tile_neighbors(int rank, int ntileI, int ntileJ, int Nghost, int NghostPoints,
+                                       int EWperiodic, int NSperiodic, int *out12)
+{
+  const int I = rank % ntileI, J = rank / ntileI;
+  auto table = [&](int i, int j) { return (i < 0 || i >= ntileI || j < 0 || j >= ntileJ) ? -1 : j * ntileI + i; };
+  Neigh n;
+  n.GsendW = n.GsendE = n.GrecvW = n.GrecvE = Nghost;
+  n.GsendS = n.GsendN = n.GrecvS = n.GrecvN = Nghost;
+  n.Wtile = table(I - 1, J);
+  n.Etile = table(I + 1, J);
+  if (EWperiodic && ntileI > 1) {
+    if (table(I - 1, J) < 0) { n.Wtile = table(ntileI - 1, J); if (NghostPoints != 3) n.GrecvW = Nghost + 1; }
+    else if (table(I + 1, J) < 0) { n.Etile = table(0, J); if (NghostPoints != 3) n.GsendE = Nghost + 1; }
+  }
+  n.Stile = table(I, J - 1);
+  n.Ntile = table(I, J + 1);
+  if (NSperiodic && ntileJ > 1) {
+    if (table(I, J - 1) < 0) { n.Stile = table(I, ntileJ - 1); if (NghostPoints != 3) n.GrecvS = Nghost + 1; }
+    else if (table(I, J + 1) < 0) { n.Ntile = table(I, 0); if (NghostPoints != 3) n.GsendN = Nghost + 1; }
+  }
+  const int v[12] = {n.Wtile, n.Etile, n.Stile, n.Ntile, n.GsendW, n.GsendE, n.GrecvW, n.GrecvE,
+                     n.GsendS, n.GsendN, n.GrecvS, n.GrecvN};
+  memcpy(out12, v, sizeof v);
+  return 0;
+}
+
+static Neigh g_neigh;
+static double *g_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLo, sendHi, recvLo, recvHi
+static size_t g_buf_doubles = 0;
+
+int halo_init()
+{
+  int rc = rccl_load();
+  if (rc) return rc;
+  rccl_uid_t id;
+  memcpy(&id, g_ctx.nccl_id, 128);
+  rccl_comm_t comm = nullptr;
+  RCCL_TRY(rccl.initrank(&comm, g_ctx.ntileI * g_ctx.ntileJ, id, g_ctx.rank));
+  g_ctx.nccl_comm = comm;
+  return 0;
+}
+
+int halo_finalize()
+{
+  for (auto &p : g_buf) { if (p) hipFree(p); p = nullptr; }
+  g_buf_doubles = 0;
+  if (g_ctx.nccl_comm && rccl.destroy) rccl.destroy((rccl_comm_t)g_ctx.nccl_comm);
+  g_ctx.nccl_comm = nullptr;
+  return 0;
+}
+
+// ------------------------------------------------ single-tile periodic copy --
+// exchange_2d.F:229-414 / exchange_3d.F:259-470: A(Lm+1:Lm+Ng)=A(1:Ng),
+// A(-2:0)=A(Lm-2:Lm); v- and psi-type start at j=Jstr, rho/u-type at JstrR.
+__global__ void k_periodic_ew(const RomsDev *__restrict__ c, double *__restrict__ A, int nk, int jmin, int jmax)
+{
+  DEV_PROLOGUE(c)
+  const int j = jmin + blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (j > jmax || k >= nk) return;
+  const int Lm = b.Lm;
+  double *P = A + (long)k * nij;
+  for (int m = 1; m <= b.NghostPoints; m++) P[I2(Lm + m, j)] = P[I2(m, j)];
+  for (int m = 0; m <= 2; m++) P[I2(-m, j)] = P[I2(Lm - m, j)];
+}
+
+// --------------------------------------------------- multi-tile pack/unpack --
+// dir 0: columns i0..i0+G-1 over the full j-range; dir 1: rows j0..j0+G-1 over
+// the full i-range.  Buffer order (k, m, running index) -- ours, not MPI's.
+__global__ void k_pack(const RomsDev *__restrict__ c, const double *__restrict__ A, double *__restrict__ buf,
+                       int nk, int dir, int start, int G, int unpack)
+{
+  DEV_PROLOGUE(c)
+  const int len = dir == 0 ? (int)nj : (int)ni;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y % G, k = blockIdx.y / G;
+  if (r >= len || k >= nk) return;
+  const long a = dir == 0 ? I2(start + m, LBj + r) : I2(LBi + r, start + m);
+  const long q = ((long)k * G + m) * len + r;
+  if (unpack) const_cast<double *>(A)[a + (long)k * nij] = buf[q];
+  else buf[q] = A[a + (long)k * nij];
+}
+
+static int ensure_buffers(size_t doubles)
+{
+  if (doubles <= g_buf_doubles) return 0;
+  for (auto &p : g_buf) {
+    if (p) hipFree(p);
+    HIP_TRY(hipMalloc(&p, sizeof(double) * doubles));
+  }
+  g_buf_doubles = doubles;
+  return 0;
+}
+
+static int exchange_phase(double *A, int nk, int dir)
+{
+  const roms_bounds_t &b = g_ctx.b;
+  const Neigh &n = g_neigh;
+  const int lo = dir == 0 ? n.Wtile : n.Stile, hi = dir == 0 ? n.Etile : n.Ntile;
+  if (lo < 0 && hi < 0) return 0;
+  const int GsLo = dir == 0 ? n.GsendW : n.GsendS, GsHi = dir == 0 ? n.GsendE : n.GsendN;
+  const int GrLo = dir == 0 ? n.GrecvW : n.GrecvS, GrHi = dir == 0 ? n.GrecvE : n.GrecvN;
+  const int len = dir == 0 ? (b.UBj - b.LBj + 1) : (b.UBi - b.LBi + 1);
+  const int str = dir == 0 ? b.Istr : b.Jstr, end = dir == 0 ? b.Iend : b.Jend;
+  const int Gmax = b.NghostPoints + 1;
+  int rc = ensure_buffers((size_t)nk * Gmax * len);
+  if (rc) return rc;
+  const dim3 blk(256);
+  auto launch = [&](double *buf, int start, int G, int unpack) {
+    dim3 grid((len + 255) / 256, (unsigned)(nk * G));
+    hipLaunchKernelGGL(k_pack, grid, blk, 0, g_ctx.stream, g_ctx.devc, A, buf, nk, dir, start, G, unpack);
+  };
+  if (lo >= 0) launch(g_buf[0], str, GsLo, 0);                 // my first GsLo interior lines
+  if (hi >= 0) launch(g_buf[1], end - GsHi + 1, GsHi, 0);      // my last GsHi interior lines
+  KERNEL_CHECK("k_pack");
+  rccl_comm_t comm = (rccl_comm_t)g_ctx.nccl_comm;
+  RCCL_TRY(rccl.gstart());
+  // order matters when lo == hi (two tiles in a periodic direction): my low-side
+  // send pairs with the peer's high-side receive.
+  if (lo >= 0) RCCL_TRY(rccl.send(g_buf[0], (size_t)nk * GsLo * len, RCCL_FLOAT64, lo, comm, g_ctx.stream));
+  if (hi >= 0) RCCL_TRY(rccl.send(g_buf[1], (size_t)nk * GsHi * len, RCCL_FLOAT64, hi, comm, g_ctx.stream));
+  if (hi >= 0) RCCL_TRY(rccl.recv(g_buf[3], (size_t)nk * GrHi * len, RCCL_FLOAT64, hi, comm, g_ctx.stream));
+  if (lo >= 0) RCCL_TRY(rccl.recv(g_buf[2], (size_t)nk * GrLo * len, RCCL_FLOAT64, lo, comm, g_ctx.stream));
+  RCCL_TRY(rccl.gend());
+  if (lo >= 0) launch(g_buf[2], str - GrLo, GrLo, 1);
+  if (hi >= 0) launch(g_buf[3], end + 1, GrHi, 1);
+  KERNEL_CHECK("k_unpack");
+  return 0;
+}
+
+int halo_exchange3d(int gtype, int nk, double *A)
+{
+  const roms_bounds_t &b = g_ctx.b;
+  if (b.ntileI * b.ntileJ == 1) {
+    if (!b.EWperiodic) return 0;
+    int jmin, jmax;
+    if (b.NSperiodic) { jmin = b.Jstr; jmax = b.Jend; }
+    else { jmin = (gtype == GT_R || gtype == GT_U) ? b.JstrR : b.Jstr; jmax = b.JendR; }
+    dim3 grid((jmax - jmin + 1 + 63) / 64, nk);
+    hipLaunchKernelGGL(k_periodic_ew, grid, dim3(64), 0, g_ctx.stream, g_ctx.devc, A, nk, jmin, jmax);
+    KERNEL_CHECK("k_periodic_ew");
+    return 0;
+  }
+  static bool have_neigh = false;
+  if (!have_neigh) {
+    int v[12];
+    roms_hip_tile_neighbors(g_ctx.rank, b.ntileI, b.ntileJ, b.NghostPoints, b.NghostPoints,
+                            b.EWperiodic, b.NSperiodic, v);
+    g_neigh = Neigh{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]};
+    have_neigh = true;
+  }
+  // a periodic direction held by ONE tile row/column is a local copy
+  if (b.EWperiodic && b.ntileI == 1) {
+    dim3 grid((b.UBj - b.LBj + 1 + 63) / 64, nk);
+    hipLaunchKernelGGL(k_periodic_ew, grid, dim3(64), 0, g_ctx.stream, g_ctx.devc, A, nk, b.LBj, b.UBj);
+    KERNEL_CHECK("k_periodic_ew");
+  }
+  int rc = exchange_phase(A, nk, 0);
+  if (rc) return rc;
+  return exchange_phase(A, nk, 1);
+}
+
+int halo_exchange2d(int gtype, double *A, int) { return halo_exchange3d(gtype, 1, A); }
+
+// Exported for tests: exchange one registered field (all planes, or one
+// trailing level when level > 0 and the field has time levels / tracers).
+extern "C" int roms_hip_exchange(int field_id, int level)
+{
+  if (!g_ctx.inited || field_id < 0 || field_id >= FID_COUNT || !g_ctx.dev[field_id])
+    return roms_fail("roms_hip_exchange", "field not registered");
+  int rc = roms_flush_consts();
+  if (rc) return rc;
+  const roms_bounds_t &b = g_ctx.b;
+  const long nij = (long)(b.UBi - b.LBi + 1) * (long)(b.UBj - b.LBj + 1);
+  const int nk = (int)(g_ctx.count[field_id] / nij);
+  (void)level;
+  return halo_exchange3d(GT_R, nk, g_ctx.dev[field_id]);
+}

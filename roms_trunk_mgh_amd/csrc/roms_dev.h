@@ -1,0 +1,114 @@
+// roms_dev.h -- internal header of libroms_hip.so (gfx950 / CDNA4 only).
+//
+// One process drives one GPU and one ROMS tile.  All module arrays of the tile
+// live in HBM for the whole run (device mirrors of mod_ocean/mod_grid/
+// mod_coupling/mod_mixing/mod_forces, same column-major i-fastest layout and
+// the same LBi:UBi,LBj:UBj extents as the host arrays), so host and device
+// index arithmetic is shared.  Kernels receive a pointer to one device-resident
+// constant block (bounds + parameters + field pointers); wave-uniform reads of
+// it compile to scalar loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "roms_hip.h"
+
+struct RomsDev {
+  roms_bounds_t b;
+  roms_params_t p;
+  roms_fields_t F;      // device pointers
+  // device scratch = the _tile routines' automatic work arrays
+  double *ws3[8];       // 3-D scratch, each nij*(N+1) doubles
+  double *ws2[32];      // 2-D scratch, each nij doubles
+};
+
+struct RomsCtx {
+  bool inited = false;
+  int rank = 0, ntileI = 1, ntileJ = 1, device = 0;
+  hipStream_t stream = nullptr;
+  roms_bounds_t b{};
+  roms_params_t p{};
+  bool have_bounds = false, have_params = false;
+  double *host[FID_COUNT] = {nullptr};
+  double *dev[FID_COUNT] = {nullptr};
+  long count[FID_COUNT] = {0};
+  RomsDev hostc{};            // host copy of the constant block
+  RomsDev *devc = nullptr;    // device copy
+  bool devc_dirty = true;
+  bool timing = false;
+  std::string last_error;
+  // halo exchange (RCCL) state lives in halo.hip
+  void *nccl_comm = nullptr;
+  unsigned char nccl_id[128];
+  bool have_nccl_id = false;
+};
+
+extern RomsCtx g_ctx;
+
+int  roms_fail(const char *where, const char *what);
+int  roms_flush_consts();                 // upload hostc -> devc when dirty
+long roms_field_count(int kind, const roms_bounds_t &b);
+
+#define HIP_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) return roms_fail(#expr, hipGetErrorString(e_));     \
+  } while (0)
+
+#define KERNEL_CHECK(name)                                                    \
+  do {                                                                        \
+    hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess) return roms_fail(name, hipGetErrorString(e_));      \
+  } while (0)
+
+// ------------------------------------------------------------------------
+// timing (hipEvents on the library stream) for bench.py's roofline object
+// ------------------------------------------------------------------------
+struct ScopedTimer {
+  const char *name;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  explicit ScopedTimer(const char *n);
+  ~ScopedTimer();
+};
+
+// ------------------------------------------------------------------------
+// device-side index helpers
+// ------------------------------------------------------------------------
+#define DEV_PROLOGUE(c)                                                        \
+  const roms_bounds_t &b = (c)->b;                                             \
+  const int LBi = b.LBi, LBj = b.LBj;                                          \
+  const int N = b.N;                                                           \
+  const long ni = b.UBi - b.LBi + 1, nj = b.UBj - b.LBj + 1, nij = ni * nj;    \
+  const long n3r = nij * N, n3w = nij * (N + 1);                               \
+  (void)nj; (void)n3r; (void)n3w;
+
+#define I2(i,j)    ((long)((i) - LBi) + (long)((j) - LBj) * ni)
+#define I3(i,j,k)  (I2(i,j) + (long)((k) - 1) * nij)
+#define I3W(i,j,k) (I2(i,j) + (long)(k) * nij)
+
+// grid-point type codes for the periodic exchange (exchange_2d.F / _3d.F)
+enum { GT_R = 0, GT_U, GT_V, GT_P };
+
+// thread (tx,ty) -> horizontal index; blocks are 64 x 4 so that one wavefront
+// covers 64 consecutive i (one 512-byte line per k-level access).
+#define BLK_X 64
+#define BLK_Y 4
+static inline dim3 grid2d(int nx, int ny) {
+  return dim3((unsigned)((nx + BLK_X - 1) / BLK_X), (unsigned)((ny + BLK_Y - 1) / BLK_Y), 1);
+}
+static inline dim3 block2d() { return dim3(BLK_X, BLK_Y, 1); }
+
+// ------------------------------------------------------------------------
+// internal launchers shared between translation units
+// ------------------------------------------------------------------------
+int halo_exchange2d(int gtype, double *A, int nfields_stride_unused = 0);
+int halo_exchange3d(int gtype, int nk, double *A);
+int bc_zeta(int kout);
+int bc_u2d(int kout);
+int bc_v2d(int kout);
+int bc_u3d(int nout);
+int bc_v3d(int nout);
+int bc_t3d(int nout, int itrc);
+int bc_w3d(double *A);
+int check_lbc();

@@ -1,0 +1,144 @@
+"""ctypes binding of libroms_hip.so -- the Python stand-in for the Fortran
+ISO_C_BINDING shims (fortran/roms_hip_mod.F90).  Method names mirror the
+reference's module procedures (`step3d_t(ng,tile)` -> `call("step3d_t", s)`).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is
+present, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libroms_hip.so")
+_LIB = None
+
+ENTRIES = ["set_massflux", "rho_eos", "omega", "set_zeta", "set_depth", "rhs3d",
+           "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile", "uv3dmix2", "step2d",
+           "step3d_uv", "step3d_t"]
+
+# every symbol include/roms_hip.h declares
+DECLARED_SYMBOLS = (
+    ["roms_hip_init", "roms_hip_finalize", "roms_hip_get_unique_id", "roms_hip_set_bounds",
+     "roms_hip_set_params", "roms_hip_register_field", "roms_hip_sync_to_device",
+     "roms_hip_sync_to_host", "roms_hip_sync_all_to_device", "roms_hip_sync_all_to_host",
+     "roms_hip_device_ptr", "roms_hip_device_synchronize", "roms_hip_last_error",
+     "roms_hip_step2d_loop", "roms_hip_exchange", "roms_hip_timing_enable",
+     "roms_hip_timing_last_ms"] + ["roms_hip_" + e for e in ENTRIES])
+
+
+def load():
+    """dlopen libroms_hip.so (does not touch the GPU)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m roms_trunk_mgh_amd._build` "
+            "(there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    abi.check_abi(lib)
+    lib.roms_hip_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.roms_hip_set_bounds.argtypes = [C.POINTER(abi.Bounds)]
+    lib.roms_hip_set_params.argtypes = [C.POINTER(abi.Params)]
+    lib.roms_hip_register_field.argtypes = [C.c_int, C.c_void_p, C.c_long]
+    lib.roms_hip_last_error.restype = C.c_char_p
+    lib.roms_hip_device_ptr.restype = C.c_void_p
+    lib.roms_hip_device_ptr.argtypes = [C.c_int]
+    lib.roms_hip_timing_last_ms.restype = C.c_double
+    lib.roms_hip_timing_last_ms.argtypes = [C.c_char_p]
+    lib.roms_hip_get_unique_id.argtypes = [C.c_void_p]
+    for e in ENTRIES:
+        fn = getattr(lib, "roms_hip_" + e, None)
+        if fn is not None:
+            fn.restype = C.c_int
+            fn.argtypes = [C.POINTER(abi.StepIdx)]
+    if hasattr(lib, "roms_hip_step2d_loop"):
+        lib.roms_hip_step2d_loop.argtypes = [C.POINTER(abi.StepIdx), C.POINTER(C.c_int)]
+    if hasattr(lib, "roms_hip_tile_neighbors"):
+        lib.roms_hip_tile_neighbors.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)]
+    _LIB = lib
+    return lib
+
+
+def tile_neighbors(rank, ntileI, ntileJ, Nghost, NghostPoints, EWperiodic, NSperiodic):
+    """Host-only helper of the library (mp_exchange.F:73-286); needs no GPU."""
+    out = (C.c_int * 12)()
+    load().roms_hip_tile_neighbors(rank, ntileI, ntileJ, Nghost, NghostPoints,
+                                   int(EWperiodic), int(NSperiodic), out)
+    keys = ["Wtile", "Etile", "Stile", "Ntile", "GsendW", "GsendE", "GrecvW", "GrecvE",
+            "GsendS", "GsendN", "GrecvS", "GrecvN"]
+    return dict(zip(keys, list(out)))
+
+
+class RomsHip:
+    """One tile on one GPU.  Owns nothing on the host: the TileState arrays stay
+    the caller's (as the Fortran module arrays do)."""
+
+    name = "hip"
+
+    def __init__(self, state, rank=0, device=0, nccl_unique_id=None):
+        self.st = state
+        self.l = load()
+        b = state.b
+        uid = None
+        if nccl_unique_id is not None:
+            self._uid = C.create_string_buffer(bytes(nccl_unique_id), 128)
+            uid = C.cast(self._uid, C.c_void_p)
+        self._chk(self.l.roms_hip_init(rank, b.ntileI, b.ntileJ, device, uid), "init")
+        self._chk(self.l.roms_hip_set_bounds(C.byref(b)), "set_bounds")
+        self._chk(self.l.roms_hip_set_params(C.byref(state.p)), "set_params")
+        for name, _, _ in abi.FIELDS:
+            a = state.arr[name]
+            self._chk(self.l.roms_hip_register_field(abi.FIELD_ID[name], a.ctypes.data, a.size),
+                      "register_field " + name)
+        self._chk(self.l.roms_hip_sync_all_to_device(), "sync_all_to_device")
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.l.roms_hip_last_error()
+            raise RuntimeError(f"roms_hip {what} failed rc={rc}: {msg.decode() if msg else ''}")
+
+    def call(self, kernel, s):
+        self._chk(getattr(self.l, "roms_hip_" + kernel)(C.byref(s)), kernel)
+
+    def step2d_loop(self, s, indx1):
+        ii = C.c_int(indx1)
+        self._chk(self.l.roms_hip_step2d_loop(C.byref(s), C.byref(ii)), "step2d_loop")
+        return ii.value
+
+    def to_device(self, names=None):
+        if names is None:
+            self._chk(self.l.roms_hip_sync_all_to_device(), "sync_all_to_device")
+        else:
+            for n in names:
+                self._chk(self.l.roms_hip_sync_to_device(abi.FIELD_ID[n]), "sync_to_device")
+
+    def to_host(self, names=None):
+        if names is None:
+            self._chk(self.l.roms_hip_sync_all_to_host(), "sync_all_to_host")
+        else:
+            for n in names:
+                self._chk(self.l.roms_hip_sync_to_host(abi.FIELD_ID[n]), "sync_to_host")
+        return self.st
+
+    def sync(self):
+        self._chk(self.l.roms_hip_device_synchronize(), "device_synchronize")
+
+    def timing(self, on=True):
+        self.l.roms_hip_timing_enable(int(on))
+
+    def last_ms(self, entry):
+        return self.l.roms_hip_timing_last_ms(entry.encode())
+
+    def close(self):
+        self.l.roms_hip_finalize()
+
+    def __del__(self):
+        try:
+            self.l.roms_hip_finalize()
+        except Exception:
+            pass

@@ -1,0 +1,43 @@
+"""Developer tool: time single hot-path entries on a named configuration with
+the library's hipEvent timers.  Usage: python tools_bench_kernel.py BENCHMARK3 step3d_t [reps]"""
+import sys
+import time
+
+sys.path.insert(0, "tests")
+import util  # noqa: E402
+from roms_trunk_mgh_amd import hip  # noqa: E402
+
+
+def main():
+    config = sys.argv[1] if len(sys.argv) > 1 else "BENCHMARK3"
+    kernels = sys.argv[2].split(",") if len(sys.argv) > 2 else ["step3d_t"]
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    t0 = time.time()
+    st = util.prepared_state(config)
+    util.hz_weighted_tnew(st)
+    print(f"state built in {time.time()-t0:.1f}s", flush=True)
+    h = hip.RomsHip(st)
+    s = util.step_idx()
+    b = st.b
+    cells = b.Lm * b.Mm * b.N
+    for k in kernels:
+        h.timing(False)
+        for _ in range(3):
+            h.call(k, s)
+        h.sync()
+        h.timing(True)
+        ms = []
+        for _ in range(reps):
+            h.call(k, s)
+            ms.append(h.last_ms(k))
+        ms.sort()
+        med = ms[len(ms) // 2]
+        print(f"{k}: median {med:.4f} ms  min {ms[0]:.4f}  cells={cells}", flush=True)
+        if k == "step3d_t":
+            byts = 8.0 * (4 * b.NT + 4) * cells
+            print(f"   algorithmic {byts/1e9:.3f} GB -> {byts/med/1e6:.1f} GB/s = {byts/med/1e6/8000:.3f} of 8 TB/s")
+    h.close()
+
+
+if __name__ == "__main__":
+    main()
