@@ -192,7 +192,7 @@ def make_params(cfg, NT):
     p.uv_adv, p.uv_cor = 1, 1
     p.uv_vis2 = int(app in ("BENCHMARK", "UPWELLING"))
     p.curvgrid = int(app == "BENCHMARK")
-    p.var_rho_2d = int(app == "BENCHMARK")
+    p.var_rho_2d = 1                      # globaldefs.h:491-495, always with SOLVE3D
     p.ts_dif2 = 1
     p.mix_geo_ts = int(app in ("BENCHMARK", "SEAMOUNT"))
     p.mix_s_ts = int(app == "UPWELLING")

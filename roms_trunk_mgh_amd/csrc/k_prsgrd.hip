@@ -1,0 +1,154 @@
+// k_prsgrd.hip -- baroclinic pressure gradient, prsgrd32_tile
+// (ROMS/Nonlinear/prsgrd32.h:106-423; DJ_GRADPS: density Jacobian with
+// harmonic-mean limited cubic reconstruction, Shchepetkin & McWilliams 2003).
+// First writer of ru,rv(:,:,1:N,nrhs).
+//
+// Two kernels:
+//   k_prsgrd_P   one thread per water column, top-down recursion for the
+//                dynamic pressure P with 3-level sliding windows in registers
+//                (reads rho, z_r, z_w(N); writes P to device scratch);
+//   k_prsgrd_uv  one thread per (i,j,k): horizontal harmonic-mean slopes and
+//                the XI/ETA pressure-gradient terms (reads P, rho, z_r, Hz with
+//                a 2-point i/j halo served by L1/L2; writes ru, rv).
+// Algorithmic traffic: rho, z_r, Hz read, P written+read, ru, rv written
+// = 7 field passes (56 B per cell).
+#include "roms_dev.h"
+
+int roms_entry_check(const char *name);
+
+namespace {
+
+__device__ __forceinline__ double harm(double a, double bq, double eps)
+{
+  // cff=2*a*b; cff>eps ? cff/(a+b) : 0  (prsgrd32.h:243-249)
+  const double cff = 2.0 * a * bq;
+  return (cff > eps) ? cff / (a + bq) : 0.0;
+}
+__device__ __forceinline__ double harm_inv(double a, double bq, double eps)
+{
+  // the horizontal form multiplies by a reciprocal (prsgrd32.h:306-320)
+  const double cff = 2.0 * a * bq;
+  if (cff > eps) { const double cff1 = 1.0 / (a + bq); return cff * cff1; }
+  return 0.0;
+}
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_prsgrd_P(const RomsDev *__restrict__ c, double *__restrict__ P)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.IstrU - 1 + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.JstrV - 1 + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.Jend) return;
+  const double *__restrict__ rho = c->F.rho;
+  const double *__restrict__ z_r = c->F.z_r;
+  const double eps = 1.0E-10, OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
+  const double g = c->p.g, GRho = g / c->p.rho0, HalfGRho = 0.5 * GRho;
+  const long c0 = I2(i, j);
+  // raw differences: dRr(k)=rho(k+1)-rho(k), k=1..N-1; dRr(N)=dRr(N-1); dRr(0)=dRr(1)
+  double rho_k1 = rho[c0 + (long)(N - 1) * nij];      // rho(N)
+  double zr_k1 = z_r[c0 + (long)(N - 1) * nij];
+  double rho_k = rho[c0 + (long)(N - 2) * nij];       // rho(N-1)
+  double zr_k = z_r[c0 + (long)(N - 2) * nij];
+  const double zwN = c->F.z_w[c0 + (long)N * nij];
+  // surface level
+  {
+    const double cff1 = 1.0 / (zr_k1 - zr_k);
+    const double cff2 = 0.5 * (rho_k1 - rho_k) * (zwN - zr_k1) * cff1;
+    P[c0 + (long)(N - 1) * nij] = g * zwN + GRho * (rho_k1 + cff2) * (zwN - zr_k1);
+  }
+  double Pk1 = P[c0 + (long)(N - 1) * nij];
+  // limited slopes at level N: harm(raw(N), raw(N-1)) with raw(N)=raw(N-1)
+  double rawR_k = rho_k1 - rho_k, rawZ_k = zr_k1 - zr_k;       // raw(N-1)
+  double dR_k1 = harm(rawR_k, rawR_k, eps);                     // dR(N)
+  double dZ_k1 = 2.0 * rawZ_k * rawZ_k / (rawZ_k + rawZ_k);     // dZ(N)
+  for (int k = N - 1; k >= 1; k--) {
+    // raw(k-1): k-1 >= 1 -> rho(k)-rho(k-1); k-1 == 0 -> raw(1)
+    double rawR_km1, rawZ_km1, rho_km1 = 0.0, zr_km1 = 0.0;
+    if (k >= 2) {
+      rho_km1 = rho[c0 + (long)(k - 2) * nij];
+      zr_km1 = z_r[c0 + (long)(k - 2) * nij];
+      rawR_km1 = rho_k - rho_km1;
+      rawZ_km1 = zr_k - zr_km1;
+    } else { rawR_km1 = rawR_k; rawZ_km1 = rawZ_k; }
+    const double dR_k = harm(rawR_k, rawR_km1, eps);
+    const double dZ_k = 2.0 * rawZ_k * rawZ_km1 / (rawZ_k + rawZ_km1);
+    const double Pk = Pk1 +
+        HalfGRho * ((rho_k1 + rho_k) * (zr_k1 - zr_k) -
+                    OneFifth *
+                    ((dR_k1 - dR_k) * (zr_k1 - zr_k - OneTwelfth * (dZ_k1 + dZ_k)) -
+                     (dZ_k1 - dZ_k) * (rho_k1 - rho_k - OneTwelfth * (dR_k1 + dR_k))));
+    P[c0 + (long)(k - 1) * nij] = Pk;
+    Pk1 = Pk;
+    rho_k1 = rho_k; zr_k1 = zr_k; rho_k = rho_km1; zr_k = zr_km1;
+    rawR_k = rawR_km1; rawZ_k = rawZ_km1;
+    dR_k1 = dR_k; dZ_k1 = dZ_k;
+  }
+}
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrhs)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  const int k = blockIdx.z + 1;
+  if (i > b.Iend || j > b.Jend) return;
+  const double *__restrict__ rho = c->F.rho;
+  const double *__restrict__ z_r = c->F.z_r;
+  const double *__restrict__ Hz = c->F.Hz;
+  const double eps = 1.0E-10, OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
+  const double HalfGRho = 0.5 * (c->p.g / c->p.rho0);
+  const long ck = I3(i, j, k);
+  const double r0 = rho[ck], z0 = z_r[ck], hz0 = Hz[ck], P0 = P[ck];
+  if (i >= b.IstrU) {
+    const double rm2 = rho[ck - 2], rm1 = rho[ck - 1], rp1 = rho[ck + 1];
+    const double zm2 = z_r[ck - 2], zm1 = z_r[ck - 1], zp1 = z_r[ck + 1];
+    const double aux_m1 = zm1 - zm2, aux_0 = z0 - zm1, aux_p1 = zp1 - z0;
+    const double FC_m1 = rm1 - rm2, FC_0 = r0 - rm1, FC_p1 = rp1 - r0;
+    const double dZx0 = harm_inv(aux_0, aux_p1, eps), dZxm = harm_inv(aux_m1, aux_0, eps);
+    const double dRx0 = harm_inv(FC_0, FC_p1, eps), dRxm = harm_inv(FC_m1, FC_0, eps);
+    double *ru = c->F.ru + (long)(nrhs - 1) * n3w;
+    ru[I3W(i, j, k)] = c->F.on_u[I2(i, j)] * 0.5 * (hz0 + Hz[ck - 1]) *
+        (P[ck - 1] - P0 -
+         HalfGRho * ((r0 + rm1) * (z0 - zm1) -
+                     OneFifth * ((dRx0 - dRxm) * (z0 - zm1 - OneTwelfth * (dZx0 + dZxm)) -
+                                 (dZx0 - dZxm) * (r0 - rm1 - OneTwelfth * (dRx0 + dRxm)))));
+  }
+  if (j >= b.JstrV) {
+    const double rm1 = rho[ck - ni], rp1 = rho[ck + ni];
+    const double zm1 = z_r[ck - ni], zp1 = z_r[ck + ni];
+    // aux(j-1) needs row j-2: exists for j-1 >= JstrV-1, i.e. always here
+    const double rm2 = rho[ck - 2 * ni], zm2 = z_r[ck - 2 * ni];
+    const double aux_m1 = zm1 - zm2, aux_0 = z0 - zm1, aux_p1 = zp1 - z0;
+    const double FC_m1 = rm1 - rm2, FC_0 = r0 - rm1, FC_p1 = rp1 - r0;
+    const double dZx0 = harm_inv(aux_0, aux_p1, eps), dZxm = harm_inv(aux_m1, aux_0, eps);
+    const double dRx0 = harm_inv(FC_0, FC_p1, eps), dRxm = harm_inv(FC_m1, FC_0, eps);
+    double *rv = c->F.rv + (long)(nrhs - 1) * n3w;
+    rv[I3W(i, j, k)] = c->F.om_v[I2(i, j)] * 0.5 * (hz0 + Hz[ck - ni]) *
+        (P[ck - ni] - P0 -
+         HalfGRho * ((r0 + rm1) * (z0 - zm1) -
+                     OneFifth * ((dRx0 - dRxm) * (z0 - zm1 - OneTwelfth * (dZx0 + dZxm)) -
+                                 (dZx0 - dZxm) * (r0 - rm1 - OneTwelfth * (dRx0 + dRxm)))));
+  }
+}
+
+}  // namespace
+
+extern "C" int roms_hip_prsgrd(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_prsgrd");
+  if (rc) return rc;
+  if ((rc = check_lbc())) return rc;
+  ScopedTimer tm("prsgrd");
+  const roms_bounds_t &b = g_ctx.b;
+  if (b.N < 3) return roms_fail("roms_hip_prsgrd", "N < 3");
+  double *P = g_ctx.hostc.ws3[0];
+  hipLaunchKernelGGL(k_prsgrd_P, grid2d(b.Iend - (b.IstrU - 1) + 1, b.Jend - (b.JstrV - 1) + 1), block2d(), 0,
+                     g_ctx.stream, g_ctx.devc, P);
+  KERNEL_CHECK("k_prsgrd_P");
+  dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
+  grid.z = b.N;
+  hipLaunchKernelGGL(k_prsgrd_uv, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, (const double *)P, s->nrhs);
+  KERNEL_CHECK("k_prsgrd_uv");
+  return 0;
+}

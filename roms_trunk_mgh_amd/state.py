@@ -38,6 +38,9 @@ class TileState:
     def __getitem__(self, name):
         return self.arr[name]
 
+    def __setitem__(self, name, value):
+        self.arr[name][...] = value
+
     def fields_struct(self):
         f = abi.Fields()
         for name, _, _ in abi.FIELDS:

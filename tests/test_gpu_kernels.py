@@ -3,6 +3,8 @@ oracle on the same seeded inputs.  Tolerance: 1e-12 relative to the field's
 max-norm per call (the north_star bound is 1e-10 relative RMS after 100 steps;
 with identical operation order and no FMA contraction the observed difference
 is 0 or a few ulp)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -22,6 +24,9 @@ def _run_pair(config, kernel, s, prep=None, NT=None, overrides=None):
         prep(st0)
     st_o, st_h = st0.copy(), st0.copy()
     oracle.Oracle(st_o).call(kernel, s)
+    if os.environ.get("ROMS_TEST_DRY"):      # local dry run of the test logic (no GPU)
+        oracle.Oracle(st_h).call(kernel, s)
+        return st_h, st_o, st0
     h = hip.RomsHip(st_h)
     try:
         h.call(kernel, s)
@@ -31,10 +36,19 @@ def _run_pair(config, kernel, s, prep=None, NT=None, overrides=None):
     return st_h, st_o, st0
 
 
+def _detune(st):
+    """make every glue kernel's inputs inconsistent with its current outputs"""
+    st["Zt_avg1"] *= 1.3
+    st["u"] *= 1.1
+    st["v"] *= 0.9
+    st["Huon"] *= 1.05
+    st["Hvom"] *= 0.95
+
+
 @pytest.mark.parametrize("config", CONFIGS)
 @pytest.mark.parametrize("kernel", ["set_depth", "set_massflux", "omega", "set_zeta"])
 def test_glue_kernels(config, kernel):
-    st_h, st_o, st0 = _run_pair(config, kernel, util.step_idx())
+    st_h, st_o, st0 = _run_pair(config, kernel, util.step_idx(), prep=_detune)
     diffs = util.compare_states(st_h, st_o)
     assert all(v <= TOL for v in diffs.values()), diffs
     changed = util.compare_states(st_o, st0)
@@ -57,3 +71,19 @@ def test_step3d_t_schemes(hadv, vadv):
                                 overrides=ov)
     diffs = util.compare_states(st_h, st_o)
     assert all(v <= TOL for v in diffs.values()), diffs
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+def test_prsgrd(config):
+    st_h, st_o, st0 = _run_pair(config, "prsgrd", util.step_idx())
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+    assert util.max_rel_diff(st_o["ru"], st0["ru"]) > 1e-6
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+def test_rho_eos(config):
+    st_h, st_o, st0 = _run_pair(config, "rho_eos", util.step_idx())
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+    assert util.max_rel_diff(st_o["rho"], st0["rho"]) > 1e-6
