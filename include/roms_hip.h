@@ -109,6 +109,8 @@ typedef struct roms_params {
   int    ts_dif2, mix_geo_ts, mix_s_ts, salinity, lmd_nonlocal, solar_source;
   int    splines_vdiff, splines_vvisc;
   double Akt_bak[ROMS_MAXNT], Akv_bak;
+  /* Jerlov water type constants of lmd_swfrac.F:6 (mod_scalars.F:1502-1512), uniform WTYPE */
+  double swfrac_mu1, swfrac_mu2, swfrac_r1;
 } roms_params_t;
 
 /* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and

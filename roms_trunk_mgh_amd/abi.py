@@ -92,6 +92,7 @@ class Params(C.Structure):
         ("salinity", C.c_int), ("lmd_nonlocal", C.c_int), ("solar_source", C.c_int),
         ("splines_vdiff", C.c_int), ("splines_vvisc", C.c_int),
         ("Akt_bak", C.c_double * ROMS_MAXNT), ("Akv_bak", C.c_double),
+        ("swfrac_mu1", C.c_double), ("swfrac_mu2", C.c_double), ("swfrac_r1", C.c_double),
     ]
 
 

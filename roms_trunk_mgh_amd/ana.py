@@ -203,6 +203,8 @@ def make_params(cfg, NT):
     for it in range(NT):
         p.Akt_bak[it] = {"BENCHMARK": 1.0e-5}.get(app, 1.0e-6)
     p.Akv_bak = {"BENCHMARK": 1.0e-4}.get(app, 1.0e-5)
+    # WTYPE == 1 (roms_benchmark*.in:392): mod_scalars.F:1502-1512
+    p.swfrac_mu1, p.swfrac_mu2, p.swfrac_r1 = 0.35, 23.0, 0.58
     return p
 
 

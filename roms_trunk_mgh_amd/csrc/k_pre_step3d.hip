@@ -1,0 +1,302 @@
+// k_pre_step3d.hip -- predictor step, pre_step3d_tile
+// (ROMS/Nonlinear/pre_step3d.F:123-1156).
+//
+//   k_pre_t   one thread per water column and tracer, one upward sweep:
+//             horizontal + vertical advective fluxes of t(nstp), artificial
+//             continuity, t(n+1/2) -> t(:,:,:,3,itrc)  (:342-915), and the
+//             start of the corrector t(:,:,:,nnew,itrc) = Hz*t(nstp) + explicit
+//             vertical flux divergence incl. KPP non-local and solar terms
+//             (:917-1010, lmd_swfrac.F:6).  A thread reads t(nnew) only in its
+//             own column before overwriting it, so the fusion is hazard-free.
+//   k_pre_uv  one thread per column: start of u,v(nnew) with the AB3 terms
+//             5/12 ru(nrhs) - 16/12 ru(3-nrhs) and surface/bottom stress
+//             (:1012-1120).
+// Algorithmic traffic (BENCHMARK, NT=2): per tracer read t(nstp), t(nnew), Akt,
+// ghats; write t(3), t(nnew) = 48 B; shared Huon,Hvom,W,Hz,z_r,z_w = 48 B; momentum
+// part reads u,v(nstp), ru,rv x2, Akv, writes u,v(nnew) = 72 B.
+#include "roms_dev.h"
+#include "advect.h"
+
+int roms_entry_check(const char *name);
+
+namespace {
+
+template <int HADV, int VADV, int NMAX>
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int itrc0)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  const int itrc = itrc0 + blockIdx.z;
+  if (i > b.Iend || j > b.Jend) return;
+  const roms_params_t &p = c->p;
+  const int ltrc = itrc < b.NAT ? itrc : b.NAT;
+  const double dt = p.dt;
+  const double *__restrict__ ts = c->F.t + ((long)(nstp - 1) + 3L * (itrc - 1)) * n3r;
+  double *__restrict__ t3 = c->F.t + (2L + 3L * (itrc - 1)) * n3r;
+  double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
+  const double *__restrict__ Huon = c->F.Huon;
+  const double *__restrict__ Hvom = c->F.Hvom;
+  const double *__restrict__ Wv = c->F.W;
+  const double *__restrict__ Hz = c->F.Hz;
+  const double *__restrict__ z_r = c->F.z_r;
+  const double *__restrict__ z_w = c->F.z_w;
+  const double *__restrict__ Akt = c->F.Akt + (long)(ltrc - 1) * n3w;
+  const long c0 = I2(i, j);
+  const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
+  const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
+  // time-stepping weights, pre_step3d.F:586-600
+  const double Gamma = 1.0 / 6.0;
+  double cff, cff1, cff2;
+  if (first_step) { cff = 0.5 * dt; cff1 = 1.0; cff2 = 0.0; }
+  else { cff = (1.0 - Gamma) * dt; cff1 = 0.5 + Gamma; cff2 = 0.5 - Gamma; }
+  const double cpp = cff * c->F.pm[c0] * c->F.pn[c0];
+  // explicit vertical flux pieces
+  const double cff3 = dt * (1.0 - p.lambda);
+  const bool nonlocal = p.lmd_nonlocal && itrc <= b.NAT;
+  const bool solar = p.solar_source && itrc == 1;
+  const double *__restrict__ ghats = c->F.ghats + (long)((itrc <= b.NAT ? itrc : 1) - 1) * n3w;
+  const double *__restrict__ AktN = c->F.Akt + (long)((itrc <= b.NAT ? itrc : 1) - 1) * n3w;   // Akt(..,itrc) of the non-local term
+  const double srf = c->F.srflx[c0];
+  const double zwN = z_w[c0 + (long)N * nij];
+  const double fac1 = -1.0 / p.swfrac_mu1, fac2 = -1.0 / p.swfrac_mu2, fac3 = p.swfrac_r1;
+
+  // vertical schemes that need the whole column first
+  double a4cf[(VADV == ADV_A4) ? NMAX + 2 : 1];
+  double spl[(VADV == ADV_SPLINES) ? NMAX + 1 : 1];
+  if constexpr (VADV == ADV_A4) {
+    const double eps = 1.0E-16;
+    double dprev = 0.0, tk = ts[c0];
+#pragma unroll
+    for (int k = 1; k <= NMAX; k++) {
+      if (k <= N) {
+        double dk;
+        if (k < N) { const double tk1 = ts[c0 + (long)k * nij]; dk = tk1 - tk; tk = tk1; }
+        else dk = dprev;
+        if (k == 1) dprev = dk;
+        const double cf = 2.0 * dk * dprev;
+        a4cf[k] = (cf > eps) ? cf / (dk + dprev) : 0.0;
+        dprev = dk;
+      }
+    }
+  }
+  if constexpr (VADV == ADV_SPLINES) {
+    // pre_step3d.F:622-650 (note 1.5/0.5/3/2 instead of step3d_t's 2/1/2/1)
+    double cfs[NMAX + 1];
+    spl[0] = 1.5 * ts[c0];
+    cfs[1] = 0.5;
+#pragma unroll
+    for (int k = 1; k < NMAX; k++) {
+      if (k <= N - 1) {
+        const double hk = Hz[c0 + (long)(k - 1) * nij], hk1 = Hz[c0 + (long)k * nij];
+        const double cf = 1.0 / (2.0 * hk + hk1 * (2.0 - cfs[k]));
+        cfs[k + 1] = cf * hk;
+        spl[k] = cf * (3.0 * (hk * ts[c0 + (long)k * nij] + hk1 * ts[c0 + (long)(k - 1) * nij]) - hk1 * spl[k - 1]);
+      }
+    }
+#pragma unroll
+    for (int k = 1; k <= NMAX; k++)
+      if (k == N) spl[k] = (3.0 * ts[c0 + (long)(N - 1) * nij] - spl[k - 1]) / (2.0 - cfs[k]);
+#pragma unroll
+    for (int k = NMAX - 1; k >= 0; k--) {
+      if (k <= N - 1) {
+        spl[k] = spl[k] - cfs[k + 1] * spl[k + 1];
+        spl[k + 1] = Wv[c0 + (long)(k + 1) * nij] * spl[k + 1];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k <= NMAX; k++) if (k == 0 || k == N) spl[k] = 0.0;
+  }
+
+  double tkm1 = 0.0, tk = ts[c0], tkp1 = (N >= 2) ? ts[c0 + nij] : 0.0, tkp2;
+  double FCprev = 0.0;                                        // advective FC(k-1)
+  double FDprev = dt * c->F.btflx[c0 + (long)(itrc - 1) * nij]; // diffusive FC(0)
+  double w_km1 = Wv[c0];
+  double zr_k = z_r[c0];
+  for (int k = 1; k <= N; k++) {
+    const long ck = c0 + (long)(k - 1) * nij;
+    tkp2 = (k + 2 <= N) ? ts[ck + 2 * nij] : 0.0;
+    // ---- horizontal fluxes of t(nstp) ----
+    const double xm2 = ts[ck - 2], xm1 = ts[ck - 1], xp1 = ts[ck + 1], xp2 = ts[ck + 2];
+    const double ym1 = ts[ck - ni], yp1 = ts[ck + ni];
+    const double ym2 = s_wall ? 0.0 : ts[ck - 2 * ni];
+    const double yp2 = n_wall ? 0.0 : ts[ck + 2 * ni];
+    const double hu0 = Huon[ck], hu1 = Huon[ck + 1];
+    const double hv0 = Hvom[ck], hv1 = Hvom[ck + ni];
+    const double dxm1 = xm1 - xm2, dx0 = tk - xm1, dxp1 = xp1 - tk, dxp2 = xp2 - xp1;
+    const double dy0 = tk - ym1, dyp1 = yp1 - tk;
+    const double dym1 = s_wall ? dy0 : (ym1 - ym2);
+    const double dyp2 = n_wall ? dyp1 : (yp2 - yp1);
+    const double FXi = hflux<HADV>(hu0, xm1, tk, dxm1, dx0, dxp1);
+    const double FXip1 = hflux<HADV>(hu1, tk, xp1, dx0, dxp1, dxp2);
+    const double FEj = hflux<HADV>(hv0, ym1, tk, dym1, dy0, dyp1);
+    const double FEjp1 = hflux<HADV>(hv1, tk, yp1, dy0, dyp1, dyp2);
+    const double hz = Hz[ck];
+    const double tnn = tn[ck];
+    double t3v = hz * (cff1 * tk + cff2 * tnn) - cpp * (FXip1 - FXi + FEjp1 - FEj);
+    // ---- vertical advective flux through the top face ----
+    const double w_k = Wv[ck + nij];
+    double FCk;
+    if (k == N) FCk = 0.0;
+    else if constexpr (VADV == ADV_SPLINES) FCk = spl[k];
+    else {
+      double cfk = 0.0, cfk1 = 0.0;
+      if constexpr (VADV == ADV_A4) { cfk = a4cf[k]; cfk1 = a4cf[k + 1]; }
+      FCk = vflux<VADV>(k, N, w_k, tkm1, tk, tkp1, tkp2, cfk, cfk1);
+    }
+    // ---- artificial continuity, pre_step3d.F:893-915 ----
+    const double DCk = 1.0 / (hz - cpp * (hu1 - hu0 + hv1 - hv0 + (w_k - w_km1)));
+    t3v = DCk * (t3v - cpp * (FCk - FCprev));
+    t3[ck] = t3v;
+    // ---- start of the corrector: explicit vertical flux, pre_step3d.F:917-1010 ----
+    double FDk;
+    if (k == N) FDk = dt * c->F.stflx[c0 + (long)(itrc - 1) * nij];
+    else {
+      const double zr_k1 = z_r[ck + nij];
+      const double cz = 1.0 / (zr_k1 - zr_k);
+      FDk = cff3 * cz * Akt[ck + nij] * (tkp1 - tk);
+      if (nonlocal) FDk = FDk - dt * AktN[ck + nij] * ghats[ck + nij];
+      if (solar) {
+        const double Z = zwN - z_w[ck + nij];
+        const double swdk = exp(Z * fac1) * fac3 + exp(Z * fac2) * (1.0 - fac3);
+        FDk = FDk + dt * srf * swdk;
+      }
+      zr_k = zr_k1;
+    }
+    tn[ck] = hz * tk + (FDk - FDprev);
+    FDprev = FDk;
+    FCprev = FCk;
+    w_km1 = w_k;
+    tkm1 = tk; tk = tkp1; tkp1 = tkp2;
+  }
+}
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_pre_uv(const RomsDev *__restrict__ c, int nstp, int nnew, int nrhs, int stage)
+{
+  // stage: 0 = first step (forward Euler), 1 = second step (AB2), 2 = AB3
+  DEV_PROLOGUE(c)
+  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.Jend) return;
+  const roms_params_t &p = c->p;
+  const double dt = p.dt;
+  const double cff3 = dt * (1.0 - p.lambda);
+  const double *__restrict__ z_r = c->F.z_r;
+  const double *__restrict__ Hz = c->F.Hz;
+  const double *__restrict__ Akv = c->F.Akv;
+  const double *__restrict__ pm = c->F.pm;
+  const double *__restrict__ pn = c->F.pn;
+  const long c0 = I2(i, j);
+  const int indx = 3 - nrhs;
+#pragma unroll
+  for (int comp = 0; comp < 2; comp++) {
+    if (comp == 0 && i < b.IstrU) continue;
+    if (comp == 1 && j < b.JstrV) continue;
+    const long off = comp == 0 ? 1 : ni;          // neighbour at i-1 or j-1
+    const double *__restrict__ vel = (comp == 0 ? c->F.u : c->F.v) + (long)(nstp - 1) * n3r;
+    double *__restrict__ vnew = (comp == 0 ? c->F.u : c->F.v) + (long)(nnew - 1) * n3r;
+    const double *__restrict__ r1 = (comp == 0 ? c->F.ru : c->F.rv) + (long)(nrhs - 1) * n3w;
+    const double *__restrict__ r2 = (comp == 0 ? c->F.ru : c->F.rv) + (long)(indx - 1) * n3w;
+    const double bstr = (comp == 0 ? c->F.bustr : c->F.bvstr)[c0];
+    const double sstr = (comp == 0 ? c->F.sustr : c->F.svstr)[c0];
+    const double cq = dt * 0.25;
+    const double DC0 = cq * (pm[c0] + pm[c0 - off]) * (pn[c0] + pn[c0 - off]);
+    double FCprev = dt * bstr;
+    double vk = vel[c0];
+    double zsum_k = 0.0;   // unused placeholder for clarity
+    (void)zsum_k;
+    for (int k = 1; k <= N; k++) {
+      const long ck = c0 + (long)(k - 1) * nij;
+      double FCk, vk1 = 0.0;
+      if (k == N) FCk = dt * sstr;
+      else {
+        vk1 = vel[ck + nij];
+        const double cz = 1.0 / (z_r[ck + nij] + z_r[ck + nij - off] - z_r[ck] - z_r[ck - off]);
+        FCk = cff3 * cz * (vk1 - vk) * (Akv[ck + nij] + Akv[ck + nij - off]);
+      }
+      const double hzs = Hz[ck] + Hz[ck - off];
+      const double d = FCk - FCprev;
+      double out;
+      if (stage == 0) {
+        const double a = vk * 0.5 * hzs;
+        out = a + d;
+      } else if (stage == 1) {
+        const double a = vk * 0.5 * hzs;
+        const double c3 = 0.5 * DC0;
+        out = a - c3 * r2[ck + nij] + d;
+      } else {
+        const double a = vk * 0.5 * hzs;
+        out = a + DC0 * ((5.0 / 12.0) * r1[ck + nij] - (16.0 / 12.0) * r2[ck + nij]) + d;
+      }
+      vnew[ck] = out;
+      FCprev = FCk;
+      vk = vk1;
+    }
+  }
+}
+
+template <int HADV, int VADV>
+int launch_pre_t(const roms_step_idx_t *s, int itrc0, int ntr)
+{
+  const roms_bounds_t &b = g_ctx.b;
+  dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
+  grid.z = ntr;
+  const int first = s->iic == s->ntfirst;
+  if (b.N <= 16)
+    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0);
+  else if (b.N <= 32)
+    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0);
+  else
+    return roms_fail("roms_hip_pre_step3d", "N > 32 not instantiated");
+  KERNEL_CHECK("k_pre_t");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int roms_hip_pre_step3d(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_pre_step3d");
+  if (rc) return rc;
+  if ((rc = check_lbc())) return rc;
+  const roms_bounds_t &b = g_ctx.b;
+  const roms_params_t &p = g_ctx.p;
+  if (b.N < 4) return roms_fail("roms_hip_pre_step3d", "N < 4");
+  {
+    ScopedTimer tm("pre_step3d");
+    int it = 1;
+    while (it <= b.NT) {
+      const int ha = p.Hadv[it - 1], va = p.Vadv[it - 1];
+      int n = 1;
+      while (it + n <= b.NT && p.Hadv[it + n - 1] == ha && p.Vadv[it + n - 1] == va) n++;
+      switch (ha * 16 + va) {
+      case ADV_U3 * 16 + ADV_C4:
+      case ADV_U3 * 16 + ADV_SU3:  rc = launch_pre_t<ADV_U3, ADV_C4>(s, it, n); break;
+      case ADV_A4 * 16 + ADV_A4:   rc = launch_pre_t<ADV_A4, ADV_A4>(s, it, n); break;
+      case ADV_C4 * 16 + ADV_C4:
+      case ADV_SU3 * 16 + ADV_SU3: rc = launch_pre_t<ADV_C4, ADV_C4>(s, it, n); break;
+      case ADV_C2 * 16 + ADV_C2:   rc = launch_pre_t<ADV_C2, ADV_C2>(s, it, n); break;
+      case ADV_U3 * 16 + ADV_SPLINES: rc = launch_pre_t<ADV_U3, ADV_SPLINES>(s, it, n); break;
+      case ADV_C4 * 16 + ADV_SPLINES: rc = launch_pre_t<ADV_C4, ADV_SPLINES>(s, it, n); break;
+      case ADV_A4 * 16 + ADV_SPLINES: rc = launch_pre_t<ADV_A4, ADV_SPLINES>(s, it, n); break;
+      default:
+        return roms_fail("roms_hip_pre_step3d", "advection scheme pair not implemented (MPDATA/HSIMT pending)");
+      }
+      if (rc) return rc;
+      it += n;
+    }
+    const int stage = (s->iic == s->ntfirst) ? 0 : (s->iic == s->ntfirst + 1 ? 1 : 2);
+    hipLaunchKernelGGL(k_pre_uv, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                       g_ctx.devc, s->nstp, s->nnew, s->nrhs, stage);
+    KERNEL_CHECK("k_pre_uv");
+  }
+  // t3dbc_tile(nout=3) + periodic wrap / mp_exchange4d, pre_step3d.F:1131-1145
+  const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
+  for (int it = 1; it <= b.NT; it++)
+    if ((rc = bc_t3d(3, it))) return rc;
+  for (int it = 1; it <= b.NT; it++)
+    if ((rc = halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + (2L + 3L * (it - 1)) * n3r))) return rc;
+  return 0;
+}

@@ -87,3 +87,13 @@ def test_rho_eos(config):
     diffs = util.compare_states(st_h, st_o)
     assert all(v <= TOL for v in diffs.values()), diffs
     assert util.max_rel_diff(st_o["rho"], st0["rho"]) > 1e-6
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+@pytest.mark.parametrize("iic", [1, 2, 5])
+def test_pre_step3d(config, iic):
+    st_h, st_o, st0 = _run_pair(config, "pre_step3d", util.step_idx(iic=iic))
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+    assert util.max_rel_diff(st_o["t"], st0["t"]) > 1e-6
+    assert util.max_rel_diff(st_o["u"], st0["u"]) > 1e-6
