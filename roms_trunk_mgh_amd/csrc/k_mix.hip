@@ -1,0 +1,254 @@
+// k_mix.hip -- harmonic lateral mixing on the 3-D step:
+//   t3dmix2_geo_tile  ROMS/Nonlinear/t3dmix2_geo.h:90-424  (rotated to
+//                     geopotentials, two-slab k-recursion)
+//   t3dmix2_s_tile    ROMS/Nonlinear/t3dmix2_s.h:89-306    (along s-surfaces)
+//   uv3dmix2_s_tile   ROMS/Nonlinear/uv3dmix2_s.h:114-335  (stress tensor
+//                     along s-surfaces; also accumulates rufrc, rvfrc)
+//
+// One thread per (i,j) column sweeping k upward.  The reference's two-slab
+// buffers (level k and k+1 of dZdx,dTdx,dZde,dTde, W-levels k-1 and k of dTdz,
+// FS) become register sliding windows, so the rotated operator needs one read
+// of t(nrhs), z_r, Hz and one read-modify-write of t(nnew) per tracer.
+#include "roms_dev.h"
+
+int roms_entry_check(const char *name);
+
+namespace {
+
+__device__ __forceinline__ double dmin0(double a) { return a < 0.0 ? a : 0.0; }   // MIN(a,0)
+__device__ __forceinline__ double dmax0(double a) { return a > 0.0 ? a : 0.0; }   // MAX(a,0)
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_t3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  const int itrc = 1 + blockIdx.z;
+  if (i > b.Iend || j > b.Jend) return;
+  const double dt = c->p.dt;
+  const double *__restrict__ T = c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
+  double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
+  const double *__restrict__ z_r = c->F.z_r;
+  const double *__restrict__ Hz = c->F.Hz;
+  const double *__restrict__ pm = c->F.pm;
+  const double *__restrict__ pn = c->F.pn;
+  const double *__restrict__ d2 = c->F.diff2 + (long)(itrc - 1) * nij;
+  const long c0 = I2(i, j);
+  // face metrics: xi faces i and i+1, eta faces j and j+1
+  const double mx0 = 0.5 * (pm[c0] + pm[c0 - 1]), mx1 = 0.5 * (pm[c0 + 1] + pm[c0]);
+  const double my0 = 0.5 * (pn[c0] + pn[c0 - ni]), my1 = 0.5 * (pn[c0 + ni] + pn[c0]);
+  const double cfx0 = 0.25 * (d2[c0] + d2[c0 - 1]) * c->F.on_u[c0];
+  const double cfx1 = 0.25 * (d2[c0 + 1] + d2[c0]) * c->F.on_u[c0 + 1];
+  const double cfe0 = 0.25 * (d2[c0] + d2[c0 - ni]) * c->F.om_v[c0];
+  const double cfe1 = 0.25 * (d2[c0 + ni] + d2[c0]) * c->F.om_v[c0 + ni];
+  const double cfs = 0.5 * d2[c0];
+  const double cdt = dt * pm[c0] * pn[c0];
+  // level-k ("k1") and level-(k+1) ("k2") slabs at faces i, i+1, j, j+1
+  double zx0_a, zx1_a, tx0_a, tx1_a, ze0_a, ze1_a, te0_a, te1_a;     // level k
+  double zx0_b, zx1_b, tx0_b, tx1_b, ze0_b, ze1_b, te0_b, te1_b;     // level k+1
+  // dTdz at W-level k-1 ("k1") and k ("k2") in columns (i-1,i,i+1,j-1,j+1)
+  double dzm_a = 0.0, dz0_a = 0.0, dzp_a = 0.0, dzs_a = 0.0, dzn_a = 0.0;
+  double dzm_b, dz0_b, dzp_b, dzs_b, dzn_b;
+  double FS_a = 0.0, FS_b;
+  // values of level k carried for the vertical differences
+  double Tm = T[c0 - 1], T0 = T[c0], Tp = T[c0 + 1], Ts = T[c0 - ni], Tn = T[c0 + ni];
+  double Zm = z_r[c0 - 1], Z0 = z_r[c0], Zp = z_r[c0 + 1], Zs = z_r[c0 - ni], Zn = z_r[c0 + ni];
+  // level 1 slabs (iteration k=0 of the reference)
+  zx0_b = mx0 * (Z0 - Zm); tx0_b = mx0 * (T0 - Tm);
+  zx1_b = mx1 * (Zp - Z0); tx1_b = mx1 * (Tp - T0);
+  ze0_b = my0 * (Z0 - Zs); te0_b = my0 * (T0 - Ts);
+  ze1_b = my1 * (Zn - Z0); te1_b = my1 * (Tn - T0);
+  for (int k = 1; k <= N; k++) {
+    const long ck = c0 + (long)(k - 1) * nij;
+    zx0_a = zx0_b; zx1_a = zx1_b; tx0_a = tx0_b; tx1_a = tx1_b;
+    ze0_a = ze0_b; ze1_a = ze1_b; te0_a = te0_b; te1_a = te1_b;
+    if (k < N) {
+      const long cu = ck + nij;
+      const double Tm1 = T[cu - 1], T01 = T[cu], Tp1 = T[cu + 1], Ts1 = T[cu - ni], Tn1 = T[cu + ni];
+      const double Zm1 = z_r[cu - 1], Z01 = z_r[cu], Zp1 = z_r[cu + 1], Zs1 = z_r[cu - ni], Zn1 = z_r[cu + ni];
+      zx0_b = mx0 * (Z01 - Zm1); tx0_b = mx0 * (T01 - Tm1);
+      zx1_b = mx1 * (Zp1 - Z01); tx1_b = mx1 * (Tp1 - T01);
+      ze0_b = my0 * (Z01 - Zs1); te0_b = my0 * (T01 - Ts1);
+      ze1_b = my1 * (Zn1 - Z01); te1_b = my1 * (Tn1 - T01);
+      { const double q = 1.0 / (Zm1 - Zm); dzm_b = q * (Tm1 - Tm); }
+      { const double q = 1.0 / (Z01 - Z0); dz0_b = q * (T01 - T0); }
+      { const double q = 1.0 / (Zp1 - Zp); dzp_b = q * (Tp1 - Tp); }
+      { const double q = 1.0 / (Zs1 - Zs); dzs_b = q * (Ts1 - Ts); }
+      { const double q = 1.0 / (Zn1 - Zn); dzn_b = q * (Tn1 - Tn); }
+      Tm = Tm1; T0 = T01; Tp = Tp1; Ts = Ts1; Tn = Tn1;
+      Zm = Zm1; Z0 = Z01; Zp = Zp1; Zs = Zs1; Zn = Zn1;
+    } else {
+      dzm_b = dz0_b = dzp_b = dzs_b = dzn_b = 0.0;
+    }
+    const double hz0 = Hz[ck], hzm = Hz[ck - 1], hzp = Hz[ck + 1], hzs = Hz[ck - ni], hzn = Hz[ck + ni];
+    // FX(i), FX(i+1), FE(j), FE(j+1): t3dmix2_geo.h:268-310
+    const double FX0 = cfx0 * (hz0 + hzm) *
+        (tx0_a - 0.5 * (dmin0(zx0_a) * (dzm_a + dz0_b) + dmax0(zx0_a) * (dzm_b + dz0_a)));
+    const double FX1 = cfx1 * (hzp + hz0) *
+        (tx1_a - 0.5 * (dmin0(zx1_a) * (dz0_a + dzp_b) + dmax0(zx1_a) * (dz0_b + dzp_a)));
+    const double FE0 = cfe0 * (hz0 + hzs) *
+        (te0_a - 0.5 * (dmin0(ze0_a) * (dzs_a + dz0_b) + dmax0(ze0_a) * (dzs_b + dz0_a)));
+    const double FE1 = cfe1 * (hzn + hz0) *
+        (te1_a - 0.5 * (dmin0(ze1_a) * (dz0_a + dzn_b) + dmax0(ze1_a) * (dz0_b + dzn_a)));
+    if (k < N) {
+      double c1 = dmin0(zx0_a), c2 = dmin0(zx1_b), c3 = dmax0(zx0_b), c4 = dmax0(zx1_a);
+      FS_b = cfs * (c1 * (c1 * dz0_b - tx0_a) + c2 * (c2 * dz0_b - tx1_b) +
+                    c3 * (c3 * dz0_b - tx0_b) + c4 * (c4 * dz0_b - tx1_a));
+      c1 = dmin0(ze0_a); c2 = dmin0(ze1_b); c3 = dmax0(ze0_b); c4 = dmax0(ze1_a);
+      FS_b = FS_b + cfs * (c1 * (c1 * dz0_b - te0_a) + c2 * (c2 * dz0_b - te1_b) +
+                           c3 * (c3 * dz0_b - te0_b) + c4 * (c4 * dz0_b - te1_a));
+    } else FS_b = 0.0;
+    const double cff1 = cdt * (FX1 - FX0);
+    const double cff2 = cdt * (FE1 - FE0);
+    const double cff3 = dt * (FS_b - FS_a);
+    const double cff4 = cff1 + cff2 + cff3;
+    tn[ck] = tn[ck] + cff4;
+    dzm_a = dzm_b; dz0_a = dz0_b; dzp_a = dzp_b; dzs_a = dzs_b; dzn_a = dzn_b;
+    FS_a = FS_b;
+  }
+}
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  const int itrc = 1 + blockIdx.z;
+  if (i > b.Iend || j > b.Jend) return;
+  const double *__restrict__ T = c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
+  double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
+  const double *__restrict__ Hz = c->F.Hz;
+  const double *__restrict__ d2 = c->F.diff2 + (long)(itrc - 1) * nij;
+  const long c0 = I2(i, j);
+  const double cfx0 = 0.25 * (d2[c0] + d2[c0 - 1]) * c->F.pmon_u[c0];
+  const double cfx1 = 0.25 * (d2[c0 + 1] + d2[c0]) * c->F.pmon_u[c0 + 1];
+  const double cfe0 = 0.25 * (d2[c0] + d2[c0 - ni]) * c->F.pnom_v[c0];
+  const double cfe1 = 0.25 * (d2[c0 + ni] + d2[c0]) * c->F.pnom_v[c0 + ni];
+  const double cdt = c->p.dt * c->F.pm[c0] * c->F.pn[c0];
+  for (int k = 1; k <= N; k++) {
+    const long ck = c0 + (long)(k - 1) * nij;
+    const double t0 = T[ck], h0 = Hz[ck];
+    const double FX0 = cfx0 * (h0 + Hz[ck - 1]) * (t0 - T[ck - 1]);
+    const double FX1 = cfx1 * (Hz[ck + 1] + h0) * (T[ck + 1] - t0);
+    const double FE0 = cfe0 * (h0 + Hz[ck - ni]) * (t0 - T[ck - ni]);
+    const double FE1 = cfe1 * (Hz[ck + ni] + h0) * (T[ck + ni] - t0);
+    const double cff1 = cdt * (FX1 - FX0);
+    const double cff2 = cdt * (FE1 - FE0);
+    tn[ck] = tn[ck] + (cff1 + cff2);
+  }
+}
+
+// ---- uv3dmix2_s ------------------------------------------------------------
+struct VLvl {
+  const double *u, *v, *Hz;
+  const double *pm, *pn, *pmon_r, *pnom_r, *pmon_p, *pnom_p, *om_r, *on_r, *om_p, *on_p, *visc2_r, *visc2_p;
+  long ni;
+};
+// stress at rho-point a: returns cff (UFx = on_r^2 visc2_r cff ; VFe = om_r^2 visc2_r cff)
+__device__ __forceinline__ double stress_r(const VLvl &L, long a, long ak)
+{
+  return L.Hz[ak] * 0.5 *
+         (L.pmon_r[a] * ((L.pn[a] + L.pn[a + 1]) * L.u[ak + 1] - (L.pn[a - 1] + L.pn[a]) * L.u[ak]) -
+          L.pnom_r[a] * ((L.pm[a] + L.pm[a + L.ni]) * L.v[ak + L.ni] - (L.pm[a - L.ni] + L.pm[a]) * L.v[ak]));
+}
+// stress at psi-point a
+__device__ __forceinline__ double stress_p(const VLvl &L, long a, long ak)
+{
+  return 0.125 * (L.Hz[ak - 1] + L.Hz[ak] + L.Hz[ak - 1 - L.ni] + L.Hz[ak - L.ni]) *
+         (L.pmon_p[a] * ((L.pn[a - L.ni] + L.pn[a]) * L.v[ak] - (L.pn[a - 1 - L.ni] + L.pn[a - 1]) * L.v[ak - 1]) +
+          L.pnom_p[a] * ((L.pm[a - 1] + L.pm[a]) * L.u[ak] - (L.pm[a - 1 - L.ni] + L.pm[a - L.ni]) * L.u[ak - L.ni]));
+}
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_uv3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.Jend) return;
+  const bool do_u = i >= b.IstrU, do_v = j >= b.JstrV;
+  const double dt = c->p.dt;
+  VLvl L;
+  L.ni = ni;
+  L.pm = c->F.pm; L.pn = c->F.pn; L.pmon_r = c->F.pmon_r; L.pnom_r = c->F.pnom_r;
+  L.pmon_p = c->F.pmon_p; L.pnom_p = c->F.pnom_p; L.om_r = c->F.om_r; L.on_r = c->F.on_r;
+  L.om_p = c->F.om_p; L.on_p = c->F.on_p; L.visc2_r = c->F.visc2_r; L.visc2_p = c->F.visc2_p;
+  L.u = c->F.u + (long)(nrhs - 1) * n3r;
+  L.v = c->F.v + (long)(nrhs - 1) * n3r;
+  L.Hz = c->F.Hz;
+  double *__restrict__ un = c->F.u + (long)(nnew - 1) * n3r;
+  double *__restrict__ vn = c->F.v + (long)(nnew - 1) * n3r;
+  const long a = I2(i, j);
+  const double *pm = c->F.pm, *pn = c->F.pn;
+  const double cu = dt * 0.25 * (pm[a - 1] + pm[a]) * (pn[a - 1] + pn[a]);
+  const double cv = dt * 0.25 * (pm[a] + pm[a - ni]) * (pn[a] + pn[a - ni]);
+  const double hn_u = 0.5 * (pn[a - 1] + pn[a]), hm_u = 0.5 * (pm[a - 1] + pm[a]);
+  const double hn_v = 0.5 * (pn[a - ni] + pn[a]), hm_v = 0.5 * (pm[a - ni] + pm[a]);
+  // metric factors of the four stress points each component needs
+  const double kr0_x = L.on_r[a] * L.on_r[a] * L.visc2_r[a], kr0_e = L.om_r[a] * L.om_r[a] * L.visc2_r[a];
+  const double krm_x = L.on_r[a - 1] * L.on_r[a - 1] * L.visc2_r[a - 1];
+  const double krs_e = L.om_r[a - ni] * L.om_r[a - ni] * L.visc2_r[a - ni];
+  const double kp0_e = L.om_p[a] * L.om_p[a] * L.visc2_p[a], kp0_x = L.on_p[a] * L.on_p[a] * L.visc2_p[a];
+  const double kpn_e = L.om_p[a + ni] * L.om_p[a + ni] * L.visc2_p[a + ni];
+  const double kpe_x = L.on_p[a + 1] * L.on_p[a + 1] * L.visc2_p[a + 1];
+  double ruf = do_u ? c->F.rufrc[a] : 0.0, rvf = do_v ? c->F.rvfrc[a] : 0.0;
+  for (int k = 1; k <= N; k++) {
+    const long ak = a + (long)(k - 1) * nij;
+    const double sr0 = stress_r(L, a, ak);
+    const double sp0 = stress_p(L, a, ak);
+    if (do_u) {
+      const double srm = stress_r(L, a - 1, ak - 1);
+      const double spn = stress_p(L, a + ni, ak + ni);
+      const double cff1 = hn_u * (kr0_x * sr0 - krm_x * srm);
+      const double cff2 = hm_u * (kpn_e * spn - kp0_e * sp0);
+      const double cff3 = cu * (cff1 + cff2);
+      ruf = ruf + cff1 + cff2;
+      un[ak] = un[ak] + cff3;
+    }
+    if (do_v) {
+      const double srs = stress_r(L, a - ni, ak - ni);
+      const double spe = stress_p(L, a + 1, ak + 1);
+      const double cff1 = hn_v * (kpe_x * spe - kp0_x * sp0);
+      const double cff2 = hm_v * (kr0_e * sr0 - krs_e * srs);
+      const double cff3 = cv * (cff1 - cff2);
+      rvf = rvf + cff1 - cff2;
+      vn[ak] = vn[ak] + cff3;
+    }
+  }
+  if (do_u) c->F.rufrc[a] = ruf;
+  if (do_v) c->F.rvfrc[a] = rvf;
+}
+
+}  // namespace
+
+extern "C" int roms_hip_t3dmix2(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_t3dmix2");
+  if (rc) return rc;
+  ScopedTimer tm("t3dmix2");
+  const roms_bounds_t &b = g_ctx.b;
+  dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
+  grid.z = b.NT;
+  if (g_ctx.p.mix_geo_ts)
+    hipLaunchKernelGGL(k_t3dmix2_geo, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew);
+  else if (g_ctx.p.mix_s_ts)
+    hipLaunchKernelGGL(k_t3dmix2_s, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew);
+  else
+    return roms_fail("roms_hip_t3dmix2", "no tracer mixing option (MIX_GEO_TS / MIX_S_TS) selected");
+  KERNEL_CHECK("k_t3dmix2");
+  return 0;
+}
+
+extern "C" int roms_hip_uv3dmix2(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_uv3dmix2");
+  if (rc) return rc;
+  ScopedTimer tm("uv3dmix2");
+  const roms_bounds_t &b = g_ctx.b;
+  hipLaunchKernelGGL(k_uv3dmix2_s, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                     g_ctx.devc, s->nrhs, s->nnew);
+  KERNEL_CHECK("k_uv3dmix2_s");
+  return 0;
+}

@@ -97,3 +97,21 @@ def test_pre_step3d(config, iic):
     assert all(v <= TOL for v in diffs.values()), diffs
     assert util.max_rel_diff(st_o["t"], st0["t"]) > 1e-6
     assert util.max_rel_diff(st_o["u"], st0["u"]) > 1e-6
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+@pytest.mark.parametrize("kernel", ["t3dmix2", "uv3dmix2", "rhs3d_tile"])
+def test_rhs_pieces(config, kernel):
+    ov = {"tnu2": 300.0, "visc2": 800.0}      # make the mixing terms non-trivial everywhere
+    st_h, st_o, st0 = _run_pair(config, kernel, util.step_idx(), overrides=ov)
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+    assert util.compare_states(st_o, st0), "kernel did not modify anything"
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+@pytest.mark.parametrize("iic", [1, 4])
+def test_rhs3d_driver(config, iic):
+    st_h, st_o, st0 = _run_pair(config, "rhs3d", util.step_idx(iic=iic))
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
