@@ -1,0 +1,230 @@
+// k_step3d_uv.hip -- corrector step for 3-D momentum, step3d_uv_tile
+// (ROMS/Nonlinear/step3d_uv.F:111-1482).
+//
+//   k_uv_column  one thread per water column (u-column at (i,j) and v-column at
+//                (i,j)): AB3 step u(nnew) += 23/12 dt ru(nrhs) (:303-315),
+//                divide by Hz, implicit vertical viscosity in spline form --
+//                a wavefront-serial Thomas solve per column with the column
+//                state in VGPRs (:346-400, :679-735) -- and replacement of the
+//                vertical mean by DU_avg1/DV_avg1 (:466-520).
+//   k_uv_couple  one thread per column over JstrT:JendT: ubar,vbar(:,:,1:2),
+//                boundary-row mean correction and the corrected mass fluxes
+//                Huon,Hvom with DU_avg2/DV_avg2 (:997-1460); the intermediate
+//                fluxes stay in VGPRs between the two vertical passes.
+// Algorithmic traffic: read Akv,Hz,ru,rv, read+write u,v(nnew), then read
+// u,v(nnew),Hz, read+write Huon,Hvom = 14 passes.
+#include "roms_dev.h"
+
+int roms_entry_check(const char *name);
+
+namespace {
+
+// One momentum column.  off = 1 (u: neighbour i-1) or ni (v: neighbour j-1).
+template <int NMAX>
+__device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
+                                          double *__restrict__ vel, const double *__restrict__ rhs,
+                                          double dc0, double metric, double Davg1)
+{
+  const double *__restrict__ Akv = c->F.Akv;
+  const double *__restrict__ Hz = c->F.Hz;
+  const double dt = c->p.dt;
+  double un[NMAX + 1], CF[NMAX + 1], DC[NMAX + 1];
+  CF[0] = 0.0;
+  DC[0] = 0.0;
+  double hzk_m1 = 0.0, ohz_m1 = 0.0, ak_m2 = 0.0;
+  double ak_m1 = 0.5 * (Akv[c0 - off] + Akv[c0]);           // AK(0)
+  double sumH = 0.0;
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      const long ck = c0 + (long)(k - 1) * nij;
+      const double ak_0 = 0.5 * (Akv[ck + nij - off] + Akv[ck + nij]);   // AK(k)
+      const double hzk = 0.5 * (Hz[ck - off] + Hz[ck]);
+      const double ohz = 1.0 / hzk;
+      double uv = vel[ck];
+      uv = uv + dc0 * rhs[ck + nij];
+      uv = uv * ohz;
+      un[k] = uv;
+      if (k >= 2) {
+        const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
+        const double fc = c6 * hzk_m1 - dt * ak_m2 * ohz_m1;
+        const double cf = c6 * hzk - dt * ak_0 * ohz;
+        const double bc = c3 * (hzk_m1 + hzk) + dt * ak_m1 * (ohz_m1 + ohz);
+        const double cff = 1.0 / (bc - fc * CF[k - 2]);
+        CF[k - 1] = cff * cf;
+        DC[k - 1] = cff * (un[k] - un[k - 1] - fc * DC[k - 2]);
+      }
+      sumH = (k == 1) ? hzk : sumH + hzk;
+      hzk_m1 = hzk; ohz_m1 = ohz; ak_m2 = ak_m1; ak_m1 = ak_0;
+    }
+  }
+  // back substitution (descending) with the viscous update
+  double dcA_up = 0.0, dc_up = 0.0;
+#pragma unroll
+  for (int kk = NMAX - 1; kk >= 0; kk--) {
+    if (kk <= N - 1) {
+      double dcA = 0.0;
+      if (kk >= 1) {
+        const double dc = DC[kk] - CF[kk] * dc_up;
+        dc_up = dc;
+        const double ak = 0.5 * (Akv[c0 + (long)kk * nij - off] + Akv[c0 + (long)kk * nij]);
+        dcA = dc * ak;
+      }
+      const long ck = c0 + (long)kk * nij;           // level kk+1
+      const double hzk = 0.5 * (Hz[ck - off] + Hz[ck]);
+      const double ohz = 1.0 / hzk;
+      un[kk + 1] = un[kk + 1] + dt * ohz * (dcA_up - dcA);
+      dcA_up = dcA;
+    }
+  }
+  // vertical mean replacement, step3d_uv.F:466-520 (sums ascend in k)
+  double sumU = 0.0;
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      const long ck = c0 + (long)(k - 1) * nij;
+      const double hzk = 0.5 * (Hz[ck - off] + Hz[ck]);
+      sumU = (k == 1) ? un[k] * hzk : sumU + un[k] * hzk;
+    }
+  }
+  const double cff1 = 1.0 / (sumH * metric);
+  const double corr = (sumU * metric - Davg1) * cff1;
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++)
+    if (k <= N) vel[c0 + (long)(k - 1) * nij] = un[k] - corr;
+}
+
+template <int NMAX>
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_uv_column(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.Jend) return;
+  const long c0 = I2(i, j);
+  const double *pm = c->F.pm, *pn = c->F.pn;
+  // blockIdx.z selects the component so that both columns do not share VGPRs
+  if (blockIdx.z == 0) {
+    if (i < b.IstrU) return;
+    const double dc0 = cff * (pm[c0] + pm[c0 - 1]) * (pn[c0] + pn[c0 - 1]);
+    uv_column<NMAX>(c, c0, 1, nij, N, c->F.u + (long)(nnew - 1) * n3r, c->F.ru + (long)(nrhs - 1) * n3w, dc0,
+                    c->F.on_u[c0], c->F.DU_avg1[c0]);
+  } else {
+    if (j < b.JstrV) return;
+    const double dc0 = cff * (pm[c0] + pm[c0 - ni]) * (pn[c0] + pn[c0 - ni]);
+    uv_column<NMAX>(c, c0, ni, nij, N, c->F.v + (long)(nnew - 1) * n3r, c->F.rv + (long)(nrhs - 1) * n3w, dc0,
+                    c->F.om_v[c0], c->F.DV_avg1[c0]);
+  }
+}
+
+// Coupling of one column; comp 0 = u (neighbour i-1), 1 = v (neighbour j-1).
+template <int NMAX>
+__device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
+                                              double *__restrict__ vel, double *__restrict__ Hflx,
+                                              double *__restrict__ bar, double metric, double Davg1, double Davg2,
+                                              bool fix_mean)
+{
+  const double *__restrict__ Hz = c->F.Hz;
+  const double cff = 0.5 * metric;
+  double DC0 = 0.0, CF0 = 0.0;
+  double hu[NMAX + 1];
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      const long ck = c0 + (long)(k - 1) * nij;
+      const double dck = cff * (Hz[ck] + Hz[ck - off]);
+      DC0 = DC0 + dck;
+      CF0 = CF0 + dck * vel[ck];
+    }
+  }
+  DC0 = 1.0 / DC0;
+  CF0 = DC0 * (CF0 - Davg1);
+  const double bv = DC0 * Davg1;
+  bar[c0] = bv;
+  bar[c0 + nij] = bv;
+  double FC0 = 0.0;
+#pragma unroll
+  for (int k = NMAX; k >= 1; k--) {
+    if (k <= N) {
+      const long ck = c0 + (long)(k - 1) * nij;
+      const double dck = cff * (Hz[ck] + Hz[ck - off]);
+      double uv = vel[ck];
+      if (fix_mean) { uv = uv - CF0; vel[ck] = uv; }      // boundary rows, :1087-1110
+      const double h = 0.5 * (Hflx[ck] + uv * dck);
+      hu[k] = h;
+      FC0 = FC0 + h;
+    }
+  }
+  FC0 = DC0 * (FC0 - Davg2);
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      const long ck = c0 + (long)(k - 1) * nij;
+      const double dck = cff * (Hz[ck] + Hz[ck - off]);
+      Hflx[ck] = hu[k] - dck * FC0;
+    }
+  }
+}
+
+template <int NMAX>
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_uv_couple(const RomsDev *__restrict__ c, int nnew)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.IstrT + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.JstrT + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.IendT || j > b.JendT) return;
+  const long c0 = I2(i, j);
+  const bool ns_wall = !b.NSperiodic;
+  if (blockIdx.z == 0) {
+    if (i < b.IstrP) return;
+    const bool fix = ns_wall && (j == 0 || j == b.Mm + 1) && i >= b.IstrU && i <= b.Iend;
+    couple_column<NMAX>(c, c0, 1, nij, N, c->F.u + (long)(nnew - 1) * n3r, c->F.Huon, c->F.ubar, c->F.on_u[c0],
+                        c->F.DU_avg1[c0], c->F.DU_avg2[c0], fix);
+  } else {
+    if (j < b.Jstr) return;
+    const bool fix = ns_wall && (j == 1 || j == b.Mm + 1) && i >= b.Istr && i <= b.Iend;
+    couple_column<NMAX>(c, c0, ni, nij, N, c->F.v + (long)(nnew - 1) * n3r, c->F.Hvom, c->F.vbar, c->F.om_v[c0],
+                        c->F.DV_avg1[c0], c->F.DV_avg2[c0], fix);
+  }
+}
+
+}  // namespace
+
+extern "C" int roms_hip_step3d_uv(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_step3d_uv");
+  if (rc) return rc;
+  if ((rc = check_lbc())) return rc;
+  const roms_bounds_t &b = g_ctx.b;
+  const double dt = g_ctx.p.dt;
+  double cff;
+  if (s->iic == s->ntfirst) cff = 0.25 * dt;
+  else if (s->iic == s->ntfirst + 1) cff = 0.25 * dt * 3.0 / 2.0;
+  else cff = 0.25 * dt * 23.0 / 12.0;
+  {
+    ScopedTimer tm("step3d_uv");
+    dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
+    grid.z = 2;
+    if (b.N <= 16) hipLaunchKernelGGL(k_uv_column<16>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
+    else if (b.N <= 32) hipLaunchKernelGGL(k_uv_column<32>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
+    else return roms_fail("roms_hip_step3d_uv", "N > 32 not instantiated");
+    KERNEL_CHECK("k_uv_column");
+    if ((rc = bc_u3d(s->nnew))) return rc;
+    if ((rc = bc_v3d(s->nnew))) return rc;
+    dim3 grid2 = grid2d(b.IendT - b.IstrT + 1, b.JendT - b.JstrT + 1);
+    grid2.z = 2;
+    if (b.N <= 16) hipLaunchKernelGGL(k_uv_couple<16>, grid2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nnew);
+    else hipLaunchKernelGGL(k_uv_couple<32>, grid2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nnew);
+    KERNEL_CHECK("k_uv_couple");
+  }
+  const long nij = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1);
+  const long n3r = nij * b.N;
+  if ((rc = halo_exchange3d(GT_U, b.N, g_ctx.dev[FID_u] + (long)(s->nnew - 1) * n3r))) return rc;
+  if ((rc = halo_exchange3d(GT_V, b.N, g_ctx.dev[FID_v] + (long)(s->nnew - 1) * n3r))) return rc;
+  if ((rc = halo_exchange3d(GT_U, b.N, g_ctx.dev[FID_Huon]))) return rc;
+  if ((rc = halo_exchange3d(GT_V, b.N, g_ctx.dev[FID_Hvom]))) return rc;
+  if ((rc = halo_exchange3d(GT_U, 2, g_ctx.dev[FID_ubar]))) return rc;
+  return halo_exchange3d(GT_V, 2, g_ctx.dev[FID_vbar]);
+}
