@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: simulated-days per wall-second of the ROMS
+nonlinear 3-D time-stepping hot path on BENCHMARK3 (2048x256x30), on N MI355X.
+
+A "step" is one full baroclinic step of the hot path:
+set_massflux, rho_eos, omega, set_zeta, rhs3d (pre_step3d, prsgrd, t3dmix2,
+rhs3d_tile, uv3dmix2), the 59-call barotropic step2d loop, set_depth,
+step3d_uv, omega, step3d_t -- on synthetic (analytic) BENCHMARK inputs that are
+resident in HBM before the timed region starts.  The per-step physics outside
+the hot path (bulk_flux, lmd_vmix, set_vbc: SURVEY.md section 8f-1) is held
+fixed, see DESIGN.md.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 the driver launches this file under torch.distributed.run, one rank
+per GPU; the grid is split into NtileI x NtileJ = N tiles (2x1, 4x1, 4x2) and the
+halo swaps run over RCCL inside libroms_hip.so (strong scaling: the global grid
+is fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TILINGS = {1: (1, 1), 2: (2, 1), 4: (4, 1), 8: (4, 2)}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(config, nsteps):
+    """The CPU oracle (a single-thread plain-C port of the reference kernels)
+    timed on the host of the GPU box for a bounded number of full steps of the
+    same workload.  Reported baseline, not the optimisation target."""
+    import oracle
+    from roms_trunk_mgh_amd import ana, main3d
+    st = ana.make_tile(config, perturb=1.0)
+    m = main3d.Main3D(oracle.Oracle(st))
+    m.initial()
+    m.step()                      # first step (forward Euler branch) untimed
+    t0 = time.perf_counter()
+    m.run(nsteps)
+    wall = time.perf_counter() - t0
+    return nsteps * st.p.dt / 86400.0 / wall, wall
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="BENCHMARK3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from roms_trunk_mgh_amd import ana, hip, main3d
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.gpus not in TILINGS:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    ntI, ntJ = TILINGS[args.gpus]
+
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU visible: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    uid = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # control plane (barrier, max-reduce of timings, id broadcast): gloo on the host;
+        # data plane (halo swaps): RCCL inside libroms_hip.so
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            lib = hip.load()
+            if lib.roms_hip_get_unique_id(buf) != 0:
+                raise SystemExit("ncclGetUniqueId failed")
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        dist.broadcast(t, src=0)
+        uid = bytes(t.numpy().tobytes())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    st = ana.make_tile(args.config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0)
+    be = hip.RomsHip(st, rank=rank, device=local_rank, nccl_unique_id=uid)
+    m = main3d.Main3D(be)
+    m.initial()
+    for _ in range(args.warmup):
+        m.step()
+    be.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.step()
+    be.sync()
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+
+    # ---- roofline of the dominant graded kernel: step3d_t (live hipEvent timing) ----
+    be.timing(True)
+    per_kernel = {}
+    names = ["set_massflux", "rho_eos", "omega", "set_zeta", "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile",
+             "uv3dmix2", "step2d_loop", "set_depth", "step3d_uv", "step3d_t"]
+    acc = {n: [] for n in names}
+    for _ in range(5):
+        m.step()
+        for n in names:
+            v = be.last_ms(n)
+            if v >= 0:
+                acc[n].append(v)
+    be.timing(False)
+    for n in names:
+        if acc[n]:
+            per_kernel[n] = sum(acc[n]) / len(acc[n])
+    b = st.b
+    tile_cells = (b.Iend - b.Istr + 1) * (b.Jend - b.Jstr + 1) * b.N
+    alg_bytes = 8.0 * (4 * b.NT + 4) * tile_cells
+    t_ms = per_kernel.get("step3d_t", float("nan"))
+    achieved = alg_bytes / (t_ms * 1e-3) / 1e9
+    # finite check: the timed run must not have blown up
+    be.to_host(["zeta", "t"])
+    import numpy as np
+    ok = bool(np.isfinite(st["zeta"]).all() and np.isfinite(st["t"]).all())
+    be.close()
+
+    if rank == 0:
+        dt = st.p.dt
+        value = args.steps * dt / 86400.0 / wall
+        out = {
+            "metric": "simulated-days/wall-sec", "value": value, "unit": "simulated-days/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config} {b.Lm}x{b.Mm}x{b.N} NT={b.NT} "
+                                   f"nonlinear 3-D step incl. {2 * st.p.nfast + 1} step2d calls, "
+                                   f"U3/C4 tracer advection, fixed analytic forcing/mixing",
+                       "tiling": f"{ntI}x{ntJ}", "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok},
+            "roofline": {"kernel": "k_step3d_t (step3d_t_tile)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_ms": t_ms, "algorithmic_bytes": alg_bytes},
+            "kernel_ms": per_kernel,
+        }
+        if not args.no_cpu_baseline and args.gpus == 1:
+            v, w = cpu_baseline(args.config, args.cpu_steps)
+            out["cpu_baseline"] = {"value": v, "unit": "simulated-days/s", "cores": 1, "kind": "port",
+                                   "sample": f"{args.cpu_steps} full steps of {args.config} on one host core "
+                                             f"({w:.1f} s), oracle/ C restatement, gcc -O2"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Host-side mirror of the reference's step sequencer `main3d`
+(ROMS/Nonlinear/main3d.F:3-927) restricted to the hot path of SURVEY.md section 8a.
+
+In a ROMS build the unchanged Fortran main3d drives libroms_hip.so through the
+ISO_C_BINDING shims (fortran/roms_hip_mod.F90).  This Python driver exists
+because the full Fortran executable cannot be linked in this environment
+(netCDF-Fortran is absent); it issues exactly the same calls in the same order,
+against either backend (`hip.RomsHip` = the product, or the CPU oracle in tests):
+
+    main3d.F:189-191  nstp/nnew/nrhs rotation
+    main3d.F:307-309  set_massflux, rho_eos            (diag: not on the path)
+    main3d.F:388-394  bulk_flux, set_vbc               -> fixed forcing inputs
+    main3d.F:467-475  lmd_vmix -> fixed mixing inputs; omega
+    main3d.F:489      set_zeta
+    main3d.F:563      rhs3d
+    main3d.F:592-700  LOOP_2D (predictor/corrector step2d)
+    main3d.F:736      set_depth
+    main3d.F:762      step3d_uv
+    main3d.F:789      omega
+    main3d.F:814      step3d_t
+    main3d.F:914      iic += 1
+"""
+from . import abi
+
+
+class Main3D:
+    def __init__(self, backend, ntstart=1):
+        self.be = backend
+        self.iic = ntstart
+        self.ntstart = ntstart
+        self.ntfirst = ntstart
+        self.indx1 = 1                      # mod_stepping.F initial value
+        self.s = abi.StepIdx(iic=ntstart, ntfirst=ntstart, nstp=1, nnew=2, nrhs=1,
+                             kstp=1, krhs=1, knew=1, iif=1, predictor_2d_step=0)
+
+    def initial(self):
+        """The hot-path part of ROMS/Nonlinear/initial.F:337-571:
+        set_depth, set_massflux, omega, rho_eos on the initial state."""
+        s = self.s
+        s.nstp, s.nnew, s.nrhs = 1, 2, 1
+        for k in ("set_depth", "set_massflux", "omega", "rho_eos"):
+            self.be.call(k, s)
+
+    def _rotate(self):
+        s = self.s
+        s.iic = self.iic
+        s.ntfirst = self.ntfirst
+        s.nstp = 1 + (self.iic - self.ntstart) % 2
+        s.nnew = 3 - s.nstp
+        s.nrhs = s.nstp
+
+    def step(self):
+        be, s = self.be, self
+        self._rotate()
+        s = self.s
+        be.call("set_massflux", s)
+        be.call("rho_eos", s)
+        be.call("omega", s)
+        be.call("set_zeta", s)
+        be.call("rhs3d", s)
+        self.indx1 = be.step2d_loop(s, self.indx1)
+        be.call("set_depth", s)
+        be.call("step3d_uv", s)
+        be.call("omega", s)
+        be.call("step3d_t", s)
+        self.iic += 1
+
+    def run(self, nsteps):
+        for _ in range(nsteps):
+            self.step()
