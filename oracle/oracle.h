@@ -147,6 +147,8 @@ enum { GT_R = 0, GT_U, GT_V, GT_P };
 #define OARGS const roms_bounds_t *b, const roms_params_t *p, const roms_step_idx_t *s, roms_fields_t *F
 
 /* ---- helpers (oracle_base.c) ---- */
+typedef void (*o_exchange_hook_t)(double *A, int nk, int gtype);
+void oracle_set_exchange_hook(o_exchange_hook_t fn);
 void o_exchange2d(const roms_bounds_t *b, int gtype, double *A);
 void o_exchange3d(const roms_bounds_t *b, int gtype, int nk, double *A);
 int  o_check_lbc(const roms_bounds_t *b, const roms_params_t *p);

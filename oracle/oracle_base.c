@@ -28,7 +28,20 @@ int o_check_lbc(const roms_bounds_t *b, const roms_params_t *p)
 
 /* exchange_{r,u,v,p}2d_tile -- ROMS/Nonlinear/exchange_2d.F:43/229/416/603.
  * Periodic ghost copy, only when the direction is not partitioned. */
+/* Multi-tile runs (CPU tests of the N>1 protocol): the test harness installs a
+ * hook that performs mp_exchange2d/3d (mp_exchange.F:290/1413) between ranks. */
+static o_exchange_hook_t g_hook = 0;
+void oracle_set_exchange_hook(o_exchange_hook_t fn) { g_hook = fn; }
+
+static void o_periodic2d(const roms_bounds_t *b, int gtype, double *A);
+
 void o_exchange2d(const roms_bounds_t *b, int gtype, double *A)
+{
+  o_periodic2d(b, gtype, A);
+  if (g_hook && b->ntileI * b->ntileJ > 1) g_hook(A, 1, gtype);
+}
+
+static void o_periodic2d(const roms_bounds_t *b, int gtype, double *A)
 {
   const int Lm = b->Lm, LBi = b->LBi, LBj = b->LBj;
   const long ni = b->UBi - b->LBi + 1;
@@ -62,7 +75,8 @@ void o_exchange2d(const roms_bounds_t *b, int gtype, double *A)
 void o_exchange3d(const roms_bounds_t *b, int gtype, int nk, double *A)
 {
   const long nij = (long)(b->UBi - b->LBi + 1) * (b->UBj - b->LBj + 1);
-  for (int k = 0; k < nk; k++) o_exchange2d(b, gtype, A + (long)k * nij);
+  for (int k = 0; k < nk; k++) o_periodic2d(b, gtype, A + (long)k * nij);
+  if (g_hook && b->ntileI * b->ntileJ > 1) g_hook(A, nk, gtype);
 }
 
 /* zetabc_tile, closed S/N walls -- ROMS/Nonlinear/zetabc.F:48 */

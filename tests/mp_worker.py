@@ -1,0 +1,51 @@
+"""Worker for the multi-process CPU tests: each rank runs the CPU oracle on one
+tile and swaps halos through the Python mirror of mp_exchange over gloo."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0):
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from roms_trunk_mgh_amd import ana, halo, main3d
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb)
+    b = st.b
+    ni, nj = st.ni, st.nj
+    sr = halo.gloo_sendrecv(dist, torch)
+
+    HOOK = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+    def hook(ptr, nk, gtype):
+        A = np.ctypeslib.as_array(ptr, shape=(nk * nj * ni,)).reshape((ni, nj, nk), order="F")
+        halo.exchange(A, b, rank, sr)
+
+    cb = HOOK(hook)
+    lib = oracle.lib()
+    lib.oracle_set_exchange_hook.argtypes = [HOOK]
+    lib.oracle_set_exchange_hook(cb)
+    m = main3d.Main3D(oracle.Oracle(st))
+    m.initial()
+    m.run(nsteps)
+    lib.oracle_set_exchange_hook(HOOK(0))
+    np.savez(os.path.join(outdir, f"tile{rank}.npz"),
+             bounds=np.array([b.Istr, b.Iend, b.Jstr, b.Jend, b.LBi, b.LBj]),
+             **{k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz")})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    a = sys.argv
+    run_rank(int(a[1]), int(a[2]), int(a[3]), int(a[4]), a[5], int(a[6]), int(a[7]), a[8])

@@ -1,0 +1,56 @@
+"""CPU: tile bounds (mirror of get_bounds.F) -- hand-derived expectations from
+get_bounds.F:1348-1853 and structural properties for several tilings."""
+import pytest
+
+from roms_trunk_mgh_amd.bounds import make_bounds, tile_bounds_2d
+
+
+def test_single_tile_periodic_ew_closed_ns():
+    b = make_bounds(512, 64, 30, 2, 2)
+    assert (b.LBi, b.UBi, b.LBj, b.UBj) == (-2, 514, 0, 65)           # -2:514 x 0:65
+    assert (b.Istr, b.Iend, b.Jstr, b.Jend) == (1, 512, 1, 64)
+    # periodic in i: no special u-range; closed in j: JstrV = Jstr+1
+    assert (b.IstrU, b.IstrR, b.IendR, b.IstrT, b.IendT) == (1, 1, 512, 1, 512)
+    assert (b.JstrV, b.JstrR, b.JendR, b.JstrT, b.JendT) == (2, 0, 65, 0, 65)
+    assert (b.Istrm1, b.Istrm2, b.IstrUm1, b.Iendp1, b.Iendp2, b.Iendp2i) == (0, -1, 0, 513, 514, 514)
+    assert (b.Jstrm1, b.Jstrm2, b.JstrVm1, b.JstrVm2, b.Jendp1, b.Jendp2, b.Jendp2i) == (1, 0, 2, 1, 64, 65, 64)
+    assert (b.west_edge, b.east_edge, b.south_edge, b.north_edge) == (1, 1, 1, 1)
+
+
+def test_three_ghost_points():
+    b = make_bounds(64, 32, 10, 6, 2, NghostPoints=3)
+    assert (b.LBi, b.UBi, b.LBj, b.UBj) == (-3, 67, 0, 33)
+
+
+@pytest.mark.parametrize("nI,nJ", [(2, 1), (4, 1), (4, 2), (2, 2), (3, 2)])
+def test_tiles_partition_the_domain(nI, nJ):
+    Lm, Mm = 2048, 256
+    seen = set()
+    for t in range(nI * nJ):
+        b = make_bounds(Lm, Mm, 30, 2, 2, nI, nJ, t)
+        for i in (b.Istr, b.Iend):
+            for j in (b.Jstr, b.Jend):
+                assert 1 <= i <= Lm and 1 <= j <= Mm
+        cells = {(b.Istr, b.Iend, b.Jstr, b.Jend)}
+        assert not (cells & seen)
+        seen |= cells
+        # allocated extents = tile + ghost points (get_bounds.F:164-183), physical edge otherwise
+        assert b.LBi == (-2 if b.Itile == 0 else b.Istr - 2)
+        assert b.UBi == (Lm + 2 if b.Itile == nI - 1 else b.Iend + 2)
+        assert b.LBj == (0 if b.Jtile == 0 else b.Jstr - 2)
+        assert b.UBj == (Mm + 1 if b.Jtile == nJ - 1 else b.Jend + 2)
+        # interior tile edges never shift the U/V/R ranges
+        if b.Jtile > 0:
+            assert b.JstrV == b.Jstr and b.JstrR == b.Jstr
+        if b.Jtile < nJ - 1:
+            assert b.JendR == b.Jend and b.Jendp2 == b.Jend + 2
+    area = sum((e1 - s1 + 1) * (e2 - s2 + 1) for (s1, e1, s2, e2) in seen)
+    assert area == Lm * Mm
+
+
+def test_tile_bounds_2d_margin_centred():
+    # ChunkSize = ceil(Lm/NtileI), margins split evenly (get_bounds.F:985-1004)
+    assert tile_bounds_2d(10, 10, 3, 1, 0)[2:4] == (1, 3)
+    assert tile_bounds_2d(10, 10, 3, 1, 1)[2:4] == (4, 7)
+    assert tile_bounds_2d(10, 10, 3, 1, 2)[2:4] == (8, 10)
+    assert tile_bounds_2d(2048, 256, 4, 2, 5) == (1, 1, 513, 1024, 129, 256)

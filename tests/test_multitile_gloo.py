@@ -1,0 +1,62 @@
+"""CPU, multi-process: the N>1 path.  The oracle runs one tile per process
+(world_size 2 and 4, gloo) with the halo-exchange protocol of mp_exchange.F
+restated in roms_trunk_mgh_amd/halo.py; after 3 full steps every tile's owned
+points AND ghost points must equal the single-tile run bit for bit -- the
+reference's own acceptance rule ("identical results across tilings")."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from roms_trunk_mgh_amd import ana, main3d
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _single(config, nsteps):
+    import oracle
+    st = ana.make_tile(config, perturb=1.0)
+    m = main3d.Main3D(oracle.Oracle(st))
+    m.initial()
+    m.run(nsteps)
+    return st
+
+
+@pytest.mark.parametrize("ntI,ntJ,config", [(2, 1, "UPWELLING"), (1, 2, "UPWELLING"), (2, 2, "SEAMOUNT"),
+                                            (2, 1, "BENCHMARK_TINY")])
+def test_tiled_equals_single(tmp_path, ntI, ntJ, config):
+    nsteps = 3
+    world = ntI * ntJ
+    port = _free_port()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker.py"), str(r), str(world), str(ntI),
+                               str(ntJ), config, str(nsteps), str(port), str(tmp_path)], env=env)
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    ref = _single(config, nsteps)
+    rb = ref.b
+    for r in range(world):
+        d = np.load(os.path.join(tmp_path, f"tile{r}.npz"))
+        Istr, Iend, Jstr, Jend, LBi, LBj = [int(x) for x in d["bounds"]]
+        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz"):
+            a = d[name]
+            ni, nj = a.shape[0], a.shape[1]
+            # whole allocated tile (owned + ghost points) against the same index range of the single-tile run
+            i0, j0 = LBi - rb.LBi, LBj - rb.LBj
+            want = ref[name][i0:i0 + ni, j0:j0 + nj]
+            own = (slice(Istr - LBi, Iend - LBi + 1), slice(Jstr - LBj, Jend - LBj + 1))
+            assert np.array_equal(a[own], want[own]), (name, r, float(np.abs(a[own] - want[own]).max()))
+            if name in ("zeta", "t", "Hz", "W"):      # rho-type: every ghost point is defined
+                assert np.array_equal(a, want), (name, r, "ghost points differ")

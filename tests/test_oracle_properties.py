@@ -1,0 +1,131 @@
+"""CPU: pin the oracle with what the domain guarantees, since the reference's
+step2d / pre_step3d / rhs3d / step3d_uv / step3d_t / omega cannot be compiled
+here (mod_sources -> netCDF).  These are size-independent properties of the
+ROMS discretisation that only hold if the kernels AND their coupling are right:
+
+  * constancy preservation: a uniform tracer stays uniform through the whole
+    split-explicit step (requires omega, set_depth, the fast-time averaged
+    fluxes DU_avg2, the step3d_uv mass-flux correction and both tracer
+    advection stages to be mutually consistent);
+  * volume conservation of the barotropic loop;
+  * tracer-content conservation with closed/periodic boundaries;
+  * the spline-form implicit operator against a dense solve;
+  * SEAMOUNT rest state: velocities are pure pressure-gradient error, small.
+"""
+import numpy as np
+import pytest
+
+import util
+from roms_trunk_mgh_amd import ana, main3d
+
+
+def _run(config, nsteps, prep=None, perturb=1.0, overrides=None, NT=None):
+    import oracle
+    st = ana.make_tile(config, perturb=perturb, overrides=overrides, NT=NT)
+    if prep:
+        prep(st)
+    m = main3d.Main3D(oracle.Oracle(st))
+    m.initial()
+    m.run(nsteps)
+    return st, m
+
+
+@pytest.mark.parametrize("config", ["UPWELLING", "BENCHMARK_TINY"])
+def test_constancy_preservation(config):
+    def prep(st):
+        st["t"][:, :, :, :, 1] = 35.0          # salinity uniform
+        st["stflx"][:, :, 1] = 0.0
+        st["btflx"][:, :, 1] = 0.0
+        st["ghats"][:, :, :, 1] = 0.0
+    st, m = _run(config, 25, prep)
+    S = st.interior("t")[:, :, :, m.s.nnew - 1, 1]
+    assert float(np.abs(st["u"]).max()) > 1e-3      # the flow is not trivial
+    assert float(np.abs(S - 35.0).max()) < 5e-11, float(np.abs(S - 35.0).max())
+
+
+@pytest.mark.parametrize("config", ["UPWELLING", "BENCHMARK_TINY"])
+def test_volume_and_tracer_conservation(config):
+    import oracle
+    st = ana.make_tile(config, perturb=1.0)
+    st["stflx"][:] = 0.0
+    st["srflx"][:] = 0.0
+    st["ghats"][:] = 0.0
+    st["diff2"][:] = 0.0               # rotated mixing is not flux-form at the walls
+    m = main3d.Main3D(oracle.Oracle(st))
+    m.initial()
+    area = st.interior("omn")
+    vol0 = float(np.sum(area * st.interior("zeta")[:, :, 0]))
+
+    def content():
+        k = m.s.nnew - 1 if m.iic > 1 else 0
+        return float(np.sum(area[:, :, None] * st.interior("Hz") * st.interior("t")[:, :, :, k, 0]))
+    m.step()
+    c0 = content()
+    m.run(15)
+    vol1 = float(np.sum(area * st.interior("zeta")[:, :, m.indx1 - 1]))
+    c1 = content()
+    tot = float(np.sum(area * st.interior("h")))
+    assert abs(vol1 - vol0) / tot < 1e-13
+    assert abs(c1 - c0) / abs(c0) < 1e-12, (c0, c1)
+
+
+def test_spline_implicit_operator_against_dense_solve():
+    """step3d_t.F:1370-1455: (I - dt d/dz Akt d/dz) in spline form, one column."""
+    import oracle
+    st = util.prepared_state("UPWELLING")
+    util.hz_weighted_tnew(st)
+    b, p = st.b, st.p
+    st["Huon"][:] = 0.0
+    st["Hvom"][:] = 0.0
+    st["W"][:] = 0.0
+    s = util.step_idx()
+    tin = (st["t"][:, :, :, s.nnew - 1, 0] / st["Hz"]).copy()
+    oracle.Oracle(st).call("step3d_t", s)
+    i, j = st.I(7), st.J(11)
+    N, dt = b.N, p.dt
+    Hz = st["Hz"][i, j, :]
+    Ak = st["Akt"][i, j, :, 0]
+    # unknown DC(k), k=1..N-1: FC DC(k-1) + BC DC(k) + CF DC(k+1) = t(k+1)-t(k)
+    A = np.zeros((N - 1, N - 1))
+    rhs = np.zeros(N - 1)
+    for k in range(1, N):
+        FC = Hz[k - 1] / 6.0 - dt * Ak[k - 1] / Hz[k - 1]
+        CF = Hz[k] / 6.0 - dt * Ak[k + 1] / Hz[k]
+        BC = (Hz[k - 1] + Hz[k]) / 3.0 + dt * Ak[k] * (1.0 / Hz[k - 1] + 1.0 / Hz[k])
+        A[k - 1, k - 1] = BC
+        if k > 1:
+            A[k - 1, k - 2] = FC
+        if k < N - 1:
+            A[k - 1, k] = CF
+        rhs[k - 1] = tin[i, j, k] - tin[i, j, k - 1]
+    DC = np.concatenate(([0.0], np.linalg.solve(A, rhs), [0.0])) * Ak
+    want = tin[i, j, :] + dt / Hz * (DC[1:] - DC[:-1])
+    got = st["t"][i, j, :, s.nnew - 1, 0]
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-13)
+
+
+def test_seamount_stays_near_rest():
+    st, m = _run("SEAMOUNT", 30, perturb=0.0)
+    # the exact solution is rest; what moves is pressure-gradient error of the
+    # density-Jacobian scheme on this steep (rx0 ~ 0.3) seamount: O(mm/s) after 30 min
+    assert float(np.abs(st["u"]).max()) < 5e-3
+    assert float(np.abs(st["zeta"]).max()) < 5e-3
+    assert np.isfinite(st["t"]).all()
+
+
+def test_u3_flux_form_is_third_order_for_smooth_fields():
+    """horizontal U3 flux divergence of a smooth tracer in uniform flow converges
+    with order ~3-4 under grid refinement (step3d_t.F:596-700)."""
+    errs = []
+    for Lm in (32, 64):
+        x = (np.arange(-2, Lm + 3) - 0.5) / Lm
+        t = np.sin(2 * np.pi * x)
+        d = t[1:] - t[:-1]                       # FX(i) = t(i)-t(i-1), i index 1..
+        curv = d[1:] - d[:-1]                    # curv(i) = FX(i+1)-FX(i)
+        # flux at face i for Huon>0: 0.5(t(i-1)+t(i)) - 1/6 curv(i-1)
+        F = 0.5 * (t[1:-2] + t[2:-1]) - curv[:-1] / 6.0
+        div = (F[1:] - F[:-1]) * Lm
+        xc = x[2:-2]
+        errs.append(np.abs(div - 2 * np.pi * np.cos(2 * np.pi * xc)).max())
+    order = np.log2(errs[0] / errs[1])
+    assert order > 2.7, (errs, order)
