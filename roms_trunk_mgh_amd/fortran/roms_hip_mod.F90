@@ -1,0 +1,185 @@
+!=======================================================================
+!  roms_hip_mod -- thin ISO_C_BINDING layer between the unchanged ROMS
+!  Fortran driver (ROMS/Nonlinear/main3d.F) and libroms_hip.so.
+!
+!  The reference's seam is the module-procedure name: main3d does
+!  `USE step3d_t_mod, ONLY : step3d_t` and `CALL step3d_t (ng, tile)`
+!  (main3d.F:94-124, :814).  A maintainer keeps main3d.F as it is and
+!  replaces the BODY of each wrapper `X(ng,tile)` by a call into this
+!  module (see INTEGRATION.md for the per-file edits), e.g.
+!
+!      SUBROUTINE step3d_t (ng, tile)          ! step3d_t.F:40
+!        USE roms_hip_mod
+!        integer, intent(in) :: ng, tile
+!        CALL roms_hip_call (roms_hip_step3d_t, ng, 35, __LINE__, MyFile)
+!      END SUBROUTINE step3d_t
+!
+!  Everything here is interface + glue: no arithmetic of the hot path is
+!  done on the host.
+!=======================================================================
+MODULE roms_hip_mod
+  USE, INTRINSIC :: iso_c_binding
+  IMPLICIT NONE
+  PRIVATE
+
+  !  mirrors `roms_step_idx_t` of include/roms_hip.h
+  TYPE, BIND(C), PUBLIC :: roms_step_idx_t
+    INTEGER(c_int) :: iic, ntfirst
+    INTEGER(c_int) :: nstp, nnew, nrhs
+    INTEGER(c_int) :: kstp, krhs, knew
+    INTEGER(c_int) :: iif, predictor_2d_step
+  END TYPE roms_step_idx_t
+
+  !  field identifiers = enum roms_field_id (order of include/roms_fields.def)
+  INTEGER(c_int), PARAMETER, PUBLIC :: FID_zeta=0, FID_ubar=1, FID_vbar=2, FID_rzeta=3,    &
+ &    FID_rubar=4, FID_rvbar=5, FID_u=6, FID_v=7, FID_t=8, FID_ru=9, FID_rv=10, FID_W=11,   &
+ &    FID_rho=12, FID_pden=13, FID_h=14, FID_f=15, FID_fomn=16, FID_pm=17, FID_pn=18,       &
+ &    FID_om_r=19, FID_on_r=20, FID_om_u=21, FID_on_u=22, FID_om_v=23, FID_on_v=24,         &
+ &    FID_om_p=25, FID_on_p=26, FID_omn=27, FID_pmon_r=28, FID_pnom_r=29, FID_pmon_p=30,    &
+ &    FID_pnom_p=31, FID_pmon_u=32, FID_pnom_u=33, FID_pmon_v=34, FID_pnom_v=35,            &
+ &    FID_dmde=36, FID_dndx=37, FID_Hz=38, FID_Huon=39, FID_Hvom=40, FID_z_r=41,            &
+ &    FID_z_w=42, FID_DU_avg1=43, FID_DU_avg2=44, FID_DV_avg1=45, FID_DV_avg2=46,           &
+ &    FID_Zt_avg1=47, FID_rufrc=48, FID_rvfrc=49, FID_rhoA=50, FID_rhoS=51, FID_Akv=52,     &
+ &    FID_Akt=53, FID_ghats=54, FID_bvf=55, FID_alpha=56, FID_beta=57, FID_visc2_p=58,      &
+ &    FID_visc2_r=59, FID_diff2=60, FID_sustr=61, FID_svstr=62, FID_bustr=63,               &
+ &    FID_bvstr=64, FID_srflx=65, FID_stflx=66, FID_btflx=67
+
+  INTERFACE
+    INTEGER(c_int) FUNCTION roms_hip_init (rank, ntileI, ntileJ, device_id, uid)            &
+ &                 BIND(C, name='roms_hip_init')
+      IMPORT :: c_int, c_ptr
+      INTEGER(c_int), VALUE :: rank, ntileI, ntileJ, device_id
+      TYPE(c_ptr), VALUE :: uid
+    END FUNCTION roms_hip_init
+    INTEGER(c_int) FUNCTION roms_hip_finalize () BIND(C, name='roms_hip_finalize')
+      IMPORT :: c_int
+    END FUNCTION roms_hip_finalize
+    INTEGER(c_int) FUNCTION roms_hip_get_unique_id (out128) BIND(C, name='roms_hip_get_unique_id')
+      IMPORT :: c_int, c_ptr
+      TYPE(c_ptr), VALUE :: out128
+    END FUNCTION roms_hip_get_unique_id
+    INTEGER(c_int) FUNCTION roms_hip_set_bounds (b) BIND(C, name='roms_hip_set_bounds')
+      IMPORT :: c_int, c_ptr
+      TYPE(c_ptr), VALUE :: b          ! c_loc of a roms_bounds_t image (see roms_hip_bounds)
+    END FUNCTION roms_hip_set_bounds
+    INTEGER(c_int) FUNCTION roms_hip_set_params (p) BIND(C, name='roms_hip_set_params')
+      IMPORT :: c_int, c_ptr
+      TYPE(c_ptr), VALUE :: p
+    END FUNCTION roms_hip_set_params
+    INTEGER(c_int) FUNCTION roms_hip_register_field (id, host_ptr, n) BIND(C, name='roms_hip_register_field')
+      IMPORT :: c_int, c_ptr, c_long
+      INTEGER(c_int), VALUE :: id
+      TYPE(c_ptr), VALUE :: host_ptr   ! c_loc(OCEAN(ng)%t(LBi,LBj,1,1,1)) etc.
+      INTEGER(c_long), VALUE :: n
+    END FUNCTION roms_hip_register_field
+    INTEGER(c_int) FUNCTION roms_hip_sync_to_device (id) BIND(C, name='roms_hip_sync_to_device')
+      IMPORT :: c_int
+      INTEGER(c_int), VALUE :: id
+    END FUNCTION roms_hip_sync_to_device
+    INTEGER(c_int) FUNCTION roms_hip_sync_to_host (id) BIND(C, name='roms_hip_sync_to_host')
+      IMPORT :: c_int
+      INTEGER(c_int), VALUE :: id
+    END FUNCTION roms_hip_sync_to_host
+    INTEGER(c_int) FUNCTION roms_hip_sync_all_to_device () BIND(C, name='roms_hip_sync_all_to_device')
+      IMPORT :: c_int
+    END FUNCTION roms_hip_sync_all_to_device
+    INTEGER(c_int) FUNCTION roms_hip_sync_all_to_host () BIND(C, name='roms_hip_sync_all_to_host')
+      IMPORT :: c_int
+    END FUNCTION roms_hip_sync_all_to_host
+    FUNCTION roms_hip_last_error () BIND(C, name='roms_hip_last_error') RESULT(msg)
+      IMPORT :: c_ptr
+      TYPE(c_ptr) :: msg
+    END FUNCTION roms_hip_last_error
+    INTEGER(c_int) FUNCTION roms_hip_step2d_loop (s, indx1) BIND(C, name='roms_hip_step2d_loop')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(inout) :: s
+      INTEGER(c_int), INTENT(inout) :: indx1
+    END FUNCTION roms_hip_step2d_loop
+  END INTERFACE
+
+  !  one interface per kernel entry, all `int f(const roms_step_idx_t*)`
+  ABSTRACT INTERFACE
+    INTEGER(c_int) FUNCTION roms_hip_entry (s) BIND(C)
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION roms_hip_entry
+  END INTERFACE
+  INTERFACE
+    INTEGER(c_int) FUNCTION roms_hip_set_massflux (s) BIND(C, name='roms_hip_set_massflux')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_rho_eos (s) BIND(C, name='roms_hip_rho_eos')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_omega (s) BIND(C, name='roms_hip_omega')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_set_zeta (s) BIND(C, name='roms_hip_set_zeta')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_set_depth (s) BIND(C, name='roms_hip_set_depth')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_rhs3d (s) BIND(C, name='roms_hip_rhs3d')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_step2d (s) BIND(C, name='roms_hip_step2d')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_step3d_uv (s) BIND(C, name='roms_hip_step3d_uv')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_step3d_t (s) BIND(C, name='roms_hip_step3d_t')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+  END INTERFACE
+
+  PUBLIC :: roms_hip_init, roms_hip_finalize, roms_hip_get_unique_id
+  PUBLIC :: roms_hip_set_bounds, roms_hip_set_params, roms_hip_register_field
+  PUBLIC :: roms_hip_sync_to_device, roms_hip_sync_to_host
+  PUBLIC :: roms_hip_sync_all_to_device, roms_hip_sync_all_to_host, roms_hip_last_error
+  PUBLIC :: roms_hip_set_massflux, roms_hip_rho_eos, roms_hip_omega, roms_hip_set_zeta
+  PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
+  PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t
+  PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
+
+CONTAINS
+
+  !  Fill the index block from mod_stepping / mod_scalars values
+  !  (main3d.F:189-191 and :597-662 keep them current).
+  FUNCTION roms_hip_make_idx (iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor) RESULT(s)
+    INTEGER, INTENT(in) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif
+    LOGICAL, INTENT(in) :: predictor
+    TYPE(roms_step_idx_t) :: s
+    s%iic = iic;   s%ntfirst = ntfirst
+    s%nstp = nstp; s%nnew = nnew; s%nrhs = nrhs
+    s%kstp = kstp; s%krhs = krhs; s%knew = knew
+    s%iif = iif
+    s%predictor_2d_step = MERGE(1_c_int, 0_c_int, predictor)
+  END FUNCTION roms_hip_make_idx
+
+  !  Map the library's return code onto ROMS' exit_flag convention
+  !  (mod_scalars.F:523-532): 0 = NoError, 2 = communication (as
+  !  mp_exchange.F:551), 8 = fatal algorithm result.  The caller then tests
+  !  FoundError(exit_flag, NoError, __LINE__, MyFile) as main3d.F:178 does.
+  SUBROUTINE roms_hip_status (rc, exit_flag)
+    INTEGER(c_int), INTENT(in) :: rc
+    INTEGER, INTENT(inout) :: exit_flag
+    IF (rc == 0) RETURN
+    IF (rc == 2) THEN
+      exit_flag = 2
+    ELSE
+      exit_flag = 8
+    END IF
+  END SUBROUTINE roms_hip_status
+
+END MODULE roms_hip_mod
