@@ -101,6 +101,10 @@ extern "C" int roms_hip_init(int rank, int ntileI, int ntileJ, int device_id, co
   g_ctx.ntileJ = ntileJ;
   g_ctx.device = device_id;
   g_ctx.have_nccl_id = false;
+  {
+    const char *e = getenv("ROMS_HIP_NO_FUSED2D");
+    g_ctx.no_fused_2d = e && e[0] == '1';
+  }
   if (nccl_unique_id) {
     memcpy(g_ctx.nccl_id, nccl_unique_id, 128);
     g_ctx.have_nccl_id = true;

@@ -25,28 +25,44 @@ namespace {
 
 struct S2 {
   int krhs, kstp, knew, nstp, nnew, iif, iic, ntfirst, predictor;
+  int sm;   // 1 = single tile, E-W periodic: kernels cover the whole allocated tile and every
+            // ghost point is computed from its SOURCE point (periodic image in i, wall mirror in
+            // j), which reproduces "compute interior, apply zetabc/u2dbc/v2dbc, periodic copy"
+            // bit for bit without the extra launches of exchange_*2d_tile and the 2-D BCs.
 };
+
+__device__ __forceinline__ int wrap_i(const roms_bounds_t &b, int i)
+{
+  return (i < 1) ? i + b.Lm : ((i > b.Lm) ? i - b.Lm : i);
+}
+
+__device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const S2 &s,
+                                           const double *__restrict__ DUon, const double *__restrict__ DVom,
+                                           double *__restrict__ zeta_new, double *__restrict__ zwrk, long a, long o,
+                                           bool write_scratch, bool write_zeta, bool write_rzeta, long nij, long ni);
 
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k2d_flux(const RomsDev *__restrict__ c, S2 s, double *__restrict__ DUon, double *__restrict__ DVom)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrU - 2 + blockIdx.x * BLK_X + threadIdx.x;
+  const int i0 = s.sm ? b.LBi : b.IstrU - 2, i1 = s.sm ? b.UBi : b.Iendp2;
+  const int i = i0 + blockIdx.x * BLK_X + threadIdx.x;
   const int j = b.JstrV - 2 + blockIdx.y * BLK_Y + threadIdx.y;
-  if (i > b.Iendp2 || j > b.Jendp2) return;
+  if (i > i1 || j > b.Jendp2) return;
+  const int is = s.sm ? wrap_i(b, i) : i;
   const double *__restrict__ zeta = c->F.zeta + (long)(s.krhs - 1) * nij;
   const double *__restrict__ h = c->F.h;
-  const long a = I2(i, j);
+  const long a = I2(is, j), o = I2(i, j);
   const double Drhs = zeta[a] + h[a];
-  if (i >= b.IstrU - 1) {
+  if (s.sm || i >= b.IstrU - 1) {
     const double cff = 0.5 * c->F.on_u[a];
     const double cff1 = cff * (Drhs + (zeta[a - 1] + h[a - 1]));
-    DUon[a] = c->F.ubar[a + (long)(s.krhs - 1) * nij] * cff1;
+    DUon[o] = c->F.ubar[a + (long)(s.krhs - 1) * nij] * cff1;
   }
   if (j >= b.JstrV - 1) {
     const double cff = 0.5 * c->F.om_v[a];
     const double cff1 = cff * (Drhs + (zeta[a - ni] + h[a - ni]));
-    DVom[a] = c->F.vbar[a + (long)(s.krhs - 1) * nij] * cff1;
+    DVom[o] = c->F.vbar[a + (long)(s.krhs - 1) * nij] * cff1;
   }
 }
 
@@ -97,6 +113,76 @@ k2d_zeta(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, c
   if (iif > nfast) return;
   // ---- free surface, :770-868 ----
   if (i < b.IstrU - 1 || i > b.Iend || j < b.JstrV - 1 || j > b.Jend) return;
+  const bool own = i >= b.Istr && j >= b.Jstr;
+  zeta_point(c, s, DUon, DVom, zeta_new, zwrk, a, a, true, own, own, nij, ni);
+}
+
+// Source-mapped variant (single tile, E-W periodic, closed N-S walls): one
+// thread per ALLOCATED point.  Thread (i,j) evaluates the free-surface step at
+// its source point (periodic image in i; wall row -> adjacent interior row =
+// the zero-gradient zetabc) and stores at (i,j): zeta(knew), rzeta(krhs),
+// zeta_new and zwrk come out with their ghost points already filled.
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k2d_zeta_sm(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, const double *__restrict__ DVom,
+            double *__restrict__ zeta_new, double *__restrict__ zwrk)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.LBi + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.LBj + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.UBi || j > b.UBj) return;
+  const roms_params_t &p = c->p;
+  const int iif = s.iif, nfast = p.nfast;
+  const long o = I2(i, j);
+  // ---- fast-time averaging on the owned ranges only, :614-682 ----
+  if (i >= b.IstrR && i <= b.IendR && j >= b.JstrR && j <= b.JendR) {
+    const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
+    const bool inU = i >= b.Istr, inV = j >= b.Jstr;
+    if (s.predictor) {
+      if (iif == 1) {
+        const double cff2 = (-1.0 / 12.0) * p.weight2[iif];
+        c->F.Zt_avg1[o] = 0.0;
+        if (inU) { c->F.DU_avg1[o] = 0.0; c->F.DU_avg2[o] = cff2 * DUon[o]; }
+        if (inV) { c->F.DV_avg1[o] = 0.0; c->F.DV_avg2[o] = cff2 * DVom[o]; }
+      } else {
+        const double cff1 = p.weight1[iif - 2];
+        const double cff2 = (8.0 / 12.0) * p.weight2[iif - 1] - (1.0 / 12.0) * p.weight2[iif];
+        c->F.Zt_avg1[o] = c->F.Zt_avg1[o] + cff1 * zk[o];
+        if (inU) {
+          c->F.DU_avg1[o] = c->F.DU_avg1[o] + cff1 * DUon[o];
+          c->F.DU_avg2[o] = c->F.DU_avg2[o] + cff2 * DUon[o];
+        }
+        if (inV) {
+          c->F.DV_avg1[o] = c->F.DV_avg1[o] + cff1 * DVom[o];
+          c->F.DV_avg2[o] = c->F.DV_avg2[o] + cff2 * DVom[o];
+        }
+      }
+    } else {
+      const double cff2 = (iif == 1) ? p.weight2[iif - 1] : (5.0 / 12.0) * p.weight2[iif - 1];
+      if (inU) c->F.DU_avg2[o] = c->F.DU_avg2[o] + cff2 * DUon[o];
+      if (inV) c->F.DV_avg2[o] = c->F.DV_avg2[o] + cff2 * DVom[o];
+    }
+  }
+  if (iif > nfast) return;
+  // ---- free surface at the source point ----
+  const int is = wrap_i(b, i);
+  int js = j;
+  if (b.south_edge && j == b.Jstr - 1) js = b.Jstr;       // zetabc closed: zero gradient
+  if (b.north_edge && j == b.Jend + 1) js = b.Jend;
+  if (js < b.Jstr || js > b.Jend) return;
+  const long a = I2(is, js);
+  const bool own_row = (js == j);
+  zeta_point(c, s, DUon, DVom, zeta_new, zwrk, a, o, own_row, true, own_row, nij, ni);
+}
+
+// One free-surface point: evaluate at index a, store at index o.
+__device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const S2 &s,
+                                           const double *__restrict__ DUon, const double *__restrict__ DVom,
+                                           double *__restrict__ zeta_new, double *__restrict__ zwrk, long a, long o,
+                                           bool write_scratch, bool write_zeta, bool write_rzeta, long nij, long ni)
+{
+  const roms_params_t &p = c->p;
+  const int iif = s.iif;
+  const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
   const double dtfast = p.dtfast;
   const double *__restrict__ zs = c->F.zeta + (long)(s.kstp - 1) * nij;
   const double pmn_a = c->F.pm[a], pn_a = c->F.pn[a];
@@ -124,12 +210,9 @@ k2d_zeta(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, c
                                  cff3 * c->F.rzeta[a + (long)(ptsk - 1) * nij]);
     zw = cff5 * zn + cff4 * zk[a];
   }
-  zeta_new[a] = zn;
-  zwrk[a] = zw;
-  if (i >= b.Istr && j >= b.Jstr) {
-    c->F.zeta[a + (long)(s.knew - 1) * nij] = zn;
-    if (s.predictor) c->F.rzeta[a + (long)(s.krhs - 1) * nij] = rhs;
-  }
+  if (write_scratch) { zeta_new[o] = zn; zwrk[o] = zw; }
+  if (write_zeta) c->F.zeta[o + (long)(s.knew - 1) * nij] = zn;
+  if (write_rzeta && s.predictor) c->F.rzeta[o + (long)(s.krhs - 1) * nij] = rhs;
 }
 
 // ---------------------------------------------------------------- momentum --
@@ -187,12 +270,35 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
         const double *__restrict__ zeta_new, const double *__restrict__ zwrk)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
-  if (i > b.Iend || j > b.Jend) return;
   const roms_params_t &p = c->p;
-  const bool do_u = i >= b.IstrU, do_v = j >= b.JstrV;
+  // (it,jt) = target point this thread stores to; (i,j) = source point it evaluates.
+  // Without source mapping they coincide and the range is the tile interior.
+  int it, jt, i, j;
+  double fu = 1.0;                 // u2dbc closed-wall factor gamma2 on ghost rows
+  bool do_u, do_v, owner = true, v_wall = false;
+  if (!s.sm) {
+    it = i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+    jt = j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+    if (i > b.Iend || j > b.Jend) return;
+    do_u = i >= b.IstrU;
+    do_v = j >= b.JstrV;
+  } else {
+    it = b.LBi + blockIdx.x * BLK_X + threadIdx.x;
+    jt = b.LBj + blockIdx.y * BLK_Y + threadIdx.y;
+    if (it > b.UBi || jt > b.UBj) return;
+    i = wrap_i(b, it);
+    j = jt;
+    if (b.south_edge && jt == b.Jstr - 1) { j = b.Jstr; fu = p.gamma2; }
+    if (b.north_edge && jt == b.Jend + 1) { j = b.Jend; fu = p.gamma2; }
+    if (j < b.Jstr || j > b.Jend) return;
+    owner = (it == i) && (jt == j);
+    do_u = true;
+    do_v = (jt == j) && j >= b.JstrV;
+    // v2dbc closed: vbar = 0 on the wall rows Jstr (south) and Jend+1 (north)
+    v_wall = (b.south_edge && jt == b.Jstr) || (b.north_edge && jt == b.Jend + 1);
+  }
   const long a = I2(i, j);
+  const long o = I2(it, jt);
   const double *__restrict__ h = c->F.h;
   const double *__restrict__ rhoA = c->F.rhoA;
   const double *__restrict__ rhoS = c->F.rhoS;
@@ -326,16 +432,16 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
       if (s.iic == s.ntfirst) rhs_u = rhs_u + rf;
       else if (s.iic == s.ntfirst + 1) rhs_u = rhs_u + 1.5 * rf - 0.5 * ru_n[a];
       else rhs_u = rhs_u + (23.0 / 12.0) * rf - (16.0 / 12.0) * ru_n[a] + (5.0 / 12.0) * ru_s[a];
-      c->F.rufrc[a] = rf;
-      ru_s[a] = rf;
+      if (owner) c->F.rufrc[a] = rf;
+      if (owner) ru_s[a] = rf;
     }
     if (do_v) {
       const double rf = c->F.rvfrc[a] - rhs_v;
       if (s.iic == s.ntfirst) rhs_v = rhs_v + rf;
       else if (s.iic == s.ntfirst + 1) rhs_v = rhs_v + 1.5 * rf - 0.5 * rv_n[a];
       else rhs_v = rhs_v + (23.0 / 12.0) * rf - (16.0 / 12.0) * rv_n[a] + (5.0 / 12.0) * rv_s[a];
-      c->F.rvfrc[a] = rf;
-      rv_s[a] = rf;
+      if (owner) c->F.rvfrc[a] = rf;
+      if (owner) rv_s[a] = rf;
     }
   } else {
     if (do_u) rhs_u = rhs_u + c->F.rufrc[a];
@@ -358,8 +464,8 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
     else un = (us * (Dst0 + (zs[q] + h[q])) +
                cff * (a1 * rhs_u + a2 * c->F.rubar[a + (long)(s.kstp - 1) * nij] -
                       a3 * c->F.rubar[a + (long)(ptsk - 1) * nij])) * fc;
-    c->F.ubar[a + (long)(s.knew - 1) * nij] = un;
-    if (s.predictor) c->F.rubar[a + (long)(s.krhs - 1) * nij] = rhs_u;
+    c->F.ubar[o + (long)(s.knew - 1) * nij] = (fu == 1.0) ? un : fu * un;
+    if (s.predictor && owner) c->F.rubar[a + (long)(s.krhs - 1) * nij] = rhs_u;
   }
   if (do_v) {
     const long q = a - ni;
@@ -371,9 +477,10 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
     else vn = (vs * (Dst0 + (zs[q] + h[q])) +
                cff * (a1 * rhs_v + a2 * c->F.rvbar[a + (long)(s.kstp - 1) * nij] -
                       a3 * c->F.rvbar[a + (long)(ptsk - 1) * nij])) * fc;
-    c->F.vbar[a + (long)(s.knew - 1) * nij] = vn;
-    if (s.predictor) c->F.rvbar[a + (long)(s.krhs - 1) * nij] = rhs_v;
+    c->F.vbar[o + (long)(s.knew - 1) * nij] = vn;
+    if (s.predictor && owner) c->F.rvbar[a + (long)(s.krhs - 1) * nij] = rhs_v;
   }
+  if (v_wall) c->F.vbar[o + (long)(s.knew - 1) * nij] = 0.0;
 }
 
 int step2d_impl(const roms_step_idx_t *si)
@@ -381,10 +488,36 @@ int step2d_impl(const roms_step_idx_t *si)
   const roms_bounds_t &b = g_ctx.b;
   const roms_params_t &p = g_ctx.p;
   int rc;
-  S2 s{si->krhs, si->kstp, si->knew, si->nstp, si->nnew, si->iif, si->iic, si->ntfirst, si->predictor_2d_step};
+  S2 s{si->krhs, si->kstp, si->knew, si->nstp, si->nnew, si->iif, si->iic, si->ntfirst, si->predictor_2d_step, 0};
   double *DUon = g_ctx.hostc.ws2[0], *DVom = g_ctx.hostc.ws2[1];
   double *zeta_new = g_ctx.hostc.ws2[2], *zwrk = g_ctx.hostc.ws2[3];
   const long nij = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1);
+  // Source-mapped fast path: one tile, E-W periodic, closed N-S walls.  Not used on
+  // the first predictor of a step: there the momentum kernel read-modify-writes
+  // rufrc and ru(:,:,0,nstp) at the source points (:1884-2037), which ghost-point
+  // threads would race with.
+  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !(s.iif == 1 && s.predictor) &&
+                  !g_ctx.no_fused_2d;
+  if (sm) {
+    s.sm = 1;
+    const dim3 full = grid2d(b.UBi - b.LBi + 1, b.UBj - b.LBj + 1);
+    hipLaunchKernelGGL(k2d_flux, grid2d(b.UBi - b.LBi + 1, b.Jendp2 - (b.JstrV - 2) + 1), block2d(), 0, g_ctx.stream,
+                       g_ctx.devc, s, DUon, DVom);
+    KERNEL_CHECK("k2d_flux");
+    hipLaunchKernelGGL(k2d_zeta_sm, full, block2d(), 0, g_ctx.stream, g_ctx.devc, s, (const double *)DUon,
+                       (const double *)DVom, zeta_new, zwrk);
+    KERNEL_CHECK("k2d_zeta_sm");
+    if (s.iif == p.nfast + 1 && s.predictor) {
+      if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_Zt_avg1]))) return rc;
+      if ((rc = halo_exchange2d(GT_U, g_ctx.dev[FID_DU_avg1]))) return rc;
+      if ((rc = halo_exchange2d(GT_V, g_ctx.dev[FID_DV_avg1]))) return rc;
+    }
+    if (s.iif > p.nfast) return 0;
+    hipLaunchKernelGGL(k2d_mom, full, block2d(), 0, g_ctx.stream, g_ctx.devc, s, (const double *)DUon,
+                       (const double *)DVom, (const double *)zeta_new, (const double *)zwrk);
+    KERNEL_CHECK("k2d_mom");
+    return 0;
+  }
   hipLaunchKernelGGL(k2d_flux, grid2d(b.Iendp2 - (b.IstrU - 2) + 1, b.Jendp2 - (b.JstrV - 2) + 1), block2d(), 0,
                      g_ctx.stream, g_ctx.devc, s, DUon, DVom);
   KERNEL_CHECK("k2d_flux");

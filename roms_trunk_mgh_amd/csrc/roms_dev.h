@@ -37,6 +37,7 @@ struct RomsCtx {
   RomsDev *devc = nullptr;    // device copy
   bool devc_dirty = true;
   bool timing = false;
+  bool no_fused_2d = false;   // ROMS_HIP_NO_FUSED2D=1: always use the general BC + halo launches in step2d
   std::string last_error;
   // halo exchange (RCCL) state lives in halo.hip
   void *nccl_comm = nullptr;
