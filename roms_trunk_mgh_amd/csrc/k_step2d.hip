@@ -20,6 +20,8 @@
 #include "roms_dev.h"
 
 int roms_entry_check(const char *name);
+int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DVom, const double *zeta_new,
+                            const double *zwrk);   // k_step2d_mom.hip
 
 namespace {
 
@@ -513,6 +515,7 @@ int step2d_impl(const roms_step_idx_t *si)
       if ((rc = halo_exchange2d(GT_V, g_ctx.dev[FID_DV_avg1]))) return rc;
     }
     if (s.iif > p.nfast) return 0;
+    if (!g_ctx.no_lds_2d) return roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, zeta_new, zwrk);
     hipLaunchKernelGGL(k2d_mom, full, block2d(), 0, g_ctx.stream, g_ctx.devc, s, (const double *)DUon,
                        (const double *)DVom, (const double *)zeta_new, (const double *)zwrk);
     KERNEL_CHECK("k2d_mom");
@@ -536,9 +539,14 @@ int step2d_impl(const roms_step_idx_t *si)
   if (s.predictor && (rc = halo_exchange2d(GT_R, g_ctx.dev[FID_rzeta] + (long)(s.krhs - 1) * nij))) return rc;
   if ((rc = bc_zeta(s.knew))) return rc;
   if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_zeta] + (long)(s.knew - 1) * nij))) return rc;
-  hipLaunchKernelGGL(k2d_mom, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc,
-                     s, (const double *)DUon, (const double *)DVom, (const double *)zeta_new, (const double *)zwrk);
-  KERNEL_CHECK("k2d_mom");
+  if (!g_ctx.no_lds_2d) {
+    if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, zeta_new, zwrk))) return rc;
+  } else {
+    hipLaunchKernelGGL(k2d_mom, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                       g_ctx.devc, s, (const double *)DUon, (const double *)DVom, (const double *)zeta_new,
+                       (const double *)zwrk);
+    KERNEL_CHECK("k2d_mom");
+  }
   if ((rc = bc_u2d(s.knew))) return rc;
   if ((rc = bc_v2d(s.knew))) return rc;
   if ((rc = halo_exchange2d(GT_U, g_ctx.dev[FID_ubar] + (long)(s.knew - 1) * nij))) return rc;

@@ -1,0 +1,323 @@
+// k_step2d_mom.hip -- LDS-tiled momentum kernel of step2d_tile
+// (ROMS/Nonlinear/step2d_LF_AM3.h:939-2255): same arithmetic as k2d_mom in
+// k_step2d.hip, but the five fields the wide stencils read -- ubar(krhs),
+// vbar(krhs), DUon, DVom and the total depth Drhs = zeta(krhs)+h -- are staged
+// once per workgroup into LDS with their 2-point C-grid halo (68 x 8 doubles
+// per field for a 64 x 4 workgroup, 21.8 KB).  The 4th-order advection,
+// Coriolis, curvilinear and viscous terms then read LDS instead of issuing
+// ~100 L2 requests per point.
+//
+// Source mapping (single tile, E-W periodic, closed N-S walls): threads cover
+// i = LBi:UBi; ghost columns evaluate at their periodic image (the tile is
+// loaded through the same wrap, so neighbour relations are preserved), and the
+// wall-adjacent rows also store the u2dbc / v2dbc closed-wall values, so no
+// boundary-condition or periodic-copy launch follows.
+#include "roms_dev.h"
+
+namespace {
+
+struct S2 {
+  int krhs, kstp, knew, nstp, nnew, iif, iic, ntfirst, predictor, sm;
+};
+
+#define TP (BLK_X + 4)       // tile pitch (i)
+#define TJ (BLK_Y + 4)       // tile rows  (j)
+#define C6 (1.0 / 6.0)
+
+struct T2 {                  // LDS tiles, addressed with TARGET coordinates
+  const double *ub, *vb, *DU, *DV, *D;
+  int i0, j0;                // target coordinates of tile element (0,0)
+  int Istr, Iend, Jstr, Jend;
+  bool s_edge, n_edge, w_edge, e_edge;
+  __device__ __forceinline__ int at(int i, int j) const { return (i - i0) + (j - j0) * TP; }
+};
+
+__device__ __forceinline__ double d2x(const double *f, int a) { return f[a - 1] - 2.0 * f[a] + f[a + 1]; }
+__device__ __forceinline__ double d2y(const double *f, int a) { return f[a - TP] - 2.0 * f[a] + f[a + TP]; }
+
+__device__ __forceinline__ double UFx2(const T2 &m, int i, int j)      // :1079-1125
+{
+  int ia = i, ib = i + 1;
+  if (m.w_edge) { if (ia == m.Istr) ia = m.Istr + 1; if (ib == m.Istr) ib = m.Istr + 1; }
+  if (m.e_edge) { if (ia == m.Iend + 1) ia = m.Iend; if (ib == m.Iend + 1) ib = m.Iend; }
+  const int a = m.at(i, j);
+  return 0.25 * (m.ub[a] + m.ub[a + 1] - C6 * (d2x(m.ub, m.at(ia, j)) + d2x(m.ub, m.at(ib, j)))) *
+         (m.DU[a] + m.DU[a + 1] - C6 * (d2x(m.DU, m.at(ia, j)) + d2x(m.DU, m.at(ib, j))));
+}
+__device__ __forceinline__ double UFe2(const T2 &m, int i, int j)      // :1127-1165
+{
+  int ja = j, jb = j - 1;
+  if (m.s_edge) { if (ja == m.Jstr - 1) ja = m.Jstr; if (jb == m.Jstr - 1) jb = m.Jstr; }
+  if (m.n_edge) { if (ja == m.Jend + 1) ja = m.Jend; if (jb == m.Jend + 1) jb = m.Jend; }
+  const int a = m.at(i, j);
+  return 0.25 * (m.ub[a] + m.ub[a - TP] - C6 * (d2y(m.ub, m.at(i, ja)) + d2y(m.ub, m.at(i, jb)))) *
+         (m.DV[a] + m.DV[a - 1] - C6 * (d2x(m.DV, a) + d2x(m.DV, a - 1)));
+}
+__device__ __forceinline__ double VFx2(const T2 &m, int i, int j)      // :1167-1205
+{
+  int ia = i, ib = i - 1;
+  if (m.w_edge) { if (ia == m.Istr - 1) ia = m.Istr; if (ib == m.Istr - 1) ib = m.Istr; }
+  if (m.e_edge) { if (ia == m.Iend + 1) ia = m.Iend; if (ib == m.Iend + 1) ib = m.Iend; }
+  const int a = m.at(i, j);
+  return 0.25 * (m.vb[a] + m.vb[a - 1] - C6 * (d2x(m.vb, m.at(ia, j)) + d2x(m.vb, m.at(ib, j)))) *
+         (m.DU[a] + m.DU[a - TP] - C6 * (d2y(m.DU, a) + d2y(m.DU, a - TP)));
+}
+__device__ __forceinline__ double VFe2(const T2 &m, int i, int j)      // :1207-1256
+{
+  int ja = j, jb = j + 1;
+  if (m.s_edge) { if (ja == m.Jstr) ja = m.Jstr + 1; if (jb == m.Jstr) jb = m.Jstr + 1; }
+  if (m.n_edge) { if (ja == m.Jend + 1) ja = m.Jend; if (jb == m.Jend + 1) jb = m.Jend; }
+  const int a = m.at(i, j);
+  return 0.25 * (m.vb[a] + m.vb[a + TP] - C6 * (d2y(m.vb, m.at(i, ja)) + d2y(m.vb, m.at(i, jb)))) *
+         (m.DV[a] + m.DV[a + TP] - C6 * (d2y(m.DV, m.at(i, ja)) + d2y(m.DV, m.at(i, jb))));
+}
+
+__device__ __forceinline__ int wrap_i(const roms_bounds_t &b, int i)
+{
+  return (i < 1) ? i + b.Lm : ((i > b.Lm) ? i - b.Lm : i);
+}
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, const double *__restrict__ DVom,
+            const double *__restrict__ zeta_new, const double *__restrict__ zwrk)
+{
+  DEV_PROLOGUE(c)
+  const roms_params_t &p = c->p;
+  __shared__ double sU[TJ * TP], sV[TJ * TP], sDU[TJ * TP], sDV[TJ * TP], sD[TJ * TP];
+  const int ibase = s.sm ? b.LBi : b.Istr;
+  const int ilast = s.sm ? b.UBi : b.Iend;
+  const int it0 = ibase + blockIdx.x * BLK_X, j0 = b.Jstr + blockIdx.y * BLK_Y;
+  const int it = it0 + threadIdx.x, j = j0 + threadIdx.y;
+  const double *__restrict__ ubk = c->F.ubar + (long)(s.krhs - 1) * nij;
+  const double *__restrict__ vbk = c->F.vbar + (long)(s.krhs - 1) * nij;
+  const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
+  const double *__restrict__ h = c->F.h;
+  // ---- stage the stencil fields (target coordinates it0-2.., j0-2..) ----
+  {
+    const int tid = threadIdx.y * BLK_X + threadIdx.x;
+    for (int e = tid; e < TJ * TP; e += BLK_X * BLK_Y) {
+      const int li = e % TP, lj = e / TP;
+      int gi = it0 - 2 + li, gj = j0 - 2 + lj;
+      if (s.sm) gi = wrap_i(b, gi);
+      else gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
+      gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
+      const long g = I2(gi, gj);
+      sU[e] = ubk[g];
+      sV[e] = vbk[g];
+      sDU[e] = DUon[g];
+      sDV[e] = DVom[g];
+      sD[e] = zk[g] + h[g];
+    }
+  }
+  __syncthreads();
+  if (it > ilast || j > b.Jend) return;
+  const int i = s.sm ? wrap_i(b, it) : it;          // source column
+  const bool owner = (i == it);
+  const bool do_u = s.sm ? true : (i >= b.IstrU);
+  const bool do_v = j >= b.JstrV;
+  const long a = I2(i, j);                          // source index in global arrays
+  const long o = I2(it, j);                         // target index
+  const double *__restrict__ rhoA = c->F.rhoA;
+  const double *__restrict__ rhoS = c->F.rhoS;
+  const double *__restrict__ pm = c->F.pm;
+  const double *__restrict__ pn = c->F.pn;
+  const double *__restrict__ zs = c->F.zeta + (long)(s.kstp - 1) * nij;
+  T2 m;
+  m.ub = sU; m.vb = sV; m.DU = sDU; m.DV = sDV; m.D = sD;
+  m.i0 = it0 - 2; m.j0 = j0 - 2;
+  m.Istr = b.Istr; m.Iend = b.Iend; m.Jstr = b.Jstr; m.Jend = b.Jend;
+  m.s_edge = b.south_edge && !b.NSperiodic; m.n_edge = b.north_edge && !b.NSperiodic;
+  m.w_edge = b.west_edge && !b.EWperiodic;  m.e_edge = b.east_edge && !b.EWperiodic;
+  const int t = m.at(it, j);                        // this point in the tiles
+  const double fac = 1000.0 / p.rho0;
+  // ---- pressure gradient, :939-1019 ----
+  const double zw0 = zwrk[a];
+  const double gz0 = (fac + rhoS[a]) * zw0, gz20 = gz0 * zw0, gsa0 = zw0 * (rhoS[a] - rhoA[a]);
+  const double cg = 0.5 * p.g, c3 = 1.0 / 3.0;
+  double rhs_u = 0.0, rhs_v = 0.0;
+  if (do_u) {
+    const long q = a - 1;
+    const double zw = zwrk[q];
+    const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
+    rhs_u = cg * c->F.on_u[a] *
+            ((h[q] + h[a]) * (gz - gz0) +
+             (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
+             (gz2 - gz20));
+  }
+  if (do_v) {
+    const long q = a - ni;
+    const double zw = zwrk[q];
+    const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
+    rhs_v = cg * c->F.om_v[a] *
+            ((h[q] + h[a]) * (gz - gz0) +
+             (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
+             (gz2 - gz20));
+  }
+  // ---- advection, :1079-1283 ----
+  if (p.uv_adv) {
+    if (do_u) {
+      const double cff1 = UFx2(m, it, j) - UFx2(m, it - 1, j);
+      const double cff2 = UFe2(m, it, j + 1) - UFe2(m, it, j);
+      rhs_u = rhs_u - (cff1 + cff2);
+    }
+    if (do_v) {
+      const double cff1 = VFx2(m, it + 1, j) - VFx2(m, it, j);
+      const double cff2 = VFe2(m, it, j) - VFe2(m, it, j - 1);
+      rhs_v = rhs_v - (cff1 + cff2);
+    }
+  }
+  const double D0 = sD[t], Dw = sD[t - 1], Ds = sD[t - TP];
+  // ---- Coriolis, :1291-1325 ----
+  if (p.uv_cor) {
+    const double *fomn = c->F.fomn;
+    const double cf0 = 0.5 * D0 * fomn[a];
+    const double UFx0 = cf0 * (sV[t] + sV[t + TP]);
+    const double VFe0 = cf0 * (sU[t] + sU[t + 1]);
+    if (do_u) {
+      const double cfw = 0.5 * Dw * fomn[a - 1];
+      const double UFxw = cfw * (sV[t - 1] + sV[t - 1 + TP]);
+      rhs_u = rhs_u + 0.5 * (UFx0 + UFxw);
+    }
+    if (do_v) {
+      const double cfs = 0.5 * Ds * fomn[a - ni];
+      const double VFes = cfs * (sU[t - TP] + sU[t - TP + 1]);
+      rhs_v = rhs_v - 0.5 * (VFe0 + VFes);
+    }
+  }
+  // ---- curvilinear terms, :1333-1382 ----
+  if (p.curvgrid && p.uv_adv) {
+    const double *dndx = c->F.dndx, *dmde = c->F.dmde;
+    auto cell = [&](long q, int tq, double D, double &ufx, double &vfe) {
+      const double cff1 = 0.5 * (sV[tq] + sV[tq + TP]);
+      const double cff2 = 0.5 * (sU[tq] + sU[tq + 1]);
+      const double cff3 = cff1 * dndx[q];
+      const double cff4 = cff2 * dmde[q];
+      const double cff = D * (cff3 - cff4);
+      ufx = cff * cff1;
+      vfe = cff * cff2;
+    };
+    double u0, v0, u1, v1;
+    cell(a, t, D0, u0, v0);
+    if (do_u) { cell(a - 1, t - 1, Dw, u1, v1); rhs_u = rhs_u + 0.5 * (u0 + u1); }
+    if (do_v) { cell(a - ni, t - TP, Ds, u1, v1); rhs_v = rhs_v - 0.5 * (v0 + v1); }
+  }
+  // ---- harmonic viscosity, :1394-1471 ----
+  if (p.uv_vis2) {
+    const double *visc2_r = c->F.visc2_r, *visc2_p = c->F.visc2_p;
+    const double *pmon_r = c->F.pmon_r, *pnom_r = c->F.pnom_r, *pmon_p = c->F.pmon_p, *pnom_p = c->F.pnom_p;
+    const double *om_r = c->F.om_r, *on_r = c->F.on_r, *om_p = c->F.om_p, *on_p = c->F.on_p;
+    auto str_r = [&](long q, int tq) {
+      return visc2_r[q] * sD[tq] * 0.5 *
+             (pmon_r[q] * ((pn[q] + pn[q + 1]) * sU[tq + 1] - (pn[q - 1] + pn[q]) * sU[tq]) -
+              pnom_r[q] * ((pm[q] + pm[q + ni]) * sV[tq + TP] - (pm[q - ni] + pm[q]) * sV[tq]));
+    };
+    auto str_p = [&](long q, int tq) {
+      const double Dp = 0.25 * (sD[tq] + sD[tq - 1] + sD[tq - TP] + sD[tq - 1 - TP]);
+      return visc2_p[q] * Dp * 0.5 *
+             (pmon_p[q] * ((pn[q - ni] + pn[q]) * sV[tq] - (pn[q - 1 - ni] + pn[q - 1]) * sV[tq - 1]) +
+              pnom_p[q] * ((pm[q - 1] + pm[q]) * sU[tq] - (pm[q - 1 - ni] + pm[q - ni]) * sU[tq - TP]));
+    };
+    const double sr0 = str_r(a, t), sp0 = str_p(a, t);
+    if (do_u) {
+      const double srw = str_r(a - 1, t - 1), spn = str_p(a + ni, t + TP);
+      const double UFx0 = on_r[a] * on_r[a] * sr0, UFxw = on_r[a - 1] * on_r[a - 1] * srw;
+      const double UFe0 = om_p[a] * om_p[a] * sp0, UFen = om_p[a + ni] * om_p[a + ni] * spn;
+      const double cff1 = 0.5 * (pn[a - 1] + pn[a]) * (UFx0 - UFxw);
+      const double cff2 = 0.5 * (pm[a - 1] + pm[a]) * (UFen - UFe0);
+      rhs_u = rhs_u + (cff1 + cff2);
+    }
+    if (do_v) {
+      const double srs = str_r(a - ni, t - TP), spe = str_p(a + 1, t + 1);
+      const double VFx0 = on_p[a] * on_p[a] * sp0, VFxe = on_p[a + 1] * on_p[a + 1] * spe;
+      const double VFe0 = om_r[a] * om_r[a] * sr0, VFes = om_r[a - ni] * om_r[a - ni] * srs;
+      const double cff1 = 0.5 * (pn[a - ni] + pn[a]) * (VFxe - VFx0);
+      const double cff2 = 0.5 * (pm[a - ni] + pm[a]) * (VFe0 - VFes);
+      rhs_v = rhs_v + (cff1 - cff2);
+    }
+  }
+  // ---- coupling between 2-D and 3-D equations, :1884-2065 ----
+  if (s.iif == 1 && s.predictor) {
+    // never source-mapped (step2d_impl), so owner is always true here
+    double *ru_s = c->F.ru + (long)(s.nstp - 1) * n3w;
+    double *rv_s = c->F.rv + (long)(s.nstp - 1) * n3w;
+    const double *ru_n = c->F.ru + (long)(s.nnew - 1) * n3w;
+    const double *rv_n = c->F.rv + (long)(s.nnew - 1) * n3w;
+    if (do_u) {
+      const double rf = c->F.rufrc[a] - rhs_u;
+      if (s.iic == s.ntfirst) rhs_u = rhs_u + rf;
+      else if (s.iic == s.ntfirst + 1) rhs_u = rhs_u + 1.5 * rf - 0.5 * ru_n[a];
+      else rhs_u = rhs_u + (23.0 / 12.0) * rf - (16.0 / 12.0) * ru_n[a] + (5.0 / 12.0) * ru_s[a];
+      c->F.rufrc[a] = rf;
+      ru_s[a] = rf;
+    }
+    if (do_v) {
+      const double rf = c->F.rvfrc[a] - rhs_v;
+      if (s.iic == s.ntfirst) rhs_v = rhs_v + rf;
+      else if (s.iic == s.ntfirst + 1) rhs_v = rhs_v + 1.5 * rf - 0.5 * rv_n[a];
+      else rhs_v = rhs_v + (23.0 / 12.0) * rf - (16.0 / 12.0) * rv_n[a] + (5.0 / 12.0) * rv_s[a];
+      c->F.rvfrc[a] = rf;
+      rv_s[a] = rf;
+    }
+  } else {
+    if (do_u) rhs_u = rhs_u + c->F.rufrc[a];
+    if (do_v) rhs_v = rhs_v + c->F.rvfrc[a];
+  }
+  // ---- time step, :2098-2255 ----
+  const double dtfast = p.dtfast;
+  const double Dn0 = zeta_new[a] + h[a], Dst0 = zs[a] + h[a];
+  const int ptsk = 3 - s.kstp;
+  const bool am3 = !(s.iif == 1 || s.predictor);
+  const double c1 = (s.iif == 1) ? 0.5 * dtfast : dtfast;
+  const double a1 = 0.5 * dtfast * 5.0 / 12.0, a2 = 0.5 * dtfast * 8.0 / 12.0, a3 = 0.5 * dtfast * 1.0 / 12.0;
+  double *__restrict__ ubn = c->F.ubar + (long)(s.knew - 1) * nij;
+  double *__restrict__ vbn = c->F.vbar + (long)(s.knew - 1) * nij;
+  if (do_u) {
+    const long q = a - 1;
+    const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
+    const double fc = 1.0 / (Dn0 + (zeta_new[q] + h[q]));
+    const double us = c->F.ubar[a + (long)(s.kstp - 1) * nij];
+    double un;
+    if (!am3) un = (us * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_u) * fc;
+    else un = (us * (Dst0 + (zs[q] + h[q])) +
+               cff * (a1 * rhs_u + a2 * c->F.rubar[a + (long)(s.kstp - 1) * nij] -
+                      a3 * c->F.rubar[a + (long)(ptsk - 1) * nij])) * fc;
+    ubn[o] = un;
+    if (s.predictor && owner) c->F.rubar[a + (long)(s.krhs - 1) * nij] = rhs_u;
+    if (s.sm) {                                        // u2dbc closed walls, u2dbc_im.F:51
+      if (b.south_edge && j == b.Jstr) ubn[o - ni] = p.gamma2 * un;
+      if (b.north_edge && j == b.Jend) ubn[o + ni] = p.gamma2 * un;
+    }
+  }
+  if (do_v) {
+    const long q = a - ni;
+    const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
+    const double fc = 1.0 / (Dn0 + (zeta_new[q] + h[q]));
+    const double vs = c->F.vbar[a + (long)(s.kstp - 1) * nij];
+    double vn;
+    if (!am3) vn = (vs * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_v) * fc;
+    else vn = (vs * (Dst0 + (zs[q] + h[q])) +
+               cff * (a1 * rhs_v + a2 * c->F.rvbar[a + (long)(s.kstp - 1) * nij] -
+                      a3 * c->F.rvbar[a + (long)(ptsk - 1) * nij])) * fc;
+    vbn[o] = vn;
+    if (s.predictor && owner) c->F.rvbar[a + (long)(s.krhs - 1) * nij] = rhs_v;
+  }
+  if (s.sm) {                                          // v2dbc closed walls, v2dbc_im.F:52
+    if (b.south_edge && j == b.Jstr) vbn[o] = 0.0;
+    if (b.north_edge && j == b.Jend) vbn[o + ni] = 0.0;
+  }
+}
+
+}  // namespace
+
+// Launcher used by step2d_impl (k_step2d.hip); s10 = the ten ints of its S2.
+int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DVom, const double *zeta_new,
+                            const double *zwrk)
+{
+  const roms_bounds_t &b = g_ctx.b;
+  S2 s{s10[0], s10[1], s10[2], s10[3], s10[4], s10[5], s10[6], s10[7], s10[8], s10[9]};
+  const int nx = s.sm ? (b.UBi - b.LBi + 1) : (b.Iend - b.Istr + 1);
+  hipLaunchKernelGGL(k2d_mom_lds, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s, DUon,
+                     DVom, zeta_new, zwrk);
+  KERNEL_CHECK("k2d_mom_lds");
+  return 0;
+}

@@ -38,6 +38,7 @@ struct RomsCtx {
   bool devc_dirty = true;
   bool timing = false;
   bool no_fused_2d = false;   // ROMS_HIP_NO_FUSED2D=1: always use the general BC + halo launches in step2d
+  bool no_lds_2d = false;     // ROMS_HIP_NO_LDS2D=1: momentum kernel without LDS staging (A/B reference)
   std::string last_error;
   // halo exchange (RCCL) state lives in halo.hip
   void *nccl_comm = nullptr;
