@@ -106,6 +106,8 @@ extern "C" int roms_hip_init(int rank, int ntileI, int ntileJ, int device_id, co
     g_ctx.no_fused_2d = e && e[0] == '1';
     e = getenv("ROMS_HIP_NO_LDS2D");
     g_ctx.no_lds_2d = e && e[0] == '1';
+    e = getenv("ROMS_HIP_NO_LDS3D");
+    g_ctx.no_lds_3d = e && e[0] == '1';
   }
   if (nccl_unique_id) {
     memcpy(g_ctx.nccl_id, nccl_unique_id, 128);

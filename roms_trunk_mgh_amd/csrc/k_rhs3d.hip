@@ -15,6 +15,7 @@
 #include "roms_dev.h"
 
 int roms_entry_check(const char *name);
+int roms_launch_rhs3d_lds(int nrhs);
 
 namespace {
 
@@ -248,6 +249,7 @@ extern "C" int roms_hip_rhs3d_tile(const roms_step_idx_t *s)
   ScopedTimer tm("rhs3d_tile");
   const roms_bounds_t &b = g_ctx.b;
   if (b.N < 4) return roms_fail("roms_hip_rhs3d_tile", "N < 4");
+  if (!g_ctx.no_lds_3d) return roms_launch_rhs3d_lds(s->nrhs);      // LDS-staged version (k_rhs3d_lds.hip)
   hipLaunchKernelGGL(k_rhs3d, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
                      g_ctx.devc, s->nrhs);
   KERNEL_CHECK("k_rhs3d");

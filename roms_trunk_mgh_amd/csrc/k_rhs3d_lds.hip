@@ -1,0 +1,235 @@
+// k_rhs3d_lds.hip -- LDS-staged version of k_rhs3d (rhs3d_tile,
+// ROMS/Nonlinear/rhs3d.F:174-1673); same arithmetic, same operation order.
+//
+// A 64 x 4 workgroup sweeps its columns upward level by level.  For every
+// level the five fields the horizontal operators read -- u, v, Huon, Hvom
+// (2-point C-grid halo) and Hz -- are staged into LDS once (68 x 8 doubles per
+// field, 21.8 KB per workgroup) and the third-order upstream fluxes, Coriolis
+// and curvilinear terms are evaluated from LDS.  HBM/L2 sees each plane ~1.5x
+// (halo rows) instead of the ~12 re-reads per point of the direct version.
+// The k-window of u, v for the 4th-order vertical advection stays in VGPRs and
+// the vertical sums rufrc/rvfrc accumulate in registers.
+#include "roms_dev.h"
+
+namespace {
+
+#define TP (BLK_X + 4)
+#define TJ (BLK_Y + 4)
+#define Gadv (-0.25)
+
+struct T3 {
+  const double *u, *v, *Hu, *Hv, *Hz;      // LDS tiles
+  int i0, j0;
+  int Istr, Iend, Jstr, Jend;
+  bool s_edge, n_edge, w_edge, e_edge;
+  __device__ __forceinline__ int at(int i, int j) const { return (i - i0) + (j - j0) * TP; }
+};
+
+__device__ __forceinline__ double d2x(const double *f, int a) { return f[a - 1] - 2.0 * f[a] + f[a + 1]; }
+__device__ __forceinline__ double d2y(const double *f, int a) { return f[a - TP] - 2.0 * f[a] + f[a + TP]; }
+
+__device__ __forceinline__ int ex_uxx(const T3 &L, int i) {           // rhs3d.F:668-685
+  if (L.w_edge && i == L.Istr) return L.Istr + 1;
+  if (L.e_edge && i == L.Iend + 1) return L.Iend;
+  return i;
+}
+__device__ __forceinline__ int ey_uee(const T3 &L, int j) {           // :717-733
+  if (L.s_edge && j == L.Jstr - 1) return L.Jstr;
+  if (L.n_edge && j == L.Jend + 1) return L.Jend;
+  return j;
+}
+__device__ __forceinline__ int ex_vxx(const T3 &L, int i) {           // :770-786
+  if (L.w_edge && i == L.Istr - 1) return L.Istr;
+  if (L.e_edge && i == L.Iend + 1) return L.Iend;
+  return i;
+}
+__device__ __forceinline__ int ey_vee(const T3 &L, int j) {           // :820-838
+  if (L.s_edge && j == L.Jstr) return L.Jstr + 1;
+  if (L.n_edge && j == L.Jend + 1) return L.Jend;
+  return j;
+}
+
+__device__ __forceinline__ double UFx_at(const T3 &L, int i, int j)   // :688-704
+{
+  const int a = L.at(i, j);
+  const double cff1 = L.u[a] + L.u[a + 1];
+  const int ia = ex_uxx(L, i), ib = ex_uxx(L, i + 1);
+  const double cff = (cff1 > 0.0) ? d2x(L.u, L.at(ia, j)) : d2x(L.u, L.at(ib, j));
+  return 0.25 * (cff1 + Gadv * cff) *
+         (L.Hu[a] + L.Hu[a + 1] + Gadv * 0.5 * (d2x(L.Hu, L.at(ia, j)) + d2x(L.Hu, L.at(ib, j))));
+}
+__device__ __forceinline__ double UFe_at(const T3 &L, int i, int j)   // :741-757
+{
+  const int a = L.at(i, j);
+  const double cff1 = L.u[a] + L.u[a - TP];
+  const double cff2 = L.Hv[a] + L.Hv[a - 1];
+  const double cff = (cff2 > 0.0) ? d2y(L.u, L.at(i, ey_uee(L, j - 1))) : d2y(L.u, L.at(i, ey_uee(L, j)));
+  return 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (d2x(L.Hv, a) + d2x(L.Hv, a - 1)));
+}
+__device__ __forceinline__ double VFx_at(const T3 &L, int i, int j)   // :794-810
+{
+  const int a = L.at(i, j);
+  const double cff1 = L.v[a] + L.v[a - 1];
+  const double cff2 = L.Hu[a] + L.Hu[a - TP];
+  const double cff = (cff2 > 0.0) ? d2x(L.v, L.at(ex_vxx(L, i - 1), j)) : d2x(L.v, L.at(ex_vxx(L, i), j));
+  return 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (d2y(L.Hu, a) + d2y(L.Hu, a - TP)));
+}
+__device__ __forceinline__ double VFe_at(const T3 &L, int i, int j)   // :846-862
+{
+  const int a = L.at(i, j);
+  const double cff1 = L.v[a] + L.v[a + TP];
+  const int ja = ey_vee(L, j), jb = ey_vee(L, j + 1);
+  const double cff = (cff1 > 0.0) ? d2y(L.v, L.at(i, ja)) : d2y(L.v, L.at(i, jb));
+  return 0.25 * (cff1 + Gadv * cff) *
+         (L.Hv[a] + L.Hv[a + TP] + Gadv * 0.5 * (d2y(L.Hv, L.at(i, ja)) + d2y(L.Hv, L.at(i, jb))));
+}
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
+{
+  DEV_PROLOGUE(c)
+  __shared__ double sU[TJ * TP], sV[TJ * TP], sHu[TJ * TP], sHv[TJ * TP], sHz[TJ * TP];
+  const roms_params_t &p = c->p;
+  const int i0 = b.Istr + blockIdx.x * BLK_X, j0 = b.Jstr + blockIdx.y * BLK_Y;
+  const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
+  const bool active = i <= b.Iend && j <= b.Jend;
+  const bool do_u = active && i >= b.IstrU, do_v = active && j >= b.JstrV;
+  const double *__restrict__ ug = c->F.u + (long)(nrhs - 1) * n3r;
+  const double *__restrict__ vg = c->F.v + (long)(nrhs - 1) * n3r;
+  const double *__restrict__ Wg = c->F.W;
+  double *__restrict__ ru = c->F.ru + (long)(nrhs - 1) * n3w;
+  double *__restrict__ rv = c->F.rv + (long)(nrhs - 1) * n3w;
+  const int ic = active ? i : b.Iend, jc = active ? j : b.Jend;     // clamped for address formation only
+  const long c0 = I2(ic, jc);
+  T3 L;
+  L.u = sU; L.v = sV; L.Hu = sHu; L.Hv = sHv; L.Hz = sHz;
+  L.i0 = i0 - 2; L.j0 = j0 - 2;
+  L.Istr = b.Istr; L.Iend = b.Iend; L.Jstr = b.Jstr; L.Jend = b.Jend;
+  L.s_edge = b.south_edge && !b.NSperiodic; L.n_edge = b.north_edge && !b.NSperiodic;
+  L.w_edge = b.west_edge && !b.EWperiodic;  L.e_edge = b.east_edge && !b.EWperiodic;
+  const bool cor = p.uv_cor != 0, curv = p.curvgrid != 0 && p.uv_adv != 0, adv = p.uv_adv != 0;
+  const int t = L.at(i, j);
+  const int tid = threadIdx.y * BLK_X + threadIdx.x;
+  // per-thread constants of the cell terms
+  const double fomn0 = c->F.fomn[c0], fomnw = c->F.fomn[c0 - 1], fomns = c->F.fomn[c0 - ni];
+  double dndx0 = 0, dndxw = 0, dndxs = 0, dmde0 = 0, dmdew = 0, dmdes = 0;
+  if (curv) {
+    dndx0 = c->F.dndx[c0]; dndxw = c->F.dndx[c0 - 1]; dndxs = c->F.dndx[c0 - ni];
+    dmde0 = c->F.dmde[c0]; dmdew = c->F.dmde[c0 - 1]; dmdes = c->F.dmde[c0 - ni];
+  }
+  double u_m1 = 0.0, u_0 = ug[c0], u_p1 = ug[c0 + nij], u_p2;
+  double v_m1 = 0.0, v_0 = vg[c0], v_p1 = vg[c0 + nij], v_p2;
+  double FCu_prev = 0.0, FCv_prev = 0.0, sum_u = 0.0, sum_v = 0.0;
+  const double c9 = 9.0 / 16.0, c1 = 1.0 / 16.0;
+
+  for (int k = 1; k <= N; k++) {
+    const long koff = (long)(k - 1) * nij;
+    __syncthreads();                                  // previous level fully consumed
+    for (int e = tid; e < TJ * TP; e += BLK_X * BLK_Y) {
+      const int li = e % TP, lj = e / TP;
+      int gi = i0 - 2 + li, gj = j0 - 2 + lj;
+      gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
+      gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
+      const long g = I2(gi, gj) + koff;
+      sU[e] = ug[g];
+      sV[e] = vg[g];
+      sHu[e] = c->F.Huon[g];
+      sHv[e] = c->F.Hvom[g];
+      sHz[e] = c->F.Hz[g];
+    }
+    __syncthreads();
+    u_p2 = (k + 2 <= N) ? ug[c0 + koff + 2 * nij] : 0.0;
+    v_p2 = (k + 2 <= N) ? vg[c0 + koff + 2 * nij] : 0.0;
+    const long cw = c0 + (long)k * nij;
+    double ruv = do_u ? ru[cw] : 0.0;
+    double rvv = do_v ? rv[cw] : 0.0;
+    if (active) {
+      if (cor) {
+        const double cf0 = 0.5 * sHz[t] * fomn0;
+        const double a0 = cf0 * (sV[t] + sV[t + TP]), b0 = cf0 * (sU[t] + sU[t + 1]);
+        if (do_u) {
+          const double cf1 = 0.5 * sHz[t - 1] * fomnw;
+          const double a1 = cf1 * (sV[t - 1] + sV[t - 1 + TP]);
+          ruv = ruv + 0.5 * (a0 + a1);
+        }
+        if (do_v) {
+          const double cf2 = 0.5 * sHz[t - TP] * fomns;
+          const double b2 = cf2 * (sU[t - TP] + sU[t - TP + 1]);
+          rvv = rvv - 0.5 * (b0 + b2);
+        }
+      }
+      if (curv) {
+        auto cell = [&](int q, double dn, double dm, double &ufx, double &vfe) {
+          const double cff1 = 0.5 * (sV[q] + sV[q + TP]);
+          const double cff2 = 0.5 * (sU[q] + sU[q + 1]);
+          const double cff3 = cff1 * dn;
+          const double cff4 = cff2 * dm;
+          const double cff = sHz[q] * (cff3 - cff4);
+          ufx = cff * cff1;
+          vfe = cff * cff2;
+        };
+        double a0, b0, a1, b1;
+        cell(t, dndx0, dmde0, a0, b0);
+        if (do_u) { cell(t - 1, dndxw, dmdew, a1, b1); ruv = ruv + 0.5 * (a0 + a1); }
+        if (do_v) { cell(t - TP, dndxs, dmdes, a1, b1); rvv = rvv - 0.5 * (b0 + b1); }
+      }
+      if (adv) {
+        if (do_u) {
+          const double cff1 = UFx_at(L, i, j) - UFx_at(L, i - 1, j);
+          const double cff2 = UFe_at(L, i, j + 1) - UFe_at(L, i, j);
+          ruv = ruv - (cff1 + cff2);
+        }
+        if (do_v) {
+          const double cff1 = VFx_at(L, i + 1, j) - VFx_at(L, i, j);
+          const double cff2 = VFe_at(L, i, j) - VFe_at(L, i, j - 1);
+          rvv = rvv - (cff1 + cff2);
+        }
+        double FCu = 0.0, FCv = 0.0;
+        if (k < N) {
+          if (do_u) {
+            const double um = (k == 1) ? u_0 : u_m1;
+            const double up = (k == N - 1) ? u_p1 : u_p2;
+            FCu = (c9 * (u_0 + u_p1) - c1 * (um + up)) *
+                  (c9 * (Wg[cw] + Wg[cw - 1]) - c1 * (Wg[cw + 1] + Wg[cw - 2]));
+          }
+          if (do_v) {
+            const double vm = (k == 1) ? v_0 : v_m1;
+            const double vp = (k == N - 1) ? v_p1 : v_p2;
+            FCv = (c9 * (v_0 + v_p1) - c1 * (vm + vp)) *
+                  (c9 * (Wg[cw] + Wg[cw - ni]) - c1 * (Wg[cw + ni] + Wg[cw - 2 * ni]));
+          }
+        }
+        ruv = ruv - (FCu - FCu_prev);
+        rvv = rvv - (FCv - FCv_prev);
+        FCu_prev = FCu; FCv_prev = FCv;
+      }
+      if (do_u) { ru[cw] = ruv; sum_u = (k == 1) ? ruv : sum_u + ruv; }
+      if (do_v) { rv[cw] = rvv; sum_v = (k == 1) ? rvv : sum_v + rvv; }
+    }
+    u_m1 = u_0; u_0 = u_p1; u_p1 = u_p2;
+    v_m1 = v_0; v_0 = v_p1; v_p1 = v_p2;
+  }
+  if (do_u) {
+    const double cff = c->F.om_u[c0] * c->F.on_u[c0];
+    const double cff1 = c->F.sustr[c0] * cff;
+    const double cff2 = -c->F.bustr[c0] * cff;
+    c->F.rufrc[c0] = sum_u + cff1 + cff2;
+  }
+  if (do_v) {
+    const double cff = c->F.om_v[c0] * c->F.on_v[c0];
+    const double cff1 = c->F.svstr[c0] * cff;
+    const double cff2 = -c->F.bvstr[c0] * cff;
+    c->F.rvfrc[c0] = sum_v + cff1 + cff2;
+  }
+}
+
+}  // namespace
+
+int roms_launch_rhs3d_lds(int nrhs)
+{
+  const roms_bounds_t &b = g_ctx.b;
+  hipLaunchKernelGGL(k_rhs3d_lds, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                     g_ctx.devc, nrhs);
+  KERNEL_CHECK("k_rhs3d_lds");
+  return 0;
+}

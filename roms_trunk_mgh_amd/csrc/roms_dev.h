@@ -39,6 +39,7 @@ struct RomsCtx {
   bool timing = false;
   bool no_fused_2d = false;   // ROMS_HIP_NO_FUSED2D=1: always use the general BC + halo launches in step2d
   bool no_lds_2d = false;     // ROMS_HIP_NO_LDS2D=1: momentum kernel without LDS staging (A/B reference)
+  bool no_lds_3d = false;     // ROMS_HIP_NO_LDS3D=1: rhs3d_tile without LDS staging (A/B reference)
   std::string last_error;
   // halo exchange (RCCL) state lives in halo.hip
   void *nccl_comm = nullptr;
