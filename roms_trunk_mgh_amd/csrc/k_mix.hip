@@ -22,9 +22,11 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_t3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
-  const int itrc = 1 + blockIdx.z;
+  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, b.NT);
+  if (!tt.valid) return;
+  const int i = b.Istr + tt.bx * BLK_X + threadIdx.x;
+  const int j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
+  const int itrc = 1 + tt.itr;
   if (i > b.Iend || j > b.Jend) return;
   const double dt = c->p.dt;
   const double *__restrict__ T = c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
@@ -113,9 +115,11 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
-  const int itrc = 1 + blockIdx.z;
+  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, b.NT);
+  if (!tt.valid) return;
+  const int i = b.Istr + tt.bx * BLK_X + threadIdx.x;
+  const int j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
+  const int itrc = 1 + tt.itr;
   if (i > b.Iend || j > b.Jend) return;
   const double *__restrict__ T = c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
   double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
@@ -229,8 +233,7 @@ extern "C" int roms_hip_t3dmix2(const roms_step_idx_t *s)
   if (rc) return rc;
   ScopedTimer tm("t3dmix2");
   const roms_bounds_t &b = g_ctx.b;
-  dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
-  grid.z = b.NT;
+  const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, b.NT);
   if (g_ctx.p.mix_geo_ts)
     hipLaunchKernelGGL(k_t3dmix2_geo, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew);
   else if (g_ctx.p.mix_s_ts)

@@ -23,12 +23,14 @@ namespace {
 
 template <int HADV, int VADV, int NMAX>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
-k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int itrc0)
+k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int itrc0, int ntr)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
-  const int itrc = itrc0 + blockIdx.z;
+  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
+  if (!tt.valid) return;
+  const int i = b.Istr + tt.bx * BLK_X + threadIdx.x;
+  const int j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
+  const int itrc = itrc0 + tt.itr;
   if (i > b.Iend || j > b.Jend) return;
   const roms_params_t &p = c->p;
   const int ltrc = itrc < b.NAT ? itrc : b.NAT;
@@ -241,13 +243,12 @@ template <int HADV, int VADV>
 int launch_pre_t(const roms_step_idx_t *s, int itrc0, int ntr)
 {
   const roms_bounds_t &b = g_ctx.b;
-  dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
-  grid.z = ntr;
+  const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
   const int first = s->iic == s->ntfirst;
   if (b.N <= 16)
-    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0);
+    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
   else if (b.N <= 32)
-    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0);
+    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
   else
     return roms_fail("roms_hip_pre_step3d", "N > 32 not instantiated");
   KERNEL_CHECK("k_pre_t");

@@ -31,12 +31,14 @@ namespace {
 
 template <int HADV, int VADV, int NMAX>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
-k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0)
+k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
-  const int itrc = itrc0 + blockIdx.z;          // 1-based tracer index
+  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
+  if (!tt.valid) return;
+  const int i = b.Istr + tt.bx * BLK_X + threadIdx.x;
+  const int j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
+  const int itrc = itrc0 + tt.itr;              // 1-based tracer index
   if (i > b.Iend || j > b.Jend) return;
   const int ltrc = itrc < b.NAT ? itrc : b.NAT;
   const double dt = c->p.dt;
@@ -195,12 +197,11 @@ template <int HADV, int VADV>
 int launch_nmax(int nnew, int itrc0, int ntr)
 {
   const roms_bounds_t &b = g_ctx.b;
-  dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
-  grid.z = ntr;
+  const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
   if (b.N <= 16)
-    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0);
+    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
   else if (b.N <= 32)
-    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0);
+    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
   else
     return roms_fail("roms_hip_step3d_t", "N > 32 not instantiated");
   KERNEL_CHECK("k_step3d_t");

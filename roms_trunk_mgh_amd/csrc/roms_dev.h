@@ -102,6 +102,32 @@ static inline dim3 grid2d(int nx, int ny) {
 }
 static inline dim3 block2d() { return dim3(BLK_X, BLK_Y, 1); }
 
+// XCD-aware (tile, tracer) decode of a 1-D grid for the per-tracer kernels.
+// Workgroups B and B+8 run on the same XCD (round-robin dispatch over the 8
+// XCDs, MI355X_MICROARCH.md), so consecutive workgroups of one XCD take the SAME
+// horizontal tile for consecutive tracers: the tracer-independent fields
+// (Huon, Hvom, W, Hz, z_r ...) one of them streams are L2 hits for the other.
+// Placement only affects speed, never results.
+struct TileTr { int bx, by, itr; bool valid; };
+#ifdef __HIPCC__
+__device__ __forceinline__ TileTr decode_tile_tracer(int nx, int ny, int ntr)
+{
+  const int nbx = (nx + BLK_X - 1) / BLK_X, nby = (ny + BLK_Y - 1) / BLK_Y;
+  const int B = blockIdx.x, xcd = B & 7, q = B >> 3;
+  TileTr r;
+  r.itr = q % ntr;
+  const int tl = (q / ntr) * 8 + xcd;
+  r.valid = tl < nbx * nby;
+  r.bx = tl % nbx;
+  r.by = tl / nbx;
+  return r;
+}
+#endif
+static inline dim3 grid_tile_tracer(int nx, int ny, int ntr) {
+  const int nt = ((nx + BLK_X - 1) / BLK_X) * ((ny + BLK_Y - 1) / BLK_Y);
+  return dim3((unsigned)(((nt + 7) / 8) * 8 * ntr), 1, 1);
+}
+
 // ------------------------------------------------------------------------
 // internal launchers shared between translation units
 // ------------------------------------------------------------------------
