@@ -1,0 +1,67 @@
+#!/bin/bash
+# oracle/build_ref.sh -- TEST INFRASTRUCTURE ONLY.
+#
+# Builds, from the reference sources WHERE THEY LIE under /root/reference, the
+# subset of the hot-path files that compiles stand-alone with flang -- i.e.
+# without netCDF-Fortran, which the image lacks (no stand-ins are written for
+# it; files that need it, directly or through mod_sources -> mod_netcdf, are
+# simply not part of this build: step2d, pre_step3d, rhs3d, step3d_uv,
+# step3d_t, omega).  Outputs go only to oracle/_ref/ (git-ignored):
+#
+#   oracle/_ref/<APP>/libref.so   reference objects + our bind(C) wrapper
+#                                 (oracle/ref_wrap.F90) for APP in
+#                                 BENCHMARK, UPWELLING, SEAMOUNT
+#
+# This is the reference's own recipe (makefile:207, Compilers/Linux-gfortran.mk:
+# 43-44: cpp -P -traditional then the Fortran compiler), serial build (no
+# DISTRIBUTE/MPI), flags -O2 without fast-math and without FMA contraction.
+set -e
+REF=${REF:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/_ref
+FC=${FC:-flang}
+FFLAGS="-O2 -fPIC -ffp-contract=off"
+[ -d "$REF/ROMS" ] || { echo "reference not present: nothing to build"; exit 0; }
+command -v $FC >/dev/null || { echo "flang not present: nothing to build"; exit 0; }
+
+# dependency-ordered list (reference files only)
+FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iounits Modules/mod_scalars
+ Modules/mod_parallel Utility/strings Utility/yaml_parser Utility/get_metadata Modules/mod_ncparam
+ Modules/mod_grid Modules/mod_ocean Modules/mod_coupling Modules/mod_mixing Modules/mod_forces
+ Modules/mod_stepping Modules/mod_clima Modules/mod_boundary Modules/mod_eoscoef Modules/mod_diags
+ Utility/round Utility/dateclock Nonlinear/exchange_2d Nonlinear/exchange_3d Utility/get_bounds
+ Utility/set_weights Utility/mp_routines Utility/timers Nonlinear/prsgrd Nonlinear/t3dmix Nonlinear/uv3dmix Nonlinear/set_depth
+ Nonlinear/set_massflux Nonlinear/rho_eos Nonlinear/set_zeta"
+
+build_app () {
+  local APP=$1 hdr=$(echo $1 | tr A-Z a-z).h
+  # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
+  [ "$APP" = UPWELLING ] && hdr=upwelling_nodiag.h
+  local D=$OUT/$APP
+  if [ -f $D/libref.so ] && [ $D/libref.so -nt $HERE/ref_wrap.F90 ] && [ $D/libref.so -nt $HERE/build_ref.sh ]; then
+    return 0
+  fi
+  mkdir -p $D && cd $D
+  local CPPF=(-P -traditional -w -D$APP "-DROMS_HEADER=\"$hdr\"" "-DROOT_DIR=\"$REF\"" '-DHOST_NAME="x"'
+     '-DMY_OS="Linux"' '-DMY_CPU="x86_64"' '-DMY_FORT="flang"' '-DMY_FC="flang"' '-DMY_FFLAGS="-O2"'
+     '-DSVN_URL="x"' '-DSVN_REV="x"' '-DANALYTICAL_DIR="x"' '-DHEADER_DIR="x"' "-DHEADER=\"$hdr\""
+     '-DMY_ANALYTICAL_DIR="x"' '-DMY_HEADER_DIR="x"' "-DMY_HEADER=\"$hdr\"" '-DMY_ROOT_DIR="x"' '-DMY_ANALYTICAL="x"'
+     -I$HERE/ref_headers -I$REF/ROMS/Include -I$REF/ROMS/Nonlinear -I$REF/ROMS/Utility -I$REF/ROMS/Modules)
+  local objs=""
+  for f in $FILES; do
+    local bn=$(basename $f)
+    cpp "${CPPF[@]}" $REF/ROMS/$f.F > $bn.f90
+    $FC $FFLAGS -c $bn.f90 -o $bn.o > $bn.log 2>&1 || { echo "[$APP] $f failed"; tail -5 $bn.log; exit 1; }
+    objs="$objs $bn.o"
+  done
+  cpp -P -traditional -w -D$APP $HERE/ref_wrap.F90 > ref_wrap_pp.f90
+  $FC $FFLAGS -c ref_wrap_pp.f90 -o ref_wrap.o > ref_wrap.log 2>&1 || { echo "[$APP] ref_wrap failed"; tail -20 ref_wrap.log; exit 1; }
+  $FC -shared -o libref.so $objs ref_wrap.o
+  rm -f *.f90            # keep no preprocessed reference text around
+  echo "[$APP] built $D/libref.so"
+}
+
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT}; do
+  build_app $app &
+done
+wait

@@ -1,0 +1,64 @@
+"""Front end of oracle/_ref/<APP>/libref.so -- the subset of the reference's own
+Fortran that compiles here (oracle/build_ref.sh) behind oracle/ref_wrap.F90.
+TEST INFRASTRUCTURE ONLY.  One process can hold one configuration (the
+reference keeps its state in module variables), so tests run it in a child."""
+import ctypes as C
+import os
+
+from roms_trunk_mgh_amd import abi
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+KERNEL_ID = {"set_depth": 1, "set_massflux": 2, "set_zeta": 3, "rho_eos": 4, "prsgrd": 5,
+             "t3dmix2": 6, "uv3dmix2": 7}
+
+
+def lib_path(app):
+    return os.path.join(_DIR, "_ref", app, "libref.so")
+
+
+def available(app):
+    return os.path.exists(lib_path(app))
+
+
+class Ref:
+    def __init__(self, state):
+        app = state.cfg["app"]
+        self.l = C.CDLL(lib_path(app))
+        self.st = state
+        self.l.ref_abi_sizeof.argtypes = [C.c_int]
+        want = [C.sizeof(abi.Bounds), C.sizeof(abi.Params), C.sizeof(abi.StepIdx), C.sizeof(abi.Fields)]
+        got = [self.l.ref_abi_sizeof(i) for i in range(4)]
+        if want != got:
+            raise RuntimeError(f"ref ABI mismatch python={want} fortran={got}")
+        self.l.ref_setup.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params)]
+        rc = self.l.ref_setup(C.byref(state.b), C.byref(state.p))
+        if rc != 0:
+            raise RuntimeError("ref_setup failed")
+        self.l.ref_call.argtypes = [C.c_int, C.POINTER(abi.Bounds), C.POINTER(abi.Params),
+                                    C.POINTER(abi.StepIdx), C.POINTER(abi.Fields)]
+        self.F = state.fields_struct()
+
+    def bounds(self):
+        out = (C.c_int * 50)()
+        self.l.ref_get_bounds(out)
+        names = ("LBi UBi LBj UBj Istr Iend Jstr Jend "
+                 "IstrB IendB IstrM IstrP IendP IstrR IendR IstrT IendT IstrU "
+                 "JstrB JendB JstrM JstrP JendP JstrR JendR JstrT JendT JstrV "
+                 "Istrm3 Istrm2 Istrm1 IstrUm2 IstrUm1 Iendp1 Iendp2 Iendp2i Iendp3 "
+                 "Jstrm3 Jstrm2 Jstrm1 JstrVm2 JstrVm1 Jendp1 Jendp2 Jendp2i Jendp3 "
+                 "west_edge east_edge south_edge north_edge").split()
+        return dict(zip(names, list(out)))
+
+    def set_weights(self, ndtfast):
+        import numpy as np
+        w1 = np.zeros(2 * ndtfast)
+        w2 = np.zeros(2 * ndtfast)
+        nf = C.c_int(0)
+        self.l.ref_set_weights.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        self.l.ref_set_weights(ndtfast, C.byref(nf), w1.ctypes.data, w2.ctypes.data)
+        return nf.value, w1, w2
+
+    def call(self, kernel, s):
+        rc = self.l.ref_call(KERNEL_ID[kernel], C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))
+        if rc != 0:
+            raise RuntimeError(f"ref_call {kernel} rc={rc}")

@@ -1,0 +1,342 @@
+!=======================================================================
+!  ref_wrap.F90 -- TEST INFRASTRUCTURE ONLY (our code, not the reference's).
+!
+!  bind(C) doorway to the reference objects that oracle/build_ref.sh compiles
+!  from /root/reference with flang.  It drives the reference through ITS OWN
+!  public API: allocate_param / initialize_param / allocate_scalars /
+!  initialize_scalars / initialize_parallel, get_domain_edges / get_tile /
+!  get_bounds exactly as inp_par.F:300-420 does, allocate_grid / _ocean /
+!  _coupling / _mixing / _forces, then the module procedures
+!  set_depth, set_massflux, set_zeta, rho_eos, prsgrd, t3dmix2, uv3dmix2,
+!  set_weights.  Arrays travel in the same roms_fields_t / roms_bounds_t /
+!  roms_params_t images as the C oracle uses (include/roms_hip.h).
+!  Serial build (no DISTRIBUTE): one tile covering the whole grid.
+!=======================================================================
+MODULE ref_wrap_types
+  USE, INTRINSIC :: iso_c_binding
+  IMPLICIT NONE
+  TYPE, BIND(C) :: bounds_t
+    INTEGER(c_int) :: Lm, Mm, N, NT, NAT
+    INTEGER(c_int) :: ntileI, ntileJ, tile, Itile, Jtile
+    INTEGER(c_int) :: NghostPoints, EWperiodic, NSperiodic
+    INTEGER(c_int) :: west_edge, east_edge, south_edge, north_edge
+    INTEGER(c_int) :: LBi, UBi, LBj, UBj
+    INTEGER(c_int) :: Istr, Iend, Jstr, Jend
+    INTEGER(c_int) :: IstrB, IendB, IstrM, IstrP, IendP, IstrR, IendR, IstrT, IendT, IstrU
+    INTEGER(c_int) :: JstrB, JendB, JstrM, JstrP, JendP, JstrR, JendR, JstrT, JendT, JstrV
+    INTEGER(c_int) :: Istrm3, Istrm2, Istrm1, IstrUm2, IstrUm1
+    INTEGER(c_int) :: Iendp1, Iendp2, Iendp2i, Iendp3
+    INTEGER(c_int) :: Jstrm3, Jstrm2, Jstrm1, JstrVm2, JstrVm1
+    INTEGER(c_int) :: Jendp1, Jendp2, Jendp2i, Jendp3
+  END TYPE bounds_t
+  TYPE, BIND(C) :: params_t
+    REAL(c_double) :: dt, dtfast, g, rho0, gamma2, lambda
+    INTEGER(c_int) :: ndtfast, nfast
+    REAL(c_double) :: weight1(256), weight2(256)
+    INTEGER(c_int) :: Vtransform
+    REAL(c_double) :: hc
+    REAL(c_double) :: sc_r(65), Cs_r(65), sc_w(65), Cs_w(65)
+    INTEGER(c_int) :: Hadv(16), Vadv(16)
+    INTEGER(c_int) :: lbc_west, lbc_east, lbc_south, lbc_north
+    INTEGER(c_int) :: nonlin_eos
+    REAL(c_double) :: R0, T0, S0, Tcoef, Scoef
+    INTEGER(c_int) :: uv_adv, uv_cor, uv_vis2, curvgrid, var_rho_2d
+    INTEGER(c_int) :: ts_dif2, mix_geo_ts, mix_s_ts, salinity, lmd_nonlocal, solar_source
+    INTEGER(c_int) :: splines_vdiff, splines_vvisc
+    REAL(c_double) :: Akt_bak(16), Akv_bak
+    REAL(c_double) :: swfrac_mu1, swfrac_mu2, swfrac_r1
+  END TYPE params_t
+  TYPE, BIND(C) :: stepidx_t
+    INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
+  END TYPE stepidx_t
+  !  order of include/roms_fields.def
+  TYPE, BIND(C) :: fields_t
+    TYPE(c_ptr) :: zeta, ubar, vbar, rzeta, rubar, rvbar, u, v, t, ru, rv, W, rho, pden
+    TYPE(c_ptr) :: h, f, fomn, pm, pn, om_r, on_r, om_u, on_u, om_v, on_v, om_p, on_p, omn
+    TYPE(c_ptr) :: pmon_r, pnom_r, pmon_p, pnom_p, pmon_u, pnom_u, pmon_v, pnom_v, dmde, dndx
+    TYPE(c_ptr) :: Hz, Huon, Hvom, z_r, z_w
+    TYPE(c_ptr) :: DU_avg1, DU_avg2, DV_avg1, DV_avg2, Zt_avg1, rufrc, rvfrc, rhoA, rhoS
+    TYPE(c_ptr) :: Akv, Akt, ghats, bvf, alpha, beta, visc2_p, visc2_r, diff2
+    TYPE(c_ptr) :: sustr, svstr, bustr, bvstr, srflx, stflx, btflx
+  END TYPE fields_t
+END MODULE ref_wrap_types
+
+!-----------------------------------------------------------------------
+FUNCTION ref_abi_sizeof (which) BIND(C, name='ref_abi_sizeof') RESULT(n)
+  USE ref_wrap_types
+  INTEGER(c_int), VALUE :: which
+  INTEGER(c_int) :: n
+  TYPE(bounds_t) :: b
+  TYPE(params_t) :: p
+  TYPE(stepidx_t) :: s
+  TYPE(fields_t) :: f
+  n = -1
+  IF (which == 0) n = INT(c_sizeof(b), c_int)
+  IF (which == 1) n = INT(c_sizeof(p), c_int)
+  IF (which == 2) n = INT(c_sizeof(s), c_int)
+  IF (which == 3) n = INT(c_sizeof(f), c_int)
+END FUNCTION ref_abi_sizeof
+
+!-----------------------------------------------------------------------
+!  Mirror of the start-up sequence of inp_par.F / read_phypar.F for one grid.
+FUNCTION ref_setup (b, p) BIND(C, name='ref_setup') RESULT(rc)
+  USE ref_wrap_types
+  USE mod_param
+  USE mod_parallel
+  USE mod_scalars
+  USE mod_iounits
+  USE mod_stepping, ONLY : allocate_stepping
+  USE mod_grid,     ONLY : allocate_grid
+  USE mod_ocean,    ONLY : allocate_ocean
+  USE mod_coupling, ONLY : allocate_coupling
+  USE mod_mixing,   ONLY : allocate_mixing
+  USE mod_forces,   ONLY : allocate_forces
+  TYPE(bounds_t), INTENT(in) :: b
+  TYPE(params_t), INTENT(in) :: p
+  INTEGER(c_int) :: rc
+  INTEGER :: ng, tile, Itile, Jtile, Nghost, k, LBi, UBi, LBj, UBj
+  LOGICAL, SAVE :: done = .FALSE.
+  rc = 0
+  IF (done) RETURN
+  done = .TRUE.
+  ng = 1
+  Ngrids = 1
+  CALL allocate_param
+  Lm(ng) = b%Lm;  Mm(ng) = b%Mm;  N(ng) = b%N
+  NtileI(ng) = 1; NtileJ(ng) = 1
+  NAT = b%NAT
+  CALL initialize_param
+  CALL initialize_parallel
+  CALL allocate_parallel (Ngrids)
+  CALL allocate_scalars
+  CALL initialize_scalars
+  CALL allocate_stepping (Ngrids)
+  EWperiodic(ng) = b%EWperiodic /= 0
+  NSperiodic(ng) = b%NSperiodic /= 0
+  NghostPoints = b%NghostPoints
+  !  inp_par.F:340-420
+  DO tile = -1, NtileI(ng)*NtileJ(ng)-1
+    CALL get_domain_edges (ng, tile,                                         &
+ &        DOMAIN(ng) % Eastern_Edge    (tile), DOMAIN(ng) % Western_Edge    (tile), &
+ &        DOMAIN(ng) % Northern_Edge   (tile), DOMAIN(ng) % Southern_Edge   (tile), &
+ &        DOMAIN(ng) % NorthEast_Corner(tile), DOMAIN(ng) % NorthWest_Corner(tile), &
+ &        DOMAIN(ng) % SouthEast_Corner(tile), DOMAIN(ng) % SouthWest_Corner(tile), &
+ &        DOMAIN(ng) % NorthEast_Test  (tile), DOMAIN(ng) % NorthWest_Test  (tile), &
+ &        DOMAIN(ng) % SouthEast_Test  (tile), DOMAIN(ng) % SouthWest_Test  (tile))
+  END DO
+  Nghost = NghostPoints
+  BOUNDS(ng) % LBij = 0
+  BOUNDS(ng) % UBij = MAX(Lm(ng)+1, Mm(ng)+1)
+  DO tile = -1, NtileI(ng)*NtileJ(ng)-1
+    BOUNDS(ng) % tile(tile) = tile
+    CALL get_tile (ng, tile, Itile, Jtile,                                    &
+ &     BOUNDS(ng) % Istr(tile),  BOUNDS(ng) % Iend(tile),  BOUNDS(ng) % Jstr(tile),  BOUNDS(ng) % Jend(tile),  &
+ &     BOUNDS(ng) % IstrM(tile), BOUNDS(ng) % IstrR(tile), BOUNDS(ng) % IstrU(tile), BOUNDS(ng) % IendR(tile), &
+ &     BOUNDS(ng) % JstrM(tile), BOUNDS(ng) % JstrR(tile), BOUNDS(ng) % JstrV(tile), BOUNDS(ng) % JendR(tile), &
+ &     BOUNDS(ng) % IstrB(tile), BOUNDS(ng) % IendB(tile), BOUNDS(ng) % IstrP(tile), BOUNDS(ng) % IendP(tile), &
+ &     BOUNDS(ng) % IstrT(tile), BOUNDS(ng) % IendT(tile),                                                     &
+ &     BOUNDS(ng) % JstrB(tile), BOUNDS(ng) % JendB(tile), BOUNDS(ng) % JstrP(tile), BOUNDS(ng) % JendP(tile), &
+ &     BOUNDS(ng) % JstrT(tile), BOUNDS(ng) % JendT(tile),                                                     &
+ &     BOUNDS(ng) % Istrm3(tile), BOUNDS(ng) % Istrm2(tile), BOUNDS(ng) % Istrm1(tile),                        &
+ &     BOUNDS(ng) % IstrUm2(tile), BOUNDS(ng) % IstrUm1(tile),                                                 &
+ &     BOUNDS(ng) % Iendp1(tile), BOUNDS(ng) % Iendp2(tile), BOUNDS(ng) % Iendp2i(tile), BOUNDS(ng) % Iendp3(tile), &
+ &     BOUNDS(ng) % Jstrm3(tile), BOUNDS(ng) % Jstrm2(tile), BOUNDS(ng) % Jstrm1(tile),                        &
+ &     BOUNDS(ng) % JstrVm2(tile), BOUNDS(ng) % JstrVm1(tile),                                                 &
+ &     BOUNDS(ng) % Jendp1(tile), BOUNDS(ng) % Jendp2(tile), BOUNDS(ng) % Jendp2i(tile), BOUNDS(ng) % Jendp3(tile))
+    CALL get_bounds (ng, tile, 0, Nghost, Itile, Jtile,                        &
+ &     BOUNDS(ng) % LBi(tile), BOUNDS(ng) % UBi(tile), BOUNDS(ng) % LBj(tile), BOUNDS(ng) % UBj(tile))
+  END DO
+  !  scalars the kernels read (read_phypar.F would set them from roms_*.in)
+  dt(ng) = p%dt
+  g = p%g
+  rho0 = p%rho0
+  Vtransform(ng) = p%Vtransform
+  hc(ng) = p%hc
+  DO k = 1, N(ng)
+    SCALARS(ng) % sc_r(k) = p%sc_r(k+1)
+    SCALARS(ng) % Cs_r(k) = p%Cs_r(k+1)
+  END DO
+  DO k = 0, N(ng)
+    SCALARS(ng) % sc_w(k) = p%sc_w(k+1)
+    SCALARS(ng) % Cs_w(k) = p%Cs_w(k+1)
+  END DO
+  R0(ng) = p%R0; T0(ng) = p%T0; S0(ng) = p%S0; Tcoef(ng) = p%Tcoef; Scoef(ng) = p%Scoef
+  LBi = BOUNDS(ng)%LBi(0); UBi = BOUNDS(ng)%UBi(0); LBj = BOUNDS(ng)%LBj(0); UBj = BOUNDS(ng)%UBj(0)
+  CALL allocate_grid (ng, LBi, UBi, LBj, UBj, BOUNDS(ng)%LBij, BOUNDS(ng)%UBij)
+  CALL allocate_ocean (ng, LBi, UBi, LBj, UBj)
+  CALL allocate_coupling (ng, LBi, UBi, LBj, UBj)
+  CALL allocate_mixing (ng, LBi, UBi, LBj, UBj)
+  CALL allocate_forces (ng, LBi, UBi, LBj, UBj)
+END FUNCTION ref_setup
+
+!-----------------------------------------------------------------------
+!  BOUNDS(ng)%...(tile 0) in the order of roms_bounds_t from Istr on.
+SUBROUTINE ref_get_bounds (out) BIND(C, name='ref_get_bounds')
+  USE ref_wrap_types
+  USE mod_param
+  INTEGER(c_int), INTENT(out) :: out(0:49)
+  INTEGER :: t
+  t = 0
+  out(0:3)   = (/ BOUNDS(1)%LBi(t), BOUNDS(1)%UBi(t), BOUNDS(1)%LBj(t), BOUNDS(1)%UBj(t) /)
+  out(4:7)   = (/ BOUNDS(1)%Istr(t), BOUNDS(1)%Iend(t), BOUNDS(1)%Jstr(t), BOUNDS(1)%Jend(t) /)
+  out(8:17)  = (/ BOUNDS(1)%IstrB(t), BOUNDS(1)%IendB(t), BOUNDS(1)%IstrM(t), BOUNDS(1)%IstrP(t),      &
+ &               BOUNDS(1)%IendP(t), BOUNDS(1)%IstrR(t), BOUNDS(1)%IendR(t), BOUNDS(1)%IstrT(t),      &
+ &               BOUNDS(1)%IendT(t), BOUNDS(1)%IstrU(t) /)
+  out(18:27) = (/ BOUNDS(1)%JstrB(t), BOUNDS(1)%JendB(t), BOUNDS(1)%JstrM(t), BOUNDS(1)%JstrP(t),      &
+ &               BOUNDS(1)%JendP(t), BOUNDS(1)%JstrR(t), BOUNDS(1)%JendR(t), BOUNDS(1)%JstrT(t),      &
+ &               BOUNDS(1)%JendT(t), BOUNDS(1)%JstrV(t) /)
+  out(28:32) = (/ BOUNDS(1)%Istrm3(t), BOUNDS(1)%Istrm2(t), BOUNDS(1)%Istrm1(t), BOUNDS(1)%IstrUm2(t), BOUNDS(1)%IstrUm1(t) /)
+  out(33:36) = (/ BOUNDS(1)%Iendp1(t), BOUNDS(1)%Iendp2(t), BOUNDS(1)%Iendp2i(t), BOUNDS(1)%Iendp3(t) /)
+  out(37:41) = (/ BOUNDS(1)%Jstrm3(t), BOUNDS(1)%Jstrm2(t), BOUNDS(1)%Jstrm1(t), BOUNDS(1)%JstrVm2(t), BOUNDS(1)%JstrVm1(t) /)
+  out(42:45) = (/ BOUNDS(1)%Jendp1(t), BOUNDS(1)%Jendp2(t), BOUNDS(1)%Jendp2i(t), BOUNDS(1)%Jendp3(t) /)
+  out(46:49) = (/ MERGE(1,0,DOMAIN(1)%Western_Edge(t)), MERGE(1,0,DOMAIN(1)%Eastern_Edge(t)),         &
+ &               MERGE(1,0,DOMAIN(1)%Southern_Edge(t)), MERGE(1,0,DOMAIN(1)%Northern_Edge(t)) /)
+END SUBROUTINE ref_get_bounds
+
+!-----------------------------------------------------------------------
+!  set_weights (ROMS/Utility/set_weights.F:3)
+SUBROUTINE ref_set_weights (ndtfast_in, nfast_out, w1, w2) BIND(C, name='ref_set_weights')
+  USE ref_wrap_types
+  USE mod_param
+  USE mod_scalars
+  USE mod_iounits
+  INTEGER(c_int), VALUE :: ndtfast_in
+  INTEGER(c_int), INTENT(out) :: nfast_out
+  REAL(c_double), INTENT(out) :: w1(2*ndtfast_in), w2(2*ndtfast_in)
+  INTEGER :: i
+  ndtfast(1) = ndtfast_in
+  IF (allocated(weight)) deallocate (weight)
+  allocate ( weight(2, 0:256, 1) )
+  weight = 0.0_r8
+  LwrtInfo(1) = .FALSE.
+  CALL set_weights (1)
+  nfast_out = nfast(1)
+  DO i = 1, 2*ndtfast_in
+    w1(i) = weight(1,i,1)
+    w2(i) = weight(2,i,1)
+  END DO
+END SUBROUTINE ref_set_weights
+
+!-----------------------------------------------------------------------
+!  Run one reference module procedure on the arrays of F (copied into the
+!  reference's module state, results copied back).
+!  kernel: 1 set_depth  2 set_massflux  3 set_zeta  4 rho_eos  5 prsgrd
+!          6 t3dmix2    7 uv3dmix2
+FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
+  USE ref_wrap_types
+  USE mod_param
+  USE mod_scalars
+  USE mod_stepping
+  USE mod_grid
+  USE mod_ocean
+  USE mod_coupling
+  USE mod_mixing
+  USE set_depth_mod,    ONLY : set_depth
+  USE set_massflux_mod, ONLY : set_massflux
+  USE set_zeta_mod,     ONLY : set_zeta
+  USE rho_eos_mod,      ONLY : rho_eos
+  USE prsgrd_mod,       ONLY : prsgrd
+  USE t3dmix2_mod,      ONLY : t3dmix2
+  USE uv3dmix2_mod,     ONLY : uv3dmix2
+  INTEGER(c_int), VALUE :: kernel
+  TYPE(bounds_t), INTENT(in) :: b
+  TYPE(params_t), INTENT(in) :: p
+  TYPE(stepidx_t), INTENT(in) :: s
+  TYPE(fields_t), INTENT(in) :: F
+  INTEGER(c_int) :: rc
+  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT
+  REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:), a5(:,:,:,:,:)
+  ng = 1; tile = 0
+  LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
+  ni = UBi-LBi+1; nj = UBj-LBj+1; NN = b%N; NTT = b%NT
+  rc = 0
+  IF (LBi /= BOUNDS(ng)%LBi(0) .OR. UBi /= BOUNDS(ng)%UBi(0) .OR. LBj /= BOUNDS(ng)%LBj(0) .OR. UBj /= BOUNDS(ng)%UBj(0)) THEN
+    rc = 1
+    RETURN
+  END IF
+  nstp(ng) = s%nstp; nnew(ng) = s%nnew; nrhs(ng) = s%nrhs
+  dt(ng) = p%dt
+  ! ---- copy in ----
+  CALL c_f_pointer (F%h, a2, (/ni,nj/));        GRID(ng)%h = a2
+  CALL c_f_pointer (F%pm, a2, (/ni,nj/));       GRID(ng)%pm = a2
+  CALL c_f_pointer (F%pn, a2, (/ni,nj/));       GRID(ng)%pn = a2
+  CALL c_f_pointer (F%om_u, a2, (/ni,nj/));     GRID(ng)%om_u = a2
+  CALL c_f_pointer (F%on_u, a2, (/ni,nj/));     GRID(ng)%on_u = a2
+  CALL c_f_pointer (F%om_v, a2, (/ni,nj/));     GRID(ng)%om_v = a2
+  CALL c_f_pointer (F%on_v, a2, (/ni,nj/));     GRID(ng)%on_v = a2
+  CALL c_f_pointer (F%om_r, a2, (/ni,nj/));     GRID(ng)%om_r = a2
+  CALL c_f_pointer (F%on_r, a2, (/ni,nj/));     GRID(ng)%on_r = a2
+  CALL c_f_pointer (F%om_p, a2, (/ni,nj/));     GRID(ng)%om_p = a2
+  CALL c_f_pointer (F%on_p, a2, (/ni,nj/));     GRID(ng)%on_p = a2
+  CALL c_f_pointer (F%pmon_r, a2, (/ni,nj/));   GRID(ng)%pmon_r = a2
+  CALL c_f_pointer (F%pnom_r, a2, (/ni,nj/));   GRID(ng)%pnom_r = a2
+  CALL c_f_pointer (F%pmon_p, a2, (/ni,nj/));   GRID(ng)%pmon_p = a2
+  CALL c_f_pointer (F%pnom_p, a2, (/ni,nj/));   GRID(ng)%pnom_p = a2
+  CALL c_f_pointer (F%pmon_u, a2, (/ni,nj/));   GRID(ng)%pmon_u = a2
+  CALL c_f_pointer (F%pnom_v, a2, (/ni,nj/));   GRID(ng)%pnom_v = a2
+  CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
+  CALL c_f_pointer (F%Huon, a3, (/ni,nj,NN/));  GRID(ng)%Huon = a3
+  CALL c_f_pointer (F%Hvom, a3, (/ni,nj,NN/));  GRID(ng)%Hvom = a3
+  CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
+  CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); GRID(ng)%z_w = a3
+  CALL c_f_pointer (F%zeta, a3, (/ni,nj,3/));   OCEAN(ng)%zeta = a3
+  CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   OCEAN(ng)%u = a4
+  CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   OCEAN(ng)%v = a4
+  CALL c_f_pointer (F%ru, a4, (/ni,nj,NN+1,2/)); OCEAN(ng)%ru = a4
+  CALL c_f_pointer (F%rv, a4, (/ni,nj,NN+1,2/)); OCEAN(ng)%rv = a4
+  CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); OCEAN(ng)%t = a5
+  CALL c_f_pointer (F%rho, a3, (/ni,nj,NN/));   OCEAN(ng)%rho = a3
+  CALL c_f_pointer (F%pden, a3, (/ni,nj,NN/));  OCEAN(ng)%pden = a3
+  CALL c_f_pointer (F%Zt_avg1, a2, (/ni,nj/));  COUPLING(ng)%Zt_avg1 = a2
+  CALL c_f_pointer (F%rufrc, a2, (/ni,nj/));    COUPLING(ng)%rufrc = a2
+  CALL c_f_pointer (F%rvfrc, a2, (/ni,nj/));    COUPLING(ng)%rvfrc = a2
+  CALL c_f_pointer (F%rhoA, a2, (/ni,nj/));     COUPLING(ng)%rhoA = a2
+  CALL c_f_pointer (F%rhoS, a2, (/ni,nj/));     COUPLING(ng)%rhoS = a2
+#if defined BENCHMARK || defined UPWELLING
+  CALL c_f_pointer (F%visc2_p, a2, (/ni,nj/));  MIXING(ng)%visc2_p = a2
+  CALL c_f_pointer (F%visc2_r, a2, (/ni,nj/));  MIXING(ng)%visc2_r = a2
+#endif
+  CALL c_f_pointer (F%diff2, a3, (/ni,nj,NTT/)); MIXING(ng)%diff2 = a3
+#ifdef BENCHMARK
+  CALL c_f_pointer (F%bvf, a3, (/ni,nj,NN+1/)); MIXING(ng)%bvf = a3
+  CALL c_f_pointer (F%alpha, a2, (/ni,nj/));    MIXING(ng)%alpha = a2
+  CALL c_f_pointer (F%beta, a2, (/ni,nj/));     MIXING(ng)%beta = a2
+#endif
+  ! ---- the reference procedure ----
+  SELECT CASE (kernel)
+  CASE (1); CALL set_depth (ng, tile, iNLM)
+  CASE (2); CALL set_massflux (ng, tile, iNLM)
+  CASE (3); CALL set_zeta (ng, tile)
+  CASE (4); CALL rho_eos (ng, tile, iNLM)
+  CASE (5); CALL prsgrd (ng, tile)
+  CASE (6); CALL t3dmix2 (ng, tile)
+#if defined BENCHMARK || defined UPWELLING
+  CASE (7); CALL uv3dmix2 (ng, tile)
+#endif
+  CASE DEFAULT; rc = 2
+  END SELECT
+  ! ---- copy out ----
+  CALL c_f_pointer (F%h, a2, (/ni,nj/));        a2 = GRID(ng)%h
+  CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    a3 = GRID(ng)%Hz
+  CALL c_f_pointer (F%Huon, a3, (/ni,nj,NN/));  a3 = GRID(ng)%Huon
+  CALL c_f_pointer (F%Hvom, a3, (/ni,nj,NN/));  a3 = GRID(ng)%Hvom
+  CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   a3 = GRID(ng)%z_r
+  CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); a3 = GRID(ng)%z_w
+  CALL c_f_pointer (F%zeta, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%zeta
+  CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   a4 = OCEAN(ng)%u
+  CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   a4 = OCEAN(ng)%v
+  CALL c_f_pointer (F%ru, a4, (/ni,nj,NN+1,2/)); a4 = OCEAN(ng)%ru
+  CALL c_f_pointer (F%rv, a4, (/ni,nj,NN+1,2/)); a4 = OCEAN(ng)%rv
+  CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); a5 = OCEAN(ng)%t
+  CALL c_f_pointer (F%rho, a3, (/ni,nj,NN/));   a3 = OCEAN(ng)%rho
+  CALL c_f_pointer (F%pden, a3, (/ni,nj,NN/));  a3 = OCEAN(ng)%pden
+  CALL c_f_pointer (F%rufrc, a2, (/ni,nj/));    a2 = COUPLING(ng)%rufrc
+  CALL c_f_pointer (F%rvfrc, a2, (/ni,nj/));    a2 = COUPLING(ng)%rvfrc
+  CALL c_f_pointer (F%rhoA, a2, (/ni,nj/));     a2 = COUPLING(ng)%rhoA
+  CALL c_f_pointer (F%rhoS, a2, (/ni,nj/));     a2 = COUPLING(ng)%rhoS
+#ifdef BENCHMARK
+  CALL c_f_pointer (F%bvf, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%bvf
+  CALL c_f_pointer (F%alpha, a2, (/ni,nj/));    a2 = MIXING(ng)%alpha
+  CALL c_f_pointer (F%beta, a2, (/ni,nj/));     a2 = MIXING(ng)%beta
+#endif
+END FUNCTION ref_call

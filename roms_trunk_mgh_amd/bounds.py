@@ -81,11 +81,15 @@ def make_bounds(Lm, Mm, N, NT, NAT, ntileI=1, ntileJ=1, tile=0,
     di = _var_bounds_1d(Istr, Iend, west, east, EWperiodic, Lm)
     dj = _var_bounds_1d(Jstr, Jend, south, north, NSperiodic, Mm)
 
-    # get_bounds.F:20-183, gtype=0 branch (full extents incl. ghost points)
+    # get_bounds.F:20-183, gtype=0 branch (full extents incl. ghost points).
+    # Im, Jm carry the reference's even-size padding (mod_param.F initialize_param:
+    # I_padd=(Lm+2)/2-(Lm+1)/2, Im=Lm+I_padd), so an even Lm allocates one spare column.
+    Im = Lm + ((Lm + 2) // 2 - (Lm + 1) // 2)
+    Jm = Mm + ((Mm + 2) // 2 - (Mm + 1) // 2)
     Imin = -NghostPoints if EWperiodic else 0
-    Imax = Lm + NghostPoints if EWperiodic else Lm + 1
+    Imax = Im + NghostPoints if EWperiodic else Im + 1
     Jmin = -NghostPoints if NSperiodic else 0
-    Jmax = Mm + NghostPoints if NSperiodic else Mm + 1
+    Jmax = Jm + NghostPoints if NSperiodic else Jm + 1
     LBi = Imin if Itile == 0 else Istr - NghostPoints
     UBi = Imax if Itile == ntileI - 1 else Iend + NghostPoints
     LBj = Jmin if Jtile == 0 else Jstr - NghostPoints

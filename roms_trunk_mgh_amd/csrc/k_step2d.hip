@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k2d_flux(const RomsDev *__restrict__ c, S2 s, double *__restrict__ DUon, double *__restrict__ DVom)
 {
   DEV_PROLOGUE(c)
-  const int i0 = s.sm ? b.LBi : b.IstrU - 2, i1 = s.sm ? b.UBi : b.Iendp2;
+  const int i0 = s.sm ? b.LBi : b.IstrU - 2, i1 = s.sm ? (b.Lm + b.NghostPoints) : b.Iendp2;
   const int i = i0 + blockIdx.x * BLK_X + threadIdx.x;
   const int j = b.JstrV - 2 + blockIdx.y * BLK_Y + threadIdx.y;
   if (i > i1 || j > b.Jendp2) return;
@@ -131,7 +131,7 @@ k2d_zeta_sm(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   DEV_PROLOGUE(c)
   const int i = b.LBi + blockIdx.x * BLK_X + threadIdx.x;
   const int j = b.LBj + blockIdx.y * BLK_Y + threadIdx.y;
-  if (i > b.UBi || j > b.UBj) return;
+  if (i > b.Lm + b.NghostPoints || j > b.UBj) return;
   const roms_params_t &p = c->p;
   const int iif = s.iif, nfast = p.nfast;
   const long o = I2(i, j);
@@ -287,7 +287,7 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
   } else {
     it = b.LBi + blockIdx.x * BLK_X + threadIdx.x;
     jt = b.LBj + blockIdx.y * BLK_Y + threadIdx.y;
-    if (it > b.UBi || jt > b.UBj) return;
+    if (it > b.Lm + b.NghostPoints || jt > b.UBj) return;
     i = wrap_i(b, it);
     j = jt;
     if (b.south_edge && jt == b.Jstr - 1) { j = b.Jstr; fu = p.gamma2; }

@@ -85,7 +85,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const roms_params_t &p = c->p;
   __shared__ double sU[TJ * TP], sV[TJ * TP], sDU[TJ * TP], sDV[TJ * TP], sD[TJ * TP];
   const int ibase = s.sm ? b.LBi : b.Istr;
-  const int ilast = s.sm ? b.UBi : b.Iend;
+  const int ilast = s.sm ? (b.Lm + b.NghostPoints) : b.Iend;
   const int it0 = ibase + blockIdx.x * BLK_X, j0 = b.Jstr + blockIdx.y * BLK_Y;
   const int it = it0 + threadIdx.x, j = j0 + threadIdx.y;
   const double *__restrict__ ubk = c->F.ubar + (long)(s.krhs - 1) * nij;

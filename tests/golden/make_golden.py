@@ -1,0 +1,83 @@
+"""Generates tests/golden/ref_<CONFIG>.npz from the REFERENCE's own Fortran
+(oracle/_ref/<APP>/libref.so = files of /root/reference compiled with flang by
+oracle/build_ref.sh; see oracle/ref_wrap.F90).  Run in this container:
+
+    python tests/golden/make_golden.py
+
+For every kernel the reference can run here, the inputs are the seeded state of
+tests/util.prepared_state (deterministic; a checksum of the inputs is stored) and
+the stored vectors are the reference OUTPUT arrays that the kernel changed.
+One child process per configuration (the reference keeps module state)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CONFIGS = ["BENCHMARK_TINY", "UPWELLING", "SEAMOUNT"]
+OVERRIDES = {"BENCHMARK_TINY": {"tnu2": 300.0, "visc2": 800.0}, "UPWELLING": {"tnu2": 300.0, "visc2": 800.0},
+             "SEAMOUNT": {"tnu2": 300.0}}
+KERNELS = ["set_depth", "set_massflux", "set_zeta", "rho_eos", "prsgrd", "t3dmix2", "uv3dmix2"]
+
+
+def input_state(config):
+    import util
+    st = util.prepared_state(config, overrides=OVERRIDES[config])
+    st["Zt_avg1"] *= 1.3
+    st["u"] *= 1.1
+    return st
+
+
+def checksum(st):
+    h = hashlib.sha256()
+    for name in sorted(st.arr):
+        h.update(np.ascontiguousarray(st.arr[name]).tobytes())
+    return h.hexdigest()
+
+
+def child(config):
+    import util
+    from oracle import ref
+    from roms_trunk_mgh_amd import abi
+    st0 = input_state(config)
+    out = {"input_sha256": np.array(checksum(st0))}
+    r0 = ref.Ref(st0.copy())
+    bb = r0.bounds()
+    out["bounds_names"] = np.array(sorted(bb))
+    out["bounds_values"] = np.array([bb[k] for k in sorted(bb)], dtype=np.int64)
+    nf, w1, w2 = r0.set_weights(st0.p.ndtfast)
+    out["nfast"] = np.array(nf)
+    out["weight1"], out["weight2"] = w1, w2
+    s = util.step_idx()
+    for k in KERNELS:
+        if k == "uv3dmix2" and config == "SEAMOUNT":
+            continue
+        st = st0.copy()
+        ref.Ref(st).call(k, s)
+        for name, kind, _ in abi.FIELDS:
+            a, a0 = st[name], st0[name]
+            if np.array_equal(a, a0):
+                continue
+            # store only the horizontal-plane stacks (trailing time level / tracer) that changed
+            nplane = a.shape[0] * a.shape[1] * (a.shape[2] if a.ndim > 3 else 1)
+            fa = a.reshape((nplane, -1), order="F")
+            f0 = a0.reshape((nplane, -1), order="F")
+            for q in range(fa.shape[1]):
+                if not np.array_equal(fa[:, q], f0[:, q]):
+                    out[f"{k}__{name}__{q}"] = fa[:, q].copy()
+    np.savez_compressed(os.path.join(HERE, f"ref_{config}.npz"), **out)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        child(sys.argv[1])
+    else:
+        for c in CONFIGS:
+            subprocess.run([sys.executable, os.path.abspath(__file__), c], check=True)
+            print(c, os.path.getsize(os.path.join(HERE, f"ref_{c}.npz")) // 1024, "KiB")

@@ -1,5 +1,7 @@
-"""CPU: tile bounds (mirror of get_bounds.F) -- hand-derived expectations from
-get_bounds.F:1348-1853 and structural properties for several tilings."""
+"""CPU: tile bounds (mirror of get_bounds.F) -- expectations derived from
+get_bounds.F:1348-1853 / mod_param.F initialize_param, confirmed against the
+flang build of the reference's own get_tile/get_bounds (tests/test_ref_pinning.py),
+plus structural properties for several tilings."""
 import pytest
 
 from roms_trunk_mgh_amd.bounds import make_bounds, tile_bounds_2d
@@ -7,7 +9,8 @@ from roms_trunk_mgh_amd.bounds import make_bounds, tile_bounds_2d
 
 def test_single_tile_periodic_ew_closed_ns():
     b = make_bounds(512, 64, 30, 2, 2)
-    assert (b.LBi, b.UBi, b.LBj, b.UBj) == (-2, 514, 0, 65)           # -2:514 x 0:65
+    # even Lm/Mm allocate one spare column/row: Im = Lm+1, Jm = Mm+1 (mod_param.F initialize_param)
+    assert (b.LBi, b.UBi, b.LBj, b.UBj) == (-2, 515, 0, 66)
     assert (b.Istr, b.Iend, b.Jstr, b.Jend) == (1, 512, 1, 64)
     # periodic in i: no special u-range; closed in j: JstrV = Jstr+1
     assert (b.IstrU, b.IstrR, b.IendR, b.IstrT, b.IendT) == (1, 1, 512, 1, 512)
@@ -17,9 +20,14 @@ def test_single_tile_periodic_ew_closed_ns():
     assert (b.west_edge, b.east_edge, b.south_edge, b.north_edge) == (1, 1, 1, 1)
 
 
+def test_odd_sizes_have_no_padding():
+    b = make_bounds(41, 81, 16, 2, 2)
+    assert (b.LBi, b.UBi, b.LBj, b.UBj) == (-2, 43, 0, 82)
+
+
 def test_three_ghost_points():
-    b = make_bounds(64, 32, 10, 6, 2, NghostPoints=3)
-    assert (b.LBi, b.UBi, b.LBj, b.UBj) == (-3, 67, 0, 33)
+    b = make_bounds(63, 31, 10, 6, 2, NghostPoints=3)
+    assert (b.LBi, b.UBi, b.LBj, b.UBj) == (-3, 66, 0, 32)
 
 
 @pytest.mark.parametrize("nI,nJ", [(2, 1), (4, 1), (4, 2), (2, 2), (3, 2)])
@@ -36,9 +44,9 @@ def test_tiles_partition_the_domain(nI, nJ):
         seen |= cells
         # allocated extents = tile + ghost points (get_bounds.F:164-183), physical edge otherwise
         assert b.LBi == (-2 if b.Itile == 0 else b.Istr - 2)
-        assert b.UBi == (Lm + 2 if b.Itile == nI - 1 else b.Iend + 2)
+        assert b.UBi == (Lm + 1 + 2 if b.Itile == nI - 1 else b.Iend + 2)
         assert b.LBj == (0 if b.Jtile == 0 else b.Jstr - 2)
-        assert b.UBj == (Mm + 1 if b.Jtile == nJ - 1 else b.Jend + 2)
+        assert b.UBj == (Mm + 1 + 1 if b.Jtile == nJ - 1 else b.Jend + 2)
         # interior tile edges never shift the U/V/R ranges
         if b.Jtile > 0:
             assert b.JstrV == b.Jstr and b.JstrR == b.Jstr

@@ -1,0 +1,80 @@
+"""Golden vectors produced by the REFERENCE's own Fortran (tests/golden/
+make_golden.py, from oracle/_ref) -- they travel with the repo, the reference does
+not.  CPU: the C oracle reproduces them bit for bit.  GPU (-m gpu): so does the
+HIP path through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CONFIGS = ["BENCHMARK_TINY", "UPWELLING", "SEAMOUNT"]
+
+
+def _load(config):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(HERE, "golden", f"ref_{config}.npz"))
+    st0 = mg.input_state(config)
+    assert mg.checksum(st0) == str(g["input_sha256"]), "seeded inputs changed: regenerate the fixtures"
+    return g, st0, mg
+
+
+def _check(st, st0, g, kernel, tol=0.0):
+    keys = [k for k in g.files if k.startswith(kernel + "__")]
+    assert keys, kernel
+    worst = 0.0
+    for key in keys:
+        _, name, q = key.split("__")
+        a = st[name]
+        nplane = a.shape[0] * a.shape[1] * (a.shape[2] if a.ndim > 3 else 1)
+        got = a.reshape((nplane, -1), order="F")[:, int(q)]
+        want = g[key]
+        scale = max(float(np.abs(want).max()), 1e-300)
+        worst = max(worst, float(np.abs(got - want).max()) / scale)
+    assert worst <= tol, (kernel, worst)
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+def test_oracle_reproduces_reference_vectors(config):
+    import oracle
+    from roms_trunk_mgh_amd import bounds as B
+    g, st0, mg = _load(config)
+    # tile bounds and barotropic filter weights from the reference's get_tile / set_weights
+    mine = st0.b.as_dict()
+    for k, v in zip(g["bounds_names"], g["bounds_values"]):
+        assert mine[str(k)] == int(v), k
+    assert int(g["nfast"]) == st0.p.nfast
+    n2 = 2 * st0.p.ndtfast
+    assert max(abs(g["weight1"][i] - st0.p.weight1[i]) for i in range(n2)) < 1e-15
+    assert max(abs(g["weight2"][i] - st0.p.weight2[i]) for i in range(n2)) < 1e-15
+    s = util.step_idx()
+    for k in mg.KERNELS:
+        if k == "uv3dmix2" and config == "SEAMOUNT":
+            continue
+        st = st0.copy()
+        oracle.Oracle(st).call(k, s)
+        _check(st, st0, g, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", CONFIGS)
+def test_hip_reproduces_reference_vectors(config):
+    from roms_trunk_mgh_amd import hip
+    g, st0, mg = _load(config)
+    s = util.step_idx()
+    for k in mg.KERNELS:
+        if k == "uv3dmix2" and config == "SEAMOUNT":
+            continue
+        st = st0.copy()
+        h = hip.RomsHip(st)
+        try:
+            h.call(k, s)
+            h.to_host()
+        finally:
+            h.close()
+        _check(st, st0, g, k, tol=1e-13)

@@ -59,4 +59,7 @@ def test_tiled_equals_single(tmp_path, ntI, ntJ, config):
             own = (slice(Istr - LBi, Iend - LBi + 1), slice(Jstr - LBj, Jend - LBj + 1))
             assert np.array_equal(a[own], want[own]), (name, r, float(np.abs(a[own] - want[own]).max()))
             if name in ("zeta", "t", "Hz", "W"):      # rho-type: every ghost point is defined
-                assert np.array_equal(a, want), (name, r, "ghost points differ")
+                # (not the reference's spare padding column/row of even-sized grids, Im=Lm+1/Jm=Mm+1)
+                iv = min(ni, rb.Lm + rb.NghostPoints - LBi + 1)
+                jv = min(nj, rb.Mm + 1 - LBj + 1)
+                assert np.array_equal(a[:iv, :jv], want[:iv, :jv]), (name, r, "ghost points differ")
