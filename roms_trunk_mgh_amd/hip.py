@@ -79,10 +79,14 @@ class RomsHip:
     the caller's (as the Fortran module arrays do)."""
 
     name = "hip"
+    _live = None
 
     def __init__(self, state, rank=0, device=0, nccl_unique_id=None):
         self.st = state
         self.l = load()
+        if RomsHip._live is not None:
+            RomsHip._live.close()
+        RomsHip._live = self
         b = state.b
         uid = None
         if nccl_unique_id is not None:
@@ -135,10 +139,14 @@ class RomsHip:
         return self.l.roms_hip_timing_last_ms(entry.encode())
 
     def close(self):
-        self.l.roms_hip_finalize()
+        # the library holds ONE context per process: only its current owner may tear it down
+        # (a stale object being garbage-collected must not finalize its successor's context)
+        if RomsHip._live is self:
+            RomsHip._live = None
+            self.l.roms_hip_finalize()
 
     def __del__(self):
         try:
-            self.l.roms_hip_finalize()
+            self.close()
         except Exception:
             pass
