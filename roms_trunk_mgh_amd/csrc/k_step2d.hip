@@ -38,8 +38,7 @@ __device__ __forceinline__ int wrap_i(const roms_bounds_t &b, int i)
   return (i < 1) ? i + b.Lm : ((i > b.Lm) ? i - b.Lm : i);
 }
 
-__device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const S2 &s,
-                                           const double *__restrict__ DUon, const double *__restrict__ DVom,
+__device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const S2 &s, const double rhs,
                                            double *__restrict__ zeta_new, double *__restrict__ zwrk, long a, long o,
                                            bool write_scratch, bool write_zeta, bool write_rzeta, long nij, long ni);
 
@@ -116,7 +115,8 @@ k2d_zeta(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, c
   // ---- free surface, :770-868 ----
   if (i < b.IstrU - 1 || i > b.Iend || j < b.JstrV - 1 || j > b.Jend) return;
   const bool own = i >= b.Istr && j >= b.Jstr;
-  zeta_point(c, s, DUon, DVom, zeta_new, zwrk, a, a, true, own, own, nij, ni);
+  const double rhs = (DUon[a] - DUon[a + 1]) + (DVom[a] - DVom[a + ni]);
+  zeta_point(c, s, rhs, zeta_new, zwrk, a, a, true, own, own, nij, ni);
 }
 
 // Source-mapped variant (single tile, E-W periodic, closed N-S walls): one
@@ -135,6 +135,24 @@ k2d_zeta_sm(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const roms_params_t &p = c->p;
   const int iif = s.iif, nfast = p.nfast;
   const long o = I2(i, j);
+  // DUon / DVom (:509-544): from scratch, or -- when k2d_flux was not launched (DUon == nullptr) --
+  // evaluated in place with the same expression, so no separate flux kernel is needed
+  const double *__restrict__ zkq = c->F.zeta + (long)(s.krhs - 1) * nij;
+  const double *__restrict__ hq = c->F.h;
+  const double *__restrict__ ubq = c->F.ubar + (long)(s.krhs - 1) * nij;
+  const double *__restrict__ vbq = c->F.vbar + (long)(s.krhs - 1) * nij;
+  auto du = [&](long q) -> double {
+    if (DUon) return DUon[q];
+    const double cff = 0.5 * c->F.on_u[q];
+    const double cff1 = cff * ((zkq[q] + hq[q]) + (zkq[q - 1] + hq[q - 1]));
+    return ubq[q] * cff1;
+  };
+  auto dv = [&](long q) -> double {
+    if (DVom) return DVom[q];
+    const double cff = 0.5 * c->F.om_v[q];
+    const double cff1 = cff * ((zkq[q] + hq[q]) + (zkq[q - ni] + hq[q - ni]));
+    return vbq[q] * cff1;
+  };
   // ---- fast-time averaging on the owned ranges only, :614-682 ----
   if (i >= b.IstrR && i <= b.IendR && j >= b.JstrR && j <= b.JendR) {
     const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
@@ -143,25 +161,25 @@ k2d_zeta_sm(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       if (iif == 1) {
         const double cff2 = (-1.0 / 12.0) * p.weight2[iif];
         c->F.Zt_avg1[o] = 0.0;
-        if (inU) { c->F.DU_avg1[o] = 0.0; c->F.DU_avg2[o] = cff2 * DUon[o]; }
-        if (inV) { c->F.DV_avg1[o] = 0.0; c->F.DV_avg2[o] = cff2 * DVom[o]; }
+        if (inU) { c->F.DU_avg1[o] = 0.0; c->F.DU_avg2[o] = cff2 * du(o); }
+        if (inV) { c->F.DV_avg1[o] = 0.0; c->F.DV_avg2[o] = cff2 * dv(o); }
       } else {
         const double cff1 = p.weight1[iif - 2];
         const double cff2 = (8.0 / 12.0) * p.weight2[iif - 1] - (1.0 / 12.0) * p.weight2[iif];
         c->F.Zt_avg1[o] = c->F.Zt_avg1[o] + cff1 * zk[o];
         if (inU) {
-          c->F.DU_avg1[o] = c->F.DU_avg1[o] + cff1 * DUon[o];
-          c->F.DU_avg2[o] = c->F.DU_avg2[o] + cff2 * DUon[o];
+          c->F.DU_avg1[o] = c->F.DU_avg1[o] + cff1 * du(o);
+          c->F.DU_avg2[o] = c->F.DU_avg2[o] + cff2 * du(o);
         }
         if (inV) {
-          c->F.DV_avg1[o] = c->F.DV_avg1[o] + cff1 * DVom[o];
-          c->F.DV_avg2[o] = c->F.DV_avg2[o] + cff2 * DVom[o];
+          c->F.DV_avg1[o] = c->F.DV_avg1[o] + cff1 * dv(o);
+          c->F.DV_avg2[o] = c->F.DV_avg2[o] + cff2 * dv(o);
         }
       }
     } else {
       const double cff2 = (iif == 1) ? p.weight2[iif - 1] : (5.0 / 12.0) * p.weight2[iif - 1];
-      if (inU) c->F.DU_avg2[o] = c->F.DU_avg2[o] + cff2 * DUon[o];
-      if (inV) c->F.DV_avg2[o] = c->F.DV_avg2[o] + cff2 * DVom[o];
+      if (inU) c->F.DU_avg2[o] = c->F.DU_avg2[o] + cff2 * du(o);
+      if (inV) c->F.DV_avg2[o] = c->F.DV_avg2[o] + cff2 * dv(o);
     }
   }
   if (iif > nfast) return;
@@ -173,12 +191,12 @@ k2d_zeta_sm(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   if (js < b.Jstr || js > b.Jend) return;
   const long a = I2(is, js);
   const bool own_row = (js == j);
-  zeta_point(c, s, DUon, DVom, zeta_new, zwrk, a, o, own_row, true, own_row, nij, ni);
+  const double rhs = (du(a) - du(a + 1)) + (dv(a) - dv(a + ni));
+  zeta_point(c, s, rhs, zeta_new, zwrk, a, o, own_row, true, own_row, nij, ni);
 }
 
 // One free-surface point: evaluate at index a, store at index o.
-__device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const S2 &s,
-                                           const double *__restrict__ DUon, const double *__restrict__ DVom,
+__device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const S2 &s, const double rhs,
                                            double *__restrict__ zeta_new, double *__restrict__ zwrk, long a, long o,
                                            bool write_scratch, bool write_zeta, bool write_rzeta, long nij, long ni)
 {
@@ -188,7 +206,6 @@ __device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const 
   const double dtfast = p.dtfast;
   const double *__restrict__ zs = c->F.zeta + (long)(s.kstp - 1) * nij;
   const double pmn_a = c->F.pm[a], pn_a = c->F.pn[a];
-  const double rhs = (DUon[a] - DUon[a + 1]) + (DVom[a] - DVom[a + ni]);
   double zn, zw;
   if (iif == 1) {
     const double cff1 = dtfast;

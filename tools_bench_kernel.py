@@ -12,10 +12,13 @@ def main():
     config = sys.argv[1] if len(sys.argv) > 1 else "BENCHMARK3"
     kernels = sys.argv[2].split(",") if len(sys.argv) > 2 else ["step3d_t"]
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    sets = dict(a.split("=") for a in sys.argv[4:])      # e.g. uv_vis2=0 uv_adv=0
     t0 = time.time()
     st = util.prepared_state(config)
     util.hz_weighted_tnew(st)
     print(f"state built in {time.time()-t0:.1f}s", flush=True)
+    for k_, v_ in sets.items():
+        setattr(st.p, k_, type(getattr(st.p, k_))(float(v_)))
     h = hip.RomsHip(st)
     s = util.step_idx()
     b = st.b
