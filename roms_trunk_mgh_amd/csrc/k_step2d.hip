@@ -520,9 +520,15 @@ int step2d_impl(const roms_step_idx_t *si)
   if (sm) {
     s.sm = 1;
     const dim3 full = grid2d(b.UBi - b.LBi + 1, b.UBj - b.LBj + 1);
-    hipLaunchKernelGGL(k2d_flux, grid2d(b.UBi - b.LBi + 1, b.Jendp2 - (b.JstrV - 2) + 1), block2d(), 0, g_ctx.stream,
-                       g_ctx.devc, s, DUon, DVom);
-    KERNEL_CHECK("k2d_flux");
+    if (!g_ctx.no_lds_2d) {
+      // DUon/DVom are evaluated in place by the two remaining kernels: 2 launches per call
+      DUon = nullptr;
+      DVom = nullptr;
+    } else {
+      hipLaunchKernelGGL(k2d_flux, grid2d(b.UBi - b.LBi + 1, b.Jendp2 - (b.JstrV - 2) + 1), block2d(), 0,
+                         g_ctx.stream, g_ctx.devc, s, DUon, DVom);
+      KERNEL_CHECK("k2d_flux");
+    }
     hipLaunchKernelGGL(k2d_zeta_sm, full, block2d(), 0, g_ctx.stream, g_ctx.devc, s, (const double *)DUon,
                        (const double *)DVom, zeta_new, zwrk);
     KERNEL_CHECK("k2d_zeta_sm");

@@ -102,11 +102,23 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       else gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
       gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
       const long g = I2(gi, gj);
-      sU[e] = ubk[g];
-      sV[e] = vbk[g];
-      sDU[e] = DUon[g];
-      sDV[e] = DVom[g];
-      sD[e] = zk[g] + h[g];
+      const double ug = ubk[g], vg = vbk[g], Dg = zk[g] + h[g];
+      sU[e] = ug;
+      sV[e] = vg;
+      sD[e] = Dg;
+      if (DUon) {
+        sDU[e] = DUon[g];
+        sDV[e] = DVom[g];
+      } else {
+        // DUon, DVom evaluated in place (:509-544), identical expression to k2d_flux; the
+        // ghost columns/rows they reach hold exact copies, so no separate flux pass is needed
+        const double cu = 0.5 * c->F.on_u[g];
+        sDU[e] = ug * (cu * (Dg + (zk[g - 1] + h[g - 1])));
+        if (gj >= b.LBj + 1) {
+          const double cv = 0.5 * c->F.om_v[g];
+          sDV[e] = vg * (cv * (Dg + (zk[g - ni] + h[g - ni])));
+        } else sDV[e] = 0.0;
+      }
     }
   }
   __syncthreads();
