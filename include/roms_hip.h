@@ -197,6 +197,13 @@ int roms_hip_exchange(int field_id, int level);
 int roms_hip_timing_enable(int on);
 double roms_hip_timing_last_ms(const char *entry);
 
+/* Profiling aid (no reference counterpart): one streaming copy of n_doubles
+ * from 3-D scratch array 0 to scratch array 1 in the library's access pattern
+ * (one double per lane, i-fastest).  A known byte count -- 8*n read, 8*n
+ * written -- against which rocprofv3's FETCH_SIZE / WRITE_SIZE counters are
+ * calibrated for this pattern.  n_doubles <= nij*(N+1). */
+int roms_hip_calib_stream(long n_doubles);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,27 @@ extern "C" double roms_hip_timing_last_ms(const char *entry)
   return it == g_last_ms.end() ? -1.0 : it->second;
 }
 
+// counter calibration: a streaming copy with the library's one-double-per-lane pattern
+__global__ void __launch_bounds__(256) k_calib_stream(const double *__restrict__ src, double *__restrict__ dst, long n)
+{
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) dst[e] = src[e];
+}
+int roms_entry_check(const char *where);
+extern "C" int roms_hip_calib_stream(long n)
+{
+  int rc = roms_entry_check("roms_hip_calib_stream");
+  if (rc) return rc;
+  const roms_bounds_t &b = g_ctx.b;
+  const long cap = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * (b.N + 1);
+  if (n < 1 || n > cap) return roms_fail("roms_hip_calib_stream", "n_doubles outside 1..nij*(N+1)");
+  ScopedTimer tm("calib_stream");
+  hipLaunchKernelGGL(k_calib_stream, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_ctx.stream,
+                     (const double *)g_ctx.hostc.ws3[0], g_ctx.hostc.ws3[1], n);
+  KERNEL_CHECK("k_calib_stream");
+  return 0;
+}
+
 // ------------------------------------------------------------- life cycle --
 extern "C" int roms_abi_sizeof(int which)
 {

@@ -12,6 +12,7 @@
 #include "roms_dev.h"
 
 int roms_entry_check(const char *name);
+int roms_launch_uv3dmix2_v2(int nrhs, int nnew);
 
 namespace {
 
@@ -250,6 +251,7 @@ extern "C" int roms_hip_uv3dmix2(const roms_step_idx_t *s)
   if (rc) return rc;
   ScopedTimer tm("uv3dmix2");
   const roms_bounds_t &b = g_ctx.b;
+  if (!g_ctx.no_lds_3d) return roms_launch_uv3dmix2_v2(s->nrhs, s->nnew);   // k_uv3dmix2.hip
   hipLaunchKernelGGL(k_uv3dmix2_s, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
                      g_ctx.devc, s->nrhs, s->nnew);
   KERNEL_CHECK("k_uv3dmix2_s");

@@ -22,6 +22,7 @@
 // uses -ffp-contract=off), so results agree with the CPU restatement to the
 // last bit except where a library function differs.
 #include "roms_dev.h"
+#include <cstdlib>
 
 int roms_entry_check(const char *name);
 
@@ -29,15 +30,20 @@ int roms_entry_check(const char *name);
 
 namespace {
 
-template <int HADV, int VADV, int NMAX>
-__global__ void __launch_bounds__(BLK_X *BLK_Y)
+// TY = rows of columns per workgroup (64 x TY threads); LDSO = 1 keeps 1/Hz of the
+// column in LDS between the upward and the downward sweep (one HBM pass less per tracer).
+template <int HADV, int VADV, int NMAX, int TY, int LDSO>
+__global__ void __launch_bounds__(BLK_X *TY)
 k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
 {
   DEV_PROLOGUE(c)
-  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
+  constexpr int NTH = BLK_X * TY;
+  __shared__ double s_ohz[LDSO ? NMAX * NTH : 1];
+  const int tid = threadIdx.y * BLK_X + threadIdx.x;
+  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr, TY);
   if (!tt.valid) return;
   const int i = b.Istr + tt.bx * BLK_X + threadIdx.x;
-  const int j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
+  const int j = b.Jstr + tt.by * TY + threadIdx.y;
   const int itrc = itrc0 + tt.itr;              // 1-based tracer index
   if (i > b.Iend || j > b.Jend) return;
   const int ltrc = itrc < b.NAT ? itrc : b.NAT;
@@ -155,6 +161,7 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       tv = tv - cffdt * (FCk - FCprev);
       tv = tv * ohz;
       tn[k] = tv;
+      if constexpr (LDSO) s_ohz[(k - 1) * NTH + tid] = ohz;
       FCprev = FCk;
       // ---- Thomas forward elimination for row kk = k-1, step3d_t.F:1376-1410 ----
       const double akt_0 = Akt[ck + nij];          // Akt(i,j,k)
@@ -185,7 +192,9 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
         dcA = dc * Akt[c0 + (long)kk * nij];
       }
       const long ck = c0 + (long)kk * nij;        // level kk+1
-      const double ohz = 1.0 / Hz[ck];
+      double ohz;
+      if constexpr (LDSO) ohz = s_ohz[kk * NTH + tid];
+      else ohz = 1.0 / Hz[ck];
       const double cff1 = dt * ohz * (dcA_up - dcA);
       tn_g[ck] = tn[kk + 1] + cff1;
       dcA_up = dcA;
@@ -193,19 +202,38 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   }
 }
 
-template <int HADV, int VADV>
-int launch_nmax(int nnew, int itrc0, int ntr)
+template <int HADV, int VADV, int TY, int LDSO>
+int launch_var(int nnew, int itrc0, int ntr)
 {
   const roms_bounds_t &b = g_ctx.b;
-  const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
+  const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr, TY);
+  const dim3 block(BLK_X, TY, 1);
   if (b.N <= 16)
-    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16, TY, LDSO>), grid, block, 0, g_ctx.stream, g_ctx.devc, nnew, itrc0,
+                       ntr);
   else if (b.N <= 32)
-    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32, TY, LDSO>), grid, block, 0, g_ctx.stream, g_ctx.devc, nnew, itrc0,
+                       ntr);
   else
     return roms_fail("roms_hip_step3d_t", "N > 32 not instantiated");
   KERNEL_CHECK("k_step3d_t");
   return 0;
+}
+
+template <int HADV, int VADV>
+int launch_nmax(int nnew, int itrc0, int ntr)
+{
+  if constexpr (HADV == ADV_U3 && VADV == ADV_C4) {
+    // A/B variants (ROMS_HIP_S3T_VARIANT) while the workgroup shape is being tuned
+    static const int variant = getenv("ROMS_HIP_S3T_VARIANT") ? atoi(getenv("ROMS_HIP_S3T_VARIANT")) : 0;
+    switch (variant) {
+    case 1: return launch_var<HADV, VADV, 4, 1>(nnew, itrc0, ntr);
+    case 2: return launch_var<HADV, VADV, 8, 0>(nnew, itrc0, ntr);
+    case 3: return launch_var<HADV, VADV, 8, 1>(nnew, itrc0, ntr);
+    default: break;
+    }
+  }
+  return launch_var<HADV, VADV, 4, 0>(nnew, itrc0, ntr);
 }
 
 }  // namespace

@@ -110,9 +110,9 @@ static inline dim3 block2d() { return dim3(BLK_X, BLK_Y, 1); }
 // Placement only affects speed, never results.
 struct TileTr { int bx, by, itr; bool valid; };
 #ifdef __HIPCC__
-__device__ __forceinline__ TileTr decode_tile_tracer(int nx, int ny, int ntr)
+__device__ __forceinline__ TileTr decode_tile_tracer(int nx, int ny, int ntr, int ty = BLK_Y)
 {
-  const int nbx = (nx + BLK_X - 1) / BLK_X, nby = (ny + BLK_Y - 1) / BLK_Y;
+  const int nbx = (nx + BLK_X - 1) / BLK_X, nby = (ny + ty - 1) / ty;
   const int B = blockIdx.x, xcd = B & 7, q = B >> 3;
   TileTr r;
   r.itr = q % ntr;
@@ -123,8 +123,8 @@ __device__ __forceinline__ TileTr decode_tile_tracer(int nx, int ny, int ntr)
   return r;
 }
 #endif
-static inline dim3 grid_tile_tracer(int nx, int ny, int ntr) {
-  const int nt = ((nx + BLK_X - 1) / BLK_X) * ((ny + BLK_Y - 1) / BLK_Y);
+static inline dim3 grid_tile_tracer(int nx, int ny, int ntr, int ty = BLK_Y) {
+  const int nt = ((nx + BLK_X - 1) / BLK_X) * ((ny + ty - 1) / ty);
   return dim3((unsigned)(((nt + 7) / 8) * 8 * ntr), 1, 1);
 }
 

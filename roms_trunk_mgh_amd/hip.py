@@ -27,7 +27,7 @@ DECLARED_SYMBOLS = (
      "roms_hip_sync_to_host", "roms_hip_sync_all_to_device", "roms_hip_sync_all_to_host",
      "roms_hip_device_ptr", "roms_hip_device_synchronize", "roms_hip_last_error",
      "roms_hip_step2d_loop", "roms_hip_exchange", "roms_hip_timing_enable",
-     "roms_hip_timing_last_ms"] + ["roms_hip_" + e for e in ENTRIES])
+     "roms_hip_timing_last_ms", "roms_hip_calib_stream"] + ["roms_hip_" + e for e in ENTRIES])
 
 
 def load():
@@ -58,6 +58,7 @@ def load():
             fn.argtypes = [C.POINTER(abi.StepIdx)]
     if hasattr(lib, "roms_hip_step2d_loop"):
         lib.roms_hip_step2d_loop.argtypes = [C.POINTER(abi.StepIdx), C.POINTER(C.c_int)]
+    lib.roms_hip_calib_stream.argtypes = [C.c_long]
     if hasattr(lib, "roms_hip_tile_neighbors"):
         lib.roms_hip_tile_neighbors.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)]
     _LIB = lib
@@ -134,6 +135,9 @@ class RomsHip:
 
     def timing(self, on=True):
         self.l.roms_hip_timing_enable(int(on))
+
+    def calib_stream(self, n_doubles):
+        self._chk(self.l.roms_hip_calib_stream(n_doubles), "calib_stream")
 
     def last_ms(self, entry):
         return self.l.roms_hip_timing_last_ms(entry.encode())

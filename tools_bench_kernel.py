@@ -3,7 +3,9 @@ the library's hipEvent timers.  Usage: python tools_bench_kernel.py BENCHMARK3 s
 import sys
 import time
 
-sys.path.insert(0, "tests")
+import os  # noqa: E402
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [_ROOT, os.path.join(_ROOT, "tests")]
 import util  # noqa: E402
 from roms_trunk_mgh_amd import hip  # noqa: E402
 
@@ -24,6 +26,15 @@ def main():
     b = st.b
     cells = b.Lm * b.Mm * b.N
     for k in kernels:
+        if k == "calib_stream":
+            # known byte count for the PMC counters: 8*n read + 8*n written per launch
+            n = (b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N
+            h.timing(True)
+            for _ in range(reps):
+                h.calib_stream(n)
+            print(f"calib_stream: n={n} doubles, {8*n} B read + {8*n} B written per launch, "
+                  f"{h.last_ms('calib_stream'):.4f} ms", flush=True)
+            continue
         h.timing(False)
         for _ in range(3):
             h.call(k, s)
