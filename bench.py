@@ -74,7 +74,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; a rehearsal of N ranks on a one-GPU box (ROMS_BENCH_SHARE_GPU=1) folds them
+    device = local_rank % torch.cuda.device_count() if os.environ.get("ROMS_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(device)
 
     uid = None
     if world > 1:
@@ -97,7 +99,31 @@ def main():
             dist.barrier()
 
     st = ana.make_tile(args.config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0)
-    be = hip.RomsHip(st, rank=rank, device=local_rank, nccl_unique_id=uid)
+    # halo transport: RCCL (ncclSend/ncclRecv inside the library) unless ROMS_BENCH_HALO=relay or
+    # the communicator cannot be created on every rank; the relay moves the same packed ghost
+    # lines through pinned host memory + gloo (slower; recorded in config.halo_transport)
+    transport = "none" if world == 1 else "rccl"
+    be = None
+    if world > 1 and os.environ.get("ROMS_BENCH_HALO") != "relay":
+        ok_init = 1
+        try:
+            be = hip.RomsHip(st, rank=rank, device=device, nccl_unique_id=uid)
+        except RuntimeError as e:
+            sys.stderr.write(f"[bench rank {rank}] RCCL transport unavailable: {e}\n")
+            ok_init = 0
+        flag = torch.tensor([ok_init], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if be is not None:
+                be.close()
+            be = None
+            transport = "relay"
+    elif world > 1:
+        transport = "relay"
+    if be is None:
+        be = hip.RomsHip(st, rank=rank, device=device, nccl_unique_id=None if transport != "rccl" else uid)
+        if transport == "relay":
+            be.set_halo_relay_gloo(dist, torch)
     m = main3d.Main3D(be)
     m.initial()
     for _ in range(args.warmup):
@@ -155,8 +181,8 @@ def main():
             "config": {"workload": f"{args.config} {b.Lm}x{b.Mm}x{b.N} NT={b.NT} "
                                    f"nonlinear 3-D step incl. {2 * st.p.nfast + 1} step2d calls, "
                                    f"U3/C4 tracer advection, fixed analytic forcing/mixing",
-                       "tiling": f"{ntI}x{ntJ}", "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok},
-            "roofline": {"kernel": "k_step3d_t (step3d_t_tile)", "bound": "hbm", "achieved": achieved,
+                       "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok},
+            "roofline": {"kernel": "k_step3d_t_pipe (step3d_t_tile)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "avg_ms": t_ms, "algorithmic_bytes": alg_bytes},
             "kernel_ms": per_kernel,

@@ -192,6 +192,22 @@ int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1);
  * tracer) or 0 for all.  Exported for tests. */
 int roms_hip_exchange(int field_id, int level);
 
+/* Second halo transport: a host relay.  When roms_hip_init got no RCCL id (NULL) on a
+ * multi-tile run, every exchange phase packs the ghost lines on the device, copies them
+ * to pinned host memory and calls `fn`, which must deliver send_lo to rank lo_rank and
+ * send_hi to rank hi_rank and fill recv_lo / recv_hi from the same ranks (a rank < 0
+ * means no neighbour on that side; dir 0 = west/east phase, 1 = south/north phase;
+ * counts are in doubles) -- e.g. with the MPI_Isend/MPI_Irecv the reference's
+ * mp_exchange2d (ROMS/Utility/mp_exchange.F:290-560) already uses.  Return 0 on success.
+ * The RCCL transport is the fast one; the relay exists for hosts that own the
+ * interconnect and for rehearsing N tiles on fewer GPUs. */
+typedef int (*roms_halo_relay_fn)(void *user, int dir, int lo_rank, int hi_rank,
+                                  const double *send_lo, long n_send_lo,
+                                  const double *send_hi, long n_send_hi,
+                                  double *recv_lo, long n_recv_lo,
+                                  double *recv_hi, long n_recv_hi);
+int roms_hip_set_halo_relay(roms_halo_relay_fn fn, void *user);
+
 /* Timing helper: average device milliseconds of the last call of each entry
  * measured with hipEvents on the library's stream (bench.py roofline). */
 int roms_hip_timing_enable(int on);

@@ -107,6 +107,7 @@ extern "C" const char *roms_hip_last_error(void) { return g_ctx.last_error.c_str
 
 int halo_init();      // halo.hip
 int halo_finalize();
+extern "C" int roms_hip_finalize(void);
 
 extern "C" int roms_hip_init(int rank, int ntileI, int ntileJ, int device_id, const void *nccl_unique_id)
 {
@@ -138,10 +139,11 @@ extern "C" int roms_hip_init(int rank, int ntileI, int ntileJ, int device_id, co
   memset(&g_ctx.hostc, 0, sizeof(RomsDev));
   g_ctx.devc_dirty = true;
   g_ctx.inited = true;
-  if (ntileI * ntileJ > 1) {
-    if (!g_ctx.have_nccl_id) return roms_fail("roms_hip_init", "multi-tile run needs an RCCL unique id");
+  if (ntileI * ntileJ > 1 && g_ctx.have_nccl_id) {
+    // without an id the halos must go through a host relay (roms_hip_set_halo_relay);
+    // the first exchange fails loudly if neither transport exists
     int rc = halo_init();
-    if (rc) return rc;
+    if (rc) { roms_hip_finalize(); return rc; }
   }
   return 0;
 }

@@ -115,8 +115,26 @@ extern "C" int roms_hip_tile_neighbors(int rank, int ntileI, int ntileJ, int Ngh
 }
 
 static Neigh g_neigh;
+static bool g_have_neigh = false;
 static double *g_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLo, sendHi, recvLo, recvHi
-static size_t g_buf_doubles = 0;
+static double *g_hbuf[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned host mirrors (relay transport)
+static size_t g_buf_doubles = 0, g_hbuf_doubles = 0;
+
+// Host-relay transport: the packed ghost lines are handed to a host callback that moves
+// them with whatever the host application already has (the reference's own MPI, or gloo
+// in the tests) -- the same pack/unpack kernels, neighbour table and phase order as the
+// RCCL transport, with a device<->pinned-host copy on either side.
+typedef int (*roms_halo_relay_fn)(void *user, int dir, int lo_rank, int hi_rank,
+                                  const double *send_lo, long n_send_lo, const double *send_hi, long n_send_hi,
+                                  double *recv_lo, long n_recv_lo, double *recv_hi, long n_recv_hi);
+static roms_halo_relay_fn g_relay = nullptr;
+static void *g_relay_user = nullptr;
+extern "C" int roms_hip_set_halo_relay(roms_halo_relay_fn fn, void *user)
+{
+  g_relay = fn;
+  g_relay_user = user;
+  return 0;
+}
 
 int halo_init()
 {
@@ -133,7 +151,11 @@ int halo_init()
 int halo_finalize()
 {
   for (auto &p : g_buf) { if (p) hipFree(p); p = nullptr; }
-  g_buf_doubles = 0;
+  for (auto &p : g_hbuf) { if (p) hipHostFree(p); p = nullptr; }
+  g_buf_doubles = g_hbuf_doubles = 0;
+  g_have_neigh = false;
+  g_relay = nullptr;
+  g_relay_user = nullptr;
   if (g_ctx.nccl_comm && rccl.destroy) rccl.destroy((rccl_comm_t)g_ctx.nccl_comm);
   g_ctx.nccl_comm = nullptr;
   return 0;
@@ -203,6 +225,33 @@ static int exchange_phase(double *A, int nk, int dir)
   if (lo >= 0) launch(g_buf[0], str, GsLo, 0);                 // my first GsLo interior lines
   if (hi >= 0) launch(g_buf[1], end - GsHi + 1, GsHi, 0);      // my last GsHi interior lines
   KERNEL_CHECK("k_pack");
+  if (!g_ctx.nccl_comm) {
+    if (!g_relay)
+      return roms_fail("halo exchange", "multi-tile run without a transport: pass an RCCL unique id to "
+                                        "roms_hip_init or set a host relay (roms_hip_set_halo_relay)");
+    const size_t need = (size_t)nk * Gmax * len;
+    if (need > g_hbuf_doubles) {
+      for (auto &p : g_hbuf) {
+        if (p) hipHostFree(p);
+        HIP_TRY(hipHostMalloc(&p, sizeof(double) * need, hipHostMallocDefault));
+      }
+      g_hbuf_doubles = need;
+    }
+    const long nsl = (long)nk * GsLo * len, nsh = (long)nk * GsHi * len;
+    const long nrl = (long)nk * GrLo * len, nrh = (long)nk * GrHi * len;
+    if (lo >= 0) HIP_TRY(hipMemcpyAsync(g_hbuf[0], g_buf[0], sizeof(double) * nsl, hipMemcpyDeviceToHost, g_ctx.stream));
+    if (hi >= 0) HIP_TRY(hipMemcpyAsync(g_hbuf[1], g_buf[1], sizeof(double) * nsh, hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    const int rrc = g_relay(g_relay_user, dir, lo, hi, g_hbuf[0], lo >= 0 ? nsl : 0, g_hbuf[1], hi >= 0 ? nsh : 0,
+                            g_hbuf[2], lo >= 0 ? nrl : 0, g_hbuf[3], hi >= 0 ? nrh : 0);
+    if (rrc) return roms_fail("halo exchange", "host relay callback failed");
+    if (lo >= 0) HIP_TRY(hipMemcpyAsync(g_buf[2], g_hbuf[2], sizeof(double) * nrl, hipMemcpyHostToDevice, g_ctx.stream));
+    if (hi >= 0) HIP_TRY(hipMemcpyAsync(g_buf[3], g_hbuf[3], sizeof(double) * nrh, hipMemcpyHostToDevice, g_ctx.stream));
+    if (lo >= 0) launch(g_buf[2], str - GrLo, GrLo, 1);
+    if (hi >= 0) launch(g_buf[3], end + 1, GrHi, 1);
+    KERNEL_CHECK("k_unpack");
+    return 0;
+  }
   rccl_comm_t comm = (rccl_comm_t)g_ctx.nccl_comm;
   RCCL_TRY(rccl.gstart());
   // order matters when lo == hi (two tiles in a periodic direction): my low-side
@@ -231,13 +280,12 @@ int halo_exchange3d(int gtype, int nk, double *A)
     KERNEL_CHECK("k_periodic_ew");
     return 0;
   }
-  static bool have_neigh = false;
-  if (!have_neigh) {
+  if (!g_have_neigh) {
     int v[12];
     roms_hip_tile_neighbors(g_ctx.rank, b.ntileI, b.ntileJ, b.NghostPoints, b.NghostPoints,
                             b.EWperiodic, b.NSperiodic, v);
     g_neigh = Neigh{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]};
-    have_neigh = true;
+    g_have_neigh = true;
   }
   // a periodic direction held by ONE tile row/column is a local copy
   if (b.EWperiodic && b.ntileI == 1) {

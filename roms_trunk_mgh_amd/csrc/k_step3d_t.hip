@@ -30,37 +30,45 @@ int roms_entry_check(const char *name);
 
 namespace {
 
-// TY = rows of columns per workgroup (64 x TY threads); LDSO = 1 keeps 1/Hz of the
-// column in LDS between the upward and the downward sweep (one HBM pass less per tracer).
-template <int HADV, int VADV, int NMAX, int TY, int LDSO>
-__global__ void __launch_bounds__(BLK_X *TY)
+// Classic form (ROMS_HIP_S3T_VARIANT=0), kept as the A/B reference of the pipelined kernel
+// below.
+//
+// Tuning notes (MI355X, BENCHMARK3, profiles/r01c): the kernel is bound by memory LATENCY
+// per level, not by bytes -- FETCH_SIZE barely moves the time.  Issuing every load of a
+// level before the first use took 0.59 -> 0.53 ms.  Taller workgroups (64x8) changed
+// neither traffic nor time (j-halo rows are L2 hits).  A compile-time N (no guards in the
+// unrolled loop) let the scheduler hoist loads of many levels at once and was 2-3x SLOWER
+// (occupancy 1 or scratch spills), so the run-time guards stay.  Keeping 1/Hz in LDS for the
+// downward sweep saved 0.15 GB of fetch and 0.03 ms; the pipelined kernel uses the LDS for
+// tn() instead.  XCD strips (roms_dev.h) cut the fetch from 2.1 to 1.8 GB.
+template <int HADV, int VADV, int NMAX>
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
 {
   DEV_PROLOGUE(c)
-  constexpr int NTH = BLK_X * TY;
-  __shared__ double s_ohz[LDSO ? NMAX * NTH : 1];
-  const int tid = threadIdx.y * BLK_X + threadIdx.x;
-  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr, TY);
+  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
   if (!tt.valid) return;
   const int i = b.Istr + tt.bx * BLK_X + threadIdx.x;
-  const int j = b.Jstr + tt.by * TY + threadIdx.y;
+  const int j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
   const int itrc = itrc0 + tt.itr;              // 1-based tracer index
   if (i > b.Iend || j > b.Jend) return;
   const int ltrc = itrc < b.NAT ? itrc : b.NAT;
   const double dt = c->p.dt;
-  const double *__restrict__ t3 = c->F.t + (2L + 3L * (itrc - 1)) * n3r;
-  double *__restrict__ tn_g = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
-  const double *__restrict__ Huon = c->F.Huon;
-  const double *__restrict__ Hvom = c->F.Hvom;
-  const double *__restrict__ Wv = c->F.W;
-  const double *__restrict__ Hz = c->F.Hz;
-  const double *__restrict__ Akt = c->F.Akt + (long)(ltrc - 1) * n3w;
+  const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (itrc - 1)) * n3r);
+  const gd_t tn_g = (gd_t)(c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r);
+  const gcd_t Huon = (gcd_t)c->F.Huon;
+  const gcd_t Hvom = (gcd_t)c->F.Hvom;
+  const gcd_t Wv = (gcd_t)c->F.W;
+  const gcd_t Hz = (gcd_t)c->F.Hz;
+  const gcd_t Akt = (gcd_t)(c->F.Akt + (long)(ltrc - 1) * n3w);
   const double cffdt = dt * c->F.pm[I2(i, j)] * c->F.pn[I2(i, j)];
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;       // FE(Jstr-1)=FE(Jstr)
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;       // FE(Jend+2)=FE(Jend+1)
   const bool n_wall1 = b.north_edge && !b.NSperiodic && j == b.Jend - 1;
   (void)n_wall1;
   const long c0 = I2(i, j);
+  // wall rows: the outer stencil point is not used (:741-760); read a valid address instead
+  const long oym2 = s_wall ? 0 : -2 * ni, oyp2 = n_wall ? 0 : 2 * ni;
 
   double tn[NMAX + 1], CF[NMAX + 1], DC[NMAX + 1];
   CF[0] = 0.0;
@@ -123,12 +131,17 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   for (int k = 1; k <= NMAX; k++) {
     if (k <= N) {
       const long ck = c0 + (long)(k - 1) * nij;
+      // every load of the level is issued up front (one memory round trip per level)
+      const double hz = Hz[ck];
+      double tv = tn_g[ck];
+      const double akt_0 = Akt[ck + nij];          // Akt(i,j,k)
+      const double wtop = Wv[ck + nij];
       tkp2 = (k + 2 <= N) ? t3[ck + 2 * nij] : 0.0;
       // ---- horizontal fluxes, step3d_t.F:596-828 ----
       const double xm2 = t3[ck - 2], xm1 = t3[ck - 1], xp1 = t3[ck + 1], xp2 = t3[ck + 2];
       const double ym1 = t3[ck - ni], yp1 = t3[ck + ni];
-      const double ym2 = s_wall ? 0.0 : t3[ck - 2 * ni];
-      const double yp2 = n_wall ? 0.0 : t3[ck + 2 * ni];
+      const double ym2 = t3[ck + oym2];
+      const double yp2 = t3[ck + oyp2];
       const double hu0 = Huon[ck], hu1 = Huon[ck + 1];
       const double hv0 = Hvom[ck], hv1 = Hvom[ck + ni];
       const double dxm1 = xm1 - xm2, dx0 = tk - xm1, dxp1 = xp1 - tk, dxp2 = xp2 - xp1;
@@ -146,12 +159,10 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       else {
         double cfk = 0.0, cfk1 = 0.0;
         if constexpr (VADV == ADV_A4) { cfk = a4cf[k]; cfk1 = a4cf[k + 1]; }
-        FCk = vflux<VADV>(k, N, Wv[ck + nij], tkm1, tk, tkp1, tkp2, cfk, cfk1);
+        FCk = vflux<VADV>(k, N, wtop, tkm1, tk, tkp1, tkp2, cfk, cfk1);
       }
       // ---- advective update, step3d_t.F:857-875 and :1168-1208 ----
-      const double hz = Hz[ck];
       const double ohz = 1.0 / hz;
-      double tv = tn_g[ck];
       {
         const double cff1 = cffdt * (FXip1 - FXi);
         const double cff2 = cffdt * (FEjp1 - FEj);
@@ -161,10 +172,8 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       tv = tv - cffdt * (FCk - FCprev);
       tv = tv * ohz;
       tn[k] = tv;
-      if constexpr (LDSO) s_ohz[(k - 1) * NTH + tid] = ohz;
       FCprev = FCk;
       // ---- Thomas forward elimination for row kk = k-1, step3d_t.F:1376-1410 ----
-      const double akt_0 = Akt[ck + nij];          // Akt(i,j,k)
       if (k >= 2) {
         const double cff6 = 1.0 / 6.0, cff3r = 1.0 / 3.0;
         const double fc = cff6 * hz_m1 - dt * akt_m2 * ohz_m1;
@@ -192,9 +201,7 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
         dcA = dc * Akt[c0 + (long)kk * nij];
       }
       const long ck = c0 + (long)kk * nij;        // level kk+1
-      double ohz;
-      if constexpr (LDSO) ohz = s_ohz[kk * NTH + tid];
-      else ohz = 1.0 / Hz[ck];
+      const double ohz = 1.0 / Hz[ck];
       const double cff1 = dt * ohz * (dcA_up - dcA);
       tn_g[ck] = tn[kk + 1] + cff1;
       dcA_up = dcA;
@@ -202,20 +209,213 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   }
 }
 
-template <int HADV, int VADV, int TY, int LDSO>
+// ---------------------------------------------------------------------------
+// Software-pipelined variant.  The post-advection tracer column tn() lives in LDS
+// ([level][thread], conflict-free), which frees ~60 VGPRs; they hold the 17 loads of level
+// k+1, issued BEFORE level k is computed, so one memory round trip overlaps a whole level
+// of arithmetic (and the other wave of the SIMD).  The downward sweep prefetches Akt and
+// Hz two levels ahead.  Arithmetic is identical to k_step3d_t.
+// ---------------------------------------------------------------------------
+struct LevelIn {
+  double tkp2, xm2, xm1, xp1, xp2, ym2, ym1, yp1, yp2, hu0, hu1, hv0, hv1, w, hz, tv, akt;
+};
+
+template <int HADV, int VADV, int NMAX>
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
+{
+  DEV_PROLOGUE(c)
+  constexpr int NTH = BLK_X * BLK_Y;
+  __shared__ double s_tn[NMAX * NTH];
+  const int tid = threadIdx.y * BLK_X + threadIdx.x;
+  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
+  if (!tt.valid) return;
+  const int i = b.Istr + tt.bx * BLK_X + threadIdx.x;
+  const int j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
+  const int itrc = itrc0 + tt.itr;
+  if (i > b.Iend || j > b.Jend) return;
+  const int ltrc = itrc < b.NAT ? itrc : b.NAT;
+  const double dt = c->p.dt;
+  const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (itrc - 1)) * n3r);
+  const gd_t tn_g = (gd_t)(c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r);
+  const gcd_t Huon = (gcd_t)c->F.Huon;
+  const gcd_t Hvom = (gcd_t)c->F.Hvom;
+  const gcd_t Wv = (gcd_t)c->F.W;
+  const gcd_t Hz = (gcd_t)c->F.Hz;
+  const gcd_t Akt = (gcd_t)(c->F.Akt + (long)(ltrc - 1) * n3w);
+  const double cffdt = dt * c->F.pm[I2(i, j)] * c->F.pn[I2(i, j)];
+  const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
+  const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
+  const long c0 = I2(i, j);
+  const long oym2 = s_wall ? 0 : -2 * ni, oyp2 = n_wall ? 0 : 2 * ni;
+
+  double CF[NMAX + 1], DC[NMAX + 1];
+  CF[0] = 0.0;
+  DC[0] = 0.0;
+
+  double a4cf[(VADV == ADV_A4) ? NMAX + 2 : 1];
+  double spl[(VADV == ADV_SPLINES) ? NMAX + 1 : 1];
+  if constexpr (VADV == ADV_A4) {
+    const double eps = 1.0E-16;
+    double dprev = 0.0, tk = t3[c0];
+#pragma unroll
+    for (int k = 1; k <= NMAX; k++) {
+      if (k <= N) {
+        double dk;
+        if (k < N) { const double tk1 = t3[c0 + (long)k * nij]; dk = tk1 - tk; tk = tk1; }
+        else dk = dprev;
+        if (k == 1) dprev = dk;
+        const double cff = 2.0 * dk * dprev;
+        a4cf[k] = (cff > eps) ? cff / (dk + dprev) : 0.0;
+        dprev = dk;
+      }
+    }
+  }
+  if constexpr (VADV == ADV_SPLINES) {
+    double cfs[NMAX + 1];
+    spl[0] = 2.0 * t3[c0];
+    cfs[1] = 1.0;
+#pragma unroll
+    for (int k = 1; k < NMAX; k++) {
+      if (k <= N - 1) {
+        const double hk = Hz[c0 + (long)(k - 1) * nij], hk1 = Hz[c0 + (long)k * nij];
+        const double cff = 1.0 / (2.0 * hk + hk1 * (2.0 - cfs[k]));
+        cfs[k + 1] = cff * hk;
+        spl[k] = cff * (3.0 * (hk * t3[c0 + (long)k * nij] + hk1 * t3[c0 + (long)(k - 1) * nij]) - hk1 * spl[k - 1]);
+      }
+    }
+    double top = 0.0;
+#pragma unroll
+    for (int k = 1; k <= NMAX; k++)
+      if (k == N) { top = (2.0 * t3[c0 + (long)(N - 1) * nij] - spl[k - 1]) / (1.0 - cfs[k]); spl[k] = top; }
+#pragma unroll
+    for (int k = NMAX - 1; k >= 0; k--) {
+      if (k <= N - 1) {
+        spl[k] = spl[k] - cfs[k + 1] * spl[k + 1];
+        spl[k + 1] = Wv[c0 + (long)(k + 1) * nij] * spl[k + 1];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k <= NMAX; k++) if (k == 0 || k == N) spl[k] = 0.0;
+  }
+
+  auto load_level = [&](int k) {
+    LevelIn L;
+    const long ck = c0 + (long)(k - 1) * nij;
+    L.hz = Hz[ck];
+    L.tv = tn_g[ck];
+    L.akt = Akt[ck + nij];
+    L.w = Wv[ck + nij];
+    L.tkp2 = (k + 2 <= N) ? t3[ck + 2 * nij] : 0.0;
+    L.xm2 = t3[ck - 2]; L.xm1 = t3[ck - 1]; L.xp1 = t3[ck + 1]; L.xp2 = t3[ck + 2];
+    L.ym1 = t3[ck - ni]; L.yp1 = t3[ck + ni];
+    L.ym2 = t3[ck + oym2];
+    L.yp2 = t3[ck + oyp2];
+    L.hu0 = Huon[ck]; L.hu1 = Huon[ck + 1];
+    L.hv0 = Hvom[ck]; L.hv1 = Hvom[ck + ni];
+    return L;
+  };
+
+  double tkm1 = 0.0, tk = t3[c0], tkp1 = (N >= 2) ? t3[c0 + nij] : 0.0;
+  double FCprev = 0.0, tn_prev = 0.0;
+  double hz_m1 = 0.0, ohz_m1 = 0.0, akt_m2 = 0.0, akt_m1 = Akt[c0];
+  LevelIn cur = load_level(1);
+
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      LevelIn nxt;
+      if (k + 1 <= N) nxt = load_level(k + 1);       // in flight while level k is computed
+      const double tkp2 = cur.tkp2;
+      const double dxm1 = cur.xm1 - cur.xm2, dx0 = tk - cur.xm1, dxp1 = cur.xp1 - tk, dxp2 = cur.xp2 - cur.xp1;
+      const double dy0 = tk - cur.ym1, dyp1 = cur.yp1 - tk;
+      const double dym1 = s_wall ? dy0 : (cur.ym1 - cur.ym2);
+      const double dyp2 = n_wall ? dyp1 : (cur.yp2 - cur.yp1);
+      const double FXi = hflux<HADV>(cur.hu0, cur.xm1, tk, dxm1, dx0, dxp1);
+      const double FXip1 = hflux<HADV>(cur.hu1, tk, cur.xp1, dx0, dxp1, dxp2);
+      const double FEj = hflux<HADV>(cur.hv0, cur.ym1, tk, dym1, dy0, dyp1);
+      const double FEjp1 = hflux<HADV>(cur.hv1, tk, cur.yp1, dy0, dyp1, dyp2);
+      double FCk;
+      if (k == N) FCk = 0.0;
+      else if constexpr (VADV == ADV_SPLINES) FCk = spl[k];
+      else {
+        double cfk = 0.0, cfk1 = 0.0;
+        if constexpr (VADV == ADV_A4) { cfk = a4cf[k]; cfk1 = a4cf[k + 1]; }
+        FCk = vflux<VADV>(k, N, cur.w, tkm1, tk, tkp1, tkp2, cfk, cfk1);
+      }
+      const double hz = cur.hz;
+      const double ohz = 1.0 / hz;
+      double tv = cur.tv;
+      {
+        const double cff1 = cffdt * (FXip1 - FXi);
+        const double cff2 = cffdt * (FEjp1 - FEj);
+        const double cff3 = cff1 + cff2;
+        tv = tv - cff3;
+      }
+      tv = tv - cffdt * (FCk - FCprev);
+      tv = tv * ohz;
+      s_tn[(k - 1) * NTH + tid] = tv;
+      FCprev = FCk;
+      const double akt_0 = cur.akt;
+      if (k >= 2) {
+        const double cff6 = 1.0 / 6.0, cff3r = 1.0 / 3.0;
+        const double fc = cff6 * hz_m1 - dt * akt_m2 * ohz_m1;
+        const double cf = cff6 * hz - dt * akt_0 * ohz;
+        const double bc = cff3r * (hz_m1 + hz) + dt * akt_m1 * (ohz_m1 + ohz);
+        const double cff = 1.0 / (bc - fc * CF[k - 2]);
+        CF[k - 1] = cff * cf;
+        DC[k - 1] = cff * (tv - tn_prev - fc * DC[k - 2]);
+      }
+      tn_prev = tv;
+      hz_m1 = hz; ohz_m1 = ohz; akt_m2 = akt_m1; akt_m1 = akt_0;
+      tkm1 = tk; tk = tkp1; tkp1 = tkp2;
+      cur = nxt;
+    }
+  }
+
+  // ---- back substitution + final update; Akt(kk), Hz(kk+1) prefetched two levels ahead ----
+  double dcA_up = 0.0, dc_up = 0.0;
+  double akA = Akt[c0 + (long)(N - 1) * nij], hzA = Hz[c0 + (long)(N - 1) * nij];
+  double akB = 0.0, hzB = 0.0;
+  if (N >= 2) { akB = Akt[c0 + (long)(N - 2) * nij]; hzB = Hz[c0 + (long)(N - 2) * nij]; }
+#pragma unroll
+  for (int kk = NMAX - 1; kk >= 0; kk--) {
+    if (kk <= N - 1) {
+      double akC = 0.0, hzC = 0.0;
+      if (kk >= 2) { akC = Akt[c0 + (long)(kk - 2) * nij]; hzC = Hz[c0 + (long)(kk - 2) * nij]; }
+      double dcA = 0.0;
+      if (kk >= 1) {
+        const double dc = DC[kk] - CF[kk] * dc_up;
+        dc_up = dc;
+        dcA = dc * akA;
+      }
+      const long ck = c0 + (long)kk * nij;
+      const double ohz = 1.0 / hzA;
+      const double cff1 = dt * ohz * (dcA_up - dcA);
+      tn_g[ck] = s_tn[kk * NTH + tid] + cff1;
+      dcA_up = dcA;
+      akA = akB; hzA = hzB; akB = akC; hzB = hzC;
+    }
+  }
+}
+
+template <int HADV, int VADV, int MODE>
 int launch_var(int nnew, int itrc0, int ntr)
 {
   const roms_bounds_t &b = g_ctx.b;
-  const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr, TY);
-  const dim3 block(BLK_X, TY, 1);
-  if (b.N <= 16)
-    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16, TY, LDSO>), grid, block, 0, g_ctx.stream, g_ctx.devc, nnew, itrc0,
-                       ntr);
-  else if (b.N <= 32)
-    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32, TY, LDSO>), grid, block, 0, g_ctx.stream, g_ctx.devc, nnew, itrc0,
-                       ntr);
-  else
-    return roms_fail("roms_hip_step3d_t", "N > 32 not instantiated");
+  const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
+  if (b.N > 32) return roms_fail("roms_hip_step3d_t", "N > 32 not instantiated");
+  if constexpr (MODE == 2) {
+    if (b.N <= 16)
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+  } else {
+    if (b.N <= 16)
+      hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else
+      hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+  }
   KERNEL_CHECK("k_step3d_t");
   return 0;
 }
@@ -223,17 +423,10 @@ int launch_var(int nnew, int itrc0, int ntr)
 template <int HADV, int VADV>
 int launch_nmax(int nnew, int itrc0, int ntr)
 {
-  if constexpr (HADV == ADV_U3 && VADV == ADV_C4) {
-    // A/B variants (ROMS_HIP_S3T_VARIANT) while the workgroup shape is being tuned
-    static const int variant = getenv("ROMS_HIP_S3T_VARIANT") ? atoi(getenv("ROMS_HIP_S3T_VARIANT")) : 0;
-    switch (variant) {
-    case 1: return launch_var<HADV, VADV, 4, 1>(nnew, itrc0, ntr);
-    case 2: return launch_var<HADV, VADV, 8, 0>(nnew, itrc0, ntr);
-    case 3: return launch_var<HADV, VADV, 8, 1>(nnew, itrc0, ntr);
-    default: break;
-    }
-  }
-  return launch_var<HADV, VADV, 4, 0>(nnew, itrc0, ntr);
+  // ROMS_HIP_S3T_VARIANT: 0 = classic kernel (A/B reference), otherwise the pipelined kernel
+  static const int variant = getenv("ROMS_HIP_S3T_VARIANT") ? atoi(getenv("ROMS_HIP_S3T_VARIANT")) : 2;
+  if (variant == 0) return launch_var<HADV, VADV, 0>(nnew, itrc0, ntr);
+  return launch_var<HADV, VADV, 2>(nnew, itrc0, ntr);
 }
 
 }  // namespace

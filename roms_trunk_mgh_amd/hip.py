@@ -27,7 +27,12 @@ DECLARED_SYMBOLS = (
      "roms_hip_sync_to_host", "roms_hip_sync_all_to_device", "roms_hip_sync_all_to_host",
      "roms_hip_device_ptr", "roms_hip_device_synchronize", "roms_hip_last_error",
      "roms_hip_step2d_loop", "roms_hip_exchange", "roms_hip_timing_enable",
-     "roms_hip_timing_last_ms", "roms_hip_calib_stream"] + ["roms_hip_" + e for e in ENTRIES])
+     "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay"] + ["roms_hip_" + e for e in ENTRIES])
+
+
+_DP = C.POINTER(C.c_double)
+RELAY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _DP, C.c_long, _DP, C.c_long,
+                       _DP, C.c_long, _DP, C.c_long)
 
 
 def load():
@@ -59,6 +64,7 @@ def load():
     if hasattr(lib, "roms_hip_step2d_loop"):
         lib.roms_hip_step2d_loop.argtypes = [C.POINTER(abi.StepIdx), C.POINTER(C.c_int)]
     lib.roms_hip_calib_stream.argtypes = [C.c_long]
+    lib.roms_hip_set_halo_relay.argtypes = [RELAY_FN, C.c_void_p]
     if hasattr(lib, "roms_hip_tile_neighbors"):
         lib.roms_hip_tile_neighbors.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)]
     _LIB = lib
@@ -135,6 +141,34 @@ class RomsHip:
 
     def timing(self, on=True):
         self.l.roms_hip_timing_enable(int(on))
+
+    def set_halo_relay_gloo(self, dist, torch):
+        """Route the halo exchange through torch.distributed (gloo, host memory) instead of
+        RCCL: roms_hip_set_halo_relay with a callback doing the paired isend/irecv of one
+        phase.  Used to rehearse N tiles on fewer GPUs and as the pattern for a host-MPI relay."""
+        def cb(_user, _dir, lo, hi, send_lo, nsl, send_hi, nsh, recv_lo, nrl, recv_hi, nrh):
+            try:
+                reqs = []
+                view = lambda p, n: torch.from_numpy(np.ctypeslib.as_array(p, shape=(n,)))
+                # when lo == hi (two tiles in a periodic direction) my low-side send pairs
+                # with the peer's high-side receive: tags keep the two apart
+                if lo >= 0:
+                    reqs.append(dist.isend(view(send_lo, nsl), dst=lo, tag=1))
+                if hi >= 0:
+                    reqs.append(dist.isend(view(send_hi, nsh), dst=hi, tag=2))
+                if hi >= 0:
+                    reqs.append(dist.irecv(view(recv_hi, nrh), src=hi, tag=1))
+                if lo >= 0:
+                    reqs.append(dist.irecv(view(recv_lo, nrl), src=lo, tag=2))
+                for r in reqs:
+                    r.wait()
+                return 0
+            except Exception as e:      # an exception must not unwind through the C frame
+                import sys
+                print(f"halo relay failed: {e!r}", file=sys.stderr, flush=True)
+                return 1
+        self._relay = RELAY_FN(cb)      # keep the thunk alive
+        self._chk(self.l.roms_hip_set_halo_relay(self._relay, None), "set_halo_relay")
 
     def calib_stream(self, n_doubles):
         self._chk(self.l.roms_hip_calib_stream(n_doubles), "calib_stream")

@@ -1,0 +1,74 @@
+"""GPU, multi-process: the N>1 device path.  One process per tile (2 and 4 tiles, all on
+the one GPU of the test box), halos through the library's host-relay transport over gloo.
+After 3 full steps every tile's owned AND ghost points must equal the single-tile HIP run
+bit for bit -- the reference's acceptance rule "identical results across tilings" -- which
+exercises the general (multi-tile) branch of every kernel, the pack/unpack kernels, the
+neighbour table incl. the periodic Nghost+1 rule and the two-phase corner propagation.
+The RCCL calls themselves need one GPU per rank and run only in bench.py --gpus N."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from roms_trunk_mgh_amd import ana, main3d
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _single(config, nsteps):
+    from roms_trunk_mgh_amd import hip
+    st = ana.make_tile(config, perturb=1.0)
+    be = hip.RomsHip(st)
+    m = main3d.Main3D(be)
+    m.initial()
+    m.run(nsteps)
+    be.to_host()
+    be.close()
+    return st
+
+
+@pytest.mark.parametrize("ntI,ntJ,config", [(2, 1, "BENCHMARK_TINY"), (1, 2, "UPWELLING"), (2, 2, "SEAMOUNT"),
+                                            (4, 1, "BENCHMARK_TINY")])
+def test_tiled_hip_equals_single_hip(tmp_path, ntI, ntJ, config):
+    nsteps = 3
+    world = ntI * ntJ
+    ref = _single(config, nsteps)          # before the children start: at most `world` + 1 GPU processes
+    port = _free_port()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_gpu_worker.py"), str(r), str(world), str(ntI),
+                               str(ntJ), config, str(nsteps), str(port), str(tmp_path)], env=env)
+             for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    rb = ref.b
+    for r in range(world):
+        d = np.load(os.path.join(tmp_path, f"tile{r}.npz"))
+        Istr, Iend, Jstr, Jend, LBi, LBj = [int(x) for x in d["bounds"]]
+        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz"):
+            a = d[name]
+            ni, nj = a.shape[0], a.shape[1]
+            i0, j0 = LBi - rb.LBi, LBj - rb.LBj
+            want = ref[name][i0:i0 + ni, j0:j0 + nj]
+            own = (slice(Istr - LBi, Iend - LBi + 1), slice(Jstr - LBj, Jend - LBj + 1))
+            assert np.array_equal(a[own], want[own]), (name, r, float(np.abs(a[own] - want[own]).max()))
+            if name in ("zeta", "t", "Hz", "W"):      # rho-type: every ghost point is defined
+                iv = min(ni, rb.Lm + rb.NghostPoints - LBi + 1)
+                jv = min(nj, rb.Mm + 1 - LBj + 1)
+                assert np.array_equal(a[:iv, :jv], want[:iv, :jv]), (name, r, "ghost points differ")
