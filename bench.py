@@ -31,6 +31,21 @@ TILINGS = {1: (1, 1), 2: (2, 1), 4: (4, 1), 8: (4, 2)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def pmc_traffic(config, gpus):
+    """HBM-side bytes per launch of the roofline kernel, from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).  Counters
+    cannot be read from inside the bench; the figure holds for the configuration it was measured on
+    (whole grid on one GPU) and is null otherwise."""
+    if gpus != 1:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            k = json.load(f)[config]["k_step3d_t_pipe"]
+        return float(k["fetch_bytes"] + k["write_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(config, nsteps):
     """The CPU oracle (a single-thread plain-C port of the reference kernels)
     timed on the host of the GPU box for a bounded number of full steps of the
@@ -184,7 +199,8 @@ def main():
                        "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok},
             "roofline": {"kernel": "k_step3d_t_pipe (step3d_t_tile)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_ms": t_ms, "algorithmic_bytes": alg_bytes},
+                         "traffic": pmc_traffic(args.config, args.gpus), "traffic_unit": "bytes/launch",
+                         "avg_ms": t_ms, "algorithmic_bytes": alg_bytes},
             "kernel_ms": per_kernel,
         }
         if not args.no_cpu_baseline and args.gpus == 1:
