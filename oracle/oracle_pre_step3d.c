@@ -18,8 +18,9 @@ int oracle_pre_step3d(OARGS)
   double cff, cff1, cff2, cff3, cff4, Gamma;
   for (int itrc = 1; itrc <= NT; itrc++) {
     int ha = p->Hadv[itrc - 1], va = p->Vadv[itrc - 1];
-    if (ha == ADV_MPDATA || ha == ADV_HSIMT || ha == ADV_SPLINES) return 8;
-    if (va == ADV_MPDATA || va == ADV_HSIMT || va == ADV_U3) return 8;
+    if (ha == ADV_HSIMT || ha == ADV_SPLINES) return 8;
+    if (va == ADV_HSIMT || va == ADV_U3) return 8;
+    if ((ha == ADV_MPDATA) != (va == ADV_MPDATA)) return 8;
   }
   double *CF_ = walloc(nis * (N + 1)), *DC_ = walloc(nis * (N + 1)), *FC_ = walloc(nis * (N + 1));
   double *swdk_ = walloc(nis * njs * (N + 1));
@@ -54,7 +55,21 @@ int oracle_pre_step3d(OARGS)
   for (int itrc = 1; itrc <= NT; itrc++) {
     const int ha = p->Hadv[itrc - 1];
     for (int k = 1; k <= N; k++) {
-      if (ha == ADV_C2) {
+      if (ha == ADV_MPDATA) {
+        /* first-order upstream fluxes, pre_step3d.F:364-386 */
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istr; i <= Iend + 1; i++) {
+            cff1 = MAX(Huon(i, j, k), 0.0);
+            cff2 = MIN(Huon(i, j, k), 0.0);
+            FX(i, j) = cff1 * t(i - 1, j, k, nstp, itrc) + cff2 * t(i, j, k, nstp, itrc);
+          }
+        for (int j = Jstr; j <= Jend + 1; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff1 = MAX(Hvom(i, j, k), 0.0);
+            cff2 = MIN(Hvom(i, j, k), 0.0);
+            FE(i, j) = cff1 * t(i, j - 1, k, nstp, itrc) + cff2 * t(i, j, k, nstp, itrc);
+          }
+      } else if (ha == ADV_C2) {
         for (int j = Jstr; j <= Jend; j++)
           for (int i = Istr; i <= Iend + 1; i++)
             FX(i, j) = Huon(i, j, k) * 0.5 * (t(i - 1, j, k, nstp, itrc) + t(i, j, k, nstp, itrc));
@@ -115,7 +130,7 @@ int oracle_pre_step3d(OARGS)
                          (t(i, j - 1, k, nstp, itrc) + t(i, j, k, nstp, itrc) - cff2 * (grad(i, j) - grad(i, j - 1)));
           }
       }
-      Gamma = 1.0 / 6.0;
+      Gamma = (ha == ADV_MPDATA) ? 0.5 : 1.0 / 6.0;          /* pre_step3d.F:557-563 */
       if (iic == ntfirst) { cff = 0.5 * dt; cff1 = 1.0; cff2 = 0.0; }
       else { cff = (1.0 - Gamma) * dt; cff1 = 0.5 + Gamma; cff2 = 0.5 - Gamma; }
       for (int j = Jstr; j <= Jend; j++)
@@ -130,7 +145,16 @@ int oracle_pre_step3d(OARGS)
   for (int j = Jstr; j <= Jend; j++) {
     for (int itrc = 1; itrc <= NT; itrc++) {
       const int va = p->Vadv[itrc - 1];
-      if (va == ADV_SPLINES) {
+      if (va == ADV_MPDATA) {
+        /* first-order upstream vertical flux, pre_step3d.F:729-748 */
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff1 = MAX(W(i, j, k), 0.0);
+            cff2 = MIN(W(i, j, k), 0.0);
+            FC(i, k) = cff1 * t(i, j, k, nstp, itrc) + cff2 * t(i, j, k + 1, nstp, itrc);
+          }
+        for (int i = Istr; i <= Iend; i++) { FC(i, 0) = 0.0; FC(i, N) = 0.0; }
+      } else if (va == ADV_SPLINES) {
         for (int i = Istr; i <= Iend; i++) { FC(i, 0) = 1.5 * t(i, j, 1, nstp, itrc); CF(i, 1) = 0.5; }
         for (int k = 1; k <= N - 1; k++)
           for (int i = Istr; i <= Iend; i++) {
@@ -182,7 +206,7 @@ int oracle_pre_step3d(OARGS)
           FC(i, N) = 0.0;
         }
       }
-      Gamma = 1.0 / 6.0;
+      Gamma = (va == ADV_MPDATA) ? 0.5 : 1.0 / 6.0;          /* pre_step3d.F:793-799 */
       if (iic == ntfirst) cff = 0.5 * dt;
       else cff = (1.0 - Gamma) * dt;
       for (int k = 1; k <= N; k++)

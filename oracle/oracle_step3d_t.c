@@ -6,6 +6,10 @@
  */
 #include "oracle.h"
 
+int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const roms_step_idx_t *s,
+                        roms_fields_t *F, const double *oHz_, const double *t3_,
+                        double *Ta_, double *Ua_, double *Va_, double *Wa_);   /* oracle_mpdata_adiff.c */
+
 int oracle_step3d_t(OARGS)
 {
   ORACLE_PROLOGUE
@@ -13,16 +17,29 @@ int oracle_step3d_t(OARGS)
   const int nnew = s->nnew;
   const double dt = p->dt;
   const double eps = 1.0E-16;
+  int Lmpdata = 0;
   for (int itrc = 1; itrc <= NT; itrc++) {
     int ha = p->Hadv[itrc - 1], va = p->Vadv[itrc - 1];
-    if (ha == ADV_MPDATA || ha == ADV_HSIMT || ha == ADV_SPLINES) return 8;
-    if (va == ADV_MPDATA || va == ADV_HSIMT || va == ADV_U3) return 8;
+    if (ha == ADV_HSIMT || ha == ADV_SPLINES) return 8;
+    if (va == ADV_HSIMT || va == ADV_U3) return 8;
+    /* the reference lets H and V differ; only the pair MPDATA/MPDATA is restated */
+    if ((ha == ADV_MPDATA) != (va == ADV_MPDATA)) return 8;
+    if (ha == ADV_MPDATA) Lmpdata = 1;
   }
+  if (Lmpdata && b->NghostPoints != 3) return 8;          /* inp_par.F:266-278 */
   double *FX_ = walloc(nis * njs), *FE_ = walloc(nis * njs);
   double *curv_ = walloc(nis * njs), *grad_ = walloc(nis * njs);
   double *oHz_ = walloc(nis * njs * N);
   double *CF_ = walloc(nis * (N + 1)), *BC_ = walloc(nis * (N + 1));
   double *DC_ = walloc(nis * (N + 1)), *FC_ = walloc(nis * (N + 1));
+  /* step3d_t.F:311-330: Ta(..,N,NT), Ua, Va, Wa allocated only when MPDATA is in use */
+  double *Ta_ = Lmpdata ? walloc(nis * njs * N * NT) : NULL;
+  double *Ua_ = Lmpdata ? walloc(nis * njs * N) : NULL, *Va_ = Lmpdata ? walloc(nis * njs * N) : NULL;
+  double *Wa_ = Lmpdata ? walloc(nis * njs * (N + 1)) : NULL;
+#define Ta(i,j,k,it) Ta_[WS3(i,j,k) + (long)((it) - 1) * nis * njs * N]
+#define Ua(i,j,k)    Ua_[WS3(i,j,k)]
+#define Va(i,j,k)    Va_[WS3(i,j,k)]
+#define Wa(i,j,k)    Wa_[WS2(i,j) + (long)(k) * nis * njs]
 #define FX(i,j)    FX_[WS2(i,j)]
 #define FE(i,j)    FE_[WS2(i,j)]
 #define curv(i,j)  curv_[WS2(i,j)]
@@ -34,14 +51,45 @@ int oracle_step3d_t(OARGS)
 #define FC(i,k)    FC_[WSK(i,k)]
 
   /* step3d_t.F:340-360 */
-  for (int k = 1; k <= N; k++)
-    for (int j = Jstr; j <= Jend; j++)
-      for (int i = Istr; i <= Iend; i++) oHz(i, j, k) = 1.0 / Hz(i, j, k);
+  if (Lmpdata) {
+    for (int k = 1; k <= N; k++)
+      for (int j = Jstrm2; j <= Jendp2; j++)
+        for (int i = Istrm2; i <= Iendp2; i++) oHz(i, j, k) = 1.0 / Hz(i, j, k);
+  } else {
+    for (int k = 1; k <= N; k++)
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend; i++) oHz(i, j, k) = 1.0 / Hz(i, j, k);
+  }
 
   /* T_LOOP1 / K_LOOP: horizontal advection, step3d_t.F:363-880 */
   for (int itrc = 1; itrc <= NT; itrc++) {
     const int ha = p->Hadv[itrc - 1];
+    /* three-point footprint: refresh the ghost points of t(nnew) first, :369-386 */
+    if (ha == ADV_MPDATA) o_exchange3d(b, GT_R, N, &t(LBi, LBj, 1, nnew, itrc));
     for (int k = 1; k <= N; k++) {
+      if (ha == ADV_MPDATA) {
+        /* first-order upstream fluxes on the extended range, :409-428 */
+        for (int j = JstrVm2; j <= Jendp2i; j++)
+          for (int i = IstrUm2; i <= Iendp3; i++) {
+            double cff1 = MAX(Huon(i, j, k), 0.0), cff2 = MIN(Huon(i, j, k), 0.0);
+            FX(i, j) = cff1 * t(i - 1, j, k, 3, itrc) + cff2 * t(i, j, k, 3, itrc);
+          }
+        for (int j = JstrVm2; j <= Jendp3; j++)
+          for (int i = IstrUm2; i <= Iendp2i; i++) {
+            double cff1 = MAX(Hvom(i, j, k), 0.0), cff2 = MIN(Hvom(i, j, k), 0.0);
+            FE(i, j) = cff1 * t(i, j - 1, k, 3, itrc) + cff2 * t(i, j, k, 3, itrc);
+          }
+        /* intermediate diffusive tracer Ta (m Tunits), :831-840 */
+        for (int j = JstrVm2; j <= Jendp2i; j++)
+          for (int i = IstrUm2; i <= Iendp2i; i++) {
+            double cff = dt * pm(i, j) * pn(i, j);
+            double cff1 = cff * (FX(i + 1, j) - FX(i, j));
+            double cff2 = cff * (FE(i, j + 1) - FE(i, j));
+            double cff3 = cff1 + cff2;
+            Ta(i, j, k, itrc) = t(i, j, k, nnew, itrc) - cff3;
+          }
+        continue;
+      }
       if (ha == ADV_C2) {
         for (int j = Jstr; j <= Jend; j++)
           for (int i = Istr; i <= Iend + 1; i++)
@@ -130,7 +178,26 @@ int oracle_step3d_t(OARGS)
   /* T_LOOP2 / J_LOOP1: vertical advection, step3d_t.F:883-1210 */
   for (int itrc = 1; itrc <= NT; itrc++) {
     const int va = p->Vadv[itrc - 1];
-    for (int j = Jstr; j <= Jend; j++) {
+    const int JminT = (va == ADV_MPDATA) ? JstrVm2 : Jstr, JmaxT = (va == ADV_MPDATA) ? Jendp2i : Jend;
+    for (int j = JminT; j <= JmaxT; j++) {
+      if (va == ADV_MPDATA) {
+        /* first-order upstream vertical flux, :1002-1018; Ta in Tunits, :1168-1177 */
+        for (int i = IstrUm2; i <= Iendp2i; i++) {
+          for (int k = 1; k <= N - 1; k++) {
+            double cff1 = MAX(W(i, j, k), 0.0), cff2 = MIN(W(i, j, k), 0.0);
+            FC(i, k) = cff1 * t(i, j, k, 3, itrc) + cff2 * t(i, j, k + 1, 3, itrc);
+          }
+          FC(i, 0) = 0.0;
+          FC(i, N) = 0.0;
+        }
+        for (int i = IstrUm2; i <= Iendp2i; i++) CF(i, 0) = dt * pm(i, j) * pn(i, j);
+        for (int k = 1; k <= N; k++)
+          for (int i = IstrUm2; i <= Iendp2i; i++) {
+            double cff1 = CF(i, 0) * (FC(i, k) - FC(i, k - 1));
+            Ta(i, j, k, itrc) = (Ta(i, j, k, itrc) - cff1) * oHz(i, j, k);
+          }
+        continue;
+      }
       if (va == ADV_SPLINES) {
         for (int i = Istr; i <= Iend; i++) {
           FC(i, 0) = 2.0 * t(i, j, 1, 3, itrc);
@@ -216,10 +283,96 @@ int oracle_step3d_t(OARGS)
     }
   }
 
-  /* J_LOOP2: implicit vertical diffusion, spline form, step3d_t.F:1363-1455 */
+  /* T_LOOP3: MPDATA anti-diffusive correction, step3d_t.F:1217-1318 */
+  for (int itrc = 1; itrc <= NT; itrc++) {
+    if (p->Hadv[itrc - 1] != ADV_MPDATA) continue;
+    int rc = oracle_mpdata_adiff(b, p, s, F, oHz_, &t(LBi, LBj, 1, 3, itrc), &Ta(IminS, JminS, 1, itrc),
+                                 Ua_, Va_, Wa_);
+    if (rc) return rc;
+    for (int k = 1; k <= N; k++) {
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend + 1; i++) {
+          double cff1 = MAX(Ua(i, j, k), 0.0), cff2 = MIN(Ua(i, j, k), 0.0);
+          FX(i, j) = (cff1 * Ta(i - 1, j, k, itrc) + cff2 * Ta(i, j, k, itrc)) *
+                     0.5 * (Hz(i, j, k) + Hz(i - 1, j, k)) * on_u(i, j);
+        }
+      for (int j = Jstr; j <= Jend + 1; j++)
+        for (int i = Istr; i <= Iend; i++) {
+          double cff1 = MAX(Va(i, j, k), 0.0), cff2 = MIN(Va(i, j, k), 0.0);
+          FE(i, j) = (cff1 * Ta(i, j - 1, k, itrc) + cff2 * Ta(i, j, k, itrc)) *
+                     0.5 * (Hz(i, j, k) + Hz(i, j - 1, k)) * om_v(i, j);
+        }
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend; i++) {
+          double cff = dt * pm(i, j) * pn(i, j);
+          double cff1 = cff * (FX(i + 1, j) - FX(i, j));
+          double cff2 = cff * (FE(i, j + 1) - FE(i, j));
+          double cff3 = cff1 + cff2;
+          t(i, j, k, nnew, itrc) = Ta(i, j, k, itrc) * Hz(i, j, k) - cff3;
+        }
+    }
+    for (int j = Jstr; j <= Jend; j++) {
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          double cff1 = MAX(Wa(i, j, k), 0.0), cff2 = MIN(Wa(i, j, k), 0.0);
+          FC(i, k) = cff1 * Ta(i, j, k, itrc) + cff2 * Ta(i, j, k + 1, itrc);
+        }
+      for (int i = Istr; i <= Iend; i++) {
+        FC(i, 0) = 0.0;
+        FC(i, N) = 0.0;
+      }
+      for (int i = Istr; i <= Iend; i++) CF(i, 0) = dt * pm(i, j) * pn(i, j);
+      for (int k = 1; k <= N; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          double cff1 = CF(i, 0) * (FC(i, k) - FC(i, k - 1));
+          t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) - cff1;      /* stays in m Tunits */
+        }
+    }
+  }
+
+  /* J_LOOP2: implicit vertical diffusion, step3d_t.F:1363-1560 */
   for (int j = Jstr; j <= Jend; j++) {
     for (int itrc = 1; itrc <= NT; itrc++) {
       const int ltrc = MIN(NAT, itrc);
+      if (p->Hadv[itrc - 1] == ADV_MPDATA) {
+        /* classic tridiagonal for MPDATA tracers (also under SPLINES_VDIFF), :1431-1501 */
+        double cff = -dt * p->lambda;
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            double cff1 = 1.0 / (z_r(i, j, k + 1) - z_r(i, j, k));
+            FC(i, k) = cff * cff1 * Akt(i, j, k, ltrc);
+          }
+        for (int i = Istr; i <= Iend; i++) {
+          FC(i, 0) = 0.0;
+          FC(i, N) = 0.0;
+        }
+        for (int k = 1; k <= N; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            BC(i, k) = Hz(i, j, k) - FC(i, k) - FC(i, k - 1);
+            DC(i, k) = t(i, j, k, nnew, itrc);
+          }
+        for (int i = Istr; i <= Iend; i++) {
+          cff = 1.0 / BC(i, 1);
+          CF(i, 1) = cff * FC(i, 1);
+          DC(i, 1) = cff * DC(i, 1);
+        }
+        for (int k = 2; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff = 1.0 / (BC(i, k) - FC(i, k - 1) * CF(i, k - 1));
+            CF(i, k) = cff * FC(i, k);
+            DC(i, k) = cff * (DC(i, k) - FC(i, k - 1) * DC(i, k - 1));
+          }
+        for (int i = Istr; i <= Iend; i++) {
+          DC(i, N) = (DC(i, N) - FC(i, N - 1) * DC(i, N - 1)) / (BC(i, N) - FC(i, N - 1) * CF(i, N - 1));
+          t(i, j, N, nnew, itrc) = DC(i, N);
+        }
+        for (int k = N - 1; k >= 1; k--)
+          for (int i = Istr; i <= Iend; i++) {
+            DC(i, k) = DC(i, k) - CF(i, k) * DC(i, k + 1);
+            t(i, j, k, nnew, itrc) = DC(i, k);
+          }
+        continue;
+      }
       double cff1 = 1.0 / 6.0;
       for (int k = 1; k <= N - 1; k++)
         for (int i = Istr; i <= Iend; i++) {
@@ -259,5 +412,6 @@ int oracle_step3d_t(OARGS)
   }
   free(FX_); free(FE_); free(curv_); free(grad_); free(oHz_);
   free(CF_); free(BC_); free(DC_); free(FC_);
+  free(Ta_); free(Ua_); free(Va_); free(Wa_);
   return 0;
 }

@@ -62,3 +62,14 @@ class Ref:
         rc = self.l.ref_call(KERNEL_ID[kernel], C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))
         if rc != 0:
             raise RuntimeError(f"ref_call {kernel} rc={rc}")
+
+    def mpdata_adiff(self, oHz, t3, Ta, Ua, Va, Wa):
+        """mpdata_adiff_tile on caller-held private arrays (Fortran-ordered float64):
+        oHz, Ta, Ua, Va (nis,njs,N), Wa (nis,njs,N+1), t3 = t(:,:,:,3,itrc) (ni,nj,N)."""
+        self.l.ref_mpdata_adiff.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.Fields)] + \
+                                           [C.c_void_p] * 6
+        rc = self.l.ref_mpdata_adiff(C.byref(self.st.b), C.byref(self.st.p), C.byref(self.F),
+                                     oHz.ctypes.data, t3.ctypes.data, Ta.ctypes.data, Ua.ctypes.data,
+                                     Va.ctypes.data, Wa.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"ref_mpdata_adiff rc={rc}")

@@ -340,3 +340,63 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   CALL c_f_pointer (F%beta, a2, (/ni,nj/));     a2 = MIXING(ng)%beta
 #endif
 END FUNCTION ref_call
+
+!-----------------------------------------------------------------------
+!  mpdata_adiff_tile (ROMS/Nonlinear/mpdata_adiff.F:38) on caller-held private
+!  arrays: oHz, Ta, Ua, Va are (IminS:ImaxS,JminS:JmaxS,N), Wa is (..,..,0:N),
+!  t3 is t(:,:,:,3,itrc) in module layout.
+FUNCTION ref_mpdata_adiff (b, p, F, oHz, t3, Ta, Ua, Va, Wa) BIND(C, name='ref_mpdata_adiff') RESULT(rc)
+  USE ref_wrap_types
+  USE mod_param
+  USE mod_scalars
+  USE mod_ncparam
+  USE mod_grid
+  USE mod_ocean
+  USE mpdata_adiff_mod, ONLY : mpdata_adiff_tile
+  TYPE(bounds_t), INTENT(in) :: b
+  TYPE(params_t), INTENT(in) :: p
+  TYPE(fields_t), INTENT(in) :: F
+  TYPE(c_ptr), VALUE :: oHz, t3, Ta, Ua, Va, Wa
+  INTEGER(c_int) :: rc
+  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, IminS, ImaxS, JminS, JmaxS, nis, njs
+  REAL(c_double), POINTER :: a2(:,:), a3(:,:,:)
+  REAL(c_double), POINTER :: poHz(:,:,:), pt3(:,:,:), pTa(:,:,:), pUa(:,:,:), pVa(:,:,:), pWa(:,:,:)
+  ng = 1; tile = 0
+  LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
+  ni = UBi-LBi+1; nj = UBj-LBj+1; NN = b%N
+  rc = 0
+  IF (LBi /= BOUNDS(ng)%LBi(0) .OR. UBi /= BOUNDS(ng)%UBi(0) .OR. LBj /= BOUNDS(ng)%LBj(0) .OR. UBj /= BOUNDS(ng)%UBj(0)) THEN
+    rc = 1
+    RETURN
+  END IF
+  dt(ng) = p%dt
+  !  the generic LBC indices initialize_ncparam would set (mod_ncparam.F:1235-1236)
+  isBu3d = isUvel
+  isBv3d = isVvel
+  LBC(iwest , isBu3d, ng)%closed = p%lbc_west  == 1
+  LBC(ieast , isBu3d, ng)%closed = p%lbc_east  == 1
+  LBC(isouth, isBv3d, ng)%closed = p%lbc_south == 1
+  LBC(inorth, isBv3d, ng)%closed = p%lbc_north == 1
+  CALL c_f_pointer (F%pm, a2, (/ni,nj/));       GRID(ng)%pm = a2
+  CALL c_f_pointer (F%pn, a2, (/ni,nj/));       GRID(ng)%pn = a2
+  CALL c_f_pointer (F%omn, a2, (/ni,nj/));      GRID(ng)%omn = a2
+  CALL c_f_pointer (F%om_u, a2, (/ni,nj/));     GRID(ng)%om_u = a2
+  CALL c_f_pointer (F%on_v, a2, (/ni,nj/));     GRID(ng)%on_v = a2
+  CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
+  CALL c_f_pointer (F%Huon, a3, (/ni,nj,NN/));  GRID(ng)%Huon = a3
+  CALL c_f_pointer (F%Hvom, a3, (/ni,nj,NN/));  GRID(ng)%Hvom = a3
+  CALL c_f_pointer (F%W, a3, (/ni,nj,NN+1/));   OCEAN(ng)%W = a3
+  IminS = BOUNDS(ng)%Istr(tile)-3; ImaxS = BOUNDS(ng)%Iend(tile)+3
+  JminS = BOUNDS(ng)%Jstr(tile)-3; JmaxS = BOUNDS(ng)%Jend(tile)+3
+  nis = ImaxS-IminS+1; njs = JmaxS-JminS+1
+  CALL c_f_pointer (oHz, poHz, (/nis,njs,NN/))
+  CALL c_f_pointer (t3,  pt3,  (/ni,nj,NN/))
+  CALL c_f_pointer (Ta,  pTa,  (/nis,njs,NN/))
+  CALL c_f_pointer (Ua,  pUa,  (/nis,njs,NN/))
+  CALL c_f_pointer (Va,  pVa,  (/nis,njs,NN/))
+  CALL c_f_pointer (Wa,  pWa,  (/nis,njs,NN+1/))
+  CALL mpdata_adiff_tile (ng, tile, LBi, UBi, LBj, UBj, IminS, ImaxS, JminS, JmaxS,   &
+ &                        GRID(ng)%pm, GRID(ng)%pn, GRID(ng)%omn, GRID(ng)%om_u, GRID(ng)%on_v, &
+ &                        GRID(ng)%z_r, poHz, GRID(ng)%Huon, GRID(ng)%Hvom, OCEAN(ng)%W, &
+ &                        pt3, pTa, pUa, pVa, pWa)
+END FUNCTION ref_mpdata_adiff

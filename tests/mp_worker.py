@@ -11,7 +11,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0):
+def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, variant=""):
     import torch
     import torch.distributed as dist
     import oracle
@@ -20,7 +20,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0):
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb)
+    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
+    st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb, **kw)
     b = st.b
     ni, nj = st.ni, st.nj
     sr = halo.gloo_sendrecv(dist, torch)
@@ -48,4 +49,5 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0):
 
 if __name__ == "__main__":
     a = sys.argv
-    run_rank(int(a[1]), int(a[2]), int(a[3]), int(a[4]), a[5], int(a[6]), int(a[7]), a[8])
+    run_rank(int(a[1]), int(a[2]), int(a[3]), int(a[4]), a[5], int(a[6]), int(a[7]), a[8],
+             variant=a[9] if len(a) > 9 else "")

@@ -24,28 +24,31 @@ def _free_port():
     return p
 
 
-def _single(config, nsteps):
+def _single(config, nsteps, variant=""):
     import oracle
-    st = ana.make_tile(config, perturb=1.0)
+    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
+    st = ana.make_tile(config, perturb=1.0, **kw)
     m = main3d.Main3D(oracle.Oracle(st))
     m.initial()
     m.run(nsteps)
     return st
 
 
-@pytest.mark.parametrize("ntI,ntJ,config", [(2, 1, "UPWELLING"), (1, 2, "UPWELLING"), (2, 2, "SEAMOUNT"),
-                                            (2, 1, "BENCHMARK_TINY")])
-def test_tiled_equals_single(tmp_path, ntI, ntJ, config):
+@pytest.mark.parametrize("ntI,ntJ,config,variant", [(2, 1, "UPWELLING", ""), (1, 2, "UPWELLING", ""),
+                                                    (2, 2, "SEAMOUNT", ""), (2, 1, "BENCHMARK_TINY", ""),
+                                                    # MPDATA on 6 tracers: three ghost points, extended flux ranges
+                                                    (2, 2, "BENCHMARK_TINY", "mpdata")])
+def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     nsteps = 3
     world = ntI * ntJ
     port = _free_port()
     env = dict(os.environ, OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker.py"), str(r), str(world), str(ntI),
-                               str(ntJ), config, str(nsteps), str(port), str(tmp_path)], env=env)
+                               str(ntJ), config, str(nsteps), str(port), str(tmp_path), variant], env=env)
              for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
-    ref = _single(config, nsteps)
+    ref = _single(config, nsteps, variant)
     rb = ref.b
     for r in range(world):
         d = np.load(os.path.join(tmp_path, f"tile{r}.npz"))
