@@ -11,6 +11,10 @@ __device__ __forceinline__ double hflux(double Hflx, double tm1, double t0, doub
   // differences centred on faces (dm1 = face-1, d0 = this face, dp1 = face+1).
   if constexpr (HADV == ADV_C2) {
     return Hflx * 0.5 * (tm1 + t0);
+  } else if constexpr (HADV == ADV_MPDATA) {
+    // first-order upstream (the MPDATA predictor, pre_step3d.F:364-386 / step3d_t.F:409-428)
+    const double cff1 = fmax(Hflx, 0.0), cff2 = fmin(Hflx, 0.0);
+    return cff1 * tm1 + cff2 * t0;
   } else if constexpr (HADV == ADV_U3) {
     const double curv_m1 = d0 - dm1;     // curv at cell m1
     const double curv_0 = dp1 - d0;      // curv at cell 0
@@ -41,6 +45,10 @@ __device__ __forceinline__ double vflux(int k, int N, double Wk, double tkm1, do
 {
   if constexpr (VADV == ADV_C2) {
     return Wk * 0.5 * (tk + tkp1);
+  } else if constexpr (VADV == ADV_MPDATA) {
+    // first-order upstream, pre_step3d.F:729-748
+    const double cff1 = fmax(Wk, 0.0), cff2 = fmin(Wk, 0.0);
+    return cff1 * tk + cff2 * tkp1;
   } else if constexpr (VADV == ADV_A4) {
     const double cff1 = 1.0 / 3.0;
     return Wk * 0.5 * (tk + tkp1 - cff1 * (a4_cf_kp1 - a4_cf_k));

@@ -1,0 +1,462 @@
+// k_mpdata.hip -- the MPDATA branch of step3d_t_tile (ROMS/Nonlinear/step3d_t.F:363-1318,
+// :1431-1501) with mpdata_adiff_tile (ROMS/Nonlinear/mpdata_adiff.F:38-1105) for one tracer:
+//
+//   K1 k_mp_ta     first-order upstream H + V advection on the extended range
+//                  (IstrUm2:Iendp2i, JstrVm2:Jendp2i) -> intermediate tracer Ta (Tunits),
+//                  wall rows copied (mpdata_adiff.F:170-240)
+//   K2 k_mp_adiff  anti-diffusive velocities Ua, Va, Wa incl. the third-order terms
+//                  (MPDATA_HOT) and the |.| <= |Um| clamp (mpdata_adiff.F:258-840)
+//   K3 k_mp_beta   flux-corrected-transport factors beta_up / beta_dn (:842-1030)
+//   K4 k_mp_update limited transports (:1032-1100) -> corrected H and V advection of Ta
+//                  (step3d_t.F:1235-1316) -> classic tridiagonal vertical diffusion
+//                  (:1431-1501), one thread per column, Thomas arrays in VGPRs
+//
+// Ta, Ua, Va, Wa, beta_up, beta_dn live in the library's 3-D scratch arrays with the
+// module extents (LBi:UBi,LBj:UBj) -- a superset of the reference's private IminS:ImaxS
+// extents with three ghost points.  oHz and odz are recomputed where they are used (the
+// same IEEE division, so the same bits).  Expressions keep the reference's association.
+#include "roms_dev.h"
+
+int roms_entry_check(const char *name);
+
+namespace {
+
+#define EPS_MP  1.0E-18
+#define EPS2_MP 1.0E-10
+
+struct MpArgs {
+  double *Ta, *Ua, *Va, *Wa, *bup, *bdn;   // scratch, module horizontal extents
+  int nnew, itrc;
+};
+
+__device__ __forceinline__ double upstream(double flx, double a, double b)
+{
+  return fmax(flx, 0.0) * a + fmin(flx, 0.0) * b;
+}
+
+// ---------------------------------------------------------------- K1: Ta ----
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.IstrUm2 + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.JstrVm2 + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.Iendp2i || j > b.Jendp2i) return;
+  const double dt = c->p.dt;
+  const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (m.itrc - 1)) * n3r);
+  const gcd_t tn = (gcd_t)(c->F.t + ((long)(m.nnew - 1) + 3L * (m.itrc - 1)) * n3r);
+  const gcd_t Huon = (gcd_t)c->F.Huon, Hvom = (gcd_t)c->F.Hvom, Wv = (gcd_t)c->F.W, Hz = (gcd_t)c->F.Hz;
+  const gd_t Ta = (gd_t)m.Ta;
+  const long c0 = I2(i, j);
+  const double cff = dt * c->F.pm[c0] * c->F.pn[c0];
+  const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
+  const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
+  double FCm1 = 0.0;
+  for (int k = 1; k <= N; k++) {
+    const long a = c0 + (long)(k - 1) * nij;
+    const double t0 = t3[a];
+    const double FXi = upstream(Huon[a], t3[a - 1], t0);
+    const double FXip1 = upstream(Huon[a + 1], t0, t3[a + 1]);
+    const double FEj = upstream(Hvom[a], t3[a - ni], t0);
+    const double FEjp1 = upstream(Hvom[a + ni], t0, t3[a + ni]);
+    const double cff1 = cff * (FXip1 - FXi);
+    const double cff2 = cff * (FEjp1 - FEj);
+    const double cff3 = cff1 + cff2;
+    double ta = tn[a] - cff3;                                   // step3d_t.F:838
+    const double FCk = (k < N) ? upstream(Wv[a + nij], t0, t3[a + nij]) : 0.0;   // :1006-1018
+    const double c1 = cff * (FCk - FCm1);
+    ta = (ta - c1) * (1.0 / Hz[a]);                             // :1175
+    FCm1 = FCk;
+    Ta[a] = ta;
+    if (s_wall) Ta[a - ni] = ta;                                // mpdata_adiff.F:193-199
+    if (n_wall) Ta[a + ni] = ta;
+  }
+}
+
+// ------------------------------------------------- K2: Ua, Va, Wa (raw) ----
+// vertical-gradient factor C and mean vertical Courant number Wm of a face between
+// column p (offset 0) and column q (offset dq), mpdata_adiff.F:262-310 / :456-504
+__device__ __forceinline__ void face_CW(const gcd_t Ta, const gcd_t z_r, const gcd_t Wv, const double *__restrict__ pm,
+                                        const double *__restrict__ pn, long a2, long a, long dq, long nij, int k, int N,
+                                        double dt, double &C, double &Wm)
+{
+  // a = index of (p,k) in rho arrays, a2 = 2-D index of p; q = p + dq
+  const long aq = a + dq, a2q = a2 + dq;
+  auto odz = [&](long x) { return 1.0 / (z_r[x + nij] - z_r[x]); };       // odz at level of x
+  const long w = a + nij, wq = aq + nij;      // W(.,.,k) of a K_3DW array = rho index + nij
+  if (k == 1) {
+    C = 0.25 * ((Ta[a + nij] - Ta[a]) * odz(a) + (Ta[aq + nij] - Ta[aq]) * odz(aq)) *
+        (z_r[a + nij] - z_r[a] + z_r[aq + nij] - z_r[aq]) / (Ta[aq] + Ta[a] + EPS_MP);
+    Wm = 0.25 * dt * (Wv[wq] * odz(aq) * pm[a2q] * pn[a2q] + Wv[w] * odz(a) * pm[a2] * pn[a2]);
+  } else if (k < N) {
+    C = 0.0625 *
+        ((Ta[a + nij] - Ta[a]) * odz(a) + (Ta[a] - Ta[a - nij]) * odz(a - nij) +
+         (Ta[aq + nij] - Ta[aq]) * odz(aq) + (Ta[aq] - Ta[aq - nij]) * odz(aq - nij)) *
+        (z_r[a + nij] - z_r[a - nij] + z_r[aq + nij] - z_r[aq - nij]) / (Ta[aq] + Ta[a] + EPS_MP);
+    Wm = 0.25 * dt *
+         ((Wv[wq - nij] * odz(aq - nij) + Wv[wq] * odz(aq)) * pm[a2q] * pn[a2q] +
+          (Wv[w] * odz(a) + Wv[w - nij] * odz(a - nij)) * pm[a2] * pn[a2]);
+  } else {
+    C = 0.25 * ((Ta[a] - Ta[a - nij]) * odz(a - nij) + (Ta[aq] - Ta[aq - nij]) * odz(aq - nij)) *
+        (z_r[a] - z_r[a - nij] + z_r[aq] - z_r[aq - nij]) / (Ta[aq] + Ta[a] + EPS_MP);
+    Wm = 0.25 * dt * (Wv[wq - nij] * odz(aq - nij) * pm[a2q] * pn[a2q] + Wv[w - nij] * odz(a - nij) * pm[a2] * pn[a2]);
+  }
+}
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
+{
+  DEV_PROLOGUE(c)
+  // union of the three ranges: i = IstrU-1 : Iendp2, j = JstrV-1 : Jendp2
+  const int i = b.IstrU - 1 + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.JstrV - 1 + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.Iendp2 || j > b.Jendp2) return;
+  const bool do_u = j <= b.Jendp1;                                  // Ua: j = JstrV-1:Jendp1, i = IstrU-1:Iendp2
+  const bool do_v = j >= b.JstrVm1 && i <= b.Iendp1;                // Va: j = JstrVm1:Jendp2, i = IstrU-1:Iendp1
+  const bool do_w = j <= b.Jendp1 && i <= b.Iendp1;                 // Wa: j = JstrV-1:Jendp1, i = IstrU-1:Iendp1
+  const double dt = c->p.dt;
+  const gcd_t Ta = (gcd_t)m.Ta;
+  const gcd_t z_r = (gcd_t)c->F.z_r, Wv = (gcd_t)c->F.W, Hz = (gcd_t)c->F.Hz;
+  const gcd_t Huon = (gcd_t)c->F.Huon, Hvom = (gcd_t)c->F.Hvom;
+  const double *__restrict__ pm = c->F.pm, *__restrict__ pn = c->F.pn;
+  const double *__restrict__ on_v = c->F.on_v, *__restrict__ om_u = c->F.om_u;
+  const gd_t Ua = (gd_t)m.Ua, Va = (gd_t)m.Va, Wa = (gd_t)m.Wa;
+  const long a2 = I2(i, j);
+  const bool v_wall_n = b.north_edge && !b.NSperiodic && j == b.Jend + 1;   // Va(i,Jend+1) = 0, mpdata_adiff.F:694-700
+  auto oHz = [&](long x) { return 1.0 / Hz[x]; };
+  for (int k = 1; k <= N; k++) {
+    const long a = a2 + (long)(k - 1) * nij;
+    const double T0 = Ta[a];
+    // ---------------- XI face between (i-1,j) and (i,j) ----------------
+    if (do_u) {
+      const double Tw = Ta[a - 1];
+      double ua = 0.0;
+      if (!((Tw <= 0.0) || (T0 <= 0.0) || (fabs(Tw - T0) <= EPS2_MP))) {
+        double Ck, Wk;
+        face_CW(Ta, z_r, Wv, pm, pn, a2, a, -1, nij, k, N, dt, Ck, Wk);
+        const double A = (T0 - Tw) / (T0 + Tw + EPS_MP);
+        double B = 0.03125 *
+                   ((Ta[a + ni] - T0) * (pn[a2] + pn[a2 + ni]) + (T0 - Ta[a - ni]) * (pn[a2 - ni] + pn[a2]) +
+                    (Ta[a - 1 + ni] - Tw) * (pn[a2 - 1] + pn[a2 - 1 + ni]) +
+                    (Tw - Ta[a - 1 - ni]) * (pn[a2 - 1 - ni] + pn[a2 - 1]));
+        B = B * (on_v[a2] + on_v[a2 + ni] + on_v[a2 - 1] + on_v[a2 - 1 + ni]) / (Tw + T0 + EPS_MP);
+        const double Um = 0.125 * Huon[a] * dt * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a - 1) + oHz(a));
+        const double Vm = 0.03125 * dt *
+                          (Hvom[a - 1] * (pm[a2 - 1] + pm[a2 - 1 - ni]) * (pn[a2 - 1] + pn[a2 - 1 - ni]) *
+                               (oHz(a - 1) + oHz(a - 1 - ni)) +
+                           Hvom[a - 1 + ni] * (pm[a2 - 1 + ni] + pm[a2 - 1]) * (pn[a2 - 1 + ni] + pn[a2 - 1]) *
+                               (oHz(a - 1 + ni) + oHz(a - 1)) +
+                           Hvom[a] * (pm[a2] + pm[a2 - ni]) * (pn[a2] + pn[a2 - ni]) * (oHz(a) + oHz(a - ni)) +
+                           Hvom[a + ni] * (pm[a2 + ni] + pm[a2]) * (pn[a2 + ni] + pn[a2]) * (oHz(a + ni) + oHz(a)));
+        const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
+        const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
+        const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
+        const double AA = A * A, BB = B * B, CC = Ck * Ck, AB = A * B, AC = A * Ck;
+        const double XX = X * X, YY = Y * Y, ZZ = Z * Z, XY = X * Y, XZ = X * Z;
+        const double sig_alfa = 1.0 / (1.0 - fabs(A) + EPS_MP);
+        const double sig_beta = -A / ((1.0 - fabs(A)) * (1.0 - AA) + EPS_MP);
+        const double sig_gama = 2.0 * fabs(AA * A) / ((1.0 - fabs(A)) * (1.0 - AA) * (1.0 - fabs(AA * A)) + EPS_MP);
+        const double sig_a = -B / ((1.0 - fabs(A)) * (1.0 - fabs(AB)) + EPS_MP);
+        const double sig_b = AB / ((1.0 - fabs(A)) * (1.0 - AA * fabs(B)) + EPS_MP) *
+                             (fabs(B) / (1.0 - fabs(AB) + EPS_MP) + 2.0 * A / (1.0 - AA + EPS_MP));
+        const double sig_c = fabs(A) * BB / ((1.0 - fabs(A)) * (1.0 - BB * fabs(A)) * (1.0 - fabs(AB)) + EPS_MP);
+        const double sig_d = -Ck / ((1.0 - fabs(A)) * (1.0 - fabs(AC)) + EPS_MP);
+        const double sig_e = AC / ((1.0 - fabs(A)) * (1.0 - AA * fabs(Ck)) + EPS_MP) *
+                             (fabs(Ck) / (1.0 - fabs(AC) + EPS_MP) + 2.0 * A / (1.0 - AA + EPS_MP));
+        const double sig_f = fabs(A) * CC / ((1.0 - fabs(A)) * (1.0 - CC * fabs(A)) * (1.0 - fabs(AC)) + EPS_MP);
+        const double u0 = sig_alfa * X + sig_beta * XX + sig_gama * XX * X + sig_a * XY + sig_b * XX * Y +
+                          sig_c * X * YY + sig_d * XZ + sig_e * XX * Z + sig_f * X * ZZ;
+        ua = fmin(fabs(u0), 1.0 * fabs(Um)) * copysign(1.0, u0);
+      }
+      Ua[a] = ua;
+    }
+    // ---------------- ETA face between (i,j-1) and (i,j) ----------------
+    if (do_v) {
+      const double Ts = Ta[a - ni];
+      double va = 0.0;
+      if (!v_wall_n && !((Ts <= 0.0) || (T0 <= 0.0) || (fabs(Ts - T0) <= EPS2_MP))) {
+        double Ck, Wk;
+        face_CW(Ta, z_r, Wv, pm, pn, a2, a, -ni, nij, k, N, dt, Ck, Wk);
+        double A = 0.03125 *
+                   ((Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]) + (T0 - Ta[a - 1]) * (pm[a2 - 1] + pm[a2]) +
+                    (Ta[a + 1 - ni] - Ts) * (pm[a2 + 1 - ni] + pm[a2 - ni]) +
+                    (Ts - Ta[a - 1 - ni]) * (pm[a2 - 1 - ni] + pm[a2 - ni]));
+        A = A * (om_u[a2] + om_u[a2 + 1] + om_u[a2 - ni] + om_u[a2 + 1 - ni]) / (Ts + T0 + EPS_MP);
+        const double B = (T0 - Ts) / (T0 + Ts + EPS_MP);
+        const double Um = 0.03125 * dt *
+                          (Huon[a + 1] * (pm[a2 + 1] + pm[a2]) * (pn[a2 + 1] + pn[a2]) * (oHz(a + 1) + oHz(a)) +
+                           Huon[a + 1 - ni] * (pm[a2 + 1 - ni] + pm[a2 - ni]) * (pn[a2 + 1 - ni] + pn[a2 - ni]) *
+                               (oHz(a + 1 - ni) + oHz(a - ni)) +
+                           Huon[a] * (pm[a2 - 1] + pm[a2]) * (pn[a2 - 1] + pn[a2]) * (oHz(a - 1) + oHz(a)) +
+                           Huon[a - ni] * (pm[a2 - 1 - ni] + pm[a2 - ni]) * (pn[a2 - 1 - ni] + pn[a2 - ni]) *
+                               (oHz(a - 1 - ni) + oHz(a - ni)));
+        const double Vm = 0.125 * Hvom[a] * dt * (pn[a2 - ni] + pn[a2]) * (pm[a2 - ni] + pm[a2]) * (oHz(a - ni) + oHz(a));
+        const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
+        const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
+        const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
+        const double AA = A * A, BB = B * B, CC = Ck * Ck, AB = A * B, BC = B * Ck;
+        const double XX = X * X, YY = Y * Y, ZZ = Z * Z, XY = X * Y, YZ = Y * Z;
+        const double sig_alfa = 1.0 / (1.0 - fabs(B) + EPS_MP);
+        const double sig_beta = -B / ((1.0 - fabs(B)) * (1.0 - BB) + EPS_MP);
+        const double sig_gama = 2.0 * fabs(BB * B) / ((1.0 - fabs(B)) * (1.0 - BB) * (1.0 - fabs(BB * B)) + EPS_MP);
+        const double sig_a = -A / ((1.0 - fabs(B)) * (1.0 - fabs(AB)) + EPS_MP);
+        const double sig_b = AB / ((1.0 - fabs(B)) * (1.0 - BB * fabs(A)) + EPS_MP) *
+                             (fabs(A) / (1.0 - fabs(AB) + EPS_MP) + 2.0 * B / (1.0 - BB + EPS_MP));
+        const double sig_c = fabs(B) * AA / ((1.0 - fabs(B)) * (1.0 - AA * fabs(B)) * (1.0 - fabs(AB)) + EPS_MP);
+        const double sig_d = -Ck / ((1.0 - fabs(B)) * (1.0 - fabs(BC)) + EPS_MP);
+        const double sig_e = BC / ((1.0 - fabs(B)) * (1.0 - BB * fabs(Ck)) + EPS_MP) *
+                             (fabs(Ck) / (1.0 - fabs(BC) + EPS_MP) + 2.0 * B / (1.0 - BB + EPS_MP));
+        const double sig_f = fabs(B) * CC / ((1.0 - fabs(B)) * (1.0 - CC * fabs(B)) * (1.0 - fabs(BC)) + EPS_MP);
+        const double v0 = sig_alfa * Y + sig_beta * YY + sig_gama * YY * Y + sig_a * XY + sig_b * Y * XX +
+                          sig_c * YY * X + sig_d * YZ + sig_e * YY * Z + sig_f * Y * ZZ;
+        va = fmin(fabs(v0), 1.0 * fabs(Vm)) * copysign(1.0, v0);
+      }
+      Va[a] = va;
+      // closed southern wall: Va(i,Jstr) = 0 (:683-689); row Jstr is below this kernel's Va range
+      if (b.south_edge && !b.NSperiodic && j == b.Jstr + 1) Va[a - ni] = 0.0;
+    }
+    // ---------------- W face between levels k and k+1 ----------------
+    if (do_w) {
+      const long aw = a + nij;                 // Wa(i,j,k) in a (0:N) array
+      if (k == 1) Wa[a2] = 0.0;                // Wa(i,j,0)
+      if (k == N) { Wa[aw] = 0.0; continue; }  // Wa(i,j,N)
+      const double Tu = Ta[a + nij];
+      double wa = 0.0;
+      if (!((T0 <= 0.0) || (Tu <= 0.0) || (fabs(T0 - Tu) <= EPS2_MP))) {
+        const double Ck = (Tu - T0) / (Tu + T0 + EPS_MP);
+        double A = 0.0625 *
+                   ((Ta[a + 1 + nij] - Tu) * (pm[a2 + 1] + pm[a2]) + (Tu - Ta[a - 1 + nij]) * (pm[a2] + pm[a2 - 1]) +
+                    (Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]) + (T0 - Ta[a - 1]) * (pm[a2] + pm[a2 - 1]));
+        double B = 0.0625 *
+                   ((Ta[a + ni + nij] - Tu) * (pn[a2 + ni] + pn[a2]) + (Tu - Ta[a - ni + nij]) * (pn[a2] + pn[a2 - ni]) +
+                    (Ta[a + ni] - T0) * (pn[a2 + ni] + pn[a2]) + (T0 - Ta[a - ni]) * (pn[a2] + pn[a2 - ni]));
+        A = A * (om_u[a2 + 1] + om_u[a2]) / (Tu + T0 + EPS_MP);
+        B = B * (on_v[a2 + ni] + on_v[a2]) / (Tu + T0 + EPS_MP);
+        const double Um = 0.03125 * dt *
+                          (Huon[a] * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a) + oHz(a - 1)) +
+                           Huon[a + nij] * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a + nij) + oHz(a - 1 + nij)) +
+                           Huon[a + 1] * (pm[a2] + pm[a2 + 1]) * (pn[a2] + pn[a2 + 1]) * (oHz(a) + oHz(a + 1)) +
+                           Huon[a + 1 + nij] * (pm[a2] + pm[a2 + 1]) * (pn[a2] + pn[a2 + 1]) *
+                               (oHz(a + nij) + oHz(a + 1 + nij)));
+        const double Vm = 0.03125 * dt *
+                          (Hvom[a] * (pm[a2] + pm[a2 - ni]) * (pn[a2] + pn[a2 - ni]) * (oHz(a) + oHz(a - ni)) +
+                           Hvom[a + nij] * (pm[a2] + pm[a2 - ni]) * (pn[a2] + pn[a2 - ni]) * (oHz(a + nij) + oHz(a - ni + nij)) +
+                           Hvom[a + ni] * (pm[a2] + pm[a2 + ni]) * (pn[a2] + pn[a2 + ni]) * (oHz(a) + oHz(a + ni)) +
+                           Hvom[a + ni + nij] * (pm[a2] + pm[a2 + ni]) * (pn[a2] + pn[a2 + ni]) *
+                               (oHz(a + nij) + oHz(a + ni + nij)));
+        const double Wk = Wv[aw] * (1.0 / (z_r[a + nij] - z_r[a])) * pm[a2] * pn[a2] * dt;
+        const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
+        const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
+        const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
+        const double AA = A * A, BB = B * B, CC = Ck * Ck, AC = A * Ck, BC = B * Ck;
+        const double XX = X * X, YY = Y * Y, ZZ = Z * Z, XZ = X * Z, YZ = Y * Z;
+        const double sig_alfa = 1.0 / (1.0 - fabs(Ck) + EPS_MP);
+        const double sig_beta = -Ck / ((1.0 - fabs(Ck)) * (1.0 - CC) + EPS_MP);
+        const double sig_gama = 2.0 * fabs(CC * Ck) / ((1.0 - fabs(Ck)) * (1.0 - CC) * (1.0 - fabs(CC * Ck)) + EPS_MP);
+        const double sig_a = -B / ((1.0 - fabs(Ck)) * (1.0 - fabs(BC)) + EPS_MP);
+        const double sig_b = BC / ((1.0 - fabs(Ck)) * (1.0 - CC * fabs(B)) + EPS_MP) *
+                             (fabs(B) / (1.0 - fabs(BC) + EPS_MP) + 2.0 * Ck / (1.0 - CC + EPS_MP));
+        const double sig_c = fabs(Ck) * BB / ((1.0 - fabs(Ck)) * (1.0 - B * B * fabs(Ck)) * (1.0 - fabs(BC)) + EPS_MP);
+        const double sig_d = -A / ((1.0 - fabs(Ck)) * (1.0 - fabs(AC)) + EPS_MP);
+        const double sig_e = AC / ((1.0 - fabs(Ck)) * (1.0 - CC * fabs(A)) + EPS_MP) *
+                             (fabs(A) / (1.0 - fabs(AC) + EPS_MP) + 2.0 * Ck / (1.0 - CC + EPS_MP));
+        const double sig_f = fabs(Ck) * AA / ((1.0 - fabs(Ck)) * (1.0 - AA * fabs(Ck)) * (1.0 - fabs(AC)) + EPS_MP);
+        const double w0 = sig_alfa * Z + sig_beta * ZZ + sig_gama * ZZ * Z + sig_a * YZ + sig_b * ZZ * Y +
+                          sig_c * Z * YY + sig_d * XZ + sig_e * ZZ * X + sig_f * Z * XX;
+        wa = fmin(fabs(w0), 1.0 * fabs(Wk)) * copysign(1.0, w0);
+      }
+      Wa[aw] = wa;
+    }
+  }
+}
+
+// ------------------------------------------------------ K3: beta_up/dn ----
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_mp_beta(const RomsDev *__restrict__ c, MpArgs m)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.IstrU - 1 + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.JstrV - 1 + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.Iendp1 || j > b.Jendp1) return;
+  const gcd_t Ta = (gcd_t)m.Ta, Ua = (gcd_t)m.Ua, Va = (gcd_t)m.Va, Wa = (gcd_t)m.Wa;
+  const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (m.itrc - 1)) * n3r);
+  const gd_t bup = (gd_t)m.bup, bdn = (gd_t)m.bdn;
+  const long a2 = I2(i, j);
+  for (int k = 1; k <= N; k++) {
+    const long a = a2 + (long)(k - 1) * nij;
+    const long aw = a + nij;                                     // Wa(i,j,k); Wa(i,j,k-1) = Wa[a]
+    const double T0 = Ta[a], Tw = Ta[a - 1], Te = Ta[a + 1], Ts = Ta[a - ni], Tn = Ta[a + ni];
+    double Tmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
+                                 t3[a - ni]), Tn), t3[a + ni]);
+    double Tmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
+                                 t3[a - ni]), Tn), t3[a + ni]);
+    if (k > 1) {
+      Tmax = fmax(fmax(Tmax, Ta[a - nij]), t3[a - nij]);
+      Tmin = fmin(fmin(Tmin, Ta[a - nij]), t3[a - nij]);
+    }
+    if (k < N) {
+      Tmax = fmax(fmax(Tmax, Ta[a + nij]), t3[a + nij]);
+      Tmin = fmin(fmin(Tmin, Ta[a + nij]), t3[a + nij]);
+    }
+    const double ua0 = Ua[a], ua1 = Ua[a + 1], va0 = Va[a], va1 = Va[a + ni];
+    double cff1 = Tw * fmax(0.0, ua0) - Te * fmin(0.0, ua1) + Ts * fmax(0.0, va0) - Tn * fmin(0.0, va1);
+    double cff2 = T0 * fmax(0.0, ua1) - T0 * fmin(0.0, ua0) + T0 * fmax(0.0, va1) - T0 * fmin(0.0, va0);
+    if (k == 1) {
+      cff1 = cff1 - Ta[a + nij] * fmin(0.0, Wa[aw]);
+      cff2 = cff2 + T0 * fmax(0.0, Wa[aw]);
+    } else if (k < N) {
+      cff1 = cff1 + Ta[a - nij] * fmax(0.0, Wa[a]) - Ta[a + nij] * fmin(0.0, Wa[aw]);
+      cff2 = cff2 + T0 * fmax(0.0, Wa[aw]) - T0 * fmin(0.0, Wa[a]);
+    } else {
+      cff1 = cff1 + Ta[a - nij] * fmax(0.0, Wa[a]);
+      cff2 = cff2 - T0 * fmin(0.0, Wa[a]);
+    }
+    bup[a] = (Tmax - T0) / (cff1 + EPS_MP);
+    bdn[a] = (T0 - Tmin) / (cff2 + EPS_MP);
+  }
+}
+
+// -------------------------- K4: limited transports, update, tridiagonal ----
+template <int NMAX>
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.Jend) return;
+  const double dt = c->p.dt;
+  const gcd_t Ta = (gcd_t)m.Ta, Ua = (gcd_t)m.Ua, Va = (gcd_t)m.Va, Wa = (gcd_t)m.Wa;
+  const gcd_t bup = (gcd_t)m.bup, bdn = (gcd_t)m.bdn;
+  const gcd_t Hz = (gcd_t)c->F.Hz, z_r = (gcd_t)c->F.z_r;
+  const int ltrc = m.itrc < b.NAT ? m.itrc : b.NAT;
+  const gcd_t Akt = (gcd_t)(c->F.Akt + (long)(ltrc - 1) * n3w);
+  const gd_t tn = (gd_t)(c->F.t + ((long)(m.nnew - 1) + 3L * (m.itrc - 1)) * n3r);
+  const long a2 = I2(i, j);
+  const double cffa = 1.0 / dt;                                   // mpdata_adiff.F:254
+  const double cpp = dt * c->F.pm[a2] * c->F.pn[a2];
+  const double omu0 = c->F.om_u[a2], omu1 = c->F.om_u[a2 + 1], onv0 = c->F.on_v[a2], onv1 = c->F.on_v[a2 + ni];
+  const double onu0 = c->F.on_u[a2], onu1 = c->F.on_u[a2 + 1], omv0 = c->F.om_v[a2], omv1 = c->F.om_v[a2 + ni];
+  const double omn = c->F.omn[a2];
+  // walls of the limited transports, mpdata_adiff.F:1068-1100 (E-W periodic, closed N-S)
+  const bool v0_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;       // Va(i,Jstr) = 0
+  const bool v1_wall = b.north_edge && !b.NSperiodic && j == b.Jend;       // Va(i,Jend+1) = 0
+  auto lim_u = [&](long x, double om) {       // limited Ua at index x (face between x-1 and x), :1034-1040
+    const double cff1 = fmin(fmin(bdn[x - 1], bup[x]), 1.0);
+    const double cff2 = fmin(fmin(bup[x - 1], bdn[x]), 1.0);
+    return (cff1 * fmax(0.0, Ua[x]) + cff2 * fmin(0.0, Ua[x])) * cffa * om;
+  };
+  auto lim_v = [&](long x, double on) {       // :1042-1049
+    const double cff1 = fmin(fmin(bdn[x - ni], bup[x]), 1.0);
+    const double cff2 = fmin(fmin(bup[x - ni], bdn[x]), 1.0);
+    return (cff1 * fmax(0.0, Va[x]) + cff2 * fmin(0.0, Va[x])) * cffa * on;
+  };
+  double DCm[NMAX + 1];      // right-hand side / solution
+  double CFm[NMAX + 1];
+  double FCm1 = 0.0;         // corrected vertical flux through the bottom face
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      const long a = a2 + (long)(k - 1) * nij;
+      const double T0 = Ta[a], hz = Hz[a];
+      const double u0 = lim_u(a, omu0), u1 = lim_u(a + 1, omu1);
+      const double v0 = v0_wall ? 0.0 : lim_v(a, onv0);
+      const double v1 = v1_wall ? 0.0 : lim_v(a + ni, onv1);
+      // corrected horizontal fluxes, step3d_t.F:1238-1255
+      const double FXi = (fmax(u0, 0.0) * Ta[a - 1] + fmin(u0, 0.0) * T0) * 0.5 * (hz + Hz[a - 1]) * onu0;
+      const double FXip1 = (fmax(u1, 0.0) * T0 + fmin(u1, 0.0) * Ta[a + 1]) * 0.5 * (Hz[a + 1] + hz) * onu1;
+      const double FEj = (fmax(v0, 0.0) * Ta[a - ni] + fmin(v0, 0.0) * T0) * 0.5 * (hz + Hz[a - ni]) * omv0;
+      const double FEjp1 = (fmax(v1, 0.0) * T0 + fmin(v1, 0.0) * Ta[a + ni]) * 0.5 * (Hz[a + ni] + hz) * omv1;
+      const double cff1 = cpp * (FXip1 - FXi);
+      const double cff2 = cpp * (FEjp1 - FEj);
+      const double cff3 = cff1 + cff2;
+      double tv = T0 * hz - cff3;                                 // :1265
+      // corrected vertical flux through the top face, :1281-1290 with the limited Wa (:1051-1060)
+      double FCk = 0.0;
+      if (k < N) {
+        const long aw = a + nij;
+        const double c1 = fmin(fmin(bdn[a], bup[a + nij]), 1.0);
+        const double c2 = fmin(fmin(bup[a], bdn[a + nij]), 1.0);
+        const double w = (c1 * fmax(0.0, Wa[aw]) + c2 * fmin(0.0, Wa[aw])) * cffa * omn * (z_r[a + nij] - z_r[a]);
+        FCk = fmax(w, 0.0) * T0 + fmin(w, 0.0) * Ta[a + nij];
+      }
+      tv = tv - cpp * (FCk - FCm1);                               // :1305 (m Tunits)
+      FCm1 = FCk;
+      DCm[k] = tv;
+    }
+  }
+  // classic tridiagonal, step3d_t.F:1431-1501
+  const double cfl = -dt * c->p.lambda;
+  double FCprev = 0.0;       // FC(k-1)
+  double CFprev = 0.0, DCprev = 0.0;
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      const long a = a2 + (long)(k - 1) * nij;
+      double FCk = 0.0;
+      if (k < N) {
+        const double cff1 = 1.0 / (z_r[a + nij] - z_r[a]);
+        FCk = cfl * cff1 * Akt[a + nij];                          // Akt(i,j,k)
+      }
+      const double BCk = Hz[a] - FCk - FCprev;
+      if (k == 1) {
+        const double cff = 1.0 / BCk;
+        CFm[1] = cff * FCk;
+        DCm[1] = cff * DCm[1];
+      } else if (k < N) {
+        const double cff = 1.0 / (BCk - FCprev * CFprev);
+        CFm[k] = cff * FCk;
+        DCm[k] = cff * (DCm[k] - FCprev * DCprev);
+      } else {
+        DCm[k] = (DCm[k] - FCprev * DCprev) / (BCk - FCprev * CFprev);
+      }
+      CFprev = CFm[k < N ? k : 1];
+      DCprev = DCm[k];
+      FCprev = FCk;
+    }
+  }
+  double up = 0.0;
+#pragma unroll
+  for (int k = NMAX; k >= 1; k--) {
+    if (k <= N) {
+      const long a = a2 + (long)(k - 1) * nij;
+      double v;
+      if (k == N) v = DCm[k];
+      else v = DCm[k] - CFm[k] * up;
+      up = v;
+      tn[a] = v;
+    }
+  }
+}
+
+}  // namespace
+
+// One MPDATA tracer of step3d_t; called by roms_hip_step3d_t (k_step3d_t.hip).
+int roms_launch_step3d_t_mpdata(int nnew, int itrc)
+{
+  const roms_bounds_t &b = g_ctx.b;
+  if (b.NghostPoints != 3) return roms_fail("roms_hip_step3d_t", "MPDATA needs NghostPoints = 3 (inp_par.F:266-278)");
+  if (b.N > 32) return roms_fail("roms_hip_step3d_t", "N > 32 not instantiated");
+  int rc;
+  const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
+  // three-point footprint: refresh the ghost points of t(nnew) first, step3d_t.F:369-386
+  if ((rc = halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r))) return rc;
+  MpArgs m;
+  m.Ta = g_ctx.hostc.ws3[1]; m.Ua = g_ctx.hostc.ws3[2]; m.Va = g_ctx.hostc.ws3[3]; m.Wa = g_ctx.hostc.ws3[4];
+  m.bup = g_ctx.hostc.ws3[5]; m.bdn = g_ctx.hostc.ws3[6];
+  m.nnew = nnew; m.itrc = itrc;
+  hipLaunchKernelGGL(k_mp_ta, grid2d(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1), block2d(), 0, g_ctx.stream,
+                     g_ctx.devc, m);
+  KERNEL_CHECK("k_mp_ta");
+  hipLaunchKernelGGL(k_mp_adiff, grid2d(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1), block2d(), 0,
+                     g_ctx.stream, g_ctx.devc, m);
+  KERNEL_CHECK("k_mp_adiff");
+  hipLaunchKernelGGL(k_mp_beta, grid2d(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1), block2d(), 0,
+                     g_ctx.stream, g_ctx.devc, m);
+  KERNEL_CHECK("k_mp_beta");
+  const dim3 g = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
+  if (b.N <= 16) hipLaunchKernelGGL((k_mp_update<16>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+  else hipLaunchKernelGGL((k_mp_update<32>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+  KERNEL_CHECK("k_mp_update");
+  return 0;
+}

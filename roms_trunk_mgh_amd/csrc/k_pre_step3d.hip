@@ -49,7 +49,8 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
   // time-stepping weights, pre_step3d.F:586-600
-  const double Gamma = 1.0 / 6.0;
+  // (MPDATA tracers use Gamma = 1/2, :557-563 and :793-799; H and V scheme are both MPDATA or neither)
+  const double Gamma = (HADV == ADV_MPDATA) ? 0.5 : 1.0 / 6.0;
   double cff, cff1, cff2;
   if (first_step) { cff = 0.5 * dt; cff1 = 1.0; cff2 = 0.0; }
   else { cff = (1.0 - Gamma) * dt; cff1 = 0.5 + Gamma; cff2 = 0.5 - Gamma; }
@@ -282,8 +283,9 @@ extern "C" int roms_hip_pre_step3d(const roms_step_idx_t *s)
       case ADV_U3 * 16 + ADV_SPLINES: rc = launch_pre_t<ADV_U3, ADV_SPLINES>(s, it, n); break;
       case ADV_C4 * 16 + ADV_SPLINES: rc = launch_pre_t<ADV_C4, ADV_SPLINES>(s, it, n); break;
       case ADV_A4 * 16 + ADV_SPLINES: rc = launch_pre_t<ADV_A4, ADV_SPLINES>(s, it, n); break;
+      case ADV_MPDATA * 16 + ADV_MPDATA: rc = launch_pre_t<ADV_MPDATA, ADV_MPDATA>(s, it, n); break;
       default:
-        return roms_fail("roms_hip_pre_step3d", "advection scheme pair not implemented (MPDATA/HSIMT pending)");
+        return roms_fail("roms_hip_pre_step3d", "advection scheme pair not implemented (HSIMT; MPDATA only as H+V pair)");
       }
       if (rc) return rc;
       it += n;

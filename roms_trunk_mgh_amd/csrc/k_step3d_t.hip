@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 int roms_entry_check(const char *name);
+int roms_launch_step3d_t_mpdata(int nnew, int itrc);      // k_mpdata.hip
 
 #include "advect.h"
 
@@ -459,8 +460,12 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
       case ADV_U3 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_U3, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_C4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_C4, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_A4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_A4, ADV_SPLINES>(s->nnew, it, n); break;
+      case ADV_MPDATA * 16 + ADV_MPDATA:
+        // multi-pass: upstream step, anti-diffusive velocities, FCT limiter, corrected step (k_mpdata.hip)
+        for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q);
+        break;
       default:
-        return roms_fail("roms_hip_step3d_t", "advection scheme pair not implemented (MPDATA/HSIMT pending)");
+        return roms_fail("roms_hip_step3d_t", "advection scheme pair not implemented (HSIMT; MPDATA only as H+V pair)");
       }
       if (rc) return rc;
       it += n;

@@ -1,0 +1,90 @@
+"""-m gpu: the MPDATA row (configuration 5: passive tracers, three
+ghost points).  HIP vs CPU oracle through the C ABI; the oracle's mpdata_adiff is itself pinned
+bit for bit against the reference's Fortran (tests/test_ref_pinning.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+from roms_trunk_mgh_amd import ana, hip, main3d
+from roms_trunk_mgh_amd.state import rel_rms
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+MP = {"Hadv": "MPDATA", "Vadv": "MPDATA"}
+# T and S with the default U3/C4, the four passive tracers with MPDATA (per-tracer run-time choice)
+MIXED = {"Hadv": "U3", "Vadv": "C4", "Hadv_list": ["U3", "U3"] + ["MPDATA"] * 4, "Vadv_list": ["C4", "C4"] + ["MPDATA"] * 4}
+
+
+def _pair(config, kernel, s, overrides, prep=None):
+    import oracle
+    st0 = util.prepared_state(config, NT=6, overrides=overrides)
+    assert st0.b.NghostPoints == 3
+    if prep:
+        prep(st0)
+    st_o, st_h = st0.copy(), st0.copy()
+    oracle.Oracle(st_o).call(kernel, s)
+    if os.environ.get("ROMS_TEST_DRY"):
+        oracle.Oracle(st_h).call(kernel, s)
+        return st_h, st_o, st0
+    h = hip.RomsHip(st_h)
+    try:
+        h.call(kernel, s)
+        h.to_host()
+    finally:
+        h.close()
+    return st_h, st_o, st0
+
+
+@pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING"])
+@pytest.mark.parametrize("ov", [MP, MIXED], ids=["all6", "mixed"])
+def test_step3d_t_mpdata(config, ov):
+    st_h, st_o, st0 = _pair(config, "step3d_t", util.step_idx(), ov, prep=util.hz_weighted_tnew)
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+    assert util.max_rel_diff(st_o["t"][..., 5], st0["t"][..., 5]) > 1e-6
+
+
+@pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING"])
+@pytest.mark.parametrize("iic", [1, 5])
+def test_pre_step3d_mpdata(config, iic):
+    st_h, st_o, st0 = _pair(config, "pre_step3d", util.step_idx(iic=iic), MP)
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+    assert util.max_rel_diff(st_o["t"], st0["t"]) > 1e-6
+
+
+@pytest.mark.parametrize("kernel", ["set_massflux", "omega", "rhs3d", "step3d_uv", "set_depth"])
+def test_other_kernels_with_three_ghost_points(kernel):
+    st_h, st_o, _ = _pair("BENCHMARK_TINY", kernel, util.step_idx(iic=5), MP)
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+
+
+def test_100_steps_mpdata():
+    """configuration 5 in small: BENCHMARK physics, T/S + 4 passive tracers, all MPDATA."""
+    import oracle
+    st_o = ana.make_tile("BENCHMARK_TINY", NT=6, overrides=MP, perturb=1.0)
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o))
+    mo.initial()
+    mo.run(100)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be)
+        mh.initial()
+        mh.run(100)
+        be.to_host()
+    finally:
+        be.close()
+    s = mo.s
+    out = {"zeta": rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], 1e-3)}
+    for name in ("u", "v"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], 1e-4)
+    for it in range(6):
+        out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
+    assert np.isfinite(st_h["t"]).all()
+    assert all(v <= 1e-10 for v in out.values()), out
+    # MPDATA keeps the positive-definite passive tracers positive
+    assert float(st_h.interior("t")[..., s.nnew - 1, 2:].min()) > 0.0
