@@ -51,11 +51,8 @@ def main(config):
 def main_mpdata(config):
     """mpdata_adiff_tile: reference Fortran vs C oracle on the same private arrays, with the
     3-ghost-point bounds an MPDATA run uses (also pins get_bounds for NghostPoints = 3)."""
-    import ctypes as C
-    import oracle
     import util
     from oracle import ref
-    from roms_trunk_mgh_amd import abi
     st = util.prepared_state(config, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"})
     b = st.b
     out = {"NghostPoints": int(b.NghostPoints)}
@@ -63,43 +60,15 @@ def main_mpdata(config):
     bb = r.bounds()
     mine = b.as_dict()
     out["bounds_mismatch"] = {k: (v, mine[k]) for k, v in bb.items() if mine[k] != v}
-    IminS, ImaxS, JminS, JmaxS = b.Istr - 3, b.Iend + 3, b.Jstr - 3, b.Jend + 3
-    nis, njs, N = ImaxS - IminS + 1, JmaxS - JminS + 1, b.N
-    ii = np.arange(IminS, ImaxS + 1, dtype=np.float64)[:, None, None]
-    jj = np.arange(JminS, JmaxS + 1, dtype=np.float64)[None, :, None]
-    kk = np.arange(1, N + 1, dtype=np.float64)[None, None, :]
-    # positive, smooth, fully 3-D; a patch of exact zeros and a flat patch exercise the
-    # "no anti-diffusion" branches (Ta <= 0, |dTa| <= eps2)
-    Ta0 = 2.0 + np.sin(0.37 * ii + 0.2) * np.cos(0.23 * jj) + 0.5 * np.cos(0.31 * kk + 0.1 * ii) + 0.0 * jj
-    Ta0[5:9, 4:8, 3:6] = 0.0
-    Ta0[20:26, 10:15, :] = 1.5
-    Ta0 = np.asfortranarray(Ta0)
-    oHz = np.zeros((nis, njs, N), order="F")
-    i0, j0 = IminS - b.LBi, JminS - b.LBj
-    ia, ib = max(b.LBi, IminS), min(b.UBi, ImaxS)
-    ja, jb = max(b.LBj, JminS), min(b.UBj, JmaxS)
-    hz = st["Hz"][ia - b.LBi:ib - b.LBi + 1, ja - b.LBj:jb - b.LBj + 1, :]
-    oHz[ia - IminS:ib - IminS + 1, ja - JminS:jb - JminS + 1, :] = 1.0 / np.where(hz > 0.0, hz, 1.0)
-    t3 = st["t"][:, :, :, 2, 0]
-    assert t3.flags.f_contiguous
-    res = {}
-    for who in ("ref", "oracle"):
-        Ta = Ta0.copy(order="F")
-        Ua = np.zeros((nis, njs, N), order="F")
-        Va = np.zeros((nis, njs, N), order="F")
-        Wa = np.zeros((nis, njs, N + 1), order="F")
-        if who == "ref":
-            r.mpdata_adiff(oHz, t3, Ta, Ua, Va, Wa)
-        else:
-            lib = oracle.lib()
-            lib.oracle_mpdata_adiff.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.StepIdx),
-                                                C.POINTER(abi.Fields)] + [C.c_void_p] * 6
-            F = st.fields_struct()
-            s = util.step_idx()
-            rc = lib.oracle_mpdata_adiff(C.byref(st.b), C.byref(st.p), C.byref(s), C.byref(F), oHz.ctypes.data,
-                                         t3.ctypes.data, Ta.ctypes.data, Ua.ctypes.data, Va.ctypes.data, Wa.ctypes.data)
-            assert rc == 0
-        res[who] = dict(Ta=Ta, Ua=Ua, Va=Va, Wa=Wa)
+    oHz, Ta0, t3 = util.mpdata_private_arrays(st)
+    nis, njs, N = Ta0.shape
+    Ta = Ta0.copy(order="F")
+    Ua = np.zeros((nis, njs, N), order="F")
+    Va = np.zeros((nis, njs, N), order="F")
+    Wa = np.zeros((nis, njs, N + 1), order="F")
+    r.mpdata_adiff(oHz, t3, Ta, Ua, Va, Wa)
+    res = {"ref": dict(Ta=Ta, Ua=Ua, Va=Va, Wa=Wa)}
+    res["oracle"] = dict(zip(("Ta", "Ua", "Va", "Wa"), util.oracle_mpdata_adiff(st, oHz, Ta0, t3)))
     out["diff"] = {k: float(np.abs(res["ref"][k] - res["oracle"][k]).max()) for k in ("Ta", "Ua", "Va", "Wa")}
     out["nonzero"] = {k: int(np.count_nonzero(res["ref"][k])) for k in ("Ua", "Va", "Wa")}
     out["amax"] = {k: float(np.abs(res["ref"][k]).max()) for k in ("Ua", "Va", "Wa")}

@@ -78,3 +78,27 @@ def test_hip_reproduces_reference_vectors(config):
         finally:
             h.close()
         _check(st, st0, g, k, tol=1e-13)
+
+
+def test_oracle_reproduces_reference_mpdata_adiff():
+    """mpdata_adiff_tile: the committed outputs of the reference's Fortran (three levels stored,
+    all elements through a SHA-256) vs the C oracle on the same deterministic inputs."""
+    import hashlib
+    import util
+    path = os.path.join(HERE, "golden", "ref_mpdata_BENCHMARK_TINY.npz")
+    g = np.load(path)
+
+    def sha(*arrays):
+        h = hashlib.sha256()
+        for a in arrays:
+            h.update(np.ascontiguousarray(a + 0.0).tobytes())
+        return h.hexdigest()
+
+    st = util.prepared_state("BENCHMARK_TINY", overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"})
+    oHz, Ta0, t3 = util.mpdata_private_arrays(st)
+    assert sha(oHz, Ta0, t3) == str(g["input_sha256"]), "fixture inputs changed: regenerate with make_golden_mpdata.py"
+    Ta, Ua, Va, Wa = util.oracle_mpdata_adiff(st, oHz, Ta0, t3)
+    ks = [int(k) for k in g["levels"]]
+    assert np.array_equal(Ua[:, :, ks], g["Ua"]) and np.array_equal(Va[:, :, ks], g["Va"])
+    assert np.array_equal(Wa[:, :, [k + 1 for k in ks]], g["Wa"]) and np.array_equal(Ta[:, :, ks], g["Ta"])
+    assert sha(Ta, Ua, Va, Wa) == str(g["output_sha256"])

@@ -95,3 +95,49 @@ def compare_states(st_a, st_ref, names=None):
         if d > 0.0:
             out[name] = d
     return out
+
+
+def mpdata_private_arrays(st):
+    """Deterministic inputs for an isolated mpdata_adiff_tile call: the tile-private arrays
+    oHz, Ta (IminS:ImaxS,JminS:JmaxS,N) and the module-layout t(:,:,:,3,1).  Ta is positive,
+    smooth and fully 3-D, with a patch of exact zeros and a flat patch so that the
+    "no anti-diffusion" branches (Ta <= 0, |dTa| <= eps2) are taken too."""
+    b = st.b
+    IminS, ImaxS, JminS, JmaxS = b.Istr - 3, b.Iend + 3, b.Jstr - 3, b.Jend + 3
+    nis, njs, N = ImaxS - IminS + 1, JmaxS - JminS + 1, b.N
+    ii = np.arange(IminS, ImaxS + 1, dtype=np.float64)[:, None, None]
+    jj = np.arange(JminS, JmaxS + 1, dtype=np.float64)[None, :, None]
+    kk = np.arange(1, N + 1, dtype=np.float64)[None, None, :]
+    Ta = 2.0 + np.sin(0.37 * ii + 0.2) * np.cos(0.23 * jj) + 0.5 * np.cos(0.31 * kk + 0.1 * ii) + 0.0 * jj
+    Ta[5:9, 4:8, 3:6] = 0.0
+    Ta[20:26, 10:15, :] = 1.5
+    Ta = np.asfortranarray(Ta)
+    oHz = np.zeros((nis, njs, N), order="F")
+    ia, ib = max(b.LBi, IminS), min(b.UBi, ImaxS)
+    ja, jb = max(b.LBj, JminS), min(b.UBj, JmaxS)
+    hz = st["Hz"][ia - b.LBi:ib - b.LBi + 1, ja - b.LBj:jb - b.LBj + 1, :]
+    oHz[ia - IminS:ib - IminS + 1, ja - JminS:jb - JminS + 1, :] = 1.0 / np.where(hz > 0.0, hz, 1.0)
+    t3 = st["t"][:, :, :, 2, 0]
+    assert t3.flags.f_contiguous
+    return oHz, Ta, t3
+
+
+def oracle_mpdata_adiff(st, oHz, Ta, t3):
+    """Run the C oracle's mpdata_adiff on private arrays; returns (Ta, Ua, Va, Wa)."""
+    import ctypes as C
+    import oracle
+    from roms_trunk_mgh_amd import abi
+    nis, njs, N = Ta.shape
+    Ta = Ta.copy(order="F")
+    Ua = np.zeros((nis, njs, N), order="F")
+    Va = np.zeros((nis, njs, N), order="F")
+    Wa = np.zeros((nis, njs, N + 1), order="F")
+    lib = oracle.lib()
+    lib.oracle_mpdata_adiff.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.StepIdx),
+                                        C.POINTER(abi.Fields)] + [C.c_void_p] * 6
+    F = st.fields_struct()
+    s = step_idx()
+    rc = lib.oracle_mpdata_adiff(C.byref(st.b), C.byref(st.p), C.byref(s), C.byref(F), oHz.ctypes.data,
+                                 t3.ctypes.data, Ta.ctypes.data, Ua.ctypes.data, Va.ctypes.data, Wa.ctypes.data)
+    assert rc == 0
+    return Ta, Ua, Va, Wa
