@@ -18,6 +18,7 @@
 // reference's ~25 private (IminS:ImaxS,JminS:JmaxS) work arrays become
 // registers; only DUon, DVom, zeta_new, zwrk live in device scratch.
 #include "roms_dev.h"
+#include <cstdlib>
 
 int roms_entry_check(const char *name);
 int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DVom, const double *zeta_new,
@@ -520,6 +521,12 @@ int step2d_impl(const roms_step_idx_t *si)
   if (sm) {
     s.sm = 1;
     const dim3 full = grid2d(b.UBi - b.LBi + 1, b.UBj - b.LBj + 1);
+    static const bool no_fuse_zeta = getenv("ROMS_HIP_NO_FUSED_ZETA") != nullptr;     // A/B switch
+    if (!g_ctx.no_lds_2d && !no_fuse_zeta && s.iif <= p.nfast) {
+      // ONE launch: free surface, fast-time averages and momentum (k2d_mom_lds<true>)
+      s.sm = 2;
+      return roms_launch_k2d_mom_lds((const int *)&s, nullptr, nullptr, nullptr, nullptr);
+    }
     if (!g_ctx.no_lds_2d) {
       // DUon/DVom are evaluated in place by the two remaining kernels: 2 launches per call
       DUon = nullptr;

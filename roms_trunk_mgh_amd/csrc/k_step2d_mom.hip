@@ -77,6 +77,45 @@ __device__ __forceinline__ int wrap_i(const roms_bounds_t &b, int i)
   return (i < 1) ? i + b.Lm : ((i > b.Lm) ? i - b.Lm : i);
 }
 
+// One free-surface point (step2d_LF_AM3.h:770-868) evaluated at source index a: the new free surface zn
+// and the time-weighted zw the pressure gradient uses.  Same expressions as zeta_point (k_step2d.hip).
+__device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S2 &s, const double rhs, long a, long nij,
+                                          double &zn, double &zw)
+{
+  const roms_params_t &p = c->p;
+  const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
+  const double *__restrict__ zs = c->F.zeta + (long)(s.kstp - 1) * nij;
+  const double dtfast = p.dtfast;
+  const double pmn_a = c->F.pm[a], pn_a = c->F.pn[a];
+  if (s.iif == 1) {
+    const double cff1 = dtfast;
+    zn = zs[a] + pmn_a * pn_a * cff1 * rhs;
+    zw = 0.5 * (zs[a] + zn);
+  } else if (s.predictor) {
+    const double cff1 = 2.0 * dtfast;
+    const double cff4 = 4.0 / 25.0;
+    const double cff5 = 1.0 - 2.0 * cff4;
+    zn = zs[a] + pmn_a * pn_a * cff1 * rhs;
+    zw = cff5 * zk[a] + cff4 * (zs[a] + zn);
+  } else {
+    const int ptsk = 3 - s.kstp;
+    const double cff1 = dtfast * 5.0 / 12.0;
+    const double cff2 = dtfast * 8.0 / 12.0;
+    const double cff3 = dtfast * 1.0 / 12.0;
+    const double cff4 = 2.0 / 5.0;
+    const double cff5 = 1.0 - cff4;
+    const double cff = cff1 * rhs;
+    zn = zs[a] + pmn_a * pn_a * (cff + cff2 * c->F.rzeta[a + (long)(s.kstp - 1) * nij] -
+                                 cff3 * c->F.rzeta[a + (long)(ptsk - 1) * nij]);
+    zw = cff5 * zn + cff4 * zk[a];
+  }
+}
+
+// FUSED (single tile, source-mapped calls only): the free-surface step and the fast-time averaging
+// of k2d_zeta_sm are done here as well -- zeta_new and zwrk are evaluated from the staged DUon/DVom
+// tiles for the (65 x 5) points this workgroup's momentum stencil touches and kept in LDS, so one
+// step2d call is ONE launch and the zeta_new/zwrk scratch round trip disappears.
+template <bool FUSED>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, const double *__restrict__ DVom,
             const double *__restrict__ zeta_new, const double *__restrict__ zwrk)
@@ -84,6 +123,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   DEV_PROLOGUE(c)
   const roms_params_t &p = c->p;
   __shared__ double sU[TJ * TP], sV[TJ * TP], sDU[TJ * TP], sDV[TJ * TP], sD[TJ * TP];
+  __shared__ double sZn[FUSED ? TJ * TP : 1], sZw[FUSED ? TJ * TP : 1];
   const int ibase = s.sm ? b.LBi : b.Istr;
   const int ilast = s.sm ? (b.Lm + b.NghostPoints) : b.Iend;
   const int it0 = ibase + blockIdx.x * BLK_X, j0 = b.Jstr + blockIdx.y * BLK_Y;
@@ -122,6 +162,23 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     }
   }
   __syncthreads();
+  if constexpr (FUSED) {
+    // free surface at tile points li = 1..BLK_X+1, lj = 1..BLK_Y+1 (targets it0-1.., j0-1..)
+    const int tid = threadIdx.y * BLK_X + threadIdx.x;
+    constexpr int ZW = BLK_X + 1, ZH = BLK_Y + 1;
+    for (int q = tid; q < ZW * ZH; q += BLK_X * BLK_Y) {
+      const int li = 1 + q % ZW, lj = 1 + q / ZW;
+      const int e = lj * TP + li;
+      int gi = wrap_i(b, it0 - 2 + li), gj = j0 - 2 + lj;
+      gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
+      const double rhs = (sDU[e] - sDU[e + 1]) + (sDV[e] - sDV[e + TP]);
+      double zn, zw;
+      zeta_eval(c, s, rhs, I2(gi, gj), nij, zn, zw);
+      sZn[e] = zn;
+      sZw[e] = zw;
+    }
+    __syncthreads();
+  }
   if (it > ilast || j > b.Jend) return;
   const int i = s.sm ? wrap_i(b, it) : it;          // source column
   const bool owner = (i == it);
@@ -143,13 +200,52 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const int t = m.at(it, j);                        // this point in the tiles
   const double fac = 1000.0 / p.rho0;
   // ---- pressure gradient, :939-1019 ----
-  const double zw0 = zwrk[a];
+  if constexpr (FUSED) {
+    // ---- what k2d_zeta_sm did: fast-time averages on the owned ranges and zeta(knew), rzeta(krhs) ----
+    const int iif = s.iif;
+    const double *__restrict__ zkr = c->F.zeta + (long)(s.krhs - 1) * nij;
+    auto average = [&](long oo, int tt, bool inU, bool inV) {       // step2d_LF_AM3.h:614-682 at target oo
+      if (s.predictor) {
+        // (iif == 1 never comes here: the first predictor of a step uses the general path)
+        const double cff1 = p.weight1[iif - 2];
+        const double cff2 = (8.0 / 12.0) * p.weight2[iif - 1] - (1.0 / 12.0) * p.weight2[iif];
+        c->F.Zt_avg1[oo] = c->F.Zt_avg1[oo] + cff1 * zkr[oo];
+        if (inU) {
+          c->F.DU_avg1[oo] = c->F.DU_avg1[oo] + cff1 * sDU[tt];
+          c->F.DU_avg2[oo] = c->F.DU_avg2[oo] + cff2 * sDU[tt];
+        }
+        if (inV) {
+          c->F.DV_avg1[oo] = c->F.DV_avg1[oo] + cff1 * sDV[tt];
+          c->F.DV_avg2[oo] = c->F.DV_avg2[oo] + cff2 * sDV[tt];
+        }
+      } else {
+        const double cff2 = (iif == 1) ? p.weight2[iif - 1] : (5.0 / 12.0) * p.weight2[iif - 1];
+        if (inU) c->F.DU_avg2[oo] = c->F.DU_avg2[oo] + cff2 * sDU[tt];
+        if (inV) c->F.DV_avg2[oo] = c->F.DV_avg2[oo] + cff2 * sDV[tt];
+      }
+    };
+    const bool in_i = it >= b.IstrR && it <= b.IendR;
+    if (in_i) {
+      const bool inU = it >= b.Istr;
+      average(o, t, inU, true);
+      if (j == b.Jstr && b.JstrR < b.Jstr) average(o - ni, t - TP, inU, false);   // row JstrR = Jstr-1
+      if (j == b.Jend && b.JendR > b.Jend) average(o + ni, t + TP, inU, true);    // row JendR = Jend+1
+    }
+    const double zn = sZn[t];
+    double *__restrict__ zout = c->F.zeta + (long)(s.knew - 1) * nij;
+    zout[o] = zn;
+    if (b.south_edge && j == b.Jstr) zout[o - ni] = zn;             // zetabc closed: zero gradient
+    if (b.north_edge && j == b.Jend) zout[o + ni] = zn;
+    if (s.predictor)      // at the target: ghost columns hold the periodic copy, as after the exchange
+      c->F.rzeta[o + (long)(s.krhs - 1) * nij] = (sDU[t] - sDU[t + 1]) + (sDV[t] - sDV[t + TP]);
+  }
+  const double zw0 = FUSED ? sZw[t] : zwrk[a];
   const double gz0 = (fac + rhoS[a]) * zw0, gz20 = gz0 * zw0, gsa0 = zw0 * (rhoS[a] - rhoA[a]);
   const double cg = 0.5 * p.g, c3 = 1.0 / 3.0;
   double rhs_u = 0.0, rhs_v = 0.0;
   if (do_u) {
     const long q = a - 1;
-    const double zw = zwrk[q];
+    const double zw = FUSED ? sZw[t - 1] : zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
     rhs_u = cg * c->F.on_u[a] *
             ((h[q] + h[a]) * (gz - gz0) +
@@ -158,7 +254,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   }
   if (do_v) {
     const long q = a - ni;
-    const double zw = zwrk[q];
+    const double zw = FUSED ? sZw[t - TP] : zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
     rhs_v = cg * c->F.om_v[a] *
             ((h[q] + h[a]) * (gz - gz0) +
@@ -276,7 +372,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   }
   // ---- time step, :2098-2255 ----
   const double dtfast = p.dtfast;
-  const double Dn0 = zeta_new[a] + h[a], Dst0 = zs[a] + h[a];
+  const double Dn0 = (FUSED ? sZn[t] : zeta_new[a]) + h[a], Dst0 = zs[a] + h[a];
   const int ptsk = 3 - s.kstp;
   const bool am3 = !(s.iif == 1 || s.predictor);
   const double c1 = (s.iif == 1) ? 0.5 * dtfast : dtfast;
@@ -286,7 +382,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   if (do_u) {
     const long q = a - 1;
     const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
-    const double fc = 1.0 / (Dn0 + (zeta_new[q] + h[q]));
+    const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - 1] : zeta_new[q]) + h[q]));
     const double us = c->F.ubar[a + (long)(s.kstp - 1) * nij];
     double un;
     if (!am3) un = (us * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_u) * fc;
@@ -303,7 +399,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   if (do_v) {
     const long q = a - ni;
     const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
-    const double fc = 1.0 / (Dn0 + (zeta_new[q] + h[q]));
+    const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - TP] : zeta_new[q]) + h[q]));
     const double vs = c->F.vbar[a + (long)(s.kstp - 1) * nij];
     double vn;
     if (!am3) vn = (vs * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_v) * fc;
@@ -328,8 +424,14 @@ int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DV
   const roms_bounds_t &b = g_ctx.b;
   S2 s{s10[0], s10[1], s10[2], s10[3], s10[4], s10[5], s10[6], s10[7], s10[8], s10[9]};
   const int nx = s.sm ? (b.UBi - b.LBi + 1) : (b.Iend - b.Istr + 1);
-  hipLaunchKernelGGL(k2d_mom_lds, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s, DUon,
-                     DVom, zeta_new, zwrk);
+  if (s.sm == 2) {      // fused free-surface + momentum call (source-mapped, fluxes in place)
+    s.sm = 1;
+    hipLaunchKernelGGL(k2d_mom_lds<true>, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
+                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
+                       (const double *)nullptr);
+  } else
+    hipLaunchKernelGGL(k2d_mom_lds<false>, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
+                       DUon, DVom, zeta_new, zwrk);
   KERNEL_CHECK("k2d_mom_lds");
   return 0;
 }
