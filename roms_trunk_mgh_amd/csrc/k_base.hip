@@ -90,9 +90,10 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_set_massflux(const RomsDev *__restrict__ c, int nrhs)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrT + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrT + blockIdx.y * BLK_Y + threadIdx.y;
-  const int k = blockIdx.z + 1;
+  const Blk XB = xcd_block();
+  const int i = b.IstrT + XB.x * BLK_X + threadIdx.x;
+  const int j = b.JstrT + XB.y * BLK_Y + threadIdx.y;
+  const int k = XB.z + 1;
   if (i > b.IendT || j > b.JendT) return;
   const double *__restrict__ Hz = c->F.Hz;
   const double *__restrict__ u = c->F.u + (long)(nrhs - 1) * n3r;
@@ -129,8 +130,9 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_omega(const RomsDev *__restrict__ c)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
   const double *__restrict__ Huon = c->F.Huon;
   const double *__restrict__ Hvom = c->F.Hvom;
@@ -180,8 +182,9 @@ extern "C" int roms_hip_omega(const roms_step_idx_t *s)
 __global__ void k_set_zeta(const RomsDev *__restrict__ c)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrR + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrR + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.IstrR + XB.x * BLK_X + threadIdx.x;
+  const int j = b.JstrR + XB.y * BLK_Y + threadIdx.y;
   if (i > b.IendR || j > b.JendR) return;
   const double z = c->F.Zt_avg1[I2(i, j)];
   c->F.zeta[I2(i, j)] = z;
@@ -210,8 +213,9 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_set_depth(const RomsDev *__restrict__ c)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrT + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrT + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.IstrT + XB.x * BLK_X + threadIdx.x;
+  const int j = b.JstrT + XB.y * BLK_Y + threadIdx.y;
   if (i > b.IendT || j > b.JendT) return;
   const roms_params_t &p = c->p;
   const double hc = p.hc;

@@ -180,8 +180,9 @@ k_pre_uv(const RomsDev *__restrict__ c, int nstp, int nnew, int nrhs, int stage)
 {
   // stage: 0 = first step (forward Euler), 1 = second step (AB2), 2 = AB3
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
   const roms_params_t &p = c->p;
   const double dt = p.dt;

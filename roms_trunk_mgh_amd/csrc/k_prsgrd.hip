@@ -36,8 +36,9 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_prsgrd_P(const RomsDev *__restrict__ c, double *__restrict__ P)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrU - 1 + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrV - 1 + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.IstrU - 1 + XB.x * BLK_X + threadIdx.x;
+  const int j = b.JstrV - 1 + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
   const double *__restrict__ rho = c->F.rho;
   const double *__restrict__ z_r = c->F.z_r;
@@ -89,9 +90,10 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrhs)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
-  const int k = blockIdx.z + 1;
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
+  const int k = XB.z + 1;
   if (i > b.Iend || j > b.Jend) return;
   const double *__restrict__ rho = c->F.rho;
   const double *__restrict__ z_r = c->F.z_r;

@@ -68,8 +68,9 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_rho_eos_nonlin(const RomsDev *__restrict__ c, int nrhs)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrT + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrT + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.IstrT + XB.x * BLK_X + threadIdx.x;
+  const int j = b.JstrT + XB.y * BLK_Y + threadIdx.y;
   if (i > b.IendT || j > b.JendT) return;
   const long c0 = I2(i, j);
   const double *__restrict__ T = c->F.t + (long)(nrhs - 1) * n3r;                 // itemp = 1
@@ -135,8 +136,9 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_rho_eos_lin(const RomsDev *__restrict__ c, int nrhs)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrT + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrT + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.IstrT + XB.x * BLK_X + threadIdx.x;
+  const int j = b.JstrT + XB.y * BLK_Y + threadIdx.y;
   if (i > b.IendT || j > b.JendT) return;
   const long c0 = I2(i, j);
   const double *__restrict__ T = c->F.t + (long)(nrhs - 1) * n3r;

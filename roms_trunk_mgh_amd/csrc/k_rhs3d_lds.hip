@@ -88,9 +88,10 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
 {
   DEV_PROLOGUE(c)
+  const Blk XB = xcd_block();
   __shared__ double sU[TJ * TP], sV[TJ * TP], sHu[TJ * TP], sHv[TJ * TP], sHz[TJ * TP];
   const roms_params_t &p = c->p;
-  const int i0 = b.Istr + blockIdx.x * BLK_X, j0 = b.Jstr + blockIdx.y * BLK_Y;
+  const int i0 = b.Istr + XB.x * BLK_X, j0 = b.Jstr + XB.y * BLK_Y;
   const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
   const bool active = i <= b.Iend && j <= b.Jend;
   const bool do_u = active && i >= b.IstrU, do_v = active && j >= b.JstrV;

@@ -99,13 +99,14 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_uv_column(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
   const long c0 = I2(i, j);
   const double *pm = c->F.pm, *pn = c->F.pn;
   // blockIdx.z selects the component so that both columns do not share VGPRs
-  if (blockIdx.z == 0) {
+  if (XB.z == 0) {
     if (i < b.IstrU) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - 1]) * (pn[c0] + pn[c0 - 1]);
     uv_column<NMAX>(c, c0, 1, nij, N, c->F.u + (long)(nnew - 1) * n3r, c->F.ru + (long)(nrhs - 1) * n3w, dc0,
@@ -172,12 +173,13 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_uv_couple(const RomsDev *__restrict__ c, int nnew)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrT + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrT + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.IstrT + XB.x * BLK_X + threadIdx.x;
+  const int j = b.JstrT + XB.y * BLK_Y + threadIdx.y;
   if (i > b.IendT || j > b.JendT) return;
   const long c0 = I2(i, j);
   const bool ns_wall = !b.NSperiodic;
-  if (blockIdx.z == 0) {
+  if (XB.z == 0) {
     if (i < b.IstrP) return;
     const bool fix = ns_wall && (j == 0 || j == b.Mm + 1) && i >= b.IstrU && i <= b.Iend;
     couple_column<NMAX>(c, c0, 1, nij, N, c->F.u + (long)(nnew - 1) * n3r, c->F.Huon, c->F.ubar, c->F.on_u[c0],

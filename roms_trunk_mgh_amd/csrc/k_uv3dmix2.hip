@@ -60,8 +60,9 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_uv3dmix2_v2(const RomsDev *__restrict__ c, int nrhs, int nnew)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
   const bool do_u = i >= b.IstrU, do_v = j >= b.JstrV;
   const double dt = c->p.dt;

@@ -78,6 +78,30 @@ struct ScopedTimer {
 // ------------------------------------------------------------------------
 // device-side index helpers
 // ------------------------------------------------------------------------
+// XCD-aware renumbering of a 2-D / 3-D grid, inside the kernel (the launch is unchanged): hardware
+// deals workgroups to the 8 XCDs round-robin in linear order, so linear id L runs on XCD L % 8.  When
+// the grid has a multiple of 8 tile columns each XCD is given a contiguous strip of columns, walked
+// row by row with the z-index (component / level) fastest -- x-neighbours then share their boundary
+// cache lines in one L2 and z-neighbours share the fields both read (see decode_tile_tracer).  A
+// bijection on the same grid; placement only affects speed.
+struct Blk { int x, y, z; };
+#ifdef __HIPCC__
+__device__ __forceinline__ Blk xcd_block()
+{
+  Blk r{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  const int nbx = gridDim.x, nby = gridDim.y, nz = gridDim.z;
+  if ((nbx & 7) == 0) {
+    const int L = r.x + nbx * (r.y + nby * r.z);
+    const int xcd = L & 7, q = L >> 3, w = nbx >> 3;
+    r.z = q % nz;
+    const int t = q / nz;
+    r.x = xcd * w + t % w;
+    r.y = t / w;
+  }
+  return r;
+}
+#endif
+
 #define DEV_PROLOGUE(c)                                                        \
   const roms_bounds_t &b = (c)->b;                                             \
   const int LBi = b.LBi, LBj = b.LBj;                                          \
