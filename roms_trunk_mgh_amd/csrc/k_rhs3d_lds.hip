@@ -89,7 +89,11 @@ k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
 {
   DEV_PROLOGUE(c)
   const Blk XB = xcd_block();
-  __shared__ double sU[TJ * TP], sV[TJ * TP], sHu[TJ * TP], sHv[TJ * TP], sHz[TJ * TP];
+  // two LDS buffers: level k+1 is fetched into registers while level k is computed from LDS, and is
+  // stored into the other buffer at the top of the next iteration -- one barrier per level, and the
+  // global-load latency of a level overlaps the arithmetic of the previous one
+  constexpr int TT = TJ * TP;
+  __shared__ double sU[2 * TT], sV[2 * TT], sHu[2 * TT], sHv[2 * TT], sHz[2 * TT];
   const roms_params_t &p = c->p;
   const int i0 = b.Istr + XB.x * BLK_X, j0 = b.Jstr + XB.y * BLK_Y;
   const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
@@ -103,7 +107,6 @@ k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
   const int ic = active ? i : b.Iend, jc = active ? j : b.Jend;     // clamped for address formation only
   const long c0 = I2(ic, jc);
   T3 L;
-  L.u = sU; L.v = sV; L.Hu = sHu; L.Hv = sHv; L.Hz = sHz;
   L.i0 = i0 - 2; L.j0 = j0 - 2;
   L.Istr = b.Istr; L.Iend = b.Iend; L.Jstr = b.Jstr; L.Jend = b.Jend;
   L.s_edge = b.south_edge && !b.NSperiodic; L.n_edge = b.north_edge && !b.NSperiodic;
@@ -123,49 +126,93 @@ k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
   double FCu_prev = 0.0, FCv_prev = 0.0, sum_u = 0.0, sum_v = 0.0;
   const double c9 = 9.0 / 16.0, c1 = 1.0 / 16.0;
 
-  for (int k = 1; k <= N; k++) {
+  // staging slots of this thread: tile elements tid, tid+256, tid+512 (the tile has 544)
+  constexpr int NSLOT = (TT + BLK_X * BLK_Y - 1) / (BLK_X * BLK_Y);
+  long gof[NSLOT];
+#pragma unroll
+  for (int q = 0; q < NSLOT; q++) {
+    const int e = tid + q * BLK_X * BLK_Y;
+    const int li = e % TP, lj = (e / TP) % TJ;
+    int gi = i0 - 2 + li, gj = j0 - 2 + lj;
+    gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
+    gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
+    gof[q] = I2(gi, gj);
+  }
+  const gcd_t gU = (gcd_t)ug, gV = (gcd_t)vg, gHu = (gcd_t)c->F.Huon, gHv = (gcd_t)c->F.Hvom, gHz = (gcd_t)c->F.Hz;
+  const gcd_t gW = (gcd_t)Wg;
+  const gd_t gru = (gd_t)ru, grv = (gd_t)rv;
+  struct Stage { double u[NSLOT], v[NSLOT], hu[NSLOT], hv[NSLOT], hz[NSLOT]; };
+  struct Own { double up2, vp2, ru, rv, w0, wm1, wp1, wm2, wmn, wpn, wm2n; };
+  auto gload = [&](int k) {
+    Stage R;
     const long koff = (long)(k - 1) * nij;
-    __syncthreads();                                  // previous level fully consumed
-    for (int e = tid; e < TJ * TP; e += BLK_X * BLK_Y) {
-      const int li = e % TP, lj = e / TP;
-      int gi = i0 - 2 + li, gj = j0 - 2 + lj;
-      gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
-      gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
-      const long g = I2(gi, gj) + koff;
-      sU[e] = ug[g];
-      sV[e] = vg[g];
-      sHu[e] = c->F.Huon[g];
-      sHv[e] = c->F.Hvom[g];
-      sHz[e] = c->F.Hz[g];
+#pragma unroll
+    for (int q = 0; q < NSLOT; q++) {
+      const long g = gof[q] + koff;
+      if (tid + q * BLK_X * BLK_Y < TT) {
+        R.u[q] = gU[g]; R.v[q] = gV[g]; R.hu[q] = gHu[g]; R.hv[q] = gHv[g]; R.hz[q] = gHz[g];
+      } else {
+        R.u[q] = R.v[q] = R.hu[q] = R.hv[q] = R.hz[q] = 0.0;
+      }
+    }
+    return R;
+  };
+  auto oload = [&](int k) {
+    Own P;
+    const long koff = (long)(k - 1) * nij;
+    const long cw = c0 + (long)k * nij;
+    P.up2 = (k + 2 <= N) ? gU[c0 + koff + 2 * nij] : 0.0;
+    P.vp2 = (k + 2 <= N) ? gV[c0 + koff + 2 * nij] : 0.0;
+    P.ru = do_u ? gru[cw] : 0.0;
+    P.rv = do_v ? grv[cw] : 0.0;
+    P.w0 = gW[cw];
+    // the W stencil of the vertical flux (k < N, u: i-2..i+1, v: j-2..j+1); inactive lanes read their own point
+    P.wm1 = do_u ? gW[cw - 1] : P.w0; P.wp1 = do_u ? gW[cw + 1] : P.w0; P.wm2 = do_u ? gW[cw - 2] : P.w0;
+    P.wmn = do_v ? gW[cw - ni] : P.w0; P.wpn = do_v ? gW[cw + ni] : P.w0; P.wm2n = do_v ? gW[cw - 2 * ni] : P.w0;
+    return P;
+  };
+  Stage R = gload(1);
+  Own P = oload(1);
+
+  for (int k = 1; k <= N; k++) {
+    const int buf = (k & 1) * TT;
+    double *bU = sU + buf, *bV = sV + buf, *bHu = sHu + buf, *bHv = sHv + buf, *bHz = sHz + buf;
+#pragma unroll
+    for (int q = 0; q < NSLOT; q++) {
+      const int e = tid + q * BLK_X * BLK_Y;
+      if (e < TT) { bU[e] = R.u[q]; bV[e] = R.v[q]; bHu[e] = R.hu[q]; bHv[e] = R.hv[q]; bHz[e] = R.hz[q]; }
     }
     __syncthreads();
-    u_p2 = (k + 2 <= N) ? ug[c0 + koff + 2 * nij] : 0.0;
-    v_p2 = (k + 2 <= N) ? vg[c0 + koff + 2 * nij] : 0.0;
+    const Own Pk = P;
+    if (k < N) { R = gload(k + 1); P = oload(k + 1); }      // in flight while level k is computed
+    L.u = bU; L.v = bV; L.Hu = bHu; L.Hv = bHv; L.Hz = bHz;
+    u_p2 = Pk.up2;
+    v_p2 = Pk.vp2;
     const long cw = c0 + (long)k * nij;
-    double ruv = do_u ? ru[cw] : 0.0;
-    double rvv = do_v ? rv[cw] : 0.0;
+    double ruv = Pk.ru;
+    double rvv = Pk.rv;
     if (active) {
       if (cor) {
-        const double cf0 = 0.5 * sHz[t] * fomn0;
-        const double a0 = cf0 * (sV[t] + sV[t + TP]), b0 = cf0 * (sU[t] + sU[t + 1]);
+        const double cf0 = 0.5 * bHz[t] * fomn0;
+        const double a0 = cf0 * (bV[t] + bV[t + TP]), b0 = cf0 * (bU[t] + bU[t + 1]);
         if (do_u) {
-          const double cf1 = 0.5 * sHz[t - 1] * fomnw;
-          const double a1 = cf1 * (sV[t - 1] + sV[t - 1 + TP]);
+          const double cf1 = 0.5 * bHz[t - 1] * fomnw;
+          const double a1 = cf1 * (bV[t - 1] + bV[t - 1 + TP]);
           ruv = ruv + 0.5 * (a0 + a1);
         }
         if (do_v) {
-          const double cf2 = 0.5 * sHz[t - TP] * fomns;
-          const double b2 = cf2 * (sU[t - TP] + sU[t - TP + 1]);
+          const double cf2 = 0.5 * bHz[t - TP] * fomns;
+          const double b2 = cf2 * (bU[t - TP] + bU[t - TP + 1]);
           rvv = rvv - 0.5 * (b0 + b2);
         }
       }
       if (curv) {
         auto cell = [&](int q, double dn, double dm, double &ufx, double &vfe) {
-          const double cff1 = 0.5 * (sV[q] + sV[q + TP]);
-          const double cff2 = 0.5 * (sU[q] + sU[q + 1]);
+          const double cff1 = 0.5 * (bV[q] + bV[q + TP]);
+          const double cff2 = 0.5 * (bU[q] + bU[q + 1]);
           const double cff3 = cff1 * dn;
           const double cff4 = cff2 * dm;
-          const double cff = sHz[q] * (cff3 - cff4);
+          const double cff = bHz[q] * (cff3 - cff4);
           ufx = cff * cff1;
           vfe = cff * cff2;
         };
@@ -191,21 +238,21 @@ k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
             const double um = (k == 1) ? u_0 : u_m1;
             const double up = (k == N - 1) ? u_p1 : u_p2;
             FCu = (c9 * (u_0 + u_p1) - c1 * (um + up)) *
-                  (c9 * (Wg[cw] + Wg[cw - 1]) - c1 * (Wg[cw + 1] + Wg[cw - 2]));
+                  (c9 * (Pk.w0 + Pk.wm1) - c1 * (Pk.wp1 + Pk.wm2));
           }
           if (do_v) {
             const double vm = (k == 1) ? v_0 : v_m1;
             const double vp = (k == N - 1) ? v_p1 : v_p2;
             FCv = (c9 * (v_0 + v_p1) - c1 * (vm + vp)) *
-                  (c9 * (Wg[cw] + Wg[cw - ni]) - c1 * (Wg[cw + ni] + Wg[cw - 2 * ni]));
+                  (c9 * (Pk.w0 + Pk.wmn) - c1 * (Pk.wpn + Pk.wm2n));
           }
         }
         ruv = ruv - (FCu - FCu_prev);
         rvv = rvv - (FCv - FCv_prev);
         FCu_prev = FCu; FCv_prev = FCv;
       }
-      if (do_u) { ru[cw] = ruv; sum_u = (k == 1) ? ruv : sum_u + ruv; }
-      if (do_v) { rv[cw] = rvv; sum_v = (k == 1) ? rvv : sum_v + rvv; }
+      if (do_u) { gru[cw] = ruv; sum_u = (k == 1) ? ruv : sum_u + ruv; }
+      if (do_v) { grv[cw] = rvv; sum_v = (k == 1) ? rvv : sum_v + rvv; }
     }
     u_m1 = u_0; u_0 = u_p1; u_p1 = u_p2;
     v_m1 = v_0; v_0 = v_p1; v_p1 = v_p2;
