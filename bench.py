@@ -119,6 +119,11 @@ def main():
     # lines through pinned host memory + gloo (slower; recorded in config.halo_transport)
     transport = "none" if world == 1 else "rccl"
     be = None
+    # RCCL prints a version banner on stdout when the communicator is created; this file's stdout
+    # carries exactly one JSON line, so stdout points at stderr while the transport is set up
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world > 1 and os.environ.get("ROMS_BENCH_HALO") != "relay":
         ok_init = 1
         try:
@@ -143,6 +148,10 @@ def main():
     m.initial()
     for _ in range(args.warmup):
         m.step()
+    be.sync()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     be.sync()
     torch.cuda.synchronize()
     barrier()

@@ -15,6 +15,7 @@
 // dlopen of librccl.so) so that a Fortran host and a Python host share one build.
 #include "roms_dev.h"
 #include <dlfcn.h>
+#include <vector>
 
 // ------------------------------------------------------------ RCCL binding --
 typedef struct { char internal[128]; } rccl_uid_t;
@@ -204,7 +205,12 @@ static int ensure_buffers(size_t doubles)
   return 0;
 }
 
-static int exchange_phase(double *A, int nk, int dir)
+// One exchange = a list of fields (each nk planes) whose ghost lines travel in ONE message per
+// neighbour and phase: every RCCL group costs a fixed latency, and the barotropic loop alone issues
+// hundreds of exchanges per step.  Buffer layout per side: field after field, each (k, m, r).
+struct HaloItem { int gtype, nk; double *A; };
+
+static int exchange_phase(const HaloItem *items, int nitems, int dir)
 {
   const roms_bounds_t &b = g_ctx.b;
   const Neigh &n = g_neigh;
@@ -215,21 +221,30 @@ static int exchange_phase(double *A, int nk, int dir)
   const int len = dir == 0 ? (b.UBj - b.LBj + 1) : (b.UBi - b.LBi + 1);
   const int str = dir == 0 ? b.Istr : b.Jstr, end = dir == 0 ? b.Iend : b.Jend;
   const int Gmax = b.NghostPoints + 1;
-  int rc = ensure_buffers((size_t)nk * Gmax * len);
+  long nktot = 0;
+  for (int f = 0; f < nitems; f++) nktot += items[f].nk;
+  int rc = ensure_buffers((size_t)nktot * Gmax * len);
   if (rc) return rc;
   const dim3 blk(256);
-  auto launch = [&](double *buf, int start, int G, int unpack) {
-    dim3 grid((len + 255) / 256, (unsigned)(nk * G));
-    hipLaunchKernelGGL(k_pack, grid, blk, 0, g_ctx.stream, g_ctx.devc, A, buf, nk, dir, start, G, unpack);
+  auto launch_all = [&](double *buf, int start, int G, int unpack) {
+    long koff = 0;
+    for (int f = 0; f < nitems; f++) {
+      dim3 grid((len + 255) / 256, (unsigned)(items[f].nk * G));
+      hipLaunchKernelGGL(k_pack, grid, blk, 0, g_ctx.stream, g_ctx.devc, items[f].A, buf + koff * G * len, items[f].nk,
+                         dir, start, G, unpack);
+      koff += items[f].nk;
+    }
   };
-  if (lo >= 0) launch(g_buf[0], str, GsLo, 0);                 // my first GsLo interior lines
-  if (hi >= 0) launch(g_buf[1], end - GsHi + 1, GsHi, 0);      // my last GsHi interior lines
+  if (lo >= 0) launch_all(g_buf[0], str, GsLo, 0);                 // my first GsLo interior lines
+  if (hi >= 0) launch_all(g_buf[1], end - GsHi + 1, GsHi, 0);      // my last GsHi interior lines
   KERNEL_CHECK("k_pack");
+  const long nsl = nktot * GsLo * len, nsh = nktot * GsHi * len;
+  const long nrl = nktot * GrLo * len, nrh = nktot * GrHi * len;
   if (!g_ctx.nccl_comm) {
     if (!g_relay)
       return roms_fail("halo exchange", "multi-tile run without a transport: pass an RCCL unique id to "
                                         "roms_hip_init or set a host relay (roms_hip_set_halo_relay)");
-    const size_t need = (size_t)nk * Gmax * len;
+    const size_t need = (size_t)nktot * Gmax * len;
     if (need > g_hbuf_doubles) {
       for (auto &p : g_hbuf) {
         if (p) hipHostFree(p);
@@ -237,8 +252,6 @@ static int exchange_phase(double *A, int nk, int dir)
       }
       g_hbuf_doubles = need;
     }
-    const long nsl = (long)nk * GsLo * len, nsh = (long)nk * GsHi * len;
-    const long nrl = (long)nk * GrLo * len, nrh = (long)nk * GrHi * len;
     if (lo >= 0) HIP_TRY(hipMemcpyAsync(g_hbuf[0], g_buf[0], sizeof(double) * nsl, hipMemcpyDeviceToHost, g_ctx.stream));
     if (hi >= 0) HIP_TRY(hipMemcpyAsync(g_hbuf[1], g_buf[1], sizeof(double) * nsh, hipMemcpyDeviceToHost, g_ctx.stream));
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
@@ -247,36 +260,36 @@ static int exchange_phase(double *A, int nk, int dir)
     if (rrc) return roms_fail("halo exchange", "host relay callback failed");
     if (lo >= 0) HIP_TRY(hipMemcpyAsync(g_buf[2], g_hbuf[2], sizeof(double) * nrl, hipMemcpyHostToDevice, g_ctx.stream));
     if (hi >= 0) HIP_TRY(hipMemcpyAsync(g_buf[3], g_hbuf[3], sizeof(double) * nrh, hipMemcpyHostToDevice, g_ctx.stream));
-    if (lo >= 0) launch(g_buf[2], str - GrLo, GrLo, 1);
-    if (hi >= 0) launch(g_buf[3], end + 1, GrHi, 1);
-    KERNEL_CHECK("k_unpack");
-    return 0;
+  } else {
+    rccl_comm_t comm = (rccl_comm_t)g_ctx.nccl_comm;
+    RCCL_TRY(rccl.gstart());
+    // order matters when lo == hi (two tiles in a periodic direction): my low-side
+    // send pairs with the peer's high-side receive.
+    if (lo >= 0) RCCL_TRY(rccl.send(g_buf[0], (size_t)nsl, RCCL_FLOAT64, lo, comm, g_ctx.stream));
+    if (hi >= 0) RCCL_TRY(rccl.send(g_buf[1], (size_t)nsh, RCCL_FLOAT64, hi, comm, g_ctx.stream));
+    if (hi >= 0) RCCL_TRY(rccl.recv(g_buf[3], (size_t)nrh, RCCL_FLOAT64, hi, comm, g_ctx.stream));
+    if (lo >= 0) RCCL_TRY(rccl.recv(g_buf[2], (size_t)nrl, RCCL_FLOAT64, lo, comm, g_ctx.stream));
+    RCCL_TRY(rccl.gend());
   }
-  rccl_comm_t comm = (rccl_comm_t)g_ctx.nccl_comm;
-  RCCL_TRY(rccl.gstart());
-  // order matters when lo == hi (two tiles in a periodic direction): my low-side
-  // send pairs with the peer's high-side receive.
-  if (lo >= 0) RCCL_TRY(rccl.send(g_buf[0], (size_t)nk * GsLo * len, RCCL_FLOAT64, lo, comm, g_ctx.stream));
-  if (hi >= 0) RCCL_TRY(rccl.send(g_buf[1], (size_t)nk * GsHi * len, RCCL_FLOAT64, hi, comm, g_ctx.stream));
-  if (hi >= 0) RCCL_TRY(rccl.recv(g_buf[3], (size_t)nk * GrHi * len, RCCL_FLOAT64, hi, comm, g_ctx.stream));
-  if (lo >= 0) RCCL_TRY(rccl.recv(g_buf[2], (size_t)nk * GrLo * len, RCCL_FLOAT64, lo, comm, g_ctx.stream));
-  RCCL_TRY(rccl.gend());
-  if (lo >= 0) launch(g_buf[2], str - GrLo, GrLo, 1);
-  if (hi >= 0) launch(g_buf[3], end + 1, GrHi, 1);
+  if (lo >= 0) launch_all(g_buf[2], str - GrLo, GrLo, 1);
+  if (hi >= 0) launch_all(g_buf[3], end + 1, GrHi, 1);
   KERNEL_CHECK("k_unpack");
   return 0;
 }
 
-int halo_exchange3d(int gtype, int nk, double *A)
+static int halo_run(const HaloItem *items, int nitems)
 {
   const roms_bounds_t &b = g_ctx.b;
+  if (nitems <= 0) return 0;
   if (b.ntileI * b.ntileJ == 1) {
     if (!b.EWperiodic) return 0;
-    int jmin, jmax;
-    if (b.NSperiodic) { jmin = b.Jstr; jmax = b.Jend; }
-    else { jmin = (gtype == GT_R || gtype == GT_U) ? b.JstrR : b.Jstr; jmax = b.JendR; }
-    dim3 grid((jmax - jmin + 1 + 63) / 64, nk);
-    hipLaunchKernelGGL(k_periodic_ew, grid, dim3(64), 0, g_ctx.stream, g_ctx.devc, A, nk, jmin, jmax);
+    for (int f = 0; f < nitems; f++) {
+      int jmin, jmax;
+      if (b.NSperiodic) { jmin = b.Jstr; jmax = b.Jend; }
+      else { jmin = (items[f].gtype == GT_R || items[f].gtype == GT_U) ? b.JstrR : b.Jstr; jmax = b.JendR; }
+      dim3 grid((jmax - jmin + 1 + 63) / 64, items[f].nk);
+      hipLaunchKernelGGL(k_periodic_ew, grid, dim3(64), 0, g_ctx.stream, g_ctx.devc, items[f].A, items[f].nk, jmin, jmax);
+    }
     KERNEL_CHECK("k_periodic_ew");
     return 0;
   }
@@ -289,13 +302,36 @@ int halo_exchange3d(int gtype, int nk, double *A)
   }
   // a periodic direction held by ONE tile row/column is a local copy
   if (b.EWperiodic && b.ntileI == 1) {
-    dim3 grid((b.UBj - b.LBj + 1 + 63) / 64, nk);
-    hipLaunchKernelGGL(k_periodic_ew, grid, dim3(64), 0, g_ctx.stream, g_ctx.devc, A, nk, b.LBj, b.UBj);
+    for (int f = 0; f < nitems; f++) {
+      dim3 grid((b.UBj - b.LBj + 1 + 63) / 64, items[f].nk);
+      hipLaunchKernelGGL(k_periodic_ew, grid, dim3(64), 0, g_ctx.stream, g_ctx.devc, items[f].A, items[f].nk, b.LBj, b.UBj);
+    }
     KERNEL_CHECK("k_periodic_ew");
   }
-  int rc = exchange_phase(A, nk, 0);
+  int rc = exchange_phase(items, nitems, 0);
   if (rc) return rc;
-  return exchange_phase(A, nk, 1);
+  return exchange_phase(items, nitems, 1);
+}
+
+// Batching: between halo_batch_begin() and halo_batch_end() the exchange calls only record their
+// field; halo_batch_end() moves them all in one message per neighbour and phase.  Callers batch
+// exchanges that follow one another with no kernel in between (same result, fewer messages).
+static std::vector<HaloItem> g_batch;
+static bool g_batching = false;
+void halo_batch_begin() { g_batching = true; g_batch.clear(); }
+int halo_batch_end()
+{
+  g_batching = false;
+  const int rc = halo_run(g_batch.data(), (int)g_batch.size());
+  g_batch.clear();
+  return rc;
+}
+
+int halo_exchange3d(int gtype, int nk, double *A)
+{
+  const HaloItem it{gtype, nk, A};
+  if (g_batching) { g_batch.push_back(it); return 0; }
+  return halo_run(&it, 1);
 }
 
 int halo_exchange2d(int gtype, double *A, int) { return halo_exchange3d(gtype, 1, A); }

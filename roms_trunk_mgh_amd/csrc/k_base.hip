@@ -115,8 +115,10 @@ extern "C" int roms_hip_set_massflux(const roms_step_idx_t *s)
   grid.z = b.N;
   hipLaunchKernelGGL(k_set_massflux, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs);
   KERNEL_CHECK("k_set_massflux");
-  if ((rc = halo_exchange3d(GT_U, b.N, g_ctx.dev[FID_Huon]))) return rc;
-  return halo_exchange3d(GT_V, b.N, g_ctx.dev[FID_Hvom]);
+  halo_batch_begin();
+  halo_exchange3d(GT_U, b.N, g_ctx.dev[FID_Huon]);
+  halo_exchange3d(GT_V, b.N, g_ctx.dev[FID_Hvom]);
+  return halo_batch_end();
 }
 
 // ---------------------------------------------------------------------------
@@ -265,8 +267,10 @@ extern "C" int roms_hip_set_depth(const roms_step_idx_t *s)
   hipLaunchKernelGGL(k_set_depth, grid2d(b.IendT - b.IstrT + 1, b.JendT - b.JstrT + 1), block2d(), 0,
                      g_ctx.stream, g_ctx.devc);
   KERNEL_CHECK("k_set_depth");
-  if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_h]))) return rc;
-  if ((rc = halo_exchange3d(GT_R, b.N + 1, g_ctx.dev[FID_z_w]))) return rc;
-  if ((rc = halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_z_r]))) return rc;
-  return halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_Hz]);
+  halo_batch_begin();
+  halo_exchange2d(GT_R, g_ctx.dev[FID_h]);
+  halo_exchange3d(GT_R, b.N + 1, g_ctx.dev[FID_z_w]);
+  halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_z_r]);
+  halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_Hz]);
+  return halo_batch_end();
 }

@@ -300,7 +300,7 @@ extern "C" int roms_hip_pre_step3d(const roms_step_idx_t *s)
   const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
   for (int it = 1; it <= b.NT; it++)
     if ((rc = bc_t3d(3, it))) return rc;
-  for (int it = 1; it <= b.NT; it++)
-    if ((rc = halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + (2L + 3L * (it - 1)) * n3r))) return rc;
-  return 0;
+  halo_batch_begin();
+  for (int it = 1; it <= b.NT; it++) halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + (2L + 3L * (it - 1)) * n3r);
+  return halo_batch_end();
 }

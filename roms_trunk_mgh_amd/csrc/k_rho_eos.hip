@@ -178,14 +178,15 @@ extern "C" int roms_hip_rho_eos(const roms_step_idx_t *s)
   else
     hipLaunchKernelGGL(k_rho_eos_lin, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs);
   KERNEL_CHECK("k_rho_eos");
-  if ((rc = halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_rho]))) return rc;
-  if ((rc = halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_pden]))) return rc;
-  if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_rhoA]))) return rc;
-  if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_rhoS]))) return rc;
+  halo_batch_begin();
+  halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_rho]);
+  halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_pden]);
+  halo_exchange2d(GT_R, g_ctx.dev[FID_rhoA]);
+  halo_exchange2d(GT_R, g_ctx.dev[FID_rhoS]);
   if (g_ctx.p.nonlin_eos) {
-    if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_alpha]))) return rc;
-    if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_beta]))) return rc;
-    if ((rc = halo_exchange3d(GT_R, b.N + 1, g_ctx.dev[FID_bvf]))) return rc;
+    halo_exchange2d(GT_R, g_ctx.dev[FID_alpha]);
+    halo_exchange2d(GT_R, g_ctx.dev[FID_beta]);
+    halo_exchange3d(GT_R, b.N + 1, g_ctx.dev[FID_bvf]);
   }
-  return 0;
+  return halo_batch_end();
 }

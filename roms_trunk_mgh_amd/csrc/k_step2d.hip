@@ -68,6 +68,40 @@ k2d_flux(const RomsDev *__restrict__ c, S2 s, double *__restrict__ DUon, double 
   }
 }
 
+// DUon, DVom of level `lev` on the points this tile owns (interior + physical boundary rows); the
+// ghost points then come with the end-of-call exchange.  Used inside LOOP_2D on several tiles: the
+// fluxes of the NEXT call travel in the same message as zeta, ubar, vbar of this one.
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k2d_flux_own(const RomsDev *__restrict__ c, int lev, double *__restrict__ DUon, double *__restrict__ DVom)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.JstrR + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.JendR) return;
+  const double *__restrict__ zeta = c->F.zeta + (long)(lev - 1) * nij;
+  const double *__restrict__ h = c->F.h;
+  const long a = I2(i, j);
+  // zeta on a closed-wall row is the zero-gradient copy of the adjacent interior row (zetabc.F:48);
+  // it is read from that row directly because bc_zeta fills the wall rows of the OWN columns only and
+  // the ghost column i-1 has not been exchanged yet
+  auto zrow = [&](int jj) {
+    if (b.south_edge && !b.NSperiodic && jj < b.Jstr) return b.Jstr;
+    if (b.north_edge && !b.NSperiodic && jj > b.Jend) return b.Jend;
+    return jj;
+  };
+  const double Drhs = zeta[I2(i, zrow(j))] + h[a];
+  {
+    const double cff = 0.5 * c->F.on_u[a];
+    const double cff1 = cff * (Drhs + (zeta[I2(i - 1, zrow(j))] + h[a - 1]));
+    DUon[a] = c->F.ubar[a + (long)(lev - 1) * nij] * cff1;
+  }
+  if (j >= b.JstrV - 1 && j >= b.LBj + 1) {
+    const double cff = 0.5 * c->F.om_v[a];
+    const double cff1 = cff * (Drhs + (zeta[I2(i, zrow(j - 1))] + h[a - ni]));
+    DVom[a] = c->F.vbar[a + (long)(lev - 1) * nij] * cff1;
+  }
+}
+
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k2d_zeta(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, const double *__restrict__ DVom,
          double *__restrict__ zeta_new, double *__restrict__ zwrk)
@@ -117,7 +151,9 @@ k2d_zeta(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, c
   if (i < b.IstrU - 1 || i > b.Iend || j < b.JstrV - 1 || j > b.Jend) return;
   const bool own = i >= b.Istr && j >= b.Jstr;
   const double rhs = (DUon[a] - DUon[a + 1]) + (DVom[a] - DVom[a + ni]);
-  zeta_point(c, s, rhs, zeta_new, zwrk, a, a, true, own, own, nij, ni);
+  // zeta(knew) is stored on the extended range too: the low-side ghost value computed here is, bit
+  // for bit, what the exchange delivers later, and k2d_flux_own (next call's fluxes) needs it now
+  zeta_point(c, s, rhs, zeta_new, zwrk, a, a, true, true, own, nij, ni);
 }
 
 // Source-mapped variant (single tile, E-W periodic, closed N-S walls): one
@@ -503,7 +539,12 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
   if (v_wall) c->F.vbar[o + (long)(s.knew - 1) * nij] = 0.0;
 }
 
-int step2d_impl(const roms_step_idx_t *si)
+// DUon/DVom scratch already holds the exchanged fluxes of barotropic level g_flux_lev (left there by the
+// previous call of the same LOOP_2D)
+bool g_flux_ready = false;
+int g_flux_lev = 0;
+
+int step2d_impl(const roms_step_idx_t *si, bool in_loop)
 {
   const roms_bounds_t &b = g_ctx.b;
   const roms_params_t &p = g_ctx.p;
@@ -551,24 +592,33 @@ int step2d_impl(const roms_step_idx_t *si)
     KERNEL_CHECK("k2d_mom");
     return 0;
   }
-  hipLaunchKernelGGL(k2d_flux, grid2d(b.Iendp2 - (b.IstrU - 2) + 1, b.Jendp2 - (b.JstrV - 2) + 1), block2d(), 0,
-                     g_ctx.stream, g_ctx.devc, s, DUon, DVom);
-  KERNEL_CHECK("k2d_flux");
-  if ((rc = halo_exchange2d(GT_U, DUon))) return rc;
-  if ((rc = halo_exchange2d(GT_V, DVom))) return rc;
+  // General path (several tiles; first predictor of a step on one tile).  Messages per call: inside
+  // LOOP_2D ONE fused exchange at the end (rzeta, zeta, ubar, vbar of this call + DUon, DVom of the
+  // next one, whose krhs is this call's knew); a stand-alone call exchanges its own fluxes first.
+  const bool multi = b.ntileI * b.ntileJ > 1;
+  if (!(g_flux_ready && g_flux_lev == s.krhs)) {
+    hipLaunchKernelGGL(k2d_flux, grid2d(b.Iendp2 - (b.IstrU - 2) + 1, b.Jendp2 - (b.JstrV - 2) + 1), block2d(), 0,
+                       g_ctx.stream, g_ctx.devc, s, DUon, DVom);
+    KERNEL_CHECK("k2d_flux");
+    halo_batch_begin();
+    halo_exchange2d(GT_U, DUon);
+    halo_exchange2d(GT_V, DVom);
+    if ((rc = halo_batch_end())) return rc;
+  }
+  g_flux_ready = false;
   const int i0 = b.IstrR < b.IstrU - 1 ? b.IstrR : b.IstrU - 1, j0 = b.JstrR < b.JstrV - 1 ? b.JstrR : b.JstrV - 1;
   hipLaunchKernelGGL(k2d_zeta, grid2d(b.IendR - i0 + 1, b.JendR - j0 + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
                      (const double *)DUon, (const double *)DVom, zeta_new, zwrk);
   KERNEL_CHECK("k2d_zeta");
   if (s.iif == p.nfast + 1 && s.predictor) {
-    if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_Zt_avg1]))) return rc;
-    if ((rc = halo_exchange2d(GT_U, g_ctx.dev[FID_DU_avg1]))) return rc;
-    if ((rc = halo_exchange2d(GT_V, g_ctx.dev[FID_DV_avg1]))) return rc;
+    halo_batch_begin();
+    halo_exchange2d(GT_R, g_ctx.dev[FID_Zt_avg1]);
+    halo_exchange2d(GT_U, g_ctx.dev[FID_DU_avg1]);
+    halo_exchange2d(GT_V, g_ctx.dev[FID_DV_avg1]);
+    if ((rc = halo_batch_end())) return rc;
   }
   if (s.iif > p.nfast) return 0;
-  if (s.predictor && (rc = halo_exchange2d(GT_R, g_ctx.dev[FID_rzeta] + (long)(s.krhs - 1) * nij))) return rc;
   if ((rc = bc_zeta(s.knew))) return rc;
-  if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_zeta] + (long)(s.knew - 1) * nij))) return rc;
   if (!g_ctx.no_lds_2d) {
     if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, zeta_new, zwrk))) return rc;
   } else {
@@ -579,8 +629,24 @@ int step2d_impl(const roms_step_idx_t *si)
   }
   if ((rc = bc_u2d(s.knew))) return rc;
   if ((rc = bc_v2d(s.knew))) return rc;
-  if ((rc = halo_exchange2d(GT_U, g_ctx.dev[FID_ubar] + (long)(s.knew - 1) * nij))) return rc;
-  return halo_exchange2d(GT_V, g_ctx.dev[FID_vbar] + (long)(s.knew - 1) * nij);
+  const bool defer = in_loop && multi;
+  if (defer) {
+    hipLaunchKernelGGL(k2d_flux_own, grid2d(b.Iend - b.Istr + 1, b.JendR - b.JstrR + 1), block2d(), 0, g_ctx.stream,
+                       g_ctx.devc, s.knew, DUon, DVom);
+    KERNEL_CHECK("k2d_flux_own");
+  }
+  halo_batch_begin();
+  if (s.predictor) halo_exchange2d(GT_R, g_ctx.dev[FID_rzeta] + (long)(s.krhs - 1) * nij);
+  halo_exchange2d(GT_R, g_ctx.dev[FID_zeta] + (long)(s.knew - 1) * nij);
+  halo_exchange2d(GT_U, g_ctx.dev[FID_ubar] + (long)(s.knew - 1) * nij);
+  halo_exchange2d(GT_V, g_ctx.dev[FID_vbar] + (long)(s.knew - 1) * nij);
+  if (defer) {
+    halo_exchange2d(GT_U, DUon);
+    halo_exchange2d(GT_V, DVom);
+  }
+  if ((rc = halo_batch_end())) return rc;
+  if (defer) { g_flux_ready = true; g_flux_lev = s.knew; }
+  return 0;
 }
 
 }  // namespace
@@ -591,7 +657,8 @@ extern "C" int roms_hip_step2d(const roms_step_idx_t *s)
   if (rc) return rc;
   if ((rc = check_lbc())) return rc;
   ScopedTimer tm("step2d");
-  return step2d_impl(s);
+  g_flux_ready = false;
+  return step2d_impl(s, false);
 }
 
 // LOOP_2D of main3d.F:592-700
@@ -603,6 +670,7 @@ extern "C" int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1)
   ScopedTimer tm("step2d_loop");
   const int nfast = g_ctx.p.nfast;
   int predictor = 0;
+  g_flux_ready = false;
   for (int my_iif = 1; my_iif <= nfast + 1; my_iif++) {
     const int next_indx1 = 3 - *indx1;
     if (!predictor && my_iif <= nfast + 1) {
@@ -613,7 +681,7 @@ extern "C" int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1)
       s->krhs = *indx1;
     }
     s->predictor_2d_step = predictor;
-    if ((rc = step2d_impl(s))) return rc;
+    if ((rc = step2d_impl(s, true))) return rc;
     if (predictor) {
       predictor = 0;
       s->knew = next_indx1;
@@ -623,7 +691,8 @@ extern "C" int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1)
     }
     s->predictor_2d_step = predictor;
     if (s->iif < nfast + 1)
-      if ((rc = step2d_impl(s))) return rc;
+      if ((rc = step2d_impl(s, true))) return rc;
   }
+  g_flux_ready = false;
   return 0;
 }

@@ -475,7 +475,8 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
   for (int it = 1; it <= b.NT; it++)
     if ((rc = bc_t3d(s->nnew, it))) return rc;
   const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
+  halo_batch_begin();
   for (int it = 1; it <= b.NT; it++)
-    if ((rc = halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + ((long)(s->nnew - 1) + 3L * (it - 1)) * n3r))) return rc;
-  return 0;
+    halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + ((long)(s->nnew - 1) + 3L * (it - 1)) * n3r);
+  return halo_batch_end();
 }

@@ -223,10 +223,12 @@ extern "C" int roms_hip_step3d_uv(const roms_step_idx_t *s)
   }
   const long nij = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1);
   const long n3r = nij * b.N;
-  if ((rc = halo_exchange3d(GT_U, b.N, g_ctx.dev[FID_u] + (long)(s->nnew - 1) * n3r))) return rc;
-  if ((rc = halo_exchange3d(GT_V, b.N, g_ctx.dev[FID_v] + (long)(s->nnew - 1) * n3r))) return rc;
-  if ((rc = halo_exchange3d(GT_U, b.N, g_ctx.dev[FID_Huon]))) return rc;
-  if ((rc = halo_exchange3d(GT_V, b.N, g_ctx.dev[FID_Hvom]))) return rc;
-  if ((rc = halo_exchange3d(GT_U, 2, g_ctx.dev[FID_ubar]))) return rc;
-  return halo_exchange3d(GT_V, 2, g_ctx.dev[FID_vbar]);
+  halo_batch_begin();
+  halo_exchange3d(GT_U, b.N, g_ctx.dev[FID_u] + (long)(s->nnew - 1) * n3r);
+  halo_exchange3d(GT_V, b.N, g_ctx.dev[FID_v] + (long)(s->nnew - 1) * n3r);
+  halo_exchange3d(GT_U, b.N, g_ctx.dev[FID_Huon]);
+  halo_exchange3d(GT_V, b.N, g_ctx.dev[FID_Hvom]);
+  halo_exchange3d(GT_U, 2, g_ctx.dev[FID_ubar]);
+  halo_exchange3d(GT_V, 2, g_ctx.dev[FID_vbar]);
+  return halo_batch_end();
 }

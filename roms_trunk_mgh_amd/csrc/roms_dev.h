@@ -179,6 +179,8 @@ static inline dim3 grid_tile_tracer(int nx, int ny, int ntr, int ty = BLK_Y) {
 // ------------------------------------------------------------------------
 int halo_exchange2d(int gtype, double *A, int nfields_stride_unused = 0);
 int halo_exchange3d(int gtype, int nk, double *A);
+void halo_batch_begin();                  // record the exchanges that follow ...
+int halo_batch_end();                     // ... and run them as one message per neighbour and phase
 int bc_zeta(int kout);
 int bc_u2d(int kout);
 int bc_v2d(int kout);
