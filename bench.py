@@ -93,6 +93,12 @@ def main():
     device = local_rank % torch.cuda.device_count() if os.environ.get("ROMS_BENCH_SHARE_GPU") else local_rank
     torch.cuda.set_device(device)
 
+    # RCCL prints a version banner on stdout when it is first used; this file's stdout carries
+    # exactly one JSON line, so stdout points at stderr while the transport is set up and warmed up
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     uid = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -119,11 +125,7 @@ def main():
     # lines through pinned host memory + gloo (slower; recorded in config.halo_transport)
     transport = "none" if world == 1 else "rccl"
     be = None
-    # RCCL prints a version banner on stdout when the communicator is created; this file's stdout
-    # carries exactly one JSON line, so stdout points at stderr while the transport is set up
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
+
     if world > 1 and os.environ.get("ROMS_BENCH_HALO") != "relay":
         ok_init = 1
         try:

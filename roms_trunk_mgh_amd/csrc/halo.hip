@@ -194,6 +194,34 @@ __global__ void k_pack(const RomsDev *__restrict__ c, const double *__restrict__
   else buf[q] = A[a + (long)k * nij];
 }
 
+// All fields of a batch and both sides of a phase in ONE launch (a step on several tiles issues
+// ~70 exchanges; with a launch per field, side and direction the host could not feed the GPU).
+#define HALO_MAX_ITEMS 8
+struct PackArgs {
+  double *A[HALO_MAX_ITEMS];
+  int nk[HALO_MAX_ITEMS], koff[HALO_MAX_ITEMS];
+  int n, nktot, dir, len, Gmax, unpack;
+  int start[2], G[2];          // side 0 = low neighbour, 1 = high neighbour; G = 0: side absent
+  double *buf[2];
+};
+__global__ void k_pack_multi(const RomsDev *__restrict__ c, PackArgs a)
+{
+  DEV_PROLOGUE(c)
+  const int side = blockIdx.z;
+  const int G = a.G[side];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y % a.Gmax, kk = blockIdx.y / a.Gmax;
+  if (r >= a.len || m >= G || kk >= a.nktot) return;
+  int f = 0;
+  while (f + 1 < a.n && kk >= a.koff[f + 1]) f++;
+  const int k = kk - a.koff[f];
+  const int start = a.start[side];
+  const long idx = (a.dir == 0 ? I2(start + m, LBj + r) : I2(LBi + r, start + m)) + (long)k * nij;
+  const long q = ((long)kk * G + m) * a.len + r;
+  if (a.unpack) a.A[f][idx] = a.buf[side][q];
+  else a.buf[side][q] = a.A[f][idx];
+}
+
 static int ensure_buffers(size_t doubles)
 {
   if (doubles <= g_buf_doubles) return 0;
@@ -226,17 +254,21 @@ static int exchange_phase(const HaloItem *items, int nitems, int dir)
   int rc = ensure_buffers((size_t)nktot * Gmax * len);
   if (rc) return rc;
   const dim3 blk(256);
-  auto launch_all = [&](double *buf, int start, int G, int unpack) {
-    long koff = 0;
-    for (int f = 0; f < nitems; f++) {
-      dim3 grid((len + 255) / 256, (unsigned)(items[f].nk * G));
-      hipLaunchKernelGGL(k_pack, grid, blk, 0, g_ctx.stream, g_ctx.devc, items[f].A, buf + koff * G * len, items[f].nk,
-                         dir, start, G, unpack);
-      koff += items[f].nk;
-    }
+  PackArgs pa;
+  pa.n = nitems; pa.nktot = (int)nktot; pa.dir = dir; pa.len = len; pa.Gmax = Gmax;
+  {
+    int koff = 0;
+    for (int f = 0; f < nitems; f++) { pa.A[f] = items[f].A; pa.nk[f] = items[f].nk; pa.koff[f] = koff; koff += items[f].nk; }
+  }
+  auto launch_sides = [&](double *blo, int slo, int glo, double *bhi, int shi, int ghi, int unpack) {
+    pa.buf[0] = blo; pa.start[0] = slo; pa.G[0] = lo >= 0 ? glo : 0;
+    pa.buf[1] = bhi; pa.start[1] = shi; pa.G[1] = hi >= 0 ? ghi : 0;
+    pa.unpack = unpack;
+    dim3 grid((len + 255) / 256, (unsigned)(nktot * Gmax), 2);
+    hipLaunchKernelGGL(k_pack_multi, grid, blk, 0, g_ctx.stream, g_ctx.devc, pa);
   };
-  if (lo >= 0) launch_all(g_buf[0], str, GsLo, 0);                 // my first GsLo interior lines
-  if (hi >= 0) launch_all(g_buf[1], end - GsHi + 1, GsHi, 0);      // my last GsHi interior lines
+  // my first GsLo / last GsHi interior lines
+  launch_sides(g_buf[0], str, GsLo, g_buf[1], end - GsHi + 1, GsHi, 0);
   KERNEL_CHECK("k_pack");
   const long nsl = nktot * GsLo * len, nsh = nktot * GsHi * len;
   const long nrl = nktot * GrLo * len, nrh = nktot * GrHi * len;
@@ -271,8 +303,7 @@ static int exchange_phase(const HaloItem *items, int nitems, int dir)
     if (lo >= 0) RCCL_TRY(rccl.recv(g_buf[2], (size_t)nrl, RCCL_FLOAT64, lo, comm, g_ctx.stream));
     RCCL_TRY(rccl.gend());
   }
-  if (lo >= 0) launch_all(g_buf[2], str - GrLo, GrLo, 1);
-  if (hi >= 0) launch_all(g_buf[3], end + 1, GrHi, 1);
+  launch_sides(g_buf[2], str - GrLo, GrLo, g_buf[3], end + 1, GrHi, 1);
   KERNEL_CHECK("k_unpack");
   return 0;
 }
@@ -308,9 +339,13 @@ static int halo_run(const HaloItem *items, int nitems)
     }
     KERNEL_CHECK("k_periodic_ew");
   }
-  int rc = exchange_phase(items, nitems, 0);
-  if (rc) return rc;
-  return exchange_phase(items, nitems, 1);
+  for (int f0 = 0; f0 < nitems; f0 += HALO_MAX_ITEMS) {
+    const int n = nitems - f0 < HALO_MAX_ITEMS ? nitems - f0 : HALO_MAX_ITEMS;
+    int rc = exchange_phase(items + f0, n, 0);
+    if (rc) return rc;
+    if ((rc = exchange_phase(items + f0, n, 1))) return rc;
+  }
+  return 0;
 }
 
 // Batching: between halo_batch_begin() and halo_batch_end() the exchange calls only record their
