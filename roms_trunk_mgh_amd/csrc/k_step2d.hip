@@ -22,7 +22,7 @@
 
 int roms_entry_check(const char *name);
 int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DVom, const double *zeta_new,
-                            const double *zwrk);   // k_step2d_mom.hip
+                            const double *zwrk, double *DUnext = nullptr, double *DVnext = nullptr);   // k_step2d_mom.hip
 
 namespace {
 
@@ -543,6 +543,7 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
 // previous call of the same LOOP_2D)
 bool g_flux_ready = false;
 int g_flux_lev = 0;
+int g_flux_buf = 0;       // which scratch pair holds them
 
 int step2d_impl(const roms_step_idx_t *si, bool in_loop)
 {
@@ -596,6 +597,11 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   // LOOP_2D ONE fused exchange at the end (rzeta, zeta, ubar, vbar of this call + DUon, DVom of the
   // next one, whose krhs is this call's knew); a stand-alone call exchanges its own fluxes first.
   const bool multi = b.ntileI * b.ntileJ > 1;
+  // DUon/DVom live in two scratch pairs: the fused kernel reads one (exchanged fluxes of this level)
+  // while it writes the other (own-point fluxes of the next level)
+  if (g_flux_buf) { DUon = g_ctx.hostc.ws2[4]; DVom = g_ctx.hostc.ws2[5]; }
+  double *DUnext = g_flux_buf ? g_ctx.hostc.ws2[0] : g_ctx.hostc.ws2[4];
+  double *DVnext = g_flux_buf ? g_ctx.hostc.ws2[1] : g_ctx.hostc.ws2[5];
   if (!(g_flux_ready && g_flux_lev == s.krhs)) {
     hipLaunchKernelGGL(k2d_flux, grid2d(b.Iendp2 - (b.IstrU - 2) + 1, b.Jendp2 - (b.JstrV - 2) + 1), block2d(), 0,
                        g_ctx.stream, g_ctx.devc, s, DUon, DVom);
@@ -606,6 +612,23 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
     if ((rc = halo_batch_end())) return rc;
   }
   g_flux_ready = false;
+  if (in_loop && multi && !g_ctx.no_lds_2d && s.iif <= p.nfast) {
+    // ONE compute launch + ONE exchange per call
+    s.sm = 3;
+    if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, nullptr, nullptr, DUnext, DVnext))) return rc;
+    halo_batch_begin();
+    if (s.predictor) halo_exchange2d(GT_R, g_ctx.dev[FID_rzeta] + (long)(s.krhs - 1) * nij);
+    halo_exchange2d(GT_R, g_ctx.dev[FID_zeta] + (long)(s.knew - 1) * nij);
+    halo_exchange2d(GT_U, g_ctx.dev[FID_ubar] + (long)(s.knew - 1) * nij);
+    halo_exchange2d(GT_V, g_ctx.dev[FID_vbar] + (long)(s.knew - 1) * nij);
+    halo_exchange2d(GT_U, DUnext);
+    halo_exchange2d(GT_V, DVnext);
+    if ((rc = halo_batch_end())) return rc;
+    g_flux_ready = true;
+    g_flux_lev = s.knew;
+    g_flux_buf ^= 1;
+    return 0;
+  }
   const int i0 = b.IstrR < b.IstrU - 1 ? b.IstrR : b.IstrU - 1, j0 = b.JstrR < b.JstrV - 1 ? b.JstrR : b.JstrV - 1;
   hipLaunchKernelGGL(k2d_zeta, grid2d(b.IendR - i0 + 1, b.JendR - j0 + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
                      (const double *)DUon, (const double *)DVom, zeta_new, zwrk);

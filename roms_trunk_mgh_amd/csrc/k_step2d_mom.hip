@@ -118,10 +118,15 @@ __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S
 template <bool FUSED>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, const double *__restrict__ DVom,
-            const double *__restrict__ zeta_new, const double *__restrict__ zwrk)
+            const double *__restrict__ zeta_new, const double *__restrict__ zwrk, double *__restrict__ DUnext,
+            double *__restrict__ DVnext)
 {
   DEV_PROLOGUE(c)
   const roms_params_t &p = c->p;
+  // DUnext != nullptr (FUSED on several tiles, inside LOOP_2D): the closed-wall conditions are applied here
+  // and DUon/DVom of the NEXT call (level knew) are left in DUnext/DVnext on the points this tile owns,
+  // so that one exchange per call moves everything the next call needs
+  const bool inline_bc = s.sm || DUnext != nullptr;
   __shared__ double sU[TJ * TP], sV[TJ * TP], sDU[TJ * TP], sDV[TJ * TP], sD[TJ * TP];
   __shared__ double sZn[FUSED ? TJ * TP : 1], sZw[FUSED ? TJ * TP : 1];
   const int ibase = s.sm ? b.LBi : b.Istr;
@@ -169,7 +174,9 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     for (int q = tid; q < ZW * ZH; q += BLK_X * BLK_Y) {
       const int li = 1 + q % ZW, lj = 1 + q / ZW;
       const int e = lj * TP + li;
-      int gi = wrap_i(b, it0 - 2 + li), gj = j0 - 2 + lj;
+      int gi = it0 - 2 + li, gj = j0 - 2 + lj;
+      if (s.sm) gi = wrap_i(b, gi);
+      else gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
       gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
       const double rhs = (sDU[e] - sDU[e + 1]) + (sDV[e] - sDV[e + TP]);
       double zn, zw;
@@ -205,8 +212,12 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const int iif = s.iif;
     const double *__restrict__ zkr = c->F.zeta + (long)(s.krhs - 1) * nij;
     auto average = [&](long oo, int tt, bool inU, bool inV) {       // step2d_LF_AM3.h:614-682 at target oo
-      if (s.predictor) {
-        // (iif == 1 never comes here: the first predictor of a step uses the general path)
+      if (s.predictor && iif == 1) {
+        const double cff2 = (-1.0 / 12.0) * p.weight2[iif];
+        c->F.Zt_avg1[oo] = 0.0;
+        if (inU) { c->F.DU_avg1[oo] = 0.0; c->F.DU_avg2[oo] = cff2 * sDU[tt]; }
+        if (inV) { c->F.DV_avg1[oo] = 0.0; c->F.DV_avg2[oo] = cff2 * sDV[tt]; }
+      } else if (s.predictor) {
         const double cff1 = p.weight1[iif - 2];
         const double cff2 = (8.0 / 12.0) * p.weight2[iif - 1] - (1.0 / 12.0) * p.weight2[iif];
         c->F.Zt_avg1[oo] = c->F.Zt_avg1[oo] + cff1 * zkr[oo];
@@ -391,9 +402,20 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
                       a3 * c->F.rubar[a + (long)(ptsk - 1) * nij])) * fc;
     ubn[o] = un;
     if (s.predictor && owner) c->F.rubar[a + (long)(s.krhs - 1) * nij] = rhs_u;
-    if (s.sm) {                                        // u2dbc closed walls, u2dbc_im.F:51
+    if (inline_bc) {                                   // u2dbc closed walls, u2dbc_im.F:51
       if (b.south_edge && j == b.Jstr) ubn[o - ni] = p.gamma2 * un;
       if (b.north_edge && j == b.Jend) ubn[o + ni] = p.gamma2 * un;
+    }
+    if constexpr (FUSED) {
+      if (DUnext) {                                    // DUon of level knew, :509-525 (as k2d_flux)
+        const double znw = sZn[t - 1];
+        DUnext[a] = un * ((0.5 * c->F.on_u[a]) * (Dn0 + (znw + h[q])));
+        // wall rows: u = gamma2*u(adjacent row), zeta = zero-gradient copy (u2dbc_im.F:51, zetabc.F:48)
+        if (b.south_edge && j == b.Jstr)
+          DUnext[a - ni] = (p.gamma2 * un) * ((0.5 * c->F.on_u[a - ni]) * ((sZn[t] + h[a - ni]) + (znw + h[q - ni])));
+        if (b.north_edge && j == b.Jend)
+          DUnext[a + ni] = (p.gamma2 * un) * ((0.5 * c->F.on_u[a + ni]) * ((sZn[t] + h[a + ni]) + (znw + h[q + ni])));
+      }
     }
   }
   if (do_v) {
@@ -408,10 +430,22 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
                       a3 * c->F.rvbar[a + (long)(ptsk - 1) * nij])) * fc;
     vbn[o] = vn;
     if (s.predictor && owner) c->F.rvbar[a + (long)(s.krhs - 1) * nij] = rhs_v;
+    if constexpr (FUSED) {
+      if (DVnext) DVnext[a] = vn * ((0.5 * c->F.om_v[a]) * (Dn0 + (sZn[t - TP] + h[q])));   // :527-544
+    }
   }
-  if (s.sm) {                                          // v2dbc closed walls, v2dbc_im.F:52
+  if (inline_bc) {                                     // v2dbc closed walls, v2dbc_im.F:52
     if (b.south_edge && j == b.Jstr) vbn[o] = 0.0;
     if (b.north_edge && j == b.Jend) vbn[o + ni] = 0.0;
+  }
+  if constexpr (FUSED) {
+    if (DVnext) {                                      // wall rows: v = 0 there
+      const double zn0 = sZn[t];
+      if (b.south_edge && j == b.Jstr)
+        DVnext[a] = 0.0 * ((0.5 * c->F.om_v[a]) * ((zn0 + h[a]) + (zn0 + h[a - ni])));
+      if (b.north_edge && j == b.Jend)
+        DVnext[a + ni] = 0.0 * ((0.5 * c->F.om_v[a + ni]) * ((zn0 + h[a + ni]) + (zn0 + h[a])));
+    }
   }
 }
 
@@ -419,19 +453,23 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
 
 // Launcher used by step2d_impl (k_step2d.hip); s10 = the ten ints of its S2.
 int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DVom, const double *zeta_new,
-                            const double *zwrk)
+                            const double *zwrk, double *DUnext, double *DVnext)
 {
   const roms_bounds_t &b = g_ctx.b;
   S2 s{s10[0], s10[1], s10[2], s10[3], s10[4], s10[5], s10[6], s10[7], s10[8], s10[9]};
-  const int nx = s.sm ? (b.UBi - b.LBi + 1) : (b.Iend - b.Istr + 1);
+  const int nx = (s.sm == 1 || s.sm == 2) ? (b.UBi - b.LBi + 1) : (b.Iend - b.Istr + 1);
   if (s.sm == 2) {      // fused free-surface + momentum call (source-mapped, fluxes in place)
     s.sm = 1;
     hipLaunchKernelGGL(k2d_mom_lds<true>, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
                        (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
-                       (const double *)nullptr);
+                       (const double *)nullptr, (double *)nullptr, (double *)nullptr);
+  } else if (s.sm == 3) {   // fused call on several tiles: exchanged DUon/DVom in, next call's fluxes out
+    s.sm = 0;
+    hipLaunchKernelGGL(k2d_mom_lds<true>, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
+                       DUon, DVom, (const double *)nullptr, (const double *)nullptr, DUnext, DVnext);
   } else
     hipLaunchKernelGGL(k2d_mom_lds<false>, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
-                       DUon, DVom, zeta_new, zwrk);
+                       DUon, DVom, zeta_new, zwrk, (double *)nullptr, (double *)nullptr);
   KERNEL_CHECK("k2d_mom_lds");
   return 0;
 }
