@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--config", default="BENCHMARK3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-physics", dest="physics", action="store_false",
+                    help="keep the outputs of bulk_flux + set_vbc fixed instead of recomputing them on the "
+                         "device every step (SURVEY 8f-1); default: recompute, as the reference's step does")
     args = ap.parse_args()
 
     import torch
@@ -146,7 +149,7 @@ def main():
         be = hip.RomsHip(st, rank=rank, device=device, nccl_unique_id=None if transport != "rccl" else uid)
         if transport == "relay":
             be.set_halo_relay_gloo(dist, torch)
-    m = main3d.Main3D(be)
+    m = main3d.Main3D(be, physics=args.physics)
     m.initial()
     for _ in range(args.warmup):
         m.step()
@@ -172,7 +175,7 @@ def main():
     # ---- roofline of the dominant graded kernel: step3d_t (live hipEvent timing) ----
     be.timing(True)
     per_kernel = {}
-    names = ["set_massflux", "rho_eos", "omega", "set_zeta", "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile",
+    names = ["bulk_flux", "set_vbc", "set_massflux", "rho_eos", "omega", "set_zeta", "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile",
              "uv3dmix2", "step2d_loop", "set_depth", "step3d_uv", "step3d_t"]
     acc = {n: [] for n in names}
     for _ in range(5):
@@ -207,7 +210,8 @@ def main():
             "config": {"workload": f"{args.config} {b.Lm}x{b.Mm}x{b.N} NT={b.NT} "
                                    f"nonlinear 3-D step incl. {2 * st.p.nfast + 1} step2d calls, "
                                    f"U3/C4 tracer advection, fixed analytic forcing/mixing",
-                       "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok},
+                       "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "per_step_physics": "bulk_flux+set_vbc on device" if args.physics
+                       else "fixed inputs", "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok},
             "roofline": {"kernel": "k_step3d_t_pipe (step3d_t_tile)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.config, args.gpus), "traffic_unit": "bytes/launch",

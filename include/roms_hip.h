@@ -111,6 +111,10 @@ typedef struct roms_params {
   double Akt_bak[ROMS_MAXNT], Akv_bak;
   /* Jerlov water type constants of lmd_swfrac.F:6 (mod_scalars.F:1502-1512), uniform WTYPE */
   double swfrac_mu1, swfrac_mu2, swfrac_r1;
+  /* per-step physics between the hot kernels */
+  int    uv_drag;                    /* bottom stress law of set_vbc.F: 1 = UV_LDRAG, 2 = UV_QDRAG */
+  int    pad_physics_;
+  double blk_ZQ, blk_ZT, blk_ZW;     /* measurement heights of bulk_flux.F (roms_*.in BLK_ZQ/ZT/ZW) */
 } roms_params_t;
 
 /* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and
@@ -180,6 +184,12 @@ int roms_hip_step2d(const roms_step_idx_t *s);
 int roms_hip_step3d_uv(const roms_step_idx_t *s);
 /* step3d_t(ng,tile)                ROMS/Nonlinear/step3d_t.F:40      */
 int roms_hip_step3d_t(const roms_step_idx_t *s);
+
+/* Per-step physics between the hot kernels, main3d.F:388-430:
+ * bulk_flux(ng,tile)               ROMS/Nonlinear/bulk_flux.F:46     */
+int roms_hip_bulk_flux(const roms_step_idx_t *s);
+/* set_vbc(ng,tile)                 ROMS/Nonlinear/set_vbc.F:34       */
+int roms_hip_set_vbc(const roms_step_idx_t *s);
 
 /* The whole barotropic loop LOOP_2D of main3d.F:592-700 in one call
  * (predictor/corrector sequencing done inside, optionally replayed from a

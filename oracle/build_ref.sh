@@ -31,7 +31,8 @@ FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iouni
  Modules/mod_stepping Modules/mod_clima Modules/mod_boundary Modules/mod_eoscoef Modules/mod_diags
  Utility/round Utility/dateclock Nonlinear/exchange_2d Nonlinear/exchange_3d Utility/get_bounds
  Utility/set_weights Utility/mp_routines Utility/timers Nonlinear/prsgrd Nonlinear/t3dmix Nonlinear/uv3dmix Nonlinear/set_depth
-  Nonlinear/set_massflux Nonlinear/rho_eos Nonlinear/set_zeta Nonlinear/mpdata_adiff"
+  Nonlinear/set_massflux Nonlinear/rho_eos Nonlinear/set_zeta Nonlinear/mpdata_adiff
+ Nonlinear/bc_2d Nonlinear/set_vbc Nonlinear/bulk_flux"
 
 build_app () {
   local APP=$1 hdr=$(echo $1 | tr A-Z a-z).h

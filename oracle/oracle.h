@@ -131,6 +131,20 @@
 #define srflx(i,j)    F->srflx[I2(i,j)]
 #define stflx(i,j,it) F->stflx[I2(i,j) + (long)((it)-1) * nij]
 #define btflx(i,j,it) F->btflx[I2(i,j) + (long)((it)-1) * nij]
+#define rdrag2(i,j)   F->rdrag2[I2(i,j)]
+#define rdrag(i,j)    F->rdrag[I2(i,j)]
+#define stflux(i,j,it) F->stflux[I2(i,j) + (long)((it)-1) * nij]
+#define btflux(i,j,it) F->btflux[I2(i,j) + (long)((it)-1) * nij]
+#define Uwind(i,j)    F->Uwind[I2(i,j)]
+#define Vwind(i,j)    F->Vwind[I2(i,j)]
+#define Tair(i,j)     F->Tair[I2(i,j)]
+#define Pair(i,j)     F->Pair[I2(i,j)]
+#define Hair(i,j)     F->Hair[I2(i,j)]
+#define rain(i,j)     F->rain[I2(i,j)]
+#define cloud(i,j)    F->cloud[I2(i,j)]
+#define lrflx(i,j)    F->lrflx[I2(i,j)]
+#define lhflx(i,j)    F->lhflx[I2(i,j)]
+#define shflx(i,j)    F->shflx[I2(i,j)]
 
 /* private (automatic) work arrays of the _tile routines */
 #define WS2(i,j)   ((long)((i) - IminS) + (long)((j) - JminS) * nis)   /* (IminS:ImaxS,JminS:JmaxS) */

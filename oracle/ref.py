@@ -73,3 +73,12 @@ class Ref:
                                      Va.ctypes.data, Wa.ctypes.data)
         if rc != 0:
             raise RuntimeError(f"ref_mpdata_adiff rc={rc}")
+
+    def physics(self, kernel, s):
+        """set_vbc / bulk_flux through the reference's own module procedures."""
+        kid = {"set_vbc": 1, "bulk_flux": 2}[kernel]
+        self.l.ref_physics.argtypes = [C.c_int, C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.StepIdx),
+                                       C.POINTER(abi.Fields)]
+        rc = self.l.ref_physics(kid, C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))
+        if rc != 0:
+            raise RuntimeError(f"ref_physics {kernel} rc={rc}")

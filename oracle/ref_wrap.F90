@@ -45,6 +45,8 @@ MODULE ref_wrap_types
     INTEGER(c_int) :: splines_vdiff, splines_vvisc
     REAL(c_double) :: Akt_bak(16), Akv_bak
     REAL(c_double) :: swfrac_mu1, swfrac_mu2, swfrac_r1
+    INTEGER(c_int) :: uv_drag, pad_physics
+    REAL(c_double) :: blk_ZQ, blk_ZT, blk_ZW
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -58,6 +60,8 @@ MODULE ref_wrap_types
     TYPE(c_ptr) :: DU_avg1, DU_avg2, DV_avg1, DV_avg2, Zt_avg1, rufrc, rvfrc, rhoA, rhoS
     TYPE(c_ptr) :: Akv, Akt, ghats, bvf, alpha, beta, visc2_p, visc2_r, diff2
     TYPE(c_ptr) :: sustr, svstr, bustr, bvstr, srflx, stflx, btflx
+    TYPE(c_ptr) :: rdrag2, stflux, btflux, Uwind, Vwind, Tair, Pair, Hair, rain, cloud
+    TYPE(c_ptr) :: lrflx, lhflx, shflx, evap, hsbl, rdrag
   END TYPE fields_t
 END MODULE ref_wrap_types
 
@@ -340,6 +344,110 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   CALL c_f_pointer (F%beta, a2, (/ni,nj/));     a2 = MIXING(ng)%beta
 #endif
 END FUNCTION ref_call
+
+!-----------------------------------------------------------------------
+!  Per-step physics between the hot kernels: kernel 1 = set_vbc (set_vbc.F:34),
+!  2 = bulk_flux (bulk_flux.F:46, BULK_FLUXES applications only = BENCHMARK here).  This file is
+!  preprocessed with -D<APP> only, so the application's options are spelled out by application:
+!  UV_QDRAG: BENCHMARK, SEAMOUNT; UV_LDRAG: UPWELLING; BULK_FLUXES: BENCHMARK.
+FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
+  USE ref_wrap_types
+  USE mod_param
+  USE mod_scalars
+  USE mod_ncparam
+  USE mod_stepping
+  USE mod_grid
+  USE mod_ocean
+  USE mod_mixing
+  USE mod_forces
+  USE mod_boundary, ONLY : allocate_boundary
+  USE set_vbc_mod,   ONLY : set_vbc
+#ifdef BENCHMARK
+  USE bulk_flux_mod, ONLY : bulk_flux
+#endif
+  INTEGER(c_int), VALUE :: kernel
+  TYPE(bounds_t), INTENT(in) :: b
+  TYPE(params_t), INTENT(in) :: p
+  TYPE(stepidx_t), INTENT(in) :: s
+  TYPE(fields_t), INTENT(in) :: F
+  INTEGER(c_int) :: rc
+  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT
+  LOGICAL, SAVE :: have_boundary = .FALSE.
+  REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:), a5(:,:,:,:,:)
+  ng = 1; tile = 0
+  LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
+  ni = UBi-LBi+1; nj = UBj-LBj+1; NN = b%N; NTT = b%NT
+  rc = 0
+  IF (.NOT. have_boundary) THEN
+    CALL allocate_boundary (ng)          ! LBC_apply switches read by bc_u2d_tile / bc_v2d_tile
+    have_boundary = .TRUE.
+  END IF
+  nstp(ng) = s%nstp; nnew(ng) = s%nnew; nrhs(ng) = s%nrhs
+  rho0 = p%rho0; g = p%g
+  gamma2(ng) = p%gamma2
+  !  generic LBC indices (mod_ncparam.F:1229-1232) and the closed S/N walls of the supported set-up
+  isBu2d = isUbar; isBv2d = isVbar
+  LBC(isouth, isBu2d, ng)%closed = p%lbc_south == 1
+  LBC(inorth, isBu2d, ng)%closed = p%lbc_north == 1
+  LBC(isouth, isBv2d, ng)%closed = p%lbc_south == 1
+  LBC(inorth, isBv2d, ng)%closed = p%lbc_north == 1
+  CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
+  CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
+  CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); GRID(ng)%z_w = a3
+  CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   OCEAN(ng)%u = a4
+  CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   OCEAN(ng)%v = a4
+  CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); OCEAN(ng)%t = a5
+  CALL c_f_pointer (F%rho, a3, (/ni,nj,NN/));   OCEAN(ng)%rho = a3
+#if defined BENCHMARK || defined SEAMOUNT
+  CALL c_f_pointer (F%rdrag2, a2, (/ni,nj/));   GRID(ng)%rdrag2 = a2
+#endif
+#ifdef UPWELLING
+  CALL c_f_pointer (F%rdrag, a2, (/ni,nj/));    GRID(ng)%rdrag = a2
+#endif
+  CALL c_f_pointer (F%bustr, a2, (/ni,nj/));    FORCES(ng)%bustr = a2
+  CALL c_f_pointer (F%bvstr, a2, (/ni,nj/));    FORCES(ng)%bvstr = a2
+  CALL c_f_pointer (F%sustr, a2, (/ni,nj/));    FORCES(ng)%sustr = a2
+  CALL c_f_pointer (F%svstr, a2, (/ni,nj/));    FORCES(ng)%svstr = a2
+  CALL c_f_pointer (F%stflux, a3, (/ni,nj,NTT/)); FORCES(ng)%stflux = a3
+  CALL c_f_pointer (F%btflux, a3, (/ni,nj,NTT/)); FORCES(ng)%btflux = a3
+  CALL c_f_pointer (F%stflx, a3, (/ni,nj,NTT/)); FORCES(ng)%stflx = a3
+  CALL c_f_pointer (F%btflx, a3, (/ni,nj,NTT/)); FORCES(ng)%btflx = a3
+#ifdef BENCHMARK
+  blk_ZQ(ng) = p%blk_ZQ; blk_ZT(ng) = p%blk_ZT; blk_ZW(ng) = p%blk_ZW
+  CALL c_f_pointer (F%alpha, a2, (/ni,nj/));    MIXING(ng)%alpha = a2
+  CALL c_f_pointer (F%beta, a2, (/ni,nj/));     MIXING(ng)%beta = a2
+  CALL c_f_pointer (F%srflx, a2, (/ni,nj/));    FORCES(ng)%srflx = a2
+  CALL c_f_pointer (F%Uwind, a2, (/ni,nj/));    FORCES(ng)%Uwind = a2
+  CALL c_f_pointer (F%Vwind, a2, (/ni,nj/));    FORCES(ng)%Vwind = a2
+  CALL c_f_pointer (F%Tair, a2, (/ni,nj/));     FORCES(ng)%Tair = a2
+  CALL c_f_pointer (F%Pair, a2, (/ni,nj/));     FORCES(ng)%Pair = a2
+  CALL c_f_pointer (F%Hair, a2, (/ni,nj/));     FORCES(ng)%Hair = a2
+  CALL c_f_pointer (F%rain, a2, (/ni,nj/));     FORCES(ng)%rain = a2
+  CALL c_f_pointer (F%cloud, a2, (/ni,nj/));    FORCES(ng)%cloud = a2
+  CALL c_f_pointer (F%lrflx, a2, (/ni,nj/));    FORCES(ng)%lrflx = a2
+  CALL c_f_pointer (F%lhflx, a2, (/ni,nj/));    FORCES(ng)%lhflx = a2
+  CALL c_f_pointer (F%shflx, a2, (/ni,nj/));    FORCES(ng)%shflx = a2
+#endif
+  SELECT CASE (kernel)
+  CASE (1); CALL set_vbc (ng, tile)
+#ifdef BENCHMARK
+  CASE (2); CALL bulk_flux (ng, tile)
+#endif
+  CASE DEFAULT; rc = 2
+  END SELECT
+  CALL c_f_pointer (F%bustr, a2, (/ni,nj/));    a2 = FORCES(ng)%bustr
+  CALL c_f_pointer (F%bvstr, a2, (/ni,nj/));    a2 = FORCES(ng)%bvstr
+  CALL c_f_pointer (F%sustr, a2, (/ni,nj/));    a2 = FORCES(ng)%sustr
+  CALL c_f_pointer (F%svstr, a2, (/ni,nj/));    a2 = FORCES(ng)%svstr
+  CALL c_f_pointer (F%stflux, a3, (/ni,nj,NTT/)); a3 = FORCES(ng)%stflux
+  CALL c_f_pointer (F%stflx, a3, (/ni,nj,NTT/)); a3 = FORCES(ng)%stflx
+  CALL c_f_pointer (F%btflx, a3, (/ni,nj,NTT/)); a3 = FORCES(ng)%btflx
+#ifdef BENCHMARK
+  CALL c_f_pointer (F%lrflx, a2, (/ni,nj/));    a2 = FORCES(ng)%lrflx
+  CALL c_f_pointer (F%lhflx, a2, (/ni,nj/));    a2 = FORCES(ng)%lhflx
+  CALL c_f_pointer (F%shflx, a2, (/ni,nj/));    a2 = FORCES(ng)%shflx
+#endif
+END FUNCTION ref_physics
 
 !-----------------------------------------------------------------------
 !  mpdata_adiff_tile (ROMS/Nonlinear/mpdata_adiff.F:38) on caller-held private

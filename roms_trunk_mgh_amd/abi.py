@@ -93,6 +93,8 @@ class Params(C.Structure):
         ("splines_vdiff", C.c_int), ("splines_vvisc", C.c_int),
         ("Akt_bak", C.c_double * ROMS_MAXNT), ("Akv_bak", C.c_double),
         ("swfrac_mu1", C.c_double), ("swfrac_mu2", C.c_double), ("swfrac_r1", C.c_double),
+        ("uv_drag", C.c_int), ("pad_physics_", C.c_int),
+        ("blk_ZQ", C.c_double), ("blk_ZT", C.c_double), ("blk_ZW", C.c_double),
     ]
 
 

@@ -205,6 +205,9 @@ def make_params(cfg, NT):
     p.Akv_bak = {"BENCHMARK": 1.0e-4}.get(app, 1.0e-5)
     # WTYPE == 1 (roms_benchmark*.in:392): mod_scalars.F:1502-1512
     p.swfrac_mu1, p.swfrac_mu2, p.swfrac_r1 = 0.35, 23.0, 0.58
+    # set_vbc.F: BENCHMARK and SEAMOUNT have UV_QDRAG (rdrg2 = 3.0d-03), UPWELLING UV_LDRAG (rdrg = 3.0d-04)
+    p.uv_drag = 1 if cfg["app"] == "UPWELLING" else 2
+    p.blk_ZQ = p.blk_ZT = p.blk_ZW = 10.0       # roms_*.in:382-384
     return p
 
 
@@ -395,5 +398,27 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
         A["Akv"][:] = p.Akv_bak
         for it in range(NAT):
             A["Akt"][:, :, :, it] = p.Akt_bak[it]
+    # ---- inputs of the per-step physics (set_vbc, bulk_flux): roms_*.in and ana_*.h of the app ----
+    A["rdrag2"][:] = 3.0e-3                       # RDRG2 (roms_benchmark*.in)
+    A["rdrag"][:] = 3.0e-4                        # RDRG
+    A["stflux"][:] = A["stflx"]                   # raw surface tracer fluxes (ana_stflux.h: 0; heat: fixed profile)
+    A["btflux"][:] = A["btflx"]
+    if app == "BENCHMARK":
+        cffw = 0.2 * (60.0 + st.latr)
+        A["Uwind"][:] = 15.0 * np.exp(-cffw * cffw)      # ana_winds.h:118-126, Wmag = 15 m/s
+        A["Vwind"][:] = 0.0
+        A["Tair"][:] = 4.0                           # ana_tair.h
+        A["Pair"][:] = 1025.0                        # ana_pair.h
+        A["Hair"][:] = 0.8                           # ana_humid.h
+        A["rain"][:] = 0.0                           # ana_rain.h
+        A["cloud"][:] = 0.6                          # ana_cloud.h
+    else:                                            # not BULK_FLUXES applications: plausible test inputs
+        A["Uwind"][:] = 5.0 + 2.0 * bump
+        A["Vwind"][:] = -3.0 + 1.5 * bump
+        A["Tair"][:] = 12.0
+        A["Pair"][:] = 1013.0
+        A["Hair"][:] = 0.7
+        A["rain"][:] = 1.0e-5
+        A["cloud"][:] = 0.4
     st.z_r0, st.z_w0 = z_r, z_w
     return st

@@ -42,7 +42,10 @@ MODULE roms_hip_mod
  &    FID_Zt_avg1=47, FID_rufrc=48, FID_rvfrc=49, FID_rhoA=50, FID_rhoS=51, FID_Akv=52,     &
  &    FID_Akt=53, FID_ghats=54, FID_bvf=55, FID_alpha=56, FID_beta=57, FID_visc2_p=58,      &
  &    FID_visc2_r=59, FID_diff2=60, FID_sustr=61, FID_svstr=62, FID_bustr=63,               &
- &    FID_bvstr=64, FID_srflx=65, FID_stflx=66, FID_btflx=67
+ &    FID_bvstr=64, FID_srflx=65, FID_stflx=66, FID_btflx=67,                          &
+ &    FID_rdrag2=68, FID_stflux=69, FID_btflux=70, FID_Uwind=71, FID_Vwind=72, FID_Tair=73,  &
+ &    FID_Pair=74, FID_Hair=75, FID_rain=76, FID_cloud=77, FID_lrflx=78, FID_lhflx=79,      &
+ &    FID_shflx=80, FID_evap=81, FID_hsbl=82, FID_rdrag=83
 
   INTERFACE
     INTEGER(c_int) FUNCTION roms_hip_init (rank, ntileI, ntileJ, device_id, uid)            &
@@ -141,6 +144,14 @@ MODULE roms_hip_mod
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
     END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_bulk_flux (s) BIND(C, name='roms_hip_bulk_flux')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_set_vbc (s) BIND(C, name='roms_hip_set_vbc')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
   END INTERFACE
 
   PUBLIC :: roms_hip_init, roms_hip_finalize, roms_hip_get_unique_id
@@ -149,7 +160,7 @@ MODULE roms_hip_mod
   PUBLIC :: roms_hip_sync_all_to_device, roms_hip_sync_all_to_host, roms_hip_last_error
   PUBLIC :: roms_hip_set_massflux, roms_hip_rho_eos, roms_hip_omega, roms_hip_set_zeta
   PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
-  PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t
+  PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc
   PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
 
 CONTAINS

@@ -9,7 +9,7 @@ against either backend (`hip.RomsHip` = the product, or the CPU oracle in tests)
 
     main3d.F:189-191  nstp/nnew/nrhs rotation
     main3d.F:307-309  set_massflux, rho_eos            (diag: not on the path)
-    main3d.F:388-394  bulk_flux, set_vbc               -> fixed forcing inputs
+    main3d.F:388-394  bulk_flux, set_vbc               (physics=True; else fixed forcing inputs)
     main3d.F:467-475  lmd_vmix -> fixed mixing inputs; omega
     main3d.F:489      set_zeta
     main3d.F:563      rhs3d
@@ -24,8 +24,12 @@ from . import abi
 
 
 class Main3D:
-    def __init__(self, backend, ntstart=1):
+    def __init__(self, backend, ntstart=1, physics=False):
+        """physics=True also runs the per-step physics that is on the device:
+        bulk_flux (BULK_FLUXES applications, i.e. BENCHMARK) and set_vbc, in the reference's order;
+        with physics=False their outputs stay the fixed fields ana.py filled in."""
         self.be = backend
+        self.physics = physics
         self.iic = ntstart
         self.ntstart = ntstart
         self.ntfirst = ntstart
@@ -55,6 +59,10 @@ class Main3D:
         s = self.s
         be.call("set_massflux", s)
         be.call("rho_eos", s)
+        if self.physics:
+            if getattr(be.st, "cfg", {}).get("app") == "BENCHMARK":
+                be.call("bulk_flux", s)
+            be.call("set_vbc", s)
         be.call("omega", s)
         be.call("set_zeta", s)
         be.call("rhs3d", s)

@@ -24,6 +24,8 @@ CONFIGS = ["BENCHMARK_TINY", "UPWELLING", "SEAMOUNT"]
 OVERRIDES = {"BENCHMARK_TINY": {"tnu2": 300.0, "visc2": 800.0}, "UPWELLING": {"tnu2": 300.0, "visc2": 800.0},
              "SEAMOUNT": {"tnu2": 300.0}}
 KERNELS = ["set_depth", "set_massflux", "set_zeta", "rho_eos", "prsgrd", "t3dmix2", "uv3dmix2"]
+# per-step physics; bulk_flux exists in the BULK_FLUXES application (BENCHMARK) only
+PHYSICS = ["set_vbc", "bulk_flux"]
 
 
 def input_state(config):
@@ -31,6 +33,13 @@ def input_state(config):
     st = util.prepared_state(config, overrides=OVERRIDES[config])
     st["Zt_avg1"] *= 1.3
     st["u"] *= 1.1
+    # forcing inputs that make every output of set_vbc / bulk_flux non-trivial
+    st["stflux"][:, :, 0] += 1.0e-6
+    st["Vwind"] += 0.3 * st["Uwind"] - 2.0
+    st["rain"] += 2.0e-5
+    if st.b.NT > 1:
+        st["stflux"][:, :, 1] = 2.0e-8
+        st["btflx"][:, :, 1] = 1.0e-9
     return st
 
 
@@ -55,11 +64,16 @@ def child(config):
     out["nfast"] = np.array(nf)
     out["weight1"], out["weight2"] = w1, w2
     s = util.step_idx()
-    for k in KERNELS:
+    for k in KERNELS + PHYSICS:
         if k == "uv3dmix2" and config == "SEAMOUNT":
             continue
+        if k == "bulk_flux" and not config.startswith("BENCHMARK"):
+            continue
         st = st0.copy()
-        ref.Ref(st).call(k, s)
+        if k in PHYSICS:
+            ref.Ref(st).physics(k, s)
+        else:
+            ref.Ref(st).call(k, s)
         for name, kind, _ in abi.FIELDS:
             a, a0 = st[name], st0[name]
             if np.array_equal(a, a0):

@@ -75,8 +75,41 @@ def main_mpdata(config):
     print(json.dumps(out))
 
 
+def main_physics(config):
+    """set_vbc (all applications) and bulk_flux (BENCHMARK: the BULK_FLUXES application): reference
+    Fortran vs C oracle.  set_vbc has only +,*,sqrt: bit for bit; bulk_flux calls log/exp/pow/atan
+    from two different math libraries: relative difference reported."""
+    import oracle
+    import util
+    from oracle import ref
+    st0 = util.prepared_state(config)
+    s = util.step_idx()
+    out = {}
+    kernels = ["set_vbc"] + (["bulk_flux"] if config.startswith("BENCHMARK") else [])
+    for k in kernels:
+        st_r, st_o = st0.copy(), st0.copy()
+        for st in (st_r, st_o):                     # so that every output changes
+            st["stflux"][:, :, 0] += 1.0e-6
+            st["Vwind"] += 0.3 * st["Uwind"] - 2.0          # both stress components, both signs
+            st["rain"] += 2.0e-5                            # rain heat flux and rain stress terms
+            if st.b.NT > 1:
+                st["stflux"][:, :, 1] = 2.0e-8
+                st["btflx"][:, :, 1] = 1.0e-9
+        ref.Ref(st_r).physics(k, s)
+        oracle.Oracle(st_o).call(k, s)
+        names = ["stflx", "btflx", "bustr", "bvstr"] if k == "set_vbc" else \
+                ["sustr", "svstr", "lrflx", "lhflx", "shflx", "stflux"]
+        diffs = {n: util.max_rel_diff(st_o[n], st_r[n]) for n in names}
+        changed = [n for n in names if not np.array_equal(st_r[n], st0[n])]
+        out[k] = {"max_rel_diff": max(diffs.values()), "diffs": diffs, "changed": changed,
+                  "amax": {n: float(np.abs(st_r[n]).max()) for n in names}}
+    print(json.dumps(out))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "mpdata":
+    if len(sys.argv) > 2 and sys.argv[2] == "physics":
+        main_physics(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "mpdata":
         main_mpdata(sys.argv[1])
     else:
         main(sys.argv[1])

@@ -171,3 +171,32 @@ def test_step2d_loop(config):
     diffs = util.compare_states(st_h, st_o)
     assert all(v <= 1e-11 for v in diffs.values()), diffs
     assert np.isfinite(st_o["zeta"]).all()
+
+
+def _detune_forcing(st):
+    st["stflux"][:, :, 0] += 1.0e-6
+    st["Vwind"] += 0.3 * st["Uwind"] - 2.0
+    st["rain"] += 2.0e-5
+    if st.b.NT > 1:
+        st["stflux"][:, :, 1] = 2.0e-8
+        st["btflx"][:, :, 1] = 1.0e-9
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+def test_set_vbc(config):
+    """bottom stress (quadratic / linear drag) and kinematic surface fluxes."""
+    st_h, st_o, st0 = _run_pair(config, "set_vbc", util.step_idx(), prep=_detune_forcing)
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+    assert util.max_rel_diff(st_o["bustr"], st0["bustr"]) > 1e-6
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+def test_bulk_flux(config):
+    """COARE 3.0 bulk fluxes; the device log/exp/pow/atan differ from the host's in the last bits,
+    three fixed-point iterations amplify that a little: tolerance 1e-11 of each field's maximum."""
+    st_h, st_o, st0 = _run_pair(config, "bulk_flux", util.step_idx(), prep=_detune_forcing)
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= 1e-11 for v in diffs.values()), diffs
+    for name in ("sustr", "svstr", "lhflx", "shflx", "lrflx", "stflux"):
+        assert util.max_rel_diff(st_o[name], st0[name]) > 1e-6, name

@@ -16,21 +16,21 @@ TOL = 1e-10
 FLOOR = {"zeta": 1e-3, "ubar": 1e-4, "vbar": 1e-4, "u": 1e-4, "v": 1e-4, "t": 1e-3}
 
 
-def _run(config, nsteps, perturb):
+def _run(config, nsteps, perturb, physics=False):
     import oracle
     st_o = ana.make_tile(config, perturb=perturb)
     st_h = st_o.copy()
-    mo = main3d.Main3D(oracle.Oracle(st_o))
+    mo = main3d.Main3D(oracle.Oracle(st_o), physics=physics)
     mo.initial()
     mo.run(nsteps)
     if os.environ.get("ROMS_TEST_DRY"):
-        mh = main3d.Main3D(oracle.Oracle(st_h))
+        mh = main3d.Main3D(oracle.Oracle(st_h), physics=physics)
         mh.initial()
         mh.run(nsteps)
     else:
         be = hip.RomsHip(st_h)
         try:
-            mh = main3d.Main3D(be)
+            mh = main3d.Main3D(be, physics=physics)
             mh.initial()
             mh.run(nsteps)
             be.to_host()
@@ -39,9 +39,12 @@ def _run(config, nsteps, perturb):
     return st_h, st_o, mo
 
 
-@pytest.mark.parametrize("config,perturb", [("UPWELLING", 1.0), ("SEAMOUNT", 0.0), ("BENCHMARK_TINY", 1.0)])
-def test_100_steps(config, perturb):
-    st_h, st_o, mo = _run(config, 100, perturb)
+@pytest.mark.parametrize("config,perturb,physics", [("UPWELLING", 1.0, False), ("SEAMOUNT", 0.0, False),
+                                                    ("BENCHMARK_TINY", 1.0, False),
+                                                    # with bulk_flux + set_vbc recomputed every step on the device
+                                                    ("BENCHMARK_TINY", 1.0, True), ("UPWELLING", 1.0, True)])
+def test_100_steps(config, perturb, physics):
+    st_h, st_o, mo = _run(config, 100, perturb, physics)
     s = mo.s
     out = {}
     out["zeta"] = rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], FLOOR["zeta"])
