@@ -46,14 +46,14 @@ def pmc_traffic(config, gpus):
         return None
 
 
-def cpu_baseline(config, nsteps):
+def cpu_baseline(config, nsteps, physics=True):
     """The CPU oracle (a single-thread plain-C port of the reference kernels)
     timed on the host of the GPU box for a bounded number of full steps of the
     same workload.  Reported baseline, not the optimisation target."""
     import oracle
     from roms_trunk_mgh_amd import ana, main3d
     st = ana.make_tile(config, perturb=1.0)
-    m = main3d.Main3D(oracle.Oracle(st))
+    m = main3d.Main3D(oracle.Oracle(st), physics=physics)
     m.initial()
     m.step()                      # first step (forward Euler branch) untimed
     t0 = time.perf_counter()
@@ -175,7 +175,7 @@ def main():
     # ---- roofline of the dominant graded kernel: step3d_t (live hipEvent timing) ----
     be.timing(True)
     per_kernel = {}
-    names = ["bulk_flux", "set_vbc", "set_massflux", "rho_eos", "omega", "set_zeta", "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile",
+    names = ["bulk_flux", "set_vbc", "lmd_vmix", "set_massflux", "rho_eos", "omega", "set_zeta", "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile",
              "uv3dmix2", "step2d_loop", "set_depth", "step3d_uv", "step3d_t"]
     acc = {n: [] for n in names}
     for _ in range(5):
@@ -210,7 +210,7 @@ def main():
             "config": {"workload": f"{args.config} {b.Lm}x{b.Mm}x{b.N} NT={b.NT} "
                                    f"nonlinear 3-D step incl. {2 * st.p.nfast + 1} step2d calls, "
                                    f"U3/C4 tracer advection, fixed analytic forcing/mixing",
-                       "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "per_step_physics": "bulk_flux+set_vbc on device" if args.physics
+                       "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "per_step_physics": "bulk_flux+set_vbc+lmd_vmix (KPP) on device" if args.physics
                        else "fixed inputs", "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok},
             "roofline": {"kernel": "k_step3d_t_pipe (step3d_t_tile)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -219,7 +219,7 @@ def main():
             "kernel_ms": per_kernel,
         }
         if not args.no_cpu_baseline and args.gpus == 1:
-            v, w = cpu_baseline(args.config, args.cpu_steps)
+            v, w = cpu_baseline(args.config, args.cpu_steps, args.physics)
             out["cpu_baseline"] = {"value": v, "unit": "simulated-days/s", "cores": 1, "kind": "port",
                                    "sample": f"{args.cpu_steps} full steps of {args.config} on one host core "
                                              f"({w:.1f} s), oracle/ C restatement, gcc -O2"}

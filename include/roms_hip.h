@@ -190,6 +190,8 @@ int roms_hip_step3d_t(const roms_step_idx_t *s);
 int roms_hip_bulk_flux(const roms_step_idx_t *s);
 /* set_vbc(ng,tile)                 ROMS/Nonlinear/set_vbc.F:34       */
 int roms_hip_set_vbc(const roms_step_idx_t *s);
+/* lmd_vmix(ng,tile) = lmd_vmix_tile + lmd_skpp + lmd_finish   ROMS/Nonlinear/lmd_vmix.F:37 */
+int roms_hip_lmd_vmix(const roms_step_idx_t *s);
 
 /* The whole barotropic loop LOOP_2D of main3d.F:592-700 in one call
  * (predictor/corrector sequencing done inside, optionally replayed from a

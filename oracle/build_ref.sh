@@ -32,7 +32,8 @@ FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iouni
  Utility/round Utility/dateclock Nonlinear/exchange_2d Nonlinear/exchange_3d Utility/get_bounds
  Utility/set_weights Utility/mp_routines Utility/timers Nonlinear/prsgrd Nonlinear/t3dmix Nonlinear/uv3dmix Nonlinear/set_depth
   Nonlinear/set_massflux Nonlinear/rho_eos Nonlinear/set_zeta Nonlinear/mpdata_adiff
- Nonlinear/bc_2d Nonlinear/set_vbc Nonlinear/bulk_flux"
+ Nonlinear/bc_2d Nonlinear/set_vbc Nonlinear/bulk_flux
+ Nonlinear/bc_3d Utility/shapiro Nonlinear/lmd_swfrac Nonlinear/lmd_skpp Nonlinear/lmd_vmix"
 
 build_app () {
   local APP=$1 hdr=$(echo $1 | tr A-Z a-z).h

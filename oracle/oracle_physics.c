@@ -260,3 +260,373 @@ int oracle_bulk_flux(OARGS)
   free(Taux_); free(Tauy_); free(LHeat_); free(SHeat_); free(LRad_);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * lmd_vmix = lmd_vmix_tile + lmd_skpp_tile + lmd_finish_tile: Large/McWilliams/Doney K-profile
+ * vertical mixing (ROMS/Nonlinear/lmd_vmix.F:99/465, lmd_skpp.F:98, lmd_swfrac.F:6) with the
+ * BENCHMARK option set: LMD_RIMIX + RI_SPLINES, LMD_CONVEC, LMD_SKPP, LMD_NONLOCAL, SALINITY;
+ * no LMD_DDMIX, LMD_SHAPIRO, LMD_BKPP, masking, WET_DRY.  Uniform Jerlov water type.
+ * --------------------------------------------------------------------------------------------- */
+static double o_swfrac(const roms_params_t *p, double Zscale, double Z)   /* lmd_swfrac.F:60-75 */
+{
+  const double fac1 = Zscale / p->swfrac_mu1, fac2 = Zscale / p->swfrac_mu2, fac3 = p->swfrac_r1;
+  return exp(Z * fac1) * fac3 + exp(Z * fac2) * (1.0 - fac3);
+}
+
+/* turbulent velocity scales wm, ws (lmd_skpp.F:430-455, and twice more below) */
+static void o_wscale(double Ustar, double sigma, double Bf, double *wm, double *ws)
+{
+  const double vonKar = 0.41, small = 1.0E-20, r3 = 1.0 / 3.0;
+  const double lmd_am = 1.257, lmd_as = -28.86, lmd_cm = 8.36, lmd_cs = 98.96, lmd_zetam = -0.2, lmd_zetas = -1.0;
+  const double Ustar3 = Ustar * Ustar * Ustar;
+  const double zetahat = vonKar * sigma * Bf;
+  const double zetapar = zetahat / (Ustar3 + small);
+  if (zetahat >= 0.0) {
+    *wm = vonKar * Ustar / (1.0 + 5.0 * zetapar);
+    *ws = *wm;
+  } else {
+    if (zetapar > lmd_zetam) *wm = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.25);
+    else *wm = vonKar * pow(lmd_am * Ustar3 - lmd_cm * zetahat, r3);
+    if (zetapar > lmd_zetas) *ws = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.5);
+    else *ws = vonKar * pow(lmd_as * Ustar3 - lmd_cs * zetahat, r3);
+  }
+}
+
+int oracle_lmd_vmix(OARGS)
+{
+  ORACLE_PROLOGUE
+  if (o_check_lbc(b, p)) return 8;
+  if (NAT < 2 || !p->salinity) return 8;          /* restated for the SALINITY set-up only */
+  const int nstp = s->nstp, itemp = 1, isalt = 2;
+  const double g = p->g, vonKar = 0.41;
+  /* mod_scalars.F:1552-1629 */
+  const double lmd_Ri0 = 0.7, lmd_bvfcon = -2.0E-5, lmd_nu0c = 0.01, lmd_nu0m = 10.0E-4, lmd_nu0s = 10.0E-4;
+  const double lmd_Cstar = 10.0, lmd_Cv = 1.25, lmd_Ric = 0.3, lmd_betaT = -0.2, lmd_cekman = 0.7, lmd_cmonob = 1.0;
+  const double lmd_cs = 98.96, lmd_epsilon = 0.1;
+  const double lmd_Cg = lmd_Cstar * vonKar * pow(lmd_cs * vonKar * lmd_epsilon, 1.0 / 3.0);   /* :4330 */
+  const double gorho0 = g / p->rho0;                                                          /* :4176 */
+  double *Rig_ = walloc(nis * njs * (N + 1)), *Bflux_ = walloc(nis * njs * (N + 1));
+  double *FC_ = walloc(nis * (N + 1)), *dR_ = walloc(nis * (N + 1)), *dU_ = walloc(nis * (N + 1)), *dV_ = walloc(nis * (N + 1));
+  double *Bo_ = walloc(nis * njs), *Bosol_ = walloc(nis * njs), *Bfsfc_ = walloc(nis * njs), *Ustar_ = walloc(nis * njs);
+  double *sl_dpth_ = walloc(nis * njs), *wm_ = walloc(nis * njs), *ws_ = walloc(nis * njs), *f1_ = walloc(nis * njs);
+  double *Gm1_ = walloc(nis * njs), *Gt1_ = walloc(nis * njs), *Gs1_ = walloc(nis * njs);
+  double *dGm1dS_ = walloc(nis * njs), *dGt1dS_ = walloc(nis * njs), *dGs1dS_ = walloc(nis * njs);
+  int *ksbl_ = (int *)calloc((size_t)(nis * njs), sizeof(int));
+#define Rig(i,j,k)   Rig_[WS2(i,j) + (long)(k) * nis * njs]
+#define Bflux(i,j,k) Bflux_[WS2(i,j) + (long)(k) * nis * njs]
+#define FC(i,k) FC_[WSK(i,k)]
+#define dR(i,k) dR_[WSK(i,k)]
+#define dU(i,k) dU_[WSK(i,k)]
+#define dV(i,k) dV_[WSK(i,k)]
+#define Bo(i,j) Bo_[WS2(i,j)]
+#define Bosol(i,j) Bosol_[WS2(i,j)]
+#define Bfsfc(i,j) Bfsfc_[WS2(i,j)]
+#define Ustar(i,j) Ustar_[WS2(i,j)]
+#define sl_dpth(i,j) sl_dpth_[WS2(i,j)]
+#define wm(i,j) wm_[WS2(i,j)]
+#define ws(i,j) ws_[WS2(i,j)]
+#define f1(i,j) f1_[WS2(i,j)]
+#define Gm1(i,j) Gm1_[WS2(i,j)]
+#define Gt1(i,j) Gt1_[WS2(i,j)]
+#define Gs1(i,j) Gs1_[WS2(i,j)]
+#define dGm1dS(i,j) dGm1dS_[WS2(i,j)]
+#define dGt1dS(i,j) dGt1dS_[WS2(i,j)]
+#define dGs1dS(i,j) dGs1dS_[WS2(i,j)]
+#define ksbl(i,j) ksbl_[WS2(i,j)]
+#define hsbl(i,j) F->hsbl[I2(i,j)]
+#define sustr(i,j) F->sustr[I2(i,j)]
+#define svstr(i,j) F->svstr[I2(i,j)]
+#define bustr(i,j) F->bustr[I2(i,j)]
+#define bvstr(i,j) F->bvstr[I2(i,j)]
+
+  /* ================= lmd_vmix_tile, lmd_vmix.F:190-330 ================= */
+  {
+    const double eps = 1.0E-14;
+    for (int j = MAX(1, Jstr - 1); j <= MIN(Jend + 1, Mm); j++) {
+      const int ia = MAX(1, Istr - 1), ib = MIN(Iend + 1, Lm);
+      for (int i = ia; i <= ib; i++) { FC(i, 0) = 0.0; dR(i, 0) = 0.0; dU(i, 0) = 0.0; dV(i, 0) = 0.0; }
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = ia; i <= ib; i++) {
+          const double cff = 1.0 / (2.0 * Hz(i, j, k + 1) + Hz(i, j, k) * (2.0 - FC(i, k - 1)));
+          FC(i, k) = cff * Hz(i, j, k + 1);
+          dR(i, k) = cff * (6.0 * (rho(i, j, k + 1) - rho(i, j, k)) - Hz(i, j, k) * dR(i, k - 1));
+          dU(i, k) = cff * (3.0 * (u(i, j, k + 1, nstp) - u(i, j, k, nstp) + u(i + 1, j, k + 1, nstp) - u(i + 1, j, k, nstp)) -
+                            Hz(i, j, k) * dU(i, k - 1));
+          dV(i, k) = cff * (3.0 * (v(i, j, k + 1, nstp) - v(i, j, k, nstp) + v(i, j + 1, k + 1, nstp) - v(i, j + 1, k, nstp)) -
+                            Hz(i, j, k) * dV(i, k - 1));
+        }
+      for (int i = ia; i <= ib; i++) { dR(i, N) = 0.0; dU(i, N) = 0.0; dV(i, N) = 0.0; }
+      for (int k = N - 1; k >= 1; k--)
+        for (int i = ia; i <= ib; i++) {
+          dR(i, k) = dR(i, k) - FC(i, k) * dR(i, k + 1);
+          dU(i, k) = dU(i, k) - FC(i, k) * dU(i, k + 1);
+          dV(i, k) = dV(i, k) - FC(i, k) * dV(i, k + 1);
+        }
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = ia; i <= ib; i++) {
+          const double shear2 = dU(i, k) * dU(i, k) + dV(i, k) * dV(i, k);
+          Rig(i, j, k) = bvf(i, j, k) / (shear2 + eps);
+        }
+    }
+    for (int k = 1; k <= N - 1; k++)
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend; i++) {
+          double cff = MIN(1.0, MAX(0.0, Rig(i, j, k)) / lmd_Ri0);
+          double nu_sx = 1.0 - cff * cff;
+          nu_sx = nu_sx * nu_sx * nu_sx;
+          const double shear2 = bvf(i, j, k) / (Rig(i, j, k) + eps);
+          cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
+          nu_sx = cff * nu_sx;
+          cff = 1.0 / sqrt(MAX(bvf(i, j, k), 1.0E-7));
+          const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
+          Akv(i, j, k) = lmd_iwm + lmd_nu0m * nu_sx;
+          Akt(i, j, k, itemp) = lmd_iws + lmd_nu0s * nu_sx;
+          Akt(i, j, k, isalt) = Akt(i, j, k, itemp);
+        }
+  }
+
+  /* ================= lmd_skpp_tile, lmd_skpp.F:300-930 ================= */
+  {
+    const double eps = 1.0E-10;
+    const double Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) sl_dpth(i, j) = lmd_epsilon * (z_w(i, j, N) - hsbl(i, j));
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        const double a1 = 0.5 * (sustr(i, j) + sustr(i + 1, j)), a2 = 0.5 * (svstr(i, j) + svstr(i, j + 1));
+        Ustar(i, j) = sqrt(sqrt(a1 * a1 + a2 * a2));
+      }
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        Bo(i, j) = g * (alpha(i, j) * (stflx(i, j, itemp) - srflx(i, j)) - beta(i, j) * stflx(i, j, isalt));
+        Bosol(i, j) = g * alpha(i, j) * srflx(i, j);
+      }
+    for (int k = 0; k <= N; k++)
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend; i++) {
+          const double swdk = o_swfrac(p, -1.0, z_w(i, j, N) - z_w(i, j, k));
+          Bflux(i, j, k) = (Bo(i, j) + Bosol(i, j) * (1.0 - swdk));
+          const double cff = 1.0 - (0.5 + copysign(0.5, Bflux(i, j, k)));
+          ghats(i, j, k, itemp) = -cff * (stflx(i, j, itemp) - srflx(i, j) + srflx(i, j) * (1.0 - swdk));
+          ghats(i, j, k, isalt) = cff * stflx(i, j, isalt);
+        }
+    for (int j = Jstr; j <= Jend; j++) {
+      for (int i = Istr; i <= Iend; i++) { FC(i, 0) = 0.0; dR(i, 0) = 0.0; dU(i, 0) = 0.0; dV(i, 0) = 0.0; }
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          const double cff = 1.0 / (2.0 * Hz(i, j, k + 1) + Hz(i, j, k) * (2.0 - FC(i, k - 1)));
+          FC(i, k) = cff * Hz(i, j, k + 1);
+          dR(i, k) = cff * (6.0 * (pden(i, j, k + 1) - pden(i, j, k)) - Hz(i, j, k) * dR(i, k - 1));
+          dU(i, k) = cff * (3.0 * (u(i, j, k + 1, nstp) - u(i, j, k, nstp) + u(i + 1, j, k + 1, nstp) - u(i + 1, j, k, nstp)) -
+                            Hz(i, j, k) * dU(i, k - 1));
+          dV(i, k) = cff * (3.0 * (v(i, j, k + 1, nstp) - v(i, j, k, nstp) + v(i, j + 1, k + 1, nstp) - v(i, j + 1, k, nstp)) -
+                            Hz(i, j, k) * dV(i, k - 1));
+        }
+      for (int i = Istr; i <= Iend; i++) { dR(i, N) = 0.0; dU(i, N) = 0.0; dV(i, N) = 0.0; }
+      for (int k = N - 1; k >= 1; k--)
+        for (int i = Istr; i <= Iend; i++) {
+          dR(i, k) = dR(i, k) - FC(i, k) * dR(i, k + 1);
+          dU(i, k) = dU(i, k) - FC(i, k) * dU(i, k + 1);
+          dV(i, k) = dV(i, k) - FC(i, k) * dV(i, k + 1);
+        }
+      const double cff1 = 1.0 / 3.0, cff2 = 1.0 / 6.0;
+      for (int i = Istr; i <= Iend; i++) {
+        const double Rref = pden(i, j, N) + Hz(i, j, N) * (cff1 * dR(i, N) + cff2 * dR(i, N - 1));
+        const double Uref = 0.5 * (u(i, j, N, nstp) + u(i + 1, j, N, nstp)) + Hz(i, j, N) * (cff1 * dU(i, N) + cff2 * dU(i, N - 1));
+        const double Vref = 0.5 * (v(i, j, N, nstp) + v(i, j + 1, N, nstp)) + Hz(i, j, N) * (cff1 * dV(i, N) + cff2 * dV(i, N - 1));
+        FC(i, N) = 0.0;
+        for (int k = N; k >= 1; k--) {
+          const double depth = z_w(i, j, N) - z_w(i, j, k - 1);
+          double sigma;
+          if (Bflux(i, j, k - 1) < 0.0) sigma = MIN(sl_dpth(i, j), depth);
+          else sigma = depth;
+          double wmk, wsk;
+          o_wscale(Ustar(i, j), sigma, Bflux(i, j, k - 1), &wmk, &wsk);
+          wm(i, j) = wmk; ws(i, j) = wsk;
+          const double Rk = pden(i, j, k) - Hz(i, j, k) * (cff1 * dR(i, k - 1) + cff2 * dR(i, k));
+          const double Uk = 0.5 * (u(i, j, k, nstp) + u(i + 1, j, k, nstp)) - Hz(i, j, k) * (cff1 * dU(i, k - 1) + cff2 * dU(i, k));
+          const double Vk = 0.5 * (v(i, j, k, nstp) + v(i, j + 1, k, nstp)) - Hz(i, j, k) * (cff1 * dV(i, k - 1) + cff2 * dV(i, k));
+          const double Ritop = -gorho0 * (Rref - Rk) * depth;
+          const double Ribot = (Uref - Uk) * (Uref - Uk) + (Vref - Vk) * (Vref - Vk) +
+                               Vtc * depth * wsk * sqrt(fabs(bvf(i, j, k - 1)));
+          FC(i, k - 1) = Ritop - lmd_Ric * Ribot;
+        }
+      }
+      for (int i = Istr; i <= Iend; i++) { ksbl(i, j) = 1; hsbl(i, j) = z_w(i, j, 1); }
+      for (int k = N; k >= 2; k--)
+        for (int i = Istr; i <= Iend; i++)
+          if ((ksbl(i, j) == 1) && (FC(i, k - 1) > 0.0)) {
+            hsbl(i, j) = (z_w(i, j, k) * FC(i, k - 1) - z_w(i, j, k - 1) * FC(i, k)) / (FC(i, k - 1) - FC(i, k));
+            ksbl(i, j) = k;
+          }
+    }
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        const double swdk = o_swfrac(p, -1.0, z_w(i, j, N) - hsbl(i, j));
+        Bfsfc(i, j) = (Bo(i, j) + Bosol(i, j) * (1.0 - swdk));
+      }
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        if ((Ustar(i, j) > 0.0) && (Bfsfc(i, j) > 0.0)) {
+          const double hekman = lmd_cekman * Ustar(i, j) / MAX(fabs(f(i, j)), eps);
+          const double hmonob = lmd_cmonob * Ustar(i, j) * Ustar(i, j) * Ustar(i, j) / MAX(vonKar * Bfsfc(i, j), eps);
+          hsbl(i, j) = (z_w(i, j, N) - MIN(MIN(hekman, hmonob), z_w(i, j, N) - hsbl(i, j)));
+        }
+        hsbl(i, j) = MIN(hsbl(i, j), z_w(i, j, N));
+        hsbl(i, j) = MAX(hsbl(i, j), z_w(i, j, 0));
+      }
+    /* bc_r2d_tile (closed walls: zero gradient) + periodic / tile exchange, :640-652 */
+    if (south_edge) for (int i = Istr; i <= Iend; i++) hsbl(i, Jstr - 1) = hsbl(i, Jstr);
+    if (north_edge) for (int i = Istr; i <= Iend; i++) hsbl(i, Jend + 1) = hsbl(i, Jend);
+    o_exchange2d(b, GT_R, F->hsbl);
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        ksbl(i, j) = 1;
+        for (int k = N; k >= 2; k--)
+          if ((ksbl(i, j) == 1) && (z_w(i, j, k - 1) < hsbl(i, j))) ksbl(i, j) = k;
+      }
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        const double swdk = o_swfrac(p, -1.0, z_w(i, j, N) - hsbl(i, j));
+        Bfsfc(i, j) = (Bo(i, j) + Bosol(i, j) * (1.0 - swdk));
+      }
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        sl_dpth(i, j) = lmd_epsilon * (z_w(i, j, N) - hsbl(i, j));
+        const double cff = (Bfsfc(i, j) > 0.0) ? 1.0 : lmd_epsilon;
+        const double sigma = cff * (z_w(i, j, N) - hsbl(i, j));
+        double wmk, wsk;
+        o_wscale(Ustar(i, j), sigma, Bfsfc(i, j), &wmk, &wsk);
+        wm(i, j) = wmk; ws(i, j) = wsk;
+      }
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++)
+        f1(i, j) = 5.0 * MAX(0.0, Bfsfc(i, j)) * vonKar / (Ustar(i, j) * Ustar(i, j) * Ustar(i, j) * Ustar(i, j) + eps);
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        const double zbl = z_w(i, j, N) - hsbl(i, j);
+        if (hsbl(i, j) > z_w(i, j, 1)) {
+          const int k = ksbl(i, j);
+          const double cff = 1.0 / (z_w(i, j, k) - z_w(i, j, k - 1));
+          const double cff_dn = cff * (hsbl(i, j) - z_w(i, j, k - 1));
+          const double cff_up = cff * (z_w(i, j, k) - hsbl(i, j));
+          double K_bl = cff_dn * Akv(i, j, k) + cff_up * Akv(i, j, k - 1);
+          double dK_bl = cff * (Akv(i, j, k) - Akv(i, j, k - 1));
+          Gm1(i, j) = K_bl / (zbl * wm(i, j) + eps);
+          dGm1dS(i, j) = MIN(0.0, -dK_bl / (wm(i, j) + eps) - K_bl * f1(i, j));
+          K_bl = cff_dn * Akt(i, j, k, itemp) + cff_up * Akt(i, j, k - 1, itemp);
+          dK_bl = cff * (Akt(i, j, k, itemp) - Akt(i, j, k - 1, itemp));
+          Gt1(i, j) = K_bl / (zbl * ws(i, j) + eps);
+          dGt1dS(i, j) = MIN(0.0, -dK_bl / (ws(i, j) + eps) - K_bl * f1(i, j));
+          K_bl = cff_dn * Akt(i, j, k, isalt) + cff_up * Akt(i, j, k - 1, isalt);
+          dK_bl = cff * (Akt(i, j, k, isalt) - Akt(i, j, k - 1, isalt));
+          Gs1(i, j) = K_bl / (zbl * ws(i, j) + eps);
+          dGs1dS(i, j) = MIN(0.0, -dK_bl / (ws(i, j) + eps) - K_bl * f1(i, j));
+        } else {
+          ksbl(i, j) = 0;
+          const double b1 = 0.5 * (bustr(i, j) + bustr(i + 1, j)), b2 = 0.5 * (bvstr(i, j) + bvstr(i, j + 1));
+          const double Ustarb = sqrt(sqrt(b1 * b1 + b2 * b2));
+          const double dK_bl = vonKar * Ustarb;
+          const double K_bl = dK_bl * (hsbl(i, j) - z_w(i, j, 0));
+          Gm1(i, j) = K_bl / (zbl * wm(i, j) + eps);
+          dGm1dS(i, j) = MIN(0.0, -dK_bl / (wm(i, j) + eps) - K_bl * f1(i, j));
+          Gt1(i, j) = K_bl / (zbl * ws(i, j) + eps);
+          dGt1dS(i, j) = MIN(0.0, -dK_bl / (ws(i, j) + eps) - K_bl * f1(i, j));
+          Gs1(i, j) = Gt1(i, j);
+          dGs1dS(i, j) = dGt1dS(i, j);
+        }
+      }
+    for (int k = 1; k <= N - 1; k++)
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend; i++) {
+          const double zbl = z_w(i, j, N) - hsbl(i, j);
+          if (k > ksbl(i, j)) {
+            const double depth = z_w(i, j, N) - z_w(i, j, k);
+            double sigma;
+            if (Bflux(i, j, k) < 0.0) sigma = MIN(sl_dpth(i, j), depth);
+            else sigma = depth;
+            double wmk, wsk;
+            o_wscale(Ustar(i, j), sigma, Bflux(i, j, k), &wmk, &wsk);
+            wm(i, j) = wmk; ws(i, j) = wsk;
+            sigma = depth / (zbl + eps);
+            const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
+            const double Gm = a1 + a2 * Gm1(i, j) + a3 * dGm1dS(i, j);
+            const double Gt = a1 + a2 * Gt1(i, j) + a3 * dGt1dS(i, j);
+            const double Gs = a1 + a2 * Gs1(i, j) + a3 * dGs1dS(i, j);
+            Akv(i, j, k) = depth * wmk * (1.0 + sigma * Gm);
+            Akt(i, j, k, itemp) = depth * wsk * (1.0 + sigma * Gt);
+            Akt(i, j, k, isalt) = depth * wsk * (1.0 + sigma * Gs);
+            const double cff = lmd_Cg * (1.0 - (0.5 + copysign(0.5, Bflux(i, j, k)))) / (zbl * wsk + eps);
+            ghats(i, j, k, itemp) = cff * ghats(i, j, k, itemp);
+            ghats(i, j, k, isalt) = cff * ghats(i, j, k, isalt);
+          } else {
+            ghats(i, j, k, itemp) = 0.0;
+            ghats(i, j, k, isalt) = 0.0;
+          }
+        }
+  }
+
+  /* ================= lmd_finish_tile, lmd_vmix.F:520-700 ================= */
+  for (int k = 1; k <= N - 1; k++)
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        double cff = MAX(bvf(i, j, k), lmd_bvfcon);
+        cff = MIN(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
+        double nu_sxc = 1.0 - cff * cff;
+        nu_sxc = nu_sxc * nu_sxc * nu_sxc;
+        Akv(i, j, k) = Akv(i, j, k) + lmd_nu0c * nu_sxc;
+        Akt(i, j, k, itemp) = Akt(i, j, k, itemp) + lmd_nu0c * nu_sxc;
+        Akt(i, j, k, isalt) = Akt(i, j, k, isalt) + lmd_nu0c * nu_sxc;
+      }
+  /* boundary values exactly as written there, :620-700 (note Iend-1 on the eastern edge and that
+   * the edge copies are not guarded by periodicity; the periodic exchange afterwards restores the
+   * ghost columns but the copy INTO column Iend-1 stays) */
+  for (int k = 0; k <= N; k++) {
+    if (west_edge)
+      for (int j = Jstr; j <= Jend; j++) {
+        for (int itrc = 1; itrc <= NAT; itrc++) Akt(Istr - 1, j, k, itrc) = Akt(Istr, j, k, itrc);
+        Akv(Istr - 1, j, k) = Akv(Istr, j, k);
+      }
+    if (east_edge)
+      for (int j = Jstr; j <= Jend; j++) {
+        for (int itrc = 1; itrc <= NAT; itrc++) Akt(Iend - 1, j, k, itrc) = Akt(Iend, j, k, itrc);
+        Akv(Iend - 1, j, k) = Akv(Iend, j, k);
+      }
+    if (south_edge)
+      for (int i = Istr; i <= Iend; i++) {
+        for (int itrc = 1; itrc <= NAT; itrc++) Akt(i, Jstr - 1, k, itrc) = Akt(i, Jstr, k, itrc);
+        Akv(i, Jstr - 1, k) = Akv(i, Jstr, k);
+      }
+    if (north_edge)
+      for (int i = Istr; i <= Iend; i++) {
+        for (int itrc = 1; itrc <= NAT; itrc++) Akt(i, Jend + 1, k, itrc) = Akt(i, Jend, k, itrc);
+        Akv(i, Jend + 1, k) = Akv(i, Jend, k);
+      }
+    if (south_edge && west_edge) {
+      for (int itrc = 1; itrc <= NAT; itrc++)
+        Akt(Istr - 1, Jstr - 1, k, itrc) = 0.5 * (Akt(Istr, Jstr - 1, k, itrc) + Akt(Istr - 1, Jstr, k, itrc));
+      Akv(Istr - 1, Jstr - 1, k) = 0.5 * (Akv(Istr, Jstr - 1, k) + Akv(Istr - 1, Jstr, k));
+    }
+    if (south_edge && east_edge) {
+      for (int itrc = 1; itrc <= NAT; itrc++)
+        Akt(Iend + 1, Jstr - 1, k, itrc) = 0.5 * (Akt(Iend, Jstr - 1, k, itrc) + Akt(Iend + 1, Jstr, k, itrc));
+      Akv(Iend + 1, Jstr - 1, k) = 0.5 * (Akv(Iend, Jstr - 1, k) + Akv(Iend + 1, Jstr, k));
+    }
+    if (north_edge && west_edge) {
+      for (int itrc = 1; itrc <= NAT; itrc++)
+        Akt(Istr - 1, Jend + 1, k, itrc) = 0.5 * (Akt(Istr, Jend + 1, k, itrc) + Akt(Istr - 1, Jend, k, itrc));
+      Akv(Istr - 1, Jend + 1, k) = 0.5 * (Akv(Istr, Jend + 1, k) + Akv(Istr - 1, Jend, k));
+    }
+    if (north_edge && east_edge) {
+      for (int itrc = 1; itrc <= NAT; itrc++)
+        Akt(Iend + 1, Jend + 1, k, itrc) = 0.5 * (Akt(Iend, Jend + 1, k, itrc) + Akt(Iend + 1, Jend, k, itrc));
+      Akv(Iend + 1, Jend + 1, k) = 0.5 * (Akv(Iend, Jend + 1, k) + Akv(Iend + 1, Jend, k));
+    }
+  }
+  o_bc_w3d(b, F->Akv);
+  for (int itrc = 1; itrc <= NAT; itrc++) o_bc_w3d(b, &Akt(LBi, LBj, 0, itrc));
+  free(Rig_); free(Bflux_); free(FC_); free(dR_); free(dU_); free(dV_); free(Bo_); free(Bosol_); free(Bfsfc_);
+  free(Ustar_); free(sl_dpth_); free(wm_); free(ws_); free(f1_); free(Gm1_); free(Gt1_); free(Gs1_);
+  free(dGm1dS_); free(dGt1dS_); free(dGs1dS_); free(ksbl_);
+  return 0;
+}

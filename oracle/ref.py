@@ -76,7 +76,7 @@ class Ref:
 
     def physics(self, kernel, s):
         """set_vbc / bulk_flux through the reference's own module procedures."""
-        kid = {"set_vbc": 1, "bulk_flux": 2}[kernel]
+        kid = {"set_vbc": 1, "bulk_flux": 2, "lmd_vmix": 3}[kernel]
         self.l.ref_physics.argtypes = [C.c_int, C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.StepIdx),
                                        C.POINTER(abi.Fields)]
         rc = self.l.ref_physics(kid, C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))

@@ -364,6 +364,7 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   USE set_vbc_mod,   ONLY : set_vbc
 #ifdef BENCHMARK
   USE bulk_flux_mod, ONLY : bulk_flux
+  USE lmd_vmix_mod,  ONLY : lmd_vmix
 #endif
   INTEGER(c_int), VALUE :: kernel
   TYPE(bounds_t), INTENT(in) :: b
@@ -387,6 +388,11 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   gamma2(ng) = p%gamma2
   !  generic LBC indices (mod_ncparam.F:1229-1232) and the closed S/N walls of the supported set-up
   isBu2d = isUbar; isBv2d = isVbar
+  isBr2d = isFsur; isBw3d = 6                      ! 6 = isTvar(1) (mod_ncparam.F:1196-1203)
+  LBC(isouth, isBr2d, ng)%closed = p%lbc_south == 1
+  LBC(inorth, isBr2d, ng)%closed = p%lbc_north == 1
+  LBC(isouth, isBw3d, ng)%closed = p%lbc_south == 1
+  LBC(inorth, isBw3d, ng)%closed = p%lbc_north == 1
   LBC(isouth, isBu2d, ng)%closed = p%lbc_south == 1
   LBC(inorth, isBu2d, ng)%closed = p%lbc_north == 1
   LBC(isouth, isBv2d, ng)%closed = p%lbc_south == 1
@@ -427,11 +433,22 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   CALL c_f_pointer (F%lrflx, a2, (/ni,nj/));    FORCES(ng)%lrflx = a2
   CALL c_f_pointer (F%lhflx, a2, (/ni,nj/));    FORCES(ng)%lhflx = a2
   CALL c_f_pointer (F%shflx, a2, (/ni,nj/));    FORCES(ng)%shflx = a2
+  !  lmd_vmix (LMD_MIXING + LMD_SKPP): uniform Jerlov water type WTYPE = 1 (roms_benchmark*.in:392)
+  MIXING(ng)%Jwtype = 1.0_r8
+  iic(ng) = s%iic; ntstart(ng) = s%ntfirst
+  CALL c_f_pointer (F%f, a2, (/ni,nj/));        GRID(ng)%f = a2
+  CALL c_f_pointer (F%pden, a3, (/ni,nj,NN/));  OCEAN(ng)%pden = a3
+  CALL c_f_pointer (F%bvf, a3, (/ni,nj,NN+1/)); MIXING(ng)%bvf = a3
+  CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); MIXING(ng)%Akv = a3
+  CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/));   MIXING(ng)%Akt = a4
+  CALL c_f_pointer (F%ghats, a4, (/ni,nj,NN+1,INT(b%NAT)/)); MIXING(ng)%ghats = a4
+  CALL c_f_pointer (F%hsbl, a2, (/ni,nj/));     MIXING(ng)%hsbl = a2
 #endif
   SELECT CASE (kernel)
   CASE (1); CALL set_vbc (ng, tile)
 #ifdef BENCHMARK
   CASE (2); CALL bulk_flux (ng, tile)
+  CASE (3); CALL lmd_vmix (ng, tile)
 #endif
   CASE DEFAULT; rc = 2
   END SELECT
@@ -446,6 +463,10 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   CALL c_f_pointer (F%lrflx, a2, (/ni,nj/));    a2 = FORCES(ng)%lrflx
   CALL c_f_pointer (F%lhflx, a2, (/ni,nj/));    a2 = FORCES(ng)%lhflx
   CALL c_f_pointer (F%shflx, a2, (/ni,nj/));    a2 = FORCES(ng)%shflx
+  CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akv
+  CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/));   a4 = MIXING(ng)%Akt
+  CALL c_f_pointer (F%ghats, a4, (/ni,nj,NN+1,INT(b%NAT)/)); a4 = MIXING(ng)%ghats
+  CALL c_f_pointer (F%hsbl, a2, (/ni,nj/));     a2 = MIXING(ng)%hsbl
 #endif
 END FUNCTION ref_physics
 

@@ -284,3 +284,337 @@ extern "C" int roms_hip_bulk_flux(const roms_step_idx_t *s)
   halo_exchange2d(GT_V, g_ctx.dev[FID_svstr]);
   return halo_batch_end();
 }
+
+// =================================================================================================
+// lmd_vmix = lmd_vmix_tile + lmd_skpp_tile + lmd_finish_tile (ROMS/Nonlinear/lmd_vmix.F:99/465,
+// lmd_skpp.F:98, lmd_swfrac.F:6): K-profile vertical mixing with the BENCHMARK option set (LMD_RIMIX
+// + RI_SPLINES, LMD_CONVEC, LMD_SKPP, LMD_NONLOCAL, SALINITY; uniform Jerlov water type).
+// Column-local: one thread per (i,j).  The spline work arrays of a column (FC, dU, dV, dR) and the
+// buoyancy-flux profile live in the 3-D device scratch ([level][i,j], coalesced), everything else in
+// registers; the boundary-layer depth search runs on the fly while the bulk Richardson function is
+// evaluated downward, so its profile is never stored.
+// =================================================================================================
+namespace {
+
+__device__ __forceinline__ double swfrac(const roms_params_t &p, double Z)     // lmd_swfrac.F:60-75, Zscale = -1
+{
+  const double fac1 = -1.0 / p.swfrac_mu1, fac2 = -1.0 / p.swfrac_mu2, fac3 = p.swfrac_r1;
+  return exp(Z * fac1) * fac3 + exp(Z * fac2) * (1.0 - fac3);
+}
+
+__device__ __forceinline__ void wscale(double Ustar, double sigma, double Bf, double &wm, double &ws)
+{
+  const double vonKar = 0.41, small = 1.0E-20, r3 = 1.0 / 3.0;
+  const double lmd_am = 1.257, lmd_as = -28.86, lmd_cm = 8.36, lmd_cs = 98.96, lmd_zetam = -0.2, lmd_zetas = -1.0;
+  const double Ustar3 = Ustar * Ustar * Ustar;
+  const double zetahat = vonKar * sigma * Bf;
+  const double zetapar = zetahat / (Ustar3 + small);
+  if (zetahat >= 0.0) {
+    wm = vonKar * Ustar / (1.0 + 5.0 * zetapar);
+    ws = wm;
+  } else {
+    if (zetapar > lmd_zetam) wm = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.25);
+    else wm = vonKar * pow(lmd_am * Ustar3 - lmd_cm * zetahat, r3);
+    if (zetapar > lmd_zetas) ws = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.5);
+    else ws = vonKar * pow(lmd_as * Ustar3 - lmd_cs * zetahat, r3);
+  }
+}
+
+struct LmdScratch { double *FC, *dU, *dV, *dR, *Bf; };
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w)
+{
+  DEV_PROLOGUE(c)
+  const roms_params_t &p = c->p;
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.Jend) return;
+  const long a = I2(i, j);
+  const double g = p.g, vonKar = 0.41;
+  const double lmd_Ri0 = 0.7, lmd_bvfcon = -2.0E-5, lmd_nu0c = 0.01, lmd_nu0m = 10.0E-4, lmd_nu0s = 10.0E-4;
+  const double lmd_Cstar = 10.0, lmd_Cv = 1.25, lmd_Ric = 0.3, lmd_betaT = -0.2, lmd_cekman = 0.7, lmd_cmonob = 1.0;
+  const double lmd_cs = 98.96, lmd_epsilon = 0.1;
+  const double lmd_Cg = lmd_Cstar * vonKar * pow(lmd_cs * vonKar * lmd_epsilon, 1.0 / 3.0);
+  const double gorho0 = g / p.rho0;
+  const gcd_t Hz = (gcd_t)c->F.Hz, rho = (gcd_t)c->F.rho, pden = (gcd_t)c->F.pden, bvf = (gcd_t)c->F.bvf;
+  const gcd_t z_w = (gcd_t)c->F.z_w;
+  const gcd_t u = (gcd_t)(c->F.u + (long)(nstp - 1) * n3r), v = (gcd_t)(c->F.v + (long)(nstp - 1) * n3r);
+  const gd_t Akv = (gd_t)c->F.Akv, AkT = (gd_t)c->F.Akt, AkS = (gd_t)(c->F.Akt + n3w);
+  const gd_t ghT = (gd_t)c->F.ghats, ghS = (gd_t)(c->F.ghats + n3w);
+  const gd_t FC = (gd_t)w.FC, dU = (gd_t)w.dU, dV = (gd_t)w.dV, dR = (gd_t)w.dR, Bfl = (gd_t)w.Bf;
+  auto r3i = [&](int k) { return a + (long)(k - 1) * nij; };     // rho-type level k = 1..N
+  auto w3i = [&](int k) { return a + (long)k * nij; };           // W-type level k = 0..N
+
+  // ---------- lmd_vmix_tile: shear/Richardson-number mixing with spline derivatives (:190-330) ----------
+  {
+    const double eps = 1.0E-14;
+    double FCm = 0.0, dUm = 0.0, dVm = 0.0;
+    FC[w3i(0)] = 0.0; dU[w3i(0)] = 0.0; dV[w3i(0)] = 0.0;
+    for (int k = 1; k <= N - 1; k++) {
+      const double hz = Hz[r3i(k)], hz1 = Hz[r3i(k + 1)];
+      const double cff = 1.0 / (2.0 * hz1 + hz * (2.0 - FCm));
+      const double fck = cff * hz1;
+      const double duk = cff * (3.0 * (u[r3i(k + 1)] - u[r3i(k)] + u[r3i(k + 1) + 1] - u[r3i(k) + 1]) - hz * dUm);
+      const double dvk = cff * (3.0 * (v[r3i(k + 1)] - v[r3i(k)] + v[r3i(k + 1) + ni] - v[r3i(k) + ni]) - hz * dVm);
+      FC[w3i(k)] = fck; dU[w3i(k)] = duk; dV[w3i(k)] = dvk;
+      FCm = fck; dUm = duk; dVm = dvk;
+    }
+    double dUp = 0.0, dVp = 0.0;                               // level N
+    dU[w3i(N)] = 0.0; dV[w3i(N)] = 0.0;
+    for (int k = N - 1; k >= 1; k--) {
+      const double fck = FC[w3i(k)];
+      const double duk = dU[w3i(k)] - fck * dUp, dvk = dV[w3i(k)] - fck * dVp;
+      dU[w3i(k)] = duk; dV[w3i(k)] = dvk;
+      dUp = duk; dVp = dvk;
+      double shear2 = duk * duk + dvk * dvk;
+      const double bv = bvf[w3i(k)];
+      const double Rig = bv / (shear2 + eps);
+      double cff = fmin(1.0, fmax(0.0, Rig) / lmd_Ri0);
+      double nu_sx = 1.0 - cff * cff;
+      nu_sx = nu_sx * nu_sx * nu_sx;
+      shear2 = bv / (Rig + eps);
+      cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
+      nu_sx = cff * nu_sx;
+      cff = 1.0 / sqrt(fmax(bv, 1.0E-7));
+      const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
+      Akv[w3i(k)] = lmd_iwm + lmd_nu0m * nu_sx;
+      const double at = lmd_iws + lmd_nu0s * nu_sx;
+      AkT[w3i(k)] = at;
+      AkS[w3i(k)] = at;
+    }
+  }
+
+  // ---------- lmd_skpp_tile (:300-930) ----------
+  const double eps = 1.0E-10;
+  const double Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);
+  const double zwN = z_w[w3i(N)];
+  double hsbl = c->F.hsbl[a];
+  double sl_dpth = lmd_epsilon * (zwN - hsbl);
+  const double s1 = 0.5 * (c->F.sustr[a] + c->F.sustr[a + 1]), s2 = 0.5 * (c->F.svstr[a] + c->F.svstr[a + ni]);
+  const double Ustar = sqrt(sqrt(s1 * s1 + s2 * s2));
+  const double alpha = c->F.alpha[a], beta = c->F.beta[a], srflx = c->F.srflx[a];
+  const double stT = c->F.stflx[a], stS = c->F.stflx[a + nij];
+  const double Bo = g * (alpha * (stT - srflx) - beta * stS);
+  const double Bosol = g * alpha * srflx;
+  for (int k = 0; k <= N; k++) {
+    const double swdk = swfrac(p, zwN - z_w[w3i(k)]);
+    const double bf = (Bo + Bosol * (1.0 - swdk));
+    Bfl[w3i(k)] = bf;
+    const double cff = 1.0 - (0.5 + copysign(0.5, bf));
+    ghT[w3i(k)] = -cff * (stT - srflx + srflx * (1.0 - swdk));
+    ghS[w3i(k)] = cff * stS;
+  }
+  // spline derivative of pden (FC, dU, dV of the first pass are the same recurrences: reused)
+  {
+    double dRm = 0.0;
+    dR[w3i(0)] = 0.0;
+    for (int k = 1; k <= N - 1; k++) {
+      // cff*Hz(k+1) = FC(k) was stored, but cff itself is needed: recompute it (same expression)
+      const double hz = Hz[r3i(k)], hz1 = Hz[r3i(k + 1)];
+      const double cff = 1.0 / (2.0 * hz1 + hz * (2.0 - FC[w3i(k - 1)]));
+      const double drk = cff * (6.0 * (pden[r3i(k + 1)] - pden[r3i(k)]) - hz * dRm);
+      dR[w3i(k)] = drk;
+      dRm = drk;
+    }
+    double dRp = 0.0;
+    dR[w3i(N)] = 0.0;
+    for (int k = N - 1; k >= 1; k--) {
+      const double drk = dR[w3i(k)] - FC[w3i(k)] * dRp;
+      dR[w3i(k)] = drk;
+      dRp = drk;
+    }
+  }
+  const double cff1 = 1.0 / 3.0, cff2 = 1.0 / 6.0;
+  int ksbl = 1;
+  {
+    const double hzN = Hz[r3i(N)];
+    const double Rref = pden[r3i(N)] + hzN * (cff1 * dR[w3i(N)] + cff2 * dR[w3i(N - 1)]);
+    const double Uref = 0.5 * (u[r3i(N)] + u[r3i(N) + 1]) + hzN * (cff1 * dU[w3i(N)] + cff2 * dU[w3i(N - 1)]);
+    const double Vref = 0.5 * (v[r3i(N)] + v[r3i(N) + ni]) + hzN * (cff1 * dV[w3i(N)] + cff2 * dV[w3i(N - 1)]);
+    double FCk = 0.0;                                            // FC(i,N) = 0
+    hsbl = z_w[w3i(1)];
+    for (int k = N; k >= 1; k--) {
+      const double depth = zwN - z_w[w3i(k - 1)];
+      const double bf = Bfl[w3i(k - 1)];
+      const double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
+      double wmk, wsk;
+      wscale(Ustar, sigma, bf, wmk, wsk);
+      const double hz = Hz[r3i(k)];
+      const double Rk = pden[r3i(k)] - hz * (cff1 * dR[w3i(k - 1)] + cff2 * dR[w3i(k)]);
+      const double Uk = 0.5 * (u[r3i(k)] + u[r3i(k) + 1]) - hz * (cff1 * dU[w3i(k - 1)] + cff2 * dU[w3i(k)]);
+      const double Vk = 0.5 * (v[r3i(k)] + v[r3i(k) + ni]) - hz * (cff1 * dV[w3i(k - 1)] + cff2 * dV[w3i(k)]);
+      const double Ritop = -gorho0 * (Rref - Rk) * depth;
+      const double Ribot = (Uref - Uk) * (Uref - Uk) + (Vref - Vk) * (Vref - Vk) +
+                           Vtc * depth * wsk * sqrt(fabs(bvf[w3i(k - 1)]));
+      const double FCkm1 = Ritop - lmd_Ric * Ribot;
+      // boundary-layer depth: first level (from the top, k = N..2) where the function turns positive
+      if (k >= 2 && ksbl == 1 && FCkm1 > 0.0) {
+        hsbl = (z_w[w3i(k)] * FCkm1 - z_w[w3i(k - 1)] * FCk) / (FCkm1 - FCk);
+        ksbl = k;
+      }
+      FCk = FCkm1;
+    }
+  }
+  double Bfsfc = (Bo + Bosol * (1.0 - swfrac(p, zwN - hsbl)));
+  if ((Ustar > 0.0) && (Bfsfc > 0.0)) {
+    const double hekman = lmd_cekman * Ustar / fmax(fabs(c->F.f[a]), eps);
+    const double hmonob = lmd_cmonob * Ustar * Ustar * Ustar / fmax(vonKar * Bfsfc, eps);
+    hsbl = (zwN - fmin(fmin(hekman, hmonob), zwN - hsbl));
+  }
+  hsbl = fmin(hsbl, zwN);
+  hsbl = fmax(hsbl, z_w[w3i(0)]);
+  c->F.hsbl[a] = hsbl;
+  if (!b.NSperiodic) {                                           // bc_r2d_tile: zero gradient at closed walls
+    if (b.south_edge && j == b.Jstr) c->F.hsbl[a - ni] = hsbl;
+    if (b.north_edge && j == b.Jend) c->F.hsbl[a + ni] = hsbl;
+  }
+  ksbl = 1;
+  for (int k = N; k >= 2; k--)
+    if ((ksbl == 1) && (z_w[w3i(k - 1)] < hsbl)) ksbl = k;
+  Bfsfc = (Bo + Bosol * (1.0 - swfrac(p, zwN - hsbl)));
+  sl_dpth = lmd_epsilon * (zwN - hsbl);
+  double wm, ws;
+  {
+    const double cff = (Bfsfc > 0.0) ? 1.0 : lmd_epsilon;
+    wscale(Ustar, cff * (zwN - hsbl), Bfsfc, wm, ws);
+  }
+  const double f1 = 5.0 * fmax(0.0, Bfsfc) * vonKar / (Ustar * Ustar * Ustar * Ustar + eps);
+  const double zbl = zwN - hsbl;
+  double Gm1, Gt1, Gs1, dGm1dS, dGt1dS, dGs1dS;
+  if (hsbl > z_w[w3i(1)]) {
+    const int k = ksbl;
+    const double cff = 1.0 / (z_w[w3i(k)] - z_w[w3i(k - 1)]);
+    const double cff_dn = cff * (hsbl - z_w[w3i(k - 1)]);
+    const double cff_up = cff * (z_w[w3i(k)] - hsbl);
+    double K_bl = cff_dn * Akv[w3i(k)] + cff_up * Akv[w3i(k - 1)];
+    double dK_bl = cff * (Akv[w3i(k)] - Akv[w3i(k - 1)]);
+    Gm1 = K_bl / (zbl * wm + eps);
+    dGm1dS = fmin(0.0, -dK_bl / (wm + eps) - K_bl * f1);
+    K_bl = cff_dn * AkT[w3i(k)] + cff_up * AkT[w3i(k - 1)];
+    dK_bl = cff * (AkT[w3i(k)] - AkT[w3i(k - 1)]);
+    Gt1 = K_bl / (zbl * ws + eps);
+    dGt1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
+    K_bl = cff_dn * AkS[w3i(k)] + cff_up * AkS[w3i(k - 1)];
+    dK_bl = cff * (AkS[w3i(k)] - AkS[w3i(k - 1)]);
+    Gs1 = K_bl / (zbl * ws + eps);
+    dGs1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
+  } else {
+    ksbl = 0;
+    const double b1 = 0.5 * (c->F.bustr[a] + c->F.bustr[a + 1]), b2 = 0.5 * (c->F.bvstr[a] + c->F.bvstr[a + ni]);
+    const double Ustarb = sqrt(sqrt(b1 * b1 + b2 * b2));
+    const double dK_bl = vonKar * Ustarb;
+    const double K_bl = dK_bl * (hsbl - z_w[w3i(0)]);
+    Gm1 = K_bl / (zbl * wm + eps);
+    dGm1dS = fmin(0.0, -dK_bl / (wm + eps) - K_bl * f1);
+    Gt1 = K_bl / (zbl * ws + eps);
+    dGt1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
+    Gs1 = Gt1;
+    dGs1dS = dGt1dS;
+  }
+  for (int k = 1; k <= N - 1; k++) {
+    double akv = Akv[w3i(k)], akt = AkT[w3i(k)], aks = AkS[w3i(k)];
+    if (k > ksbl) {
+      const double depth = zwN - z_w[w3i(k)];
+      const double bf = Bfl[w3i(k)];
+      double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
+      double wmk, wsk;
+      wscale(Ustar, sigma, bf, wmk, wsk);
+      sigma = depth / (zbl + eps);
+      const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
+      const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
+      const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
+      const double Gs = a1 + a2 * Gs1 + a3 * dGs1dS;
+      akv = depth * wmk * (1.0 + sigma * Gm);
+      akt = depth * wsk * (1.0 + sigma * Gt);
+      aks = depth * wsk * (1.0 + sigma * Gs);
+      const double cff = lmd_Cg * (1.0 - (0.5 + copysign(0.5, bf))) / (zbl * wsk + eps);
+      ghT[w3i(k)] = cff * ghT[w3i(k)];
+      ghS[w3i(k)] = cff * ghS[w3i(k)];
+    } else {
+      ghT[w3i(k)] = 0.0;
+      ghS[w3i(k)] = 0.0;
+    }
+    // lmd_finish_tile: convective mixing where the stratification is unstable (lmd_vmix.F:520-540)
+    double cff = fmax(bvf[w3i(k)], lmd_bvfcon);
+    cff = fmin(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
+    double nu_sxc = 1.0 - cff * cff;
+    nu_sxc = nu_sxc * nu_sxc * nu_sxc;
+    Akv[w3i(k)] = akv + lmd_nu0c * nu_sxc;
+    AkT[w3i(k)] = akt + lmd_nu0c * nu_sxc;
+    AkS[w3i(k)] = aks + lmd_nu0c * nu_sxc;
+  }
+}
+
+// lmd_finish_tile boundary values exactly as written at lmd_vmix.F:545-640: W/E columns (note Iend-1 on
+// the eastern edge, and no periodicity guard), then S/N rows, then the four corners.
+__global__ void k_lmd_edges(const RomsDev *__restrict__ c, int phase)
+{
+  DEV_PROLOGUE(c)
+  const int NAT = b.NAT;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;                                      // 0..N
+  double *Akv = c->F.Akv + (long)k * nij;
+  auto copy = [&](long dst, long src) {
+    for (int it = 0; it < NAT; it++) c->F.Akt[dst + (long)k * nij + (long)it * n3w] = c->F.Akt[src + (long)k * nij + (long)it * n3w];
+    Akv[dst] = Akv[src];
+  };
+  auto corner = [&](long dst, long s1, long s2) {
+    for (int it = 0; it < NAT; it++) {
+      double *A = c->F.Akt + (long)k * nij + (long)it * n3w;
+      A[dst] = 0.5 * (A[s1] + A[s2]);
+    }
+    Akv[dst] = 0.5 * (Akv[s1] + Akv[s2]);
+  };
+  if (phase == 0) {
+    const int j = b.Jstr + q;
+    if (j > b.Jend) return;
+    if (b.west_edge) copy(I2(b.Istr - 1, j), I2(b.Istr, j));
+    if (b.east_edge) copy(I2(b.Iend - 1, j), I2(b.Iend, j));
+  } else if (phase == 1) {
+    const int i = b.Istr + q;
+    if (i > b.Iend) return;
+    if (b.south_edge) copy(I2(i, b.Jstr - 1), I2(i, b.Jstr));
+    if (b.north_edge) copy(I2(i, b.Jend + 1), I2(i, b.Jend));
+  } else if (q == 0) {
+    if (b.south_edge && b.west_edge) corner(I2(b.Istr - 1, b.Jstr - 1), I2(b.Istr, b.Jstr - 1), I2(b.Istr - 1, b.Jstr));
+    if (b.south_edge && b.east_edge) corner(I2(b.Iend + 1, b.Jstr - 1), I2(b.Iend, b.Jstr - 1), I2(b.Iend + 1, b.Jstr));
+    if (b.north_edge && b.west_edge) corner(I2(b.Istr - 1, b.Jend + 1), I2(b.Istr, b.Jend + 1), I2(b.Istr - 1, b.Jend));
+    if (b.north_edge && b.east_edge) corner(I2(b.Iend + 1, b.Jend + 1), I2(b.Iend, b.Jend + 1), I2(b.Iend + 1, b.Jend));
+  }
+}
+
+}  // namespace
+
+extern "C" int roms_hip_lmd_vmix(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_lmd_vmix");
+  if (rc) return rc;
+  if ((rc = check_lbc())) return rc;
+  const roms_bounds_t &b = g_ctx.b;
+  if (b.NAT < 2 || !g_ctx.p.salinity) return roms_fail("roms_hip_lmd_vmix", "built for the SALINITY set-up (NAT = 2)");
+  const long nij = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1);
+  const long n3w = nij * (b.N + 1);
+  {
+    ScopedTimer tm("lmd_vmix");
+    LmdScratch w{g_ctx.hostc.ws3[1], g_ctx.hostc.ws3[2], g_ctx.hostc.ws3[3], g_ctx.hostc.ws3[4], g_ctx.hostc.ws3[5]};
+    hipLaunchKernelGGL(k_lmd_vmix, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc,
+                       s->nstp, w);
+    KERNEL_CHECK("k_lmd_vmix");
+    const int nj = b.Jend - b.Jstr + 1, ni_ = b.Iend - b.Istr + 1;
+    if (b.west_edge || b.east_edge)
+      hipLaunchKernelGGL(k_lmd_edges, dim3((nj + 63) / 64, b.N + 1), dim3(64), 0, g_ctx.stream, g_ctx.devc, 0);
+    if (b.south_edge || b.north_edge)
+      hipLaunchKernelGGL(k_lmd_edges, dim3((ni_ + 63) / 64, b.N + 1), dim3(64), 0, g_ctx.stream, g_ctx.devc, 1);
+    if ((b.south_edge || b.north_edge) && (b.west_edge || b.east_edge))
+      hipLaunchKernelGGL(k_lmd_edges, dim3(1, b.N + 1), dim3(64), 0, g_ctx.stream, g_ctx.devc, 2);
+    KERNEL_CHECK("k_lmd_edges");
+  }
+  // bc_r2d_tile(hsbl) exchange; bc_w3d_tile(Akv), bc_w3d_tile(Akt(:,:,:,itrc)): wall rows + exchange
+  if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_hsbl]))) return rc;
+  if ((rc = bc_w3d(g_ctx.dev[FID_Akv]))) return rc;
+  for (int it = 0; it < b.NAT; it++)
+    if ((rc = bc_w3d(g_ctx.dev[FID_Akt] + (long)it * n3w))) return rc;
+  return 0;
+}

@@ -152,6 +152,10 @@ MODULE roms_hip_mod
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
     END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_lmd_vmix (s) BIND(C, name='roms_hip_lmd_vmix')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
   END INTERFACE
 
   PUBLIC :: roms_hip_init, roms_hip_finalize, roms_hip_get_unique_id
@@ -160,7 +164,7 @@ MODULE roms_hip_mod
   PUBLIC :: roms_hip_sync_all_to_device, roms_hip_sync_all_to_host, roms_hip_last_error
   PUBLIC :: roms_hip_set_massflux, roms_hip_rho_eos, roms_hip_omega, roms_hip_set_zeta
   PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
-  PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc
+  PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc, roms_hip_lmd_vmix
   PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
 
 CONTAINS

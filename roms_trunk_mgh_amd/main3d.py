@@ -10,7 +10,7 @@ against either backend (`hip.RomsHip` = the product, or the CPU oracle in tests)
     main3d.F:189-191  nstp/nnew/nrhs rotation
     main3d.F:307-309  set_massflux, rho_eos            (diag: not on the path)
     main3d.F:388-394  bulk_flux, set_vbc               (physics=True; else fixed forcing inputs)
-    main3d.F:467-475  lmd_vmix -> fixed mixing inputs; omega
+    main3d.F:467-475  lmd_vmix (physics=True; else fixed mixing inputs); omega
     main3d.F:489      set_zeta
     main3d.F:563      rhs3d
     main3d.F:592-700  LOOP_2D (predictor/corrector step2d)
@@ -26,7 +26,8 @@ from . import abi
 class Main3D:
     def __init__(self, backend, ntstart=1, physics=False):
         """physics=True also runs the per-step physics that is on the device:
-        bulk_flux (BULK_FLUXES applications, i.e. BENCHMARK) and set_vbc, in the reference's order;
+        bulk_flux and lmd_vmix (BULK_FLUXES / LMD_MIXING applications, i.e. BENCHMARK) and set_vbc, in
+        the reference's order;
         with physics=False their outputs stay the fixed fields ana.py filled in."""
         self.be = backend
         self.physics = physics
@@ -60,9 +61,12 @@ class Main3D:
         be.call("set_massflux", s)
         be.call("rho_eos", s)
         if self.physics:
-            if getattr(be.st, "cfg", {}).get("app") == "BENCHMARK":
+            bench_app = getattr(be.st, "cfg", {}).get("app") == "BENCHMARK"
+            if bench_app:                     # BULK_FLUXES
                 be.call("bulk_flux", s)
             be.call("set_vbc", s)
+            if bench_app:                     # LMD_MIXING
+                be.call("lmd_vmix", s)
         be.call("omega", s)
         be.call("set_zeta", s)
         be.call("rhs3d", s)

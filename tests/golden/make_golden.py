@@ -25,7 +25,7 @@ OVERRIDES = {"BENCHMARK_TINY": {"tnu2": 300.0, "visc2": 800.0}, "UPWELLING": {"t
              "SEAMOUNT": {"tnu2": 300.0}}
 KERNELS = ["set_depth", "set_massflux", "set_zeta", "rho_eos", "prsgrd", "t3dmix2", "uv3dmix2"]
 # per-step physics; bulk_flux exists in the BULK_FLUXES application (BENCHMARK) only
-PHYSICS = ["set_vbc", "bulk_flux"]
+PHYSICS = ["set_vbc", "bulk_flux", "lmd_vmix"]
 
 
 def input_state(config):
@@ -67,7 +67,7 @@ def child(config):
     for k in KERNELS + PHYSICS:
         if k == "uv3dmix2" and config == "SEAMOUNT":
             continue
-        if k == "bulk_flux" and not config.startswith("BENCHMARK"):
+        if k in ("bulk_flux", "lmd_vmix") and not config.startswith("BENCHMARK"):
             continue
         st = st0.copy()
         if k in PHYSICS:

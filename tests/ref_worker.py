@@ -85,7 +85,7 @@ def main_physics(config):
     st0 = util.prepared_state(config)
     s = util.step_idx()
     out = {}
-    kernels = ["set_vbc"] + (["bulk_flux"] if config.startswith("BENCHMARK") else [])
+    kernels = ["set_vbc"] + (["bulk_flux", "lmd_vmix"] if config.startswith("BENCHMARK") else [])
     for k in kernels:
         st_r, st_o = st0.copy(), st0.copy()
         for st in (st_r, st_o):                     # so that every output changes
@@ -97,8 +97,9 @@ def main_physics(config):
                 st["btflx"][:, :, 1] = 1.0e-9
         ref.Ref(st_r).physics(k, s)
         oracle.Oracle(st_o).call(k, s)
-        names = ["stflx", "btflx", "bustr", "bvstr"] if k == "set_vbc" else \
-                ["sustr", "svstr", "lrflx", "lhflx", "shflx", "stflux"]
+        names = {"set_vbc": ["stflx", "btflx", "bustr", "bvstr"],
+                 "bulk_flux": ["sustr", "svstr", "lrflx", "lhflx", "shflx", "stflux"],
+                 "lmd_vmix": ["Akv", "Akt", "ghats", "hsbl"]}[k]
         diffs = {n: util.max_rel_diff(st_o[n], st_r[n]) for n in names}
         changed = [n for n in names if not np.array_equal(st_r[n], st0[n])]
         out[k] = {"max_rel_diff": max(diffs.values()), "diffs": diffs, "changed": changed,

@@ -200,3 +200,16 @@ def test_bulk_flux(config):
     assert all(v <= 1e-11 for v in diffs.values()), diffs
     for name in ("sustr", "svstr", "lhflx", "shflx", "lrflx", "stflux"):
         assert util.max_rel_diff(st_o[name], st0[name]) > 1e-6, name
+
+
+def test_lmd_vmix():
+    """KPP vertical mixing (lmd_vmix_tile + lmd_skpp + lmd_finish), BENCHMARK option set.  The device
+    pow/exp differ from the host's in the last bits: tolerance 1e-10 of each field's maximum."""
+    st_h, st_o, st0 = _run_pair("BENCHMARK_TINY", "lmd_vmix", util.step_idx(), prep=_detune_forcing)
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= 1e-10 for v in diffs.values()), diffs
+    for name in ("Akv", "Akt", "ghats", "hsbl"):
+        assert util.max_rel_diff(st_o[name], st0[name]) > 1e-6, name
+    # both regimes of the boundary-layer search must occur in the test state
+    hs = st_o.interior("hsbl")
+    assert float(hs.max()) > float(hs.min())
