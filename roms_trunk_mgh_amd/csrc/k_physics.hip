@@ -7,6 +7,7 @@
 // bulk_flux uses device log/exp/pow/atan: results agree with the host libraries to a few ulp, not
 // bit for bit (the tests state the tolerance).
 #include "roms_dev.h"
+#include <cmath>
 
 int roms_entry_check(const char *name);
 
@@ -289,10 +290,10 @@ extern "C" int roms_hip_bulk_flux(const roms_step_idx_t *s)
 // lmd_vmix = lmd_vmix_tile + lmd_skpp_tile + lmd_finish_tile (ROMS/Nonlinear/lmd_vmix.F:99/465,
 // lmd_skpp.F:98, lmd_swfrac.F:6): K-profile vertical mixing with the BENCHMARK option set (LMD_RIMIX
 // + RI_SPLINES, LMD_CONVEC, LMD_SKPP, LMD_NONLOCAL, SALINITY; uniform Jerlov water type).
-// Column-local: one thread per (i,j).  The spline work arrays of a column (FC, dU, dV, dR) and the
-// buoyancy-flux profile live in the 3-D device scratch ([level][i,j], coalesced), everything else in
-// registers; the boundary-layer depth search runs on the fly while the bulk Richardson function is
-// evaluated downward, so its profile is never stored.
+// Column-local: one thread per (i,j), two sweeps.  Upward: the forward recurrences of the three splines
+// (u, v, pden) go to the 3-D device scratch ([level][i,j], coalesced).  Downward: their back-substitution
+// is fused with the Richardson-number mixing, the bulk Richardson function and the boundary-layer depth
+// search, so no other profile is stored; the buoyancy-flux profile is recomputed (two exp) where used.
 // =================================================================================================
 namespace {
 
@@ -304,7 +305,7 @@ __device__ __forceinline__ double swfrac(const roms_params_t &p, double Z)     /
 
 __device__ __forceinline__ void wscale(double Ustar, double sigma, double Bf, double &wm, double &ws)
 {
-  const double vonKar = 0.41, small = 1.0E-20, r3 = 1.0 / 3.0;
+  const double vonKar = 0.41, small = 1.0E-20;
   const double lmd_am = 1.257, lmd_as = -28.86, lmd_cm = 8.36, lmd_cs = 98.96, lmd_zetam = -0.2, lmd_zetas = -1.0;
   const double Ustar3 = Ustar * Ustar * Ustar;
   const double zetahat = vonKar * sigma * Bf;
@@ -313,17 +314,20 @@ __device__ __forceinline__ void wscale(double Ustar, double sigma, double Bf, do
     wm = vonKar * Ustar / (1.0 + 5.0 * zetapar);
     ws = wm;
   } else {
-    if (zetapar > lmd_zetam) wm = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.25);
-    else wm = vonKar * pow(lmd_am * Ustar3 - lmd_cm * zetahat, r3);
-    if (zetapar > lmd_zetas) ws = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.5);
-    else ws = vonKar * pow(lmd_as * Ustar3 - lmd_cs * zetahat, r3);
+    // x**0.25, x**0.5, x**(1/3) of lmd_skpp.F:441-452 as sqrt(sqrt(x)), sqrt(x), cbrt(x): each within an
+    // ulp of the reference's pow (whose device version is not bit-identical to the host's either) at a
+    // fraction of the cost -- the kernel is bound by these calls, ~4 per level and sweep
+    if (zetapar > lmd_zetam) wm = vonKar * Ustar * sqrt(sqrt(1.0 - 16.0 * zetapar));
+    else wm = vonKar * cbrt(lmd_am * Ustar3 - lmd_cm * zetahat);
+    if (zetapar > lmd_zetas) ws = vonKar * Ustar * sqrt(1.0 - 16.0 * zetapar);
+    else ws = vonKar * cbrt(lmd_as * Ustar3 - lmd_cs * zetahat);
   }
 }
 
 struct LmdScratch { double *FC, *dU, *dV, *dR, *Bf; };
 
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
-k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w)
+k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg, double Vtc)
 {
   DEV_PROLOGUE(c)
   const roms_params_t &p = c->p;
@@ -334,61 +338,35 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w)
   const long a = I2(i, j);
   const double g = p.g, vonKar = 0.41;
   const double lmd_Ri0 = 0.7, lmd_bvfcon = -2.0E-5, lmd_nu0c = 0.01, lmd_nu0m = 10.0E-4, lmd_nu0s = 10.0E-4;
-  const double lmd_Cstar = 10.0, lmd_Cv = 1.25, lmd_Ric = 0.3, lmd_betaT = -0.2, lmd_cekman = 0.7, lmd_cmonob = 1.0;
-  const double lmd_cs = 98.96, lmd_epsilon = 0.1;
-  const double lmd_Cg = lmd_Cstar * vonKar * pow(lmd_cs * vonKar * lmd_epsilon, 1.0 / 3.0);
+  const double lmd_Ric = 0.3, lmd_cekman = 0.7, lmd_cmonob = 1.0, lmd_epsilon = 0.1;
   const double gorho0 = g / p.rho0;
   const gcd_t Hz = (gcd_t)c->F.Hz, rho = (gcd_t)c->F.rho, pden = (gcd_t)c->F.pden, bvf = (gcd_t)c->F.bvf;
   const gcd_t z_w = (gcd_t)c->F.z_w;
   const gcd_t u = (gcd_t)(c->F.u + (long)(nstp - 1) * n3r), v = (gcd_t)(c->F.v + (long)(nstp - 1) * n3r);
   const gd_t Akv = (gd_t)c->F.Akv, AkT = (gd_t)c->F.Akt, AkS = (gd_t)(c->F.Akt + n3w);
   const gd_t ghT = (gd_t)c->F.ghats, ghS = (gd_t)(c->F.ghats + n3w);
-  const gd_t FC = (gd_t)w.FC, dU = (gd_t)w.dU, dV = (gd_t)w.dV, dR = (gd_t)w.dR, Bfl = (gd_t)w.Bf;
+  const gd_t FC = (gd_t)w.FC, dU = (gd_t)w.dU, dV = (gd_t)w.dV, dR = (gd_t)w.dR;
   auto r3i = [&](int k) { return a + (long)(k - 1) * nij; };     // rho-type level k = 1..N
   auto w3i = [&](int k) { return a + (long)k * nij; };           // W-type level k = 0..N
 
-  // ---------- lmd_vmix_tile: shear/Richardson-number mixing with spline derivatives (:190-330) ----------
+  // ---------- one upward sweep: spline recurrences of u, v (lmd_vmix_tile :205-225 = lmd_skpp_tile
+  // :345-365) and of pden; only these forward values go to scratch ----------
   {
-    const double eps = 1.0E-14;
-    double FCm = 0.0, dUm = 0.0, dVm = 0.0;
-    FC[w3i(0)] = 0.0; dU[w3i(0)] = 0.0; dV[w3i(0)] = 0.0;
+    double FCm = 0.0, dUm = 0.0, dVm = 0.0, dRm = 0.0;
     for (int k = 1; k <= N - 1; k++) {
       const double hz = Hz[r3i(k)], hz1 = Hz[r3i(k + 1)];
       const double cff = 1.0 / (2.0 * hz1 + hz * (2.0 - FCm));
       const double fck = cff * hz1;
       const double duk = cff * (3.0 * (u[r3i(k + 1)] - u[r3i(k)] + u[r3i(k + 1) + 1] - u[r3i(k) + 1]) - hz * dUm);
       const double dvk = cff * (3.0 * (v[r3i(k + 1)] - v[r3i(k)] + v[r3i(k + 1) + ni] - v[r3i(k) + ni]) - hz * dVm);
-      FC[w3i(k)] = fck; dU[w3i(k)] = duk; dV[w3i(k)] = dvk;
-      FCm = fck; dUm = duk; dVm = dvk;
-    }
-    double dUp = 0.0, dVp = 0.0;                               // level N
-    dU[w3i(N)] = 0.0; dV[w3i(N)] = 0.0;
-    for (int k = N - 1; k >= 1; k--) {
-      const double fck = FC[w3i(k)];
-      const double duk = dU[w3i(k)] - fck * dUp, dvk = dV[w3i(k)] - fck * dVp;
-      dU[w3i(k)] = duk; dV[w3i(k)] = dvk;
-      dUp = duk; dVp = dvk;
-      double shear2 = duk * duk + dvk * dvk;
-      const double bv = bvf[w3i(k)];
-      const double Rig = bv / (shear2 + eps);
-      double cff = fmin(1.0, fmax(0.0, Rig) / lmd_Ri0);
-      double nu_sx = 1.0 - cff * cff;
-      nu_sx = nu_sx * nu_sx * nu_sx;
-      shear2 = bv / (Rig + eps);
-      cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
-      nu_sx = cff * nu_sx;
-      cff = 1.0 / sqrt(fmax(bv, 1.0E-7));
-      const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
-      Akv[w3i(k)] = lmd_iwm + lmd_nu0m * nu_sx;
-      const double at = lmd_iws + lmd_nu0s * nu_sx;
-      AkT[w3i(k)] = at;
-      AkS[w3i(k)] = at;
+      const double drk = cff * (6.0 * (pden[r3i(k + 1)] - pden[r3i(k)]) - hz * dRm);
+      FC[w3i(k)] = fck; dU[w3i(k)] = duk; dV[w3i(k)] = dvk; dR[w3i(k)] = drk;
+      FCm = fck; dUm = duk; dVm = dvk; dRm = drk;
     }
   }
 
-  // ---------- lmd_skpp_tile (:300-930) ----------
+  // ---------- surface forcing of the boundary layer, lmd_skpp.F:300-340 ----------
   const double eps = 1.0E-10;
-  const double Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);
   const double zwN = z_w[w3i(N)];
   double hsbl = c->F.hsbl[a];
   double sl_dpth = lmd_epsilon * (zwN - hsbl);
@@ -398,53 +376,72 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w)
   const double stT = c->F.stflx[a], stS = c->F.stflx[a + nij];
   const double Bo = g * (alpha * (stT - srflx) - beta * stS);
   const double Bosol = g * alpha * srflx;
-  for (int k = 0; k <= N; k++) {
+  // buoyancy flux and the non-local flux shape at W-level k (:320-338); recomputed where needed
+  // (two exp per call) instead of being stored and re-read
+  auto bflux = [&](int k, double &gT, double &gS) {
     const double swdk = swfrac(p, zwN - z_w[w3i(k)]);
     const double bf = (Bo + Bosol * (1.0 - swdk));
-    Bfl[w3i(k)] = bf;
     const double cff = 1.0 - (0.5 + copysign(0.5, bf));
-    ghT[w3i(k)] = -cff * (stT - srflx + srflx * (1.0 - swdk));
-    ghS[w3i(k)] = cff * stS;
-  }
-  // spline derivative of pden (FC, dU, dV of the first pass are the same recurrences: reused)
-  {
-    double dRm = 0.0;
-    dR[w3i(0)] = 0.0;
-    for (int k = 1; k <= N - 1; k++) {
-      // cff*Hz(k+1) = FC(k) was stored, but cff itself is needed: recompute it (same expression)
-      const double hz = Hz[r3i(k)], hz1 = Hz[r3i(k + 1)];
-      const double cff = 1.0 / (2.0 * hz1 + hz * (2.0 - FC[w3i(k - 1)]));
-      const double drk = cff * (6.0 * (pden[r3i(k + 1)] - pden[r3i(k)]) - hz * dRm);
-      dR[w3i(k)] = drk;
-      dRm = drk;
-    }
-    double dRp = 0.0;
-    dR[w3i(N)] = 0.0;
-    for (int k = N - 1; k >= 1; k--) {
-      const double drk = dR[w3i(k)] - FC[w3i(k)] * dRp;
-      dR[w3i(k)] = drk;
-      dRp = drk;
-    }
-  }
+    gT = -cff * (stT - srflx + srflx * (1.0 - swdk));
+    gS = cff * stS;
+    return bf;
+  };
+  { double gT, gS; bflux(N, gT, gS); ghT[w3i(N)] = gT; ghS[w3i(N)] = gS; }
+
+  // ---------- one downward sweep: back-substitution of the three splines fused with (a) the shear /
+  // Richardson-number mixing of lmd_vmix_tile (:240-300) and (b) the bulk Richardson function and the
+  // boundary-layer depth search of lmd_skpp_tile (:380-470) ----------
   const double cff1 = 1.0 / 3.0, cff2 = 1.0 / 6.0;
   int ksbl = 1;
   {
     const double hzN = Hz[r3i(N)];
-    const double Rref = pden[r3i(N)] + hzN * (cff1 * dR[w3i(N)] + cff2 * dR[w3i(N - 1)]);
-    const double Uref = 0.5 * (u[r3i(N)] + u[r3i(N) + 1]) + hzN * (cff1 * dU[w3i(N)] + cff2 * dU[w3i(N - 1)]);
-    const double Vref = 0.5 * (v[r3i(N)] + v[r3i(N) + ni]) + hzN * (cff1 * dV[w3i(N)] + cff2 * dV[w3i(N - 1)]);
+    const double dRNm1 = dR[w3i(N - 1)], dUNm1 = dU[w3i(N - 1)], dVNm1 = dV[w3i(N - 1)];   // final: x(N) = 0
+    const double Rref = pden[r3i(N)] + hzN * (cff1 * 0.0 + cff2 * dRNm1);
+    const double Uref = 0.5 * (u[r3i(N)] + u[r3i(N) + 1]) + hzN * (cff1 * 0.0 + cff2 * dUNm1);
+    const double Vref = 0.5 * (v[r3i(N)] + v[r3i(N) + ni]) + hzN * (cff1 * 0.0 + cff2 * dVNm1);
+    double dRk = 0.0, dUk = 0.0, dVk = 0.0;                      // final values at level k (k = N: 0)
     double FCk = 0.0;                                            // FC(i,N) = 0
     hsbl = z_w[w3i(1)];
     for (int k = N; k >= 1; k--) {
+      // final spline derivatives at level k-1
+      double dRm = 0.0, dUm = 0.0, dVm = 0.0;
+      if (k - 1 >= 1) {
+        const double fc = FC[w3i(k - 1)];
+        dRm = dR[w3i(k - 1)] - fc * dRk;
+        dUm = dU[w3i(k - 1)] - fc * dUk;
+        dVm = dV[w3i(k - 1)] - fc * dVk;
+      }
+      // (a) interior mixing at W-level k
+      if (k <= N - 1) {
+        const double epsv = 1.0E-14;
+        double shear2 = dUk * dUk + dVk * dVk;
+        const double bv = bvf[w3i(k)];
+        const double Rig = bv / (shear2 + epsv);
+        double cff = fmin(1.0, fmax(0.0, Rig) / lmd_Ri0);
+        double nu_sx = 1.0 - cff * cff;
+        nu_sx = nu_sx * nu_sx * nu_sx;
+        shear2 = bv / (Rig + epsv);
+        cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
+        nu_sx = cff * nu_sx;
+        cff = 1.0 / sqrt(fmax(bv, 1.0E-7));
+        const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
+        Akv[w3i(k)] = lmd_iwm + lmd_nu0m * nu_sx;
+        const double at = lmd_iws + lmd_nu0s * nu_sx;
+        AkT[w3i(k)] = at;
+        AkS[w3i(k)] = at;
+      }
+      // (b) bulk Richardson function at W-level k-1
       const double depth = zwN - z_w[w3i(k - 1)];
-      const double bf = Bfl[w3i(k - 1)];
+      double gT, gS;
+      const double bf = bflux(k - 1, gT, gS);
+      if (k - 1 == 0) { ghT[w3i(0)] = gT; ghS[w3i(0)] = gS; }
       const double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
       double wmk, wsk;
       wscale(Ustar, sigma, bf, wmk, wsk);
       const double hz = Hz[r3i(k)];
-      const double Rk = pden[r3i(k)] - hz * (cff1 * dR[w3i(k - 1)] + cff2 * dR[w3i(k)]);
-      const double Uk = 0.5 * (u[r3i(k)] + u[r3i(k) + 1]) - hz * (cff1 * dU[w3i(k - 1)] + cff2 * dU[w3i(k)]);
-      const double Vk = 0.5 * (v[r3i(k)] + v[r3i(k) + ni]) - hz * (cff1 * dV[w3i(k - 1)] + cff2 * dV[w3i(k)]);
+      const double Rk = pden[r3i(k)] - hz * (cff1 * dRm + cff2 * dRk);
+      const double Uk = 0.5 * (u[r3i(k)] + u[r3i(k) + 1]) - hz * (cff1 * dUm + cff2 * dUk);
+      const double Vk = 0.5 * (v[r3i(k)] + v[r3i(k) + ni]) - hz * (cff1 * dVm + cff2 * dVk);
       const double Ritop = -gorho0 * (Rref - Rk) * depth;
       const double Ribot = (Uref - Uk) * (Uref - Uk) + (Vref - Vk) * (Vref - Vk) +
                            Vtc * depth * wsk * sqrt(fabs(bvf[w3i(k - 1)]));
@@ -455,6 +452,7 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w)
         ksbl = k;
       }
       FCk = FCkm1;
+      dRk = dRm; dUk = dUm; dVk = dVm;
     }
   }
   double Bfsfc = (Bo + Bosol * (1.0 - swfrac(p, zwN - hsbl)));
@@ -517,7 +515,8 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w)
     double akv = Akv[w3i(k)], akt = AkT[w3i(k)], aks = AkS[w3i(k)];
     if (k > ksbl) {
       const double depth = zwN - z_w[w3i(k)];
-      const double bf = Bfl[w3i(k)];
+      double gT, gS;
+      const double bf = bflux(k, gT, gS);
       double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
       double wmk, wsk;
       wscale(Ustar, sigma, bf, wmk, wsk);
@@ -530,8 +529,8 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w)
       akt = depth * wsk * (1.0 + sigma * Gt);
       aks = depth * wsk * (1.0 + sigma * Gs);
       const double cff = lmd_Cg * (1.0 - (0.5 + copysign(0.5, bf))) / (zbl * wsk + eps);
-      ghT[w3i(k)] = cff * ghT[w3i(k)];
-      ghS[w3i(k)] = cff * ghS[w3i(k)];
+      ghT[w3i(k)] = cff * gT;
+      ghS[w3i(k)] = cff * gS;
     } else {
       ghT[w3i(k)] = 0.0;
       ghS[w3i(k)] = 0.0;
@@ -599,8 +598,13 @@ extern "C" int roms_hip_lmd_vmix(const roms_step_idx_t *s)
   {
     ScopedTimer tm("lmd_vmix");
     LmdScratch w{g_ctx.hostc.ws3[1], g_ctx.hostc.ws3[2], g_ctx.hostc.ws3[3], g_ctx.hostc.ws3[4], g_ctx.hostc.ws3[5]};
+    // run-time constants of mod_scalars.F:4330 (lmd_Cg) and lmd_skpp.F:300 (Vtc), evaluated on the host
+    const double vonKar = 0.41, lmd_Cstar = 10.0, lmd_Cv = 1.25, lmd_Ric = 0.3, lmd_betaT = -0.2, lmd_cs = 98.96,
+                 lmd_epsilon = 0.1;
+    const double lmd_Cg = lmd_Cstar * vonKar * pow(lmd_cs * vonKar * lmd_epsilon, 1.0 / 3.0);
+    const double Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);
     hipLaunchKernelGGL(k_lmd_vmix, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc,
-                       s->nstp, w);
+                       s->nstp, w, lmd_Cg, Vtc);
     KERNEL_CHECK("k_lmd_vmix");
     const int nj = b.Jend - b.Jstr + 1, ni_ = b.Iend - b.Istr + 1;
     if (b.west_edge || b.east_edge)
