@@ -436,7 +436,7 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc)
 {
   const roms_bounds_t &b = g_ctx.b;
   if (b.NghostPoints != 3) return roms_fail("roms_hip_step3d_t", "MPDATA needs NghostPoints = 3 (inp_par.F:266-278)");
-  if (b.N > 32) return roms_fail("roms_hip_step3d_t", "N > 32 not instantiated");
+  if (b.N > ROMS_MAXN) return roms_fail("roms_hip_step3d_t", "N > 64 not instantiated");
   int rc;
   const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
   // three-point footprint: refresh the ghost points of t(nnew) first, step3d_t.F:369-386
@@ -456,7 +456,8 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc)
   KERNEL_CHECK("k_mp_beta");
   const dim3 g = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
   if (b.N <= 16) hipLaunchKernelGGL((k_mp_update<16>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
-  else hipLaunchKernelGGL((k_mp_update<32>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+  else if (b.N <= 32) hipLaunchKernelGGL((k_mp_update<32>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+  else hipLaunchKernelGGL((k_mp_update<ROMS_MAXN>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
   KERNEL_CHECK("k_mp_update");
   return 0;
 }

@@ -251,8 +251,10 @@ int launch_pre_t(const roms_step_idx_t *s, int itrc0, int ntr)
     hipLaunchKernelGGL((k_pre_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
   else if (b.N <= 32)
     hipLaunchKernelGGL((k_pre_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
+  else if (b.N <= ROMS_MAXN)
+    hipLaunchKernelGGL((k_pre_t<HADV, VADV, ROMS_MAXN>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
   else
-    return roms_fail("roms_hip_pre_step3d", "N > 32 not instantiated");
+    return roms_fail("roms_hip_pre_step3d", "N > 64 not instantiated");
   KERNEL_CHECK("k_pre_t");
   return 0;
 }

@@ -405,12 +405,17 @@ int launch_var(int nnew, int itrc0, int ntr)
 {
   const roms_bounds_t &b = g_ctx.b;
   const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
-  if (b.N > 32) return roms_fail("roms_hip_step3d_t", "N > 32 not instantiated");
+  if (b.N > ROMS_MAXN) return roms_fail("roms_hip_step3d_t", "N > 64 not instantiated");
+  if (MODE != 2 && b.N > 32) return roms_fail("roms_hip_step3d_t", "the classic A/B kernel is instantiated for N <= 32");
   if constexpr (MODE == 2) {
     if (b.N <= 16)
       hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
-    else
+    else if (b.N <= 32)
       hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else if (b.N <= 48)     // the column arrays then spill into AGPRs (one wave per SIMD); slower per cell, same results
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 48>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 64>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
   } else {
     if (b.N <= 16)
       hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);

@@ -211,14 +211,17 @@ extern "C" int roms_hip_step3d_uv(const roms_step_idx_t *s)
     grid.z = 2;
     if (b.N <= 16) hipLaunchKernelGGL(k_uv_column<16>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
     else if (b.N <= 32) hipLaunchKernelGGL(k_uv_column<32>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
-    else return roms_fail("roms_hip_step3d_uv", "N > 32 not instantiated");
+    else if (b.N <= 48) hipLaunchKernelGGL(k_uv_column<48>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
+    else if (b.N <= ROMS_MAXN) hipLaunchKernelGGL(k_uv_column<ROMS_MAXN>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
+    else return roms_fail("roms_hip_step3d_uv", "N > 64 not instantiated");
     KERNEL_CHECK("k_uv_column");
     if ((rc = bc_u3d(s->nnew))) return rc;
     if ((rc = bc_v3d(s->nnew))) return rc;
     dim3 grid2 = grid2d(b.IendT - b.IstrT + 1, b.JendT - b.JstrT + 1);
     grid2.z = 2;
     if (b.N <= 16) hipLaunchKernelGGL(k_uv_couple<16>, grid2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nnew);
-    else hipLaunchKernelGGL(k_uv_couple<32>, grid2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nnew);
+    else if (b.N <= 32) hipLaunchKernelGGL(k_uv_couple<32>, grid2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nnew);
+    else hipLaunchKernelGGL(k_uv_couple<ROMS_MAXN>, grid2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nnew);
     KERNEL_CHECK("k_uv_couple");
   }
   const long nij = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1);

@@ -213,3 +213,15 @@ def test_lmd_vmix():
     # both regimes of the boundary-layer search must occur in the test state
     hs = st_o.interior("hsbl")
     assert float(hs.max()) > float(hs.min())
+
+
+@pytest.mark.parametrize("N", [40, 64])
+@pytest.mark.parametrize("kernel", ["step3d_t", "pre_step3d", "step3d_uv", "omega", "rhs3d"])
+def test_more_than_32_levels(kernel, N):
+    """Column kernels keep Thomas / spline arrays in registers under full unrolling: instantiated for
+    N <= 16, 32, 48, 64 (the two larger ones spill into AGPRs: slower per cell, same results)."""
+    prep = util.hz_weighted_tnew if kernel == "step3d_t" else None
+    st_h, st_o, st0 = _run_pair("UPWELLING", kernel, util.step_idx(iic=5), prep=prep, overrides={"N": N})
+    assert st0.b.N == N
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs

@@ -58,3 +58,26 @@ def test_100_steps(config, perturb, physics):
     assert all(v <= TOL for v in out.values()), out
     # the run must have done something
     assert float(np.abs(st_o["u"]).max()) > 1e-6
+
+
+def test_20_steps_48_levels():
+    """the whole step with N = 48 (register arrays of the column kernels in AGPRs)."""
+    import oracle
+    st_o = ana.make_tile("UPWELLING", perturb=1.0, overrides={"N": 48})
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o), physics=True)
+    mo.initial()
+    mo.run(20)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be, physics=True)
+        mh.initial()
+        mh.run(20)
+        be.to_host()
+    finally:
+        be.close()
+    s = mo.s
+    for name in ("u", "v"):
+        assert rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], FLOOR[name]) <= TOL
+    for it in range(st_o.b.NT):
+        assert rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], FLOOR["t"]) <= TOL
