@@ -54,6 +54,22 @@ k_t3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
   double dzm_a = 0.0, dz0_a = 0.0, dzp_a = 0.0, dzs_a = 0.0, dzn_a = 0.0;
   double dzm_b, dz0_b, dzp_b, dzs_b, dzn_b;
   double FS_a = 0.0, FS_b;
+  // Software pipeline (cf. k_step3d_t_pipe): the 16 loads an iteration consumes -- T and z_r of level
+  // k+1 at the five columns, Hz of level k at the five columns, t(nnew) of level k -- are issued one
+  // iteration ahead, so their latency overlaps the arithmetic of the previous level.
+  struct LvIn { double Tm1, T01, Tp1, Ts1, Tn1, Zm1, Z01, Zp1, Zs1, Zn1, hz0, hzm, hzp, hzs, hzn, tn; };
+  const gcd_t gT = (gcd_t)T, gZ = (gcd_t)z_r, gHz = (gcd_t)Hz;
+  const gd_t gtn = (gd_t)tn;
+  auto load_level = [&](int k) {
+    LvIn L;
+    const long ck = c0 + (long)(k - 1) * nij;
+    const long cu = (k < N) ? ck + nij : ck;               // level k+1 (clamped at the top; unused there)
+    L.Tm1 = gT[cu - 1]; L.T01 = gT[cu]; L.Tp1 = gT[cu + 1]; L.Ts1 = gT[cu - ni]; L.Tn1 = gT[cu + ni];
+    L.Zm1 = gZ[cu - 1]; L.Z01 = gZ[cu]; L.Zp1 = gZ[cu + 1]; L.Zs1 = gZ[cu - ni]; L.Zn1 = gZ[cu + ni];
+    L.hz0 = gHz[ck]; L.hzm = gHz[ck - 1]; L.hzp = gHz[ck + 1]; L.hzs = gHz[ck - ni]; L.hzn = gHz[ck + ni];
+    L.tn = gtn[ck];
+    return L;
+  };
   // values of level k carried for the vertical differences
   double Tm = T[c0 - 1], T0 = T[c0], Tp = T[c0 + 1], Ts = T[c0 - ni], Tn = T[c0 + ni];
   double Zm = z_r[c0 - 1], Z0 = z_r[c0], Zp = z_r[c0 + 1], Zs = z_r[c0 - ni], Zn = z_r[c0 + ni];
@@ -62,14 +78,16 @@ k_t3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
   zx1_b = mx1 * (Zp - Z0); tx1_b = mx1 * (Tp - T0);
   ze0_b = my0 * (Z0 - Zs); te0_b = my0 * (T0 - Ts);
   ze1_b = my1 * (Zn - Z0); te1_b = my1 * (Tn - T0);
+  LvIn cur = load_level(1);
   for (int k = 1; k <= N; k++) {
     const long ck = c0 + (long)(k - 1) * nij;
+    LvIn nxt = cur;
+    if (k < N) nxt = load_level(k + 1);
     zx0_a = zx0_b; zx1_a = zx1_b; tx0_a = tx0_b; tx1_a = tx1_b;
     ze0_a = ze0_b; ze1_a = ze1_b; te0_a = te0_b; te1_a = te1_b;
     if (k < N) {
-      const long cu = ck + nij;
-      const double Tm1 = T[cu - 1], T01 = T[cu], Tp1 = T[cu + 1], Ts1 = T[cu - ni], Tn1 = T[cu + ni];
-      const double Zm1 = z_r[cu - 1], Z01 = z_r[cu], Zp1 = z_r[cu + 1], Zs1 = z_r[cu - ni], Zn1 = z_r[cu + ni];
+      const double Tm1 = cur.Tm1, T01 = cur.T01, Tp1 = cur.Tp1, Ts1 = cur.Ts1, Tn1 = cur.Tn1;
+      const double Zm1 = cur.Zm1, Z01 = cur.Z01, Zp1 = cur.Zp1, Zs1 = cur.Zs1, Zn1 = cur.Zn1;
       zx0_b = mx0 * (Z01 - Zm1); tx0_b = mx0 * (T01 - Tm1);
       zx1_b = mx1 * (Zp1 - Z01); tx1_b = mx1 * (Tp1 - T01);
       ze0_b = my0 * (Z01 - Zs1); te0_b = my0 * (T01 - Ts1);
@@ -84,7 +102,7 @@ k_t3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
     } else {
       dzm_b = dz0_b = dzp_b = dzs_b = dzn_b = 0.0;
     }
-    const double hz0 = Hz[ck], hzm = Hz[ck - 1], hzp = Hz[ck + 1], hzs = Hz[ck - ni], hzn = Hz[ck + ni];
+    const double hz0 = cur.hz0, hzm = cur.hzm, hzp = cur.hzp, hzs = cur.hzs, hzn = cur.hzn;
     // FX(i), FX(i+1), FE(j), FE(j+1): t3dmix2_geo.h:268-310
     const double FX0 = cfx0 * (hz0 + hzm) *
         (tx0_a - 0.5 * (dmin0(zx0_a) * (dzm_a + dz0_b) + dmax0(zx0_a) * (dzm_b + dz0_a)));
@@ -106,7 +124,8 @@ k_t3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
     const double cff2 = cdt * (FE1 - FE0);
     const double cff3 = dt * (FS_b - FS_a);
     const double cff4 = cff1 + cff2 + cff3;
-    tn[ck] = tn[ck] + cff4;
+    gtn[ck] = cur.tn + cff4;
+    cur = nxt;
     dzm_a = dzm_b; dz0_a = dz0_b; dzp_a = dzp_b; dzs_a = dzs_b; dzn_a = dzn_b;
     FS_a = FS_b;
   }
