@@ -177,6 +177,26 @@ __global__ void k_periodic_ew(const RomsDev *__restrict__ c, double *__restrict_
   for (int m = 0; m <= 2; m++) P[I2(-m, j)] = P[I2(Lm - m, j)];
 }
 
+// the same copy for several fields at once: blockIdx.y runs over all planes of all fields
+struct PeriodicArgs {
+  double *A[8];
+  int koff[8], jmin[8], jmax[8];
+  int n, nktot, jlo;
+};
+__global__ void k_periodic_multi(const RomsDev *__restrict__ c, PeriodicArgs a)
+{
+  DEV_PROLOGUE(c)
+  const int j = a.jlo + blockIdx.x * blockDim.x + threadIdx.x;
+  const int kk = blockIdx.y;
+  int f = 0;
+  while (f + 1 < a.n && kk >= a.koff[f + 1]) f++;
+  if (kk >= a.nktot || j < a.jmin[f] || j > a.jmax[f]) return;
+  const int Lm = b.Lm;
+  double *P = a.A[f] + (long)(kk - a.koff[f]) * nij;
+  for (int m = 1; m <= b.NghostPoints; m++) P[I2(Lm + m, j)] = P[I2(m, j)];
+  for (int m = 0; m <= 2; m++) P[I2(-m, j)] = P[I2(Lm - m, j)];
+}
+
 // --------------------------------------------------- multi-tile pack/unpack --
 // dir 0: columns i0..i0+G-1 over the full j-range; dir 1: rows j0..j0+G-1 over
 // the full i-range.  Buffer order (k, m, running index) -- ours, not MPI's.
@@ -314,14 +334,26 @@ static int halo_run(const HaloItem *items, int nitems)
   if (nitems <= 0) return 0;
   if (b.ntileI * b.ntileJ == 1) {
     if (!b.EWperiodic) return 0;
-    for (int f = 0; f < nitems; f++) {
-      int jmin, jmax;
-      if (b.NSperiodic) { jmin = b.Jstr; jmax = b.Jend; }
-      else { jmin = (items[f].gtype == GT_R || items[f].gtype == GT_U) ? b.JstrR : b.Jstr; jmax = b.JendR; }
-      dim3 grid((jmax - jmin + 1 + 63) / 64, items[f].nk);
-      hipLaunchKernelGGL(k_periodic_ew, grid, dim3(64), 0, g_ctx.stream, g_ctx.devc, items[f].A, items[f].nk, jmin, jmax);
+    // all fields of the batch in one launch (a step issues ~50 of these otherwise)
+    for (int f0 = 0; f0 < nitems; f0 += HALO_MAX_ITEMS) {
+      PeriodicArgs pa;
+      pa.n = nitems - f0 < HALO_MAX_ITEMS ? nitems - f0 : HALO_MAX_ITEMS;
+      int nktot = 0, jlo = b.UBj, jhi = b.LBj;
+      for (int f = 0; f < pa.n; f++) {
+        const HaloItem &it = items[f0 + f];
+        int jmin, jmax;
+        if (b.NSperiodic) { jmin = b.Jstr; jmax = b.Jend; }
+        else { jmin = (it.gtype == GT_R || it.gtype == GT_U) ? b.JstrR : b.Jstr; jmax = b.JendR; }
+        pa.A[f] = it.A; pa.koff[f] = nktot; pa.jmin[f] = jmin; pa.jmax[f] = jmax;
+        nktot += it.nk;
+        jlo = jmin < jlo ? jmin : jlo;
+        jhi = jmax > jhi ? jmax : jhi;
+      }
+      pa.nktot = nktot; pa.jlo = jlo;
+      dim3 grid((jhi - jlo + 1 + 63) / 64, nktot);
+      hipLaunchKernelGGL(k_periodic_multi, grid, dim3(64), 0, g_ctx.stream, g_ctx.devc, pa);
     }
-    KERNEL_CHECK("k_periodic_ew");
+    KERNEL_CHECK("k_periodic_multi");
     return 0;
   }
   if (!g_have_neigh) {
