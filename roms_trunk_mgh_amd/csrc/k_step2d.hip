@@ -558,13 +558,16 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   // the first predictor of a step: there the momentum kernel read-modify-writes
   // rufrc and ru(:,:,0,nstp) at the source points (:1884-2037), which ghost-point
   // threads would race with.
-  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !(s.iif == 1 && s.predictor) &&
-                  !g_ctx.no_fused_2d;
+  static const bool no_fuse_zeta = getenv("ROMS_HIP_NO_FUSED_ZETA") != nullptr;     // A/B switch
+  const bool one_launch = !g_ctx.no_lds_2d && !no_fuse_zeta && s.iif <= p.nfast;     // k2d_mom_lds<true>
+  // (the kernels that use ghost threads cannot take the first predictor of a step: there the momentum
+  // part read-modify-writes rufrc and ru(:,:,0,nstp) at the source points; the one-launch kernel can)
+  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.no_fused_2d &&
+                  (one_launch || !(s.iif == 1 && s.predictor));
   if (sm) {
     s.sm = 1;
     const dim3 full = grid2d(b.UBi - b.LBi + 1, b.UBj - b.LBj + 1);
-    static const bool no_fuse_zeta = getenv("ROMS_HIP_NO_FUSED_ZETA") != nullptr;     // A/B switch
-    if (!g_ctx.no_lds_2d && !no_fuse_zeta && s.iif <= p.nfast) {
+    if (one_launch) {
       // ONE launch: free surface, fast-time averages and momentum (k2d_mom_lds<true>)
       s.sm = 2;
       return roms_launch_k2d_mom_lds((const int *)&s, nullptr, nullptr, nullptr, nullptr);

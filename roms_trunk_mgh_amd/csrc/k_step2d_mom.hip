@@ -129,8 +129,14 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const bool inline_bc = s.sm || DUnext != nullptr;
   __shared__ double sU[TJ * TP], sV[TJ * TP], sDU[TJ * TP], sDV[TJ * TP], sD[TJ * TP];
   __shared__ double sZn[FUSED ? TJ * TP : 1], sZw[FUSED ? TJ * TP : 1];
-  const int ibase = s.sm ? b.LBi : b.Istr;
-  const int ilast = s.sm ? (b.Lm + b.NghostPoints) : b.Iend;
+  // FUSED on one tile: threads cover the interior only and the owner of a column also stores its
+  // periodic images (columns Lm+1.. and ..0), instead of ghost threads repeating the work of their
+  // source column -- no nearly empty 33rd workgroup column, and the first predictor of a step (it
+  // read-modify-writes rufrc and ru(:,:,0,nstp)) has no reader/writer race any more
+  const bool img = FUSED && s.sm;
+  const bool ghost_threads = s.sm && !img;
+  const int ibase = ghost_threads ? b.LBi : b.Istr;
+  const int ilast = ghost_threads ? (b.Lm + b.NghostPoints) : b.Iend;
   const int it0 = ibase + blockIdx.x * BLK_X, j0 = b.Jstr + blockIdx.y * BLK_Y;
   const int it = it0 + threadIdx.x, j = j0 + threadIdx.y;
   const double *__restrict__ ubk = c->F.ubar + (long)(s.krhs - 1) * nij;
@@ -187,7 +193,15 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     __syncthreads();
   }
   if (it > ilast || j > b.Jend) return;
-  const int i = s.sm ? wrap_i(b, it) : it;          // source column
+  const int i = ghost_threads ? wrap_i(b, it) : it; // source column
+  // store at the target and, for an owner next to the periodic seam, at its image column(s)
+  auto put = [&](double *A, long idx, double val) {
+    A[idx] = val;
+    if (img) {
+      if (i <= b.NghostPoints) A[idx + b.Lm] = val;
+      if (i >= b.Lm - 2) A[idx - b.Lm] = val;
+    }
+  };
   const bool owner = (i == it);
   const bool do_u = s.sm ? true : (i >= b.IstrU);
   const bool do_v = j >= b.JstrV;
@@ -244,11 +258,11 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     }
     const double zn = sZn[t];
     double *__restrict__ zout = c->F.zeta + (long)(s.knew - 1) * nij;
-    zout[o] = zn;
-    if (b.south_edge && j == b.Jstr) zout[o - ni] = zn;             // zetabc closed: zero gradient
-    if (b.north_edge && j == b.Jend) zout[o + ni] = zn;
+    put(zout, o, zn);
+    if (b.south_edge && j == b.Jstr) put(zout, o - ni, zn);         // zetabc closed: zero gradient
+    if (b.north_edge && j == b.Jend) put(zout, o + ni, zn);
     if (s.predictor)      // at the target: ghost columns hold the periodic copy, as after the exchange
-      c->F.rzeta[o + (long)(s.krhs - 1) * nij] = (sDU[t] - sDU[t + 1]) + (sDV[t] - sDV[t + TP]);
+      put(c->F.rzeta + (long)(s.krhs - 1) * nij, o, (sDU[t] - sDU[t + 1]) + (sDV[t] - sDV[t + TP]));
   }
   const double zw0 = FUSED ? sZw[t] : zwrk[a];
   const double gz0 = (fac + rhoS[a]) * zw0, gz20 = gz0 * zw0, gsa0 = zw0 * (rhoS[a] - rhoA[a]);
@@ -400,11 +414,11 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     else un = (us * (Dst0 + (zs[q] + h[q])) +
                cff * (a1 * rhs_u + a2 * c->F.rubar[a + (long)(s.kstp - 1) * nij] -
                       a3 * c->F.rubar[a + (long)(ptsk - 1) * nij])) * fc;
-    ubn[o] = un;
+    put(ubn, o, un);
     if (s.predictor && owner) c->F.rubar[a + (long)(s.krhs - 1) * nij] = rhs_u;
     if (inline_bc) {                                   // u2dbc closed walls, u2dbc_im.F:51
-      if (b.south_edge && j == b.Jstr) ubn[o - ni] = p.gamma2 * un;
-      if (b.north_edge && j == b.Jend) ubn[o + ni] = p.gamma2 * un;
+      if (b.south_edge && j == b.Jstr) put(ubn, o - ni, p.gamma2 * un);
+      if (b.north_edge && j == b.Jend) put(ubn, o + ni, p.gamma2 * un);
     }
     if constexpr (FUSED) {
       if (DUnext) {                                    // DUon of level knew, :509-525 (as k2d_flux)
@@ -428,15 +442,15 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     else vn = (vs * (Dst0 + (zs[q] + h[q])) +
                cff * (a1 * rhs_v + a2 * c->F.rvbar[a + (long)(s.kstp - 1) * nij] -
                       a3 * c->F.rvbar[a + (long)(ptsk - 1) * nij])) * fc;
-    vbn[o] = vn;
+    put(vbn, o, vn);
     if (s.predictor && owner) c->F.rvbar[a + (long)(s.krhs - 1) * nij] = rhs_v;
     if constexpr (FUSED) {
       if (DVnext) DVnext[a] = vn * ((0.5 * c->F.om_v[a]) * (Dn0 + (sZn[t - TP] + h[q])));   // :527-544
     }
   }
   if (inline_bc) {                                     // v2dbc closed walls, v2dbc_im.F:52
-    if (b.south_edge && j == b.Jstr) vbn[o] = 0.0;
-    if (b.north_edge && j == b.Jend) vbn[o + ni] = 0.0;
+    if (b.south_edge && j == b.Jstr) put(vbn, o, 0.0);
+    if (b.north_edge && j == b.Jend) put(vbn, o + ni, 0.0);
   }
   if constexpr (FUSED) {
     if (DVnext) {                                      // wall rows: v = 0 there
@@ -457,7 +471,7 @@ int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DV
 {
   const roms_bounds_t &b = g_ctx.b;
   S2 s{s10[0], s10[1], s10[2], s10[3], s10[4], s10[5], s10[6], s10[7], s10[8], s10[9]};
-  const int nx = (s.sm == 1 || s.sm == 2) ? (b.UBi - b.LBi + 1) : (b.Iend - b.Istr + 1);
+  const int nx = (s.sm == 1) ? (b.UBi - b.LBi + 1) : (b.Iend - b.Istr + 1);
   if (s.sm == 2) {      // fused free-surface + momentum call (source-mapped, fluxes in place)
     s.sm = 1;
     hipLaunchKernelGGL(k2d_mom_lds<true>, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
