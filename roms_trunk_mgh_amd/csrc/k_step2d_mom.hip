@@ -137,7 +137,8 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const bool ghost_threads = s.sm && !img;
   const int ibase = ghost_threads ? b.LBi : b.Istr;
   const int ilast = ghost_threads ? (b.Lm + b.NghostPoints) : b.Iend;
-  const int it0 = ibase + blockIdx.x * BLK_X, j0 = b.Jstr + blockIdx.y * BLK_Y;
+  const Blk XB = xcd_block();
+  const int it0 = ibase + XB.x * BLK_X, j0 = b.Jstr + XB.y * BLK_Y;
   const int it = it0 + threadIdx.x, j = j0 + threadIdx.y;
   const double *__restrict__ ubk = c->F.ubar + (long)(s.krhs - 1) * nij;
   const double *__restrict__ vbk = c->F.vbar + (long)(s.krhs - 1) * nij;
