@@ -84,8 +84,7 @@ __device__ __forceinline__ double VFe_at(const T3 &L, int i, int j)   // :846-86
          (L.Hv[a] + L.Hv[a + TP] + Gadv * 0.5 * (d2y(L.Hv, L.at(i, ja)) + d2y(L.Hv, L.at(i, jb))));
 }
 
-__global__ void __launch_bounds__(BLK_X *BLK_Y)
-k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
+__device__ __forceinline__ void rhs3d_lds_body(const RomsDev *__restrict__ c, int nrhs)
 {
   DEV_PROLOGUE(c)
   const Blk XB = xcd_block();
@@ -141,38 +140,39 @@ k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
   const gcd_t gU = (gcd_t)ug, gV = (gcd_t)vg, gHu = (gcd_t)c->F.Huon, gHv = (gcd_t)c->F.Hvom, gHz = (gcd_t)c->F.Hz;
   const gcd_t gW = (gcd_t)Wg;
   const gd_t gru = (gd_t)ru, grv = (gd_t)rv;
-  struct Stage { double u[NSLOT], v[NSLOT], hu[NSLOT], hv[NSLOT], hz[NSLOT]; };
+  // staged values of the next level (plain arrays and scalars, constant indices only: a struct returned from a
+  // conditional load ended up in scratch memory, with a vmcnt(0) wait right behind the loads)
+  double Ru[NSLOT], Rv[NSLOT], Rhu[NSLOT], Rhv[NSLOT], Rhz[NSLOT];
   struct Own { double up2, vp2, ru, rv, w0, wm1, wp1, wm2, wmn, wpn, wm2n; };
   auto gload = [&](int k) {
-    Stage R;
     const long koff = (long)(k - 1) * nij;
 #pragma unroll
     for (int q = 0; q < NSLOT; q++) {
       const long g = gof[q] + koff;
-      if (tid + q * BLK_X * BLK_Y < TT) {
-        R.u[q] = gU[g]; R.v[q] = gV[g]; R.hu[q] = gHu[g]; R.hv[q] = gHv[g]; R.hz[q] = gHz[g];
-      } else {
-        R.u[q] = R.v[q] = R.hu[q] = R.hv[q] = R.hz[q] = 0.0;
+      // slots wholly inside the tile load unconditionally; the last one only where it has an element
+      if ((q + 1) * BLK_X * BLK_Y <= TT || tid < TT - q * BLK_X * BLK_Y) {
+        Ru[q] = gU[g]; Rv[q] = gV[g]; Rhu[q] = gHu[g]; Rhv[q] = gHv[g]; Rhz[q] = gHz[g];
       }
     }
-    return R;
   };
-  auto oload = [&](int k) {
-    Own P;
+  auto oload = [&](int k, Own &P) {
     const long koff = (long)(k - 1) * nij;
     const long cw = c0 + (long)k * nij;
-    P.up2 = (k + 2 <= N) ? gU[c0 + koff + 2 * nij] : 0.0;
-    P.vp2 = (k + 2 <= N) ? gV[c0 + koff + 2 * nij] : 0.0;
+    const long c2 = c0 + ((k + 2 <= N) ? koff + 2 * nij : koff);      // clamped: unused above N-2
+    P.up2 = gU[c2];
+    P.vp2 = gV[c2];
     P.ru = do_u ? gru[cw] : 0.0;
     P.rv = do_v ? grv[cw] : 0.0;
     P.w0 = gW[cw];
     // the W stencil of the vertical flux (k < N, u: i-2..i+1, v: j-2..j+1); inactive lanes read their own point
     P.wm1 = do_u ? gW[cw - 1] : P.w0; P.wp1 = do_u ? gW[cw + 1] : P.w0; P.wm2 = do_u ? gW[cw - 2] : P.w0;
     P.wmn = do_v ? gW[cw - ni] : P.w0; P.wpn = do_v ? gW[cw + ni] : P.w0; P.wm2n = do_v ? gW[cw - 2 * ni] : P.w0;
-    return P;
   };
-  Stage R = gload(1);
-  Own P = oload(1);
+#pragma unroll
+  for (int q = 0; q < NSLOT; q++) Ru[q] = Rv[q] = Rhu[q] = Rhv[q] = Rhz[q] = 0.0;
+  gload(1);
+  Own P;
+  oload(1, P);
 
   for (int k = 1; k <= N; k++) {
     const int buf = (k & 1) * TT;
@@ -180,11 +180,11 @@ k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
 #pragma unroll
     for (int q = 0; q < NSLOT; q++) {
       const int e = tid + q * BLK_X * BLK_Y;
-      if (e < TT) { bU[e] = R.u[q]; bV[e] = R.v[q]; bHu[e] = R.hu[q]; bHv[e] = R.hv[q]; bHz[e] = R.hz[q]; }
+      if (e < TT) { bU[e] = Ru[q]; bV[e] = Rv[q]; bHu[e] = Rhu[q]; bHv[e] = Rhv[q]; bHz[e] = Rhz[q]; }
     }
     __syncthreads();
     const Own Pk = P;
-    if (k < N) { R = gload(k + 1); P = oload(k + 1); }      // in flight while level k is computed
+    { const int kn = k < N ? k + 1 : N; gload(kn); oload(kn, P); }   // in flight while level k is computed
     L.u = bU; L.v = bV; L.Hu = bHu; L.Hv = bHv; L.Hz = bHz;
     u_p2 = Pk.up2;
     v_p2 = Pk.vp2;
@@ -270,6 +270,9 @@ k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs)
     c->F.rvfrc[c0] = sum_v + cff1 + cff2;
   }
 }
+
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_rhs3d_lds(const RomsDev *__restrict__ c, int nrhs) { rhs3d_lds_body(c, nrhs); }
 
 }  // namespace
 
