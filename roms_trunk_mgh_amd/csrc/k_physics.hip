@@ -351,17 +351,25 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
 
   // ---------- one upward sweep: spline recurrences of u, v (lmd_vmix_tile :205-225 = lmd_skpp_tile
   // :345-365) and of pden; only these forward values go to scratch ----------
+  // (software-pipelined: the six loads of level k+2 are issued before level k is computed)
   {
     double FCm = 0.0, dUm = 0.0, dVm = 0.0, dRm = 0.0;
+    long q = r3i(1);
+    double hz = Hz[q], ua = u[q], ub = u[q + 1], va = v[q], vb = v[q + ni], pd = pden[q];
+    q = r3i(N >= 2 ? 2 : 1);
+    double hz1 = Hz[q], ua1 = u[q], ub1 = u[q + 1], va1 = v[q], vb1 = v[q + ni], pd1 = pden[q];
     for (int k = 1; k <= N - 1; k++) {
-      const double hz = Hz[r3i(k)], hz1 = Hz[r3i(k + 1)];
+      q = r3i(k + 2 <= N ? k + 2 : N);
+      const double hz2 = Hz[q], ua2 = u[q], ub2 = u[q + 1], va2 = v[q], vb2 = v[q + ni], pd2 = pden[q];
       const double cff = 1.0 / (2.0 * hz1 + hz * (2.0 - FCm));
       const double fck = cff * hz1;
-      const double duk = cff * (3.0 * (u[r3i(k + 1)] - u[r3i(k)] + u[r3i(k + 1) + 1] - u[r3i(k) + 1]) - hz * dUm);
-      const double dvk = cff * (3.0 * (v[r3i(k + 1)] - v[r3i(k)] + v[r3i(k + 1) + ni] - v[r3i(k) + ni]) - hz * dVm);
-      const double drk = cff * (6.0 * (pden[r3i(k + 1)] - pden[r3i(k)]) - hz * dRm);
+      const double duk = cff * (3.0 * (ua1 - ua + ub1 - ub) - hz * dUm);
+      const double dvk = cff * (3.0 * (va1 - va + vb1 - vb) - hz * dVm);
+      const double drk = cff * (6.0 * (pd1 - pd) - hz * dRm);
       FC[w3i(k)] = fck; dU[w3i(k)] = duk; dV[w3i(k)] = dvk; dR[w3i(k)] = drk;
       FCm = fck; dUm = duk; dVm = dvk; dRm = drk;
+      hz = hz1; ua = ua1; ub = ub1; va = va1; vb = vb1; pd = pd1;
+      hz1 = hz2; ua1 = ua2; ub1 = ub2; va1 = va2; vb1 = vb2; pd1 = pd2;
     }
   }
 
@@ -378,14 +386,15 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   const double Bosol = g * alpha * srflx;
   // buoyancy flux and the non-local flux shape at W-level k (:320-338); recomputed where needed
   // (two exp per call) instead of being stored and re-read
-  auto bflux = [&](int k, double &gT, double &gS) {
-    const double swdk = swfrac(p, zwN - z_w[w3i(k)]);
+  auto bflux_z = [&](double zwk, double &gT, double &gS) {
+    const double swdk = swfrac(p, zwN - zwk);
     const double bf = (Bo + Bosol * (1.0 - swdk));
     const double cff = 1.0 - (0.5 + copysign(0.5, bf));
     gT = -cff * (stT - srflx + srflx * (1.0 - swdk));
     gS = cff * stS;
     return bf;
   };
+  auto bflux = [&](int k, double &gT, double &gS) { return bflux_z(z_w[w3i(k)], gT, gS); };
   { double gT, gS; bflux(N, gT, gS); ghT[w3i(N)] = gT; ghS[w3i(N)] = gS; }
 
   // ---------- one downward sweep: back-substitution of the three splines fused with (a) the shear /
@@ -394,28 +403,35 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   const double cff1 = 1.0 / 3.0, cff2 = 1.0 / 6.0;
   int ksbl = 1;
   {
-    const double hzN = Hz[r3i(N)];
-    const double dRNm1 = dR[w3i(N - 1)], dUNm1 = dU[w3i(N - 1)], dVNm1 = dV[w3i(N - 1)];   // final: x(N) = 0
-    const double Rref = pden[r3i(N)] + hzN * (cff1 * 0.0 + cff2 * dRNm1);
-    const double Uref = 0.5 * (u[r3i(N)] + u[r3i(N) + 1]) + hzN * (cff1 * 0.0 + cff2 * dUNm1);
-    const double Vref = 0.5 * (v[r3i(N)] + v[r3i(N) + ni]) + hzN * (cff1 * 0.0 + cff2 * dVNm1);
+    // inputs of iteration k: rho-type level k (hz, pd, ua/ub = u(i), u(i+1), va/vb = v(j), v(j+1)) and
+    // W-type level k-1 (fc, dr, du, dv: forward spline values; bvm, zwm); software-pipelined, the twelve
+    // loads of iteration k-1 are issued before iteration k is computed
+    long q = r3i(N), qw = w3i(N > 1 ? N - 1 : 1), qz = w3i(N - 1);
+    double hz = Hz[q], pd = pden[q], ua = u[q], ub = u[q + 1], va = v[q], vb = v[q + ni];
+    double fc = FC[qw], dr = dR[qw], du = dU[qw], dv = dV[qw], bvm = bvf[qz], zwm = z_w[qz];
+    double bvk = 0.0, zwk = zwN;                                 // W-type level k (bvf(N) is not used)
+    const double Rref = pd + hz * (cff1 * 0.0 + cff2 * dr);      // final: x(N) = 0
+    const double Uref = 0.5 * (ua + ub) + hz * (cff1 * 0.0 + cff2 * du);
+    const double Vref = 0.5 * (va + vb) + hz * (cff1 * 0.0 + cff2 * dv);
     double dRk = 0.0, dUk = 0.0, dVk = 0.0;                      // final values at level k (k = N: 0)
     double FCk = 0.0;                                            // FC(i,N) = 0
     hsbl = z_w[w3i(1)];
     for (int k = N; k >= 1; k--) {
+      q = r3i(k > 1 ? k - 1 : 1); qw = w3i(k > 2 ? k - 2 : 1); qz = w3i(k > 2 ? k - 2 : 0);
+      const double n_hz = Hz[q], n_pd = pden[q], n_ua = u[q], n_ub = u[q + 1], n_va = v[q], n_vb = v[q + ni];
+      const double n_fc = FC[qw], n_dr = dR[qw], n_du = dU[qw], n_dv = dV[qw], n_bvm = bvf[qz], n_zwm = z_w[qz];
       // final spline derivatives at level k-1
       double dRm = 0.0, dUm = 0.0, dVm = 0.0;
       if (k - 1 >= 1) {
-        const double fc = FC[w3i(k - 1)];
-        dRm = dR[w3i(k - 1)] - fc * dRk;
-        dUm = dU[w3i(k - 1)] - fc * dUk;
-        dVm = dV[w3i(k - 1)] - fc * dVk;
+        dRm = dr - fc * dRk;
+        dUm = du - fc * dUk;
+        dVm = dv - fc * dVk;
       }
       // (a) interior mixing at W-level k
       if (k <= N - 1) {
         const double epsv = 1.0E-14;
         double shear2 = dUk * dUk + dVk * dVk;
-        const double bv = bvf[w3i(k)];
+        const double bv = bvk;
         const double Rig = bv / (shear2 + epsv);
         double cff = fmin(1.0, fmax(0.0, Rig) / lmd_Ri0);
         double nu_sx = 1.0 - cff * cff;
@@ -431,28 +447,30 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
         AkS[w3i(k)] = at;
       }
       // (b) bulk Richardson function at W-level k-1
-      const double depth = zwN - z_w[w3i(k - 1)];
+      const double depth = zwN - zwm;
       double gT, gS;
-      const double bf = bflux(k - 1, gT, gS);
+      const double bf = bflux_z(zwm, gT, gS);
       if (k - 1 == 0) { ghT[w3i(0)] = gT; ghS[w3i(0)] = gS; }
       const double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
       double wmk, wsk;
       wscale(Ustar, sigma, bf, wmk, wsk);
-      const double hz = Hz[r3i(k)];
-      const double Rk = pden[r3i(k)] - hz * (cff1 * dRm + cff2 * dRk);
-      const double Uk = 0.5 * (u[r3i(k)] + u[r3i(k) + 1]) - hz * (cff1 * dUm + cff2 * dUk);
-      const double Vk = 0.5 * (v[r3i(k)] + v[r3i(k) + ni]) - hz * (cff1 * dVm + cff2 * dVk);
+      const double Rk = pd - hz * (cff1 * dRm + cff2 * dRk);
+      const double Uk = 0.5 * (ua + ub) - hz * (cff1 * dUm + cff2 * dUk);
+      const double Vk = 0.5 * (va + vb) - hz * (cff1 * dVm + cff2 * dVk);
       const double Ritop = -gorho0 * (Rref - Rk) * depth;
       const double Ribot = (Uref - Uk) * (Uref - Uk) + (Vref - Vk) * (Vref - Vk) +
-                           Vtc * depth * wsk * sqrt(fabs(bvf[w3i(k - 1)]));
+                           Vtc * depth * wsk * sqrt(fabs(bvm));
       const double FCkm1 = Ritop - lmd_Ric * Ribot;
       // boundary-layer depth: first level (from the top, k = N..2) where the function turns positive
       if (k >= 2 && ksbl == 1 && FCkm1 > 0.0) {
-        hsbl = (z_w[w3i(k)] * FCkm1 - z_w[w3i(k - 1)] * FCk) / (FCkm1 - FCk);
+        hsbl = (zwk * FCkm1 - zwm * FCk) / (FCkm1 - FCk);
         ksbl = k;
       }
       FCk = FCkm1;
       dRk = dRm; dUk = dUm; dVk = dVm;
+      bvk = bvm; zwk = zwm;
+      hz = n_hz; pd = n_pd; ua = n_ua; ub = n_ub; va = n_va; vb = n_vb;
+      fc = n_fc; dr = n_dr; du = n_du; dv = n_dv; bvm = n_bvm; zwm = n_zwm;
     }
   }
   double Bfsfc = (Bo + Bosol * (1.0 - swfrac(p, zwN - hsbl)));
@@ -511,12 +529,17 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
     Gs1 = Gt1;
     dGs1dS = dGt1dS;
   }
+  long q3 = w3i(1);
+  double n_akv = Akv[q3], n_akt = AkT[q3], n_aks = AkS[q3], n_zw = z_w[q3], n_bv = bvf[q3];
   for (int k = 1; k <= N - 1; k++) {
-    double akv = Akv[w3i(k)], akt = AkT[w3i(k)], aks = AkS[w3i(k)];
+    double akv = n_akv, akt = n_akt, aks = n_aks;
+    const double zwk = n_zw, bvk = n_bv;
+    q3 = w3i(k + 1 <= N - 1 ? k + 1 : k);                      // next level, in flight during this one
+    n_akv = Akv[q3]; n_akt = AkT[q3]; n_aks = AkS[q3]; n_zw = z_w[q3]; n_bv = bvf[q3];
     if (k > ksbl) {
-      const double depth = zwN - z_w[w3i(k)];
+      const double depth = zwN - zwk;
       double gT, gS;
-      const double bf = bflux(k, gT, gS);
+      const double bf = bflux_z(zwk, gT, gS);
       double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
       double wmk, wsk;
       wscale(Ustar, sigma, bf, wmk, wsk);
@@ -536,7 +559,7 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
       ghS[w3i(k)] = 0.0;
     }
     // lmd_finish_tile: convective mixing where the stratification is unstable (lmd_vmix.F:520-540)
-    double cff = fmax(bvf[w3i(k)], lmd_bvfcon);
+    double cff = fmax(bvk, lmd_bvfcon);
     cff = fmin(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
     double nu_sxc = 1.0 - cff * cff;
     nu_sxc = nu_sxc * nu_sxc * nu_sxc;

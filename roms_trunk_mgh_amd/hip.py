@@ -13,7 +13,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libroms_hip.so")
+# ROMS_HIP_LIBRARY: developer override (A/B of two builds of the same ABI on one GPU box)
+LIB_PATH = os.environ.get("ROMS_HIP_LIBRARY") or os.path.join(_HERE, "libroms_hip.so")
 _LIB = None
 
 ENTRIES = ["set_massflux", "rho_eos", "omega", "set_zeta", "set_depth", "rhs3d",
