@@ -6,9 +6,10 @@ A "step" is one full baroclinic step of the hot path:
 set_massflux, rho_eos, omega, set_zeta, rhs3d (pre_step3d, prsgrd, t3dmix2,
 rhs3d_tile, uv3dmix2), the 59-call barotropic step2d loop, set_depth,
 step3d_uv, omega, step3d_t -- on synthetic (analytic) BENCHMARK inputs that are
-resident in HBM before the timed region starts.  The per-step physics outside
-the hot path (bulk_flux, lmd_vmix, set_vbc: SURVEY.md section 8f-1) is held
-fixed, see DESIGN.md.
+resident in HBM before the timed region starts.  By default the per-step physics and
+diagnostics the reference's BENCHMARK step carries (bulk_flux,
+set_vbc, lmd_vmix = KPP, wvelocity, diag with NINFO = 1) run on the device as well;
+--no-physics holds their outputs fixed and times the section-8a hot path alone.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -53,7 +54,7 @@ def cpu_baseline(config, nsteps, physics=True):
     import oracle
     from roms_trunk_mgh_amd import ana, main3d
     st = ana.make_tile(config, perturb=1.0)
-    m = main3d.Main3D(oracle.Oracle(st), physics=physics)
+    m = main3d.Main3D(oracle.Oracle(st), physics=physics, diagnostics=physics)
     m.initial()
     m.step()                      # first step (forward Euler branch) untimed
     t0 = time.perf_counter()
@@ -149,7 +150,17 @@ def main():
         be = hip.RomsHip(st, rank=rank, device=device, nccl_unique_id=None if transport != "rccl" else uid)
         if transport == "relay":
             be.set_halo_relay_gloo(dist, torch)
-    m = main3d.Main3D(be, physics=args.physics)
+    m = main3d.Main3D(be, physics=args.physics, diagnostics=args.physics)      # NINFO == 1 (roms_benchmark3.in:257)
+    if world > 1 and args.physics:
+        # diag.F:398-420: the tile-local results are reduced over the ranks every time (mp_reduce / mp_reduce2)
+        tile_diag = be.diag
+
+        def global_diag(s_):
+            v = torch.from_numpy(tile_diag(s_))
+            allv = [torch.zeros(12, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(allv, v)
+            return main3d.reduce_diag(torch.stack(allv).numpy())
+        be.diag = global_diag
     m.initial()
     for _ in range(args.warmup):
         m.step()
@@ -175,7 +186,7 @@ def main():
     # ---- roofline of the dominant graded kernel: step3d_t (live hipEvent timing) ----
     be.timing(True)
     per_kernel = {}
-    names = ["bulk_flux", "set_vbc", "lmd_vmix", "set_massflux", "rho_eos", "omega", "set_zeta", "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile",
+    names = ["bulk_flux", "set_vbc", "lmd_vmix", "wvelocity", "diag", "set_massflux", "rho_eos", "omega", "set_zeta", "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile",
              "uv3dmix2", "step2d_loop", "set_depth", "step3d_uv", "step3d_t"]
     acc = {n: [] for n in names}
     for _ in range(5):
@@ -210,7 +221,7 @@ def main():
             "config": {"workload": f"{args.config} {b.Lm}x{b.Mm}x{b.N} NT={b.NT} "
                                    f"nonlinear 3-D step incl. {2 * st.p.nfast + 1} step2d calls, "
                                    f"U3/C4 tracer advection, fixed analytic forcing/mixing",
-                       "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "per_step_physics": "bulk_flux+set_vbc+lmd_vmix (KPP) on device" if args.physics
+                       "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "per_step_physics": "bulk_flux+set_vbc+lmd_vmix (KPP)+wvelocity+diag (NINFO=1) on device" if args.physics
                        else "fixed inputs", "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok},
             "roofline": {"kernel": "k_step3d_t_pipe (step3d_t_tile)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

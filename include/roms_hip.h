@@ -192,6 +192,14 @@ int roms_hip_bulk_flux(const roms_step_idx_t *s);
 int roms_hip_set_vbc(const roms_step_idx_t *s);
 /* lmd_vmix(ng,tile) = lmd_vmix_tile + lmd_skpp + lmd_finish   ROMS/Nonlinear/lmd_vmix.F:37 */
 int roms_hip_lmd_vmix(const roms_step_idx_t *s);
+/* wvelocity(ng,tile,nstp)          ROMS/Nonlinear/wvelocity.F:27     (main3d.F:475; writes wvel) */
+int roms_hip_wvelocity(const roms_step_idx_t *s);
+/* diag(ng,tile)                    ROMS/Nonlinear/diag.F:31          (main3d.F:314), the tile-local part
+ * diag.F:190-290 on time level nstp: out12 = { my_volume, my_avgke, my_avgpe, my_maxspeed, my_maxrho,
+ * my_max_C, my_max_Cu, my_max_Cv, my_max_Cw, my_max_Ci, my_max_Cj, my_max_Ck } (host memory; the call
+ * returns when they are there).  The reduction over tiles -- mp_reduce SUM/SUM/SUM/MAX/MAX and
+ * mp_reduce2 MAXLOC, diag.F:398-420 -- and the printing stay with the caller. */
+int roms_hip_diag(const roms_step_idx_t *s, double *out12);
 
 /* The whole barotropic loop LOOP_2D of main3d.F:592-700 in one call
  * (predictor/corrector sequencing done inside, optionally replayed from a

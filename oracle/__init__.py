@@ -16,7 +16,7 @@ _LIB = None
 
 KERNELS = ["set_massflux", "omega", "set_zeta", "set_depth", "rho_eos", "pre_step3d",
            "prsgrd", "t3dmix2", "rhs3d_tile", "uv3dmix2", "rhs3d", "step2d",
-           "step3d_uv", "step3d_t", "bulk_flux", "set_vbc", "lmd_vmix"]
+           "step3d_uv", "step3d_t", "bulk_flux", "set_vbc", "lmd_vmix", "wvelocity"]
 
 
 def build(force=False):
@@ -66,6 +66,19 @@ class Oracle:
         rc = fn(C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))
         if rc != 0:
             raise RuntimeError(f"oracle_{kernel} returned {rc}")
+
+    def diag(self, s):
+        import numpy as np
+        out = np.zeros(12)
+        dp = C.POINTER(C.c_double)
+        self.l.oracle_diag.restype = C.c_int
+        self.l.oracle_diag.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.StepIdx),
+                                       C.POINTER(abi.Fields), dp]
+        rc = self.l.oracle_diag(C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F),
+                                out.ctypes.data_as(dp))
+        if rc != 0:
+            raise RuntimeError(f"oracle_diag returned {rc}")
+        return out
 
     def step2d_loop(self, s, indx1):
         ii = C.c_int(indx1)

@@ -33,7 +33,8 @@ FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iouni
  Utility/set_weights Utility/mp_routines Utility/timers Nonlinear/prsgrd Nonlinear/t3dmix Nonlinear/uv3dmix Nonlinear/set_depth
   Nonlinear/set_massflux Nonlinear/rho_eos Nonlinear/set_zeta Nonlinear/mpdata_adiff
  Nonlinear/bc_2d Nonlinear/set_vbc Nonlinear/bulk_flux
- Nonlinear/bc_3d Utility/shapiro Nonlinear/lmd_swfrac Nonlinear/lmd_skpp Nonlinear/lmd_vmix"
+ Nonlinear/bc_3d Utility/shapiro Nonlinear/lmd_swfrac Nonlinear/lmd_skpp Nonlinear/lmd_vmix
+ Nonlinear/wvelocity Nonlinear/diag"
 
 build_app () {
   local APP=$1 hdr=$(echo $1 | tr A-Z a-z).h
@@ -51,6 +52,8 @@ build_app () {
      -I$HERE/ref_headers -I$REF/ROMS/Include -I$REF/ROMS/Nonlinear -I$REF/ROMS/Utility -I$REF/ROMS/Modules)
   local objs=""
   for f in $FILES; do
+    # SEAMOUNT defines ANA_DIAG: its diag.F wants analytical_mod, which this build does not carry
+    [ "$APP" = SEAMOUNT ] && [ "$f" = Nonlinear/diag ] && continue
     local bn=$(basename $f)
     cpp "${CPPF[@]}" $REF/ROMS/$f.F > $bn.f90
     $FC $FFLAGS -c $bn.f90 -o $bn.o > $bn.log 2>&1 || { echo "[$APP] $f failed"; tail -5 $bn.log; exit 1; }

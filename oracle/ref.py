@@ -82,3 +82,34 @@ class Ref:
         rc = self.l.ref_physics(kid, C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))
         if rc != 0:
             raise RuntimeError(f"ref_physics {kernel} rc={rc}")
+
+    def diagnostics(self, kernel, s, workdir="."):
+        """wvelocity (writes wvel) or diag through the reference's own module procedures.  diag keeps no
+        result (it prints and resets, diag.F:449-540); its report is captured from the file the wrapper
+        points `stdout` at and returned parsed: dict(avgke, avgpe, avgkp, volume, Ci, Cj, Ck, Cu, Cv, Cw,
+        maxspeed) at the printed precision (1pe14.6 / 1pe13.6)."""
+        import re
+        kid = {"wvelocity": 1, "diag": 2}[kernel]
+        self.l.ref_diagnostics.argtypes = [C.c_int, C.POINTER(abi.Bounds), C.POINTER(abi.Params),
+                                           C.POINTER(abi.StepIdx), C.POINTER(abi.Fields)]
+        cwd = os.getcwd()
+        os.chdir(workdir)
+        try:
+            rc = self.l.ref_diagnostics(kid, C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))
+            if rc != 0:
+                raise RuntimeError(f"ref_diagnostics {kernel} rc={rc}")
+            if kernel != "diag":
+                return None
+            text = open("ref_diag_stdout.txt").read()
+            os.remove("ref_diag_stdout.txt")
+        finally:
+            os.chdir(cwd)
+        num = r"[-+]?\d\.\d+E[-+]\d+"
+        m1 = re.search(r"^\s*(\d+) 0001-01-01 00:00:00\.00\s*(%s)\s*(%s)\s*(%s)\s*(%s)" % (num, num, num, num), text, re.M)
+        m2 = re.search(r"\((\d+),(\d+),(\d+)\)\s*(%s)\s*(%s)\s*(%s)\s*(%s)" % (num, num, num, num), text)
+        if not (m1 and m2):
+            raise RuntimeError("could not parse the reference's diag report:\n" + text)
+        return dict(istep=int(m1.group(1)), avgke=float(m1.group(2)), avgpe=float(m1.group(3)), avgkp=float(m1.group(4)),
+                    volume=float(m1.group(5)), Ci=int(m2.group(1)), Cj=int(m2.group(2)), Ck=int(m2.group(3)),
+                    Cu=float(m2.group(4)), Cv=float(m2.group(5)), Cw=float(m2.group(6)), maxspeed=float(m2.group(7)),
+                    text=text)

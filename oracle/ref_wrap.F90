@@ -62,7 +62,9 @@ MODULE ref_wrap_types
     TYPE(c_ptr) :: sustr, svstr, bustr, bvstr, srflx, stflx, btflx
     TYPE(c_ptr) :: rdrag2, stflux, btflux, Uwind, Vwind, Tair, Pair, Hair, rain, cloud
     TYPE(c_ptr) :: lrflx, lhflx, shflx, evap, hsbl, rdrag
+    TYPE(c_ptr) :: wvel
   END TYPE fields_t
+  LOGICAL, SAVE :: have_boundary = .FALSE.      ! allocate_boundary is done once per process
 END MODULE ref_wrap_types
 
 !-----------------------------------------------------------------------
@@ -373,7 +375,6 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   TYPE(fields_t), INTENT(in) :: F
   INTEGER(c_int) :: rc
   INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT
-  LOGICAL, SAVE :: have_boundary = .FALSE.
   REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:), a5(:,:,:,:,:)
   ng = 1; tile = 0
   LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
@@ -469,6 +470,89 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   CALL c_f_pointer (F%hsbl, a2, (/ni,nj/));     a2 = MIXING(ng)%hsbl
 #endif
 END FUNCTION ref_physics
+
+!-----------------------------------------------------------------------
+!  The two diagnostics main3d runs every step: kernel 1 = wvelocity (wvelocity.F:27, called as
+!  main3d.F:475 does: Ninp = nstp), 2 = diag (diag.F:31).  diag keeps nothing: it prints its results
+!  (diag.F:449-475, formats 1pe14.6 / 1pe13.6) and resets the sums, so its report is sent to the file
+!  ref_diag_stdout.txt in the working directory -- the reference's own output is the only observable.
+!  SEAMOUNT is an ANA_DIAG application: its diag.F needs analytical_mod (Functionals/analytical.F, the whole
+!  ana_*.h collection), which is not part of this build; diag is pinned on BENCHMARK and UPWELLING.
+FUNCTION ref_diagnostics (kernel, b, p, s, F) BIND(C, name='ref_diagnostics') RESULT(rc)
+  USE ref_wrap_types
+  USE mod_param
+  USE mod_parallel
+  USE mod_iounits
+  USE mod_scalars
+  USE mod_ncparam
+  USE mod_stepping
+  USE mod_grid
+  USE mod_ocean
+  USE mod_coupling
+  USE mod_boundary, ONLY : allocate_boundary
+  USE wvelocity_mod, ONLY : wvelocity
+#ifndef SEAMOUNT
+  USE diag_mod,      ONLY : diag
+#endif
+  INTEGER(c_int), VALUE :: kernel
+  TYPE(bounds_t), INTENT(in) :: b
+  TYPE(params_t), INTENT(in) :: p
+  TYPE(stepidx_t), INTENT(in) :: s
+  TYPE(fields_t), INTENT(in) :: F
+  INTEGER(c_int) :: rc
+  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, saved_stdout
+  REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:)
+  ng = 1; tile = 0
+  LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
+  ni = UBi-LBi+1; nj = UBj-LBj+1; NN = b%N
+  rc = 0
+  IF (.NOT. have_boundary) THEN
+    CALL allocate_boundary (ng)
+    have_boundary = .TRUE.
+  END IF
+  nstp(ng) = s%nstp; nnew(ng) = s%nnew; nrhs(ng) = s%nrhs; krhs(ng) = s%krhs
+  iic(ng) = s%iic; ntstart(ng) = s%ntfirst; ninfo(ng) = 1
+  rho0 = p%rho0; g = p%g; dt(ng) = p%dt
+  isBw3d = 6
+  LBC(isouth, isBw3d, ng)%closed = p%lbc_south == 1
+  LBC(inorth, isBw3d, ng)%closed = p%lbc_north == 1
+  CALL c_f_pointer (F%h, a2, (/ni,nj/));        GRID(ng)%h = a2
+  CALL c_f_pointer (F%pm, a2, (/ni,nj/));       GRID(ng)%pm = a2
+  CALL c_f_pointer (F%pn, a2, (/ni,nj/));       GRID(ng)%pn = a2
+  CALL c_f_pointer (F%omn, a2, (/ni,nj/));      GRID(ng)%omn = a2
+  CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
+  CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
+  CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); GRID(ng)%z_w = a3
+  CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   OCEAN(ng)%u = a4
+  CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   OCEAN(ng)%v = a4
+  CALL c_f_pointer (F%rho, a3, (/ni,nj,NN/));   OCEAN(ng)%rho = a3
+  CALL c_f_pointer (F%W, a3, (/ni,nj,NN+1/));   OCEAN(ng)%W = a3
+  CALL c_f_pointer (F%wvel, a3, (/ni,nj,NN+1/)); OCEAN(ng)%wvel = a3
+  CALL c_f_pointer (F%zeta, a3, (/ni,nj,3/));   OCEAN(ng)%zeta = a3
+  CALL c_f_pointer (F%ubar, a3, (/ni,nj,3/));   OCEAN(ng)%ubar = a3
+  CALL c_f_pointer (F%vbar, a3, (/ni,nj,3/));   OCEAN(ng)%vbar = a3
+  CALL c_f_pointer (F%DU_avg1, a2, (/ni,nj/));  COUPLING(ng)%DU_avg1 = a2
+  CALL c_f_pointer (F%DV_avg1, a2, (/ni,nj/));  COUPLING(ng)%DV_avg1 = a2
+  SELECT CASE (kernel)
+  CASE (1)
+    CALL wvelocity (ng, tile, nstp(ng))
+#ifndef SEAMOUNT
+  CASE (2)
+    saved_stdout = stdout
+    stdout = 77
+    OPEN (UNIT=77, FILE='ref_diag_stdout.txt', STATUS='REPLACE', ACTION='WRITE')
+    time_code(ng) = '0001-01-01 00:00:00.00'
+    max_speed = 1.0E+30_dp; max_rho = 1.0E+30_dp
+    CALL diag (ng, tile)
+    CLOSE (77)
+    stdout = saved_stdout
+#endif
+  CASE DEFAULT; rc = 2
+  END SELECT
+  CALL c_f_pointer (F%wvel, a3, (/ni,nj,NN+1/)); a3 = OCEAN(ng)%wvel
+  CALL c_f_pointer (F%DU_avg1, a2, (/ni,nj/));  a2 = COUPLING(ng)%DU_avg1
+  CALL c_f_pointer (F%DV_avg1, a2, (/ni,nj/));  a2 = COUPLING(ng)%DV_avg1
+END FUNCTION ref_diagnostics
 
 !-----------------------------------------------------------------------
 !  mpdata_adiff_tile (ROMS/Nonlinear/mpdata_adiff.F:38) on caller-held private

@@ -153,6 +153,7 @@ extern "C" int roms_hip_finalize(void)
   if (!g_ctx.inited) return 0;
   hipStreamSynchronize(g_ctx.stream);
   halo_finalize();
+  diag_release();
   for (int i = 0; i < FID_COUNT; i++) {
     if (g_ctx.dev[i]) hipFree(g_ctx.dev[i]);
     g_ctx.dev[i] = nullptr;

@@ -45,7 +45,7 @@ MODULE roms_hip_mod
  &    FID_bvstr=64, FID_srflx=65, FID_stflx=66, FID_btflx=67,                          &
  &    FID_rdrag2=68, FID_stflux=69, FID_btflux=70, FID_Uwind=71, FID_Vwind=72, FID_Tair=73,  &
  &    FID_Pair=74, FID_Hair=75, FID_rain=76, FID_cloud=77, FID_lrflx=78, FID_lhflx=79,      &
- &    FID_shflx=80, FID_evap=81, FID_hsbl=82, FID_rdrag=83
+ &    FID_shflx=80, FID_evap=81, FID_hsbl=82, FID_rdrag=83, FID_wvel=84
 
   INTERFACE
     INTEGER(c_int) FUNCTION roms_hip_init (rank, ntileI, ntileJ, device_id, uid)            &
@@ -156,6 +156,17 @@ MODULE roms_hip_mod
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
     END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_wvelocity (s) BIND(C, name='roms_hip_wvelocity')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    !  tile-local part of diag_tile; out12 = my_volume, my_avgke, my_avgpe, my_maxspeed, my_maxrho,
+    !  my_max_C, my_max_Cu, my_max_Cv, my_max_Cw, my_max_Ci, my_max_Cj, my_max_Ck (diag.F:190-290)
+    INTEGER(c_int) FUNCTION roms_hip_diag (s, out12) BIND(C, name='roms_hip_diag')
+      IMPORT :: c_int, c_double, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+      REAL(c_double), INTENT(out) :: out12(12)
+    END FUNCTION
   END INTERFACE
 
   PUBLIC :: roms_hip_init, roms_hip_finalize, roms_hip_get_unique_id
@@ -165,6 +176,7 @@ MODULE roms_hip_mod
   PUBLIC :: roms_hip_set_massflux, roms_hip_rho_eos, roms_hip_omega, roms_hip_set_zeta
   PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
   PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc, roms_hip_lmd_vmix
+  PUBLIC :: roms_hip_wvelocity, roms_hip_diag
   PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
 
 CONTAINS

@@ -19,7 +19,7 @@ _LIB = None
 
 ENTRIES = ["set_massflux", "rho_eos", "omega", "set_zeta", "set_depth", "rhs3d",
            "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile", "uv3dmix2", "step2d",
-           "step3d_uv", "step3d_t", "bulk_flux", "set_vbc", "lmd_vmix"]
+           "step3d_uv", "step3d_t", "bulk_flux", "set_vbc", "lmd_vmix", "wvelocity"]
 
 # every symbol include/roms_hip.h declares
 DECLARED_SYMBOLS = (
@@ -28,7 +28,7 @@ DECLARED_SYMBOLS = (
      "roms_hip_sync_to_host", "roms_hip_sync_all_to_device", "roms_hip_sync_all_to_host",
      "roms_hip_device_ptr", "roms_hip_device_synchronize", "roms_hip_last_error",
      "roms_hip_step2d_loop", "roms_hip_exchange", "roms_hip_timing_enable",
-     "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay"] + ["roms_hip_" + e for e in ENTRIES])
+     "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay", "roms_hip_diag"] + ["roms_hip_" + e for e in ENTRIES])
 
 
 _DP = C.POINTER(C.c_double)
@@ -116,6 +116,14 @@ class RomsHip:
 
     def call(self, kernel, s):
         self._chk(getattr(self.l, "roms_hip_" + kernel)(C.byref(s)), kernel)
+
+    def diag(self, s):
+        """Tile-local sums and maxima of diag_tile (diag.F:190-290) as a 12-vector, see roms_hip.h."""
+        import numpy as np
+        out = np.zeros(12)
+        self.l.roms_hip_diag.argtypes = [C.POINTER(abi.StepIdx), _DP]
+        self._chk(self.l.roms_hip_diag(C.byref(s), out.ctypes.data_as(_DP)), "diag")
+        return out
 
     def step2d_loop(self, s, indx1):
         ii = C.c_int(indx1)

@@ -8,9 +8,9 @@ because the full Fortran executable cannot be linked in this environment
 against either backend (`hip.RomsHip` = the product, or the CPU oracle in tests):
 
     main3d.F:189-191  nstp/nnew/nrhs rotation
-    main3d.F:307-309  set_massflux, rho_eos            (diag: not on the path)
+    main3d.F:307-314  set_massflux, rho_eos, diag      (diag: diagnostics=True, every ninfo steps)
     main3d.F:388-394  bulk_flux, set_vbc               (physics=True; else fixed forcing inputs)
-    main3d.F:467-475  lmd_vmix (physics=True; else fixed mixing inputs); omega
+    main3d.F:467-475  lmd_vmix (physics=True; else fixed mixing inputs); omega; wvelocity (diagnostics=True)
     main3d.F:489      set_zeta
     main3d.F:563      rhs3d
     main3d.F:592-700  LOOP_2D (predictor/corrector step2d)
@@ -24,13 +24,20 @@ from . import abi
 
 
 class Main3D:
-    def __init__(self, backend, ntstart=1, physics=False):
+    def __init__(self, backend, ntstart=1, physics=False, diagnostics=False, ninfo=1):
         """physics=True also runs the per-step physics that is on the device:
         bulk_flux and lmd_vmix (BULK_FLUXES / LMD_MIXING applications, i.e. BENCHMARK) and set_vbc, in
         the reference's order;
-        with physics=False their outputs stay the fixed fields ana.py filled in."""
+        with physics=False their outputs stay the fixed fields ana.py filled in.
+        diagnostics=True adds the two diagnostics the reference's step carries: wvelocity after the
+        first omega (main3d.F:475) and, every `ninfo` steps, the tile-local part of diag after rho_eos
+        (main3d.F:314; it therefore sees the wvel of the previous step, as in the reference); the
+        12-vector of the last call is kept in `last_diag` (layout: roms_hip.h, roms_hip_diag)."""
         self.be = backend
         self.physics = physics
+        self.diagnostics = diagnostics
+        self.ninfo = ninfo
+        self.last_diag = None
         self.iic = ntstart
         self.ntstart = ntstart
         self.ntfirst = ntstart
@@ -60,6 +67,8 @@ class Main3D:
         s = self.s
         be.call("set_massflux", s)
         be.call("rho_eos", s)
+        if self.diagnostics and (self.iic - 1) % self.ninfo == 0:
+            self.last_diag = be.diag(s)
         if self.physics:
             bench_app = getattr(be.st, "cfg", {}).get("app") == "BENCHMARK"
             if bench_app:                     # BULK_FLUXES
@@ -68,6 +77,8 @@ class Main3D:
             if bench_app:                     # LMD_MIXING
                 be.call("lmd_vmix", s)
         be.call("omega", s)
+        if self.diagnostics:
+            be.call("wvelocity", s)
         be.call("set_zeta", s)
         be.call("rhs3d", s)
         self.indx1 = be.step2d_loop(s, self.indx1)
@@ -80,3 +91,16 @@ class Main3D:
     def run(self, nsteps):
         for _ in range(nsteps):
             self.step()
+
+
+def reduce_diag(vectors):
+    """Combine the tile-local 12-vectors of `diag` the way diag.F:398-420 does across ranks: SUM of
+    volume, avgke, avgpe; MAX of maxspeed, maxrho; MAXLOC of the Courant number (the tile holding the
+    largest max_C supplies Cu, Cv, Cw and the location)."""
+    import numpy as np
+    v = np.asarray(vectors, dtype=float).reshape(-1, 12)
+    out = np.zeros(12)
+    out[0:3] = v[:, 0:3].sum(axis=0)
+    out[3:5] = v[:, 3:5].max(axis=0)
+    out[5:12] = v[int(np.argmax(v[:, 5])), 5:12]
+    return out

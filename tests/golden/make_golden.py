@@ -26,6 +26,12 @@ OVERRIDES = {"BENCHMARK_TINY": {"tnu2": 300.0, "visc2": 800.0}, "UPWELLING": {"t
 KERNELS = ["set_depth", "set_massflux", "set_zeta", "rho_eos", "prsgrd", "t3dmix2", "uv3dmix2"]
 # per-step physics; bulk_flux exists in the BULK_FLUXES application (BENCHMARK) only
 PHYSICS = ["set_vbc", "bulk_flux", "lmd_vmix"]
+# diagnostics of every step: wvelocity (writes wvel), then diag on the state wvelocity left; diag keeps
+# nothing but its printed report (diag.F:449-475), which is stored as
+# [avgke, avgpe, avgkp, volume, Ci, Cj, Ck, Cu, Cv, Cw, maxspeed] at the printed 7 digits (not SEAMOUNT:
+# an ANA_DIAG application, see oracle/ref_wrap.F90)
+DIAGNOSTICS = ["wvelocity"]
+DIAG_KEYS = ["avgke", "avgpe", "avgkp", "volume", "Ci", "Cj", "Ck", "Cu", "Cv", "Cw", "maxspeed"]
 
 
 def input_state(config):
@@ -64,7 +70,7 @@ def child(config):
     out["nfast"] = np.array(nf)
     out["weight1"], out["weight2"] = w1, w2
     s = util.step_idx()
-    for k in KERNELS + PHYSICS:
+    for k in KERNELS + PHYSICS + DIAGNOSTICS:
         if k == "uv3dmix2" and config == "SEAMOUNT":
             continue
         if k in ("bulk_flux", "lmd_vmix") and not config.startswith("BENCHMARK"):
@@ -72,6 +78,12 @@ def child(config):
         st = st0.copy()
         if k in PHYSICS:
             ref.Ref(st).physics(k, s)
+        elif k in DIAGNOSTICS:
+            r = ref.Ref(st)
+            r.diagnostics(k, s, HERE)
+            if config != "SEAMOUNT":
+                d = r.diagnostics("diag", s, HERE)
+                out["diag_report"] = np.array([float(d[q]) for q in DIAG_KEYS])
         else:
             ref.Ref(st).call(k, s)
         for name, kind, _ in abi.FIELDS:

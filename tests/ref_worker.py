@@ -107,8 +107,35 @@ def main_physics(config):
     print(json.dumps(out))
 
 
+def main_diag(config):
+    """wvelocity (bit for bit on wvel and on the exchanged DU_avg1/DV_avg1) and diag (the reference keeps
+    only its printed report: compared at the printed 7 digits) -- reference Fortran vs C oracle."""
+    import tempfile
+    import oracle
+    import util
+    from oracle import ref
+    st0 = util.prepared_state(config)
+    s = util.step_idx()
+    st_r, st_o = st0.copy(), st0.copy()
+    R, O = ref.Ref(st_r), oracle.Oracle(st_o)
+    tmp = tempfile.mkdtemp()
+    R.diagnostics("wvelocity", s, tmp)
+    O.call("wvelocity", s)
+    out = {"wvel_diff": float(np.abs(st_r["wvel"] - st_o["wvel"]).max()), "wvel_amax": float(np.abs(st_r["wvel"]).max()),
+           "DU_equal": bool(np.array_equal(st_r["DU_avg1"], st_o["DU_avg1"]) and np.array_equal(st_r["DV_avg1"], st_o["DV_avg1"]))}
+    if config != "SEAMOUNT":
+        d = R.diagnostics("diag", s, tmp)
+        v = O.diag(s)
+        mine = dict(avgke=v[1] / v[0], avgpe=v[2] / v[0], volume=v[0], Cu=v[6], Cv=v[7], Cw=v[8], maxspeed=v[3])
+        out["diag_rel"] = {k: abs(mine[k] - d[k]) / abs(d[k]) for k in mine}
+        out["diag_loc"] = [[int(v[9]), int(v[10]), int(v[11])], [d["Ci"], d["Cj"], d["Ck"]]]
+    print(json.dumps(out))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "physics":
+    if len(sys.argv) > 2 and sys.argv[2] == "diag":
+        main_diag(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "physics":
         main_physics(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mpdata":
         main_mpdata(sys.argv[1])

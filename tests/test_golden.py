@@ -39,6 +39,17 @@ def _check(st, st0, g, kernel, tol=0.0):
     assert worst <= tol, (kernel, worst)
 
 
+def _check_diag(v, report):
+    """v = the 12-vector of diag (roms_hip.h); report = what the reference printed for one tile:
+    avgke/volume, avgpe/volume, their sum, volume, (Ci,Cj,Ck), Cu, Cv, Cw, maxspeed -- 7 digits."""
+    mine = [v[1] / v[0], v[2] / v[0], v[1] / v[0] + v[2] / v[0], v[0], v[9], v[10], v[11], v[6], v[7], v[8], v[3]]
+    for q, (a, b) in enumerate(zip(mine, report)):
+        if q in (4, 5, 6):
+            assert int(a) == int(b), (q, a, b)
+        else:
+            assert abs(a - b) <= 6e-7 * abs(b), (q, a, b)
+
+
 @pytest.mark.parametrize("config", CONFIGS)
 def test_oracle_reproduces_reference_vectors(config):
     import oracle
@@ -61,6 +72,13 @@ def test_oracle_reproduces_reference_vectors(config):
         st = st0.copy()
         oracle.Oracle(st).call(k, s)
         _check(st, st0, g, k, tol=1e-13 if k in ("bulk_flux", "lmd_vmix") else 0.0)
+    # diagnostics: wvelocity bit for bit, then diag on that state against the reference's printed report
+    st = st0.copy()
+    o = oracle.Oracle(st)
+    o.call("wvelocity", s)
+    _check(st, st0, g, "wvelocity", tol=0.0)
+    if "diag_report" in g.files:
+        _check_diag(o.diag(s), g["diag_report"])
 
 
 @pytest.mark.gpu
@@ -82,6 +100,17 @@ def test_hip_reproduces_reference_vectors(config):
         finally:
             h.close()
         _check(st, st0, g, k, tol={"bulk_flux": 1e-11, "lmd_vmix": 1e-10}.get(k, 1e-13))
+    st = st0.copy()
+    h = hip.RomsHip(st)
+    try:
+        h.call("wvelocity", s)
+        d = h.diag(s)
+        h.to_host()
+    finally:
+        h.close()
+    _check(st, st0, g, "wvelocity", tol=0.0)
+    if "diag_report" in g.files:
+        _check_diag(d, g["diag_report"])
 
 
 def test_oracle_reproduces_reference_mpdata_adiff():

@@ -215,6 +215,51 @@ def test_lmd_vmix():
     assert float(hs.max()) > float(hs.min())
 
 
+@pytest.mark.parametrize("config", CONFIGS)
+def test_wvelocity_and_diag(config):
+    """The two diagnostics of every step.  wvelocity: bit for bit.  diag: the three sums are
+    accumulated in the reference's order (k per column, then j, then i) and the Courant maximum is found
+    in its loop order, so the twelve numbers are equal as well."""
+    import oracle
+    st0 = util.prepared_state(config)
+    _detune(st0)
+    s = util.step_idx()
+    st_o, st_h = st0.copy(), st0.copy()
+    o = oracle.Oracle(st_o)
+    o.call("wvelocity", s)
+    d_o = o.diag(s)
+    h = hip.RomsHip(st_h)
+    try:
+        h.call("wvelocity", s)
+        d_h = h.diag(s)
+        h.to_host()
+    finally:
+        h.close()
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v == 0.0 for v in diffs.values()), diffs
+    assert float(np.abs(st_o["wvel"]).max()) > 0.0
+    assert d_o[5] > 0.0 and d_o[8] > 0.0, d_o              # a Courant maximum with a vertical part exists
+    assert np.array_equal(d_h, d_o), (d_h, d_o)
+
+
+def test_diag_at_rest():
+    """All velocities zero: no Courant number exceeds zero, so the location stays (0,0,0) as in the
+    reference's strict comparison."""
+    import oracle
+    st0 = util.prepared_state("SEAMOUNT")
+    for n in ("u", "v", "wvel", "ubar", "vbar"):
+        st0[n][...] = 0.0
+    s = util.step_idx()
+    d_o = oracle.Oracle(st0.copy()).diag(s)
+    h = hip.RomsHip(st0.copy())
+    try:
+        d_h = h.diag(s)
+    finally:
+        h.close()
+    assert list(d_o[5:12]) == [0.0] * 7
+    assert np.array_equal(d_h, d_o), (d_h, d_o)
+
+
 @pytest.mark.parametrize("N", [40, 64])
 @pytest.mark.parametrize("kernel", ["step3d_t", "pre_step3d", "step3d_uv", "omega", "rhs3d"])
 def test_more_than_32_levels(kernel, N):

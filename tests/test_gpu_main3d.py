@@ -20,22 +20,23 @@ def _run(config, nsteps, perturb, physics=False):
     import oracle
     st_o = ana.make_tile(config, perturb=perturb)
     st_h = st_o.copy()
-    mo = main3d.Main3D(oracle.Oracle(st_o), physics=physics)
+    mo = main3d.Main3D(oracle.Oracle(st_o), physics=physics, diagnostics=physics)
     mo.initial()
     mo.run(nsteps)
     if os.environ.get("ROMS_TEST_DRY"):
-        mh = main3d.Main3D(oracle.Oracle(st_h), physics=physics)
+        mh = main3d.Main3D(oracle.Oracle(st_h), physics=physics, diagnostics=physics)
         mh.initial()
         mh.run(nsteps)
     else:
         be = hip.RomsHip(st_h)
         try:
-            mh = main3d.Main3D(be, physics=physics)
+            mh = main3d.Main3D(be, physics=physics, diagnostics=physics)
             mh.initial()
             mh.run(nsteps)
             be.to_host()
         finally:
             be.close()
+    mo.hip_last_diag = mh.last_diag
     return st_h, st_o, mo
 
 
@@ -58,6 +59,12 @@ def test_100_steps(config, perturb, physics):
     assert all(v <= TOL for v in out.values()), out
     # the run must have done something
     assert float(np.abs(st_o["u"]).max()) > 1e-6
+    if physics:
+        # diag of step 100 (wvelocity + diag ran every step, as main3d.F:314/475 do): energies and volume to the
+        # tolerance of the fields; the Courant maximum is a max over nearly equal candidates, so only its value
+        d_h, d_o = mo.hip_last_diag, mo.last_diag
+        assert d_o is not None and d_o[1] > 0.0
+        assert all(abs(d_h[q] - d_o[q]) <= 1e-9 * abs(d_o[q]) for q in (0, 1, 2, 3, 4, 5)), (d_h, d_o)
 
 
 def test_20_steps_48_levels():
