@@ -166,58 +166,79 @@ k_diag_rows(const RomsDev *__restrict__ c, DiagScratch w, double *__restrict__ R
   R[R_SPD * nI + o] = mspd; R[R_RHO * nI + o] = mrho;
 }
 
-// diag.F:281-290 and the loop-order rule of the Courant maximum: serial in i.  One workgroup: the partial
-// results are staged in LDS chunk by chunk by all threads, thread 0 accumulates in order.
+// diag.F:281-290, one workgroup.  The three sums are serial in i (the reference's order): the partial rows are
+// staged in LDS chunk by chunk and three wavefronts run one chain each, 16 values per round.  The maxima need no
+// order: "first strict maximum in loop order" = the largest C, ties to the smallest j, then the largest k, then
+// the smallest i -- a total order, so all threads scan a share and an LDS tree finishes.
 #define DIAG_CH 512
+struct DiagBest { double C, Cu, Cv, Cw; int i, j, k; };
+__device__ __forceinline__ bool diag_better(const DiagBest &x, const DiagBest &y)     // x ahead of y?
+{
+  if (x.C != y.C) return x.C > y.C;
+  if (!(x.C > 0.0)) return false;                     // nothing exceeds zero: keep (0,0,0)
+  if (x.j != y.j) return x.j < y.j;
+  if (x.k != y.k) return x.k > y.k;
+  return x.i < y.i;
+}
 __global__ void __launch_bounds__(256)
 k_diag_final(const RomsDev *__restrict__ c, const double *__restrict__ R, double *__restrict__ out)
 {
   const roms_bounds_t &b = c->b;
-  __shared__ double sR[R_COUNT * DIAG_CH];
+  __shared__ double sR[3 * DIAG_CH];
+  __shared__ DiagBest sB[256];
+  __shared__ double sSpd[256], sRho[256];
   const int nI = b.Iend - b.Istr + 1;
-  double vol = 0.0, pe = 0.0, ke = 0.0, mC = 0.0, mCu = 0.0, mCv = 0.0, mCw = 0.0, mspd = 0.0, mrho = -1.0E+37;
-  int mi = 0, mj = 0, mk = 0;
+  const int tid = threadIdx.x;
+  // ---- maxima ----
+  DiagBest best{0.0, 0.0, 0.0, 0.0, 0, 0, 0};
+  double mspd = 0.0, mrho = -1.0E+37;
+  for (int o = tid; o < nI; o += 256) {
+    DiagBest x{R[R_C * nI + o], R[R_CU * nI + o], R[R_CV * nI + o], R[R_CW * nI + o], b.Istr + o,
+               (int)R[R_CJ * nI + o], (int)R[R_CK * nI + o]};
+    if (diag_better(x, best)) best = x;
+    mspd = fmax(mspd, R[R_SPD * nI + o]);
+    mrho = fmax(mrho, R[R_RHO * nI + o]);
+  }
+  sB[tid] = best; sSpd[tid] = mspd; sRho[tid] = mrho;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (tid < st) {
+      if (diag_better(sB[tid + st], sB[tid])) sB[tid] = sB[tid + st];
+      sSpd[tid] = fmax(sSpd[tid], sSpd[tid + st]);
+      sRho[tid] = fmax(sRho[tid], sRho[tid + st]);
+    }
+    __syncthreads();
+  }
+  // ---- sums, serial in i ----
+  double acc = 0.0;
+  const int chain = tid / 64;                         // wavefront 0: volume, 1: potential, 2: kinetic energy
   for (int o0 = 0; o0 < nI; o0 += DIAG_CH) {
     const int n = (nI - o0 < DIAG_CH) ? nI - o0 : DIAG_CH;
     __syncthreads();
-    for (int e = threadIdx.x; e < R_COUNT * DIAG_CH; e += blockDim.x) {
+    for (int e = tid; e < 3 * DIAG_CH; e += 256) {
       const int r = e / DIAG_CH, q = e % DIAG_CH;
-      if (q < n) sR[e] = R[r * nI + o0 + q];
+      sR[e] = (q < n) ? R[(r == 0 ? R_VOL : (r == 1 ? R_PE : R_KE)) * nI + o0 + q] : 0.0;
     }
     __syncthreads();
-    // four independent serial chains, one per wavefront: volume, potential energy, kinetic energy, maxima
-    if (threadIdx.x == 0) {
-#pragma unroll 8
-      for (int q = 0; q < n; q++) vol = vol + sR[R_VOL * DIAG_CH + q];
-    } else if (threadIdx.x == 64) {
-#pragma unroll 8
-      for (int q = 0; q < n; q++) pe = pe + sR[R_PE * DIAG_CH + q];
-    } else if (threadIdx.x == 128) {
-#pragma unroll 8
-      for (int q = 0; q < n; q++) ke = ke + sR[R_KE * DIAG_CH + q];
-    } else if (threadIdx.x == 192) {
-      for (int q = 0; q < n; q++) {
-        const double C = sR[R_C * DIAG_CH + q];
-        const int cj = (int)sR[R_CJ * DIAG_CH + q], ck = (int)sR[R_CK * DIAG_CH + q];
-        // the reference meets (j,k,i) with j ascending, then k descending, then i ascending and keeps the
-        // first strict maximum: among equal maxima the one met first wins
-        const bool earlier = (cj < mj) || (cj == mj && ck > mk);
-        if (C > mC || (C == mC && C > 0.0 && earlier)) {
-          mC = C; mCu = sR[R_CU * DIAG_CH + q]; mCv = sR[R_CV * DIAG_CH + q]; mCw = sR[R_CW * DIAG_CH + q];
-          mi = b.Istr + o0 + q; mj = cj; mk = ck;
-        }
-        mspd = fmax(mspd, sR[R_SPD * DIAG_CH + q]);
-        mrho = fmax(mrho, sR[R_RHO * DIAG_CH + q]);
+    if ((tid & 63) == 0 && chain < 3) {
+      const double *src = sR + chain * DIAG_CH;
+      for (int q0 = 0; q0 < n; q0 += 16) {
+        double t[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) t[q] = src[q0 + q < DIAG_CH ? q0 + q : DIAG_CH - 1];
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+          if (q0 + q < n) acc = acc + t[q];
       }
     }
   }
-  if (threadIdx.x == 0) out[0] = vol;
-  if (threadIdx.x == 64) out[2] = pe;
-  if (threadIdx.x == 128) out[1] = ke;
-  if (threadIdx.x == 192) {
-    out[3] = mspd; out[4] = mrho;
-    out[5] = mC; out[6] = mCu; out[7] = mCv; out[8] = mCw;
-    out[9] = (double)mi; out[10] = (double)mj; out[11] = (double)mk;
+  if (tid == 0) out[0] = acc;
+  if (tid == 64) out[2] = acc;
+  if (tid == 128) out[1] = acc;
+  if (tid == 192) {
+    out[3] = sSpd[0]; out[4] = sRho[0];
+    out[5] = sB[0].C; out[6] = sB[0].Cu; out[7] = sB[0].Cv; out[8] = sB[0].Cw;
+    out[9] = (double)sB[0].i; out[10] = (double)sB[0].j; out[11] = (double)sB[0].k;
   }
 }
 
