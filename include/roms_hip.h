@@ -151,6 +151,13 @@ int roms_hip_sync_to_device(int field_id);
 int roms_hip_sync_to_host(int field_id);
 int roms_hip_sync_all_to_device(void);
 int roms_hip_sync_all_to_host(void);
+/* Asynchronous snapshot for the unchanged output / wrt_his / wrt_rst (ROMS/Nonlinear/output.F:123-208):
+ * begin() copies the n listed fields aside on the device (ordered with the kernels already issued) and starts
+ * their transfer to the registered host arrays on a second stream, then returns; the step loop may go on and
+ * overwrite the fields.  end() waits for the transfer: the host arrays then hold the fields as they were at
+ * begin().  One snapshot in flight at a time; the host arrays must not be read or written in between. */
+int roms_hip_snapshot_begin(const int *field_ids, int n);
+int roms_hip_snapshot_end(void);
 /* Device address of a field mirror (for zero-copy consumers); NULL if none. */
 double *roms_hip_device_ptr(int field_id);
 int roms_hip_device_synchronize(void);

@@ -152,6 +152,7 @@ extern "C" int roms_hip_finalize(void)
 {
   if (!g_ctx.inited) return 0;
   hipStreamSynchronize(g_ctx.stream);
+  snapshot_release();
   halo_finalize();
   diag_release();
   for (int i = 0; i < FID_COUNT; i++) {

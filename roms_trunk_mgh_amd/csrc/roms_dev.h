@@ -188,5 +188,6 @@ int bc_u3d(int nout);
 int bc_v3d(int nout);
 int bc_t3d(int nout, int itrc);
 int bc_w3d(double *A);
+void snapshot_release();                  // snapshot.hip: waits for and frees an in-flight snapshot
 void diag_release();                      // k_diag.hip: frees the buffers of roms_hip_diag
 int check_lbc();

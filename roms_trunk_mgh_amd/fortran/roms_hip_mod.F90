@@ -156,6 +156,15 @@ MODULE roms_hip_mod
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
     END FUNCTION
+    !  asynchronous snapshot for output / wrt_his / wrt_rst: ids(n) = FID_* of the fields wanted
+    INTEGER(c_int) FUNCTION roms_hip_snapshot_begin (ids, n) BIND(C, name='roms_hip_snapshot_begin')
+      IMPORT :: c_int
+      INTEGER(c_int), INTENT(in) :: ids(*)
+      INTEGER(c_int), VALUE :: n
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_snapshot_end () BIND(C, name='roms_hip_snapshot_end')
+      IMPORT :: c_int
+    END FUNCTION
     INTEGER(c_int) FUNCTION roms_hip_wvelocity (s) BIND(C, name='roms_hip_wvelocity')
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
@@ -176,7 +185,7 @@ MODULE roms_hip_mod
   PUBLIC :: roms_hip_set_massflux, roms_hip_rho_eos, roms_hip_omega, roms_hip_set_zeta
   PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
   PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc, roms_hip_lmd_vmix
-  PUBLIC :: roms_hip_wvelocity, roms_hip_diag
+  PUBLIC :: roms_hip_wvelocity, roms_hip_diag, roms_hip_snapshot_begin, roms_hip_snapshot_end
   PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
 
 CONTAINS

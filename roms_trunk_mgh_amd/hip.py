@@ -28,7 +28,8 @@ DECLARED_SYMBOLS = (
      "roms_hip_sync_to_host", "roms_hip_sync_all_to_device", "roms_hip_sync_all_to_host",
      "roms_hip_device_ptr", "roms_hip_device_synchronize", "roms_hip_last_error",
      "roms_hip_step2d_loop", "roms_hip_exchange", "roms_hip_timing_enable",
-     "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay", "roms_hip_diag"] + ["roms_hip_" + e for e in ENTRIES])
+     "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay", "roms_hip_diag",
+     "roms_hip_snapshot_begin", "roms_hip_snapshot_end"] + ["roms_hip_" + e for e in ENTRIES])
 
 
 _DP = C.POINTER(C.c_double)
@@ -116,6 +117,15 @@ class RomsHip:
 
     def call(self, kernel, s):
         self._chk(getattr(self.l, "roms_hip_" + kernel)(C.byref(s)), kernel)
+
+    def snapshot_begin(self, names):
+        """Start an asynchronous device-to-host snapshot of the named fields (roms_hip.h)."""
+        ids = (C.c_int * len(names))(*[abi.FIELD_ID[n] for n in names])
+        self.l.roms_hip_snapshot_begin.argtypes = [C.POINTER(C.c_int), C.c_int]
+        self._chk(self.l.roms_hip_snapshot_begin(ids, len(names)), "snapshot_begin")
+
+    def snapshot_end(self):
+        self._chk(self.l.roms_hip_snapshot_end(), "snapshot_end")
 
     def diag(self, s):
         """Tile-local sums and maxima of diag_tile (diag.F:190-290) as a 12-vector, see roms_hip.h."""

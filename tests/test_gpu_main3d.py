@@ -88,3 +88,37 @@ def test_20_steps_48_levels():
         assert rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], FLOOR[name]) <= TOL
     for it in range(st_o.b.NT):
         assert rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], FLOOR["t"]) <= TOL
+
+
+def test_async_snapshot():
+    """a snapshot started after step 5 and collected after step 8 holds the state of step 5,
+    whatever the steps in between did to the device fields."""
+    names = ["zeta", "ubar", "vbar", "u", "v", "t"]
+    st_a = ana.make_tile("BENCHMARK_TINY", perturb=1.0)
+    st_b = st_a.copy()
+    be = hip.RomsHip(st_a)
+    try:
+        m = main3d.Main3D(be, physics=True)
+        m.initial()
+        m.run(5)
+        be.to_host(names)                      # synchronous reference copy of step 5
+        want = {n: st_a[n].copy() for n in names}
+    finally:
+        be.close()
+    be = hip.RomsHip(st_b)
+    try:
+        m = main3d.Main3D(be, physics=True)
+        m.initial()
+        m.run(5)
+        be.snapshot_begin(names)
+        m.run(3)                               # overwrites every snapshotted field on the device
+        be.snapshot_end()
+        got = {n: st_b[n].copy() for n in names}
+        be.snapshot_begin(["zeta"])            # a second one reuses the staging buffers
+        be.snapshot_end()
+        be.to_host(["t"])
+        assert not np.array_equal(st_b["t"], got["t"])         # the device had really moved on
+    finally:
+        be.close()
+    for n in names:
+        assert np.array_equal(got[n], want[n]), n
