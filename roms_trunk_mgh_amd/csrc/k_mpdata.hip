@@ -15,6 +15,7 @@
 // module extents (LBi:UBi,LBj:UBj) -- a superset of the reference's private IminS:ImaxS
 // extents with three ghost points.  oHz and odz are recomputed where they are used (the
 // same IEEE division, so the same bits).  Expressions keep the reference's association.
+#include <cstdlib>
 #include "roms_dev.h"
 
 int roms_entry_check(const char *name);
@@ -26,12 +27,38 @@ namespace {
 
 struct MpArgs {
   double *Ta, *Ua, *Va, *Wa, *bup, *bdn;   // scratch, module horizontal extents
+  const double *oHz, *odz;                 // 1/Hz and 1/(z_r(k+1)-z_r(k)), k_mp_metrics (once per step3d_t call)
   int nnew, itrc;
 };
 
 __device__ __forceinline__ double upstream(double flx, double a, double b)
 {
   return fmax(flx, 0.0) * a + fmin(flx, 0.0) * b;
+}
+
+// ------------------------------------------------------- K0: oHz, odz ----
+// mpdata_adiff.F:150-168 keeps oHz and odz in private arrays; here once per step3d_t call for all MPDATA
+// tracers (Hz and z_r do not change in between).  k_mp_adiff is bound by FP64 division throughput: with
+// the reciprocals recomputed at every use it spent half of its divisions on these two.
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_mp_metrics(const RomsDev *__restrict__ c, double *__restrict__ oHz, double *__restrict__ odz)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.LBi + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.LBj + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.UBi || j > b.UBj) return;
+  const gcd_t Hz = (gcd_t)c->F.Hz, z_r = (gcd_t)c->F.z_r;
+  const long a2 = I2(i, j);
+  double zr = z_r[a2];
+  for (int k = 1; k <= N; k++) {
+    const long a = a2 + (long)(k - 1) * nij;
+    oHz[a] = 1.0 / Hz[a];
+    if (k < N) {
+      const double zu = z_r[a + nij];
+      odz[a] = 1.0 / (zu - zr);
+      zr = zu;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- K1: Ta ----
@@ -76,13 +103,13 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
 // ------------------------------------------------- K2: Ua, Va, Wa (raw) ----
 // vertical-gradient factor C and mean vertical Courant number Wm of a face between
 // column p (offset 0) and column q (offset dq), mpdata_adiff.F:262-310 / :456-504
-__device__ __forceinline__ void face_CW(const gcd_t Ta, const gcd_t z_r, const gcd_t Wv, const double *__restrict__ pm,
-                                        const double *__restrict__ pn, long a2, long a, long dq, long nij, int k, int N,
+__device__ __forceinline__ void face_CW(const gcd_t Ta, const gcd_t z_r, const gcd_t odzA, const gcd_t Wv, const gcd_t pm,
+                                        const gcd_t pn, long a2, long a, long dq, long nij, int k, int N,
                                         double dt, double &C, double &Wm)
 {
   // a = index of (p,k) in rho arrays, a2 = 2-D index of p; q = p + dq
   const long aq = a + dq, a2q = a2 + dq;
-  auto odz = [&](long x) { return 1.0 / (z_r[x + nij] - z_r[x]); };       // odz at level of x
+  auto odz = [&](long x) { return odzA[x]; };                             // odz at level of x
   const long w = a + nij, wq = aq + nij;      // W(.,.,k) of a K_3DW array = rho index + nij
   if (k == 1) {
     C = 0.25 * ((Ta[a + nij] - Ta[a]) * odz(a) + (Ta[aq + nij] - Ta[aq]) * odz(aq)) *
@@ -103,6 +130,9 @@ __device__ __forceinline__ void face_CW(const gcd_t Ta, const gcd_t z_r, const g
   }
 }
 
+// One launch for the three faces (they share the Ta, Huon, Hvom, oHz loads): 208 VGPRs, two waves per SIMD.
+// The kernel is FP64-issue bound (per cell and level ~1800 VALU instructions, 49 divisions among them); one
+// launch per face raises the occupancy to 3-4 waves but repeats the shared loads and was 20 % slower.
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
 {
@@ -118,12 +148,12 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
   const gcd_t Ta = (gcd_t)m.Ta;
   const gcd_t z_r = (gcd_t)c->F.z_r, Wv = (gcd_t)c->F.W, Hz = (gcd_t)c->F.Hz;
   const gcd_t Huon = (gcd_t)c->F.Huon, Hvom = (gcd_t)c->F.Hvom;
-  const double *__restrict__ pm = c->F.pm, *__restrict__ pn = c->F.pn;
-  const double *__restrict__ on_v = c->F.on_v, *__restrict__ om_u = c->F.om_u;
+  const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn, on_v = (gcd_t)c->F.on_v, om_u = (gcd_t)c->F.om_u;
   const gd_t Ua = (gd_t)m.Ua, Va = (gd_t)m.Va, Wa = (gd_t)m.Wa;
   const long a2 = I2(i, j);
   const bool v_wall_n = b.north_edge && !b.NSperiodic && j == b.Jend + 1;   // Va(i,Jend+1) = 0, mpdata_adiff.F:694-700
-  auto oHz = [&](long x) { return 1.0 / Hz[x]; };
+  const gcd_t oHzA = (gcd_t)m.oHz, odzA = (gcd_t)m.odz;
+  auto oHz = [&](long x) { return oHzA[x]; };
   for (int k = 1; k <= N; k++) {
     const long a = a2 + (long)(k - 1) * nij;
     const double T0 = Ta[a];
@@ -133,7 +163,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
       double ua = 0.0;
       if (!((Tw <= 0.0) || (T0 <= 0.0) || (fabs(Tw - T0) <= EPS2_MP))) {
         double Ck, Wk;
-        face_CW(Ta, z_r, Wv, pm, pn, a2, a, -1, nij, k, N, dt, Ck, Wk);
+        face_CW(Ta, z_r, odzA, Wv, pm, pn, a2, a, -1, nij, k, N, dt, Ck, Wk);
         const double A = (T0 - Tw) / (T0 + Tw + EPS_MP);
         double B = 0.03125 *
                    ((Ta[a + ni] - T0) * (pn[a2] + pn[a2 + ni]) + (T0 - Ta[a - ni]) * (pn[a2 - ni] + pn[a2]) +
@@ -176,7 +206,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
       double va = 0.0;
       if (!v_wall_n && !((Ts <= 0.0) || (T0 <= 0.0) || (fabs(Ts - T0) <= EPS2_MP))) {
         double Ck, Wk;
-        face_CW(Ta, z_r, Wv, pm, pn, a2, a, -ni, nij, k, N, dt, Ck, Wk);
+        face_CW(Ta, z_r, odzA, Wv, pm, pn, a2, a, -ni, nij, k, N, dt, Ck, Wk);
         double A = 0.03125 *
                    ((Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]) + (T0 - Ta[a - 1]) * (pm[a2 - 1] + pm[a2]) +
                     (Ta[a + 1 - ni] - Ts) * (pm[a2 + 1 - ni] + pm[a2 - ni]) +
@@ -244,7 +274,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
                            Hvom[a + ni] * (pm[a2] + pm[a2 + ni]) * (pn[a2] + pn[a2 + ni]) * (oHz(a) + oHz(a + ni)) +
                            Hvom[a + ni + nij] * (pm[a2] + pm[a2 + ni]) * (pn[a2] + pn[a2 + ni]) *
                                (oHz(a + nij) + oHz(a + ni + nij)));
-        const double Wk = Wv[aw] * (1.0 / (z_r[a + nij] - z_r[a])) * pm[a2] * pn[a2] * dt;
+        const double Wk = Wv[aw] * odzA[a] * pm[a2] * pn[a2] * dt;
         const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
         const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
         const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
@@ -432,7 +462,7 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
 }  // namespace
 
 // One MPDATA tracer of step3d_t; called by roms_hip_step3d_t (k_step3d_t.hip).
-int roms_launch_step3d_t_mpdata(int nnew, int itrc)
+int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
 {
   const roms_bounds_t &b = g_ctx.b;
   if (b.NghostPoints != 3) return roms_fail("roms_hip_step3d_t", "MPDATA needs NghostPoints = 3 (inp_par.F:266-278)");
@@ -444,7 +474,13 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc)
   MpArgs m;
   m.Ta = g_ctx.hostc.ws3[1]; m.Ua = g_ctx.hostc.ws3[2]; m.Va = g_ctx.hostc.ws3[3]; m.Wa = g_ctx.hostc.ws3[4];
   m.bup = g_ctx.hostc.ws3[5]; m.bdn = g_ctx.hostc.ws3[6];
+  m.oHz = g_ctx.hostc.ws3[0]; m.odz = g_ctx.hostc.ws3[7];
   m.nnew = nnew; m.itrc = itrc;
+  if (first) {
+    hipLaunchKernelGGL(k_mp_metrics, grid2d(b.UBi - b.LBi + 1, b.UBj - b.LBj + 1), block2d(), 0, g_ctx.stream, g_ctx.devc,
+                       g_ctx.hostc.ws3[0], g_ctx.hostc.ws3[7]);
+    KERNEL_CHECK("k_mp_metrics");
+  }
   hipLaunchKernelGGL(k_mp_ta, grid2d(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1), block2d(), 0, g_ctx.stream,
                      g_ctx.devc, m);
   KERNEL_CHECK("k_mp_ta");

@@ -25,7 +25,7 @@
 #include <cstdlib>
 
 int roms_entry_check(const char *name);
-int roms_launch_step3d_t_mpdata(int nnew, int itrc);      // k_mpdata.hip
+int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first);      // k_mpdata.hip
 
 #include "advect.h"
 
@@ -467,7 +467,7 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
       case ADV_A4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_A4, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_MPDATA * 16 + ADV_MPDATA:
         // multi-pass: upstream step, anti-diffusive velocities, FCT limiter, corrected step (k_mpdata.hip)
-        for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q);
+        for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q, q == 0);
         break;
       default:
         return roms_fail("roms_hip_step3d_t", "advection scheme pair not implemented (HSIMT; MPDATA only as H+V pair)");
