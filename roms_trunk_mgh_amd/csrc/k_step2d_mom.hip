@@ -83,10 +83,10 @@ __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S
                                           double &zn, double &zw)
 {
   const roms_params_t &p = c->p;
-  const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
-  const double *__restrict__ zs = c->F.zeta + (long)(s.kstp - 1) * nij;
+  const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
+  const gcd_t zs = (gcd_t)(c->F.zeta + (long)(s.kstp - 1) * nij);
   const double dtfast = p.dtfast;
-  const double pmn_a = c->F.pm[a], pn_a = c->F.pn[a];
+  const double pmn_a = GF(pm)[a], pn_a = GF(pn)[a];
   if (s.iif == 1) {
     const double cff1 = dtfast;
     zn = zs[a] + pmn_a * pn_a * cff1 * rhs;
@@ -105,8 +105,8 @@ __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S
     const double cff4 = 2.0 / 5.0;
     const double cff5 = 1.0 - cff4;
     const double cff = cff1 * rhs;
-    zn = zs[a] + pmn_a * pn_a * (cff + cff2 * c->F.rzeta[a + (long)(s.kstp - 1) * nij] -
-                                 cff3 * c->F.rzeta[a + (long)(ptsk - 1) * nij]);
+    zn = zs[a] + pmn_a * pn_a * (cff + cff2 * GF(rzeta)[a + (long)(s.kstp - 1) * nij] -
+                                 cff3 * GF(rzeta)[a + (long)(ptsk - 1) * nij]);
     zw = cff5 * zn + cff4 * zk[a];
   }
 }
@@ -140,10 +140,10 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const Blk XB = xcd_block();
   const int it0 = ibase + XB.x * BLK_X, j0 = b.Jstr + XB.y * BLK_Y;
   const int it = it0 + threadIdx.x, j = j0 + threadIdx.y;
-  const double *__restrict__ ubk = c->F.ubar + (long)(s.krhs - 1) * nij;
-  const double *__restrict__ vbk = c->F.vbar + (long)(s.krhs - 1) * nij;
-  const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
-  const double *__restrict__ h = c->F.h;
+  const gcd_t ubk = (gcd_t)(c->F.ubar + (long)(s.krhs - 1) * nij);
+  const gcd_t vbk = (gcd_t)(c->F.vbar + (long)(s.krhs - 1) * nij);
+  const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
+  const gcd_t h = (gcd_t)(c->F.h);
   // ---- stage the stencil fields (target coordinates it0-2.., j0-2..) ----
   {
     const int tid = threadIdx.y * BLK_X + threadIdx.x;
@@ -164,10 +164,10 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       } else {
         // DUon, DVom evaluated in place (:509-544), identical expression to k2d_flux; the
         // ghost columns/rows they reach hold exact copies, so no separate flux pass is needed
-        const double cu = 0.5 * c->F.on_u[g];
+        const double cu = 0.5 * GF(on_u)[g];
         sDU[e] = ug * (cu * (Dg + (zk[g - 1] + h[g - 1])));
         if (gj >= b.LBj + 1) {
-          const double cv = 0.5 * c->F.om_v[g];
+          const double cv = 0.5 * GF(om_v)[g];
           sDV[e] = vg * (cv * (Dg + (zk[g - ni] + h[g - ni])));
         } else sDV[e] = 0.0;
       }
@@ -196,7 +196,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   if (it > ilast || j > b.Jend) return;
   const int i = ghost_threads ? wrap_i(b, it) : it; // source column
   // store at the target and, for an owner next to the periodic seam, at its image column(s)
-  auto put = [&](double *A, long idx, double val) {
+  auto put = [&](gd_t A, long idx, double val) {
     A[idx] = val;
     if (img) {
       if (i <= b.NghostPoints) A[idx + b.Lm] = val;
@@ -208,11 +208,11 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const bool do_v = j >= b.JstrV;
   const long a = I2(i, j);                          // source index in global arrays
   const long o = I2(it, j);                         // target index
-  const double *__restrict__ rhoA = c->F.rhoA;
-  const double *__restrict__ rhoS = c->F.rhoS;
-  const double *__restrict__ pm = c->F.pm;
-  const double *__restrict__ pn = c->F.pn;
-  const double *__restrict__ zs = c->F.zeta + (long)(s.kstp - 1) * nij;
+  const gcd_t rhoA = (gcd_t)(c->F.rhoA);
+  const gcd_t rhoS = (gcd_t)(c->F.rhoS);
+  const gcd_t pm = (gcd_t)(c->F.pm);
+  const gcd_t pn = (gcd_t)(c->F.pn);
+  const gcd_t zs = (gcd_t)(c->F.zeta + (long)(s.kstp - 1) * nij);
   T2 m;
   m.ub = sU; m.vb = sV; m.DU = sDU; m.DV = sDV; m.D = sD;
   m.i0 = it0 - 2; m.j0 = j0 - 2;
@@ -225,29 +225,29 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   if constexpr (FUSED) {
     // ---- what k2d_zeta_sm did: fast-time averages on the owned ranges and zeta(knew), rzeta(krhs) ----
     const int iif = s.iif;
-    const double *__restrict__ zkr = c->F.zeta + (long)(s.krhs - 1) * nij;
+    const gcd_t zkr = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
     auto average = [&](long oo, int tt, bool inU, bool inV) {       // step2d_LF_AM3.h:614-682 at target oo
       if (s.predictor && iif == 1) {
         const double cff2 = (-1.0 / 12.0) * p.weight2[iif];
-        c->F.Zt_avg1[oo] = 0.0;
-        if (inU) { c->F.DU_avg1[oo] = 0.0; c->F.DU_avg2[oo] = cff2 * sDU[tt]; }
-        if (inV) { c->F.DV_avg1[oo] = 0.0; c->F.DV_avg2[oo] = cff2 * sDV[tt]; }
+        GF(Zt_avg1)[oo] = 0.0;
+        if (inU) { GF(DU_avg1)[oo] = 0.0; GF(DU_avg2)[oo] = cff2 * sDU[tt]; }
+        if (inV) { GF(DV_avg1)[oo] = 0.0; GF(DV_avg2)[oo] = cff2 * sDV[tt]; }
       } else if (s.predictor) {
         const double cff1 = p.weight1[iif - 2];
         const double cff2 = (8.0 / 12.0) * p.weight2[iif - 1] - (1.0 / 12.0) * p.weight2[iif];
-        c->F.Zt_avg1[oo] = c->F.Zt_avg1[oo] + cff1 * zkr[oo];
+        GF(Zt_avg1)[oo] = GF(Zt_avg1)[oo] + cff1 * zkr[oo];
         if (inU) {
-          c->F.DU_avg1[oo] = c->F.DU_avg1[oo] + cff1 * sDU[tt];
-          c->F.DU_avg2[oo] = c->F.DU_avg2[oo] + cff2 * sDU[tt];
+          GF(DU_avg1)[oo] = GF(DU_avg1)[oo] + cff1 * sDU[tt];
+          GF(DU_avg2)[oo] = GF(DU_avg2)[oo] + cff2 * sDU[tt];
         }
         if (inV) {
-          c->F.DV_avg1[oo] = c->F.DV_avg1[oo] + cff1 * sDV[tt];
-          c->F.DV_avg2[oo] = c->F.DV_avg2[oo] + cff2 * sDV[tt];
+          GF(DV_avg1)[oo] = GF(DV_avg1)[oo] + cff1 * sDV[tt];
+          GF(DV_avg2)[oo] = GF(DV_avg2)[oo] + cff2 * sDV[tt];
         }
       } else {
         const double cff2 = (iif == 1) ? p.weight2[iif - 1] : (5.0 / 12.0) * p.weight2[iif - 1];
-        if (inU) c->F.DU_avg2[oo] = c->F.DU_avg2[oo] + cff2 * sDU[tt];
-        if (inV) c->F.DV_avg2[oo] = c->F.DV_avg2[oo] + cff2 * sDV[tt];
+        if (inU) GF(DU_avg2)[oo] = GF(DU_avg2)[oo] + cff2 * sDU[tt];
+        if (inV) GF(DV_avg2)[oo] = GF(DV_avg2)[oo] + cff2 * sDV[tt];
       }
     };
     const bool in_i = it >= b.IstrR && it <= b.IendR;
@@ -258,12 +258,12 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       if (j == b.Jend && b.JendR > b.Jend) average(o + ni, t + TP, inU, true);    // row JendR = Jend+1
     }
     const double zn = sZn[t];
-    double *__restrict__ zout = c->F.zeta + (long)(s.knew - 1) * nij;
+    const gd_t zout = (gd_t)(c->F.zeta + (long)(s.knew - 1) * nij);
     put(zout, o, zn);
     if (b.south_edge && j == b.Jstr) put(zout, o - ni, zn);         // zetabc closed: zero gradient
     if (b.north_edge && j == b.Jend) put(zout, o + ni, zn);
     if (s.predictor)      // at the target: ghost columns hold the periodic copy, as after the exchange
-      put(c->F.rzeta + (long)(s.krhs - 1) * nij, o, (sDU[t] - sDU[t + 1]) + (sDV[t] - sDV[t + TP]));
+      put((gd_t)(c->F.rzeta + (long)(s.krhs - 1) * nij), o, (sDU[t] - sDU[t + 1]) + (sDV[t] - sDV[t + TP]));
   }
   const double zw0 = FUSED ? sZw[t] : zwrk[a];
   const double gz0 = (fac + rhoS[a]) * zw0, gz20 = gz0 * zw0, gsa0 = zw0 * (rhoS[a] - rhoA[a]);
@@ -273,7 +273,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const long q = a - 1;
     const double zw = FUSED ? sZw[t - 1] : zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
-    rhs_u = cg * c->F.on_u[a] *
+    rhs_u = cg * GF(on_u)[a] *
             ((h[q] + h[a]) * (gz - gz0) +
              (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
              (gz2 - gz20));
@@ -282,7 +282,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const long q = a - ni;
     const double zw = FUSED ? sZw[t - TP] : zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
-    rhs_v = cg * c->F.om_v[a] *
+    rhs_v = cg * GF(om_v)[a] *
             ((h[q] + h[a]) * (gz - gz0) +
              (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
              (gz2 - gz20));
@@ -303,7 +303,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const double D0 = sD[t], Dw = sD[t - 1], Ds = sD[t - TP];
   // ---- Coriolis, :1291-1325 ----
   if (p.uv_cor) {
-    const double *fomn = c->F.fomn;
+    const gcd_t fomn = (gcd_t)(c->F.fomn);
     const double cf0 = 0.5 * D0 * fomn[a];
     const double UFx0 = cf0 * (sV[t] + sV[t + TP]);
     const double VFe0 = cf0 * (sU[t] + sU[t + 1]);
@@ -320,7 +320,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   }
   // ---- curvilinear terms, :1333-1382 ----
   if (p.curvgrid && p.uv_adv) {
-    const double *dndx = c->F.dndx, *dmde = c->F.dmde;
+    const gcd_t dndx = (gcd_t)c->F.dndx, dmde = (gcd_t)c->F.dmde;
     auto cell = [&](long q, int tq, double D, double &ufx, double &vfe) {
       const double cff1 = 0.5 * (sV[tq] + sV[tq + TP]);
       const double cff2 = 0.5 * (sU[tq] + sU[tq + 1]);
@@ -337,9 +337,9 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   }
   // ---- harmonic viscosity, :1394-1471 ----
   if (p.uv_vis2) {
-    const double *visc2_r = c->F.visc2_r, *visc2_p = c->F.visc2_p;
-    const double *pmon_r = c->F.pmon_r, *pnom_r = c->F.pnom_r, *pmon_p = c->F.pmon_p, *pnom_p = c->F.pnom_p;
-    const double *om_r = c->F.om_r, *on_r = c->F.on_r, *om_p = c->F.om_p, *on_p = c->F.on_p;
+    const gcd_t visc2_r = (gcd_t)c->F.visc2_r, visc2_p = (gcd_t)c->F.visc2_p;
+    const gcd_t pmon_r = (gcd_t)c->F.pmon_r, pnom_r = (gcd_t)c->F.pnom_r, pmon_p = (gcd_t)c->F.pmon_p, pnom_p = (gcd_t)c->F.pnom_p;
+    const gcd_t om_r = (gcd_t)c->F.om_r, on_r = (gcd_t)c->F.on_r, om_p = (gcd_t)c->F.om_p, on_p = (gcd_t)c->F.on_p;
     auto str_r = [&](long q, int tq) {
       return visc2_r[q] * sD[tq] * 0.5 *
              (pmon_r[q] * ((pn[q] + pn[q + 1]) * sU[tq + 1] - (pn[q - 1] + pn[q]) * sU[tq]) -
@@ -372,29 +372,29 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   // ---- coupling between 2-D and 3-D equations, :1884-2065 ----
   if (s.iif == 1 && s.predictor) {
     // never source-mapped (step2d_impl), so owner is always true here
-    double *ru_s = c->F.ru + (long)(s.nstp - 1) * n3w;
-    double *rv_s = c->F.rv + (long)(s.nstp - 1) * n3w;
-    const double *ru_n = c->F.ru + (long)(s.nnew - 1) * n3w;
-    const double *rv_n = c->F.rv + (long)(s.nnew - 1) * n3w;
+    const gd_t ru_s = (gd_t)(c->F.ru + (long)(s.nstp - 1) * n3w);
+    const gd_t rv_s = (gd_t)(c->F.rv + (long)(s.nstp - 1) * n3w);
+    const gcd_t ru_n = (gcd_t)(c->F.ru + (long)(s.nnew - 1) * n3w);
+    const gcd_t rv_n = (gcd_t)(c->F.rv + (long)(s.nnew - 1) * n3w);
     if (do_u) {
-      const double rf = c->F.rufrc[a] - rhs_u;
+      const double rf = GF(rufrc)[a] - rhs_u;
       if (s.iic == s.ntfirst) rhs_u = rhs_u + rf;
       else if (s.iic == s.ntfirst + 1) rhs_u = rhs_u + 1.5 * rf - 0.5 * ru_n[a];
       else rhs_u = rhs_u + (23.0 / 12.0) * rf - (16.0 / 12.0) * ru_n[a] + (5.0 / 12.0) * ru_s[a];
-      c->F.rufrc[a] = rf;
+      GF(rufrc)[a] = rf;
       ru_s[a] = rf;
     }
     if (do_v) {
-      const double rf = c->F.rvfrc[a] - rhs_v;
+      const double rf = GF(rvfrc)[a] - rhs_v;
       if (s.iic == s.ntfirst) rhs_v = rhs_v + rf;
       else if (s.iic == s.ntfirst + 1) rhs_v = rhs_v + 1.5 * rf - 0.5 * rv_n[a];
       else rhs_v = rhs_v + (23.0 / 12.0) * rf - (16.0 / 12.0) * rv_n[a] + (5.0 / 12.0) * rv_s[a];
-      c->F.rvfrc[a] = rf;
+      GF(rvfrc)[a] = rf;
       rv_s[a] = rf;
     }
   } else {
-    if (do_u) rhs_u = rhs_u + c->F.rufrc[a];
-    if (do_v) rhs_v = rhs_v + c->F.rvfrc[a];
+    if (do_u) rhs_u = rhs_u + GF(rufrc)[a];
+    if (do_v) rhs_v = rhs_v + GF(rvfrc)[a];
   }
   // ---- time step, :2098-2255 ----
   const double dtfast = p.dtfast;
@@ -403,20 +403,20 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const bool am3 = !(s.iif == 1 || s.predictor);
   const double c1 = (s.iif == 1) ? 0.5 * dtfast : dtfast;
   const double a1 = 0.5 * dtfast * 5.0 / 12.0, a2 = 0.5 * dtfast * 8.0 / 12.0, a3 = 0.5 * dtfast * 1.0 / 12.0;
-  double *__restrict__ ubn = c->F.ubar + (long)(s.knew - 1) * nij;
-  double *__restrict__ vbn = c->F.vbar + (long)(s.knew - 1) * nij;
+  const gd_t ubn = (gd_t)(c->F.ubar + (long)(s.knew - 1) * nij);
+  const gd_t vbn = (gd_t)(c->F.vbar + (long)(s.knew - 1) * nij);
   if (do_u) {
     const long q = a - 1;
     const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
     const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - 1] : zeta_new[q]) + h[q]));
-    const double us = c->F.ubar[a + (long)(s.kstp - 1) * nij];
+    const double us = GF(ubar)[a + (long)(s.kstp - 1) * nij];
     double un;
     if (!am3) un = (us * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_u) * fc;
     else un = (us * (Dst0 + (zs[q] + h[q])) +
-               cff * (a1 * rhs_u + a2 * c->F.rubar[a + (long)(s.kstp - 1) * nij] -
-                      a3 * c->F.rubar[a + (long)(ptsk - 1) * nij])) * fc;
+               cff * (a1 * rhs_u + a2 * GF(rubar)[a + (long)(s.kstp - 1) * nij] -
+                      a3 * GF(rubar)[a + (long)(ptsk - 1) * nij])) * fc;
     put(ubn, o, un);
-    if (s.predictor && owner) c->F.rubar[a + (long)(s.krhs - 1) * nij] = rhs_u;
+    if (s.predictor && owner) GF(rubar)[a + (long)(s.krhs - 1) * nij] = rhs_u;
     if (inline_bc) {                                   // u2dbc closed walls, u2dbc_im.F:51
       if (b.south_edge && j == b.Jstr) put(ubn, o - ni, p.gamma2 * un);
       if (b.north_edge && j == b.Jend) put(ubn, o + ni, p.gamma2 * un);
@@ -424,12 +424,12 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     if constexpr (FUSED) {
       if (DUnext) {                                    // DUon of level knew, :509-525 (as k2d_flux)
         const double znw = sZn[t - 1];
-        DUnext[a] = un * ((0.5 * c->F.on_u[a]) * (Dn0 + (znw + h[q])));
+        DUnext[a] = un * ((0.5 * GF(on_u)[a]) * (Dn0 + (znw + h[q])));
         // wall rows: u = gamma2*u(adjacent row), zeta = zero-gradient copy (u2dbc_im.F:51, zetabc.F:48)
         if (b.south_edge && j == b.Jstr)
-          DUnext[a - ni] = (p.gamma2 * un) * ((0.5 * c->F.on_u[a - ni]) * ((sZn[t] + h[a - ni]) + (znw + h[q - ni])));
+          DUnext[a - ni] = (p.gamma2 * un) * ((0.5 * GF(on_u)[a - ni]) * ((sZn[t] + h[a - ni]) + (znw + h[q - ni])));
         if (b.north_edge && j == b.Jend)
-          DUnext[a + ni] = (p.gamma2 * un) * ((0.5 * c->F.on_u[a + ni]) * ((sZn[t] + h[a + ni]) + (znw + h[q + ni])));
+          DUnext[a + ni] = (p.gamma2 * un) * ((0.5 * GF(on_u)[a + ni]) * ((sZn[t] + h[a + ni]) + (znw + h[q + ni])));
       }
     }
   }
@@ -437,16 +437,16 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const long q = a - ni;
     const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
     const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - TP] : zeta_new[q]) + h[q]));
-    const double vs = c->F.vbar[a + (long)(s.kstp - 1) * nij];
+    const double vs = GF(vbar)[a + (long)(s.kstp - 1) * nij];
     double vn;
     if (!am3) vn = (vs * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_v) * fc;
     else vn = (vs * (Dst0 + (zs[q] + h[q])) +
-               cff * (a1 * rhs_v + a2 * c->F.rvbar[a + (long)(s.kstp - 1) * nij] -
-                      a3 * c->F.rvbar[a + (long)(ptsk - 1) * nij])) * fc;
+               cff * (a1 * rhs_v + a2 * GF(rvbar)[a + (long)(s.kstp - 1) * nij] -
+                      a3 * GF(rvbar)[a + (long)(ptsk - 1) * nij])) * fc;
     put(vbn, o, vn);
-    if (s.predictor && owner) c->F.rvbar[a + (long)(s.krhs - 1) * nij] = rhs_v;
+    if (s.predictor && owner) GF(rvbar)[a + (long)(s.krhs - 1) * nij] = rhs_v;
     if constexpr (FUSED) {
-      if (DVnext) DVnext[a] = vn * ((0.5 * c->F.om_v[a]) * (Dn0 + (sZn[t - TP] + h[q])));   // :527-544
+      if (DVnext) DVnext[a] = vn * ((0.5 * GF(om_v)[a]) * (Dn0 + (sZn[t - TP] + h[q])));   // :527-544
     }
   }
   if (inline_bc) {                                     // v2dbc closed walls, v2dbc_im.F:52
@@ -457,9 +457,9 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     if (DVnext) {                                      // wall rows: v = 0 there
       const double zn0 = sZn[t];
       if (b.south_edge && j == b.Jstr)
-        DVnext[a] = 0.0 * ((0.5 * c->F.om_v[a]) * ((zn0 + h[a]) + (zn0 + h[a - ni])));
+        DVnext[a] = 0.0 * ((0.5 * GF(om_v)[a]) * ((zn0 + h[a]) + (zn0 + h[a - ni])));
       if (b.north_edge && j == b.Jend)
-        DVnext[a + ni] = 0.0 * ((0.5 * c->F.om_v[a + ni]) * ((zn0 + h[a + ni]) + (zn0 + h[a])));
+        DVnext[a + ni] = 0.0 * ((0.5 * GF(om_v)[a + ni]) * ((zn0 + h[a + ni]) + (zn0 + h[a])));
     }
   }
 }

@@ -116,6 +116,8 @@ __device__ __forceinline__ Blk xcd_block()
 // against lgkmcnt, so LDS traffic and scalar loads no longer wait on them.
 typedef const double __attribute__((address_space(1))) *gcd_t;
 typedef double __attribute__((address_space(1))) *gd_t;
+// field `name` of the constant block as a global-address-space pointer (device code with `c` in scope)
+#define GF(name) ((gd_t)c->F.name)
 
 #define I2(i,j)    ((long)((i) - LBi) + (long)((j) - LBj) * ni)
 #define I3(i,j,k)  (I2(i,j) + (long)((k) - 1) * nij)
