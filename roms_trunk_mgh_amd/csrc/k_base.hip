@@ -95,14 +95,14 @@ k_set_massflux(const RomsDev *__restrict__ c, int nrhs)
   const int j = b.JstrT + XB.y * BLK_Y + threadIdx.y;
   const int k = XB.z + 1;
   if (i > b.IendT || j > b.JendT) return;
-  const double *__restrict__ Hz = c->F.Hz;
-  const double *__restrict__ u = c->F.u + (long)(nrhs - 1) * n3r;
-  const double *__restrict__ v = c->F.v + (long)(nrhs - 1) * n3r;
+  const gcd_t Hz = (gcd_t)(c->F.Hz);
+  const gcd_t u = (gcd_t)(c->F.u + (long)(nrhs - 1) * n3r);
+  const gcd_t v = (gcd_t)(c->F.v + (long)(nrhs - 1) * n3r);
   const double hz = Hz[I3(i, j, k)];
   if (i >= b.IstrP)
-    c->F.Huon[I3(i, j, k)] = 0.5 * (hz + Hz[I3(i - 1, j, k)]) * u[I3(i, j, k)] * c->F.on_u[I2(i, j)];
+    GF(Huon)[I3(i, j, k)] = 0.5 * (hz + Hz[I3(i - 1, j, k)]) * u[I3(i, j, k)] * GF(on_u)[I2(i, j)];
   if (j >= b.JstrP)
-    c->F.Hvom[I3(i, j, k)] = 0.5 * (hz + Hz[I3(i, j - 1, k)]) * v[I3(i, j, k)] * c->F.om_v[I2(i, j)];
+    GF(Hvom)[I3(i, j, k)] = 0.5 * (hz + Hz[I3(i, j - 1, k)]) * v[I3(i, j, k)] * GF(om_v)[I2(i, j)];
 }
 
 extern "C" int roms_hip_set_massflux(const roms_step_idx_t *s)
@@ -136,10 +136,10 @@ k_omega(const RomsDev *__restrict__ c)
   const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
   const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
-  const double *__restrict__ Huon = c->F.Huon;
-  const double *__restrict__ Hvom = c->F.Hvom;
-  const double *__restrict__ z_w = c->F.z_w;
-  double *__restrict__ W = c->F.W;
+  const gcd_t Huon = (gcd_t)(c->F.Huon);
+  const gcd_t Hvom = (gcd_t)(c->F.Hvom);
+  const gcd_t z_w = (gcd_t)(c->F.z_w);
+  const gd_t W = (gd_t)(c->F.W);
   double w[NMAX + 1];
   w[0] = 0.0;
 #pragma unroll
@@ -188,9 +188,9 @@ __global__ void k_set_zeta(const RomsDev *__restrict__ c)
   const int i = b.IstrR + XB.x * BLK_X + threadIdx.x;
   const int j = b.JstrR + XB.y * BLK_Y + threadIdx.y;
   if (i > b.IendR || j > b.JendR) return;
-  const double z = c->F.Zt_avg1[I2(i, j)];
-  c->F.zeta[I2(i, j)] = z;
-  c->F.zeta[I2(i, j) + nij] = z;
+  const double z = GF(Zt_avg1)[I2(i, j)];
+  GF(zeta)[I2(i, j)] = z;
+  GF(zeta)[I2(i, j) + nij] = z;
 }
 
 extern "C" int roms_hip_set_zeta(const roms_step_idx_t *s)
@@ -221,11 +221,11 @@ k_set_depth(const RomsDev *__restrict__ c)
   if (i > b.IendT || j > b.JendT) return;
   const roms_params_t &p = c->p;
   const double hc = p.hc;
-  const double hwater = c->F.h[I2(i, j)];
-  const double zt = c->F.Zt_avg1[I2(i, j)];
-  double *__restrict__ z_w = c->F.z_w;
-  double *__restrict__ z_r = c->F.z_r;
-  double *__restrict__ Hz = c->F.Hz;
+  const double hwater = GF(h)[I2(i, j)];
+  const double zt = GF(Zt_avg1)[I2(i, j)];
+  const gd_t z_w = (gd_t)(c->F.z_w);
+  const gd_t z_r = (gd_t)(c->F.z_r);
+  const gd_t Hz = (gd_t)(c->F.Hz);
   double zw_prev = -hwater;
   z_w[I3W(i, j, 0)] = zw_prev;
   if (p.Vtransform == 1) {

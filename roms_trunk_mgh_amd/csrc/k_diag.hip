@@ -29,7 +29,7 @@ k_wvelocity(const RomsDev *__restrict__ c, int ninp)
   const gcd_t u = (gcd_t)(c->F.u + (long)(ninp - 1) * n3r), v = (gcd_t)(c->F.v + (long)(ninp - 1) * n3r);
   const gcd_t z_r = (gcd_t)c->F.z_r, z_w = (gcd_t)c->F.z_w, W = (gcd_t)c->F.W;
   const gd_t wvel = (gd_t)c->F.wvel;
-  const double *pm = c->F.pm, *pn = c->F.pn;
+  const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn;
   const double pmw = pm[a - 1] + pm[a], pme = pm[a] + pm[a + 1];
   const double pns = pn[a - ni] + pn[a], pnn = pn[a] + pn[a + ni];
   const double pmn = pm[a] * pn[a];
@@ -47,7 +47,7 @@ k_wvelocity(const RomsDev *__restrict__ c, int ninp)
   auto w3i = [&](int k) { return a + (long)k * nij; };
   const double cff1 = 3.0 / 8.0, cff2 = 3.0 / 4.0, cff3 = 1.0 / 8.0, cff4 = 9.0 / 16.0, cff5 = 1.0 / 16.0;
   const double zw0 = z_w[w3i(0)], zwN = z_w[w3i(N)];
-  const double wrk = (c->F.DU_avg1[a] - c->F.DU_avg1[a + 1] + c->F.DV_avg1[a] - c->F.DV_avg1[a + ni]) / (zwN - zw0);
+  const double wrk = (GF(DU_avg1)[a] - GF(DU_avg1)[a + 1] + GF(DV_avg1)[a] - GF(DV_avg1)[a + ni]) / (zwN - zw0);
   double v1 = vert_at(1), v2 = vert_at(2), v3 = vert_at(3);
   {
     const double slope = (z_r[a] - zw0) / (z_r[a + nij] - z_r[a]);           // extrapolation slope
@@ -88,7 +88,7 @@ k_diag_col(const RomsDev *__restrict__ c, int idia, DiagScratch w)
   const gcd_t Hz = (gcd_t)c->F.Hz, z_r = (gcd_t)c->F.z_r, z_w = (gcd_t)c->F.z_w, rho = (gcd_t)c->F.rho;
   const gcd_t wvel = (gcd_t)c->F.wvel;
   const double zwN = z_w[a + (long)N * nij], zw0 = z_w[a];
-  const double pm = c->F.pm[a], pn = c->F.pn[a], dt = p.dt;
+  const double pm = GF(pm)[a], pn = GF(pn)[a], dt = p.dt;
   double ke = 0.0, pe = 0.5 * p.g * zwN * zwN;
   const double cff = p.g / p.rho0;
   double mC = 0.0, mCu = 0.0, mCv = 0.0, mCw = 0.0, mspd = 0.0, mrho = -1.0E+37;
@@ -111,7 +111,7 @@ k_diag_col(const RomsDev *__restrict__ c, int idia, DiagScratch w)
     wv_up = wv_dn;
   }
   // the terms of the j-sums (diag.F:268-278), so that the serial pass reads three values per point
-  const double om = c->F.omn[a];
+  const double om = GF(omn)[a];
   w.vol[a] = om * (zwN - zw0);
   ke = om * ke;
   pe = om * pe;

@@ -75,7 +75,7 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
   const gcd_t Huon = (gcd_t)c->F.Huon, Hvom = (gcd_t)c->F.Hvom, Wv = (gcd_t)c->F.W, Hz = (gcd_t)c->F.Hz;
   const gd_t Ta = (gd_t)m.Ta;
   const long c0 = I2(i, j);
-  const double cff = dt * c->F.pm[c0] * c->F.pn[c0];
+  const double cff = dt * GF(pm)[c0] * GF(pn)[c0];
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
   double FCm1 = 0.0;
@@ -364,10 +364,10 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
   const gd_t tn = (gd_t)(c->F.t + ((long)(m.nnew - 1) + 3L * (m.itrc - 1)) * n3r);
   const long a2 = I2(i, j);
   const double cffa = 1.0 / dt;                                   // mpdata_adiff.F:254
-  const double cpp = dt * c->F.pm[a2] * c->F.pn[a2];
-  const double omu0 = c->F.om_u[a2], omu1 = c->F.om_u[a2 + 1], onv0 = c->F.on_v[a2], onv1 = c->F.on_v[a2 + ni];
-  const double onu0 = c->F.on_u[a2], onu1 = c->F.on_u[a2 + 1], omv0 = c->F.om_v[a2], omv1 = c->F.om_v[a2 + ni];
-  const double omn = c->F.omn[a2];
+  const double cpp = dt * GF(pm)[a2] * GF(pn)[a2];
+  const double omu0 = GF(om_u)[a2], omu1 = GF(om_u)[a2 + 1], onv0 = GF(on_v)[a2], onv1 = GF(on_v)[a2 + ni];
+  const double onu0 = GF(on_u)[a2], onu1 = GF(on_u)[a2 + 1], omv0 = GF(om_v)[a2], omv1 = GF(om_v)[a2 + ni];
+  const double omn = GF(omn)[a2];
   // walls of the limited transports, mpdata_adiff.F:1068-1100 (E-W periodic, closed N-S)
   const bool v0_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;       // Va(i,Jstr) = 0
   const bool v1_wall = b.north_edge && !b.NSperiodic && j == b.Jend;       // Va(i,Jend+1) = 0

@@ -23,49 +23,49 @@ k_set_vbc(const RomsDev *__restrict__ c, int nrhs)
   if (i > b.IendR || j > b.JendR) return;
   const long a = I2(i, j);
   const int NT = b.NT;
-  const double *__restrict__ u = c->F.u + (long)(nrhs - 1) * n3r;
-  const double *__restrict__ v = c->F.v + (long)(nrhs - 1) * n3r;
+  const gcd_t u = (gcd_t)(c->F.u + (long)(nrhs - 1) * n3r);
+  const gcd_t v = (gcd_t)(c->F.v + (long)(nrhs - 1) * n3r);
   // kinematic surface / bottom tracer fluxes, set_vbc.F:262-312
-  c->F.stflx[a] = c->F.stflux[a];
-  c->F.btflx[a] = c->F.btflux[a];
+  GF(stflx)[a] = GF(stflux)[a];
+  GF(btflx)[a] = GF(btflux)[a];
   if (p.salinity && NT >= 2) {
-    const double *__restrict__ S = c->F.t + ((long)(nrhs - 1) + 3L * 1) * n3r;      // t(:,:,:,nrhs,isalt)
-    const double EmP = c->F.stflux[a + nij];
-    c->F.stflx[a + nij] = EmP * S[a + (long)(N - 1) * nij];
-    c->F.btflx[a + nij] = c->F.btflx[a + nij] * S[a];
+    const gcd_t S = (gcd_t)(c->F.t + ((long)(nrhs - 1) + 3L * 1) * n3r);      // t(:,:,:,nrhs,isalt)
+    const double EmP = GF(stflux)[a + nij];
+    GF(stflx)[a + nij] = EmP * S[a + (long)(N - 1) * nij];
+    GF(btflx)[a + nij] = GF(btflx)[a + nij] * S[a];
   }
   // bottom stress, :380-470 (k = 1 is the first plane of u, v)
   const bool on_u = i >= b.IstrU && i <= b.Iend && j >= b.Jstr && j <= b.Jend;
   const bool on_v = i >= b.Istr && i <= b.Iend && j >= b.JstrV && j <= b.Jend;
   if (p.uv_drag == 2) {
-    const double *__restrict__ r2 = c->F.rdrag2;
+    const gcd_t r2 = (gcd_t)(c->F.rdrag2);
     if (on_u) {
       const double cff1 = 0.25 * (v[a] + v[a + ni] + v[a - 1] + v[a - 1 + ni]);
       const double cff2 = sqrt(u[a] * u[a] + cff1 * cff1);
       const double bu = 0.5 * (r2[a - 1] + r2[a]) * u[a] * cff2;
-      c->F.bustr[a] = bu;
-      if (b.south_edge && !b.NSperiodic && j == b.Jstr) c->F.bustr[a - ni] = p.gamma2 * bu;   // bc_u2d_tile
-      if (b.north_edge && !b.NSperiodic && j == b.Jend) c->F.bustr[a + ni] = p.gamma2 * bu;
+      GF(bustr)[a] = bu;
+      if (b.south_edge && !b.NSperiodic && j == b.Jstr) GF(bustr)[a - ni] = p.gamma2 * bu;   // bc_u2d_tile
+      if (b.north_edge && !b.NSperiodic && j == b.Jend) GF(bustr)[a + ni] = p.gamma2 * bu;
     }
     if (on_v) {
       const double cff1 = 0.25 * (u[a] + u[a + 1] + u[a - ni] + u[a + 1 - ni]);
       const double cff2 = sqrt(cff1 * cff1 + v[a] * v[a]);
-      c->F.bvstr[a] = 0.5 * (r2[a - ni] + r2[a]) * v[a] * cff2;
+      GF(bvstr)[a] = 0.5 * (r2[a - ni] + r2[a]) * v[a] * cff2;
     }
   } else {
-    const double *__restrict__ r1 = c->F.rdrag;
+    const gcd_t r1 = (gcd_t)(c->F.rdrag);
     if (on_u) {
       const double bu = 0.5 * (r1[a - 1] + r1[a]) * u[a];
-      c->F.bustr[a] = bu;
-      if (b.south_edge && !b.NSperiodic && j == b.Jstr) c->F.bustr[a - ni] = p.gamma2 * bu;
-      if (b.north_edge && !b.NSperiodic && j == b.Jend) c->F.bustr[a + ni] = p.gamma2 * bu;
+      GF(bustr)[a] = bu;
+      if (b.south_edge && !b.NSperiodic && j == b.Jstr) GF(bustr)[a - ni] = p.gamma2 * bu;
+      if (b.north_edge && !b.NSperiodic && j == b.Jend) GF(bustr)[a + ni] = p.gamma2 * bu;
     }
-    if (on_v) c->F.bvstr[a] = 0.5 * (r1[a - ni] + r1[a]) * v[a];
+    if (on_v) GF(bvstr)[a] = 0.5 * (r1[a - ni] + r1[a]) * v[a];
   }
   // bc_v2d_tile, closed walls: normal component zero on the wall rows
   if (i >= b.Istr && i <= b.Iend && !b.NSperiodic) {
-    if (b.south_edge && j == b.Jstr) c->F.bvstr[a] = 0.0;
-    if (b.north_edge && j == b.Jend) c->F.bvstr[a + ni] = 0.0;
+    if (b.south_edge && j == b.Jstr) GF(bvstr)[a] = 0.0;
+    if (b.north_edge && j == b.Jend) GF(bvstr)[a + ni] = 0.0;
   }
 }
 
@@ -119,13 +119,13 @@ k_bulk_flux(const RomsDev *__restrict__ c, int nrhs, double *__restrict__ Taux, 
   const double g = p.g, rho0 = p.rho0;
   const double blk_ZQ = p.blk_ZQ, blk_ZT = p.blk_ZT, blk_ZW = p.blk_ZW;
   const double eps = 1.0E-20, r3 = 1.0 / 3.0;
-  const double Ua = c->F.Uwind[a], Va = c->F.Vwind[a];
+  const double Ua = GF(Uwind)[a], Va = GF(Vwind)[a];
   const double Wmag = sqrt(Ua * Ua + Va * Va);
-  const double PairM = c->F.Pair[a];
-  const double TairC = c->F.Tair[a], TairK = TairC + 273.16;
-  const double TseaC = c->F.t[a + (long)(N - 1) * nij + (long)(nrhs - 1) * n3r], TseaK = TseaC + 273.16;
-  const double RH = c->F.Hair[a];
-  const double cl = c->F.cloud[a], rn = c->F.rain[a];
+  const double PairM = GF(Pair)[a];
+  const double TairC = GF(Tair)[a], TairK = TairC + 273.16;
+  const double TseaC = GF(t)[a + (long)(N - 1) * nij + (long)(nrhs - 1) * n3r], TseaK = TseaC + 273.16;
+  const double RH = GF(Hair)[a];
+  const double cl = GF(cloud)[a], rn = GF(rain)[a];
   const double delTc = 0.0, delQc = 0.0;
   double cff = (0.7859 + 0.03477 * TairC) / (1.0 + 0.00412 * TairC);
   const double e_sat = pow(10.0, cff);
@@ -217,10 +217,10 @@ k_bulk_flux(const RomsDev *__restrict__ c, int nrhs, double *__restrict__ Taux, 
   if (i >= b.IstrR && j >= b.JstrR) {
     const double Hscale = 1.0 / (rho0 * Cp);
     const double lr = LRad * Hscale, lh = -LHeat * Hscale, sh = -SHeat * Hscale;
-    c->F.lrflx[a] = lr;
-    c->F.lhflx[a] = lh;
-    c->F.shflx[a] = sh;
-    c->F.stflux[a] = (c->F.srflx[a] + lr + lh + sh);
+    GF(lrflx)[a] = lr;
+    GF(lhflx)[a] = lh;
+    GF(shflx)[a] = sh;
+    GF(stflux)[a] = (GF(srflx)[a] + lr + lh + sh);
   }
 }
 
@@ -234,8 +234,8 @@ k_bulk_stress(const RomsDev *__restrict__ c, const double *__restrict__ Taux, co
   if (i > b.IendR || j > b.JendR) return;
   const long a = I2(i, j);
   const double cff = 0.5 / c->p.rho0;
-  if (i >= b.Istr) c->F.sustr[a] = cff * (Taux[a - 1] + Taux[a]);
-  if (j >= b.Jstr) c->F.svstr[a] = cff * (Tauy[a - ni] + Tauy[a]);
+  if (i >= b.Istr) GF(sustr)[a] = cff * (Taux[a - 1] + Taux[a]);
+  if (j >= b.Jstr) GF(svstr)[a] = cff * (Tauy[a - ni] + Tauy[a]);
 }
 
 }  // namespace
@@ -376,12 +376,12 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   // ---------- surface forcing of the boundary layer, lmd_skpp.F:300-340 ----------
   const double eps = 1.0E-10;
   const double zwN = z_w[w3i(N)];
-  double hsbl = c->F.hsbl[a];
+  double hsbl = GF(hsbl)[a];
   double sl_dpth = lmd_epsilon * (zwN - hsbl);
-  const double s1 = 0.5 * (c->F.sustr[a] + c->F.sustr[a + 1]), s2 = 0.5 * (c->F.svstr[a] + c->F.svstr[a + ni]);
+  const double s1 = 0.5 * (GF(sustr)[a] + GF(sustr)[a + 1]), s2 = 0.5 * (GF(svstr)[a] + GF(svstr)[a + ni]);
   const double Ustar = sqrt(sqrt(s1 * s1 + s2 * s2));
-  const double alpha = c->F.alpha[a], beta = c->F.beta[a], srflx = c->F.srflx[a];
-  const double stT = c->F.stflx[a], stS = c->F.stflx[a + nij];
+  const double alpha = GF(alpha)[a], beta = GF(beta)[a], srflx = GF(srflx)[a];
+  const double stT = GF(stflx)[a], stS = GF(stflx)[a + nij];
   const double Bo = g * (alpha * (stT - srflx) - beta * stS);
   const double Bosol = g * alpha * srflx;
   // buoyancy flux and the non-local flux shape at W-level k (:320-338); recomputed where needed
@@ -475,16 +475,16 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   }
   double Bfsfc = (Bo + Bosol * (1.0 - swfrac(p, zwN - hsbl)));
   if ((Ustar > 0.0) && (Bfsfc > 0.0)) {
-    const double hekman = lmd_cekman * Ustar / fmax(fabs(c->F.f[a]), eps);
+    const double hekman = lmd_cekman * Ustar / fmax(fabs(GF(f)[a]), eps);
     const double hmonob = lmd_cmonob * Ustar * Ustar * Ustar / fmax(vonKar * Bfsfc, eps);
     hsbl = (zwN - fmin(fmin(hekman, hmonob), zwN - hsbl));
   }
   hsbl = fmin(hsbl, zwN);
   hsbl = fmax(hsbl, z_w[w3i(0)]);
-  c->F.hsbl[a] = hsbl;
+  GF(hsbl)[a] = hsbl;
   if (!b.NSperiodic) {                                           // bc_r2d_tile: zero gradient at closed walls
-    if (b.south_edge && j == b.Jstr) c->F.hsbl[a - ni] = hsbl;
-    if (b.north_edge && j == b.Jend) c->F.hsbl[a + ni] = hsbl;
+    if (b.south_edge && j == b.Jstr) GF(hsbl)[a - ni] = hsbl;
+    if (b.north_edge && j == b.Jend) GF(hsbl)[a + ni] = hsbl;
   }
   ksbl = 1;
   for (int k = N; k >= 2; k--)
@@ -518,7 +518,7 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
     dGs1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
   } else {
     ksbl = 0;
-    const double b1 = 0.5 * (c->F.bustr[a] + c->F.bustr[a + 1]), b2 = 0.5 * (c->F.bvstr[a] + c->F.bvstr[a + ni]);
+    const double b1 = 0.5 * (GF(bustr)[a] + GF(bustr)[a + 1]), b2 = 0.5 * (GF(bvstr)[a] + GF(bvstr)[a + ni]);
     const double Ustarb = sqrt(sqrt(b1 * b1 + b2 * b2));
     const double dK_bl = vonKar * Ustarb;
     const double K_bl = dK_bl * (hsbl - z_w[w3i(0)]);
@@ -577,14 +577,14 @@ __global__ void k_lmd_edges(const RomsDev *__restrict__ c, int phase)
   const int NAT = b.NAT;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;                                      // 0..N
-  double *Akv = c->F.Akv + (long)k * nij;
+  const gd_t Akv = (gd_t)(c->F.Akv + (long)k * nij);
   auto copy = [&](long dst, long src) {
-    for (int it = 0; it < NAT; it++) c->F.Akt[dst + (long)k * nij + (long)it * n3w] = c->F.Akt[src + (long)k * nij + (long)it * n3w];
+    for (int it = 0; it < NAT; it++) GF(Akt)[dst + (long)k * nij + (long)it * n3w] = GF(Akt)[src + (long)k * nij + (long)it * n3w];
     Akv[dst] = Akv[src];
   };
   auto corner = [&](long dst, long s1, long s2) {
     for (int it = 0; it < NAT; it++) {
-      double *A = c->F.Akt + (long)k * nij + (long)it * n3w;
+      const gd_t A = (gd_t)(c->F.Akt + (long)k * nij + (long)it * n3w);
       A[dst] = 0.5 * (A[s1] + A[s2]);
     }
     Akv[dst] = 0.5 * (Akv[s1] + Akv[s2]);

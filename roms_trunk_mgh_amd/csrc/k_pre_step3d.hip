@@ -35,16 +35,16 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
   const roms_params_t &p = c->p;
   const int ltrc = itrc < b.NAT ? itrc : b.NAT;
   const double dt = p.dt;
-  const double *__restrict__ ts = c->F.t + ((long)(nstp - 1) + 3L * (itrc - 1)) * n3r;
-  double *__restrict__ t3 = c->F.t + (2L + 3L * (itrc - 1)) * n3r;
-  double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
-  const double *__restrict__ Huon = c->F.Huon;
-  const double *__restrict__ Hvom = c->F.Hvom;
-  const double *__restrict__ Wv = c->F.W;
-  const double *__restrict__ Hz = c->F.Hz;
-  const double *__restrict__ z_r = c->F.z_r;
-  const double *__restrict__ z_w = c->F.z_w;
-  const double *__restrict__ Akt = c->F.Akt + (long)(ltrc - 1) * n3w;
+  const gcd_t ts = (gcd_t)(c->F.t + ((long)(nstp - 1) + 3L * (itrc - 1)) * n3r);
+  const gd_t t3 = (gd_t)(c->F.t + (2L + 3L * (itrc - 1)) * n3r);
+  const gd_t tn = (gd_t)(c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r);
+  const gcd_t Huon = (gcd_t)(c->F.Huon);
+  const gcd_t Hvom = (gcd_t)(c->F.Hvom);
+  const gcd_t Wv = (gcd_t)(c->F.W);
+  const gcd_t Hz = (gcd_t)(c->F.Hz);
+  const gcd_t z_r = (gcd_t)(c->F.z_r);
+  const gcd_t z_w = (gcd_t)(c->F.z_w);
+  const gcd_t Akt = (gcd_t)(c->F.Akt + (long)(ltrc - 1) * n3w);
   const long c0 = I2(i, j);
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
@@ -54,14 +54,14 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
   double cff, cff1, cff2;
   if (first_step) { cff = 0.5 * dt; cff1 = 1.0; cff2 = 0.0; }
   else { cff = (1.0 - Gamma) * dt; cff1 = 0.5 + Gamma; cff2 = 0.5 - Gamma; }
-  const double cpp = cff * c->F.pm[c0] * c->F.pn[c0];
+  const double cpp = cff * GF(pm)[c0] * GF(pn)[c0];
   // explicit vertical flux pieces
   const double cff3 = dt * (1.0 - p.lambda);
   const bool nonlocal = p.lmd_nonlocal && itrc <= b.NAT;
   const bool solar = p.solar_source && itrc == 1;
-  const double *__restrict__ ghats = c->F.ghats + (long)((itrc <= b.NAT ? itrc : 1) - 1) * n3w;
-  const double *__restrict__ AktN = c->F.Akt + (long)((itrc <= b.NAT ? itrc : 1) - 1) * n3w;   // Akt(..,itrc) of the non-local term
-  const double srf = c->F.srflx[c0];
+  const gcd_t ghats = (gcd_t)(c->F.ghats + (long)((itrc <= b.NAT ? itrc : 1) - 1) * n3w);
+  const gcd_t AktN = (gcd_t)(c->F.Akt + (long)((itrc <= b.NAT ? itrc : 1) - 1) * n3w);   // Akt(..,itrc) of the non-local term
+  const double srf = GF(srflx)[c0];
   const double zwN = z_w[c0 + (long)N * nij];
   const double fac1 = -1.0 / p.swfrac_mu1, fac2 = -1.0 / p.swfrac_mu2, fac3 = p.swfrac_r1;
 
@@ -114,7 +114,7 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
 
   double tkm1 = 0.0, tk = ts[c0], tkp1 = (N >= 2) ? ts[c0 + nij] : 0.0, tkp2;
   double FCprev = 0.0;                                        // advective FC(k-1)
-  double FDprev = dt * c->F.btflx[c0 + (long)(itrc - 1) * nij]; // diffusive FC(0)
+  double FDprev = dt * GF(btflx)[c0 + (long)(itrc - 1) * nij]; // diffusive FC(0)
   double w_km1 = Wv[c0];
   double zr_k = z_r[c0];
   for (int k = 1; k <= N; k++) {
@@ -154,7 +154,7 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
     t3[ck] = t3v;
     // ---- start of the corrector: explicit vertical flux, pre_step3d.F:917-1010 ----
     double FDk;
-    if (k == N) FDk = dt * c->F.stflx[c0 + (long)(itrc - 1) * nij];
+    if (k == N) FDk = dt * GF(stflx)[c0 + (long)(itrc - 1) * nij];
     else {
       const double zr_k1 = z_r[ck + nij];
       const double cz = 1.0 / (zr_k1 - zr_k);
@@ -187,11 +187,11 @@ k_pre_uv(const RomsDev *__restrict__ c, int nstp, int nnew, int nrhs, int stage)
   const roms_params_t &p = c->p;
   const double dt = p.dt;
   const double cff3 = dt * (1.0 - p.lambda);
-  const double *__restrict__ z_r = c->F.z_r;
-  const double *__restrict__ Hz = c->F.Hz;
-  const double *__restrict__ Akv = c->F.Akv;
-  const double *__restrict__ pm = c->F.pm;
-  const double *__restrict__ pn = c->F.pn;
+  const gcd_t z_r = (gcd_t)(c->F.z_r);
+  const gcd_t Hz = (gcd_t)(c->F.Hz);
+  const gcd_t Akv = (gcd_t)(c->F.Akv);
+  const gcd_t pm = (gcd_t)(c->F.pm);
+  const gcd_t pn = (gcd_t)(c->F.pn);
   const long c0 = I2(i, j);
   const int indx = 3 - nrhs;
 #pragma unroll
@@ -199,10 +199,10 @@ k_pre_uv(const RomsDev *__restrict__ c, int nstp, int nnew, int nrhs, int stage)
     if (comp == 0 && i < b.IstrU) continue;
     if (comp == 1 && j < b.JstrV) continue;
     const long off = comp == 0 ? 1 : ni;          // neighbour at i-1 or j-1
-    const double *__restrict__ vel = (comp == 0 ? c->F.u : c->F.v) + (long)(nstp - 1) * n3r;
-    double *__restrict__ vnew = (comp == 0 ? c->F.u : c->F.v) + (long)(nnew - 1) * n3r;
-    const double *__restrict__ r1 = (comp == 0 ? c->F.ru : c->F.rv) + (long)(nrhs - 1) * n3w;
-    const double *__restrict__ r2 = (comp == 0 ? c->F.ru : c->F.rv) + (long)(indx - 1) * n3w;
+    const gcd_t vel = (gcd_t)((comp == 0 ? c->F.u : c->F.v) + (long)(nstp - 1) * n3r);
+    const gd_t vnew = (gd_t)((comp == 0 ? c->F.u : c->F.v) + (long)(nnew - 1) * n3r);
+    const gcd_t r1 = (gcd_t)((comp == 0 ? c->F.ru : c->F.rv) + (long)(nrhs - 1) * n3w);
+    const gcd_t r2 = (gcd_t)((comp == 0 ? c->F.ru : c->F.rv) + (long)(indx - 1) * n3w);
     const double bstr = (comp == 0 ? c->F.bustr : c->F.bvstr)[c0];
     const double sstr = (comp == 0 ? c->F.sustr : c->F.svstr)[c0];
     const double cq = dt * 0.25;

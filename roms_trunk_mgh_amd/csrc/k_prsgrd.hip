@@ -40,8 +40,8 @@ k_prsgrd_P(const RomsDev *__restrict__ c, double *__restrict__ P)
   const int i = b.IstrU - 1 + XB.x * BLK_X + threadIdx.x;
   const int j = b.JstrV - 1 + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
-  const double *__restrict__ rho = c->F.rho;
-  const double *__restrict__ z_r = c->F.z_r;
+  const gcd_t rho = (gcd_t)(c->F.rho);
+  const gcd_t z_r = (gcd_t)(c->F.z_r);
   const double eps = 1.0E-10, OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
   const double g = c->p.g, GRho = g / c->p.rho0, HalfGRho = 0.5 * GRho;
   const long c0 = I2(i, j);
@@ -50,7 +50,7 @@ k_prsgrd_P(const RomsDev *__restrict__ c, double *__restrict__ P)
   double zr_k1 = z_r[c0 + (long)(N - 1) * nij];
   double rho_k = rho[c0 + (long)(N - 2) * nij];       // rho(N-1)
   double zr_k = z_r[c0 + (long)(N - 2) * nij];
-  const double zwN = c->F.z_w[c0 + (long)N * nij];
+  const double zwN = GF(z_w)[c0 + (long)N * nij];
   // surface level
   {
     const double cff1 = 1.0 / (zr_k1 - zr_k);
@@ -95,9 +95,9 @@ k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrh
   const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
   const int k = XB.z + 1;
   if (i > b.Iend || j > b.Jend) return;
-  const double *__restrict__ rho = c->F.rho;
-  const double *__restrict__ z_r = c->F.z_r;
-  const double *__restrict__ Hz = c->F.Hz;
+  const gcd_t rho = (gcd_t)(c->F.rho);
+  const gcd_t z_r = (gcd_t)(c->F.z_r);
+  const gcd_t Hz = (gcd_t)(c->F.Hz);
   const double eps = 1.0E-10, OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
   const double HalfGRho = 0.5 * (c->p.g / c->p.rho0);
   const long ck = I3(i, j, k);
@@ -109,8 +109,8 @@ k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrh
     const double FC_m1 = rm1 - rm2, FC_0 = r0 - rm1, FC_p1 = rp1 - r0;
     const double dZx0 = harm_inv(aux_0, aux_p1, eps), dZxm = harm_inv(aux_m1, aux_0, eps);
     const double dRx0 = harm_inv(FC_0, FC_p1, eps), dRxm = harm_inv(FC_m1, FC_0, eps);
-    double *ru = c->F.ru + (long)(nrhs - 1) * n3w;
-    ru[I3W(i, j, k)] = c->F.on_u[I2(i, j)] * 0.5 * (hz0 + Hz[ck - 1]) *
+    const gd_t ru = (gd_t)(c->F.ru + (long)(nrhs - 1) * n3w);
+    ru[I3W(i, j, k)] = GF(on_u)[I2(i, j)] * 0.5 * (hz0 + Hz[ck - 1]) *
         (P[ck - 1] - P0 -
          HalfGRho * ((r0 + rm1) * (z0 - zm1) -
                      OneFifth * ((dRx0 - dRxm) * (z0 - zm1 - OneTwelfth * (dZx0 + dZxm)) -
@@ -125,8 +125,8 @@ k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrh
     const double FC_m1 = rm1 - rm2, FC_0 = r0 - rm1, FC_p1 = rp1 - r0;
     const double dZx0 = harm_inv(aux_0, aux_p1, eps), dZxm = harm_inv(aux_m1, aux_0, eps);
     const double dRx0 = harm_inv(FC_0, FC_p1, eps), dRxm = harm_inv(FC_m1, FC_0, eps);
-    double *rv = c->F.rv + (long)(nrhs - 1) * n3w;
-    rv[I3W(i, j, k)] = c->F.om_v[I2(i, j)] * 0.5 * (hz0 + Hz[ck - ni]) *
+    const gd_t rv = (gd_t)(c->F.rv + (long)(nrhs - 1) * n3w);
+    rv[I3W(i, j, k)] = GF(om_v)[I2(i, j)] * 0.5 * (hz0 + Hz[ck - ni]) *
         (P[ck - ni] - P0 -
          HalfGRho * ((r0 + rm1) * (z0 - zm1) -
                      OneFifth * ((dRx0 - dRxm) * (z0 - zm1 - OneTwelfth * (dZx0 + dZxm)) -

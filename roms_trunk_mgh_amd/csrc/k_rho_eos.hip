@@ -73,12 +73,12 @@ k_rho_eos_nonlin(const RomsDev *__restrict__ c, int nrhs)
   const int j = b.JstrT + XB.y * BLK_Y + threadIdx.y;
   if (i > b.IendT || j > b.JendT) return;
   const long c0 = I2(i, j);
-  const double *__restrict__ T = c->F.t + (long)(nrhs - 1) * n3r;                 // itemp = 1
-  const double *__restrict__ S = c->F.t + ((long)(nrhs - 1) + 3L) * n3r;          // isalt = 2
+  const gcd_t T = (gcd_t)(c->F.t + (long)(nrhs - 1) * n3r);                 // itemp = 1
+  const gcd_t S = (gcd_t)(c->F.t + ((long)(nrhs - 1) + 3L) * n3r);          // isalt = 2
   const bool salt = c->p.salinity != 0 && b.NT >= 2;
-  const double *__restrict__ z_r = c->F.z_r;
-  const double *__restrict__ z_w = c->F.z_w;
-  const double *__restrict__ Hz = c->F.Hz;
+  const gcd_t z_r = (gcd_t)(c->F.z_r);
+  const gcd_t z_w = (gcd_t)(c->F.z_w);
+  const gcd_t Hz = (gcd_t)(c->F.Hz);
   const double g = c->p.g;
   double rhoA = 0.0, rhoS = 0.0;
   EosPt up{};
@@ -99,12 +99,12 @@ k_rho_eos_nonlin(const RomsDev *__restrict__ c, int nrhs)
       const double Tcof = -(e.DbulkDT * cff1 + e.Dden1DT * cff2);
       const double Scof = (e.DbulkDS * cff1 + e.Dden1DS * cff2);
       const double r = 1.0 / wrk;
-      c->F.alpha[c0] = r * Tcof;
-      c->F.beta[c0] = r * Scof;
+      GF(alpha)[c0] = r * Tcof;
+      GF(beta)[c0] = r * Scof;
       const double cf1 = e.den * hz;
       rhoS = 0.5 * cf1 * hz;
       rhoA = cf1;
-      c->F.bvf[c0 + (long)N * nij] = 0.0;
+      GF(bvf)[c0 + (long)N * nij] = 0.0;
     } else {
       e = eos_point<false>(tt, ts, zr);
       const double cf1 = e.den * hz;
@@ -118,18 +118,18 @@ k_rho_eos_nonlin(const RomsDev *__restrict__ c, int nrhs)
       const double c2 = 1.0 / (bulk_dn + 0.1 * zw);
       const double den_up = c1 * (up.den1 * bulk_up);
       const double den_dn = c2 * (e.den1 * bulk_dn);
-      c->F.bvf[c0 + (long)k * nij] = -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (zr_up - zr));
+      GF(bvf)[c0 + (long)k * nij] = -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (zr_up - zr));
     }
-    c->F.rho[ck] = e.den;
-    c->F.pden[ck] = e.den1 - 1000.0;
+    GF(rho)[ck] = e.den;
+    GF(pden)[ck] = e.den1 - 1000.0;
     up = e;
     zr_up = zr;
   }
-  c->F.bvf[c0] = 0.0;
+  GF(bvf)[c0] = 0.0;
   const double cff2 = 1.0 / c->p.rho0;
   const double cff1 = 1.0 / (z_w[c0 + (long)N * nij] - z_w[c0]);
-  c->F.rhoA[c0] = cff2 * cff1 * rhoA;
-  c->F.rhoS[c0] = 2.0 * cff1 * cff1 * cff2 * rhoS;
+  GF(rhoA)[c0] = cff2 * cff1 * rhoA;
+  GF(rhoS)[c0] = 2.0 * cff1 * cff1 * cff2 * rhoS;
 }
 
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
@@ -141,8 +141,8 @@ k_rho_eos_lin(const RomsDev *__restrict__ c, int nrhs)
   const int j = b.JstrT + XB.y * BLK_Y + threadIdx.y;
   if (i > b.IendT || j > b.JendT) return;
   const long c0 = I2(i, j);
-  const double *__restrict__ T = c->F.t + (long)(nrhs - 1) * n3r;
-  const double *__restrict__ S = c->F.t + ((long)(nrhs - 1) + 3L) * n3r;
+  const gcd_t T = (gcd_t)(c->F.t + (long)(nrhs - 1) * n3r);
+  const gcd_t S = (gcd_t)(c->F.t + ((long)(nrhs - 1) + 3L) * n3r);
   const bool salt = c->p.salinity != 0 && b.NT >= 2;
   const double R0 = c->p.R0, T0 = c->p.T0, S0 = c->p.S0, Tcoef = c->p.Tcoef, Scoef = c->p.Scoef;
   double rhoA = 0.0, rhoS = 0.0;
@@ -151,17 +151,17 @@ k_rho_eos_lin(const RomsDev *__restrict__ c, int nrhs)
     double r = R0 - R0 * Tcoef * (T[ck] - T0);
     if (salt) r = r + R0 * Scoef * (S[ck] - S0);
     r = r - 1000.0;
-    c->F.rho[ck] = r;
-    c->F.pden[ck] = r;
-    const double hz = c->F.Hz[ck];
+    GF(rho)[ck] = r;
+    GF(pden)[ck] = r;
+    const double hz = GF(Hz)[ck];
     const double cf1 = r * hz;
     if (k == N) { rhoS = 0.5 * cf1 * hz; rhoA = cf1; }
     else { rhoS = rhoS + hz * (rhoA + 0.5 * cf1); rhoA = rhoA + cf1; }
   }
   const double cff2 = 1.0 / c->p.rho0;
-  const double cff1 = 1.0 / (c->F.z_w[c0 + (long)N * nij] - c->F.z_w[c0]);
-  c->F.rhoA[c0] = cff2 * cff1 * rhoA;
-  c->F.rhoS[c0] = 2.0 * cff1 * cff1 * cff2 * rhoS;
+  const double cff1 = 1.0 / (GF(z_w)[c0 + (long)N * nij] - GF(z_w)[c0]);
+  GF(rhoA)[c0] = cff2 * cff1 * rhoA;
+  GF(rhoS)[c0] = 2.0 * cff1 * cff1 * cff2 * rhoS;
 }
 
 }  // namespace

@@ -98,11 +98,11 @@ __device__ __forceinline__ void rhs3d_lds_body(const RomsDev *__restrict__ c, in
   const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
   const bool active = i <= b.Iend && j <= b.Jend;
   const bool do_u = active && i >= b.IstrU, do_v = active && j >= b.JstrV;
-  const double *__restrict__ ug = c->F.u + (long)(nrhs - 1) * n3r;
-  const double *__restrict__ vg = c->F.v + (long)(nrhs - 1) * n3r;
-  const double *__restrict__ Wg = c->F.W;
-  double *__restrict__ ru = c->F.ru + (long)(nrhs - 1) * n3w;
-  double *__restrict__ rv = c->F.rv + (long)(nrhs - 1) * n3w;
+  const gcd_t ug = (gcd_t)(c->F.u + (long)(nrhs - 1) * n3r);
+  const gcd_t vg = (gcd_t)(c->F.v + (long)(nrhs - 1) * n3r);
+  const gcd_t Wg = (gcd_t)(c->F.W);
+  const gd_t ru = (gd_t)(c->F.ru + (long)(nrhs - 1) * n3w);
+  const gd_t rv = (gd_t)(c->F.rv + (long)(nrhs - 1) * n3w);
   const int ic = active ? i : b.Iend, jc = active ? j : b.Jend;     // clamped for address formation only
   const long c0 = I2(ic, jc);
   T3 L;
@@ -114,11 +114,11 @@ __device__ __forceinline__ void rhs3d_lds_body(const RomsDev *__restrict__ c, in
   const int t = L.at(i, j);
   const int tid = threadIdx.y * BLK_X + threadIdx.x;
   // per-thread constants of the cell terms
-  const double fomn0 = c->F.fomn[c0], fomnw = c->F.fomn[c0 - 1], fomns = c->F.fomn[c0 - ni];
+  const double fomn0 = GF(fomn)[c0], fomnw = GF(fomn)[c0 - 1], fomns = GF(fomn)[c0 - ni];
   double dndx0 = 0, dndxw = 0, dndxs = 0, dmde0 = 0, dmdew = 0, dmdes = 0;
   if (curv) {
-    dndx0 = c->F.dndx[c0]; dndxw = c->F.dndx[c0 - 1]; dndxs = c->F.dndx[c0 - ni];
-    dmde0 = c->F.dmde[c0]; dmdew = c->F.dmde[c0 - 1]; dmdes = c->F.dmde[c0 - ni];
+    dndx0 = GF(dndx)[c0]; dndxw = GF(dndx)[c0 - 1]; dndxs = GF(dndx)[c0 - ni];
+    dmde0 = GF(dmde)[c0]; dmdew = GF(dmde)[c0 - 1]; dmdes = GF(dmde)[c0 - ni];
   }
   double u_m1 = 0.0, u_0 = ug[c0], u_p1 = ug[c0 + nij], u_p2;
   double v_m1 = 0.0, v_0 = vg[c0], v_p1 = vg[c0 + nij], v_p2;
@@ -258,16 +258,16 @@ __device__ __forceinline__ void rhs3d_lds_body(const RomsDev *__restrict__ c, in
     v_m1 = v_0; v_0 = v_p1; v_p1 = v_p2;
   }
   if (do_u) {
-    const double cff = c->F.om_u[c0] * c->F.on_u[c0];
-    const double cff1 = c->F.sustr[c0] * cff;
-    const double cff2 = -c->F.bustr[c0] * cff;
-    c->F.rufrc[c0] = sum_u + cff1 + cff2;
+    const double cff = GF(om_u)[c0] * GF(on_u)[c0];
+    const double cff1 = GF(sustr)[c0] * cff;
+    const double cff2 = -GF(bustr)[c0] * cff;
+    GF(rufrc)[c0] = sum_u + cff1 + cff2;
   }
   if (do_v) {
-    const double cff = c->F.om_v[c0] * c->F.on_v[c0];
-    const double cff1 = c->F.svstr[c0] * cff;
-    const double cff2 = -c->F.bvstr[c0] * cff;
-    c->F.rvfrc[c0] = sum_v + cff1 + cff2;
+    const double cff = GF(om_v)[c0] * GF(on_v)[c0];
+    const double cff1 = GF(svstr)[c0] * cff;
+    const double cff2 = -GF(bvstr)[c0] * cff;
+    GF(rvfrc)[c0] = sum_v + cff1 + cff2;
   }
 }
 

@@ -52,19 +52,19 @@ k2d_flux(const RomsDev *__restrict__ c, S2 s, double *__restrict__ DUon, double 
   const int j = b.JstrV - 2 + blockIdx.y * BLK_Y + threadIdx.y;
   if (i > i1 || j > b.Jendp2) return;
   const int is = s.sm ? wrap_i(b, i) : i;
-  const double *__restrict__ zeta = c->F.zeta + (long)(s.krhs - 1) * nij;
-  const double *__restrict__ h = c->F.h;
+  const gcd_t zeta = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
+  const gcd_t h = (gcd_t)(c->F.h);
   const long a = I2(is, j), o = I2(i, j);
   const double Drhs = zeta[a] + h[a];
   if (s.sm || i >= b.IstrU - 1) {
-    const double cff = 0.5 * c->F.on_u[a];
+    const double cff = 0.5 * GF(on_u)[a];
     const double cff1 = cff * (Drhs + (zeta[a - 1] + h[a - 1]));
-    DUon[o] = c->F.ubar[a + (long)(s.krhs - 1) * nij] * cff1;
+    DUon[o] = GF(ubar)[a + (long)(s.krhs - 1) * nij] * cff1;
   }
   if (j >= b.JstrV - 1) {
-    const double cff = 0.5 * c->F.om_v[a];
+    const double cff = 0.5 * GF(om_v)[a];
     const double cff1 = cff * (Drhs + (zeta[a - ni] + h[a - ni]));
-    DVom[o] = c->F.vbar[a + (long)(s.krhs - 1) * nij] * cff1;
+    DVom[o] = GF(vbar)[a + (long)(s.krhs - 1) * nij] * cff1;
   }
 }
 
@@ -78,8 +78,8 @@ k2d_flux_own(const RomsDev *__restrict__ c, int lev, double *__restrict__ DUon, 
   const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
   const int j = b.JstrR + blockIdx.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.JendR) return;
-  const double *__restrict__ zeta = c->F.zeta + (long)(lev - 1) * nij;
-  const double *__restrict__ h = c->F.h;
+  const gcd_t zeta = (gcd_t)(c->F.zeta + (long)(lev - 1) * nij);
+  const gcd_t h = (gcd_t)(c->F.h);
   const long a = I2(i, j);
   // zeta on a closed-wall row is the zero-gradient copy of the adjacent interior row (zetabc.F:48);
   // it is read from that row directly because bc_zeta fills the wall rows of the OWN columns only and
@@ -91,14 +91,14 @@ k2d_flux_own(const RomsDev *__restrict__ c, int lev, double *__restrict__ DUon, 
   };
   const double Drhs = zeta[I2(i, zrow(j))] + h[a];
   {
-    const double cff = 0.5 * c->F.on_u[a];
+    const double cff = 0.5 * GF(on_u)[a];
     const double cff1 = cff * (Drhs + (zeta[I2(i - 1, zrow(j))] + h[a - 1]));
-    DUon[a] = c->F.ubar[a + (long)(lev - 1) * nij] * cff1;
+    DUon[a] = GF(ubar)[a + (long)(lev - 1) * nij] * cff1;
   }
   if (j >= b.JstrV - 1 && j >= b.LBj + 1) {
-    const double cff = 0.5 * c->F.om_v[a];
+    const double cff = 0.5 * GF(om_v)[a];
     const double cff1 = cff * (Drhs + (zeta[I2(i, zrow(j - 1))] + h[a - ni]));
-    DVom[a] = c->F.vbar[a + (long)(lev - 1) * nij] * cff1;
+    DVom[a] = GF(vbar)[a + (long)(lev - 1) * nij] * cff1;
   }
 }
 
@@ -116,7 +116,7 @@ k2d_zeta(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, c
   const roms_params_t &p = c->p;
   const long a = I2(i, j);
   const int iif = s.iif, nfast = p.nfast;
-  const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
+  const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
   // ---- fast-time averaging, :614-682 ----
   const bool inR = i >= b.IstrR && j >= b.JstrR;
   if (inR) {
@@ -124,26 +124,26 @@ k2d_zeta(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, c
     if (s.predictor) {
       if (iif == 1) {
         const double cff2 = (-1.0 / 12.0) * p.weight2[iif];
-        c->F.Zt_avg1[a] = 0.0;
-        if (inU) { c->F.DU_avg1[a] = 0.0; c->F.DU_avg2[a] = cff2 * DUon[a]; }
-        if (inV) { c->F.DV_avg1[a] = 0.0; c->F.DV_avg2[a] = cff2 * DVom[a]; }
+        GF(Zt_avg1)[a] = 0.0;
+        if (inU) { GF(DU_avg1)[a] = 0.0; GF(DU_avg2)[a] = cff2 * DUon[a]; }
+        if (inV) { GF(DV_avg1)[a] = 0.0; GF(DV_avg2)[a] = cff2 * DVom[a]; }
       } else {
         const double cff1 = p.weight1[iif - 2];
         const double cff2 = (8.0 / 12.0) * p.weight2[iif - 1] - (1.0 / 12.0) * p.weight2[iif];
-        c->F.Zt_avg1[a] = c->F.Zt_avg1[a] + cff1 * zk[a];
+        GF(Zt_avg1)[a] = GF(Zt_avg1)[a] + cff1 * zk[a];
         if (inU) {
-          c->F.DU_avg1[a] = c->F.DU_avg1[a] + cff1 * DUon[a];
-          c->F.DU_avg2[a] = c->F.DU_avg2[a] + cff2 * DUon[a];
+          GF(DU_avg1)[a] = GF(DU_avg1)[a] + cff1 * DUon[a];
+          GF(DU_avg2)[a] = GF(DU_avg2)[a] + cff2 * DUon[a];
         }
         if (inV) {
-          c->F.DV_avg1[a] = c->F.DV_avg1[a] + cff1 * DVom[a];
-          c->F.DV_avg2[a] = c->F.DV_avg2[a] + cff2 * DVom[a];
+          GF(DV_avg1)[a] = GF(DV_avg1)[a] + cff1 * DVom[a];
+          GF(DV_avg2)[a] = GF(DV_avg2)[a] + cff2 * DVom[a];
         }
       }
     } else {
       const double cff2 = (iif == 1) ? p.weight2[iif - 1] : (5.0 / 12.0) * p.weight2[iif - 1];
-      if (inU) c->F.DU_avg2[a] = c->F.DU_avg2[a] + cff2 * DUon[a];
-      if (inV) c->F.DV_avg2[a] = c->F.DV_avg2[a] + cff2 * DVom[a];
+      if (inU) GF(DU_avg2)[a] = GF(DU_avg2)[a] + cff2 * DUon[a];
+      if (inV) GF(DV_avg2)[a] = GF(DV_avg2)[a] + cff2 * DVom[a];
     }
   }
   if (iif > nfast) return;
@@ -174,49 +174,49 @@ k2d_zeta_sm(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const long o = I2(i, j);
   // DUon / DVom (:509-544): from scratch, or -- when k2d_flux was not launched (DUon == nullptr) --
   // evaluated in place with the same expression, so no separate flux kernel is needed
-  const double *__restrict__ zkq = c->F.zeta + (long)(s.krhs - 1) * nij;
-  const double *__restrict__ hq = c->F.h;
-  const double *__restrict__ ubq = c->F.ubar + (long)(s.krhs - 1) * nij;
-  const double *__restrict__ vbq = c->F.vbar + (long)(s.krhs - 1) * nij;
+  const gcd_t zkq = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
+  const gcd_t hq = (gcd_t)(c->F.h);
+  const gcd_t ubq = (gcd_t)(c->F.ubar + (long)(s.krhs - 1) * nij);
+  const gcd_t vbq = (gcd_t)(c->F.vbar + (long)(s.krhs - 1) * nij);
   auto du = [&](long q) -> double {
     if (DUon) return DUon[q];
-    const double cff = 0.5 * c->F.on_u[q];
+    const double cff = 0.5 * GF(on_u)[q];
     const double cff1 = cff * ((zkq[q] + hq[q]) + (zkq[q - 1] + hq[q - 1]));
     return ubq[q] * cff1;
   };
   auto dv = [&](long q) -> double {
     if (DVom) return DVom[q];
-    const double cff = 0.5 * c->F.om_v[q];
+    const double cff = 0.5 * GF(om_v)[q];
     const double cff1 = cff * ((zkq[q] + hq[q]) + (zkq[q - ni] + hq[q - ni]));
     return vbq[q] * cff1;
   };
   // ---- fast-time averaging on the owned ranges only, :614-682 ----
   if (i >= b.IstrR && i <= b.IendR && j >= b.JstrR && j <= b.JendR) {
-    const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
+    const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
     const bool inU = i >= b.Istr, inV = j >= b.Jstr;
     if (s.predictor) {
       if (iif == 1) {
         const double cff2 = (-1.0 / 12.0) * p.weight2[iif];
-        c->F.Zt_avg1[o] = 0.0;
-        if (inU) { c->F.DU_avg1[o] = 0.0; c->F.DU_avg2[o] = cff2 * du(o); }
-        if (inV) { c->F.DV_avg1[o] = 0.0; c->F.DV_avg2[o] = cff2 * dv(o); }
+        GF(Zt_avg1)[o] = 0.0;
+        if (inU) { GF(DU_avg1)[o] = 0.0; GF(DU_avg2)[o] = cff2 * du(o); }
+        if (inV) { GF(DV_avg1)[o] = 0.0; GF(DV_avg2)[o] = cff2 * dv(o); }
       } else {
         const double cff1 = p.weight1[iif - 2];
         const double cff2 = (8.0 / 12.0) * p.weight2[iif - 1] - (1.0 / 12.0) * p.weight2[iif];
-        c->F.Zt_avg1[o] = c->F.Zt_avg1[o] + cff1 * zk[o];
+        GF(Zt_avg1)[o] = GF(Zt_avg1)[o] + cff1 * zk[o];
         if (inU) {
-          c->F.DU_avg1[o] = c->F.DU_avg1[o] + cff1 * du(o);
-          c->F.DU_avg2[o] = c->F.DU_avg2[o] + cff2 * du(o);
+          GF(DU_avg1)[o] = GF(DU_avg1)[o] + cff1 * du(o);
+          GF(DU_avg2)[o] = GF(DU_avg2)[o] + cff2 * du(o);
         }
         if (inV) {
-          c->F.DV_avg1[o] = c->F.DV_avg1[o] + cff1 * dv(o);
-          c->F.DV_avg2[o] = c->F.DV_avg2[o] + cff2 * dv(o);
+          GF(DV_avg1)[o] = GF(DV_avg1)[o] + cff1 * dv(o);
+          GF(DV_avg2)[o] = GF(DV_avg2)[o] + cff2 * dv(o);
         }
       }
     } else {
       const double cff2 = (iif == 1) ? p.weight2[iif - 1] : (5.0 / 12.0) * p.weight2[iif - 1];
-      if (inU) c->F.DU_avg2[o] = c->F.DU_avg2[o] + cff2 * du(o);
-      if (inV) c->F.DV_avg2[o] = c->F.DV_avg2[o] + cff2 * dv(o);
+      if (inU) GF(DU_avg2)[o] = GF(DU_avg2)[o] + cff2 * du(o);
+      if (inV) GF(DV_avg2)[o] = GF(DV_avg2)[o] + cff2 * dv(o);
     }
   }
   if (iif > nfast) return;
@@ -239,10 +239,10 @@ __device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const 
 {
   const roms_params_t &p = c->p;
   const int iif = s.iif;
-  const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
+  const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
   const double dtfast = p.dtfast;
-  const double *__restrict__ zs = c->F.zeta + (long)(s.kstp - 1) * nij;
-  const double pmn_a = c->F.pm[a], pn_a = c->F.pn[a];
+  const gcd_t zs = (gcd_t)(c->F.zeta + (long)(s.kstp - 1) * nij);
+  const double pmn_a = GF(pm)[a], pn_a = GF(pn)[a];
   double zn, zw;
   if (iif == 1) {
     const double cff1 = dtfast;
@@ -262,13 +262,13 @@ __device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const 
     const double cff4 = 2.0 / 5.0;
     const double cff5 = 1.0 - cff4;
     const double cff = cff1 * rhs;
-    zn = zs[a] + pmn_a * pn_a * (cff + cff2 * c->F.rzeta[a + (long)(s.kstp - 1) * nij] -
-                                 cff3 * c->F.rzeta[a + (long)(ptsk - 1) * nij]);
+    zn = zs[a] + pmn_a * pn_a * (cff + cff2 * GF(rzeta)[a + (long)(s.kstp - 1) * nij] -
+                                 cff3 * GF(rzeta)[a + (long)(ptsk - 1) * nij]);
     zw = cff5 * zn + cff4 * zk[a];
   }
   if (write_scratch) { zeta_new[o] = zn; zwrk[o] = zw; }
-  if (write_zeta) c->F.zeta[o + (long)(s.knew - 1) * nij] = zn;
-  if (write_rzeta && s.predictor) c->F.rzeta[o + (long)(s.krhs - 1) * nij] = rhs;
+  if (write_zeta) GF(zeta)[o + (long)(s.knew - 1) * nij] = zn;
+  if (write_rzeta && s.predictor) GF(rzeta)[o + (long)(s.krhs - 1) * nij] = rhs;
 }
 
 // ---------------------------------------------------------------- momentum --
@@ -355,13 +355,13 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
   }
   const long a = I2(i, j);
   const long o = I2(it, jt);
-  const double *__restrict__ h = c->F.h;
-  const double *__restrict__ rhoA = c->F.rhoA;
-  const double *__restrict__ rhoS = c->F.rhoS;
-  const double *__restrict__ pm = c->F.pm;
-  const double *__restrict__ pn = c->F.pn;
-  const double *__restrict__ zk = c->F.zeta + (long)(s.krhs - 1) * nij;
-  const double *__restrict__ zs = c->F.zeta + (long)(s.kstp - 1) * nij;
+  const gcd_t h = (gcd_t)(c->F.h);
+  const gcd_t rhoA = (gcd_t)(c->F.rhoA);
+  const gcd_t rhoS = (gcd_t)(c->F.rhoS);
+  const gcd_t pm = (gcd_t)(c->F.pm);
+  const gcd_t pn = (gcd_t)(c->F.pn);
+  const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
+  const gcd_t zs = (gcd_t)(c->F.zeta + (long)(s.kstp - 1) * nij);
   M2 m;
   m.ub = c->F.ubar + (long)(s.krhs - 1) * nij;
   m.vb = c->F.vbar + (long)(s.krhs - 1) * nij;
@@ -379,7 +379,7 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
     const long q = a - 1;
     const double zw = zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
-    rhs_u = cg * c->F.on_u[a] *
+    rhs_u = cg * GF(on_u)[a] *
             ((h[q] + h[a]) * (gz - gz0) +
              (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
              (gz2 - gz20));
@@ -388,7 +388,7 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
     const long q = a - ni;
     const double zw = zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
-    rhs_v = cg * c->F.om_v[a] *
+    rhs_v = cg * GF(om_v)[a] *
             ((h[q] + h[a]) * (gz - gz0) +
              (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
              (gz2 - gz20));
@@ -410,7 +410,7 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
   const double D0 = zk[a] + h[a], Dw = zk[a - 1] + h[a - 1], Ds = zk[a - ni] + h[a - ni];
   // ---- Coriolis, :1291-1325 ----
   if (p.uv_cor) {
-    const double *fomn = c->F.fomn;
+    const gcd_t fomn = (gcd_t)(c->F.fomn);
     const double cf0 = 0.5 * D0 * fomn[a];
     const double UFx0 = cf0 * (m.vb[a] + m.vb[a + ni]);
     const double VFe0 = cf0 * (m.ub[a] + m.ub[a + 1]);
@@ -427,7 +427,7 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
   }
   // ---- curvilinear terms, :1333-1382 ----
   if (p.curvgrid && p.uv_adv) {
-    const double *dndx = c->F.dndx, *dmde = c->F.dmde;
+    const gcd_t dndx = (gcd_t)c->F.dndx, dmde = (gcd_t)c->F.dmde;
     auto cell = [&](long q, double D, double &ufx, double &vfe) {
       const double cff1 = 0.5 * (m.vb[q] + m.vb[q + ni]);
       const double cff2 = 0.5 * (m.ub[q] + m.ub[q + 1]);
@@ -444,9 +444,9 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
   }
   // ---- harmonic viscosity, :1394-1471 ----
   if (p.uv_vis2) {
-    const double *visc2_r = c->F.visc2_r, *visc2_p = c->F.visc2_p;
-    const double *pmon_r = c->F.pmon_r, *pnom_r = c->F.pnom_r, *pmon_p = c->F.pmon_p, *pnom_p = c->F.pnom_p;
-    const double *om_r = c->F.om_r, *on_r = c->F.on_r, *om_p = c->F.om_p, *on_p = c->F.on_p;
+    const gcd_t visc2_r = (gcd_t)c->F.visc2_r, visc2_p = (gcd_t)c->F.visc2_p;
+    const gcd_t pmon_r = (gcd_t)c->F.pmon_r, pnom_r = (gcd_t)c->F.pnom_r, pmon_p = (gcd_t)c->F.pmon_p, pnom_p = (gcd_t)c->F.pnom_p;
+    const gcd_t om_r = (gcd_t)c->F.om_r, on_r = (gcd_t)c->F.on_r, om_p = (gcd_t)c->F.om_p, on_p = (gcd_t)c->F.on_p;
     auto Dat = [&](long q) { return zk[q] + h[q]; };
     auto str_r = [&](long q) {       // cff at rho-point q
       return visc2_r[q] * Dat(q) * 0.5 *
@@ -479,29 +479,29 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
   }
   // ---- coupling between 2-D and 3-D equations, :1884-2065 ----
   if (s.iif == 1 && s.predictor) {
-    double *ru_s = c->F.ru + (long)(s.nstp - 1) * n3w;      // k = 0 plane
-    double *rv_s = c->F.rv + (long)(s.nstp - 1) * n3w;
-    const double *ru_n = c->F.ru + (long)(s.nnew - 1) * n3w;
-    const double *rv_n = c->F.rv + (long)(s.nnew - 1) * n3w;
+    const gd_t ru_s = (gd_t)(c->F.ru + (long)(s.nstp - 1) * n3w);      // k = 0 plane
+    const gd_t rv_s = (gd_t)(c->F.rv + (long)(s.nstp - 1) * n3w);
+    const gcd_t ru_n = (gcd_t)(c->F.ru + (long)(s.nnew - 1) * n3w);
+    const gcd_t rv_n = (gcd_t)(c->F.rv + (long)(s.nnew - 1) * n3w);
     if (do_u) {
-      const double rf = c->F.rufrc[a] - rhs_u;
+      const double rf = GF(rufrc)[a] - rhs_u;
       if (s.iic == s.ntfirst) rhs_u = rhs_u + rf;
       else if (s.iic == s.ntfirst + 1) rhs_u = rhs_u + 1.5 * rf - 0.5 * ru_n[a];
       else rhs_u = rhs_u + (23.0 / 12.0) * rf - (16.0 / 12.0) * ru_n[a] + (5.0 / 12.0) * ru_s[a];
-      if (owner) c->F.rufrc[a] = rf;
+      if (owner) GF(rufrc)[a] = rf;
       if (owner) ru_s[a] = rf;
     }
     if (do_v) {
-      const double rf = c->F.rvfrc[a] - rhs_v;
+      const double rf = GF(rvfrc)[a] - rhs_v;
       if (s.iic == s.ntfirst) rhs_v = rhs_v + rf;
       else if (s.iic == s.ntfirst + 1) rhs_v = rhs_v + 1.5 * rf - 0.5 * rv_n[a];
       else rhs_v = rhs_v + (23.0 / 12.0) * rf - (16.0 / 12.0) * rv_n[a] + (5.0 / 12.0) * rv_s[a];
-      if (owner) c->F.rvfrc[a] = rf;
+      if (owner) GF(rvfrc)[a] = rf;
       if (owner) rv_s[a] = rf;
     }
   } else {
-    if (do_u) rhs_u = rhs_u + c->F.rufrc[a];
-    if (do_v) rhs_v = rhs_v + c->F.rvfrc[a];
+    if (do_u) rhs_u = rhs_u + GF(rufrc)[a];
+    if (do_v) rhs_v = rhs_v + GF(rvfrc)[a];
   }
   // ---- time step, :2098-2255 ----
   const double dtfast = p.dtfast;
@@ -514,29 +514,29 @@ k2d_mom(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, co
     const long q = a - 1;
     const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
     const double fc = 1.0 / (Dn0 + (zeta_new[q] + h[q]));
-    const double us = c->F.ubar[a + (long)(s.kstp - 1) * nij];
+    const double us = GF(ubar)[a + (long)(s.kstp - 1) * nij];
     double un;
     if (!am3) un = (us * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_u) * fc;
     else un = (us * (Dst0 + (zs[q] + h[q])) +
-               cff * (a1 * rhs_u + a2 * c->F.rubar[a + (long)(s.kstp - 1) * nij] -
-                      a3 * c->F.rubar[a + (long)(ptsk - 1) * nij])) * fc;
-    c->F.ubar[o + (long)(s.knew - 1) * nij] = (fu == 1.0) ? un : fu * un;
-    if (s.predictor && owner) c->F.rubar[a + (long)(s.krhs - 1) * nij] = rhs_u;
+               cff * (a1 * rhs_u + a2 * GF(rubar)[a + (long)(s.kstp - 1) * nij] -
+                      a3 * GF(rubar)[a + (long)(ptsk - 1) * nij])) * fc;
+    GF(ubar)[o + (long)(s.knew - 1) * nij] = (fu == 1.0) ? un : fu * un;
+    if (s.predictor && owner) GF(rubar)[a + (long)(s.krhs - 1) * nij] = rhs_u;
   }
   if (do_v) {
     const long q = a - ni;
     const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
     const double fc = 1.0 / (Dn0 + (zeta_new[q] + h[q]));
-    const double vs = c->F.vbar[a + (long)(s.kstp - 1) * nij];
+    const double vs = GF(vbar)[a + (long)(s.kstp - 1) * nij];
     double vn;
     if (!am3) vn = (vs * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_v) * fc;
     else vn = (vs * (Dst0 + (zs[q] + h[q])) +
-               cff * (a1 * rhs_v + a2 * c->F.rvbar[a + (long)(s.kstp - 1) * nij] -
-                      a3 * c->F.rvbar[a + (long)(ptsk - 1) * nij])) * fc;
-    c->F.vbar[o + (long)(s.knew - 1) * nij] = vn;
-    if (s.predictor && owner) c->F.rvbar[a + (long)(s.krhs - 1) * nij] = rhs_v;
+               cff * (a1 * rhs_v + a2 * GF(rvbar)[a + (long)(s.kstp - 1) * nij] -
+                      a3 * GF(rvbar)[a + (long)(ptsk - 1) * nij])) * fc;
+    GF(vbar)[o + (long)(s.knew - 1) * nij] = vn;
+    if (s.predictor && owner) GF(rvbar)[a + (long)(s.krhs - 1) * nij] = rhs_v;
   }
-  if (v_wall) c->F.vbar[o + (long)(s.knew - 1) * nij] = 0.0;
+  if (v_wall) GF(vbar)[o + (long)(s.knew - 1) * nij] = 0.0;
 }
 
 // DUon/DVom scratch already holds the exchanged fluxes of barotropic level g_flux_lev (left there by the

@@ -62,7 +62,7 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   const gcd_t Wv = (gcd_t)c->F.W;
   const gcd_t Hz = (gcd_t)c->F.Hz;
   const gcd_t Akt = (gcd_t)(c->F.Akt + (long)(ltrc - 1) * n3w);
-  const double cffdt = dt * c->F.pm[I2(i, j)] * c->F.pn[I2(i, j)];
+  const double cffdt = dt * GF(pm)[I2(i, j)] * GF(pn)[I2(i, j)];
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;       // FE(Jstr-1)=FE(Jstr)
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;       // FE(Jend+2)=FE(Jend+1)
   const bool n_wall1 = b.north_edge && !b.NSperiodic && j == b.Jend - 1;
@@ -244,7 +244,7 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   const gcd_t Wv = (gcd_t)c->F.W;
   const gcd_t Hz = (gcd_t)c->F.Hz;
   const gcd_t Akt = (gcd_t)(c->F.Akt + (long)(ltrc - 1) * n3w);
-  const double cffdt = dt * c->F.pm[I2(i, j)] * c->F.pn[I2(i, j)];
+  const double cffdt = dt * GF(pm)[I2(i, j)] * GF(pn)[I2(i, j)];
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
   const long c0 = I2(i, j);

@@ -22,11 +22,11 @@ namespace {
 // One momentum column.  off = 1 (u: neighbour i-1) or ni (v: neighbour j-1).
 template <int NMAX>
 __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
-                                          double *__restrict__ vel, const double *__restrict__ rhs,
+                                          gd_t vel, gcd_t rhs,
                                           double dc0, double metric, double Davg1)
 {
-  const double *__restrict__ Akv = c->F.Akv;
-  const double *__restrict__ Hz = c->F.Hz;
+  const gcd_t Akv = (gcd_t)(c->F.Akv);
+  const gcd_t Hz = (gcd_t)(c->F.Hz);
   const double dt = c->p.dt;
   double un[NMAX + 1], CF[NMAX + 1], DC[NMAX + 1];
   CF[0] = 0.0;
@@ -104,29 +104,29 @@ k_uv_column(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
   const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
   const long c0 = I2(i, j);
-  const double *pm = c->F.pm, *pn = c->F.pn;
+  const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn;
   // blockIdx.z selects the component so that both columns do not share VGPRs
   if (XB.z == 0) {
     if (i < b.IstrU) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - 1]) * (pn[c0] + pn[c0 - 1]);
-    uv_column<NMAX>(c, c0, 1, nij, N, c->F.u + (long)(nnew - 1) * n3r, c->F.ru + (long)(nrhs - 1) * n3w, dc0,
-                    c->F.on_u[c0], c->F.DU_avg1[c0]);
+    uv_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), (gcd_t)(c->F.ru + (long)(nrhs - 1) * n3w), dc0,
+                    GF(on_u)[c0], GF(DU_avg1)[c0]);
   } else {
     if (j < b.JstrV) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - ni]) * (pn[c0] + pn[c0 - ni]);
-    uv_column<NMAX>(c, c0, ni, nij, N, c->F.v + (long)(nnew - 1) * n3r, c->F.rv + (long)(nrhs - 1) * n3w, dc0,
-                    c->F.om_v[c0], c->F.DV_avg1[c0]);
+    uv_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), (gcd_t)(c->F.rv + (long)(nrhs - 1) * n3w), dc0,
+                    GF(om_v)[c0], GF(DV_avg1)[c0]);
   }
 }
 
 // Coupling of one column; comp 0 = u (neighbour i-1), 1 = v (neighbour j-1).
 template <int NMAX>
 __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
-                                              double *__restrict__ vel, double *__restrict__ Hflx,
-                                              double *__restrict__ bar, double metric, double Davg1, double Davg2,
+                                              gd_t vel, gd_t Hflx,
+                                              gd_t bar, double metric, double Davg1, double Davg2,
                                               bool fix_mean)
 {
-  const double *__restrict__ Hz = c->F.Hz;
+  const gcd_t Hz = (gcd_t)(c->F.Hz);
   const double cff = 0.5 * metric;
   double DC0 = 0.0, CF0 = 0.0;
   double hu[NMAX + 1];
@@ -182,13 +182,13 @@ k_uv_couple(const RomsDev *__restrict__ c, int nnew)
   if (XB.z == 0) {
     if (i < b.IstrP) return;
     const bool fix = ns_wall && (j == 0 || j == b.Mm + 1) && i >= b.IstrU && i <= b.Iend;
-    couple_column<NMAX>(c, c0, 1, nij, N, c->F.u + (long)(nnew - 1) * n3r, c->F.Huon, c->F.ubar, c->F.on_u[c0],
-                        c->F.DU_avg1[c0], c->F.DU_avg2[c0], fix);
+    couple_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), GF(Huon), GF(ubar), GF(on_u)[c0],
+                        GF(DU_avg1)[c0], GF(DU_avg2)[c0], fix);
   } else {
     if (j < b.Jstr) return;
     const bool fix = ns_wall && (j == 1 || j == b.Mm + 1) && i >= b.Istr && i <= b.Iend;
-    couple_column<NMAX>(c, c0, ni, nij, N, c->F.v + (long)(nnew - 1) * n3r, c->F.Hvom, c->F.vbar, c->F.om_v[c0],
-                        c->F.DV_avg1[c0], c->F.DV_avg2[c0], fix);
+    couple_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), GF(Hvom), GF(vbar), GF(om_v)[c0],
+                        GF(DV_avg1)[c0], GF(DV_avg2)[c0], fix);
   }
 }
 
