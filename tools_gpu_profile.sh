@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-KERNELS=calib_stream,step3d_t,rhs3d_tile,pre_step3d,step3d_uv,uv3dmix2,t3dmix2,prsgrd,rho_eos,omega,set_massflux,set_depth
+KERNELS=calib_stream,step3d_t,rhs3d_tile,pre_step3d,step3d_uv,uv3dmix2,t3dmix2,prsgrd,rho_eos,omega,set_massflux,set_depth,lmd_vmix,bulk_flux,wvelocity,diag,step2d
 export PYTHONPATH=$R
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o "$TAG" --output-format csv -- \
   python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
