@@ -220,20 +220,22 @@ int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1);
 int roms_hip_exchange(int field_id, int level);
 
 /* Second halo transport: a host relay.  When roms_hip_init got no RCCL id (NULL) on a
- * multi-tile run, every exchange phase packs the ghost lines on the device, copies them
- * to pinned host memory and calls `fn`, which must deliver send_lo to rank lo_rank and
- * send_hi to rank hi_rank and fill recv_lo / recv_hi from the same ranks (a rank < 0
- * means no neighbour on that side; dir 0 = west/east phase, 1 = south/north phase;
- * counts are in doubles) -- e.g. with the MPI_Isend/MPI_Irecv the reference's
- * mp_exchange2d (ROMS/Utility/mp_exchange.F:290-560) already uses.  Return 0 on success.
+ * multi-tile run, every exchange packs its messages on the device (one per neighbour tile: W, E, S, N
+ * and the four diagonal ones, as far as they exist), copies them to pinned host memory and calls `fn`,
+ * which must deliver send[m].buf (count doubles) to rank send[m].peer with message tag send[m].tag and
+ * fill recv[m].buf from rank recv[m].peer, tag recv[m].tag -- e.g. with the MPI_Isend / MPI_Irecv /
+ * MPI_Waitall the reference's mp_exchange2d (ROMS/Utility/mp_exchange.F:290-560) already uses.  Two
+ * messages between the same pair of ranks differ in their tag.  Return 0 on success.
  * The RCCL transport is the fast one; the relay exists for hosts that own the
  * interconnect and for rehearsing N tiles on fewer GPUs. */
-typedef int (*roms_halo_relay_fn)(void *user, int dir, int lo_rank, int hi_rank,
-                                  const double *send_lo, long n_send_lo,
-                                  const double *send_hi, long n_send_hi,
-                                  double *recv_lo, long n_recv_lo,
-                                  double *recv_hi, long n_recv_hi);
+typedef struct { int peer; int tag; long count; double *buf; } roms_halo_msg_t;
+typedef int (*roms_halo_relay_fn)(void *user, int nsend, const roms_halo_msg_t *send,
+                                  int nrecv, const roms_halo_msg_t *recv);
 int roms_hip_set_halo_relay(roms_halo_relay_fn fn, void *user);
+/* Host-only (no GPU): the messages tile `rank` exchanges per halo update for the bounds *b:
+ * out = nsend, nrecv, then (peer, tag, i0, wi, j0, wj) per message, sends first; at most 8 + 8 messages
+ * (98 ints).  Exported for the CPU tests, which play a whole 4x2 exchange with it. */
+int roms_hip_halo_plan(const roms_bounds_t *b, int rank, int *out);
 
 /* Timing helper: average device milliseconds of the last call of each entry
  * measured with hipEvents on the library's stream (bench.py roofline). */

@@ -6,8 +6,11 @@
 // host synchronisation).
 //
 // Semantics kept from the reference (mp_exchange.F:73-286, tile_neighbors):
-//   * two dependent phases, W/E first then S/N over the FULL i-range including
-//     the just-received ghost columns, so corners ride along in phase 2;
+//   * the reference runs two dependent phases, W/E first, then S/N over the FULL i-range including
+//     the just-received ghost columns, so that corners ride along in phase 2.  Here ONE phase with up
+//     to eight messages (W, E, S, N and the four diagonal tiles) leaves the same values in every ghost
+//     point -- a corner block is the diagonal tile's interior either way -- at half the latency, which
+//     is what bounds a 4x2 run (about 70 exchanges per step);
 //   * rank = Jtile*NtileI + Itile; periodic directions wrap to the far tile;
 //   * with 2 ghost points and periodicity the west-most tile receives
 //     Nghost+1 columns from the east-most tile (which sends Nghost+1).
@@ -117,17 +120,15 @@ extern "C" int roms_hip_tile_neighbors(int rank, int ntileI, int ntileJ, int Ngh
 
 static Neigh g_neigh;
 static bool g_have_neigh = false;
-static double *g_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLo, sendHi, recvLo, recvHi
-static double *g_hbuf[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned host mirrors (relay transport)
+static double *g_buf[2] = {nullptr, nullptr};     // all outgoing messages, all incoming messages (device)
+static double *g_hbuf[2] = {nullptr, nullptr};    // pinned host mirrors (relay transport)
 static size_t g_buf_doubles = 0, g_hbuf_doubles = 0;
 
-// Host-relay transport: the packed ghost lines are handed to a host callback that moves
-// them with whatever the host application already has (the reference's own MPI, or gloo
-// in the tests) -- the same pack/unpack kernels, neighbour table and phase order as the
-// RCCL transport, with a device<->pinned-host copy on either side.
-typedef int (*roms_halo_relay_fn)(void *user, int dir, int lo_rank, int hi_rank,
-                                  const double *send_lo, long n_send_lo, const double *send_hi, long n_send_hi,
-                                  double *recv_lo, long n_recv_lo, double *recv_hi, long n_recv_hi);
+// Host-relay transport: the packed messages are handed to a host callback that moves them with
+// whatever the host application already has (the reference's own MPI, or gloo in the tests) -- the
+// same pack/unpack kernels, neighbour table and message list as the RCCL transport, with one
+// device<->pinned-host copy on either side.  (typedefs: include/roms_hip.h)
+static bool g_have_plan = false;              // message plan of this tile (built at the first exchange)
 static roms_halo_relay_fn g_relay = nullptr;
 static void *g_relay_user = nullptr;
 extern "C" int roms_hip_set_halo_relay(roms_halo_relay_fn fn, void *user)
@@ -155,6 +156,7 @@ int halo_finalize()
   for (auto &p : g_hbuf) { if (p) hipHostFree(p); p = nullptr; }
   g_buf_doubles = g_hbuf_doubles = 0;
   g_have_neigh = false;
+  g_have_plan = false;
   g_relay = nullptr;
   g_relay_user = nullptr;
   if (g_ctx.nccl_comm && rccl.destroy) rccl.destroy((rccl_comm_t)g_ctx.nccl_comm);
@@ -198,48 +200,36 @@ __global__ void k_periodic_multi(const RomsDev *__restrict__ c, PeriodicArgs a)
 }
 
 // --------------------------------------------------- multi-tile pack/unpack --
-// dir 0: columns i0..i0+G-1 over the full j-range; dir 1: rows j0..j0+G-1 over
-// the full i-range.  Buffer order (k, m, running index) -- ours, not MPI's.
-__global__ void k_pack(const RomsDev *__restrict__ c, const double *__restrict__ A, double *__restrict__ buf,
-                       int nk, int dir, int start, int G, int unpack)
-{
-  DEV_PROLOGUE(c)
-  const int len = dir == 0 ? (int)nj : (int)ni;
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = blockIdx.y % G, k = blockIdx.y / G;
-  if (r >= len || k >= nk) return;
-  const long a = dir == 0 ? I2(start + m, LBj + r) : I2(LBi + r, start + m);
-  const long q = ((long)k * G + m) * len + r;
-  if (unpack) const_cast<double *>(A)[a + (long)k * nij] = buf[q];
-  else buf[q] = A[a + (long)k * nij];
-}
-
-// All fields of a batch and both sides of a phase in ONE launch (a step on several tiles issues
-// ~70 exchanges; with a launch per field, side and direction the host could not feed the GPU).
+// A message = a rectangle [i0,i0+wi) x [j0,j0+wj) of every plane of every field of the batch.
+// Buffer order per message: plane kk (field after field), then row, then column -- ours, not MPI's.
 #define HALO_MAX_ITEMS 8
+#define HALO_MAX_MSGS 8
 struct PackArgs {
   double *A[HALO_MAX_ITEMS];
-  int nk[HALO_MAX_ITEMS], koff[HALO_MAX_ITEMS];
-  int n, nktot, dir, len, Gmax, unpack;
-  int start[2], G[2];          // side 0 = low neighbour, 1 = high neighbour; G = 0: side absent
-  double *buf[2];
+  int koff[HALO_MAX_ITEMS];
+  int n, nktot, nmsg, unpack;
+  int i0[HALO_MAX_MSGS], j0[HALO_MAX_MSGS], wi[HALO_MAX_MSGS], wj[HALO_MAX_MSGS];
+  long off[HALO_MAX_MSGS];      // start of message m in buf (doubles)
+  double *buf;
 };
+// All fields of a batch and all messages of an exchange in ONE launch (a step on several tiles issues
+// ~70 exchanges; with a launch per field and side the host could not feed the GPU).
 __global__ void k_pack_multi(const RomsDev *__restrict__ c, PackArgs a)
 {
   DEV_PROLOGUE(c)
-  const int side = blockIdx.z;
-  const int G = a.G[side];
+  const int m = blockIdx.z;
+  const int wi = a.wi[m], cnt = wi * a.wj[m];
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = blockIdx.y % a.Gmax, kk = blockIdx.y / a.Gmax;
-  if (r >= a.len || m >= G || kk >= a.nktot) return;
+  const int kk = blockIdx.y;
+  if (r >= cnt) return;
   int f = 0;
   while (f + 1 < a.n && kk >= a.koff[f + 1]) f++;
   const int k = kk - a.koff[f];
-  const int start = a.start[side];
-  const long idx = (a.dir == 0 ? I2(start + m, LBj + r) : I2(LBi + r, start + m)) + (long)k * nij;
-  const long q = ((long)kk * G + m) * a.len + r;
-  if (a.unpack) a.A[f][idx] = a.buf[side][q];
-  else a.buf[side][q] = a.A[f][idx];
+  const int li = r % wi, lj = r / wi;
+  const long idx = I2(a.i0[m] + li, a.j0[m] + lj) + (long)k * nij;
+  const long q = a.off[m] + (long)kk * cnt + r;
+  if (a.unpack) a.A[f][idx] = a.buf[q];
+  else a.buf[q] = a.A[f][idx];
 }
 
 static int ensure_buffers(size_t doubles)
@@ -253,50 +243,129 @@ static int ensure_buffers(size_t doubles)
   return 0;
 }
 
-// One exchange = a list of fields (each nk planes) whose ghost lines travel in ONE message per
-// neighbour and phase: every RCCL group costs a fixed latency, and the barotropic loop alone issues
-// hundreds of exchanges per step.  Buffer layout per side: field after field, each (k, m, r).
+// Directions: 0 W, 1 E, 2 S, 3 N, 4 SW, 5 SE, 6 NW, 7 NE.  A message carries the direction code of its
+// SENDER as tag; the receive that matches a send with tag d is posted by the tile in direction d of the
+// sender, i.e. from its own direction opp(d).
+struct HaloMsg { int peer, tag, i0, wi, j0, wj; };
+struct HaloPlan { int nsend, nrecv; HaloMsg send[HALO_MAX_MSGS], recv[HALO_MAX_MSGS]; };
+static HaloPlan g_plan;
+
+static HaloPlan make_plan(const roms_bounds_t &b, const Neigh &n)
+{
+  auto tile = [&](int i, int j) { return j * b.ntileI + i; };
+  // column / row index of the neighbour tiles (with the periodic wrap), -1 = none
+  const int iW = n.Wtile >= 0 ? n.Wtile % b.ntileI : -1, iE = n.Etile >= 0 ? n.Etile % b.ntileI : -1;
+  const int jS = n.Stile >= 0 ? n.Stile / b.ntileI : -1, jN = n.Ntile >= 0 ? n.Ntile / b.ntileI : -1;
+  const bool hW = iW >= 0, hE = iE >= 0, hS = jS >= 0, hN = jN >= 0;
+  // strips stop at the tile's own range on a side that has a neighbour (the corner block comes from the
+  // diagonal tile) and run to the edge of the array where there is none (wall rows, locally copied columns)
+  const int ilo = hW ? b.Istr : b.LBi, ihi = hE ? b.Iend : b.UBi;
+  const int jlo = hS ? b.Jstr : b.LBj, jhi = hN ? b.Jend : b.UBj;
+  // send / receive extents per side
+  const int sW0 = b.Istr, sWn = n.GsendW, sE0 = b.Iend - n.GsendE + 1, sEn = n.GsendE;
+  const int rW0 = b.Istr - n.GrecvW, rWn = n.GrecvW, rE0 = b.Iend + 1, rEn = n.GrecvE;
+  const int sS0 = b.Jstr, sSn = n.GsendS, sN0 = b.Jend - n.GsendN + 1, sNn = n.GsendN;
+  const int rS0 = b.Jstr - n.GrecvS, rSn = n.GrecvS, rN0 = b.Jend + 1, rNn = n.GrecvN;
+  HaloPlan p;
+  p.nsend = p.nrecv = 0;
+  auto add = [&](int d, int peer, int si0, int swi, int sj0, int swj, int ri0, int rwi, int rj0, int rwj) {
+    if (peer < 0) return;
+    p.send[p.nsend++] = HaloMsg{peer, d, si0, swi, sj0, swj};
+    // what I receive FROM direction d was sent by that tile towards its opposite direction
+    static const int opp[8] = {1, 0, 3, 2, 7, 6, 5, 4};
+    p.recv[p.nrecv++] = HaloMsg{peer, opp[d], ri0, rwi, rj0, rwj};
+  };
+  add(0, n.Wtile, sW0, sWn, jlo, jhi - jlo + 1, rW0, rWn, jlo, jhi - jlo + 1);
+  add(1, n.Etile, sE0, sEn, jlo, jhi - jlo + 1, rE0, rEn, jlo, jhi - jlo + 1);
+  add(2, n.Stile, ilo, ihi - ilo + 1, sS0, sSn, ilo, ihi - ilo + 1, rS0, rSn);
+  add(3, n.Ntile, ilo, ihi - ilo + 1, sN0, sNn, ilo, ihi - ilo + 1, rN0, rNn);
+  add(4, (hW && hS) ? tile(iW, jS) : -1, sW0, sWn, sS0, sSn, rW0, rWn, rS0, rSn);
+  add(5, (hE && hS) ? tile(iE, jS) : -1, sE0, sEn, sS0, sSn, rE0, rEn, rS0, rSn);
+  add(6, (hW && hN) ? tile(iW, jN) : -1, sW0, sWn, sN0, sNn, rW0, rWn, rN0, rNn);
+  add(7, (hE && hN) ? tile(iE, jN) : -1, sE0, sEn, sN0, sNn, rE0, rEn, rN0, rNn);
+  // RCCL pairs the k-th send to a peer with the k-th receive from it: sends go out in the order of their
+  // tag, receives are posted in the order of the tag they expect -- the same order on both ends of a pair
+  // (two tiles in a periodic direction are each other's W and E neighbour, and twice diagonal)
+  for (int x = 0; x < p.nrecv; x++)
+    for (int y = x + 1; y < p.nrecv; y++)
+      if (p.recv[y].tag < p.recv[x].tag) { HaloMsg t = p.recv[x]; p.recv[x] = p.recv[y]; p.recv[y] = t; }
+  return p;
+}
+
+// Host-only: the message plan of tile `rank` for the bounds *b (no GPU needed), exported so that the CPU
+// tests can play a whole 4x2 exchange with numpy.  out = nsend, nrecv, then 6 ints per message (peer, tag,
+// i0, wi, j0, wj), sends first.
+extern "C" int roms_hip_halo_plan(const roms_bounds_t *b, int rank, int *out)
+{
+  int v[12];
+  roms_hip_tile_neighbors(rank, b->ntileI, b->ntileJ, b->NghostPoints, b->NghostPoints, b->EWperiodic, b->NSperiodic, v);
+  const Neigh n{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]};
+  const HaloPlan p = make_plan(*b, n);
+  int q = 0;
+  out[q++] = p.nsend;
+  out[q++] = p.nrecv;
+  for (int m = 0; m < p.nsend; m++) {
+    const HaloMsg &x = p.send[m];
+    out[q++] = x.peer; out[q++] = x.tag; out[q++] = x.i0; out[q++] = x.wi; out[q++] = x.j0; out[q++] = x.wj;
+  }
+  for (int m = 0; m < p.nrecv; m++) {
+    const HaloMsg &x = p.recv[m];
+    out[q++] = x.peer; out[q++] = x.tag; out[q++] = x.i0; out[q++] = x.wi; out[q++] = x.j0; out[q++] = x.wj;
+  }
+  return 0;
+}
+
+// One exchange = a list of fields (each nk planes) whose ghost points travel in ONE message per
+// neighbour: every RCCL group costs a fixed latency, and the barotropic loop alone issues
+// dozens of exchanges per step.
 struct HaloItem { int gtype, nk; double *A; };
 
-static int exchange_phase(const HaloItem *items, int nitems, int dir)
+static int exchange_all(const HaloItem *items, int nitems)
 {
-  const roms_bounds_t &b = g_ctx.b;
-  const Neigh &n = g_neigh;
-  const int lo = dir == 0 ? n.Wtile : n.Stile, hi = dir == 0 ? n.Etile : n.Ntile;
-  if (lo < 0 && hi < 0) return 0;
-  const int GsLo = dir == 0 ? n.GsendW : n.GsendS, GsHi = dir == 0 ? n.GsendE : n.GsendN;
-  const int GrLo = dir == 0 ? n.GrecvW : n.GrecvS, GrHi = dir == 0 ? n.GrecvE : n.GrecvN;
-  const int len = dir == 0 ? (b.UBj - b.LBj + 1) : (b.UBi - b.LBi + 1);
-  const int str = dir == 0 ? b.Istr : b.Jstr, end = dir == 0 ? b.Iend : b.Jend;
-  const int Gmax = b.NghostPoints + 1;
+  if (!g_have_plan) { g_plan = make_plan(g_ctx.b, g_neigh); g_have_plan = true; }
+  const HaloPlan &pl = g_plan;
+  if (pl.nsend == 0 && pl.nrecv == 0) return 0;
   long nktot = 0;
   for (int f = 0; f < nitems; f++) nktot += items[f].nk;
-  int rc = ensure_buffers((size_t)nktot * Gmax * len);
-  if (rc) return rc;
-  const dim3 blk(256);
   PackArgs pa;
-  pa.n = nitems; pa.nktot = (int)nktot; pa.dir = dir; pa.len = len; pa.Gmax = Gmax;
+  pa.n = nitems; pa.nktot = (int)nktot;
   {
     int koff = 0;
-    for (int f = 0; f < nitems; f++) { pa.A[f] = items[f].A; pa.nk[f] = items[f].nk; pa.koff[f] = koff; koff += items[f].nk; }
+    for (int f = 0; f < nitems; f++) { pa.A[f] = items[f].A; pa.koff[f] = koff; koff += items[f].nk; }
   }
-  auto launch_sides = [&](double *blo, int slo, int glo, double *bhi, int shi, int ghi, int unpack) {
-    pa.buf[0] = blo; pa.start[0] = slo; pa.G[0] = lo >= 0 ? glo : 0;
-    pa.buf[1] = bhi; pa.start[1] = shi; pa.G[1] = hi >= 0 ? ghi : 0;
-    pa.unpack = unpack;
-    dim3 grid((len + 255) / 256, (unsigned)(nktot * Gmax), 2);
+  long soff[HALO_MAX_MSGS], roff[HALO_MAX_MSGS], stot = 0, rtot = 0;
+  int smax = 1, rmax = 1;
+  for (int m = 0; m < pl.nsend; m++) {
+    soff[m] = stot;
+    const int cnt = pl.send[m].wi * pl.send[m].wj;
+    stot += nktot * cnt;
+    smax = cnt > smax ? cnt : smax;
+  }
+  for (int m = 0; m < pl.nrecv; m++) {
+    roff[m] = rtot;
+    const int cnt = pl.recv[m].wi * pl.recv[m].wj;
+    rtot += nktot * cnt;
+    rmax = cnt > rmax ? cnt : rmax;
+  }
+  int rc = ensure_buffers((size_t)(stot > rtot ? stot : rtot));
+  if (rc) return rc;
+  const dim3 blk(256);
+  auto launch = [&](const HaloMsg *msgs, int nmsg, const long *off, int cmax, double *buf, int unpack) {
+    pa.nmsg = nmsg; pa.unpack = unpack; pa.buf = buf;
+    for (int m = 0; m < nmsg; m++) {
+      pa.i0[m] = msgs[m].i0; pa.j0[m] = msgs[m].j0; pa.wi[m] = msgs[m].wi; pa.wj[m] = msgs[m].wj; pa.off[m] = off[m];
+    }
+    if (nmsg == 0) return;
+    dim3 grid((cmax + 255) / 256, (unsigned)nktot, (unsigned)nmsg);
     hipLaunchKernelGGL(k_pack_multi, grid, blk, 0, g_ctx.stream, g_ctx.devc, pa);
   };
-  // my first GsLo / last GsHi interior lines
-  launch_sides(g_buf[0], str, GsLo, g_buf[1], end - GsHi + 1, GsHi, 0);
+  launch(pl.send, pl.nsend, soff, smax, g_buf[0], 0);
   KERNEL_CHECK("k_pack");
-  const long nsl = nktot * GsLo * len, nsh = nktot * GsHi * len;
-  const long nrl = nktot * GrLo * len, nrh = nktot * GrHi * len;
   if (!g_ctx.nccl_comm) {
     if (!g_relay)
       return roms_fail("halo exchange", "multi-tile run without a transport: pass an RCCL unique id to "
                                         "roms_hip_init or set a host relay (roms_hip_set_halo_relay)");
-    const size_t need = (size_t)nktot * Gmax * len;
+    const size_t need = (size_t)(stot > rtot ? stot : rtot);
     if (need > g_hbuf_doubles) {
       for (auto &p : g_hbuf) {
         if (p) hipHostFree(p);
@@ -304,26 +373,28 @@ static int exchange_phase(const HaloItem *items, int nitems, int dir)
       }
       g_hbuf_doubles = need;
     }
-    if (lo >= 0) HIP_TRY(hipMemcpyAsync(g_hbuf[0], g_buf[0], sizeof(double) * nsl, hipMemcpyDeviceToHost, g_ctx.stream));
-    if (hi >= 0) HIP_TRY(hipMemcpyAsync(g_hbuf[1], g_buf[1], sizeof(double) * nsh, hipMemcpyDeviceToHost, g_ctx.stream));
+    if (stot) HIP_TRY(hipMemcpyAsync(g_hbuf[0], g_buf[0], sizeof(double) * stot, hipMemcpyDeviceToHost, g_ctx.stream));
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-    const int rrc = g_relay(g_relay_user, dir, lo, hi, g_hbuf[0], lo >= 0 ? nsl : 0, g_hbuf[1], hi >= 0 ? nsh : 0,
-                            g_hbuf[2], lo >= 0 ? nrl : 0, g_hbuf[3], hi >= 0 ? nrh : 0);
+    roms_halo_msg_t sm[HALO_MAX_MSGS], rm[HALO_MAX_MSGS];
+    for (int m = 0; m < pl.nsend; m++)
+      sm[m] = roms_halo_msg_t{pl.send[m].peer, pl.send[m].tag, nktot * pl.send[m].wi * pl.send[m].wj, g_hbuf[0] + soff[m]};
+    for (int m = 0; m < pl.nrecv; m++)
+      rm[m] = roms_halo_msg_t{pl.recv[m].peer, pl.recv[m].tag, nktot * pl.recv[m].wi * pl.recv[m].wj, g_hbuf[1] + roff[m]};
+    const int rrc = g_relay(g_relay_user, pl.nsend, sm, pl.nrecv, rm);
     if (rrc) return roms_fail("halo exchange", "host relay callback failed");
-    if (lo >= 0) HIP_TRY(hipMemcpyAsync(g_buf[2], g_hbuf[2], sizeof(double) * nrl, hipMemcpyHostToDevice, g_ctx.stream));
-    if (hi >= 0) HIP_TRY(hipMemcpyAsync(g_buf[3], g_hbuf[3], sizeof(double) * nrh, hipMemcpyHostToDevice, g_ctx.stream));
+    if (rtot) HIP_TRY(hipMemcpyAsync(g_buf[1], g_hbuf[1], sizeof(double) * rtot, hipMemcpyHostToDevice, g_ctx.stream));
   } else {
     rccl_comm_t comm = (rccl_comm_t)g_ctx.nccl_comm;
     RCCL_TRY(rccl.gstart());
-    // order matters when lo == hi (two tiles in a periodic direction): my low-side
-    // send pairs with the peer's high-side receive.
-    if (lo >= 0) RCCL_TRY(rccl.send(g_buf[0], (size_t)nsl, RCCL_FLOAT64, lo, comm, g_ctx.stream));
-    if (hi >= 0) RCCL_TRY(rccl.send(g_buf[1], (size_t)nsh, RCCL_FLOAT64, hi, comm, g_ctx.stream));
-    if (hi >= 0) RCCL_TRY(rccl.recv(g_buf[3], (size_t)nrh, RCCL_FLOAT64, hi, comm, g_ctx.stream));
-    if (lo >= 0) RCCL_TRY(rccl.recv(g_buf[2], (size_t)nrl, RCCL_FLOAT64, lo, comm, g_ctx.stream));
+    for (int m = 0; m < pl.nsend; m++)
+      RCCL_TRY(rccl.send(g_buf[0] + soff[m], (size_t)(nktot * pl.send[m].wi * pl.send[m].wj), RCCL_FLOAT64,
+                         pl.send[m].peer, comm, g_ctx.stream));
+    for (int m = 0; m < pl.nrecv; m++)
+      RCCL_TRY(rccl.recv(g_buf[1] + roff[m], (size_t)(nktot * pl.recv[m].wi * pl.recv[m].wj), RCCL_FLOAT64,
+                         pl.recv[m].peer, comm, g_ctx.stream));
     RCCL_TRY(rccl.gend());
   }
-  launch_sides(g_buf[2], str - GrLo, GrLo, g_buf[3], end + 1, GrHi, 1);
+  launch(pl.recv, pl.nrecv, roff, rmax, g_buf[1], 1);
   KERNEL_CHECK("k_unpack");
   return 0;
 }
@@ -373,9 +444,8 @@ static int halo_run(const HaloItem *items, int nitems)
   }
   for (int f0 = 0; f0 < nitems; f0 += HALO_MAX_ITEMS) {
     const int n = nitems - f0 < HALO_MAX_ITEMS ? nitems - f0 : HALO_MAX_ITEMS;
-    int rc = exchange_phase(items + f0, n, 0);
+    const int rc = exchange_all(items + f0, n);
     if (rc) return rc;
-    if ((rc = exchange_phase(items + f0, n, 1))) return rc;
   }
   return 0;
 }

@@ -29,12 +29,16 @@ DECLARED_SYMBOLS = (
      "roms_hip_device_ptr", "roms_hip_device_synchronize", "roms_hip_last_error",
      "roms_hip_step2d_loop", "roms_hip_exchange", "roms_hip_timing_enable",
      "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay", "roms_hip_diag",
-     "roms_hip_snapshot_begin", "roms_hip_snapshot_end"] + ["roms_hip_" + e for e in ENTRIES])
+     "roms_hip_snapshot_begin", "roms_hip_snapshot_end", "roms_hip_halo_plan"] + ["roms_hip_" + e for e in ENTRIES])
 
 
 _DP = C.POINTER(C.c_double)
-RELAY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _DP, C.c_long, _DP, C.c_long,
-                       _DP, C.c_long, _DP, C.c_long)
+class HaloMsg(C.Structure):
+    """roms_halo_msg_t of include/roms_hip.h"""
+    _fields_ = [("peer", C.c_int), ("tag", C.c_int), ("count", C.c_long), ("buf", _DP)]
+
+
+RELAY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(HaloMsg), C.c_int, C.POINTER(HaloMsg))
 
 
 def load():
@@ -81,6 +85,19 @@ def tile_neighbors(rank, ntileI, ntileJ, Nghost, NghostPoints, EWperiodic, NSper
     keys = ["Wtile", "Etile", "Stile", "Ntile", "GsendW", "GsendE", "GrecvW", "GrecvE",
             "GsendS", "GsendN", "GrecvS", "GrecvN"]
     return dict(zip(keys, list(out)))
+
+
+def halo_plan(bounds, rank):
+    """Host-only helper of the library: the (sends, recvs) of one halo update of tile `rank`, each a list
+    of dicts peer, tag, i0, wi, j0, wj (include/roms_hip.h, roms_hip_halo_plan); needs no GPU."""
+    out = (C.c_int * 98)()
+    lib = load()
+    lib.roms_hip_halo_plan.argtypes = [C.POINTER(abi.Bounds), C.c_int, C.POINTER(C.c_int)]
+    lib.roms_hip_halo_plan(C.byref(bounds), rank, out)
+    ns, nr = out[0], out[1]
+    keys = ["peer", "tag", "i0", "wi", "j0", "wj"]
+    msgs = [dict(zip(keys, out[2 + 6 * m: 8 + 6 * m])) for m in range(ns + nr)]
+    return msgs[:ns], msgs[ns:]
 
 
 class RomsHip:
@@ -163,22 +180,19 @@ class RomsHip:
 
     def set_halo_relay_gloo(self, dist, torch):
         """Route the halo exchange through torch.distributed (gloo, host memory) instead of
-        RCCL: roms_hip_set_halo_relay with a callback doing the paired isend/irecv of one
-        phase.  Used to rehearse N tiles on fewer GPUs and as the pattern for a host-MPI relay."""
-        def cb(_user, _dir, lo, hi, send_lo, nsl, send_hi, nsh, recv_lo, nrl, recv_hi, nrh):
+        RCCL: roms_hip_set_halo_relay with a callback doing the isend/irecv of one exchange.  Used to
+        rehearse N tiles on fewer GPUs and as the pattern for a host-MPI relay.  Deliberately WITHOUT
+        message tags: like RCCL, gloo then pairs the k-th send to a rank with the k-th receive from it,
+        so the multi-process tests also check the order in which the library lists its messages (two
+        tiles in a periodic direction exchange up to four messages per call)."""
+        def cb(_user, nsend, send, nrecv, recv):
             try:
                 reqs = []
-                view = lambda p, n: torch.from_numpy(np.ctypeslib.as_array(p, shape=(n,)))
-                # when lo == hi (two tiles in a periodic direction) my low-side send pairs
-                # with the peer's high-side receive: tags keep the two apart
-                if lo >= 0:
-                    reqs.append(dist.isend(view(send_lo, nsl), dst=lo, tag=1))
-                if hi >= 0:
-                    reqs.append(dist.isend(view(send_hi, nsh), dst=hi, tag=2))
-                if hi >= 0:
-                    reqs.append(dist.irecv(view(recv_hi, nrh), src=hi, tag=1))
-                if lo >= 0:
-                    reqs.append(dist.irecv(view(recv_lo, nrl), src=lo, tag=2))
+                view = lambda m: torch.from_numpy(np.ctypeslib.as_array(m.buf, shape=(m.count,)))
+                for q in range(nsend):
+                    reqs.append(dist.isend(view(send[q]), dst=send[q].peer))
+                for q in range(nrecv):
+                    reqs.append(dist.irecv(view(recv[q]), src=recv[q].peer))
                 for r in reqs:
                     r.wait()
                 return 0

@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -66,3 +67,46 @@ def test_tile_neighbors_matches_python_mirror():
     n = hip.tile_neighbors(3, 4, 2, 2, 2, True, False)
     assert (n["Etile"], n["Wtile"], n["Ntile"], n["Stile"]) == (0, 2, 7, -1)
     assert n["GsendE"] == 3 and hip.tile_neighbors(0, 4, 2, 2, 2, True, False)["GrecvW"] == 3
+
+
+@pytest.mark.parametrize("nI,nJ,ng", [(4, 2, 2), (4, 2, 3), (2, 2, 2), (3, 3, 2), (2, 1, 2), (1, 2, 2), (4, 1, 3), (3, 2, 2)])
+def test_halo_plan_fills_every_ghost_point(nI, nJ, ng):
+    """Play one halo update of a whole tiling on the host with the library's own message plan (one phase,
+    up to eight messages per tile, corners from the diagonal tiles): k-th send of A to B pairs with the
+    k-th receive of B from A (RCCL's rule, no tags), counts agree, and afterwards every ghost point of every
+    tile holds the owner's value -- including across the periodic seam (Nghost+1 rule) and in the corners."""
+    from roms_trunk_mgh_amd import bounds as B
+    Lm, Mm = 48, 20
+    G = np.arange((Lm + 1) * (Mm + 2), dtype=np.float64).reshape(Lm + 1, Mm + 2) + 0.5     # G[i, j], i = 1..Lm
+    wrap = lambda i: (i - 1) % Lm + 1
+    tiles = []
+    for r in range(nI * nJ):
+        b = B.make_bounds(Lm, Mm, 4, 2, 2, ntileI=nI, ntileJ=nJ, tile=r, NghostPoints=ng)
+        a = np.full((b.UBi - b.LBi + 1, b.UBj - b.LBj + 1), np.nan)
+        jlo = b.Jstr - 1 if b.south_edge else b.Jstr            # wall rows 0 and Mm+1 belong to the edge tiles
+        jhi = b.Jend + 1 if b.north_edge else b.Jend
+        for i in range(b.Istr, b.Iend + 1):
+            a[i - b.LBi, jlo - b.LBj:jhi - b.LBj + 1] = G[i, jlo:jhi + 1]
+        if nI == 1:                                             # one tile column: periodic copy is local
+            for i in list(range(b.LBi, 1)) + list(range(Lm + 1, Lm + ng + 1)):
+                a[i - b.LBi, :] = a[wrap(i) - b.LBi, :]
+        tiles.append((b, a, *hip.halo_plan(b, r)))
+    # post: queues per (src, dst) in list order
+    queues = {}
+    for r, (b, a, sends, recvs) in enumerate(tiles):
+        for m in sends:
+            blk = a[m["i0"] - b.LBi:m["i0"] - b.LBi + m["wi"], m["j0"] - b.LBj:m["j0"] - b.LBj + m["wj"]].copy()
+            queues.setdefault((r, m["peer"]), []).append((m["tag"], blk))
+    for r, (b, a, sends, recvs) in enumerate(tiles):
+        assert len(sends) == len(recvs) <= 8
+        for m in recvs:
+            tag, blk = queues[(m["peer"], r)].pop(0)
+            assert tag == m["tag"], (r, m, tag)
+            assert blk.shape == (m["wi"], m["wj"]), (r, m, blk.shape)
+            a[m["i0"] - b.LBi:m["i0"] - b.LBi + m["wi"], m["j0"] - b.LBj:m["j0"] - b.LBj + m["wj"]] = blk
+    assert all(len(q) == 0 for q in queues.values())
+    for r, (b, a, _, _) in enumerate(tiles):
+        # periodic images the reference defines: i = -2..0 (three, whatever NghostPoints) and Lm+1..Lm+ng
+        for i in range(max(b.LBi, -2), min(b.UBi, Lm + ng) + 1):
+            for j in range(max(b.LBj, 0), min(b.UBj, Mm + 1) + 1):
+                assert a[i - b.LBi, j - b.LBj] == G[wrap(i), j], (r, i, j)

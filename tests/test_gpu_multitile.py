@@ -3,7 +3,9 @@ the one GPU of the test box), halos through the library's host-relay transport o
 After 3 full steps every tile's owned AND ghost points must equal the single-tile HIP run
 bit for bit -- the reference's acceptance rule "identical results across tilings" -- which
 exercises the general (multi-tile) branch of every kernel, the pack/unpack kernels, the
-neighbour table incl. the periodic Nghost+1 rule and the two-phase corner propagation.
+neighbour table incl. the periodic Nghost+1 rule and the corner messages of the one-phase exchange
+(2x2: each tile's W and E, and its two diagonal neighbours, are the same rank -- four messages per pair,
+paired by order as RCCL does).
 The RCCL calls themselves need one GPU per rank and run only in bench.py --gpus N."""
 import os
 import socket
