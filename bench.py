@@ -220,7 +220,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config} {b.Lm}x{b.Mm}x{b.N} NT={b.NT} "
                                    f"nonlinear 3-D step incl. {2 * st.p.nfast + 1} step2d calls, "
-                                   f"U3/C4 tracer advection, fixed analytic forcing/mixing",
+                                   f"U3/C4 tracer advection, "
+                                   + ("analytic atmospheric forcing, bulk fluxes + KPP + diagnostics every step"
+                                      if args.physics else "fixed forcing / mixing fields"),
                        "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "per_step_physics": "bulk_flux+set_vbc+lmd_vmix (KPP)+wvelocity+diag (NINFO=1) on device" if args.physics
                        else "fixed inputs", "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok},
             "roofline": {"kernel": "k_step3d_t_pipe (step3d_t_tile)", "bound": "hbm", "achieved": achieved,
