@@ -1,0 +1,153 @@
+"""-m gpu: the configurations of BASELINE.json at their FULL sizes.
+
+* BENCHMARK1 (512x64x30, config 2) and BENCHMARK3 (2048x256x30, config 4 on one GPU): the whole step -- hot
+  path + bulk fluxes + KPP + wvelocity + diag, as bench.py times it -- through the C ABI against the CPU
+  oracle on the same inputs (the oracle needs ~0.4 s / ~6 s per step at these sizes), bound 1e-10 relative
+  RMS on the prognostic fields (north_star).
+* configuration 5 (MPDATA, 4 passive tracers) on the BENCHMARK1 grid against the oracle.
+* BENCHMARK3, size-independent properties of the path:
+  - equivariance under a periodic shift in i: the hot path contains no longitude, so rolling EVERY input by q
+    columns must roll the result by q columns bit for bit -- the periodic seam, the ghost columns and every
+    workgroup edge land on different data.  (Hot path + wvelocity + diag only: the reference's lmd_finish_tile
+    copies Akv/Akt from column Iend to column Iend-1 on the eastern edge whatever the periodicity --
+    lmd_vmix.F:560-575, reproduced as written -- so KPP is, like the reference's, not shift invariant.)
+  - conservation: the volume sum of diag and the salt content sum(Hz*omn*S) (no salt flux through surface or
+    bottom, flux-form advection and mixing, closed or periodic sides) stay constant to round-off."""
+import numpy as np
+import pytest
+
+from roms_trunk_mgh_amd import ana, hip, main3d
+from roms_trunk_mgh_amd.state import rel_rms
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+FLOOR = {"zeta": 1e-3, "ubar": 1e-4, "vbar": 1e-4, "u": 1e-4, "v": 1e-4, "t": 1e-3}
+
+
+def _check_prognostic(st_h, st_o, m):
+    s = m.s
+    out = {"zeta": rel_rms(st_h.interior("zeta")[..., m.indx1 - 1], st_o.interior("zeta")[..., m.indx1 - 1], FLOOR["zeta"])}
+    for name in ("ubar", "vbar"):
+        out[name] = rel_rms(st_h.interior(name)[..., 0], st_o.interior(name)[..., 0], FLOOR[name])
+    for name in ("u", "v"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], FLOOR[name])
+    for it in range(st_o.b.NT):
+        out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], FLOOR["t"])
+    assert np.isfinite(st_h["t"]).all()
+    assert all(v <= TOL for v in out.values()), out
+    assert float(np.abs(st_o["u"]).max()) > 1e-6
+
+
+@pytest.mark.parametrize("config,nsteps", [("BENCHMARK1", 40), ("BENCHMARK3", 4)])
+def test_full_size_step_vs_oracle(config, nsteps):
+    import oracle
+    st_o = ana.make_tile(config, perturb=1.0)
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o), physics=True, diagnostics=True)
+    mo.initial()
+    mo.run(nsteps)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be, physics=True, diagnostics=True)
+        mh.initial()
+        mh.run(nsteps)
+        be.to_host()
+    finally:
+        be.close()
+    _check_prognostic(st_h, st_o, mo)
+    d_h, d_o = mh.last_diag, mo.last_diag
+    assert all(abs(d_h[q] - d_o[q]) <= 1e-9 * abs(d_o[q]) for q in (0, 1, 2, 3, 4)), (d_h, d_o)
+
+
+def test_config5_mpdata_benchmark1_vs_oracle():
+    """Configuration 5 (T, S + 4 passive tracers, MPDATA for all six, three ghost points) on the full
+    BENCHMARK1 grid, 5 steps against the oracle; the positive-definite passive tracers stay positive."""
+    import oracle
+    mp = {"Hadv": "MPDATA", "Vadv": "MPDATA"}
+    st_o = ana.make_tile("BENCHMARK1", NT=6, overrides=mp, perturb=1.0)
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o), physics=True, diagnostics=True)
+    mo.initial()
+    mo.run(5)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be, physics=True, diagnostics=True)
+        mh.initial()
+        mh.run(5)
+        be.to_host()
+    finally:
+        be.close()
+    assert st_o.b.NghostPoints == 3 and st_o.b.NT == 6
+    _check_prognostic(st_h, st_o, mo)
+    assert float(st_h.interior("t")[..., mo.s.nnew - 1, 2:].min()) > 0.0
+
+
+def _roll_i(st, q):
+    """Every array shifted by q columns along the periodic direction, ghost columns refilled."""
+    b = st.b
+    Lm = b.Lm
+    out = st.copy()
+    i0 = 1 - b.LBi                                  # array index of i = 1
+    for name, a in out.arr.items():
+        core = np.roll(a[i0:i0 + Lm], q, axis=0)
+        a[i0:i0 + Lm] = core
+        for i in range(b.LBi, 1):                   # i <= 0  <-  i + Lm
+            a[i - b.LBi] = a[i + Lm - b.LBi]
+        for i in range(Lm + 1, b.UBi + 1):          # i > Lm  <-  i - Lm
+            a[i - b.LBi] = a[i - Lm - b.LBi]
+    return out
+
+
+def test_benchmark3_periodic_shift_equivariance():
+    q, nsteps = 333, 3
+    st_a = _roll_i(ana.make_tile("BENCHMARK3", perturb=1.0), 0)       # ghost columns = periodic images
+    st_b = _roll_i(st_a, q)
+    res = []
+    for st in (st_a, st_b):
+        be = hip.RomsHip(st)
+        try:
+            m = main3d.Main3D(be, physics=False, diagnostics=True)
+            m.initial()
+            m.run(nsteps)
+            be.to_host(["zeta", "ubar", "vbar", "u", "v", "t", "wvel"])
+        finally:
+            be.close()
+        res.append(m)
+    b = st_a.b
+    i0 = 1 - b.LBi
+    for name in ("zeta", "ubar", "vbar", "u", "v", "t", "wvel"):
+        a = np.roll(st_a[name][i0:i0 + b.Lm], q, axis=0)
+        assert np.array_equal(a, st_b[name][i0:i0 + b.Lm]), name
+    da, db = res[0].last_diag, res[1].last_diag
+    assert da[5] == db[5] and da[10:12].tolist() == db[10:12].tolist()      # same Courant maximum, same (j,k)
+    assert (int(da[9]) - 1 + q) % b.Lm + 1 == int(db[9])                    # ... q columns further east
+    assert float(np.abs(st_a["u"]).max()) > 1e-6
+
+
+def test_benchmark3_conservation():
+    st = ana.make_tile("BENCHMARK3", perturb=1.0)
+    # BENCHMARK starts from S = 35 everywhere: give the salinity some structure so that its sum is a real test
+    b = st.b
+    ii = np.arange(b.LBi, b.UBi + 1)[:, None, None]
+    jj = np.arange(b.LBj, b.UBj + 1)[None, :, None]
+    pat = 0.2 * np.sin(2.0 * np.pi * 3 * (ii - 0.5) / b.Lm) * np.cos(np.pi * (jj - 0.5) / b.Mm) * np.linspace(0.2, 1.0, b.N)[None, None, :]
+    for lev in range(3):
+        st["t"][:, :, :, lev, 1] += pat
+    be = hip.RomsHip(st)
+    vol, salt = [], []
+    try:
+        m = main3d.Main3D(be, physics=False, diagnostics=True)     # fixed forcing: no salt flux anywhere
+        m.initial()
+        assert float(np.abs(st["stflx"][..., 1]).max()) == 0.0 and float(np.abs(st["btflx"][..., 1]).max()) == 0.0
+        for n in range(7):
+            m.step()
+            if n >= 1:
+                vol.append(m.last_diag[0])
+                be.to_host(["t", "Hz"])
+                S = st.interior("t")[..., m.s.nnew - 1, 1]
+                salt.append(float(np.sum(st.interior("Hz") * S * st.interior("omn")[..., None])))
+    finally:
+        be.close()
+    assert max(abs(v / vol[0] - 1.0) for v in vol) <= 1e-12, vol
+    assert max(abs(x / salt[0] - 1.0) for x in salt) <= 1e-11, salt
+    assert float(np.ptp(S)) > 0.1                                   # the salinity field really has structure
