@@ -18,8 +18,10 @@ int oracle_pre_step3d(OARGS)
   double cff, cff1, cff2, cff3, cff4, Gamma;
   for (int itrc = 1; itrc <= NT; itrc++) {
     int ha = p->Hadv[itrc - 1], va = p->Vadv[itrc - 1];
-    if (ha == ADV_HSIMT || ha == ADV_SPLINES) return 8;
-    if (va == ADV_HSIMT || va == ADV_U3) return 8;
+    if (ha == ADV_SPLINES) return 8;
+    if (va == ADV_U3) return 8;
+    /* the reference lets H and V differ; MPDATA and HSIMT are restated as H+V pairs only */
+    if ((ha == ADV_HSIMT) != (va == ADV_HSIMT)) return 8;
     if ((ha == ADV_MPDATA) != (va == ADV_MPDATA)) return 8;
   }
   double *CF_ = walloc(nis * (N + 1)), *DC_ = walloc(nis * (N + 1)), *FC_ = walloc(nis * (N + 1));
@@ -55,7 +57,7 @@ int oracle_pre_step3d(OARGS)
   for (int itrc = 1; itrc <= NT; itrc++) {
     const int ha = p->Hadv[itrc - 1];
     for (int k = 1; k <= N; k++) {
-      if (ha == ADV_MPDATA) {
+      if (ha == ADV_MPDATA || ha == ADV_HSIMT) {          /* pre_step3d.F:364-386: first-order upstream for both */
         /* first-order upstream fluxes, pre_step3d.F:364-386 */
         for (int j = Jstr; j <= Jend; j++)
           for (int i = Istr; i <= Iend + 1; i++) {
@@ -130,7 +132,7 @@ int oracle_pre_step3d(OARGS)
                          (t(i, j - 1, k, nstp, itrc) + t(i, j, k, nstp, itrc) - cff2 * (grad(i, j) - grad(i, j - 1)));
           }
       }
-      Gamma = (ha == ADV_MPDATA) ? 0.5 : 1.0 / 6.0;          /* pre_step3d.F:557-563 */
+      Gamma = (ha == ADV_MPDATA || ha == ADV_HSIMT) ? 0.5 : 1.0 / 6.0;          /* pre_step3d.F:557-563 */
       if (iic == ntfirst) { cff = 0.5 * dt; cff1 = 1.0; cff2 = 0.0; }
       else { cff = (1.0 - Gamma) * dt; cff1 = 0.5 + Gamma; cff2 = 0.5 - Gamma; }
       for (int j = Jstr; j <= Jend; j++)
@@ -145,7 +147,7 @@ int oracle_pre_step3d(OARGS)
   for (int j = Jstr; j <= Jend; j++) {
     for (int itrc = 1; itrc <= NT; itrc++) {
       const int va = p->Vadv[itrc - 1];
-      if (va == ADV_MPDATA) {
+      if (va == ADV_MPDATA || va == ADV_HSIMT) {          /* pre_step3d.F:729-748 */
         /* first-order upstream vertical flux, pre_step3d.F:729-748 */
         for (int k = 1; k <= N - 1; k++)
           for (int i = Istr; i <= Iend; i++) {
@@ -206,7 +208,7 @@ int oracle_pre_step3d(OARGS)
           FC(i, N) = 0.0;
         }
       }
-      Gamma = (va == ADV_MPDATA) ? 0.5 : 1.0 / 6.0;          /* pre_step3d.F:793-799 */
+      Gamma = (va == ADV_MPDATA || va == ADV_HSIMT) ? 0.5 : 1.0 / 6.0;          /* pre_step3d.F:793-799 */
       if (iic == ntfirst) cff = 0.5 * dt;
       else cff = (1.0 - Gamma) * dt;
       for (int k = 1; k <= N; k++)

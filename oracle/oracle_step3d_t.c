@@ -17,16 +17,19 @@ int oracle_step3d_t(OARGS)
   const int nnew = s->nnew;
   const double dt = p->dt;
   const double eps = 1.0E-16;
-  int Lmpdata = 0;
+  int Lmpdata = 0, Lhsimt = 0;
+  const double eps1 = 1.0E-12, cc1 = 0.25, cc2 = 0.5, cc3 = 1.0 / 12.0;      /* step3d_t.F:255, mod_scalars.F:376-378 */
   for (int itrc = 1; itrc <= NT; itrc++) {
     int ha = p->Hadv[itrc - 1], va = p->Vadv[itrc - 1];
-    if (ha == ADV_HSIMT || ha == ADV_SPLINES) return 8;
-    if (va == ADV_HSIMT || va == ADV_U3) return 8;
+    if (ha == ADV_SPLINES) return 8;
+    if (va == ADV_U3) return 8;
+    if ((ha == ADV_HSIMT) != (va == ADV_HSIMT)) return 8;   /* restated as an H+V pair, like MPDATA */
+    if (ha == ADV_HSIMT) Lhsimt = 1;
     /* the reference lets H and V differ; only the pair MPDATA/MPDATA is restated */
     if ((ha == ADV_MPDATA) != (va == ADV_MPDATA)) return 8;
     if (ha == ADV_MPDATA) Lmpdata = 1;
   }
-  if (Lmpdata && b->NghostPoints != 3) return 8;          /* inp_par.F:266-278 */
+  if ((Lmpdata || Lhsimt) && b->NghostPoints != 3) return 8;          /* inp_par.F:266-278 */
   double *FX_ = walloc(nis * njs), *FE_ = walloc(nis * njs);
   double *curv_ = walloc(nis * njs), *grad_ = walloc(nis * njs);
   double *oHz_ = walloc(nis * njs * N);
@@ -51,7 +54,7 @@ int oracle_step3d_t(OARGS)
 #define FC(i,k)    FC_[WSK(i,k)]
 
   /* step3d_t.F:340-360 */
-  if (Lmpdata) {
+  if (Lmpdata || Lhsimt) {
     for (int k = 1; k <= N; k++)
       for (int j = Jstrm2; j <= Jendp2; j++)
         for (int i = Istrm2; i <= Iendp2; i++) oHz(i, j, k) = 1.0 / Hz(i, j, k);
@@ -65,7 +68,7 @@ int oracle_step3d_t(OARGS)
   for (int itrc = 1; itrc <= NT; itrc++) {
     const int ha = p->Hadv[itrc - 1];
     /* three-point footprint: refresh the ghost points of t(nnew) first, :369-386 */
-    if (ha == ADV_MPDATA) o_exchange3d(b, GT_R, N, &t(LBi, LBj, 1, nnew, itrc));
+    if (ha == ADV_MPDATA || ha == ADV_HSIMT) o_exchange3d(b, GT_R, N, &t(LBi, LBj, 1, nnew, itrc));
     for (int k = 1; k <= N; k++) {
       if (ha == ADV_MPDATA) {
         /* first-order upstream fluxes on the extended range, :409-428 */
@@ -90,7 +93,101 @@ int oracle_step3d_t(OARGS)
           }
         continue;
       }
-      if (ha == ADV_C2) {
+      if (ha == ADV_HSIMT) {
+        /* HSIMT with TVD limiter (Wu and Zhu, 2010), horizontal fluxes, step3d_t.F:430-590 */
+        double gX_[512 + 8], kX_[512 + 8], oX_[512 + 8];
+        double *gradX = NULL, *KaX = NULL, *oKaX = NULL, *line = NULL;
+        const long nline = (nis > njs ? nis : njs) + 8;
+        if (nline <= 520) { gradX = gX_; KaX = kX_; oKaX = oX_; }
+        else { line = (double *)malloc(sizeof(double) * 3 * nline); gradX = line; KaX = line + nline; oKaX = line + 2 * nline; }
+#define GX(i) gradX[(i) - IminS]
+#define KX(i) KaX[(i) - IminS]
+#define OX(i) oKaX[(i) - IminS]
+        for (int j = Jstr; j <= Jend; j++) {
+          for (int i = IstrU - 1; i <= Iendp2; i++) {
+            const double cff = 0.125 * (pm(i - 1, j) + pm(i, j)) * (pn(i - 1, j) + pn(i, j)) * dt;
+            const double cff1 = cff * (oHz(i - 1, j, k) + oHz(i, j, k));
+            GX(i) = t(i, j, k, 3, itrc) - t(i - 1, j, k, 3, itrc);
+            KX(i) = 1.0 - fabs(Huon(i, j, k) * cff1);
+          }
+          if (!EWperiodic) {
+            if (west_edge && Huon(Istr, j, k) >= 0.0) { GX(Istr - 1) = 0.0; KX(Istr - 1) = 0.0; }
+            if (east_edge && Huon(Iend + 1, j, k) < 0.0) { GX(Iend + 2) = 0.0; KX(Iend + 2) = 0.0; }
+          }
+          for (int i = Istr; i <= Iend + 1; i++) {
+            double sw_xi, cff;
+            if (KX(i) <= eps1) OX(i) = 0.0;
+            else OX(i) = 1.0 / MAX(KX(i), eps1);
+            if (Huon(i, j, k) >= 0.0) {
+              double rL, rkaL;
+              if (fabs(GX(i)) <= eps1) { rL = 0.0; rkaL = 0.0; }
+              else { rL = GX(i - 1) / GX(i); rkaL = KX(i - 1) * OX(i); }
+              const double a1 = cc1 * KX(i) + cc2 - cc3 * OX(i);
+              const double b1 = -cc1 * KX(i) + cc2 + cc3 * OX(i);
+              const double betaL = a1 + b1 * rL;
+              cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rL * rkaL), betaL)) * GX(i) * KX(i);
+              sw_xi = t(i - 1, j, k, 3, itrc) + cff;
+            } else {
+              double rR, rkaR;
+              if (fabs(GX(i)) <= eps1) { rR = 0.0; rkaR = 0.0; }
+              else { rR = GX(i + 1) / GX(i); rkaR = KX(i + 1) * OX(i); }
+              const double a1 = cc1 * KX(i) + cc2 - cc3 * OX(i);
+              const double b1 = -cc1 * KX(i) + cc2 + cc3 * OX(i);
+              const double betaR = a1 + b1 * rR;
+              cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rR * rkaR), betaR)) * GX(i) * KX(i);
+              sw_xi = t(i, j, k, 3, itrc) - cff;
+            }
+            FX(i, j) = sw_xi * Huon(i, j, k);
+          }
+        }
+#undef GX
+#undef KX
+#undef OX
+#define GE(j) gradX[(j) - JminS]
+#define KE(j) KaX[(j) - JminS]
+#define OE(j) oKaX[(j) - JminS]
+        for (int i = Istr; i <= Iend; i++) {
+          for (int j = JstrV - 1; j <= Jendp2; j++) {
+            const double cff = 0.125 * (pn(i, j) + pn(i, j - 1)) * (pm(i, j) + pm(i, j - 1)) * dt;
+            const double cff1 = cff * (oHz(i, j, k) + oHz(i, j - 1, k));
+            GE(j) = t(i, j, k, 3, itrc) - t(i, j - 1, k, 3, itrc);
+            KE(j) = 1.0 - fabs(Hvom(i, j, k) * cff1);
+          }
+          if (!NSperiodic) {
+            if (south_edge && Hvom(i, Jstr, k) >= 0.0) { GE(Jstr - 1) = 0.0; KE(Jstr - 1) = 0.0; }
+            if (north_edge && Hvom(i, Jend + 1, k) < 0.0) { GE(Jend + 2) = 0.0; KE(Jend + 2) = 0.0; }
+          }
+          for (int j = Jstr; j <= Jend + 1; j++) {
+            double sw_eta, cff;
+            if (KE(j) <= eps1) OE(j) = 0.0;
+            else OE(j) = 1.0 / MAX(KE(j), eps1);
+            if (Hvom(i, j, k) >= 0.0) {
+              double rD, rkaD;
+              if (fabs(GE(j)) <= eps1) { rD = 0.0; rkaD = 0.0; }
+              else { rD = GE(j - 1) / GE(j); rkaD = KE(j - 1) * OE(j); }
+              const double a1 = cc1 * KE(j) + cc2 - cc3 * OE(j);
+              const double b1 = -cc1 * KE(j) + cc2 + cc3 * OE(j);
+              const double betaD = a1 + b1 * rD;
+              cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rD * rkaD), betaD)) * GE(j) * KE(j);
+              sw_eta = t(i, j - 1, k, 3, itrc) + cff;
+            } else {
+              double rU, rkaU;
+              if (fabs(GE(j)) <= eps1) { rU = 0.0; rkaU = 0.0; }
+              else { rU = GE(j + 1) / GE(j); rkaU = KE(j + 1) * OE(j); }
+              const double a1 = cc1 * KE(j) + cc2 - cc3 * OE(j);
+              const double b1 = -cc1 * KE(j) + cc2 + cc3 * OE(j);
+              const double betaU = a1 + b1 * rU;
+              cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rU * rkaU), betaU)) * GE(j) * KE(j);
+              sw_eta = t(i, j, k, 3, itrc) - cff;
+            }
+            FE(i, j) = sw_eta * Hvom(i, j, k);
+          }
+        }
+#undef GE
+#undef KE
+#undef OE
+        free(line);
+      } else if (ha == ADV_C2) {
         for (int j = Jstr; j <= Jend; j++)
           for (int i = Istr; i <= Iend + 1; i++)
             FX(i, j) = Huon(i, j, k) * 0.5 * (t(i - 1, j, k, 3, itrc) + t(i, j, k, 3, itrc));
@@ -198,7 +295,52 @@ int oracle_step3d_t(OARGS)
           }
         continue;
       }
-      if (va == ADV_SPLINES) {
+      if (va == ADV_HSIMT) {
+        /* HSIMT with TVD limiter, vertical flux, step3d_t.F:1022-1090 */
+        double KaZ[512], oKaZ[512], gradZ[512];
+        if (N + 1 > 512) return 8;
+        for (int i = Istr; i <= Iend; i++) {
+          KaZ[0] = 0.0; oKaZ[0] = 0.0; gradZ[0] = 0.0;
+          for (int k = 1; k <= N - 1; k++) {
+            const double cff = pm(i, j) * pn(i, j) * dt;
+            KaZ[k] = 1.0 - fabs(cff * W(i, j, k) / (z_r(i, j, k + 1) - z_r(i, j, k)));
+            oKaZ[k] = 1.0 / KaZ[k];
+            gradZ[k] = t(i, j, k + 1, 3, itrc) - t(i, j, k, 3, itrc);
+          }
+          KaZ[N] = 0.0; oKaZ[N] = 0.0; gradZ[N] = 0.0;
+          for (int k = 1; k <= N - 1; k++) {
+            if ((k == 1) && (W(i, j, k) >= 0.0)) {
+              FC(i, k) = W(i, j, k) * t(i, j, k, 3, itrc);
+            } else if ((k == N - 1) && (W(i, j, k) < 0.0)) {
+              FC(i, k) = W(i, j, k) * t(i, j, k + 1, 3, itrc);
+            } else {
+              double sw, cff;
+              if (W(i, j, k) >= 0) {
+                double rD, rkaD;
+                if (fabs(gradZ[k]) <= eps1) { rD = 0.0; rkaD = 0.0; }
+                else { rD = gradZ[k - 1] / gradZ[k]; rkaD = KaZ[k - 1] * oKaZ[k]; }
+                const double a1 = cc1 * KaZ[k] + cc2 - cc3 * oKaZ[k];
+                const double b1 = -cc1 * KaZ[k] + cc2 + cc3 * oKaZ[k];
+                const double betaD = a1 + b1 * rD;
+                cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rD * rkaD), betaD)) * gradZ[k] * KaZ[k];
+                sw = t(i, j, k, 3, itrc) + cff;
+              } else {
+                double rU, rkaU;
+                if (fabs(gradZ[k]) <= eps1) { rU = 0.0; rkaU = 0.0; }
+                else { rU = gradZ[k + 1] / gradZ[k]; rkaU = KaZ[k + 1] * oKaZ[k]; }
+                const double a1 = cc1 * KaZ[k] + cc2 - cc3 * oKaZ[k];
+                const double b1 = -cc1 * KaZ[k] + cc2 + cc3 * oKaZ[k];
+                const double betaU = a1 + b1 * rU;
+                cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rU * rkaU), betaU)) * gradZ[k] * KaZ[k];
+                sw = t(i, j, k + 1, 3, itrc) - cff;
+              }
+              FC(i, k) = W(i, j, k) * sw;
+            }
+          }
+          FC(i, 0) = 0.0;
+          FC(i, N) = 0.0;
+        }
+      } else if (va == ADV_SPLINES) {
         for (int i = Istr; i <= Iend; i++) {
           FC(i, 0) = 2.0 * t(i, j, 1, 3, itrc);
           CF(i, 1) = 1.0;

@@ -287,8 +287,10 @@ extern "C" int roms_hip_pre_step3d(const roms_step_idx_t *s)
       case ADV_C4 * 16 + ADV_SPLINES: rc = launch_pre_t<ADV_C4, ADV_SPLINES>(s, it, n); break;
       case ADV_A4 * 16 + ADV_SPLINES: rc = launch_pre_t<ADV_A4, ADV_SPLINES>(s, it, n); break;
       case ADV_MPDATA * 16 + ADV_MPDATA: rc = launch_pre_t<ADV_MPDATA, ADV_MPDATA>(s, it, n); break;
+      // HSIMT: the predictor is the same first-order upstream step with Gamma = 1/2 (pre_step3d.F:364, :558, :730, :794)
+      case ADV_HSIMT * 16 + ADV_HSIMT: rc = launch_pre_t<ADV_MPDATA, ADV_MPDATA>(s, it, n); break;
       default:
-        return roms_fail("roms_hip_pre_step3d", "advection scheme pair not implemented (HSIMT; MPDATA only as H+V pair)");
+        return roms_fail("roms_hip_pre_step3d", "advection scheme pair not implemented (MPDATA and HSIMT only as H+V pairs)");
       }
       if (rc) return rc;
       it += n;

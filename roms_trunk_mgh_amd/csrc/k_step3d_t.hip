@@ -42,6 +42,70 @@ namespace {
 // (occupancy 1 or scratch spills), so the run-time guards stay.  Keeping 1/Hz in LDS for the
 // downward sweep saved 0.15 GB of fetch and 0.03 ms; the pipelined kernel uses the LDS for
 // tn() instead.  XCD strips (roms_dev.h) cut the fetch from 2.1 to 1.8 GB.
+// ---------------------------------------------------------------------------
+// HSIMT (Wu and Zhu, 2010) with the TVD limiter, step3d_t.F:430-590 (horizontal) and :1022-1090
+// (vertical).  Evaluated straight from global memory by the classic kernel: an optional scheme that
+// none of the five configurations uses, kept simple.  A face is named by the cell on its high side.
+// ---------------------------------------------------------------------------
+#define HS_EPS1 1.0E-12
+__device__ __forceinline__ double hsimt_limited(double g0, double gn, double k0, double kn, double ok0)
+{
+  // cff of :473-489 for the upwind neighbour face (gn, kn): 0.5*MAX(0,MIN(2, 2 r rka, beta))*grad*Ka
+  const double cc1 = 0.25, cc2 = 0.5, cc3 = 1.0 / 12.0;
+  double r, rka;
+  if (fabs(g0) <= HS_EPS1) { r = 0.0; rka = 0.0; }
+  else { r = gn / g0; rka = kn * ok0; }
+  const double a1 = cc1 * k0 + cc2 - cc3 * ok0;
+  const double b1 = -cc1 * k0 + cc2 + cc3 * ok0;
+  const double beta = a1 + b1 * r;
+  return 0.5 * fmax(0.0, fmin(fmin(2.0, 2.0 * r * rka), beta)) * g0 * k0;
+}
+// horizontal face between cell (a - off) and cell a; off = 1 (xi, Huon) or ni (eta, Hvom).
+// lo_zero / hi_zero: the closed-wall rule of :451-464 / :527-540 applies to the neighbour face used.
+template <int DIR>
+__device__ __forceinline__ double hsimt_hface(gcd_t t3, gcd_t H, gcd_t Hz, gcd_t pm, gcd_t pn, long a, long a2, long off,
+                                              double dt, bool lo_zero, bool hi_zero)
+{
+  auto grad = [&](long x) { return t3[x] - t3[x - off]; };
+  auto Ka = [&](long x, long x2) {
+    double cff;
+    if constexpr (DIR == 0) cff = 0.125 * (pm[x2 - off] + pm[x2]) * (pn[x2 - off] + pn[x2]) * dt;
+    else cff = 0.125 * (pn[x2] + pn[x2 - off]) * (pm[x2] + pm[x2 - off]) * dt;
+    double cff1;
+    if constexpr (DIR == 0) cff1 = cff * (1.0 / Hz[x - off] + 1.0 / Hz[x]);
+    else cff1 = cff * (1.0 / Hz[x] + 1.0 / Hz[x - off]);
+    return 1.0 - fabs(H[x] * cff1);
+  };
+  const double Hf = H[a];
+  const double g0 = grad(a), k0 = Ka(a, a2);
+  const double ok0 = (k0 <= HS_EPS1) ? 0.0 : 1.0 / fmax(k0, HS_EPS1);
+  double sw;
+  if (Hf >= 0.0) {
+    const double gn = lo_zero ? 0.0 : grad(a - off), kn = lo_zero ? 0.0 : Ka(a - off, a2 - off);
+    sw = t3[a - off] + hsimt_limited(g0, gn, k0, kn, ok0);
+  } else {
+    const double gn = hi_zero ? 0.0 : grad(a + off), kn = hi_zero ? 0.0 : Ka(a + off, a2 + off);
+    sw = t3[a] - hsimt_limited(g0, gn, k0, kn, ok0);
+  }
+  return sw * Hf;
+}
+// vertical flux through the top face of level k (W-level k), k = 1..N-1; a = index of (i,j,k) in rho arrays
+__device__ __forceinline__ double hsimt_vface(gcd_t t3, gcd_t Wv, gcd_t z_r, long a, long nij, int k, int N, double cff)
+{
+  const double Wk = Wv[a + nij];
+  if (k == 1 && Wk >= 0.0) return Wk * t3[a];
+  if (k == N - 1 && Wk < 0.0) return Wk * t3[a + nij];
+  // KaZ, gradZ at W-level q (1..N-1; zero at 0 and N), x = rho index of level q
+  auto KaZ = [&](int q, long x) { return (q < 1 || q > N - 1) ? 0.0 : 1.0 - fabs(cff * Wv[x + nij] / (z_r[x + nij] - z_r[x])); };
+  auto gradZ = [&](int q, long x) { return (q < 1 || q > N - 1) ? 0.0 : t3[x + nij] - t3[x]; };
+  const double k0 = KaZ(k, a), g0 = gradZ(k, a);
+  const double ok0 = 1.0 / k0;
+  double sw;
+  if (Wk >= 0) sw = t3[a] + hsimt_limited(g0, gradZ(k - 1, a - nij), k0, KaZ(k - 1, a - nij), ok0);
+  else sw = t3[a + nij] - hsimt_limited(g0, gradZ(k + 1, a + nij), k0, KaZ(k + 1, a + nij), ok0);
+  return Wk * sw;
+}
+
 template <int HADV, int VADV, int NMAX>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
@@ -149,14 +213,26 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       const double dy0 = tk - ym1, dyp1 = yp1 - tk;
       const double dym1 = s_wall ? dy0 : (ym1 - ym2);
       const double dyp2 = n_wall ? dyp1 : (yp2 - yp1);
-      const double FXi = hflux<HADV>(hu0, xm1, tk, dxm1, dx0, dxp1);
-      const double FXip1 = hflux<HADV>(hu1, tk, xp1, dx0, dxp1, dxp2);
-      const double FEj = hflux<HADV>(hv0, ym1, tk, dym1, dy0, dyp1);
-      const double FEjp1 = hflux<HADV>(hv1, tk, yp1, dy0, dyp1, dyp2);
+      double FXi, FXip1, FEj, FEjp1;
+      if constexpr (HADV == ADV_HSIMT) {
+        const gcd_t pmg = (gcd_t)c->F.pm, png = (gcd_t)c->F.pn;
+        FXi = hsimt_hface<0>(t3, Huon, Hz, pmg, png, ck, c0, 1, dt, false, false);
+        FXip1 = hsimt_hface<0>(t3, Huon, Hz, pmg, png, ck + 1, c0 + 1, 1, dt, false, false);
+        // closed walls: the face below Jstr (above Jend+1) enters only through its zeroed gradient, :527-540
+        FEj = hsimt_hface<1>(t3, Hvom, Hz, pmg, png, ck, c0, ni, dt, s_wall, false);
+        FEjp1 = hsimt_hface<1>(t3, Hvom, Hz, pmg, png, ck + ni, c0 + ni, ni, dt, false, n_wall);
+      } else {
+        FXi = hflux<HADV>(hu0, xm1, tk, dxm1, dx0, dxp1);
+        FXip1 = hflux<HADV>(hu1, tk, xp1, dx0, dxp1, dxp2);
+        FEj = hflux<HADV>(hv0, ym1, tk, dym1, dy0, dyp1);
+        FEjp1 = hflux<HADV>(hv1, tk, yp1, dy0, dyp1, dyp2);
+      }
       // ---- vertical flux through the top face of level k ----
       double FCk;
       if (k == N) FCk = 0.0;
       else if constexpr (VADV == ADV_SPLINES) FCk = spl[k];
+      else if constexpr (VADV == ADV_HSIMT)      // cff = pm*pn*dt in this order, :1032
+        FCk = hsimt_vface(t3, Wv, (gcd_t)c->F.z_r, ck, nij, k, N, GF(pm)[c0] * GF(pn)[c0] * dt);
       else {
         double cfk = 0.0, cfk1 = 0.0;
         if constexpr (VADV == ADV_A4) { cfk = a4cf[k]; cfk1 = a4cf[k + 1]; }
@@ -406,7 +482,8 @@ int launch_var(int nnew, int itrc0, int ntr)
   const roms_bounds_t &b = g_ctx.b;
   const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
   if (b.N > ROMS_MAXN) return roms_fail("roms_hip_step3d_t", "N > 64 not instantiated");
-  if (MODE != 2 && b.N > 32) return roms_fail("roms_hip_step3d_t", "the classic A/B kernel is instantiated for N <= 32");
+  if (MODE != 2 && HADV != ADV_HSIMT && b.N > 32)
+    return roms_fail("roms_hip_step3d_t", "the classic A/B kernel is instantiated for N <= 32");
   if constexpr (MODE == 2) {
     if (b.N <= 16)
       hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
@@ -419,8 +496,10 @@ int launch_var(int nnew, int itrc0, int ntr)
   } else {
     if (b.N <= 16)
       hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
-    else
+    else if (b.N <= 32)
       hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else if constexpr (HADV == ADV_HSIMT)
+      hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 64>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
   }
   KERNEL_CHECK("k_step3d_t");
   return 0;
@@ -465,12 +544,23 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
       case ADV_U3 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_U3, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_C4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_C4, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_A4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_A4, ADV_SPLINES>(s->nnew, it, n); break;
+      case ADV_HSIMT * 16 + ADV_HSIMT: {
+        // three-point footprint: refresh the ghost points of t(nnew) first (step3d_t.F:369-386); classic kernel
+        if (b.NghostPoints != 3) return roms_fail("roms_hip_step3d_t", "HSIMT needs NghostPoints = 3 (inp_par.F:266-278)");
+        const long n3r_ = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
+        halo_batch_begin();
+        for (int q = 0; q < n; q++)
+          halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + ((long)(s->nnew - 1) + 3L * (it + q - 1)) * n3r_);
+        if ((rc = halo_batch_end())) return rc;
+        rc = launch_var<ADV_HSIMT, ADV_HSIMT, 0>(s->nnew, it, n);
+        break;
+      }
       case ADV_MPDATA * 16 + ADV_MPDATA:
         // multi-pass: upstream step, anti-diffusive velocities, FCT limiter, corrected step (k_mpdata.hip)
         for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q, q == 0);
         break;
       default:
-        return roms_fail("roms_hip_step3d_t", "advection scheme pair not implemented (HSIMT; MPDATA only as H+V pair)");
+        return roms_fail("roms_hip_step3d_t", "advection scheme pair not implemented (MPDATA and HSIMT only as H+V pairs)");
       }
       if (rc) return rc;
       it += n;

@@ -21,6 +21,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
+    if variant == "hsimt":
+        kw = dict(overrides={"Hadv": "HSIMT", "Vadv": "HSIMT"})
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb, **kw)
     b = st.b
     ni, nj = st.ni, st.nj

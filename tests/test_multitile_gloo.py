@@ -27,6 +27,8 @@ def _free_port():
 def _single(config, nsteps, variant=""):
     import oracle
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
+    if variant == "hsimt":
+        kw = dict(overrides={"Hadv": "HSIMT", "Vadv": "HSIMT"})
     st = ana.make_tile(config, perturb=1.0, **kw)
     m = main3d.Main3D(oracle.Oracle(st))
     m.initial()
@@ -37,7 +39,9 @@ def _single(config, nsteps, variant=""):
 @pytest.mark.parametrize("ntI,ntJ,config,variant", [(2, 1, "UPWELLING", ""), (1, 2, "UPWELLING", ""),
                                                     (2, 2, "SEAMOUNT", ""), (2, 1, "BENCHMARK_TINY", ""),
                                                     # MPDATA on 6 tracers: three ghost points, extended flux ranges
-                                                    (2, 2, "BENCHMARK_TINY", "mpdata")])
+                                                    (2, 2, "BENCHMARK_TINY", "mpdata"),
+                                                    # HSIMT: three ghost points, limiter reaching two faces upwind
+                                                    (2, 2, "BENCHMARK_TINY", "hsimt")])
 def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     nsteps = 3
     world = ntI * ntJ
