@@ -151,3 +151,38 @@ def test_benchmark3_conservation():
     assert max(abs(v / vol[0] - 1.0) for v in vol) <= 1e-12, vol
     assert max(abs(x / salt[0] - 1.0) for x in salt) <= 1e-11, salt
     assert float(np.ptp(S)) > 0.1                                   # the salinity field really has structure
+
+
+def test_config5_benchmark3_properties():
+    """Configuration 5 at its full size (BENCHMARK3, T, S + 4 passive tracers, MPDATA for all six): the passive
+    tracers have no sources and no surface / bottom fluxes; advection, vertical mixing and the interior of the
+    lateral mixing are in flux form, so their content sum(Hz*omn*C) changes only through what the reference's
+    t3dmix2_geo lets through the closed walls (without MASKING it applies no zero-flux condition there: FE at
+    j = Jstr, Jend+1 is evaluated from the wall rows, t3dmix2_geo.h:300-366 -- about 4e-10 of the content per
+    step on this grid, the same in the oracle and in the reference build); MPDATA with the FCT limiter keeps
+    them positive and inside their initial range (monotone scheme)."""
+    mp = {"Hadv": "MPDATA", "Vadv": "MPDATA"}
+    st = ana.make_tile("BENCHMARK3", NT=6, overrides=mp, perturb=1.0)
+    assert st.b.NghostPoints == 3 and st.b.NT == 6
+    c0 = st.interior("t")[..., 0, 2:]
+    lo, hi = float(c0.min()), float(c0.max())
+    assert lo > 0.0 and hi > lo
+    be = hip.RomsHip(st)
+    content = []
+    try:
+        m = main3d.Main3D(be, physics=True, diagnostics=True)
+        m.initial()
+        for n in range(5):
+            m.step()
+            be.to_host(["t", "Hz"])
+            C = st.interior("t")[..., m.s.nnew - 1, 2:]
+            w = (st.interior("Hz") * st.interior("omn")[..., None])[..., None]
+            content.append([float(np.sum(w[..., 0] * C[..., q])) for q in range(4)])
+    finally:
+        be.close()
+    content = np.array(content)
+    assert np.isfinite(st["t"]).all()
+    assert float(np.abs(content / content[0] - 1.0).max()) <= 2e-8, content
+    assert float(C.min()) > 0.0
+    # horizontal mixing (TNU2 = 500) and vertical mixing only smooth: no new extrema beyond round-off
+    assert float(C.min()) >= lo * (1.0 - 1e-12) and float(C.max()) <= hi * (1.0 + 1e-12), (lo, hi, float(C.min()), float(C.max()))
