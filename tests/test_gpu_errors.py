@@ -1,0 +1,64 @@
+"""-m gpu: the error convention of the C ABI: whatever the library cannot do it
+refuses with a non-zero return code and a message in roms_hip_last_error() -- it never aborts the host
+program, never falls back to another path, and stays usable afterwards."""
+import numpy as np
+import pytest
+
+import util
+from roms_trunk_mgh_amd import abi, ana, hip
+
+pytestmark = pytest.mark.gpu
+
+
+def test_unsupported_boundary_condition_is_refused():
+    st = ana.make_tile("UPWELLING", perturb=1.0)
+    st.p.lbc_south = 7                                     # neither LBC_CLOSED nor LBC_PERIODIC (an open-boundary code)
+    h = hip.RomsHip(st)
+    try:
+        with pytest.raises(RuntimeError) as e:
+            h.call("pre_step3d", util.step_idx())
+        assert "Per Clo Per Clo" in str(e.value)
+        with pytest.raises(RuntimeError):
+            h.call("step3d_t", util.step_idx())
+    finally:
+        h.close()
+
+
+def test_unsupported_advection_pair_is_refused_and_library_stays_usable():
+    # MPDATA horizontally with C4 vertically: the reference allows it, this library restates the pair only
+    st = ana.make_tile("UPWELLING", perturb=1.0, overrides={"Hadv": "U3", "Vadv": "C4"})
+    st.p.Hadv[0] = abi.ADV["MPDATA"]
+    h = hip.RomsHip(st)
+    try:
+        with pytest.raises(RuntimeError) as e:
+            h.call("step3d_t", util.step_idx())
+        assert "not implemented" in str(e.value)
+    finally:
+        h.close()
+    # a fresh context afterwards works and gives the usual answer
+    import oracle
+    st0 = util.prepared_state("UPWELLING")
+    st_o, st_h = st0.copy(), st0.copy()
+    oracle.Oracle(st_o).call("omega", util.step_idx())
+    h = hip.RomsHip(st_h)
+    try:
+        h.call("omega", util.step_idx())
+        h.to_host()
+    finally:
+        h.close()
+    assert np.array_equal(st_h["W"], st_o["W"])
+
+
+def test_snapshot_of_unknown_field_and_double_begin_are_refused():
+    st = ana.make_tile("UPWELLING", perturb=1.0)
+    h = hip.RomsHip(st)
+    try:
+        h.snapshot_begin(["zeta"])
+        with pytest.raises(RuntimeError) as e:
+            h.snapshot_begin(["zeta"])
+        assert "in flight" in str(e.value)
+        h.snapshot_end()
+        h.snapshot_begin(["zeta"])
+        h.snapshot_end()
+    finally:
+        h.close()
