@@ -209,8 +209,8 @@ int roms_hip_wvelocity(const roms_step_idx_t *s);
 int roms_hip_diag(const roms_step_idx_t *s, double *out12);
 
 /* The whole barotropic loop LOOP_2D of main3d.F:592-700 in one call
- * (predictor/corrector sequencing done inside, optionally replayed from a
- * hipGraph).  indx1 is mod_stepping's indx1(ng), updated on return. */
+ * (predictor/corrector sequencing done inside: 2*nfast+1 launches queued on the library's
+ * stream without returning to the host).  indx1 is mod_stepping's indx1(ng), updated on return. */
 int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1);
 
 /* mp_exchange2d/3d/4d (ROMS/Utility/mp_exchange.F:290/1413/2753) together
