@@ -34,7 +34,8 @@ FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iouni
   Nonlinear/set_massflux Nonlinear/rho_eos Nonlinear/set_zeta Nonlinear/mpdata_adiff
  Nonlinear/bc_2d Nonlinear/set_vbc Nonlinear/bulk_flux
  Nonlinear/bc_3d Utility/shapiro Nonlinear/lmd_swfrac Nonlinear/lmd_skpp Nonlinear/lmd_vmix
- Nonlinear/wvelocity Nonlinear/diag"
+
+ Utility/stats Functionals/analytical Nonlinear/wvelocity Nonlinear/diag Utility/set_scoord Utility/metrics"
 
 build_app () {
   local APP=$1 hdr=$(echo $1 | tr A-Z a-z).h
@@ -49,11 +50,13 @@ build_app () {
      '-DMY_OS="Linux"' '-DMY_CPU="x86_64"' '-DMY_FORT="flang"' '-DMY_FC="flang"' '-DMY_FFLAGS="-O2"'
      '-DSVN_URL="x"' '-DSVN_REV="x"' '-DANALYTICAL_DIR="x"' '-DHEADER_DIR="x"' "-DHEADER=\"$hdr\""
      '-DMY_ANALYTICAL_DIR="x"' '-DMY_HEADER_DIR="x"' "-DMY_HEADER=\"$hdr\"" '-DMY_ROOT_DIR="x"' '-DMY_ANALYTICAL="x"'
-     -I$HERE/ref_headers -I$REF/ROMS/Include -I$REF/ROMS/Nonlinear -I$REF/ROMS/Utility -I$REF/ROMS/Modules)
+     -I$HERE/ref_headers -I$REF/ROMS/Include -I$REF/ROMS/Functionals -I$REF/ROMS/Nonlinear -I$REF/ROMS/Utility -I$REF/ROMS/Modules)
   local objs=""
   for f in $FILES; do
-    # SEAMOUNT defines ANA_DIAG: its diag.F wants analytical_mod, which this build does not carry
-    [ "$APP" = SEAMOUNT ] && [ "$f" = Nonlinear/diag ] && continue
+    # SEAMOUNT defines ANA_DIAG: Functionals/ana_diag.h uses an undeclared variable (io_err vs io_error,
+    # ana_diag.h:96/114) and does not compile under IMPLICIT NONE, so analytical_mod and diag.F (which needs
+    # it there) are left out for that application
+    [ "$APP" = SEAMOUNT ] && { [ "$f" = Nonlinear/diag ] || [ "$f" = Functionals/analytical ]; } && continue
     local bn=$(basename $f)
     cpp "${CPPF[@]}" $REF/ROMS/$f.F > $bn.f90
     $FC $FFLAGS -c $bn.f90 -o $bn.o > $bn.log 2>&1 || { echo "[$APP] $f failed"; tail -5 $bn.log; exit 1; }

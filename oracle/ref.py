@@ -113,3 +113,23 @@ class Ref:
                     volume=float(m1.group(5)), Ci=int(m2.group(1)), Cj=int(m2.group(2)), Ck=int(m2.group(3)),
                     Cu=float(m2.group(4)), Cv=float(m2.group(5)), Cw=float(m2.group(6)), maxspeed=float(m2.group(7)),
                     text=text)
+
+    def ana(self, kernel, cfg5):
+        """The reference's own analytic set-up routines (ref_ana in ref_wrap.F90): "grid" (ana_grid + metrics),
+        "scoord" (set_scoord; returns sc_r, Cs_r, sc_w, Cs_w, hc), "initial" (ana_initial), "forcing" (the
+        ana_* forcing routines of the application).  cfg5 = theta_s, theta_b, Tcline, Vstretching, tdays."""
+        import numpy as np
+        kid = {"grid": 1, "scoord": 2, "initial": 3, "forcing": 4}[kernel]
+        dp = C.POINTER(C.c_double)
+        self.l.ref_ana.argtypes = [C.c_int, C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.Fields), dp, dp]
+        cfg = np.array(cfg5, dtype=np.float64)
+        N = self.st.b.N
+        out = np.zeros(4 * (N + 1) + 1)
+        rc = self.l.ref_ana(kid, C.byref(self.st.b), C.byref(self.st.p), C.byref(self.F), cfg.ctypes.data_as(dp),
+                            out.ctypes.data_as(dp))
+        if rc != 0:
+            raise RuntimeError(f"ref_ana {kernel} rc={rc}")
+        if kernel == "scoord":
+            n1 = N + 1
+            return dict(sc_r=out[0:n1], Cs_r=out[n1:2 * n1], sc_w=out[2 * n1:3 * n1], Cs_w=out[3 * n1:4 * n1], hc=out[4 * n1])
+        return None

@@ -476,8 +476,8 @@ END FUNCTION ref_physics
 !  main3d.F:475 does: Ninp = nstp), 2 = diag (diag.F:31).  diag keeps nothing: it prints its results
 !  (diag.F:449-475, formats 1pe14.6 / 1pe13.6) and resets the sums, so its report is sent to the file
 !  ref_diag_stdout.txt in the working directory -- the reference's own output is the only observable.
-!  SEAMOUNT is an ANA_DIAG application: its diag.F needs analytical_mod (Functionals/analytical.F, the whole
-!  ana_*.h collection), which is not part of this build; diag is pinned on BENCHMARK and UPWELLING.
+!  SEAMOUNT is an ANA_DIAG application: its diag.F needs analytical_mod, and Functionals/ana_diag.h does not
+!  compile under IMPLICIT NONE (io_err vs io_error, ana_diag.h:96/114); diag is pinned on BENCHMARK and UPWELLING.
 FUNCTION ref_diagnostics (kernel, b, p, s, F) BIND(C, name='ref_diagnostics') RESULT(rc)
   USE ref_wrap_types
   USE mod_param
@@ -553,6 +553,141 @@ FUNCTION ref_diagnostics (kernel, b, p, s, F) BIND(C, name='ref_diagnostics') RE
   CALL c_f_pointer (F%DU_avg1, a2, (/ni,nj/));  a2 = COUPLING(ng)%DU_avg1
   CALL c_f_pointer (F%DV_avg1, a2, (/ni,nj/));  a2 = COUPLING(ng)%DV_avg1
 END FUNCTION ref_diagnostics
+
+!-----------------------------------------------------------------------
+!  The analytic set-up of the application, through the reference's own Functionals (analytical.F) and
+!  Utility routines -- used to pin roms_trunk_mgh_amd/ana.py (the inputs of every test and of bench.py):
+!    kernel 1  ana_grid + metrics        -> the 2-D GRID fields (h, f, pm, pn, the metric combinations)
+!    kernel 2  set_scoord                -> sc_r, Cs_r, sc_w, Cs_w in scout(4*(N+1))
+!    kernel 3  ana_initial               -> zeta, ubar, vbar, u, v, t (needs the GRID fields and z_r, z_w, Hz of F)
+!    kernel 4  the ana_* forcing of the application (BENCHMARK: winds, tair, pair, humid, rain, cloud;
+!              UPWELLING: smflux, stflux(itemp))
+!  cfg = theta_s, theta_b, Tcline, Vstretching, tdays.  Not for SEAMOUNT (its analytical.F does not compile,
+!  see build_ref.sh).
+#ifndef SEAMOUNT
+FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc)
+  USE ref_wrap_types
+  USE mod_param
+  USE mod_parallel
+  USE mod_iounits
+  USE mod_scalars
+  USE mod_ncparam
+  USE mod_stepping
+  USE mod_grid
+  USE mod_ocean
+  USE mod_forces
+  USE analytical_mod
+  USE metrics_mod, ONLY : metrics
+  INTEGER(c_int), VALUE :: kernel
+  TYPE(bounds_t), INTENT(in) :: b
+  TYPE(params_t), INTENT(in) :: p
+  TYPE(fields_t), INTENT(in) :: F
+  REAL(c_double), INTENT(in) :: cfg(5)
+  REAL(c_double), INTENT(out) :: scout(*)
+  INTEGER(c_int) :: rc
+  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT, k, saved_stdout
+  REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:), a5(:,:,:,:,:)
+  ng = 1; tile = 0
+  LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
+  ni = UBi-LBi+1; nj = UBj-LBj+1; NN = b%N; NTT = b%NT
+  rc = 0
+  theta_s(ng) = cfg(1); theta_b(ng) = cfg(2); Tcline(ng) = cfg(3); Vstretching(ng) = INT(cfg(4))
+  Vtransform(ng) = p%Vtransform
+  tdays(ng) = cfg(5); time(ng) = cfg(5)*86400.0_dp
+  dt(ng) = p%dt; ndtfast(ng) = p%ndtfast; g = p%g; rho0 = p%rho0
+  nstp(ng) = 1; nnew(ng) = 1; nrhs(ng) = 1; kstp(ng) = 1; krhs(ng) = 1; knew(ng) = 1
+  saved_stdout = stdout
+  stdout = 78                                   ! the routines report statistics: sent to a scratch file
+  OPEN (UNIT=78, STATUS='SCRATCH')
+  SELECT CASE (kernel)
+  CASE (1)
+    CALL ana_grid (ng, tile, iNLM)
+    CALL metrics (ng, tile, iNLM)
+    CALL c_f_pointer (F%h, a2, (/ni,nj/));       a2 = GRID(ng)%h
+    CALL c_f_pointer (F%f, a2, (/ni,nj/));       a2 = GRID(ng)%f
+    CALL c_f_pointer (F%fomn, a2, (/ni,nj/));    a2 = GRID(ng)%fomn
+    CALL c_f_pointer (F%pm, a2, (/ni,nj/));      a2 = GRID(ng)%pm
+    CALL c_f_pointer (F%pn, a2, (/ni,nj/));      a2 = GRID(ng)%pn
+    CALL c_f_pointer (F%om_r, a2, (/ni,nj/));    a2 = GRID(ng)%om_r
+    CALL c_f_pointer (F%on_r, a2, (/ni,nj/));    a2 = GRID(ng)%on_r
+    CALL c_f_pointer (F%om_u, a2, (/ni,nj/));    a2 = GRID(ng)%om_u
+    CALL c_f_pointer (F%on_u, a2, (/ni,nj/));    a2 = GRID(ng)%on_u
+    CALL c_f_pointer (F%om_v, a2, (/ni,nj/));    a2 = GRID(ng)%om_v
+    CALL c_f_pointer (F%on_v, a2, (/ni,nj/));    a2 = GRID(ng)%on_v
+    CALL c_f_pointer (F%om_p, a2, (/ni,nj/));    a2 = GRID(ng)%om_p
+    CALL c_f_pointer (F%on_p, a2, (/ni,nj/));    a2 = GRID(ng)%on_p
+    CALL c_f_pointer (F%omn, a2, (/ni,nj/));     a2 = GRID(ng)%omn
+    CALL c_f_pointer (F%pmon_r, a2, (/ni,nj/));  a2 = GRID(ng)%pmon_r
+    CALL c_f_pointer (F%pnom_r, a2, (/ni,nj/));  a2 = GRID(ng)%pnom_r
+    CALL c_f_pointer (F%pmon_p, a2, (/ni,nj/));  a2 = GRID(ng)%pmon_p
+    CALL c_f_pointer (F%pnom_p, a2, (/ni,nj/));  a2 = GRID(ng)%pnom_p
+    CALL c_f_pointer (F%pmon_u, a2, (/ni,nj/));  a2 = GRID(ng)%pmon_u
+    CALL c_f_pointer (F%pnom_u, a2, (/ni,nj/));  a2 = GRID(ng)%pnom_u
+    CALL c_f_pointer (F%pmon_v, a2, (/ni,nj/));  a2 = GRID(ng)%pmon_v
+    CALL c_f_pointer (F%pnom_v, a2, (/ni,nj/));  a2 = GRID(ng)%pnom_v
+# ifdef BENCHMARK
+    CALL c_f_pointer (F%dmde, a2, (/ni,nj/));    a2 = GRID(ng)%dmde
+    CALL c_f_pointer (F%dndx, a2, (/ni,nj/));    a2 = GRID(ng)%dndx
+# endif
+  CASE (2)
+    CALL set_scoord (ng)
+    DO k = 1, NN
+      scout(1+k) = SCALARS(ng)%sc_r(k)
+      scout(NN+1+1+k) = SCALARS(ng)%Cs_r(k)
+    END DO
+    scout(1) = 0.0_dp; scout(NN+2) = 0.0_dp
+    DO k = 0, NN
+      scout(2*(NN+1)+1+k) = SCALARS(ng)%sc_w(k)
+      scout(3*(NN+1)+1+k) = SCALARS(ng)%Cs_w(k)
+    END DO
+    scout(4*(NN+1)+1) = hc(ng)
+  CASE (3)
+    CALL c_f_pointer (F%h, a2, (/ni,nj/));        GRID(ng)%h = a2
+    CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
+    CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
+    CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); GRID(ng)%z_w = a3
+    !  ana_initial labels its min/max report with Vname(:,idTvar(itrc)), which the varinfo reader would fill
+    IF (.NOT. allocated(idTvar)) THEN
+      allocate ( idTvar(MT) )
+      idTvar = 1
+      Vname(1,1) = 'tracer'; Vname(2,1) = 'tracer'
+    END IF
+    CALL ana_initial (ng, tile, iNLM)
+    CALL c_f_pointer (F%zeta, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%zeta
+    CALL c_f_pointer (F%ubar, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%ubar
+    CALL c_f_pointer (F%vbar, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%vbar
+    CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   a4 = OCEAN(ng)%u
+    CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   a4 = OCEAN(ng)%v
+    CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); a5 = OCEAN(ng)%t
+  CASE (4)
+# ifdef BENCHMARK
+    CALL ana_winds (ng, tile, iNLM)
+    CALL ana_tair (ng, tile, iNLM)
+    CALL ana_pair (ng, tile, iNLM)
+    CALL ana_humid (ng, tile, iNLM)
+    CALL ana_rain (ng, tile, iNLM)
+    CALL ana_cloud (ng, tile, iNLM)
+    CALL c_f_pointer (F%Uwind, a2, (/ni,nj/));   a2 = FORCES(ng)%Uwind
+    CALL c_f_pointer (F%Vwind, a2, (/ni,nj/));   a2 = FORCES(ng)%Vwind
+    CALL c_f_pointer (F%Tair, a2, (/ni,nj/));    a2 = FORCES(ng)%Tair
+    CALL c_f_pointer (F%Pair, a2, (/ni,nj/));    a2 = FORCES(ng)%Pair
+    CALL c_f_pointer (F%Hair, a2, (/ni,nj/));    a2 = FORCES(ng)%Hair
+    CALL c_f_pointer (F%rain, a2, (/ni,nj/));    a2 = FORCES(ng)%rain
+    CALL c_f_pointer (F%cloud, a2, (/ni,nj/));   a2 = FORCES(ng)%cloud
+# endif
+# ifdef UPWELLING
+    CALL ana_smflux (ng, tile, iNLM)
+    CALL ana_stflux (ng, tile, iNLM, itemp)
+    CALL c_f_pointer (F%sustr, a2, (/ni,nj/));   a2 = FORCES(ng)%sustr
+    CALL c_f_pointer (F%svstr, a2, (/ni,nj/));   a2 = FORCES(ng)%svstr
+    CALL c_f_pointer (F%stflux, a3, (/ni,nj,NTT/)); a3 = FORCES(ng)%stflux
+# endif
+  CASE DEFAULT; rc = 2
+  END SELECT
+  CLOSE (78)
+  stdout = saved_stdout
+END FUNCTION ref_ana
+#endif
 
 !-----------------------------------------------------------------------
 !  mpdata_adiff_tile (ROMS/Nonlinear/mpdata_adiff.F:38) on caller-held private

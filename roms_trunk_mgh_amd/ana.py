@@ -283,6 +283,10 @@ def _grid_global(cfg, b, st):
     A["pmon_p"][s, s] = pm4 / pn4
     A["om_p"][s, s] = 4.0 / pm4
     A["on_p"][s, s] = 4.0 / pn4
+    # metrics.F exchanges the u- and psi-type combinations: their western-most ghost column is the periodic image
+    if b.EWperiodic and b.ntileI == 1:
+        for name in ("pmon_u", "pnom_u", "om_u", "on_u", "pmon_p", "pnom_p", "om_p", "on_p"):
+            A[name][0, :] = A[name][Lm, :]
     # ana_grid.h:757-770 (CURVGRID && UV_ADV): interior rows only, wall rows stay 0
     if app == "BENCHMARK":
         c = slice(1, -1)
@@ -389,7 +393,7 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
             A["ghats"][:, :, :, it] = gh * (1.0 if it == 0 else 0.0)
     elif app == "UPWELLING":
         # ana_smflux.h (UPWELLING): constant along-shore stress; ana_vmix.h:200,327
-        A["sustr"][:] = 0.1 / RHO0
+        A["sustr"][:] = -0.1 / RHO0                       # ana_smflux.h:316-330 after its two-day ramp
         A["srflx"][:] = 0.0
         A["Akv"][:] = 2.0e-3 + 8.0e-3 * np.exp(z_w / 150.0)
         for it in range(NAT):

@@ -31,6 +31,10 @@ PHYSICS = ["set_vbc", "bulk_flux", "lmd_vmix"]
 # [avgke, avgpe, avgkp, volume, Ci, Cj, Ck, Cu, Cv, Cw, maxspeed] at the printed 7 digits (not SEAMOUNT:
 # an ANA_DIAG application, see oracle/ref_wrap.F90)
 DIAGNOSTICS = ["wvelocity"]
+ANA_GRID = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
+            "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v"]
+ANA_FORCING_BENCHMARK = ["Uwind", "Vwind", "Tair", "Pair", "Hair", "rain", "cloud"]
+ANA_FORCING_UPWELLING = ["sustr", "svstr"]
 DIAG_KEYS = ["avgke", "avgpe", "avgkp", "volume", "Ci", "Cj", "Ck", "Cu", "Cv", "Cw", "maxspeed"]
 
 
@@ -97,6 +101,22 @@ def child(config):
             for q in range(fa.shape[1]):
                 if not np.array_equal(fa[:, q], f0[:, q]):
                     out[f"{k}__{name}__{q}"] = fa[:, q].copy()
+    # the analytic set-up itself (reference's ana_grid + metrics, ana_initial, forcing routines) for ana.py
+    if config != "SEAMOUNT":
+        import oracle
+        from roms_trunk_mgh_amd import ana
+        sta = ana.make_tile(config, perturb=0.0)
+        oracle.Oracle(sta).call("set_depth", s)
+        cfg = sta.cfg
+        cfg5 = [cfg["theta_s"], cfg["theta_b"], cfg["Tcline"], 4, 3.0]
+        ra = ref.Ref(sta)
+        ra.ana("grid", cfg5)
+        ra.ana("initial", cfg5)
+        ra.ana("forcing", cfg5)
+        names = ANA_GRID + (["dndx", "dmde"] + ANA_FORCING_BENCHMARK if config.startswith("BENCHMARK") else ANA_FORCING_UPWELLING)
+        for name in names:
+            out[f"ana__{name}"] = sta[name].copy()
+        out["ana__T0"] = sta["t"][:, :, :, 0, 0].copy()
     np.savez_compressed(os.path.join(HERE, f"ref_{config}.npz"), **out)
 
 

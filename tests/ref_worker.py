@@ -132,8 +132,80 @@ def main_diag(config):
     print(json.dumps(out))
 
 
+def main_ana(config):
+    """roms_trunk_mgh_amd/ana.py (the inputs of every test and of bench.py) against the reference's own analytic
+    routines: ana_grid + metrics, set_scoord, ana_initial and the ana_* forcing of the application."""
+    import util
+    from oracle import ref
+    from roms_trunk_mgh_amd import ana
+    st = ana.make_tile(config, perturb=0.0)
+    cfg = st.cfg
+    cfg5 = [cfg["theta_s"], cfg["theta_b"], cfg["Tcline"], 4, 0.0]
+    out = {}
+
+    def cmp(names, a, b_, interior_only=False):
+        d = {}
+        for n in names:
+            x, y = a[n], b_[n]
+            if interior_only:
+                x, y = a.interior(n), b_.interior(n)
+            scale = max(float(np.abs(y).max()), 1e-300)
+            d[n] = float(np.abs(x - y).max()) / scale
+        return d
+
+    # vertical coordinate
+    r = ref.Ref(st.copy())
+    sc = r.ana("scoord", cfg5)
+    N = st.b.N
+    out["scoord"] = {k: float(np.abs(np.array([getattr(st.p, k)[q] for q in range(N + 1)])[1 if k.endswith("_r") else 0:] -
+                                     sc[k][1 if k.endswith("_r") else 0:]).max()) for k in ("sc_r", "Cs_r", "sc_w", "Cs_w")}
+    out["hc"] = abs(sc["hc"] - st.p.hc)
+    # grid + metrics
+    st_r = st.copy()
+    for n in GRID2D + ["dndx", "dmde"]:
+        st_r[n][...] = -9.0e9
+    ref.Ref(st_r).ana("grid", cfg5)
+    # everything the reference defines: all columns up to Lm + NghostPoints, rows 0..Mm+1 (the arrays carry one
+    # spare row / column of padding when Mm / Lm is even, mod_param.F initialize_param)
+    b = st.b
+    reg = (slice(0, b.Lm + b.NghostPoints - b.LBi + 1), slice(0 - b.LBj, b.Mm + 1 - b.LBj + 1))
+    out["grid"] = {n: float(np.abs(st[n][reg] - st_r[n][reg]).max()) / max(float(np.abs(st_r[n][reg]).max()), 1e-300)
+                   for n in GRID2D + (["dndx", "dmde"] if config.startswith("BENCHMARK") else [])}
+    # initial conditions (on the z-levels set_depth gives for the state's zeta = 0)
+    import oracle
+    oracle.Oracle(st).call("set_depth", util.step_idx())
+    st_r = st.copy()
+    for n in ("zeta", "ubar", "vbar", "u", "v", "t"):
+        st_r[n][...] = -9.0e9
+    ref.Ref(st_r).ana("initial", cfg5)
+    out["initial"] = {}
+    for n in ("zeta", "ubar", "vbar", "u", "v", "t"):
+        lev = 0
+        x = st.interior(n)[..., lev] if n in ("zeta", "ubar", "vbar") else (st.interior(n)[..., lev] if n in ("u", "v") else st.interior(n)[..., lev, :])
+        y = st_r.interior(n)[..., lev] if n in ("zeta", "ubar", "vbar") else (st_r.interior(n)[..., lev] if n in ("u", "v") else st_r.interior(n)[..., lev, :])
+        out["initial"][n] = float(np.abs(x - y).max()) / max(float(np.abs(y).max()), 1e-300)
+    # forcing
+    names = ["Uwind", "Vwind", "Tair", "Pair", "Hair", "rain", "cloud"] if config.startswith("BENCHMARK") else ["sustr", "svstr"]
+    st_r = st.copy()
+    for n in names:
+        st_r[n][...] = -9.0e9
+    cfg5[4] = 3.0                                  # after the two-day ramp of the UPWELLING wind stress
+    ref.Ref(st_r).ana("forcing", cfg5)
+    out["forcing"] = cmp(names, st, st_r, interior_only=True)
+    if not config.startswith("BENCHMARK"):
+        x, y = st.interior("stflux")[..., 0], st_r.interior("stflux")[..., 0]
+        out["forcing"]["stflux_T"] = float(np.abs(x - y).max()) / max(float(np.abs(y).max()), 1e-300)
+    print(json.dumps(out))
+
+
+GRID2D = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
+          "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v"]
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "diag":
+    if len(sys.argv) > 2 and sys.argv[2] == "ana":
+        main_ana(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "diag":
         main_diag(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "physics":
         main_physics(sys.argv[1])

@@ -135,3 +135,24 @@ def test_oracle_reproduces_reference_mpdata_adiff():
     assert np.array_equal(Ua[:, :, ks], g["Ua"]) and np.array_equal(Va[:, :, ks], g["Va"])
     assert np.array_equal(Wa[:, :, [k + 1 for k in ks]], g["Wa"]) and np.array_equal(Ta[:, :, ks], g["Ta"])
     assert sha(Ta, Ua, Va, Wa) == str(g["output_sha256"])
+
+
+@pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING"])
+def test_analytic_setup_reproduces_reference_fields(config):
+    """ana.py against the fields the reference's ana_grid + metrics, ana_initial and forcing routines produced
+    (committed by make_golden.py): the check of tests/test_ref_pinning.py where the reference is absent."""
+    from roms_trunk_mgh_amd import ana
+    g = np.load(os.path.join(HERE, "golden", f"ref_{config}.npz"))
+    st = ana.make_tile(config, perturb=0.0)
+    b = st.b
+    reg = (slice(0, b.Lm + b.NghostPoints - b.LBi + 1), slice(0 - b.LBj, b.Mm + 1 - b.LBj + 1))
+    keys = [k for k in g.files if k.startswith("ana__") and k != "ana__T0"]
+    assert len(keys) >= 24
+    for key in keys:
+        name = key[5:]
+        want, got = g[key][reg], st[name][reg]
+        tol = 4e-16 if name == "h" else 0.0
+        assert float(np.abs(got - want).max()) <= tol * float(np.abs(want).max()), name
+    own = (st.I(b.Istr, b.Iend), st.J(b.Jstr, b.Jend))
+    want, got = g["ana__T0"][own], st["t"][:, :, :, 0, 0][own]
+    assert float(np.abs(got - want).max()) <= 4e-16 * float(np.abs(want).max())
