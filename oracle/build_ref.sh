@@ -41,6 +41,8 @@ build_app () {
   local APP=$1 hdr=$(echo $1 | tr A-Z a-z).h
   # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
   [ "$APP" = UPWELLING ] && hdr=upwelling_nodiag.h
+  # SEAMOUNT: same numerics without ANA_DIAG, whose ana_diag.h does not compile (see ref_headers/seamount_nodiag.h)
+  [ "$APP" = SEAMOUNT ] && hdr=seamount_nodiag.h
   local D=$OUT/$APP
   if [ -f $D/libref.so ] && [ $D/libref.so -nt $HERE/ref_wrap.F90 ] && [ $D/libref.so -nt $HERE/build_ref.sh ]; then
     return 0
@@ -53,10 +55,6 @@ build_app () {
      -I$HERE/ref_headers -I$REF/ROMS/Include -I$REF/ROMS/Functionals -I$REF/ROMS/Nonlinear -I$REF/ROMS/Utility -I$REF/ROMS/Modules)
   local objs=""
   for f in $FILES; do
-    # SEAMOUNT defines ANA_DIAG: Functionals/ana_diag.h uses an undeclared variable (io_err vs io_error,
-    # ana_diag.h:96/114) and does not compile under IMPLICIT NONE, so analytical_mod and diag.F (which needs
-    # it there) are left out for that application
-    [ "$APP" = SEAMOUNT ] && { [ "$f" = Nonlinear/diag ] || [ "$f" = Functionals/analytical ]; } && continue
     local bn=$(basename $f)
     cpp "${CPPF[@]}" $REF/ROMS/$f.F > $bn.f90
     $FC $FFLAGS -c $bn.f90 -o $bn.o > $bn.log 2>&1 || { echo "[$APP] $f failed"; tail -5 $bn.log; exit 1; }

@@ -476,8 +476,7 @@ END FUNCTION ref_physics
 !  main3d.F:475 does: Ninp = nstp), 2 = diag (diag.F:31).  diag keeps nothing: it prints its results
 !  (diag.F:449-475, formats 1pe14.6 / 1pe13.6) and resets the sums, so its report is sent to the file
 !  ref_diag_stdout.txt in the working directory -- the reference's own output is the only observable.
-!  SEAMOUNT is an ANA_DIAG application: its diag.F needs analytical_mod, and Functionals/ana_diag.h does not
-!  compile under IMPLICIT NONE (io_err vs io_error, ana_diag.h:96/114); diag is pinned on BENCHMARK and UPWELLING.
+!  SEAMOUNT is built from ref_headers/seamount_nodiag.h (ANA_DIAG off: Functionals/ana_diag.h does not compile).
 FUNCTION ref_diagnostics (kernel, b, p, s, F) BIND(C, name='ref_diagnostics') RESULT(rc)
   USE ref_wrap_types
   USE mod_param
@@ -491,9 +490,7 @@ FUNCTION ref_diagnostics (kernel, b, p, s, F) BIND(C, name='ref_diagnostics') RE
   USE mod_coupling
   USE mod_boundary, ONLY : allocate_boundary
   USE wvelocity_mod, ONLY : wvelocity
-#ifndef SEAMOUNT
   USE diag_mod,      ONLY : diag
-#endif
   INTEGER(c_int), VALUE :: kernel
   TYPE(bounds_t), INTENT(in) :: b
   TYPE(params_t), INTENT(in) :: p
@@ -536,7 +533,6 @@ FUNCTION ref_diagnostics (kernel, b, p, s, F) BIND(C, name='ref_diagnostics') RE
   SELECT CASE (kernel)
   CASE (1)
     CALL wvelocity (ng, tile, nstp(ng))
-#ifndef SEAMOUNT
   CASE (2)
     saved_stdout = stdout
     stdout = 77
@@ -546,7 +542,6 @@ FUNCTION ref_diagnostics (kernel, b, p, s, F) BIND(C, name='ref_diagnostics') RE
     CALL diag (ng, tile)
     CLOSE (77)
     stdout = saved_stdout
-#endif
   CASE DEFAULT; rc = 2
   END SELECT
   CALL c_f_pointer (F%wvel, a3, (/ni,nj,NN+1/)); a3 = OCEAN(ng)%wvel
@@ -562,9 +557,7 @@ END FUNCTION ref_diagnostics
 !    kernel 3  ana_initial               -> zeta, ubar, vbar, u, v, t (needs the GRID fields and z_r, z_w, Hz of F)
 !    kernel 4  the ana_* forcing of the application (BENCHMARK: winds, tair, pair, humid, rain, cloud;
 !              UPWELLING: smflux, stflux(itemp))
-!  cfg = theta_s, theta_b, Tcline, Vstretching, tdays.  Not for SEAMOUNT (its analytical.F does not compile,
-!  see build_ref.sh).
-#ifndef SEAMOUNT
+!  cfg = theta_s, theta_b, Tcline, Vstretching, tdays.
 FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc)
   USE ref_wrap_types
   USE mod_param
@@ -675,7 +668,7 @@ FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc
     CALL c_f_pointer (F%rain, a2, (/ni,nj/));    a2 = FORCES(ng)%rain
     CALL c_f_pointer (F%cloud, a2, (/ni,nj/));   a2 = FORCES(ng)%cloud
 # endif
-# ifdef UPWELLING
+# if defined UPWELLING || defined SEAMOUNT
     CALL ana_smflux (ng, tile, iNLM)
     CALL ana_stflux (ng, tile, iNLM, itemp)
     CALL c_f_pointer (F%sustr, a2, (/ni,nj/));   a2 = FORCES(ng)%sustr
@@ -687,7 +680,6 @@ FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc
   CLOSE (78)
   stdout = saved_stdout
 END FUNCTION ref_ana
-#endif
 
 !-----------------------------------------------------------------------
 !  mpdata_adiff_tile (ROMS/Nonlinear/mpdata_adiff.F:38) on caller-held private

@@ -28,8 +28,8 @@ KERNELS = ["set_depth", "set_massflux", "set_zeta", "rho_eos", "prsgrd", "t3dmix
 PHYSICS = ["set_vbc", "bulk_flux", "lmd_vmix"]
 # diagnostics of every step: wvelocity (writes wvel), then diag on the state wvelocity left; diag keeps
 # nothing but its printed report (diag.F:449-475), which is stored as
-# [avgke, avgpe, avgkp, volume, Ci, Cj, Ck, Cu, Cv, Cw, maxspeed] at the printed 7 digits (not SEAMOUNT:
-# an ANA_DIAG application, see oracle/ref_wrap.F90)
+# [avgke, avgpe, avgkp, volume, Ci, Cj, Ck, Cu, Cv, Cw, maxspeed] at the printed 7 digits (SEAMOUNT:
+# built without ANA_DIAG, see oracle/ref_headers/seamount_nodiag.h)
 DIAGNOSTICS = ["wvelocity"]
 ANA_GRID = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
             "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v"]
@@ -85,7 +85,7 @@ def child(config):
         elif k in DIAGNOSTICS:
             r = ref.Ref(st)
             r.diagnostics(k, s, HERE)
-            if config != "SEAMOUNT":
+            if True:
                 d = r.diagnostics("diag", s, HERE)
                 out["diag_report"] = np.array([float(d[q]) for q in DIAG_KEYS])
         else:
@@ -102,7 +102,7 @@ def child(config):
                 if not np.array_equal(fa[:, q], f0[:, q]):
                     out[f"{k}__{name}__{q}"] = fa[:, q].copy()
     # the analytic set-up itself (reference's ana_grid + metrics, ana_initial, forcing routines) for ana.py
-    if config != "SEAMOUNT":
+    if True:
         import oracle
         from roms_trunk_mgh_amd import ana
         sta = ana.make_tile(config, perturb=0.0)

@@ -123,7 +123,7 @@ def main_diag(config):
     O.call("wvelocity", s)
     out = {"wvel_diff": float(np.abs(st_r["wvel"] - st_o["wvel"]).max()), "wvel_amax": float(np.abs(st_r["wvel"]).max()),
            "DU_equal": bool(np.array_equal(st_r["DU_avg1"], st_o["DU_avg1"]) and np.array_equal(st_r["DV_avg1"], st_o["DV_avg1"]))}
-    if config != "SEAMOUNT":
+    if True:
         d = R.diagnostics("diag", s, tmp)
         v = O.diag(s)
         mine = dict(avgke=v[1] / v[0], avgpe=v[2] / v[0], volume=v[0], Cu=v[6], Cv=v[7], Cw=v[8], maxspeed=v[3])

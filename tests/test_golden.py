@@ -137,7 +137,7 @@ def test_oracle_reproduces_reference_mpdata_adiff():
     assert sha(Ta, Ua, Va, Wa) == str(g["output_sha256"])
 
 
-@pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING"])
+@pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING", "SEAMOUNT"])
 def test_analytic_setup_reproduces_reference_fields(config):
     """ana.py against the fields the reference's ana_grid + metrics, ana_initial and forcing routines produced
     (committed by make_golden.py): the check of tests/test_ref_pinning.py where the reference is absent."""
@@ -147,7 +147,7 @@ def test_analytic_setup_reproduces_reference_fields(config):
     b = st.b
     reg = (slice(0, b.Lm + b.NghostPoints - b.LBi + 1), slice(0 - b.LBj, b.Mm + 1 - b.LBj + 1))
     keys = [k for k in g.files if k.startswith("ana__") and k != "ana__T0"]
-    assert len(keys) >= 24
+    assert len(keys) >= 23
     for key in keys:
         name = key[5:]
         want, got = g[key][reg], st[name][reg]
