@@ -199,6 +199,11 @@ int roms_hip_bulk_flux(const roms_step_idx_t *s);
 int roms_hip_set_vbc(const roms_step_idx_t *s);
 /* lmd_vmix(ng,tile) = lmd_vmix_tile + lmd_skpp + lmd_finish   ROMS/Nonlinear/lmd_vmix.F:37 */
 int roms_hip_lmd_vmix(const roms_step_idx_t *s);
+/* ana_srflux(ng,tile,model)        ROMS/Functionals/ana_srflux.h:2, the ALBEDO branch (:120-150) the BENCHMARK
+ * application uses: shortwave radiation from the zenith angle at (lonr, latr) for the day of the year and the
+ * hour that caldate (ROMS/Utility/dateclock.F:73) returns for tdays(ng) -- the host passes those two numbers --
+ * with the cloud and water-vapour corrections from cloud, Tair, Hair.  Writes srflx. */
+int roms_hip_ana_srflux(double yday, double hour);
 /* wvelocity(ng,tile,nstp)          ROMS/Nonlinear/wvelocity.F:27     (main3d.F:475; writes wvel) */
 int roms_hip_wvelocity(const roms_step_idx_t *s);
 /* diag(ng,tile)                    ROMS/Nonlinear/diag.F:31          (main3d.F:314), the tile-local part

@@ -67,6 +67,16 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"oracle_{kernel} returned {rc}")
 
+    def ana_srflux(self, yday, hour):
+        self.l.oracle_ana_srflux.restype = C.c_int
+        self.l.oracle_ana_srflux.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.StepIdx),
+                                             C.POINTER(abi.Fields), C.c_double, C.c_double]
+        s0 = abi.StepIdx()
+        rc = self.l.oracle_ana_srflux(C.byref(self.st.b), C.byref(self.st.p), C.byref(s0), C.byref(self.F),
+                                      float(yday), float(hour))
+        if rc != 0:
+            raise RuntimeError(f"oracle_ana_srflux returned {rc}")
+
     def diag(self, s):
         import numpy as np
         out = np.zeros(12)

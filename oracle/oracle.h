@@ -134,6 +134,8 @@
 #define rdrag2(i,j)   F->rdrag2[I2(i,j)]
 #define rdrag(i,j)    F->rdrag[I2(i,j)]
 #define wvel(i,j,k)   F->wvel[I3W(i,j,k)]
+#define lonr(i,j)     F->lonr[I2(i,j)]
+#define latr(i,j)     F->latr[I2(i,j)]
 #define stflux(i,j,it) F->stflux[I2(i,j) + (long)((it)-1) * nij]
 #define btflux(i,j,it) F->btflux[I2(i,j) + (long)((it)-1) * nij]
 #define Uwind(i,j)    F->Uwind[I2(i,j)]

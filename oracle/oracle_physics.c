@@ -630,3 +630,34 @@ int oracle_lmd_vmix(OARGS)
   free(dGm1dS_); free(dGt1dS_); free(dGs1dS_); free(ksbl_);
   return 0;
 }
+
+/* ana_srflux_tile, ALBEDO branch (ROMS/Functionals/ana_srflux.h:120-150): yday, hour = what caldate returns
+ * for tdays(ng) (dateclock.F:73).  Csolar = 1353 W/m2, Cp = 3985 J/kg/K (mod_scalars.F). */
+int oracle_ana_srflux(OARGS, double yday, double hour)
+{
+  ORACLE_PROLOGUE
+  const double pi = 3.14159265358979323846, deg2rad = pi / 180.0;
+  const double Csolar = 1353.0, Cp = 3985.0, alb_w = 0.06;
+  double Dangle = 23.44 * cos((172.0 - yday) * 2.0 * pi / 365.2425);
+  Dangle = Dangle * deg2rad;
+  const double Hangle = (12.0 - hour) * pi / 12.0;
+  const double Rsolar = Csolar / (p->rho0 * Cp);
+  for (int j = JstrT; j <= JendT; j++)
+    for (int i = IstrT; i <= IendT; i++) {
+      const double LatRad = latr(i, j) * deg2rad;
+      const double cff1 = sin(LatRad) * sin(Dangle);
+      const double cff2 = cos(LatRad) * cos(Dangle);
+      double sr = 0.0;
+      const double zenith = cff1 + cff2 * cos(Hangle - lonr(i, j) * deg2rad);
+      if (zenith > 0.0) {
+        const double cff = (0.7859 + 0.03477 * F->Tair[I2(i, j)]) / (1.0 + 0.00412 * F->Tair[I2(i, j)]);
+        const double e_sat = pow(10.0, cff);
+        const double vap_p = e_sat * F->Hair[I2(i, j)];
+        const double cl = F->cloud[I2(i, j)];
+        sr = Rsolar * zenith * zenith * (1.0 - 0.6 * (cl * cl * cl)) /
+             ((zenith + 2.7) * vap_p * 1.0E-3 + 1.085 * zenith + 0.1);
+      }
+      F->srflx[I2(i, j)] = (1.0 - alb_w) * sr;
+    }
+  return 0;
+}

@@ -119,7 +119,7 @@ class Ref:
         "scoord" (set_scoord; returns sc_r, Cs_r, sc_w, Cs_w, hc), "initial" (ana_initial), "forcing" (the
         ana_* forcing routines of the application).  cfg5 = theta_s, theta_b, Tcline, Vstretching, tdays."""
         import numpy as np
-        kid = {"grid": 1, "scoord": 2, "initial": 3, "forcing": 4}[kernel]
+        kid = {"grid": 1, "scoord": 2, "initial": 3, "forcing": 4, "srflux": 5}[kernel]
         dp = C.POINTER(C.c_double)
         self.l.ref_ana.argtypes = [C.c_int, C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.Fields), dp, dp]
         cfg = np.array(cfg5, dtype=np.float64)
@@ -132,4 +132,6 @@ class Ref:
         if kernel == "scoord":
             n1 = N + 1
             return dict(sc_r=out[0:n1], Cs_r=out[n1:2 * n1], sc_w=out[2 * n1:3 * n1], Cs_w=out[3 * n1:4 * n1], hc=out[4 * n1])
+        if kernel == "srflux":
+            return dict(yday=float(out[0]), hour=float(out[1]))
         return None

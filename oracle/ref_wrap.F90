@@ -62,7 +62,7 @@ MODULE ref_wrap_types
     TYPE(c_ptr) :: sustr, svstr, bustr, bvstr, srflx, stflx, btflx
     TYPE(c_ptr) :: rdrag2, stflux, btflux, Uwind, Vwind, Tair, Pair, Hair, rain, cloud
     TYPE(c_ptr) :: lrflx, lhflx, shflx, evap, hsbl, rdrag
-    TYPE(c_ptr) :: wvel
+    TYPE(c_ptr) :: wvel, lonr, latr
   END TYPE fields_t
   LOGICAL, SAVE :: have_boundary = .FALSE.      ! allocate_boundary is done once per process
 END MODULE ref_wrap_types
@@ -555,6 +555,8 @@ END FUNCTION ref_diagnostics
 !    kernel 1  ana_grid + metrics        -> the 2-D GRID fields (h, f, pm, pn, the metric combinations)
 !    kernel 2  set_scoord                -> sc_r, Cs_r, sc_w, Cs_w in scout(4*(N+1))
 !    kernel 3  ana_initial               -> zeta, ubar, vbar, u, v, t (needs the GRID fields and z_r, z_w, Hz of F)
+!    kernel 5  ana_srflux (BENCHMARK: the ALBEDO branch) at tdays = cfg(5) with TIME_REF = 0 as in roms_benchmark*.in;
+!              scout(1:2) = the day of the year and the hour caldate returns for it
 !    kernel 4  the ana_* forcing of the application (BENCHMARK: winds, tair, pair, humid, rain, cloud;
 !              UPWELLING: smflux, stflux(itemp))
 !  cfg = theta_s, theta_b, Tcline, Vstretching, tdays.
@@ -571,6 +573,7 @@ FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc
   USE mod_forces
   USE analytical_mod
   USE metrics_mod, ONLY : metrics
+  USE dateclock_mod, ONLY : caldate, ref_clock
   INTEGER(c_int), VALUE :: kernel
   TYPE(bounds_t), INTENT(in) :: b
   TYPE(params_t), INTENT(in) :: p
@@ -674,6 +677,19 @@ FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc
     CALL c_f_pointer (F%sustr, a2, (/ni,nj/));   a2 = FORCES(ng)%sustr
     CALL c_f_pointer (F%svstr, a2, (/ni,nj/));   a2 = FORCES(ng)%svstr
     CALL c_f_pointer (F%stflux, a3, (/ni,nj,NTT/)); a3 = FORCES(ng)%stflux
+# endif
+# ifdef BENCHMARK
+  CASE (5)
+    time_ref = 0.0_dp
+    CALL ref_clock (time_ref)
+    CALL c_f_pointer (F%lonr, a2, (/ni,nj/));    GRID(ng)%lonr = a2
+    CALL c_f_pointer (F%latr, a2, (/ni,nj/));    GRID(ng)%latr = a2
+    CALL c_f_pointer (F%Tair, a2, (/ni,nj/));    FORCES(ng)%Tair = a2
+    CALL c_f_pointer (F%Hair, a2, (/ni,nj/));    FORCES(ng)%Hair = a2
+    CALL c_f_pointer (F%cloud, a2, (/ni,nj/));   FORCES(ng)%cloud = a2
+    CALL caldate (tdays(ng), yd_dp=scout(1), h_dp=scout(2))
+    CALL ana_srflux (ng, tile, iNLM)
+    CALL c_f_pointer (F%srflx, a2, (/ni,nj/));   a2 = FORCES(ng)%srflx
 # endif
   CASE DEFAULT; rc = 2
   END SELECT

@@ -256,6 +256,8 @@ def _grid_global(cfg, b, st):
             h = depth - 4500.0 * np.exp(-(v1 * v1 + v2 * v2))
         st.lonr, st.latr = xr, yr
     A = st.arr
+    A["lonr"][:] = st.lonr
+    A["latr"][:] = st.latr
     A["pm"][:] = pm
     A["pn"][:] = pn
     A["f"][:] = f

@@ -240,6 +240,52 @@ k_bulk_stress(const RomsDev *__restrict__ c, const double *__restrict__ Taux, co
 
 }  // namespace
 
+// ana_srflux_tile, ALBEDO branch (ROMS/Functionals/ana_srflux.h:120-150); point-local
+namespace {
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_ana_srflux(const RomsDev *__restrict__ c, double Dangle, double Hangle, double Rsolar)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.IstrT + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.JstrT + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.IendT || j > b.JendT) return;
+  const long a = I2(i, j);
+  const double pi = 3.14159265358979323846, deg2rad = pi / 180.0, alb_w = 0.06;
+  const double LatRad = GF(latr)[a] * deg2rad;
+  const double cff1 = sin(LatRad) * sin(Dangle);
+  const double cff2 = cos(LatRad) * cos(Dangle);
+  double sr = 0.0;
+  const double zenith = cff1 + cff2 * cos(Hangle - GF(lonr)[a] * deg2rad);
+  if (zenith > 0.0) {
+    const double Ta = GF(Tair)[a];
+    const double cff = (0.7859 + 0.03477 * Ta) / (1.0 + 0.00412 * Ta);
+    const double e_sat = pow(10.0, cff);
+    const double vap_p = e_sat * GF(Hair)[a];
+    const double cl = GF(cloud)[a];
+    sr = Rsolar * zenith * zenith * (1.0 - 0.6 * (cl * cl * cl)) / ((zenith + 2.7) * vap_p * 1.0E-3 + 1.085 * zenith + 0.1);
+  }
+  GF(srflx)[a] = (1.0 - alb_w) * sr;
+}
+}  // namespace
+
+extern "C" int roms_hip_ana_srflux(double yday, double hour)
+{
+  int rc = roms_entry_check("roms_hip_ana_srflux");
+  if (rc) return rc;
+  const roms_bounds_t &b = g_ctx.b;
+  // the scalar part of ana_srflux.h:120-127 on the host, as the reference does once per call
+  const double pi = 3.14159265358979323846, deg2rad = pi / 180.0, Csolar = 1353.0, Cp = 3985.0;
+  double Dangle = 23.44 * cos((172.0 - yday) * 2.0 * pi / 365.2425);
+  Dangle = Dangle * deg2rad;
+  const double Hangle = (12.0 - hour) * pi / 12.0;
+  const double Rsolar = Csolar / (g_ctx.p.rho0 * Cp);
+  ScopedTimer tm("ana_srflux");
+  hipLaunchKernelGGL(k_ana_srflux, grid2d(b.IendT - b.IstrT + 1, b.JendT - b.JstrT + 1), block2d(), 0, g_ctx.stream,
+                     g_ctx.devc, Dangle, Hangle, Rsolar);
+  KERNEL_CHECK("k_ana_srflux");
+  return 0;
+}
+
 extern "C" int roms_hip_set_vbc(const roms_step_idx_t *s)
 {
   int rc = roms_entry_check("roms_hip_set_vbc");

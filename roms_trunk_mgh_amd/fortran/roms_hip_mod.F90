@@ -45,7 +45,7 @@ MODULE roms_hip_mod
  &    FID_bvstr=64, FID_srflx=65, FID_stflx=66, FID_btflx=67,                          &
  &    FID_rdrag2=68, FID_stflux=69, FID_btflux=70, FID_Uwind=71, FID_Vwind=72, FID_Tair=73,  &
  &    FID_Pair=74, FID_Hair=75, FID_rain=76, FID_cloud=77, FID_lrflx=78, FID_lhflx=79,      &
- &    FID_shflx=80, FID_evap=81, FID_hsbl=82, FID_rdrag=83, FID_wvel=84
+ &    FID_shflx=80, FID_evap=81, FID_hsbl=82, FID_rdrag=83, FID_wvel=84, FID_lonr=85, FID_latr=86
 
   INTERFACE
     INTEGER(c_int) FUNCTION roms_hip_init (rank, ntileI, ntileJ, device_id, uid)            &
@@ -165,6 +165,11 @@ MODULE roms_hip_mod
     INTEGER(c_int) FUNCTION roms_hip_snapshot_end () BIND(C, name='roms_hip_snapshot_end')
       IMPORT :: c_int
     END FUNCTION
+    !  ana_srflux, ALBEDO branch: CALL caldate (tdays(ng), yd_dp=yday, h_dp=hour) on the host, then this
+    INTEGER(c_int) FUNCTION roms_hip_ana_srflux (yday, hour) BIND(C, name='roms_hip_ana_srflux')
+      IMPORT :: c_int, c_double
+      REAL(c_double), VALUE :: yday, hour
+    END FUNCTION
     INTEGER(c_int) FUNCTION roms_hip_wvelocity (s) BIND(C, name='roms_hip_wvelocity')
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
@@ -185,7 +190,7 @@ MODULE roms_hip_mod
   PUBLIC :: roms_hip_set_massflux, roms_hip_rho_eos, roms_hip_omega, roms_hip_set_zeta
   PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
   PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc, roms_hip_lmd_vmix
-  PUBLIC :: roms_hip_wvelocity, roms_hip_diag, roms_hip_snapshot_begin, roms_hip_snapshot_end
+  PUBLIC :: roms_hip_ana_srflux, roms_hip_wvelocity, roms_hip_diag, roms_hip_snapshot_begin, roms_hip_snapshot_end
   PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
 
 CONTAINS

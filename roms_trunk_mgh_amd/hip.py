@@ -29,7 +29,8 @@ DECLARED_SYMBOLS = (
      "roms_hip_device_ptr", "roms_hip_device_synchronize", "roms_hip_last_error",
      "roms_hip_step2d_loop", "roms_hip_exchange", "roms_hip_timing_enable",
      "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay", "roms_hip_diag",
-     "roms_hip_snapshot_begin", "roms_hip_snapshot_end", "roms_hip_halo_plan"] + ["roms_hip_" + e for e in ENTRIES])
+     "roms_hip_snapshot_begin", "roms_hip_snapshot_end", "roms_hip_halo_plan",
+     "roms_hip_ana_srflux"] + ["roms_hip_" + e for e in ENTRIES])
 
 
 _DP = C.POINTER(C.c_double)
@@ -143,6 +144,11 @@ class RomsHip:
 
     def snapshot_end(self):
         self._chk(self.l.roms_hip_snapshot_end(), "snapshot_end")
+
+    def ana_srflux(self, yday, hour):
+        """ana_srflux (ALBEDO branch) for the day of the year and hour caldate gives; writes srflx."""
+        self.l.roms_hip_ana_srflux.argtypes = [C.c_double, C.c_double]
+        self._chk(self.l.roms_hip_ana_srflux(float(yday), float(hour)), "ana_srflux")
 
     def diag(self, s):
         """Tile-local sums and maxima of diag_tile (diag.F:190-290) as a 12-vector, see roms_hip.h."""

@@ -9,6 +9,7 @@ against either backend (`hip.RomsHip` = the product, or the CPU oracle in tests)
 
     main3d.F:189-191  nstp/nnew/nrhs rotation
     main3d.F:307-314  set_massflux, rho_eos, diag      (diag: diagnostics=True, every ninfo steps)
+    main3d.F:280      set_data -> ana_srflux           (physics=True, BENCHMARK: shortwave flux of the hour)
     main3d.F:388-394  bulk_flux, set_vbc               (physics=True; else fixed forcing inputs)
     main3d.F:467-475  lmd_vmix (physics=True; else fixed mixing inputs); omega; wvelocity (diagnostics=True)
     main3d.F:489      set_zeta
@@ -21,6 +22,20 @@ against either backend (`hip.RomsHip` = the product, or the CPU oracle in tests)
     main3d.F:914      iic += 1
 """
 from . import abi
+
+
+def host_clock(tdays):
+    """What CALL caldate (tdays(ng), yd_dp=yday, h_dp=hour) returns with TIME_REF = 0 (roms_benchmark*.in:424;
+    ROMS/Utility/dateclock.F:73-236: date number of 0001-01-01 = 367, day fraction of the sum, seconds rounded
+    to the nearest one) during the first year -- enough for the runs of this repository; pinned against the
+    reference's caldate in tests/test_ref_pinning.py."""
+    import math
+    dn = 367.0 + tdays
+    frac = abs(dn - math.trunc(dn))
+    day = math.trunc(dn) - 367
+    if not 0 <= day < 365:
+        raise ValueError("host_clock covers the first 365 days only")
+    return float(day + 1) + frac, round(frac * 86400.0) / 3600.0
 
 
 class Main3D:
@@ -71,6 +86,9 @@ class Main3D:
             self.last_diag = be.diag(s)
         if self.physics:
             bench_app = getattr(be.st, "cfg", {}).get("app") == "BENCHMARK"
+            if bench_app:                     # set_data: ANA_SRFLUX with ALBEDO is the time-dependent forcing
+                dt = be.st.p.dt
+                be.ana_srflux(*host_clock((self.iic - self.ntstart) * dt / 86400.0))
             if bench_app:                     # BULK_FLUXES
                 be.call("bulk_flux", s)
             be.call("set_vbc", s)

@@ -117,6 +117,12 @@ def child(config):
         for name in names:
             out[f"ana__{name}"] = sta[name].copy()
         out["ana__T0"] = sta["t"][:, :, :, 0, 0].copy()
+        if config.startswith("BENCHMARK"):
+            # ana_srflux (ALBEDO branch) at 07:12 of day 1; the clock caldate gives is stored beside the field
+            cfg5[4] = 0.3
+            clk = ra.ana("srflux", cfg5)
+            out["srflux_clock"] = np.array([clk["yday"], clk["hour"]])
+            out["srflux_field"] = sta["srflx"].copy()
     np.savez_compressed(os.path.join(HERE, f"ref_{config}.npz"), **out)
 
 

@@ -146,6 +146,14 @@ def test_analytic_setup_reproduces_reference_fields(config):
     st = ana.make_tile(config, perturb=0.0)
     b = st.b
     reg = (slice(0, b.Lm + b.NghostPoints - b.LBi + 1), slice(0 - b.LBj, b.Mm + 1 - b.LBj + 1))
+    if "srflux_field" in g.files:
+        import oracle
+        from roms_trunk_mgh_amd import main3d
+        yd, hr = g["srflux_clock"]
+        assert main3d.host_clock(0.3) == (float(yd), float(hr))
+        so = st.copy()
+        oracle.Oracle(so).ana_srflux(yd, hr)
+        assert np.array_equal(so.interior("srflx"), g["srflux_field"][st.I(b.Istr, b.Iend), st.J(b.Jstr, b.Jend)])
     keys = [k for k in g.files if k.startswith("ana__") and k != "ana__T0"]
     assert len(keys) >= 23
     for key in keys:

@@ -242,6 +242,31 @@ def test_wvelocity_and_diag(config):
     assert np.array_equal(d_h, d_o), (d_h, d_o)
 
 
+@pytest.mark.parametrize("tdays", [0.0, 0.3, 0.5, 200.25])
+def test_ana_srflux(tdays):
+    """ana_srflux, ALBEDO branch (analytic forcing): night (zero) and day points, two seasons.
+    sin/cos/pow of the device differ from the host's in the last bits: 1e-13 of the field maximum."""
+    import oracle
+    from roms_trunk_mgh_amd import main3d
+    st0 = util.prepared_state("BENCHMARK_TINY")
+    st0["srflx"][...] = -1.0
+    yd, hr = main3d.host_clock(tdays)
+    st_o, st_h = st0.copy(), st0.copy()
+    oracle.Oracle(st_o).ana_srflux(yd, hr)
+    h = hip.RomsHip(st_h)
+    try:
+        h.ana_srflux(yd, hr)
+        h.to_host(["srflx"])
+    finally:
+        h.close()
+    x, y = st_h.interior("srflx"), st_o.interior("srflx")
+    assert float(y.min()) >= 0.0
+    if tdays != 0.0:
+        assert float(y.max()) > 0.0
+    assert float(np.abs(x - y).max()) <= 1e-13 * max(float(y.max()), 1e-5)
+    assert np.array_equal(x == 0.0, y == 0.0)           # same night side
+
+
 def test_diag_at_rest():
     """All velocities zero: no Courant number exceeds zero, so the location stays (0,0,0) as in the
     reference's strict comparison."""
