@@ -571,6 +571,7 @@ FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc
   USE mod_grid
   USE mod_ocean
   USE mod_forces
+  USE mod_mixing
   USE analytical_mod
   USE metrics_mod, ONLY : metrics
   USE dateclock_mod, ONLY : caldate, ref_clock
@@ -677,6 +678,19 @@ FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc
     CALL c_f_pointer (F%sustr, a2, (/ni,nj/));   a2 = FORCES(ng)%sustr
     CALL c_f_pointer (F%svstr, a2, (/ni,nj/));   a2 = FORCES(ng)%svstr
     CALL c_f_pointer (F%stflux, a3, (/ni,nj,NTT/)); a3 = FORCES(ng)%stflux
+# endif
+# ifdef UPWELLING
+    !  ANA_VMIX: analytic vertical mixing coefficients on the z_w of F (ana_vmix.h)
+    CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); GRID(ng)%z_w = a3
+    CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
+    CALL c_f_pointer (F%h, a2, (/ni,nj/));        GRID(ng)%h = a2
+    DO k = 1, INT(b%NAT)
+      Akt_bak(k,ng) = p%Akt_bak(k)
+    END DO
+    Akv_bak(ng) = p%Akv_bak
+    CALL ana_vmix (ng, tile, iNLM)
+    CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akv
+    CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/)); a4 = MIXING(ng)%Akt
 # endif
 # ifdef BENCHMARK
   CASE (5)

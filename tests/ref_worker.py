@@ -208,6 +208,10 @@ def main_ana(config):
             clock = max(clock, abs(yd - clk["yday"]), abs(hr - clk["hour"]))
         out["srflux"] = worst
         out["host_clock"] = clock
+    if config == "UPWELLING":            # ANA_VMIX
+        for n in ("Akv", "Akt"):
+            x, y = st.interior(n)[:, :, 1:-1], st_r.interior(n)[:, :, 1:-1]        # W-levels 1..N-1
+            out["forcing"][n] = float(np.abs(x - y).max()) / max(float(np.abs(y).max()), 1e-300)
     if not config.startswith("BENCHMARK"):
         x, y = st.interior("stflux")[..., 0], st_r.interior("stflux")[..., 0]
         out["forcing"]["stflux_T"] = float(np.abs(x - y).max()) / max(float(np.abs(y).max()), 1e-300)
