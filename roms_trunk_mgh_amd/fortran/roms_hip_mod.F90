@@ -30,6 +30,13 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: iif, predictor_2d_step
   END TYPE roms_step_idx_t
 
+  !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)
+  TYPE, BIND(C), PUBLIC :: roms_halo_msg_t
+    INTEGER(c_int) :: peer, tag
+    INTEGER(c_long) :: count
+    TYPE(c_ptr) :: buf
+  END TYPE roms_halo_msg_t
+
   !  field identifiers = enum roms_field_id (order of include/roms_fields.def)
   INTEGER(c_int), PARAMETER, PUBLIC :: FID_zeta=0, FID_ubar=1, FID_vbar=2, FID_rzeta=3,    &
  &    FID_rubar=4, FID_rvbar=5, FID_u=6, FID_v=7, FID_t=8, FID_ru=9, FID_rv=10, FID_W=11,   &
@@ -93,6 +100,13 @@ MODULE roms_hip_mod
       IMPORT :: c_ptr
       TYPE(c_ptr) :: msg
     END FUNCTION roms_hip_last_error
+    !  fn: INTEGER(c_int) FUNCTION (user, nsend, send, nrecv, recv) BIND(C) with TYPE(roms_halo_msg_t) arrays, e.g.
+    !  the MPI_Isend / MPI_Irecv / MPI_Waitall of mp_exchange2d (see roms_hip_demo_mpi.F90)
+    INTEGER(c_int) FUNCTION roms_hip_set_halo_relay (fn, user) BIND(C, name='roms_hip_set_halo_relay')
+      IMPORT :: c_int, c_funptr, c_ptr
+      TYPE(c_funptr), VALUE :: fn
+      TYPE(c_ptr), VALUE :: user
+    END FUNCTION roms_hip_set_halo_relay
     INTEGER(c_int) FUNCTION roms_hip_step2d_loop (s, indx1) BIND(C, name='roms_hip_step2d_loop')
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(inout) :: s
@@ -185,7 +199,7 @@ MODULE roms_hip_mod
 
   PUBLIC :: roms_hip_init, roms_hip_finalize, roms_hip_get_unique_id
   PUBLIC :: roms_hip_set_bounds, roms_hip_set_params, roms_hip_register_field
-  PUBLIC :: roms_hip_sync_to_device, roms_hip_sync_to_host
+  PUBLIC :: roms_hip_sync_to_device, roms_hip_sync_to_host, roms_hip_set_halo_relay
   PUBLIC :: roms_hip_sync_all_to_device, roms_hip_sync_all_to_host, roms_hip_last_error
   PUBLIC :: roms_hip_set_massflux, roms_hip_rho_eos, roms_hip_omega, roms_hip_set_zeta
   PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
