@@ -29,11 +29,12 @@ def _free_port():
     return p
 
 
-def _single(config, nsteps):
+def _single(config, nsteps, variant=""):
     from roms_trunk_mgh_amd import hip
-    st = ana.make_tile(config, perturb=1.0)
+    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
+    st = ana.make_tile(config, perturb=1.0, **kw)
     be = hip.RomsHip(st)
-    m = main3d.Main3D(be)
+    m = main3d.Main3D(be, physics=(variant == "physics"), diagnostics=(variant == "physics"))
     m.initial()
     m.run(nsteps)
     be.to_host()
@@ -41,16 +42,22 @@ def _single(config, nsteps):
     return st
 
 
-@pytest.mark.parametrize("ntI,ntJ,config", [(2, 1, "BENCHMARK_TINY"), (1, 2, "UPWELLING"), (2, 2, "SEAMOUNT"),
-                                            (4, 1, "BENCHMARK_TINY")])
-def test_tiled_hip_equals_single_hip(tmp_path, ntI, ntJ, config):
+@pytest.mark.parametrize("ntI,ntJ,config,variant", [(2, 1, "BENCHMARK_TINY", ""), (1, 2, "UPWELLING", ""),
+                                                    (2, 2, "SEAMOUNT", ""), (4, 1, "BENCHMARK_TINY", ""),
+                                                    # ragged tiles (64 = 22 + 21 + 21 columns), three different neighbours
+                                                    (3, 1, "BENCHMARK_TINY", ""),
+                                                    # three ghost points, MPDATA's extended ranges across tile edges
+                                                    (2, 2, "BENCHMARK_TINY", "mpdata"),
+                                                    # bulk fluxes, KPP, wvelocity, diag on every tile
+                                                    (2, 2, "BENCHMARK_TINY", "physics")])
+def test_tiled_hip_equals_single_hip(tmp_path, ntI, ntJ, config, variant):
     nsteps = 3
     world = ntI * ntJ
-    ref = _single(config, nsteps)          # before the children start: at most `world` + 1 GPU processes
+    ref = _single(config, nsteps, variant)          # before the children start: at most `world` + 1 GPU processes
     port = _free_port()
     env = dict(os.environ, OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_gpu_worker.py"), str(r), str(world), str(ntI),
-                               str(ntJ), config, str(nsteps), str(port), str(tmp_path)], env=env)
+                               str(ntJ), config, str(nsteps), str(port), str(tmp_path), variant], env=env)
              for r in range(world)]
     try:
         for p in procs:
