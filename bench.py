@@ -161,9 +161,23 @@ def main():
             dist.all_gather(allv, v)
             return main3d.reduce_diag(torch.stack(allv).numpy())
         be.diag = global_diag
+    # N > 1: a rank that dies leaves the others waiting in a collective for ever -- give up loudly instead
+    import threading
+    progress = {"t": time.time()}
+
+    def watchdog():
+        while True:
+            time.sleep(5.0)
+            if time.time() - progress["t"] > 180.0:
+                sys.stderr.write(f"[bench rank {rank}] no progress for 180 s (a peer rank failed?): aborting\n")
+                sys.stderr.flush()
+                os._exit(3)
+    if world > 1:
+        threading.Thread(target=watchdog, daemon=True).start()
     m.initial()
     for _ in range(args.warmup):
         m.step()
+        progress["t"] = time.time()
     be.sync()
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
@@ -174,10 +188,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         m.step()
+        progress["t"] = time.time()
     be.sync()
     torch.cuda.synchronize()
     barrier()
     wall = time.perf_counter() - t0
+    progress["t"] = time.time()
     if world > 1:
         tw = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
