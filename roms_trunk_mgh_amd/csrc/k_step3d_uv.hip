@@ -129,12 +129,15 @@ __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, lon
   const gcd_t Hz = (gcd_t)(c->F.Hz);
   const double cff = 0.5 * metric;
   double DC0 = 0.0, CF0 = 0.0;
-  double hu[NMAX + 1];
+  // dc[k] = DC(i,k) of the reference: kept in registers for the two later passes (it was re-read from Hz twice
+  // per component: 4 of the kernel's 13 field passes) -- the same product, so the same bits
+  double hu[NMAX + 1], dc[NMAX + 1];
 #pragma unroll
   for (int k = 1; k <= NMAX; k++) {
     if (k <= N) {
       const long ck = c0 + (long)(k - 1) * nij;
       const double dck = cff * (Hz[ck] + Hz[ck - off]);
+      dc[k] = dck;
       DC0 = DC0 + dck;
       CF0 = CF0 + dck * vel[ck];
     }
@@ -149,7 +152,7 @@ __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, lon
   for (int k = NMAX; k >= 1; k--) {
     if (k <= N) {
       const long ck = c0 + (long)(k - 1) * nij;
-      const double dck = cff * (Hz[ck] + Hz[ck - off]);
+      const double dck = dc[k];
       double uv = vel[ck];
       if (fix_mean) { uv = uv - CF0; vel[ck] = uv; }      // boundary rows, :1087-1110
       const double h = 0.5 * (Hflx[ck] + uv * dck);
@@ -162,8 +165,7 @@ __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, lon
   for (int k = 1; k <= NMAX; k++) {
     if (k <= N) {
       const long ck = c0 + (long)(k - 1) * nij;
-      const double dck = cff * (Hz[ck] + Hz[ck - off]);
-      Hflx[ck] = hu[k] - dck * FC0;
+      Hflx[ck] = hu[k] - dc[k] * FC0;
     }
   }
 }
