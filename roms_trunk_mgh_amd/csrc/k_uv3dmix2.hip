@@ -84,6 +84,9 @@ k_uv3dmix2_v2(const RomsDev *__restrict__ c, int nrhs, int nnew)
   const RhoC rs = do_v ? rho_coef(c, a - ni, ni) : r0;
   const PsiC p0 = psi_coef(c, a, ni), pN = psi_coef(c, a + ni, ni), pE = psi_coef(c, a + 1, ni);
   double ruf = do_u ? c->F.rufrc[a] : 0.0, rvf = do_v ? c->F.rvfrc[a] : 0.0;
+  // levels are independent apart from the two running sums: two at a time, so that the loads of the second
+  // are in flight while the first is computed
+#pragma unroll 2
   for (int k = 1; k <= N; k++) {
     const long ak = a + (long)(k - 1) * nij;
     const double sr0 = stress_r(r0, u, v, Hz, ak, ni);
