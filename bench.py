@@ -63,7 +63,79 @@ def cpu_baseline(config, nsteps, physics=True):
     return nsteps * st.p.dt / 86400.0 / wall, wall
 
 
+def _cpu_tile_worker(rank, world, ntI, ntJ, config, nsteps, port, physics):
+    """One host process = one tile of the CPU oracle; halos through the package's Python mirror of mp_exchange
+    over gloo (the arrangement of tests/test_multitile_gloo.py).  Rank 0 prints the wall time of `nsteps` steps."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from roms_trunk_mgh_amd import ana, halo, main3d
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0)
+    b, ni, nj = st.b, st.ni, st.nj
+    sr = halo.gloo_sendrecv(dist, torch)
+    HOOK = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+    def hook(ptr, nk, gtype):
+        A = np.ctypeslib.as_array(ptr, shape=(nk * nj * ni,)).reshape((ni, nj, nk), order="F")
+        halo.exchange(A, b, rank, sr)
+    cb = HOOK(hook)
+    lib = oracle.lib()
+    lib.oracle_set_exchange_hook.argtypes = [HOOK]
+    lib.oracle_set_exchange_hook(cb)
+    m = main3d.Main3D(oracle.Oracle(st), physics=physics, diagnostics=physics)
+    m.initial()
+    m.step()                      # first step (forward Euler branch) untimed
+    dist.barrier()
+    t0 = time.perf_counter()
+    m.run(nsteps)
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    lib.oracle_set_exchange_hook(HOOK(0))
+    if rank == 0:
+        print(json.dumps({"wall": wall, "dt": st.p.dt}), flush=True)
+    dist.destroy_process_group()
+
+
+def cpu_baseline_tiled(config, nsteps, physics, nproc):
+    """The same oracle on `nproc` host cores: one process per tile (4x2, 4x1 or 2x1), as the reference's MPI
+    build would run -- the closest this environment gets to its MPI-Fortran path (which needs netCDF to link)."""
+    import socket
+    import subprocess
+    ntI, ntJ = TILINGS[nproc]
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")     # CPU only
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(r), str(nproc), str(ntI), str(ntJ),
+                               config, str(nsteps), str(port), "1" if physics else "0"], env=env,
+                              stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.DEVNULL, text=True)
+             for r in range(nproc)]
+    try:
+        out0, _ = procs[0].communicate(timeout=600)
+        for pr in procs[1:]:
+            pr.wait(timeout=60)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    if any(pr.returncode != 0 for pr in procs):
+        return None
+    rec = json.loads(out0.strip().splitlines()[-1])
+    return nsteps * rec["dt"] / 86400.0 / rec["wall"], rec["wall"], f"{ntI}x{ntJ}"
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        a = sys.argv[2:]
+        _cpu_tile_worker(int(a[0]), int(a[1]), int(a[2]), int(a[3]), a[4], int(a[5]), int(a[6]), a[7] == "1")
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -71,6 +143,10 @@ def main():
     ap.add_argument("--config", default="BENCHMARK3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-tiles", type=int, default=0, choices=[0, 2, 4],
+                    help="also time the CPU oracle on this many host cores, one process per tile (off by default: the "
+                         "GPU boxes of this pool allow at most 6 processes with the device open, and the workers' "
+                         "import of torch counts)")
     ap.add_argument("--no-physics", dest="physics", action="store_false",
                     help="keep the outputs of bulk_flux + set_vbc fixed instead of recomputing them on the "
                          "device every step (SURVEY 8f-1); default: recompute, as the reference's step does")
@@ -252,6 +328,19 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "simulated-days/s", "cores": 1, "kind": "port",
                                    "sample": f"{args.cpu_steps} full steps of {args.config} on one host core "
                                              f"({w:.1f} s), oracle/ C restatement, gcc -O2"}
+            # and, on request, on several cores, one process per tile
+            nproc = args.cpu_tiles
+            try:
+                tiled = cpu_baseline_tiled(args.config, args.cpu_steps, args.physics, nproc) if nproc > 1 else None
+            except Exception as e:            # the measured line must not depend on this optional leg
+                sys.stderr.write(f"[bench] tiled CPU baseline skipped: {e!r}\n")
+                tiled = None
+            if tiled is not None:
+                out["cpu_baseline"] = {"value": tiled[0], "unit": "simulated-days/s", "cores": nproc, "kind": "port",
+                                       "sample": f"{args.cpu_steps} full steps of {args.config} on {nproc} host cores, one "
+                                                 f"process per tile ({tiled[2]}), halos over gloo ({tiled[1]:.1f} s); oracle/ C "
+                                                 f"restatement, gcc -O2",
+                                       "single_core_value": v}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
