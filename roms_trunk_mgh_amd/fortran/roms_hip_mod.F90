@@ -11,7 +11,10 @@
 !      SUBROUTINE step3d_t (ng, tile)          ! step3d_t.F:40
 !        USE roms_hip_mod
 !        integer, intent(in) :: ng, tile
-!        CALL roms_hip_call (roms_hip_step3d_t, ng, 35, __LINE__, MyFile)
+!        TYPE(roms_step_idx_t) :: s
+!        s = roms_hip_make_idx (iic(ng), ntfirst(ng), nstp(ng), nnew(ng), nrhs(ng), kstp(ng), krhs(ng),   &
+!     &                         knew(ng), iif(ng), PREDICTOR_2D_STEP(ng))
+!        CALL roms_hip_status (roms_hip_step3d_t (s), exit_flag)
 !      END SUBROUTINE step3d_t
 !
 !  Everything here is interface + glue: no arithmetic of the hot path is
@@ -29,6 +32,43 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: kstp, krhs, knew
     INTEGER(c_int) :: iif, predictor_2d_step
   END TYPE roms_step_idx_t
+
+  !  mirror `roms_bounds_t` and `roms_params_t` of include/roms_hip.h field for field (sizes checked against
+  !  roms_abi_sizeof in tests/test_fortran_shim.py): fill one of each from BOUNDS(ng)%...(tile), DOMAIN(ng)%*_Edge(tile)
+  !  and mod_scalars, declare it TARGET and hand c_loc of it to roms_hip_set_bounds / roms_hip_set_params
+  TYPE, BIND(C), PUBLIC :: roms_bounds_t
+    INTEGER(c_int) :: Lm, Mm, N, NT, NAT
+    INTEGER(c_int) :: ntileI, ntileJ, tile, Itile, Jtile
+    INTEGER(c_int) :: NghostPoints, EWperiodic, NSperiodic
+    INTEGER(c_int) :: west_edge, east_edge, south_edge, north_edge
+    INTEGER(c_int) :: LBi, UBi, LBj, UBj
+    INTEGER(c_int) :: Istr, Iend, Jstr, Jend
+    INTEGER(c_int) :: IstrB, IendB, IstrM, IstrP, IendP, IstrR, IendR, IstrT, IendT, IstrU
+    INTEGER(c_int) :: JstrB, JendB, JstrM, JstrP, JendP, JstrR, JendR, JstrT, JendT, JstrV
+    INTEGER(c_int) :: Istrm3, Istrm2, Istrm1, IstrUm2, IstrUm1
+    INTEGER(c_int) :: Iendp1, Iendp2, Iendp2i, Iendp3
+    INTEGER(c_int) :: Jstrm3, Jstrm2, Jstrm1, JstrVm2, JstrVm1
+    INTEGER(c_int) :: Jendp1, Jendp2, Jendp2i, Jendp3
+  END TYPE roms_bounds_t
+  TYPE, BIND(C), PUBLIC :: roms_params_t
+    REAL(c_double) :: dt, dtfast, g, rho0, gamma2, lambda
+    INTEGER(c_int) :: ndtfast, nfast
+    REAL(c_double) :: weight1(256), weight2(256)
+    INTEGER(c_int) :: Vtransform
+    REAL(c_double) :: hc
+    REAL(c_double) :: sc_r(65), Cs_r(65), sc_w(65), Cs_w(65)
+    INTEGER(c_int) :: Hadv(16), Vadv(16)
+    INTEGER(c_int) :: lbc_west, lbc_east, lbc_south, lbc_north
+    INTEGER(c_int) :: nonlin_eos
+    REAL(c_double) :: R0, T0, S0, Tcoef, Scoef
+    INTEGER(c_int) :: uv_adv, uv_cor, uv_vis2, curvgrid, var_rho_2d
+    INTEGER(c_int) :: ts_dif2, mix_geo_ts, mix_s_ts, salinity, lmd_nonlocal, solar_source
+    INTEGER(c_int) :: splines_vdiff, splines_vvisc
+    REAL(c_double) :: Akt_bak(16), Akv_bak
+    REAL(c_double) :: swfrac_mu1, swfrac_mu2, swfrac_r1
+    INTEGER(c_int) :: uv_drag, pad_physics
+    REAL(c_double) :: blk_ZQ, blk_ZT, blk_ZW
+  END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)
   TYPE, BIND(C), PUBLIC :: roms_halo_msg_t
@@ -70,7 +110,7 @@ MODULE roms_hip_mod
     END FUNCTION roms_hip_get_unique_id
     INTEGER(c_int) FUNCTION roms_hip_set_bounds (b) BIND(C, name='roms_hip_set_bounds')
       IMPORT :: c_int, c_ptr
-      TYPE(c_ptr), VALUE :: b          ! c_loc of a roms_bounds_t image (see roms_hip_bounds)
+      TYPE(c_ptr), VALUE :: b          ! c_loc of a TYPE(roms_bounds_t), TARGET variable
     END FUNCTION roms_hip_set_bounds
     INTEGER(c_int) FUNCTION roms_hip_set_params (p) BIND(C, name='roms_hip_set_params')
       IMPORT :: c_int, c_ptr
