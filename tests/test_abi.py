@@ -110,3 +110,21 @@ def test_halo_plan_fills_every_ghost_point(nI, nJ, ng):
         for i in range(max(b.LBi, -2), min(b.UBi, Lm + ng) + 1):
             for j in range(max(b.LBj, 0), min(b.UBj, Mm + 1) + 1):
                 assert a[i - b.LBi, j - b.LBj] == G[wrap(i), j], (r, i, j)
+
+
+def test_reduce_diag_and_host_clock():
+    """Host-side helpers of main3d.py: the reduction of the tile-local diag vectors (diag.F:398-420) and the
+    clock handed to ana_srflux (caldate with TIME_REF = 0; pinned against the reference in test_ref_pinning.py)."""
+    from roms_trunk_mgh_amd import main3d
+    a = np.array([10.0, 2.0, 3.0, 0.5, 27.0, 0.10, 0.04, 0.05, 0.01, 7, 8, 9])
+    b = np.array([20.0, 1.0, 5.0, 0.7, 26.0, 0.30, 0.10, 0.15, 0.05, 17, 18, 19])
+    r = main3d.reduce_diag([a, b])
+    assert list(r[0:3]) == [30.0, 3.0, 8.0] and list(r[3:5]) == [0.7, 27.0]
+    assert list(r[5:12]) == list(b[5:12])                      # MAXLOC: the tile with the larger Courant number
+    assert main3d.host_clock(0.0) == (1.0, 0.0)
+    yd, hr = main3d.host_clock(150.0 / 86400.0)                # one BENCHMARK step later
+    assert abs(yd - (1.0 + 150.0 / 86400.0)) < 1e-12 and abs(hr - 150.0 / 3600.0) < 1e-12
+    yd, hr = main3d.host_clock(10.5)
+    assert abs(yd - 11.5) < 1e-12 and hr == 12.0
+    with pytest.raises(ValueError):
+        main3d.host_clock(400.0)
