@@ -131,8 +131,10 @@ typedef struct roms_step_idx {
 /* Library life cycle                                                  */
 /* ------------------------------------------------------------------ */
 /* Replaces nothing; called once after ROMS_initialize (nl_roms.h:60-231).
- * nccl_unique_id: 128-byte ncclUniqueId shared by all ranks, or NULL when
- * ntileI*ntileJ == 1. */
+ * nccl_unique_id: 128-byte ncclUniqueId shared by all ranks, or NULL (one tile, or a multi-tile run whose
+ * halos go through roms_hip_set_halo_relay).  One tile WITH an id = loopback: the periodic wrap of the tile
+ * is sent through RCCL to the tile itself and every kernel takes its multi-tile branch (same results; lets a
+ * one-GPU box execute the RCCL transport). */
 int roms_hip_init(int rank, int ntileI, int ntileJ, int device_id,
                   const void *nccl_unique_id);
 int roms_hip_finalize(void);
@@ -253,6 +255,12 @@ double roms_hip_timing_last_ms(const char *entry);
  * written -- against which rocprofv3's FETCH_SIZE / WRITE_SIZE counters are
  * calibrated for this pattern.  n_doubles <= nij*(N+1). */
 int roms_hip_calib_stream(long n_doubles);
+
+/* Debugging aid (no reference counterpart): every device mirror and scratch array carries a guard band of
+ * four rows on either side, filled with one NaN bit pattern.  Returns 0 when every band is intact, an
+ * error naming the array otherwise (a kernel stored outside LBi:UBi,LBj:UBj at the first or last plane).
+ * Reads in the band are harmless by construction and deliver NaN. */
+int roms_hip_check_guards(void);
 
 #ifdef __cplusplus
 }

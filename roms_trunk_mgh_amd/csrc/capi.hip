@@ -90,6 +90,78 @@ extern "C" int roms_hip_calib_stream(long n)
   return 0;
 }
 
+// ---------------------------------------------------------- guard bands --
+// Every device mirror and every scratch array is allocated with a guard band of four rows (rounded up to
+// 256 B) in front and behind, filled with one quiet-NaN bit pattern.  A stencil that reaches a row or a
+// column outside LBi:UBi,LBj:UBj at the first or last plane of an array therefore reads mapped memory (no
+// page fault, whatever lies next to the allocation) and gets a NaN that shows up in the parity tests if the
+// value is used; a store outside an array destroys the pattern, which roms_hip_check_guards reports.
+static const unsigned long long k_guard_bits = 0x7FF8C0DEC0DEC0DEull;
+
+__global__ void k_fill_guard(unsigned long long *p, long n, unsigned long long bits)
+{
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) p[e] = bits;
+}
+
+static int guarded_alloc(double **user, double **base, long n)
+{
+  const long g = g_ctx.guard;
+  *user = *base = nullptr;
+  HIP_TRY(hipMalloc(base, sizeof(double) * (n + 2 * g)));
+  *user = *base + g;
+  if (g > 0) {
+    hipLaunchKernelGGL(k_fill_guard, dim3((unsigned)((g + 255) / 256)), dim3(256), 0, g_ctx.stream,
+                       (unsigned long long *)*base, g, k_guard_bits);
+    hipLaunchKernelGGL(k_fill_guard, dim3((unsigned)((g + 255) / 256)), dim3(256), 0, g_ctx.stream,
+                       (unsigned long long *)(*user + n), g, k_guard_bits);
+  }
+  HIP_TRY(hipMemsetAsync(*user, 0, sizeof(double) * n, g_ctx.stream));
+  return 0;
+}
+
+static void guarded_free(double **user, double **base)
+{
+  if (*base) (void)hipFree(*base);
+  *user = *base = nullptr;
+}
+
+// 0 = every guard band intact; otherwise an error naming the first damaged array (field name, or ws3[q] /
+// ws2[q] for scratch) and the distance of the first damaged word from the array.
+extern "C" int roms_hip_check_guards(void)
+{
+  if (!g_ctx.inited || !g_ctx.have_bounds) return roms_fail("roms_hip_check_guards", "set_bounds first");
+  const long g = g_ctx.guard;
+  if (g <= 0) return 0;
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  std::vector<unsigned long long> h(2 * g);
+  const roms_bounds_t &b = g_ctx.b;
+  const long nij = (long)(b.UBi - b.LBi + 1) * (long)(b.UBj - b.LBj + 1);
+  auto check = [&](const char *name, int q, const double *base, long n) -> int {
+    if (!base) return 0;
+    HIP_TRY(hipMemcpy(h.data(), base, sizeof(double) * g, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data() + g, base + g + n, sizeof(double) * g, hipMemcpyDeviceToHost));
+    for (long e = 0; e < 2 * g; e++)
+      if (h[e] != k_guard_bits) {
+        char msg[200];
+        if (q >= 0) snprintf(msg, sizeof msg, "store outside %s[%d]: %ld doubles %s the array", name, q,
+                             e < g ? g - e : e - g + 1, e < g ? "before" : "behind");
+        else snprintf(msg, sizeof msg, "store outside field %s: %ld doubles %s the array", name,
+                      e < g ? g - e : e - g + 1, e < g ? "before" : "behind");
+        return roms_fail("roms_hip_check_guards", msg);
+      }
+    return 0;
+  };
+  int rc;
+  for (int id = 0; id < FID_COUNT; id++)
+    if ((rc = check(k_field_name[id], -1, g_ctx.dev_base[id], g_ctx.count[id]))) return rc;
+  for (int q = 0; q < 8; q++)
+    if ((rc = check("ws3", q, g_ctx.ws3_base[q], nij * (b.N + 1)))) return rc;
+  for (int q = 0; q < 32; q++)
+    if ((rc = check("ws2", q, g_ctx.ws2_base[q], nij))) return rc;
+  return 0;
+}
+
 // ------------------------------------------------------------- life cycle --
 extern "C" int roms_abi_sizeof(int which)
 {
@@ -123,27 +195,28 @@ extern "C" int roms_hip_init(int rank, int ntileI, int ntileJ, int device_id, co
   g_ctx.ntileJ = ntileJ;
   g_ctx.device = device_id;
   g_ctx.have_nccl_id = false;
-  {
-    const char *e = getenv("ROMS_HIP_NO_FUSED2D");
-    g_ctx.no_fused_2d = e && e[0] == '1';
-    e = getenv("ROMS_HIP_NO_LDS2D");
-    g_ctx.no_lds_2d = e && e[0] == '1';
-    e = getenv("ROMS_HIP_NO_LDS3D");
-    g_ctx.no_lds_3d = e && e[0] == '1';
-  }
   if (nccl_unique_id) {
     memcpy(g_ctx.nccl_id, nccl_unique_id, 128);
     g_ctx.have_nccl_id = true;
   }
-  HIP_TRY(hipMalloc(&g_ctx.devc, sizeof(RomsDev)));
+  if (hipMalloc(&g_ctx.devc, sizeof(RomsDev)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamDestroy(g_ctx.stream);
+    g_ctx.stream = nullptr;
+    g_ctx.devc = nullptr;
+    return roms_fail("roms_hip_init", "hipMalloc of the constant block failed");
+  }
   memset(&g_ctx.hostc, 0, sizeof(RomsDev));
   g_ctx.devc_dirty = true;
   g_ctx.inited = true;
-  if (ntileI * ntileJ > 1 && g_ctx.have_nccl_id) {
-    // without an id the halos must go through a host relay (roms_hip_set_halo_relay);
-    // the first exchange fails loudly if neither transport exists
+  g_ctx.loopback = false;
+  if (g_ctx.have_nccl_id) {
+    // without an id the halos of a multi-tile run must go through a host relay
+    // (roms_hip_set_halo_relay); the first exchange fails loudly if neither transport exists
+    if (ntileI * ntileJ == 1 && rank != 0) { roms_hip_finalize(); return roms_fail("roms_hip_init", "one tile: rank must be 0"); }
     int rc = halo_init();
     if (rc) { roms_hip_finalize(); return rc; }
+    g_ctx.loopback = ntileI * ntileJ == 1;
   }
   return 0;
 }
@@ -156,16 +229,15 @@ extern "C" int roms_hip_finalize(void)
   halo_finalize();
   diag_release();
   for (int i = 0; i < FID_COUNT; i++) {
-    if (g_ctx.dev[i]) hipFree(g_ctx.dev[i]);
-    g_ctx.dev[i] = nullptr;
+    guarded_free(&g_ctx.dev[i], &g_ctx.dev_base[i]);
     g_ctx.host[i] = nullptr;
     g_ctx.count[i] = 0;
   }
-  for (auto &w : g_ctx.hostc.ws3) { if (w) hipFree(w); w = nullptr; }
-  for (auto &w : g_ctx.hostc.ws2) { if (w) hipFree(w); w = nullptr; }
-  if (g_ctx.devc) hipFree(g_ctx.devc);
+  for (int q = 0; q < 8; q++) guarded_free(&g_ctx.hostc.ws3[q], &g_ctx.ws3_base[q]);
+  for (int q = 0; q < 32; q++) guarded_free(&g_ctx.hostc.ws2[q], &g_ctx.ws2_base[q]);
+  if (g_ctx.devc) (void)hipFree(g_ctx.devc);
   g_ctx.devc = nullptr;
-  if (g_ctx.stream) hipStreamDestroy(g_ctx.stream);
+  if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
   g_ctx.inited = false;
   g_ctx.have_bounds = g_ctx.have_params = false;
@@ -182,17 +254,26 @@ extern "C" int roms_hip_set_bounds(const roms_bounds_t *b)
   g_ctx.hostc.b = *b;
   g_ctx.have_bounds = true;
   g_ctx.devc_dirty = true;
-  // device scratch for the _tile routines' automatic arrays
-  const long nij = (long)(b->UBi - b->LBi + 1) * (long)(b->UBj - b->LBj + 1);
-  for (auto &w : g_ctx.hostc.ws3) {
-    if (w) hipFree(w);
-    HIP_TRY(hipMalloc(&w, sizeof(double) * nij * (b->N + 1)));
-    HIP_TRY(hipMemsetAsync(w, 0, sizeof(double) * nij * (b->N + 1), g_ctx.stream));
+  // new extents invalidate every mirror registered under the old ones
+  for (int i = 0; i < FID_COUNT; i++) {
+    snapshot_forget(i);
+    guarded_free(&g_ctx.dev[i], &g_ctx.dev_base[i]);
+    g_ctx.host[i] = nullptr;
+    g_ctx.count[i] = 0;
   }
-  for (auto &w : g_ctx.hostc.ws2) {
-    if (w) hipFree(w);
-    HIP_TRY(hipMalloc(&w, sizeof(double) * nij));
-    HIP_TRY(hipMemsetAsync(w, 0, sizeof(double) * nij, g_ctx.stream));
+  memset(&g_ctx.hostc.F, 0, sizeof g_ctx.hostc.F);
+  // device scratch for the _tile routines' automatic arrays
+  const long ni = b->UBi - b->LBi + 1, nij = ni * (long)(b->UBj - b->LBj + 1);
+  g_ctx.guard = ((4 * ni + 31) / 32) * 32;
+  for (int q = 0; q < 8; q++) {
+    guarded_free(&g_ctx.hostc.ws3[q], &g_ctx.ws3_base[q]);
+    int rc = guarded_alloc(&g_ctx.hostc.ws3[q], &g_ctx.ws3_base[q], nij * (b->N + 1));
+    if (rc) return rc;
+  }
+  for (int q = 0; q < 32; q++) {
+    guarded_free(&g_ctx.hostc.ws2[q], &g_ctx.ws2_base[q]);
+    int rc = guarded_alloc(&g_ctx.hostc.ws2[q], &g_ctx.ws2_base[q], nij);
+    if (rc) return rc;
   }
   return 0;
 }
@@ -228,9 +309,12 @@ extern "C" int roms_hip_register_field(int id, double *host_ptr, long n_doubles)
     snprintf(msg, sizeof msg, "field %s: size %ld does not match bounds (%ld)", k_field_name[id], n_doubles, want);
     return roms_fail("roms_hip_register_field", msg);
   }
-  if (g_ctx.dev[id]) hipFree(g_ctx.dev[id]);
-  HIP_TRY(hipMalloc(&g_ctx.dev[id], sizeof(double) * want));
-  HIP_TRY(hipMemsetAsync(g_ctx.dev[id], 0, sizeof(double) * want, g_ctx.stream));
+  snapshot_forget(id);          // staging / page-lock of a previous registration (other size or host array)
+  guarded_free(&g_ctx.dev[id], &g_ctx.dev_base[id]);
+  {
+    int rc = guarded_alloc(&g_ctx.dev[id], &g_ctx.dev_base[id], want);
+    if (rc) return rc;
+  }
   g_ctx.host[id] = host_ptr;
   g_ctx.count[id] = want;
   double **slot = reinterpret_cast<double **>(&g_ctx.hostc.F) + id;

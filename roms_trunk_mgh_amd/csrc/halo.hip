@@ -235,10 +235,13 @@ __global__ void k_pack_multi(const RomsDev *__restrict__ c, PackArgs a)
 static int ensure_buffers(size_t doubles)
 {
   if (doubles <= g_buf_doubles) return 0;
+  // a failed allocation must leave no dangling pointer and no stale size behind (halo_finalize frees them)
+  g_buf_doubles = 0;
   for (auto &p : g_buf) {
-    if (p) hipFree(p);
-    HIP_TRY(hipMalloc(&p, sizeof(double) * doubles));
+    if (p) (void)hipFree(p);
+    p = nullptr;
   }
+  for (auto &p : g_buf) HIP_TRY(hipMalloc(&p, sizeof(double) * doubles));
   g_buf_doubles = doubles;
   return 0;
 }
@@ -367,10 +370,12 @@ static int exchange_all(const HaloItem *items, int nitems)
                                         "roms_hip_init or set a host relay (roms_hip_set_halo_relay)");
     const size_t need = (size_t)(stot > rtot ? stot : rtot);
     if (need > g_hbuf_doubles) {
+      g_hbuf_doubles = 0;
       for (auto &p : g_hbuf) {
-        if (p) hipHostFree(p);
-        HIP_TRY(hipHostMalloc(&p, sizeof(double) * need, hipHostMallocDefault));
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
       }
+      for (auto &p : g_hbuf) HIP_TRY(hipHostMalloc(&p, sizeof(double) * need, hipHostMallocDefault));
       g_hbuf_doubles = need;
     }
     if (stot) HIP_TRY(hipMemcpyAsync(g_hbuf[0], g_buf[0], sizeof(double) * stot, hipMemcpyDeviceToHost, g_ctx.stream));
@@ -403,7 +408,7 @@ static int halo_run(const HaloItem *items, int nitems)
 {
   const roms_bounds_t &b = g_ctx.b;
   if (nitems <= 0) return 0;
-  if (b.ntileI * b.ntileJ == 1) {
+  if (b.ntileI * b.ntileJ == 1 && !g_ctx.loopback) {
     if (!b.EWperiodic) return 0;
     // all fields of the batch in one launch (a step issues ~50 of these otherwise)
     for (int f0 = 0; f0 < nitems; f0 += HALO_MAX_ITEMS) {
@@ -432,10 +437,16 @@ static int halo_run(const HaloItem *items, int nitems)
     roms_hip_tile_neighbors(g_ctx.rank, b.ntileI, b.ntileJ, b.NghostPoints, b.NghostPoints,
                             b.EWperiodic, b.NSperiodic, v);
     g_neigh = Neigh{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]};
+    if (g_ctx.loopback && b.EWperiodic) {
+      // the tile is its own W and E neighbour; it is west-most and east-most at once, so both halves of
+      // the Nghost+1 rule (mp_exchange.F:155-187) apply
+      g_neigh.Wtile = g_neigh.Etile = g_ctx.rank;
+      if (b.NghostPoints != 3) g_neigh.GrecvW = g_neigh.GsendE = b.NghostPoints + 1;
+    }
     g_have_neigh = true;
   }
   // a periodic direction held by ONE tile row/column is a local copy
-  if (b.EWperiodic && b.ntileI == 1) {
+  if (b.EWperiodic && b.ntileI == 1 && !g_ctx.loopback) {
     for (int f = 0; f < nitems; f++) {
       dim3 grid((b.UBj - b.LBj + 1 + 63) / 64, items[f].nk);
       hipLaunchKernelGGL(k_periodic_ew, grid, dim3(64), 0, g_ctx.stream, g_ctx.devc, items[f].A, items[f].nk, b.LBj, b.UBj);

@@ -2,8 +2,7 @@
 //   t3dmix2_geo_tile  ROMS/Nonlinear/t3dmix2_geo.h:90-424  (rotated to
 //                     geopotentials, two-slab k-recursion)
 //   t3dmix2_s_tile    ROMS/Nonlinear/t3dmix2_s.h:89-306    (along s-surfaces)
-//   uv3dmix2_s_tile   ROMS/Nonlinear/uv3dmix2_s.h:114-335  (stress tensor
-//                     along s-surfaces; also accumulates rufrc, rvfrc)
+// (uv3dmix2_s_tile is in k_uv3dmix2.hip)
 //
 // One thread per (i,j) column sweeping k upward.  The reference's two-slab
 // buffers (level k and k+1 of dZdx,dTdx,dZde,dTde, W-levels k-1 and k of dTdz,
@@ -12,7 +11,6 @@
 #include "roms_dev.h"
 
 int roms_entry_check(const char *name);
-int roms_launch_uv3dmix2_v2(int nrhs, int nnew);
 
 namespace {
 
@@ -164,87 +162,6 @@ k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
   }
 }
 
-// ---- uv3dmix2_s ------------------------------------------------------------
-struct VLvl {
-  const double *u, *v, *Hz;
-  const double *pm, *pn, *pmon_r, *pnom_r, *pmon_p, *pnom_p, *om_r, *on_r, *om_p, *on_p, *visc2_r, *visc2_p;
-  long ni;
-};
-// stress at rho-point a: returns cff (UFx = on_r^2 visc2_r cff ; VFe = om_r^2 visc2_r cff)
-__device__ __forceinline__ double stress_r(const VLvl &L, long a, long ak)
-{
-  return L.Hz[ak] * 0.5 *
-         (L.pmon_r[a] * ((L.pn[a] + L.pn[a + 1]) * L.u[ak + 1] - (L.pn[a - 1] + L.pn[a]) * L.u[ak]) -
-          L.pnom_r[a] * ((L.pm[a] + L.pm[a + L.ni]) * L.v[ak + L.ni] - (L.pm[a - L.ni] + L.pm[a]) * L.v[ak]));
-}
-// stress at psi-point a
-__device__ __forceinline__ double stress_p(const VLvl &L, long a, long ak)
-{
-  return 0.125 * (L.Hz[ak - 1] + L.Hz[ak] + L.Hz[ak - 1 - L.ni] + L.Hz[ak - L.ni]) *
-         (L.pmon_p[a] * ((L.pn[a - L.ni] + L.pn[a]) * L.v[ak] - (L.pn[a - 1 - L.ni] + L.pn[a - 1]) * L.v[ak - 1]) +
-          L.pnom_p[a] * ((L.pm[a - 1] + L.pm[a]) * L.u[ak] - (L.pm[a - 1 - L.ni] + L.pm[a - L.ni]) * L.u[ak - L.ni]));
-}
-
-__global__ void __launch_bounds__(BLK_X *BLK_Y)
-k_uv3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
-{
-  DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
-  if (i > b.Iend || j > b.Jend) return;
-  const bool do_u = i >= b.IstrU, do_v = j >= b.JstrV;
-  const double dt = c->p.dt;
-  VLvl L;
-  L.ni = ni;
-  L.pm = c->F.pm; L.pn = c->F.pn; L.pmon_r = c->F.pmon_r; L.pnom_r = c->F.pnom_r;
-  L.pmon_p = c->F.pmon_p; L.pnom_p = c->F.pnom_p; L.om_r = c->F.om_r; L.on_r = c->F.on_r;
-  L.om_p = c->F.om_p; L.on_p = c->F.on_p; L.visc2_r = c->F.visc2_r; L.visc2_p = c->F.visc2_p;
-  L.u = c->F.u + (long)(nrhs - 1) * n3r;
-  L.v = c->F.v + (long)(nrhs - 1) * n3r;
-  L.Hz = c->F.Hz;
-  double *__restrict__ un = c->F.u + (long)(nnew - 1) * n3r;
-  double *__restrict__ vn = c->F.v + (long)(nnew - 1) * n3r;
-  const long a = I2(i, j);
-  const double *pm = c->F.pm, *pn = c->F.pn;
-  const double cu = dt * 0.25 * (pm[a - 1] + pm[a]) * (pn[a - 1] + pn[a]);
-  const double cv = dt * 0.25 * (pm[a] + pm[a - ni]) * (pn[a] + pn[a - ni]);
-  const double hn_u = 0.5 * (pn[a - 1] + pn[a]), hm_u = 0.5 * (pm[a - 1] + pm[a]);
-  const double hn_v = 0.5 * (pn[a - ni] + pn[a]), hm_v = 0.5 * (pm[a - ni] + pm[a]);
-  // metric factors of the four stress points each component needs
-  const double kr0_x = L.on_r[a] * L.on_r[a] * L.visc2_r[a], kr0_e = L.om_r[a] * L.om_r[a] * L.visc2_r[a];
-  const double krm_x = L.on_r[a - 1] * L.on_r[a - 1] * L.visc2_r[a - 1];
-  const double krs_e = L.om_r[a - ni] * L.om_r[a - ni] * L.visc2_r[a - ni];
-  const double kp0_e = L.om_p[a] * L.om_p[a] * L.visc2_p[a], kp0_x = L.on_p[a] * L.on_p[a] * L.visc2_p[a];
-  const double kpn_e = L.om_p[a + ni] * L.om_p[a + ni] * L.visc2_p[a + ni];
-  const double kpe_x = L.on_p[a + 1] * L.on_p[a + 1] * L.visc2_p[a + 1];
-  double ruf = do_u ? c->F.rufrc[a] : 0.0, rvf = do_v ? c->F.rvfrc[a] : 0.0;
-  for (int k = 1; k <= N; k++) {
-    const long ak = a + (long)(k - 1) * nij;
-    const double sr0 = stress_r(L, a, ak);
-    const double sp0 = stress_p(L, a, ak);
-    if (do_u) {
-      const double srm = stress_r(L, a - 1, ak - 1);
-      const double spn = stress_p(L, a + ni, ak + ni);
-      const double cff1 = hn_u * (kr0_x * sr0 - krm_x * srm);
-      const double cff2 = hm_u * (kpn_e * spn - kp0_e * sp0);
-      const double cff3 = cu * (cff1 + cff2);
-      ruf = ruf + cff1 + cff2;
-      un[ak] = un[ak] + cff3;
-    }
-    if (do_v) {
-      const double srs = stress_r(L, a - ni, ak - ni);
-      const double spe = stress_p(L, a + 1, ak + 1);
-      const double cff1 = hn_v * (kpe_x * spe - kp0_x * sp0);
-      const double cff2 = hm_v * (kr0_e * sr0 - krs_e * srs);
-      const double cff3 = cv * (cff1 - cff2);
-      rvf = rvf + cff1 - cff2;
-      vn[ak] = vn[ak] + cff3;
-    }
-  }
-  if (do_u) c->F.rufrc[a] = ruf;
-  if (do_v) c->F.rvfrc[a] = rvf;
-}
-
 }  // namespace
 
 extern "C" int roms_hip_t3dmix2(const roms_step_idx_t *s)
@@ -261,18 +178,5 @@ extern "C" int roms_hip_t3dmix2(const roms_step_idx_t *s)
   else
     return roms_fail("roms_hip_t3dmix2", "no tracer mixing option (MIX_GEO_TS / MIX_S_TS) selected");
   KERNEL_CHECK("k_t3dmix2");
-  return 0;
-}
-
-extern "C" int roms_hip_uv3dmix2(const roms_step_idx_t *s)
-{
-  int rc = roms_entry_check("roms_hip_uv3dmix2");
-  if (rc) return rc;
-  ScopedTimer tm("uv3dmix2");
-  const roms_bounds_t &b = g_ctx.b;
-  if (!g_ctx.no_lds_3d) return roms_launch_uv3dmix2_v2(s->nrhs, s->nnew);   // k_uv3dmix2.hip
-  hipLaunchKernelGGL(k_uv3dmix2_s, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
-                     g_ctx.devc, s->nrhs, s->nnew);
-  KERNEL_CHECK("k_uv3dmix2_s");
   return 0;
 }

@@ -1,6 +1,9 @@
 // k_step2d_mom.hip -- LDS-tiled momentum kernel of step2d_tile
-// (ROMS/Nonlinear/step2d_LF_AM3.h:939-2255): same arithmetic as k2d_mom in
-// k_step2d.hip, but the five fields the wide stencils read -- ubar(krhs),
+// (ROMS/Nonlinear/step2d_LF_AM3.h:939-2255): pressure gradient with VAR_RHO_2D
+// (:939-1019), 4th-order centred advection (:1079-1283), Coriolis (:1291-1325),
+// curvilinear terms (:1333-1382), harmonic viscosity (:1394-1471), 2D<->3D coupling
+// (:1884-2065) and the ubar/vbar step (:2098-2255).  The five fields the wide
+// stencils read -- ubar(krhs),
 // vbar(krhs), DUon, DVom and the total depth Drhs = zeta(krhs)+h -- are staged
 // once per workgroup into LDS with their 2-point C-grid halo (68 x 8 doubles
 // per field for a 64 x 4 workgroup, 21.8 KB).  The 4th-order advection,

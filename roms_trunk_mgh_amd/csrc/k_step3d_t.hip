@@ -31,8 +31,8 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first);      // k_mpdata
 
 namespace {
 
-// Classic form (ROMS_HIP_S3T_VARIANT=0), kept as the A/B reference of the pipelined kernel
-// below.
+// k_step3d_t<> below: one thread per column reading straight from global memory; instantiated for the
+// HSIMT pair only (every other scheme pair runs k_step3d_t_pipe).
 //
 // Tuning notes (MI355X, BENCHMARK3, profiles/r01c): the kernel is bound by memory LATENCY
 // per level, not by bytes -- FETCH_SIZE barely moves the time.  Issuing every load of a
@@ -476,15 +476,20 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   }
 }
 
-template <int HADV, int VADV, int MODE>
-int launch_var(int nnew, int itrc0, int ntr)
+template <int HADV, int VADV>
+int launch_nmax(int nnew, int itrc0, int ntr)
 {
   const roms_bounds_t &b = g_ctx.b;
   const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
   if (b.N > ROMS_MAXN) return roms_fail("roms_hip_step3d_t", "N > 64 not instantiated");
-  if (MODE != 2 && HADV != ADV_HSIMT && b.N > 32)
-    return roms_fail("roms_hip_step3d_t", "the classic A/B kernel is instantiated for N <= 32");
-  if constexpr (MODE == 2) {
+  if constexpr (HADV == ADV_HSIMT) {      // straight-from-memory kernel
+    if (b.N <= 16)
+      hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else if (b.N <= 32)
+      hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else
+      hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 64>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+  } else {                                // software-pipelined kernel
     if (b.N <= 16)
       hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
     else if (b.N <= 32)
@@ -493,25 +498,9 @@ int launch_var(int nnew, int itrc0, int ntr)
       hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 48>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
     else
       hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 64>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
-  } else {
-    if (b.N <= 16)
-      hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
-    else if (b.N <= 32)
-      hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
-    else if constexpr (HADV == ADV_HSIMT)
-      hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 64>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
   }
   KERNEL_CHECK("k_step3d_t");
   return 0;
-}
-
-template <int HADV, int VADV>
-int launch_nmax(int nnew, int itrc0, int ntr)
-{
-  // ROMS_HIP_S3T_VARIANT: 0 = classic kernel (A/B reference), otherwise the pipelined kernel
-  static const int variant = getenv("ROMS_HIP_S3T_VARIANT") ? atoi(getenv("ROMS_HIP_S3T_VARIANT")) : 2;
-  if (variant == 0) return launch_var<HADV, VADV, 0>(nnew, itrc0, ntr);
-  return launch_var<HADV, VADV, 2>(nnew, itrc0, ntr);
 }
 
 }  // namespace
@@ -552,7 +541,7 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
         for (int q = 0; q < n; q++)
           halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + ((long)(s->nnew - 1) + 3L * (it + q - 1)) * n3r_);
         if ((rc = halo_batch_end())) return rc;
-        rc = launch_var<ADV_HSIMT, ADV_HSIMT, 0>(s->nnew, it, n);
+        rc = launch_nmax<ADV_HSIMT, ADV_HSIMT>(s->nnew, it, n);
         break;
       }
       case ADV_MPDATA * 16 + ADV_MPDATA:

@@ -1,8 +1,8 @@
 // k_uv3dmix2.hip -- harmonic horizontal viscosity along s-surfaces,
-// uv3dmix2_s_tile (ROMS/Nonlinear/uv3dmix2_s.h:114-335), second version.
+// uv3dmix2_s_tile (ROMS/Nonlinear/uv3dmix2_s.h:114-335); also accumulates
+// rufrc, rvfrc.
 //
-// Same arithmetic and operation order as k_uv3dmix2_s (k_mix.hip); the
-// difference is what is read inside the k-loop.  Each thread needs the stress
+// One thread per (i,j) column sweeping k upward.  Each thread needs the stress
 // at three rho-points (own, west, south) and three psi-points (own, north,
 // east).  Their metric coefficients -- pmon/pnom and the four (pm+pm), (pn+pn)
 // pairs per point -- do not depend on k, so they are formed once per column
@@ -116,11 +116,16 @@ k_uv3dmix2_v2(const RomsDev *__restrict__ c, int nrhs, int nnew)
 
 }  // namespace
 
-int roms_launch_uv3dmix2_v2(int nrhs, int nnew)
+int roms_entry_check(const char *name);
+
+extern "C" int roms_hip_uv3dmix2(const roms_step_idx_t *s)
 {
+  int rc = roms_entry_check("roms_hip_uv3dmix2");
+  if (rc) return rc;
+  ScopedTimer tm("uv3dmix2");
   const roms_bounds_t &b = g_ctx.b;
   hipLaunchKernelGGL(k_uv3dmix2_v2, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
-                     g_ctx.devc, nrhs, nnew);
+                     g_ctx.devc, s->nrhs, s->nnew);
   KERNEL_CHECK("k_uv3dmix2_v2");
   return 0;
 }

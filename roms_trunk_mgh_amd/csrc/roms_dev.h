@@ -32,19 +32,24 @@ struct RomsCtx {
   bool have_bounds = false, have_params = false;
   double *host[FID_COUNT] = {nullptr};
   double *dev[FID_COUNT] = {nullptr};
+  double *dev_base[FID_COUNT] = {nullptr};   // start of the allocation (guard band in front of dev[])
   long count[FID_COUNT] = {0};
+  double *ws3_base[8] = {nullptr};
+  double *ws2_base[32] = {nullptr};
+  long guard = 0;               // doubles of guard band on either side of every mirror / scratch array
   RomsDev hostc{};            // host copy of the constant block
   RomsDev *devc = nullptr;    // device copy
   bool devc_dirty = true;
   bool timing = false;
-  bool no_fused_2d = false;   // ROMS_HIP_NO_FUSED2D=1: always use the general BC + halo launches in step2d
-  bool no_lds_2d = false;     // ROMS_HIP_NO_LDS2D=1: momentum kernel without LDS staging (A/B reference)
-  bool no_lds_3d = false;     // ROMS_HIP_NO_LDS3D=1: rhs3d_tile without LDS staging (A/B reference)
   std::string last_error;
   // halo exchange (RCCL) state lives in halo.hip
   void *nccl_comm = nullptr;
   unsigned char nccl_id[128];
   bool have_nccl_id = false;
+  // ONE tile with an RCCL id: the periodic wrap of that tile travels through the transport to the tile
+  // itself (W and E neighbour = own rank) instead of the local copy kernel, and every kernel takes its
+  // multi-tile branch.  Same results; lets a one-GPU box execute the RCCL leg (tests/test_gpu_rccl.py).
+  bool loopback = false;
 };
 
 extern RomsCtx g_ctx;
@@ -191,5 +196,6 @@ int bc_v3d(int nout);
 int bc_t3d(int nout, int itrc);
 int bc_w3d(double *A);
 void snapshot_release();                  // snapshot.hip: waits for and frees an in-flight snapshot
+void snapshot_forget(int field_id);       // snapshot.hip: the same for one field (before it is re-registered)
 void diag_release();                      // k_diag.hip: frees the buffers of roms_hip_diag
 int check_lbc();

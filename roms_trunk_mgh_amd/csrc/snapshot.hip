@@ -30,19 +30,29 @@ std::vector<SnapItem> g_pending;
 
 }  // namespace
 
+// Drop everything the snapshot machinery holds for field `id` (staging copy, bounce buffer, page-lock of
+// the host array).  roms_hip_register_field calls it BEFORE it replaces the host pointer / the size, so a
+// re-registered field never meets a staging buffer of the old size or an old locked host array.
+void snapshot_forget(int id)
+{
+  if (id < 0 || id >= FID_COUNT) return;
+  if (g_copy_stream) (void)hipStreamSynchronize(g_copy_stream);
+  for (size_t q = 0; q < g_pending.size();)
+    if (g_pending[q].id == id) g_pending.erase(g_pending.begin() + q);
+    else q++;
+  if (g_stage[id]) (void)hipFree(g_stage[id]);
+  if (g_bounce[id]) (void)hipHostFree(g_bounce[id]);
+  if (g_registered[id] && g_ctx.host[id]) (void)hipHostUnregister(g_ctx.host[id]);
+  g_stage[id] = g_bounce[id] = nullptr;
+  g_registered[id] = g_register_failed[id] = false;
+}
+
 void snapshot_release()
 {
-  if (g_copy_stream) hipStreamSynchronize(g_copy_stream);
-  for (int id = 0; id < FID_COUNT; id++) {
-    if (g_stage[id]) hipFree(g_stage[id]);
-    if (g_bounce[id]) hipHostFree(g_bounce[id]);
-    if (g_registered[id] && g_ctx.host[id]) hipHostUnregister(g_ctx.host[id]);
-    g_stage[id] = g_bounce[id] = nullptr;
-    g_registered[id] = g_register_failed[id] = false;
-  }
+  for (int id = 0; id < FID_COUNT; id++) snapshot_forget(id);
   g_pending.clear();
-  if (g_snap_event) hipEventDestroy(g_snap_event);
-  if (g_copy_stream) hipStreamDestroy(g_copy_stream);
+  if (g_snap_event) (void)hipEventDestroy(g_snap_event);
+  if (g_copy_stream) (void)hipStreamDestroy(g_copy_stream);
   g_snap_event = nullptr;
   g_copy_stream = nullptr;
 }

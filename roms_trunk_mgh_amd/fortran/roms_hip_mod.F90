@@ -133,6 +133,10 @@ MODULE roms_hip_mod
     INTEGER(c_int) FUNCTION roms_hip_sync_all_to_device () BIND(C, name='roms_hip_sync_all_to_device')
       IMPORT :: c_int
     END FUNCTION roms_hip_sync_all_to_device
+    !  debugging aid: 0 when no kernel stored outside a device array (guard bands intact)
+    INTEGER(c_int) FUNCTION roms_hip_check_guards () BIND(C, name='roms_hip_check_guards')
+      IMPORT :: c_int
+    END FUNCTION roms_hip_check_guards
     INTEGER(c_int) FUNCTION roms_hip_sync_all_to_host () BIND(C, name='roms_hip_sync_all_to_host')
       IMPORT :: c_int
     END FUNCTION roms_hip_sync_all_to_host

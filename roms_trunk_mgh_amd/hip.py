@@ -30,7 +30,7 @@ DECLARED_SYMBOLS = (
      "roms_hip_step2d_loop", "roms_hip_exchange", "roms_hip_timing_enable",
      "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay", "roms_hip_diag",
      "roms_hip_snapshot_begin", "roms_hip_snapshot_end", "roms_hip_halo_plan",
-     "roms_hip_ana_srflux"] + ["roms_hip_" + e for e in ENTRIES])
+     "roms_hip_ana_srflux", "roms_hip_check_guards"] + ["roms_hip_" + e for e in ENTRIES])
 
 
 _DP = C.POINTER(C.c_double)
@@ -215,12 +215,20 @@ class RomsHip:
     def last_ms(self, entry):
         return self.l.roms_hip_timing_last_ms(entry.encode())
 
+    def check_guards(self):
+        """Raise if a kernel stored outside one of the device arrays (roms_hip_check_guards)."""
+        self._chk(self.l.roms_hip_check_guards(), "check_guards")
+
     def close(self):
         # the library holds ONE context per process: only its current owner may tear it down
         # (a stale object being garbage-collected must not finalize its successor's context)
         if RomsHip._live is self:
             RomsHip._live = None
+            rc = self.l.roms_hip_check_guards()
+            msg = self.l.roms_hip_last_error() if rc else None
             self.l.roms_hip_finalize()
+            if rc:
+                raise RuntimeError(f"roms_hip: guard band damaged: {msg.decode() if msg else ''}")
 
     def __del__(self):
         try:

@@ -20,20 +20,36 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
+    opts = set(variant.split("+")) if variant else set()
+    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)
     b = st.b
     ndev = torch.cuda.device_count()
-    be = hip.RomsHip(st, rank=rank, device=rank % max(ndev, 1), nccl_unique_id=None)
-    be.set_halo_relay_gloo(dist, torch)
-    m = main3d.Main3D(be, physics=(variant == "physics"), diagnostics=(variant == "physics"))
+    if "rccl" in opts:
+        # the RCCL transport: one device per rank (RCCL refuses two ranks on one device); with ONE rank the
+        # library runs in loopback (the tile is its own W/E neighbour, roms_hip.h)
+        assert world <= max(ndev, 1)
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            assert hip.load().roms_hip_get_unique_id(buf) == 0
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        dist.broadcast(t, src=0)
+        be = hip.RomsHip(st, rank=rank, device=rank, nccl_unique_id=bytes(t.numpy().tobytes()))
+    else:
+        be = hip.RomsHip(st, rank=rank, device=rank % max(ndev, 1), nccl_unique_id=None)
+        be.set_halo_relay_gloo(dist, torch)
+    m = main3d.Main3D(be, physics=("physics" in opts), diagnostics=("physics" in opts))
     m.initial()
     m.run(nsteps)
     be.to_host()
     be.close()
+    out = {k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz")}
+    if "slim" in opts:      # full-size grids: only the newest time level of the 3-D prognostic fields
+        lev = m.s.nnew - 1
+        out["u"], out["v"], out["t"] = st["u"][:, :, :, lev], st["v"][:, :, :, lev], st["t"][:, :, :, lev, :]
     np.savez(os.path.join(outdir, f"tile{rank}.npz"),
-             bounds=np.array([b.Istr, b.Iend, b.Jstr, b.Jend, b.LBi, b.LBj]),
-             **{k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz")})
+             bounds=np.array([b.Istr, b.Iend, b.Jstr, b.Jend, b.LBi, b.LBj]), **out)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -23,19 +23,14 @@ def _run(config, nsteps, perturb, physics=False):
     mo = main3d.Main3D(oracle.Oracle(st_o), physics=physics, diagnostics=physics)
     mo.initial()
     mo.run(nsteps)
-    if os.environ.get("ROMS_TEST_DRY"):
-        mh = main3d.Main3D(oracle.Oracle(st_h), physics=physics, diagnostics=physics)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be, physics=physics, diagnostics=physics)
         mh.initial()
         mh.run(nsteps)
-    else:
-        be = hip.RomsHip(st_h)
-        try:
-            mh = main3d.Main3D(be, physics=physics, diagnostics=physics)
-            mh.initial()
-            mh.run(nsteps)
-            be.to_host()
-        finally:
-            be.close()
+        be.to_host()
+    finally:
+        be.close()
     mo.hip_last_diag = mh.last_diag
     return st_h, st_o, mo
 

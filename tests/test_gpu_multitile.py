@@ -31,15 +31,16 @@ def _free_port():
 
 def _single(config, nsteps, variant=""):
     from roms_trunk_mgh_amd import hip
-    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
+    opts = set(variant.split("+")) if variant else set()
+    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
     st = ana.make_tile(config, perturb=1.0, **kw)
     be = hip.RomsHip(st)
-    m = main3d.Main3D(be, physics=(variant == "physics"), diagnostics=(variant == "physics"))
+    m = main3d.Main3D(be, physics=("physics" in opts), diagnostics=("physics" in opts))
     m.initial()
     m.run(nsteps)
     be.to_host()
     be.close()
-    return st
+    return st, m.s.nnew - 1
 
 
 @pytest.mark.parametrize("ntI,ntJ,config,variant", [(2, 1, "BENCHMARK_TINY", ""), (1, 2, "UPWELLING", ""),
@@ -49,11 +50,17 @@ def _single(config, nsteps, variant=""):
                                                     # three ghost points, MPDATA's extended ranges across tile edges
                                                     (2, 2, "BENCHMARK_TINY", "mpdata"),
                                                     # bulk fluxes, KPP, wvelocity, diag on every tile
-                                                    (2, 2, "BENCHMARK_TINY", "physics")])
+                                                    (2, 2, "BENCHMARK_TINY", "physics"),
+                                                    # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
+                                                    # 512-column tiles of the 8-GPU run (4x1), both tile rows (2x2), the
+                                                    # deferred-flux step2d path and, with six MPDATA tracers, three ghost points
+                                                    (4, 1, "BENCHMARK3", "physics+slim"), (2, 2, "BENCHMARK3", "physics+slim"),
+                                                    (2, 2, "BENCHMARK3", "mpdata+slim")])
 def test_tiled_hip_equals_single_hip(tmp_path, ntI, ntJ, config, variant):
-    nsteps = 3
+    slim = "slim" in variant
+    nsteps = 2 if slim else 3
     world = ntI * ntJ
-    ref = _single(config, nsteps, variant)          # before the children start: at most `world` + 1 GPU processes
+    ref, lev = _single(config, nsteps, variant)     # before the children start: at most `world` + 1 GPU processes
     port = _free_port()
     env = dict(os.environ, OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_gpu_worker.py"), str(r), str(world), str(ntI),
@@ -61,7 +68,7 @@ def test_tiled_hip_equals_single_hip(tmp_path, ntI, ntJ, config, variant):
              for r in range(world)]
     try:
         for p in procs:
-            assert p.wait(timeout=300) == 0
+            assert p.wait(timeout=600) == 0
     finally:
         for p in procs:
             if p.poll() is None:
@@ -74,7 +81,12 @@ def test_tiled_hip_equals_single_hip(tmp_path, ntI, ntJ, config, variant):
             a = d[name]
             ni, nj = a.shape[0], a.shape[1]
             i0, j0 = LBi - rb.LBi, LBj - rb.LBj
-            want = ref[name][i0:i0 + ni, j0:j0 + nj]
+            full = ref[name]
+            if slim and name in ("u", "v"):
+                full = full[:, :, :, lev]
+            elif slim and name == "t":
+                full = full[:, :, :, lev, :]
+            want = full[i0:i0 + ni, j0:j0 + nj]
             own = (slice(Istr - LBi, Iend - LBi + 1), slice(Jstr - LBj, Jend - LBj + 1))
             assert np.array_equal(a[own], want[own]), (name, r, float(np.abs(a[own] - want[own]).max()))
             if name in ("zeta", "t", "Hz", "W"):      # rho-type: every ghost point is defined

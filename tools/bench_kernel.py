@@ -1,10 +1,10 @@
 """Developer tool: time single hot-path entries on a named configuration with
-the library's hipEvent timers.  Usage: python tools_bench_kernel.py BENCHMARK3 step3d_t [reps]"""
+the library's hipEvent timers.  Usage: python tools/bench_kernel.py BENCHMARK3 step3d_t [reps]"""
 import sys
 import time
 
 import os  # noqa: E402
-_ROOT = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [_ROOT, os.path.join(_ROOT, "tests")]
 import util  # noqa: E402
 from roms_trunk_mgh_amd import hip  # noqa: E402

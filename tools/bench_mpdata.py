@@ -2,7 +2,7 @@
 hipEvent times of pre_step3d and step3d_t, for rocprofv3 --kernel-trace --stats."""
 import os
 import sys
-_ROOT = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [_ROOT, os.path.join(_ROOT, "tests")]
 import util  # noqa: E402
 from roms_trunk_mgh_amd import hip  # noqa: E402

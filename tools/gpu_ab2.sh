@@ -1,5 +1,5 @@
 #!/bin/bash
-# Developer tool (GPU box): like tools_gpu_ab.sh but without the parity tests -- timing and
+# Developer tool (GPU box): like tools/gpu_ab.sh but without the parity tests -- timing and
 # FETCH_SIZE of one entry for each value of an environment variable.
 set -e -o pipefail
 VAR=$1; VALS=$2; ENTRY=$3
@@ -11,9 +11,9 @@ cd "$R"
 for v in $VALS; do
   if [ "$v" = "unset" ]; then unset $VAR; else export $VAR=$v; fi
   echo "=== $VAR=$v"
-  python3 tools_bench_kernel.py BENCHMARK3 $ENTRY 7 | grep -v "state built"
+  python3 tools/bench_kernel.py BENCHMARK3 $ENTRY 7 | grep -v "state built"
   (cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/f_$v" -o ab --output-format csv -- \
-    python3 "$R/tools_bench_kernel.py" BENCHMARK3 calib_stream,$ENTRY 2 > "$OUT/f_$v.log" 2> "$OUT/f_$v.err")
+    python3 "$R/tools/bench_kernel.py" BENCHMARK3 calib_stream,$ENTRY 2 > "$OUT/f_$v.log" 2> "$OUT/f_$v.err")
   python3 - "$OUT/f_$v/ab_counter_collection.csv" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)

@@ -2,7 +2,7 @@
 # Developer tool (run on the GPU box through gpurun): rocprofv3 kernel statistics of
 # bench.py plus the two PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass)
 # over single entries, with a calibration copy of known byte count in the same run.
-# Usage: tools_gpu_profile.sh TAG
+# Usage: tools/gpu_profile.sh TAG
 set -e -o pipefail
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -16,9 +16,9 @@ rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o "$TAG" --output-format csv -
   python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "stats pass done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o "$TAG" --output-format csv -- \
-  python3 "$R/tools_bench_kernel.py" BENCHMARK3 $KERNELS 3 > "$OUT/pmc_fetch.log" 2> "$OUT/pmc_fetch.err"
+  python3 "$R/tools/bench_kernel.py" BENCHMARK3 $KERNELS 3 > "$OUT/pmc_fetch.log" 2> "$OUT/pmc_fetch.err"
 echo "fetch pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o "$TAG" --output-format csv -- \
-  python3 "$R/tools_bench_kernel.py" BENCHMARK3 $KERNELS 3 > "$OUT/pmc_write.log" 2> "$OUT/pmc_write.err"
+  python3 "$R/tools/bench_kernel.py" BENCHMARK3 $KERNELS 3 > "$OUT/pmc_write.log" 2> "$OUT/pmc_write.err"
 echo "write pass done"
 ls -R "$OUT" | head -40

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: condense the two rocprofv3 PMC passes written by tools_gpu_profile.sh
+"""Developer tool: condense the two rocprofv3 PMC passes written by tools/gpu_profile.sh
 (gpurun_out/prof_TAG/pmc_fetch, pmc_write) into profiles/TAG/pmc_summary.csv and copy the
 kernel statistics of the bench pass next to it.  FETCH_SIZE is in KiB and under-counts 8-byte
 per-lane loads by 2 on gfx950 (calibrated by k_calib_stream in the same run: its corrected

@@ -4,7 +4,7 @@ snapshot_begin after step 4 / snapshot_end after step 12."""
 import os
 import sys
 import time
-_ROOT = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [_ROOT]
 from roms_trunk_mgh_amd import ana, hip, main3d  # noqa: E402
 
