@@ -113,8 +113,14 @@ typedef struct roms_params {
   double swfrac_mu1, swfrac_mu2, swfrac_r1;
   /* per-step physics between the hot kernels */
   int    uv_drag;                    /* bottom stress law of set_vbc.F: 1 = UV_LDRAG, 2 = UV_QDRAG */
-  int    pad_physics_;
+  int    mpdata_fast;                /* library switch (no reference counterpart): 1 = the anti-diffusive
+                                      * velocities of mpdata_adiff use refined reciprocals instead of IEEE
+                                      * divisions (results within the 1e-10 relative-RMS bound of the exact
+                                      * kernel, not bit-identical); 0 = exact */
   double blk_ZQ, blk_ZT, blk_ZW;     /* measurement heights of bulk_flux.F (roms_*.in BLK_ZQ/ZT/ZW) */
+  int    masking;                    /* 1 = the application defines MASKING: rmask/umask/vmask/pmask are applied
+                                      * where the reference applies them (e.g. step2d_LF_AM3.h:778, step3d_t.F:603) */
+  int    pad_masking_;
 } roms_params_t;
 
 /* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and

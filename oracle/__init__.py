@@ -33,6 +33,10 @@ def lib():
         so = os.path.join(_DIR, "_build", "liboracle.so")
         if not os.path.exists(so):
             so = build()
+        # ROMS_ORACLE_VARIANT=O3: the -O3 -march=native build, used ONLY by bench.py's cpu_baseline leg
+        # (timing); every parity check runs the -O2 -ffp-contract=off build above
+        if os.environ.get("ROMS_ORACLE_VARIANT") == "O3":
+            so = os.path.join(_DIR, "_build", "liboracle_O3.so")
         _LIB = C.CDLL(so)
         abi.check_abi(_LIB)
         for k in KERNELS:

@@ -148,6 +148,10 @@
 #define lrflx(i,j)    F->lrflx[I2(i,j)]
 #define lhflx(i,j)    F->lhflx[I2(i,j)]
 #define shflx(i,j)    F->shflx[I2(i,j)]
+#define rmask(i,j)    F->rmask[I2(i,j)]
+#define umask(i,j)    F->umask[I2(i,j)]
+#define vmask(i,j)    F->vmask[I2(i,j)]
+#define pmask(i,j)    F->pmask[I2(i,j)]
 
 /* private (automatic) work arrays of the _tile routines */
 #define WS2(i,j)   ((long)((i) - IminS) + (long)((j) - JminS) * nis)   /* (IminS:ImaxS,JminS:JmaxS) */

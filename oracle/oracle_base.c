@@ -83,9 +83,16 @@ void o_exchange3d(const roms_bounds_t *b, int gtype, int nk, double *A)
 void o_zetabc(OARGS, int kout)
 {
   ORACLE_PROLOGUE
-  (void)p; (void)s;
-  if (south_edge) for (int i = Istr; i <= Iend; i++) zeta(i, Jstr - 1, kout) = zeta(i, Jstr, kout);
-  if (north_edge) for (int i = Istr; i <= Iend; i++) zeta(i, Jend + 1, kout) = zeta(i, Jend, kout);
+  (void)s;
+  const int mk = p->masking;           /* MASKING: the boundary value times the mask of the boundary point, zetabc.F:540, :689 */
+  if (south_edge) for (int i = Istr; i <= Iend; i++) {
+    zeta(i, Jstr - 1, kout) = zeta(i, Jstr, kout);
+    if (mk) zeta(i, Jstr - 1, kout) = zeta(i, Jstr - 1, kout) * rmask(i, Jstr - 1);
+  }
+  if (north_edge) for (int i = Istr; i <= Iend; i++) {
+    zeta(i, Jend + 1, kout) = zeta(i, Jend, kout);
+    if (mk) zeta(i, Jend + 1, kout) = zeta(i, Jend + 1, kout) * rmask(i, Jend + 1);
+  }
 }
 
 /* u2dbc_tile, closed S/N -- ROMS/Nonlinear/u2dbc_im.F:51 */
@@ -94,8 +101,15 @@ void o_u2dbc(OARGS, int kout)
   ORACLE_PROLOGUE
   (void)s;
   const int Imin = EWperiodic ? IstrU : Istr, Imax = EWperiodic ? Iend : IendR;
-  if (south_edge) for (int i = Imin; i <= Imax; i++) ubar(i, Jstr - 1, kout) = p->gamma2 * ubar(i, Jstr, kout);
-  if (north_edge) for (int i = Imin; i <= Imax; i++) ubar(i, Jend + 1, kout) = p->gamma2 * ubar(i, Jend, kout);
+  const int mk = p->masking;           /* MASKING, u2dbc_im.F:975, :1133 */
+  if (south_edge) for (int i = Imin; i <= Imax; i++) {
+    ubar(i, Jstr - 1, kout) = p->gamma2 * ubar(i, Jstr, kout);
+    if (mk) ubar(i, Jstr - 1, kout) = ubar(i, Jstr - 1, kout) * umask(i, Jstr - 1);
+  }
+  if (north_edge) for (int i = Imin; i <= Imax; i++) {
+    ubar(i, Jend + 1, kout) = p->gamma2 * ubar(i, Jend, kout);
+    if (mk) ubar(i, Jend + 1, kout) = ubar(i, Jend + 1, kout) * umask(i, Jend + 1);
+  }
 }
 
 /* v2dbc_tile, closed S/N -- ROMS/Nonlinear/v2dbc_im.F:52 */
@@ -113,9 +127,16 @@ void o_u3dbc(OARGS, int nout)
   ORACLE_PROLOGUE
   (void)s;
   const int Imin = EWperiodic ? IstrU : Istr, Imax = EWperiodic ? Iend : IendR;
+  const int mk = p->masking;           /* MASKING, u3dbc_im.F:520, :678 */
   for (int k = 1; k <= N; k++) {
-    if (south_edge) for (int i = Imin; i <= Imax; i++) u(i, Jstr - 1, k, nout) = p->gamma2 * u(i, Jstr, k, nout);
-    if (north_edge) for (int i = Imin; i <= Imax; i++) u(i, Jend + 1, k, nout) = p->gamma2 * u(i, Jend, k, nout);
+    if (south_edge) for (int i = Imin; i <= Imax; i++) {
+      u(i, Jstr - 1, k, nout) = p->gamma2 * u(i, Jstr, k, nout);
+      if (mk) u(i, Jstr - 1, k, nout) = u(i, Jstr - 1, k, nout) * umask(i, Jstr - 1);
+    }
+    if (north_edge) for (int i = Imin; i <= Imax; i++) {
+      u(i, Jend + 1, k, nout) = p->gamma2 * u(i, Jend, k, nout);
+      if (mk) u(i, Jend + 1, k, nout) = u(i, Jend + 1, k, nout) * umask(i, Jend + 1);
+    }
   }
 }
 
@@ -134,10 +155,17 @@ void o_v3dbc(OARGS, int nout)
 void o_t3dbc(OARGS, int nout, int itrc)
 {
   ORACLE_PROLOGUE
-  (void)p; (void)s;
+  (void)s;
+  const int mk = p->masking;           /* MASKING, t3dbc_im.F:483, :617 */
   for (int k = 1; k <= N; k++) {
-    if (south_edge) for (int i = Istr; i <= Iend; i++) t(i, Jstr - 1, k, nout, itrc) = t(i, Jstr, k, nout, itrc);
-    if (north_edge) for (int i = Istr; i <= Iend; i++) t(i, Jend + 1, k, nout, itrc) = t(i, Jend, k, nout, itrc);
+    if (south_edge) for (int i = Istr; i <= Iend; i++) {
+      t(i, Jstr - 1, k, nout, itrc) = t(i, Jstr, k, nout, itrc);
+      if (mk) t(i, Jstr - 1, k, nout, itrc) = t(i, Jstr - 1, k, nout, itrc) * rmask(i, Jstr - 1);
+    }
+    if (north_edge) for (int i = Istr; i <= Iend; i++) {
+      t(i, Jend + 1, k, nout, itrc) = t(i, Jend, k, nout, itrc);
+      if (mk) t(i, Jend + 1, k, nout, itrc) = t(i, Jend + 1, k, nout, itrc) * rmask(i, Jend + 1);
+    }
   }
 }
 

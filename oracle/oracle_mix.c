@@ -35,12 +35,14 @@ static int t3dmix2_geo(OARGS)
         for (int j = Jstr; j <= Jend; j++)
           for (int i = Istr; i <= Iend + 1; i++) {
             cff = 0.5 * (pm(i, j) + pm(i - 1, j));
+            if (p->masking) cff = cff * umask(i, j);                                  /* MASKING, t3dmix2_geo.h:228 */
             dZdx(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i - 1, j, k + 1));
             dTdx(i, j, k2) = cff * (t(i, j, k + 1, nrhs, itrc) - t(i - 1, j, k + 1, nrhs, itrc));
           }
         for (int j = Jstr; j <= Jend + 1; j++)
           for (int i = Istr; i <= Iend; i++) {
             cff = 0.5 * (pn(i, j) + pn(i, j - 1));
+            if (p->masking) cff = cff * vmask(i, j);                                  /* MASKING, t3dmix2_geo.h:260 */
             dZde(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i, j - 1, k + 1));
             dTde(i, j, k2) = cff * (t(i, j, k + 1, nrhs, itrc) - t(i, j - 1, k + 1, nrhs, itrc));
           }
@@ -129,11 +131,13 @@ static int t3dmix2_s(OARGS)
         for (int i = Istr; i <= Iend + 1; i++) {
           cff = 0.25 * (diff2(i, j, itrc) + diff2(i - 1, j, itrc)) * pmon_u(i, j);
           FX(i, j) = cff * (Hz(i, j, k) + Hz(i - 1, j, k)) * (t(i, j, k, nrhs, itrc) - t(i - 1, j, k, nrhs, itrc));
+          if (p->masking) FX(i, j) = FX(i, j) * umask(i, j);                          /* MASKING, t3dmix2_s.h:235 */
         }
       for (int j = Jstr; j <= Jend + 1; j++)
         for (int i = Istr; i <= Iend; i++) {
           cff = 0.25 * (diff2(i, j, itrc) + diff2(i, j - 1, itrc)) * pnom_v(i, j);
           FE(i, j) = cff * (Hz(i, j, k) + Hz(i, j - 1, k)) * (t(i, j, k, nrhs, itrc) - t(i, j - 1, k, nrhs, itrc));
+          if (p->masking) FE(i, j) = FE(i, j) * vmask(i, j);                          /* MASKING, t3dmix2_s.h:275 */
         }
       for (int j = Jstr; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
@@ -182,6 +186,7 @@ int oracle_uv3dmix2(OARGS)
         cff = 0.125 * (Hz(i - 1, j, k) + Hz(i, j, k) + Hz(i - 1, j - 1, k) + Hz(i, j - 1, k)) *
               (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * v(i, j, k, nrhs) - (pn(i - 1, j - 1) + pn(i - 1, j)) * v(i - 1, j, k, nrhs)) +
                pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * u(i, j, k, nrhs) - (pm(i - 1, j - 1) + pm(i, j - 1)) * u(i, j - 1, k, nrhs)));
+        if (p->masking) cff = cff * pmask(i, j);                                      /* MASKING, uv3dmix2_s.h:272 */
         UFe(i, j) = om_p(i, j) * om_p(i, j) * visc2_p(i, j) * cff;
         VFx(i, j) = on_p(i, j) * on_p(i, j) * visc2_p(i, j) * cff;
       }

@@ -80,8 +80,10 @@ int oracle_pre_step3d(OARGS)
             FE(i, j) = Hvom(i, j, k) * 0.5 * (t(i, j - 1, k, nstp, itrc) + t(i, j, k, nstp, itrc));
       } else {
         for (int j = Jstr; j <= Jend; j++)
-          for (int i = Istrm1; i <= Iendp2; i++)
+          for (int i = Istrm1; i <= Iendp2; i++) {
             FX(i, j) = t(i, j, k, nstp, itrc) - t(i - 1, j, k, nstp, itrc);
+            if (p->masking) FX(i, j) = FX(i, j) * umask(i, j);                     /* MASKING, pre_step3d.F:398 */
+          }
         if (!EWperiodic) {
           if (west_edge) for (int j = Jstr; j <= Jend; j++) FX(Istr - 1, j) = FX(Istr, j);
           if (east_edge) for (int j = Jstr; j <= Jend; j++) FX(Iend + 2, j) = FX(Iend + 1, j);
@@ -107,8 +109,10 @@ int oracle_pre_step3d(OARGS)
                          (t(i - 1, j, k, nstp, itrc) + t(i, j, k, nstp, itrc) - cff2 * (grad(i, j) - grad(i - 1, j)));
           }
         for (int j = Jstrm1; j <= Jendp2; j++)
-          for (int i = Istr; i <= Iend; i++)
+          for (int i = Istr; i <= Iend; i++) {
             FE(i, j) = t(i, j, k, nstp, itrc) - t(i, j - 1, k, nstp, itrc);
+            if (p->masking) FE(i, j) = FE(i, j) * vmask(i, j);                     /* MASKING, pre_step3d.F:463 */
+          }
         if (!NSperiodic) {
           if (south_edge) for (int i = Istr; i <= Iend; i++) FE(i, Jstr - 1) = FE(i, Jstr);
           if (north_edge) for (int i = Istr; i <= Iend; i++) FE(i, Jend + 2) = FE(i, Jend + 1);

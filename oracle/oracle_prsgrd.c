@@ -67,7 +67,9 @@ int oracle_prsgrd(OARGS)
     for (int j = Jstr; j <= Jend; j++)
       for (int i = IstrU - 1; i <= Iend + 1; i++) {
         aux(i, j) = z_r(i, j, k) - z_r(i - 1, j, k);
+        if (p->masking) aux(i, j) = aux(i, j) * umask(i, j);                         /* MASKING, prsgrd32.h:300 */
         FC(i, j) = rho(i, j, k) - rho(i - 1, j, k);
+        if (p->masking) FC(i, j) = FC(i, j) * umask(i, j);                           /* :304 */
       }
     for (int j = Jstr; j <= Jend; j++)
       for (int i = IstrU - 1; i <= Iend; i++) {
@@ -96,7 +98,9 @@ int oracle_prsgrd(OARGS)
     for (int j = JstrV - 1; j <= Jend + 1; j++)
       for (int i = Istr; i <= Iend; i++) {
         aux(i, j) = z_r(i, j, k) - z_r(i, j - 1, k);
+        if (p->masking) aux(i, j) = aux(i, j) * vmask(i, j);                         /* MASKING, prsgrd32.h:364 */
         FC(i, j) = rho(i, j, k) - rho(i, j - 1, k);
+        if (p->masking) FC(i, j) = FC(i, j) * vmask(i, j);                           /* :368 */
       }
     for (int j = JstrV - 1; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {

@@ -23,6 +23,7 @@ int oracle_rho_eos(OARGS)
           rho(i, j, k) = R0 - R0 * Tcoef * (t(i, j, k, nrhs, itemp) - T0);
           if (p->salinity) rho(i, j, k) = rho(i, j, k) + R0 * Scoef * (t(i, j, k, nrhs, isalt) - S0);
           rho(i, j, k) = rho(i, j, k) - 1000.0;
+          if (p->masking) rho(i, j, k) = rho(i, j, k) * rmask(i, j);                 /* MASKING, rho_eos.F:717 */
           pden(i, j, k) = rho(i, j, k);
         }
       for (int i = IstrT; i <= IendT; i++) {
@@ -108,6 +109,7 @@ int oracle_rho_eos(OARGS)
         cff = 1.0 / (bulk(i, k) + Tpr10);
         den(i, k) = den1(i, k) * bulk(i, k) * cff;
         den(i, k) = den(i, k) - 1000.0;
+        if (p->masking) den(i, k) = den(i, k) * rmask(i, j);                         /* MASKING, rho_eos.F:356 */
       }
     for (int i = IstrT; i <= IendT; i++) {
       cff1 = den(i, N) * Hz(i, j, N);
@@ -160,6 +162,7 @@ int oracle_rho_eos(OARGS)
       for (int i = IstrT; i <= IendT; i++) {
         rho(i, j, k) = den(i, k);
         pden(i, j, k) = (den1(i, k) - 1000.0);
+        if (p->masking) pden(i, j, k) = pden(i, j, k) * rmask(i, j);                 /* MASKING, rho_eos.F:478 */
       }
   }
   o_exchange3d(b, GT_R, N, F->rho);

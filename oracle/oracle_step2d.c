@@ -113,6 +113,7 @@ int oracle_step2d(OARGS)
       for (int i = IstrU - 1; i <= Iend; i++) {
         rhs_zeta(i, j) = (DUon(i, j) - DUon(i + 1, j)) + (DVom(i, j) - DVom(i, j + 1));
         zeta_new(i, j) = zeta(i, j, kstp) + pm(i, j) * pn(i, j) * cff1 * rhs_zeta(i, j);
+        if (p->masking) zeta_new(i, j) = zeta_new(i, j) * rmask(i, j);      /* MASKING, :778/:804/:835 */
         Dnew(i, j) = zeta_new(i, j) + h(i, j);
         zwrk(i, j) = 0.5 * (zeta(i, j, kstp) + zeta_new(i, j));
         gzeta(i, j) = (fac + rhoS(i, j)) * zwrk(i, j);
@@ -127,6 +128,7 @@ int oracle_step2d(OARGS)
       for (int i = IstrU - 1; i <= Iend; i++) {
         rhs_zeta(i, j) = (DUon(i, j) - DUon(i + 1, j)) + (DVom(i, j) - DVom(i, j + 1));
         zeta_new(i, j) = zeta(i, j, kstp) + pm(i, j) * pn(i, j) * cff1 * rhs_zeta(i, j);
+        if (p->masking) zeta_new(i, j) = zeta_new(i, j) * rmask(i, j);      /* MASKING, :778/:804/:835 */
         Dnew(i, j) = zeta_new(i, j) + h(i, j);
         zwrk(i, j) = cff5 * zeta(i, j, krhs) + cff4 * (zeta(i, j, kstp) + zeta_new(i, j));
         gzeta(i, j) = (fac + rhoS(i, j)) * zwrk(i, j);
@@ -143,6 +145,7 @@ int oracle_step2d(OARGS)
       for (int i = IstrU - 1; i <= Iend; i++) {
         cff = cff1 * ((DUon(i, j) - DUon(i + 1, j)) + (DVom(i, j) - DVom(i, j + 1)));
         zeta_new(i, j) = zeta(i, j, kstp) + pm(i, j) * pn(i, j) * (cff + cff2 * rzeta(i, j, kstp) - cff3 * rzeta(i, j, ptsk));
+        if (p->masking) zeta_new(i, j) = zeta_new(i, j) * rmask(i, j);      /* MASKING, :778/:804/:835 */
         Dnew(i, j) = zeta_new(i, j) + h(i, j);
         zwrk(i, j) = cff5 * zeta_new(i, j) + cff4 * zeta(i, j, krhs);
         gzeta(i, j) = (fac + rhoS(i, j)) * zwrk(i, j);
@@ -296,6 +299,7 @@ int oracle_step2d(OARGS)
         cff = visc2_p(i, j) * Drhs_p(i, j) * 0.5 *
               (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * vbar(i, j, krhs) - (pn(i - 1, j - 1) + pn(i - 1, j)) * vbar(i - 1, j, krhs)) +
                pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * ubar(i, j, krhs) - (pm(i - 1, j - 1) + pm(i, j - 1)) * ubar(i, j - 1, krhs)));
+        if (p->masking) cff = cff * pmask(i, j);                                        /* MASKING, :1433 */
         UFe(i, j) = om_p(i, j) * om_p(i, j) * cff;
         VFx(i, j) = on_p(i, j) * on_p(i, j) * cff;
       }
@@ -377,12 +381,14 @@ int oracle_step2d(OARGS)
         cff = (pm(i, j) + pm(i - 1, j)) * (pn(i, j) + pn(i - 1, j));
         fac = 1.0 / (Dnew(i, j) + Dnew(i - 1, j));
         ubar(i, j, knew) = (ubar(i, j, kstp) * (Dstp(i, j) + Dstp(i - 1, j)) + cff * cff1 * rhs_ubar(i, j)) * fac;
+        if (p->masking) ubar(i, j, knew) = ubar(i, j, knew) * umask(i, j);      /* MASKING, :2120/:2175 */
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
         cff = (pm(i, j) + pm(i, j - 1)) * (pn(i, j) + pn(i, j - 1));
         fac = 1.0 / (Dnew(i, j) + Dnew(i, j - 1));
         vbar(i, j, knew) = (vbar(i, j, kstp) * (Dstp(i, j) + Dstp(i, j - 1)) + cff * cff1 * rhs_vbar(i, j)) * fac;
+        if (p->masking) vbar(i, j, knew) = vbar(i, j, knew) * vmask(i, j);      /* MASKING, :2145/:2194 */
       }
   } else {
     cff1 = 0.5 * dtfast * 5.0 / 12.0;
@@ -394,6 +400,7 @@ int oracle_step2d(OARGS)
         fac = 1.0 / (Dnew(i, j) + Dnew(i - 1, j));
         ubar(i, j, knew) = (ubar(i, j, kstp) * (Dstp(i, j) + Dstp(i - 1, j)) +
                             cff * (cff1 * rhs_ubar(i, j) + cff2 * rubar(i, j, kstp) - cff3 * rubar(i, j, ptsk))) * fac;
+        if (p->masking) ubar(i, j, knew) = ubar(i, j, knew) * umask(i, j);      /* MASKING, :2120/:2175 */
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -401,6 +408,7 @@ int oracle_step2d(OARGS)
         fac = 1.0 / (Dnew(i, j) + Dnew(i, j - 1));
         vbar(i, j, knew) = (vbar(i, j, kstp) * (Dstp(i, j) + Dstp(i, j - 1)) +
                             cff * (cff1 * rhs_vbar(i, j) + cff2 * rvbar(i, j, kstp) - cff3 * rvbar(i, j, ptsk))) * fac;
+        if (p->masking) vbar(i, j, knew) = vbar(i, j, knew) * vmask(i, j);      /* MASKING, :2145/:2194 */
       }
   }
   if (PREDICTOR) {

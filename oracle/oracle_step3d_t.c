@@ -109,6 +109,7 @@ int oracle_step3d_t(OARGS)
             const double cff1 = cff * (oHz(i - 1, j, k) + oHz(i, j, k));
             GX(i) = t(i, j, k, 3, itrc) - t(i - 1, j, k, 3, itrc);
             KX(i) = 1.0 - fabs(Huon(i, j, k) * cff1);
+            if (p->masking) { GX(i) = GX(i) * umask(i, j); KX(i) = KX(i) * umask(i, j); }   /* MASKING, :448 */
           }
           if (!EWperiodic) {
             if (west_edge && Huon(Istr, j, k) >= 0.0) { GX(Istr - 1) = 0.0; KX(Istr - 1) = 0.0; }
@@ -126,6 +127,7 @@ int oracle_step3d_t(OARGS)
               const double b1 = -cc1 * KX(i) + cc2 + cc3 * OX(i);
               const double betaL = a1 + b1 * rL;
               cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rL * rkaL), betaL)) * GX(i) * KX(i);
+              if (p->masking) cff = cff * rmask(MAX(i - 2, 0), j);                           /* MASKING, :487 */
               sw_xi = t(i - 1, j, k, 3, itrc) + cff;
             } else {
               double rR, rkaR;
@@ -135,6 +137,7 @@ int oracle_step3d_t(OARGS)
               const double b1 = -cc1 * KX(i) + cc2 + cc3 * OX(i);
               const double betaR = a1 + b1 * rR;
               cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rR * rkaR), betaR)) * GX(i) * KX(i);
+              if (p->masking) cff = cff * rmask(MIN(i + 1, Lm + 1), j);                      /* MASKING, :506 */
               sw_xi = t(i, j, k, 3, itrc) - cff;
             }
             FX(i, j) = sw_xi * Huon(i, j, k);
@@ -152,6 +155,7 @@ int oracle_step3d_t(OARGS)
             const double cff1 = cff * (oHz(i, j, k) + oHz(i, j - 1, k));
             GE(j) = t(i, j, k, 3, itrc) - t(i, j - 1, k, 3, itrc);
             KE(j) = 1.0 - fabs(Hvom(i, j, k) * cff1);
+            if (p->masking) { GE(j) = GE(j) * vmask(i, j); KE(j) = KE(j) * vmask(i, j); }   /* MASKING, :523 */
           }
           if (!NSperiodic) {
             if (south_edge && Hvom(i, Jstr, k) >= 0.0) { GE(Jstr - 1) = 0.0; KE(Jstr - 1) = 0.0; }
@@ -169,6 +173,7 @@ int oracle_step3d_t(OARGS)
               const double b1 = -cc1 * KE(j) + cc2 + cc3 * OE(j);
               const double betaD = a1 + b1 * rD;
               cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rD * rkaD), betaD)) * GE(j) * KE(j);
+              if (p->masking) cff = cff * rmask(i, MAX(j - 2, 0));                           /* MASKING, :562 */
               sw_eta = t(i, j - 1, k, 3, itrc) + cff;
             } else {
               double rU, rkaU;
@@ -178,6 +183,7 @@ int oracle_step3d_t(OARGS)
               const double b1 = -cc1 * KE(j) + cc2 + cc3 * OE(j);
               const double betaU = a1 + b1 * rU;
               cff = 0.5 * MAX(0.0, MIN(MIN(2.0, 2.0 * rU * rkaU), betaU)) * GE(j) * KE(j);
+              if (p->masking) cff = cff * rmask(i, MIN(j + 1, Mm + 1));                      /* MASKING, :581 */
               sw_eta = t(i, j, k, 3, itrc) - cff;
             }
             FE(i, j) = sw_eta * Hvom(i, j, k);
@@ -197,8 +203,10 @@ int oracle_step3d_t(OARGS)
       } else {
         /* A4 / C4 / SU3 / U3 -- step3d_t.F:596-828 */
         for (int j = Jstr; j <= Jend; j++)
-          for (int i = Istrm1; i <= Iendp2; i++)
+          for (int i = Istrm1; i <= Iendp2; i++) {
             FX(i, j) = t(i, j, k, 3, itrc) - t(i - 1, j, k, 3, itrc);
+            if (p->masking) FX(i, j) = FX(i, j) * umask(i, j);                     /* MASKING, step3d_t.F:603 */
+          }
         if (!EWperiodic) {
           if (west_edge) for (int j = Jstr; j <= Jend; j++) FX(Istr - 1, j) = FX(Istr, j);
           if (east_edge) for (int j = Jstr; j <= Jend; j++) FX(Iend + 2, j) = FX(Iend + 1, j);
@@ -229,8 +237,10 @@ int oracle_step3d_t(OARGS)
             }
           }
         for (int j = Jstrm1; j <= Jendp2; j++)
-          for (int i = Istr; i <= Iend; i++)
+          for (int i = Istr; i <= Iend; i++) {
             FE(i, j) = t(i, j, k, 3, itrc) - t(i, j - 1, k, 3, itrc);
+            if (p->masking) FE(i, j) = FE(i, j) * vmask(i, j);                     /* MASKING, step3d_t.F:667 */
+          }
         if (!NSperiodic) {
           if (south_edge) for (int i = Istr; i <= Iend; i++) FE(i, Jstr - 1) = FE(i, Jstr);
           if (north_edge) for (int i = Istr; i <= Iend; i++) FE(i, Jend + 2) = FE(i, Jend + 1);
@@ -550,6 +560,10 @@ int oracle_step3d_t(OARGS)
   /* lateral BCs + periodic wrap, step3d_t.F:1564-1626 */
   for (int itrc = 1; itrc <= NT; itrc++) {
     o_t3dbc(b, p, s, F, nnew, itrc);
+    if (p->masking)                                                       /* apply land/sea mask, step3d_t.F:1586-1596 */
+      for (int k = 1; k <= N; k++)
+        for (int j = JstrR; j <= JendR; j++)
+          for (int i = IstrR; i <= IendR; i++) t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) * rmask(i, j);
     o_exchange3d(b, GT_R, N, &t(LBi, LBj, 1, nnew, itrc));
   }
   free(FX_); free(FE_); free(curv_); free(grad_); free(oHz_);

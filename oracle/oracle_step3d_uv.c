@@ -81,7 +81,10 @@ int oracle_step3d_uv(OARGS)
       DC(i, 0) = (DC(i, 0) * on_u(i, j) - DU_avg1(i, j)) * cff1;
     }
     for (int k = 1; k <= N; k++)
-      for (int i = IstrU; i <= Iend; i++) u(i, j, k, nnew) = u(i, j, k, nnew) - DC(i, 0);
+      for (int i = IstrU; i <= Iend; i++) {
+        u(i, j, k, nnew) = u(i, j, k, nnew) - DC(i, 0);
+        if (p->masking) u(i, j, k, nnew) = u(i, j, k, nnew) * umask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+      }
 
     /* ---- v, step3d_uv.F:620-860 ---- */
     if (j >= JstrV) {
@@ -137,7 +140,10 @@ int oracle_step3d_uv(OARGS)
         DC(i, 0) = (DC(i, 0) * om_v(i, j) - DV_avg1(i, j)) * cff1;
       }
       for (int k = 1; k <= N; k++)
-        for (int i = Istr; i <= Iend; i++) v(i, j, k, nnew) = v(i, j, k, nnew) - DC(i, 0);
+        for (int i = Istr; i <= Iend; i++) {
+          v(i, j, k, nnew) = v(i, j, k, nnew) - DC(i, 0);
+          if (p->masking) v(i, j, k, nnew) = v(i, j, k, nnew) * vmask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+        }
     }
   }
 
@@ -168,10 +174,16 @@ int oracle_step3d_uv(OARGS)
     if (!NSperiodic) {
       if (j == 0)
         for (int k = 1; k <= N; k++)
-          for (int i = IstrU; i <= Iend; i++) u(i, j, k, nnew) = u(i, j, k, nnew) - CF(i, 0);
+          for (int i = IstrU; i <= Iend; i++) {
+            u(i, j, k, nnew) = u(i, j, k, nnew) - CF(i, 0);
+            if (p->masking) u(i, j, k, nnew) = u(i, j, k, nnew) * umask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+          }
       if (j == Mm + 1)
         for (int k = 1; k <= N; k++)
-          for (int i = IstrU; i <= Iend; i++) u(i, j, k, nnew) = u(i, j, k, nnew) - CF(i, 0);
+          for (int i = IstrU; i <= Iend; i++) {
+            u(i, j, k, nnew) = u(i, j, k, nnew) - CF(i, 0);
+            if (p->masking) u(i, j, k, nnew) = u(i, j, k, nnew) * umask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+          }
     }
     for (int k = N; k >= 1; k--)
       for (int i = IstrP; i <= IendT; i++) {
@@ -204,10 +216,16 @@ int oracle_step3d_uv(OARGS)
       if (!NSperiodic) {
         if (j == 1)
           for (int k = 1; k <= N; k++)
-            for (int i = Istr; i <= Iend; i++) v(i, j, k, nnew) = v(i, j, k, nnew) - CF(i, 0);
+            for (int i = Istr; i <= Iend; i++) {
+              v(i, j, k, nnew) = v(i, j, k, nnew) - CF(i, 0);
+              if (p->masking) v(i, j, k, nnew) = v(i, j, k, nnew) * vmask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+            }
         if (j == Mm + 1)
           for (int k = 1; k <= N; k++)
-            for (int i = Istr; i <= Iend; i++) v(i, j, k, nnew) = v(i, j, k, nnew) - CF(i, 0);
+            for (int i = Istr; i <= Iend; i++) {
+              v(i, j, k, nnew) = v(i, j, k, nnew) - CF(i, 0);
+              if (p->masking) v(i, j, k, nnew) = v(i, j, k, nnew) * vmask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+            }
       }
       for (int k = N; k >= 1; k--)
         for (int i = IstrT; i <= IendT; i++) {

@@ -45,8 +45,9 @@ MODULE ref_wrap_types
     INTEGER(c_int) :: splines_vdiff, splines_vvisc
     REAL(c_double) :: Akt_bak(16), Akv_bak
     REAL(c_double) :: swfrac_mu1, swfrac_mu2, swfrac_r1
-    INTEGER(c_int) :: uv_drag, pad_physics
+    INTEGER(c_int) :: uv_drag, mpdata_fast
     REAL(c_double) :: blk_ZQ, blk_ZT, blk_ZW
+    INTEGER(c_int) :: masking, pad_masking
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -63,6 +64,7 @@ MODULE ref_wrap_types
     TYPE(c_ptr) :: rdrag2, stflux, btflux, Uwind, Vwind, Tair, Pair, Hair, rain, cloud
     TYPE(c_ptr) :: lrflx, lhflx, shflx, evap, hsbl, rdrag
     TYPE(c_ptr) :: wvel, lonr, latr
+    TYPE(c_ptr) :: rmask, umask, vmask, pmask
   END TYPE fields_t
   LOGICAL, SAVE :: have_boundary = .FALSE.      ! allocate_boundary is done once per process
 END MODULE ref_wrap_types

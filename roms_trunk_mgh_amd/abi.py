@@ -93,8 +93,9 @@ class Params(C.Structure):
         ("splines_vdiff", C.c_int), ("splines_vvisc", C.c_int),
         ("Akt_bak", C.c_double * ROMS_MAXNT), ("Akv_bak", C.c_double),
         ("swfrac_mu1", C.c_double), ("swfrac_mu2", C.c_double), ("swfrac_r1", C.c_double),
-        ("uv_drag", C.c_int), ("pad_physics_", C.c_int),
+        ("uv_drag", C.c_int), ("mpdata_fast", C.c_int),
         ("blk_ZQ", C.c_double), ("blk_ZT", C.c_double), ("blk_ZW", C.c_double),
+        ("masking", C.c_int), ("pad_masking_", C.c_int),
     ]
 
 

@@ -305,6 +305,42 @@ def _grid_global(cfg, b, st):
     A["diff2"][:] = cfg["tnu2"]
 
 
+def set_masks(st, rmask):
+    """Land/sea masks of one tile from the rho-point mask (1 = water): umask, vmask as ana_mask.h:226-236,
+    pmask with the slipperiness rule of metrics.F:535-596 (all four water or one land -> 1, a straight coast,
+    two land cells on one side -> 2 = no-slip, else 0).  Arrays cover the allocated tile; `rmask` must be a
+    function of the global indices so that every tiling sees the same coast."""
+    A = st.arr
+    A["rmask"][:] = rmask
+    s, m = slice(1, None), slice(0, -1)
+    A["umask"][:] = 0.0
+    A["vmask"][:] = 0.0
+    A["pmask"][:] = 0.0
+    A["umask"][s, :] = rmask[m, :] * rmask[s, :]
+    A["vmask"][:, s] = rmask[:, m] * rmask[:, s]
+    w = rmask > 0.5
+    a, b_, c, d = w[m, s], w[s, s], w[m, m], w[s, m]          # (i-1,j) (i,j) (i-1,j-1) (i,j-1)
+    nland = (~a).astype(int) + (~b_).astype(int) + (~c).astype(int) + (~d).astype(int)
+    straight = (a & ~b_ & c & ~d) | (~a & b_ & ~c & d) | (a & b_ & ~c & ~d) | (~a & ~b_ & c & d)
+    A["pmask"][s, s] = np.where(nland <= 1, 1.0, np.where((nland == 2) & straight, 2.0, 0.0))
+    st.p.masking = 1
+
+
+def island_mask(cfg, b):
+    """A test coast that is the same for every tiling: an island (an ellipse plus a one-cell spur) east of the
+    middle of the domain and a headland attached to the southern wall; at least three water cells everywhere else."""
+    Lm, Mm = cfg["Lm"], cfg["Mm"]
+    ii = np.arange(b.LBi, b.UBi + 1, dtype=np.float64)[:, None]
+    jj = np.arange(b.LBj, b.UBj + 1, dtype=np.float64)[None, :]
+    iw = np.mod(ii - 1.0, Lm) + 1.0                            # periodic image of the ghost columns
+    ic, jc = 0.62 * Lm, 0.55 * Mm
+    ri, rj = max(3.0, 0.09 * Lm), max(3.0, 0.12 * Mm)
+    land = ((iw - ic) / ri) ** 2 + ((jj - jc) / rj) ** 2 <= 1.0
+    land |= (np.abs(iw - np.floor(ic)) < 0.5) & (jj > jc) & (jj <= jc + rj + 2.0)            # spur, one cell wide
+    land |= (np.abs(iw - 0.25 * Lm) <= max(2.0, 0.04 * Lm)) & (jj <= max(3.0, 0.15 * Mm))   # headland on the wall
+    return np.where(land, 0.0, 1.0) * np.ones((b.UBi - b.LBi + 1, b.UBj - b.LBj + 1))
+
+
 def z_levels(st, zeta2d):
     """set_depth.F:82-300, Vtransform == 2 (numpy restatement used for IC only)."""
     b, p = st.b, st.p
@@ -325,7 +361,7 @@ def z_levels(st, zeta2d):
 
 
 def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
-              perturb=0.0, seed=0):
+              perturb=0.0, seed=0, mask=None):
     """Build bounds, parameters and an initialised TileState for one tile of a
     named configuration.  `perturb` adds a smooth 2-D (i- and j-dependent)
     perturbation to the initial temperature and free surface so that
@@ -427,4 +463,15 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
         A["rain"][:] = 1.0e-5
         A["cloud"][:] = 0.4
     st.z_r0, st.z_w0 = z_r, z_w
+    # land/sea masks: all water unless asked for (MASKING applications); mask = "island" -> island_mask()
+    for name in ("rmask", "umask", "vmask", "pmask"):
+        A[name][:] = 1.0
+    p.masking = 0
+    if mask == "island":
+        set_masks(st, island_mask(cfg, b))
+        # masked initial state, as the reference's ini_fields / ana_initial leave it
+        A["zeta"][:] *= A["rmask"][:, :, None]
+        A["Zt_avg1"][:] *= A["rmask"]
+    elif mask is not None:
+        raise ValueError(f"unknown mask {mask!r}")
     return st

@@ -224,7 +224,8 @@ extern "C" int roms_hip_init(int rank, int ntileI, int ntileJ, int device_id, co
 extern "C" int roms_hip_finalize(void)
 {
   if (!g_ctx.inited) return 0;
-  hipStreamSynchronize(g_ctx.stream);
+  (void)hipStreamSynchronize(g_ctx.stream);
+  step2d_graphs_release();
   snapshot_release();
   halo_finalize();
   diag_release();
@@ -250,6 +251,7 @@ extern "C" int roms_hip_set_bounds(const roms_bounds_t *b)
   if (b->N > ROMS_MAXN || b->NT > ROMS_MAXNT) return roms_fail("roms_hip_set_bounds", "N or NT too large");
   if (b->ntileI != g_ctx.ntileI || b->ntileJ != g_ctx.ntileJ)
     return roms_fail("roms_hip_set_bounds", "tiling differs from roms_hip_init");
+  step2d_graphs_release();
   g_ctx.b = *b;
   g_ctx.hostc.b = *b;
   g_ctx.have_bounds = true;
@@ -282,6 +284,7 @@ extern "C" int roms_hip_set_params(const roms_params_t *p)
 {
   if (!g_ctx.inited) return roms_fail("roms_hip_set_params", "library not initialised");
   if (2 * p->ndtfast > ROMS_MAXFAST) return roms_fail("roms_hip_set_params", "ndtfast too large");
+  step2d_graphs_release();
   g_ctx.p = *p;
   g_ctx.hostc.p = *p;
   g_ctx.have_params = true;
@@ -309,6 +312,7 @@ extern "C" int roms_hip_register_field(int id, double *host_ptr, long n_doubles)
     snprintf(msg, sizeof msg, "field %s: size %ld does not match bounds (%ld)", k_field_name[id], n_doubles, want);
     return roms_fail("roms_hip_register_field", msg);
   }
+  step2d_graphs_release();
   snapshot_forget(id);          // staging / page-lock of a previous registration (other size or host array)
   guarded_free(&g_ctx.dev[id], &g_ctx.dev_base[id]);
   {

@@ -21,9 +21,12 @@ int check_lbc()
 // Closed S/N walls.  mode: 0 zero-gradient rho-type (zetabc.F:48, t3dbc_im.F:50,
 // bc_3d.F:588), 1 tangential u (gamma2 slip; u2dbc_im.F:51, u3dbc_im.F:50),
 // 2 normal v = 0 (v2dbc_im.F:52, v3dbc_im.F:50).  A points at the (i,j,k=first)
-// plane of the wanted time level; nk planes are processed.
+// plane of the wanted time level; nk planes are processed.  masked (MASKING applications): the boundary
+// value is multiplied by the land/sea mask of the boundary point -- rmask for zeta and tracers
+// (zetabc.F:540, t3dbc_im.F:483), umask for the tangential velocity (u2dbc_im.F:975, u3dbc_im.F:520);
+// bc_w3d_tile has no mask.
 // ---------------------------------------------------------------------------
-__global__ void k_wall_bc(const RomsDev *__restrict__ c, double *__restrict__ A, int nk, int mode)
+__global__ void k_wall_bc(const RomsDev *__restrict__ c, double *__restrict__ A, int nk, int mode, int masked)
 {
   DEV_PROLOGUE(c)
   const int k = blockIdx.y;
@@ -35,25 +38,29 @@ __global__ void k_wall_bc(const RomsDev *__restrict__ c, double *__restrict__ A,
   if (i > i1) return;
   double *P = A + (long)k * nij;
   const double g2 = c->p.gamma2;
+  const double *M = mode == 0 ? c->F.rmask : c->F.umask;
   if (b.south_edge) {
-    if (mode == 0) P[I2(i, b.Jstr - 1)] = P[I2(i, b.Jstr)];
-    else if (mode == 1) P[I2(i, b.Jstr - 1)] = g2 * P[I2(i, b.Jstr)];
+    const long q = I2(i, b.Jstr - 1);
+    if (mode == 0) { double x = P[I2(i, b.Jstr)]; if (masked) x = x * M[q]; P[q] = x; }
+    else if (mode == 1) { double x = g2 * P[I2(i, b.Jstr)]; if (masked) x = x * M[q]; P[q] = x; }
     else P[I2(i, b.Jstr)] = 0.0;
   }
   if (b.north_edge) {
-    if (mode == 0) P[I2(i, b.Jend + 1)] = P[I2(i, b.Jend)];
-    else if (mode == 1) P[I2(i, b.Jend + 1)] = g2 * P[I2(i, b.Jend)];
-    else P[I2(i, b.Jend + 1)] = 0.0;
+    const long q = I2(i, b.Jend + 1);
+    if (mode == 0) { double x = P[I2(i, b.Jend)]; if (masked) x = x * M[q]; P[q] = x; }
+    else if (mode == 1) { double x = g2 * P[I2(i, b.Jend)]; if (masked) x = x * M[q]; P[q] = x; }
+    else P[q] = 0.0;
   }
 }
 
-static int wall_bc(double *A, int nk, int mode)
+static int wall_bc(double *A, int nk, int mode, bool maskable = true)
 {
   const roms_bounds_t &b = g_ctx.b;
   if (!b.south_edge && !b.north_edge) return 0;
   const int nx = b.Iend - b.Istr + 2;
   dim3 grid((nx + 255) / 256, nk);
-  hipLaunchKernelGGL(k_wall_bc, grid, dim3(256), 0, g_ctx.stream, g_ctx.devc, A, nk, mode);
+  hipLaunchKernelGGL(k_wall_bc, grid, dim3(256), 0, g_ctx.stream, g_ctx.devc, A, nk, mode,
+                     (int)(maskable && g_ctx.p.masking));
   KERNEL_CHECK("k_wall_bc");
   return 0;
 }
@@ -76,7 +83,7 @@ int bc_t3d(int nout, int itrc)
 }
 int bc_w3d(double *A)
 {
-  int rc = wall_bc(A, g_ctx.b.N + 1, 0);
+  int rc = wall_bc(A, g_ctx.b.N + 1, 0, false);
   if (rc) return rc;
   return halo_exchange3d(GT_R, g_ctx.b.N + 1, A);
 }

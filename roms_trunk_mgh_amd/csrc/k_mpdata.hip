@@ -100,9 +100,30 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
   }
 }
 
+// Quotient n/d.  Exact variant: the IEEE division of the reference (bit-identical results).  FAST variant
+// (roms_params_t.mpdata_fast): n times a reciprocal from v_rcp_f64 refined by two Newton steps (explicit FMAs,
+// within ~1 ulp of 1/d) -- one reciprocal per distinct denominator, the compiler merges the three quotients of
+// a face that share the tracer sum.  The IEEE division costs ~30 VALU instructions on gfx950, the refined
+// reciprocal 5, and this kernel evaluates 49 quotients per cell; validated against the oracle at the north-star
+// bound (1e-10 relative RMS after 100 steps, tests/test_gpu_mpdata.py).
+template <bool FAST>
+__device__ __forceinline__ double mp_div(double n, double d)
+{
+  if constexpr (FAST) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return n * r;
+  } else {
+    return n / d;
+  }
+}
+#define DV(n, d) mp_div<FAST>((n), (d))
+
 // ------------------------------------------------- K2: Ua, Va, Wa (raw) ----
 // vertical-gradient factor C and mean vertical Courant number Wm of a face between
 // column p (offset 0) and column q (offset dq), mpdata_adiff.F:262-310 / :456-504
+template <bool FAST>
 __device__ __forceinline__ void face_CW(const gcd_t Ta, const gcd_t z_r, const gcd_t odzA, const gcd_t Wv, const gcd_t pm,
                                         const gcd_t pn, long a2, long a, long dq, long nij, int k, int N,
                                         double dt, double &C, double &Wm)
@@ -112,20 +133,20 @@ __device__ __forceinline__ void face_CW(const gcd_t Ta, const gcd_t z_r, const g
   auto odz = [&](long x) { return odzA[x]; };                             // odz at level of x
   const long w = a + nij, wq = aq + nij;      // W(.,.,k) of a K_3DW array = rho index + nij
   if (k == 1) {
-    C = 0.25 * ((Ta[a + nij] - Ta[a]) * odz(a) + (Ta[aq + nij] - Ta[aq]) * odz(aq)) *
-        (z_r[a + nij] - z_r[a] + z_r[aq + nij] - z_r[aq]) / (Ta[aq] + Ta[a] + EPS_MP);
+    C = DV(0.25 * ((Ta[a + nij] - Ta[a]) * odz(a) + (Ta[aq + nij] - Ta[aq]) * odz(aq)) *
+               (z_r[a + nij] - z_r[a] + z_r[aq + nij] - z_r[aq]), Ta[aq] + Ta[a] + EPS_MP);
     Wm = 0.25 * dt * (Wv[wq] * odz(aq) * pm[a2q] * pn[a2q] + Wv[w] * odz(a) * pm[a2] * pn[a2]);
   } else if (k < N) {
-    C = 0.0625 *
-        ((Ta[a + nij] - Ta[a]) * odz(a) + (Ta[a] - Ta[a - nij]) * odz(a - nij) +
-         (Ta[aq + nij] - Ta[aq]) * odz(aq) + (Ta[aq] - Ta[aq - nij]) * odz(aq - nij)) *
-        (z_r[a + nij] - z_r[a - nij] + z_r[aq + nij] - z_r[aq - nij]) / (Ta[aq] + Ta[a] + EPS_MP);
+    C = DV(0.0625 *
+               ((Ta[a + nij] - Ta[a]) * odz(a) + (Ta[a] - Ta[a - nij]) * odz(a - nij) +
+                (Ta[aq + nij] - Ta[aq]) * odz(aq) + (Ta[aq] - Ta[aq - nij]) * odz(aq - nij)) *
+               (z_r[a + nij] - z_r[a - nij] + z_r[aq + nij] - z_r[aq - nij]), Ta[aq] + Ta[a] + EPS_MP);
     Wm = 0.25 * dt *
          ((Wv[wq - nij] * odz(aq - nij) + Wv[wq] * odz(aq)) * pm[a2q] * pn[a2q] +
           (Wv[w] * odz(a) + Wv[w - nij] * odz(a - nij)) * pm[a2] * pn[a2]);
   } else {
-    C = 0.25 * ((Ta[a] - Ta[a - nij]) * odz(a - nij) + (Ta[aq] - Ta[aq - nij]) * odz(aq - nij)) *
-        (z_r[a] - z_r[a - nij] + z_r[aq] - z_r[aq - nij]) / (Ta[aq] + Ta[a] + EPS_MP);
+    C = DV(0.25 * ((Ta[a] - Ta[a - nij]) * odz(a - nij) + (Ta[aq] - Ta[aq - nij]) * odz(aq - nij)) *
+               (z_r[a] - z_r[a - nij] + z_r[aq] - z_r[aq - nij]), Ta[aq] + Ta[a] + EPS_MP);
     Wm = 0.25 * dt * (Wv[wq - nij] * odz(aq - nij) * pm[a2q] * pn[a2q] + Wv[w - nij] * odz(a - nij) * pm[a2] * pn[a2]);
   }
 }
@@ -133,6 +154,7 @@ __device__ __forceinline__ void face_CW(const gcd_t Ta, const gcd_t z_r, const g
 // One launch for the three faces (they share the Ta, Huon, Hvom, oHz loads): 208 VGPRs, two waves per SIMD.
 // The kernel is FP64-issue bound (per cell and level ~1800 VALU instructions, 49 divisions among them); one
 // launch per face raises the occupancy to 3-4 waves but repeats the shared loads and was 20 % slower.
+template <bool FAST>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
 {
@@ -163,13 +185,13 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
       double ua = 0.0;
       if (!((Tw <= 0.0) || (T0 <= 0.0) || (fabs(Tw - T0) <= EPS2_MP))) {
         double Ck, Wk;
-        face_CW(Ta, z_r, odzA, Wv, pm, pn, a2, a, -1, nij, k, N, dt, Ck, Wk);
-        const double A = (T0 - Tw) / (T0 + Tw + EPS_MP);
+        face_CW<FAST>(Ta, z_r, odzA, Wv, pm, pn, a2, a, -1, nij, k, N, dt, Ck, Wk);
+        const double A = DV(T0 - Tw, T0 + Tw + EPS_MP);
         double B = 0.03125 *
                    ((Ta[a + ni] - T0) * (pn[a2] + pn[a2 + ni]) + (T0 - Ta[a - ni]) * (pn[a2 - ni] + pn[a2]) +
                     (Ta[a - 1 + ni] - Tw) * (pn[a2 - 1] + pn[a2 - 1 + ni]) +
                     (Tw - Ta[a - 1 - ni]) * (pn[a2 - 1 - ni] + pn[a2 - 1]));
-        B = B * (on_v[a2] + on_v[a2 + ni] + on_v[a2 - 1] + on_v[a2 - 1 + ni]) / (Tw + T0 + EPS_MP);
+        B = DV(B * (on_v[a2] + on_v[a2 + ni] + on_v[a2 - 1] + on_v[a2 - 1 + ni]), Tw + T0 + EPS_MP);
         const double Um = 0.125 * Huon[a] * dt * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a - 1) + oHz(a));
         const double Vm = 0.03125 * dt *
                           (Hvom[a - 1] * (pm[a2 - 1] + pm[a2 - 1 - ni]) * (pn[a2 - 1] + pn[a2 - 1 - ni]) *
@@ -183,17 +205,17 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
         const double AA = A * A, BB = B * B, CC = Ck * Ck, AB = A * B, AC = A * Ck;
         const double XX = X * X, YY = Y * Y, ZZ = Z * Z, XY = X * Y, XZ = X * Z;
-        const double sig_alfa = 1.0 / (1.0 - fabs(A) + EPS_MP);
-        const double sig_beta = -A / ((1.0 - fabs(A)) * (1.0 - AA) + EPS_MP);
-        const double sig_gama = 2.0 * fabs(AA * A) / ((1.0 - fabs(A)) * (1.0 - AA) * (1.0 - fabs(AA * A)) + EPS_MP);
-        const double sig_a = -B / ((1.0 - fabs(A)) * (1.0 - fabs(AB)) + EPS_MP);
-        const double sig_b = AB / ((1.0 - fabs(A)) * (1.0 - AA * fabs(B)) + EPS_MP) *
-                             (fabs(B) / (1.0 - fabs(AB) + EPS_MP) + 2.0 * A / (1.0 - AA + EPS_MP));
-        const double sig_c = fabs(A) * BB / ((1.0 - fabs(A)) * (1.0 - BB * fabs(A)) * (1.0 - fabs(AB)) + EPS_MP);
-        const double sig_d = -Ck / ((1.0 - fabs(A)) * (1.0 - fabs(AC)) + EPS_MP);
-        const double sig_e = AC / ((1.0 - fabs(A)) * (1.0 - AA * fabs(Ck)) + EPS_MP) *
-                             (fabs(Ck) / (1.0 - fabs(AC) + EPS_MP) + 2.0 * A / (1.0 - AA + EPS_MP));
-        const double sig_f = fabs(A) * CC / ((1.0 - fabs(A)) * (1.0 - CC * fabs(A)) * (1.0 - fabs(AC)) + EPS_MP);
+        const double sig_alfa = DV(1.0, 1.0 - fabs(A) + EPS_MP);
+        const double sig_beta = DV(-A, (1.0 - fabs(A)) * (1.0 - AA) + EPS_MP);
+        const double sig_gama = DV(2.0 * fabs(AA * A), (1.0 - fabs(A)) * (1.0 - AA) * (1.0 - fabs(AA * A)) + EPS_MP);
+        const double sig_a = DV(-B, (1.0 - fabs(A)) * (1.0 - fabs(AB)) + EPS_MP);
+        const double sig_b = DV(AB, (1.0 - fabs(A)) * (1.0 - AA * fabs(B)) + EPS_MP) *
+                             (DV(fabs(B), 1.0 - fabs(AB) + EPS_MP) + DV(2.0 * A, 1.0 - AA + EPS_MP));
+        const double sig_c = DV(fabs(A) * BB, (1.0 - fabs(A)) * (1.0 - BB * fabs(A)) * (1.0 - fabs(AB)) + EPS_MP);
+        const double sig_d = DV(-Ck, (1.0 - fabs(A)) * (1.0 - fabs(AC)) + EPS_MP);
+        const double sig_e = DV(AC, (1.0 - fabs(A)) * (1.0 - AA * fabs(Ck)) + EPS_MP) *
+                             (DV(fabs(Ck), 1.0 - fabs(AC) + EPS_MP) + DV(2.0 * A, 1.0 - AA + EPS_MP));
+        const double sig_f = DV(fabs(A) * CC, (1.0 - fabs(A)) * (1.0 - CC * fabs(A)) * (1.0 - fabs(AC)) + EPS_MP);
         const double u0 = sig_alfa * X + sig_beta * XX + sig_gama * XX * X + sig_a * XY + sig_b * XX * Y +
                           sig_c * X * YY + sig_d * XZ + sig_e * XX * Z + sig_f * X * ZZ;
         ua = fmin(fabs(u0), 1.0 * fabs(Um)) * copysign(1.0, u0);
@@ -206,13 +228,13 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
       double va = 0.0;
       if (!v_wall_n && !((Ts <= 0.0) || (T0 <= 0.0) || (fabs(Ts - T0) <= EPS2_MP))) {
         double Ck, Wk;
-        face_CW(Ta, z_r, odzA, Wv, pm, pn, a2, a, -ni, nij, k, N, dt, Ck, Wk);
+        face_CW<FAST>(Ta, z_r, odzA, Wv, pm, pn, a2, a, -ni, nij, k, N, dt, Ck, Wk);
         double A = 0.03125 *
                    ((Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]) + (T0 - Ta[a - 1]) * (pm[a2 - 1] + pm[a2]) +
                     (Ta[a + 1 - ni] - Ts) * (pm[a2 + 1 - ni] + pm[a2 - ni]) +
                     (Ts - Ta[a - 1 - ni]) * (pm[a2 - 1 - ni] + pm[a2 - ni]));
-        A = A * (om_u[a2] + om_u[a2 + 1] + om_u[a2 - ni] + om_u[a2 + 1 - ni]) / (Ts + T0 + EPS_MP);
-        const double B = (T0 - Ts) / (T0 + Ts + EPS_MP);
+        A = DV(A * (om_u[a2] + om_u[a2 + 1] + om_u[a2 - ni] + om_u[a2 + 1 - ni]), Ts + T0 + EPS_MP);
+        const double B = DV(T0 - Ts, T0 + Ts + EPS_MP);
         const double Um = 0.03125 * dt *
                           (Huon[a + 1] * (pm[a2 + 1] + pm[a2]) * (pn[a2 + 1] + pn[a2]) * (oHz(a + 1) + oHz(a)) +
                            Huon[a + 1 - ni] * (pm[a2 + 1 - ni] + pm[a2 - ni]) * (pn[a2 + 1 - ni] + pn[a2 - ni]) *
@@ -226,17 +248,17 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
         const double AA = A * A, BB = B * B, CC = Ck * Ck, AB = A * B, BC = B * Ck;
         const double XX = X * X, YY = Y * Y, ZZ = Z * Z, XY = X * Y, YZ = Y * Z;
-        const double sig_alfa = 1.0 / (1.0 - fabs(B) + EPS_MP);
-        const double sig_beta = -B / ((1.0 - fabs(B)) * (1.0 - BB) + EPS_MP);
-        const double sig_gama = 2.0 * fabs(BB * B) / ((1.0 - fabs(B)) * (1.0 - BB) * (1.0 - fabs(BB * B)) + EPS_MP);
-        const double sig_a = -A / ((1.0 - fabs(B)) * (1.0 - fabs(AB)) + EPS_MP);
-        const double sig_b = AB / ((1.0 - fabs(B)) * (1.0 - BB * fabs(A)) + EPS_MP) *
-                             (fabs(A) / (1.0 - fabs(AB) + EPS_MP) + 2.0 * B / (1.0 - BB + EPS_MP));
-        const double sig_c = fabs(B) * AA / ((1.0 - fabs(B)) * (1.0 - AA * fabs(B)) * (1.0 - fabs(AB)) + EPS_MP);
-        const double sig_d = -Ck / ((1.0 - fabs(B)) * (1.0 - fabs(BC)) + EPS_MP);
-        const double sig_e = BC / ((1.0 - fabs(B)) * (1.0 - BB * fabs(Ck)) + EPS_MP) *
-                             (fabs(Ck) / (1.0 - fabs(BC) + EPS_MP) + 2.0 * B / (1.0 - BB + EPS_MP));
-        const double sig_f = fabs(B) * CC / ((1.0 - fabs(B)) * (1.0 - CC * fabs(B)) * (1.0 - fabs(BC)) + EPS_MP);
+        const double sig_alfa = DV(1.0, 1.0 - fabs(B) + EPS_MP);
+        const double sig_beta = DV(-B, (1.0 - fabs(B)) * (1.0 - BB) + EPS_MP);
+        const double sig_gama = DV(2.0 * fabs(BB * B), (1.0 - fabs(B)) * (1.0 - BB) * (1.0 - fabs(BB * B)) + EPS_MP);
+        const double sig_a = DV(-A, (1.0 - fabs(B)) * (1.0 - fabs(AB)) + EPS_MP);
+        const double sig_b = DV(AB, (1.0 - fabs(B)) * (1.0 - BB * fabs(A)) + EPS_MP) *
+                             (DV(fabs(A), 1.0 - fabs(AB) + EPS_MP) + DV(2.0 * B, 1.0 - BB + EPS_MP));
+        const double sig_c = DV(fabs(B) * AA, (1.0 - fabs(B)) * (1.0 - AA * fabs(B)) * (1.0 - fabs(AB)) + EPS_MP);
+        const double sig_d = DV(-Ck, (1.0 - fabs(B)) * (1.0 - fabs(BC)) + EPS_MP);
+        const double sig_e = DV(BC, (1.0 - fabs(B)) * (1.0 - BB * fabs(Ck)) + EPS_MP) *
+                             (DV(fabs(Ck), 1.0 - fabs(BC) + EPS_MP) + DV(2.0 * B, 1.0 - BB + EPS_MP));
+        const double sig_f = DV(fabs(B) * CC, (1.0 - fabs(B)) * (1.0 - CC * fabs(B)) * (1.0 - fabs(BC)) + EPS_MP);
         const double v0 = sig_alfa * Y + sig_beta * YY + sig_gama * YY * Y + sig_a * XY + sig_b * Y * XX +
                           sig_c * YY * X + sig_d * YZ + sig_e * YY * Z + sig_f * Y * ZZ;
         va = fmin(fabs(v0), 1.0 * fabs(Vm)) * copysign(1.0, v0);
@@ -253,15 +275,15 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
       const double Tu = Ta[a + nij];
       double wa = 0.0;
       if (!((T0 <= 0.0) || (Tu <= 0.0) || (fabs(T0 - Tu) <= EPS2_MP))) {
-        const double Ck = (Tu - T0) / (Tu + T0 + EPS_MP);
+        const double Ck = DV(Tu - T0, Tu + T0 + EPS_MP);
         double A = 0.0625 *
                    ((Ta[a + 1 + nij] - Tu) * (pm[a2 + 1] + pm[a2]) + (Tu - Ta[a - 1 + nij]) * (pm[a2] + pm[a2 - 1]) +
                     (Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]) + (T0 - Ta[a - 1]) * (pm[a2] + pm[a2 - 1]));
         double B = 0.0625 *
                    ((Ta[a + ni + nij] - Tu) * (pn[a2 + ni] + pn[a2]) + (Tu - Ta[a - ni + nij]) * (pn[a2] + pn[a2 - ni]) +
                     (Ta[a + ni] - T0) * (pn[a2 + ni] + pn[a2]) + (T0 - Ta[a - ni]) * (pn[a2] + pn[a2 - ni]));
-        A = A * (om_u[a2 + 1] + om_u[a2]) / (Tu + T0 + EPS_MP);
-        B = B * (on_v[a2 + ni] + on_v[a2]) / (Tu + T0 + EPS_MP);
+        A = DV(A * (om_u[a2 + 1] + om_u[a2]), Tu + T0 + EPS_MP);
+        B = DV(B * (on_v[a2 + ni] + on_v[a2]), Tu + T0 + EPS_MP);
         const double Um = 0.03125 * dt *
                           (Huon[a] * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a) + oHz(a - 1)) +
                            Huon[a + nij] * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a + nij) + oHz(a - 1 + nij)) +
@@ -280,17 +302,17 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
         const double AA = A * A, BB = B * B, CC = Ck * Ck, AC = A * Ck, BC = B * Ck;
         const double XX = X * X, YY = Y * Y, ZZ = Z * Z, XZ = X * Z, YZ = Y * Z;
-        const double sig_alfa = 1.0 / (1.0 - fabs(Ck) + EPS_MP);
-        const double sig_beta = -Ck / ((1.0 - fabs(Ck)) * (1.0 - CC) + EPS_MP);
-        const double sig_gama = 2.0 * fabs(CC * Ck) / ((1.0 - fabs(Ck)) * (1.0 - CC) * (1.0 - fabs(CC * Ck)) + EPS_MP);
-        const double sig_a = -B / ((1.0 - fabs(Ck)) * (1.0 - fabs(BC)) + EPS_MP);
-        const double sig_b = BC / ((1.0 - fabs(Ck)) * (1.0 - CC * fabs(B)) + EPS_MP) *
-                             (fabs(B) / (1.0 - fabs(BC) + EPS_MP) + 2.0 * Ck / (1.0 - CC + EPS_MP));
-        const double sig_c = fabs(Ck) * BB / ((1.0 - fabs(Ck)) * (1.0 - B * B * fabs(Ck)) * (1.0 - fabs(BC)) + EPS_MP);
-        const double sig_d = -A / ((1.0 - fabs(Ck)) * (1.0 - fabs(AC)) + EPS_MP);
-        const double sig_e = AC / ((1.0 - fabs(Ck)) * (1.0 - CC * fabs(A)) + EPS_MP) *
-                             (fabs(A) / (1.0 - fabs(AC) + EPS_MP) + 2.0 * Ck / (1.0 - CC + EPS_MP));
-        const double sig_f = fabs(Ck) * AA / ((1.0 - fabs(Ck)) * (1.0 - AA * fabs(Ck)) * (1.0 - fabs(AC)) + EPS_MP);
+        const double sig_alfa = DV(1.0, 1.0 - fabs(Ck) + EPS_MP);
+        const double sig_beta = DV(-Ck, (1.0 - fabs(Ck)) * (1.0 - CC) + EPS_MP);
+        const double sig_gama = DV(2.0 * fabs(CC * Ck), (1.0 - fabs(Ck)) * (1.0 - CC) * (1.0 - fabs(CC * Ck)) + EPS_MP);
+        const double sig_a = DV(-B, (1.0 - fabs(Ck)) * (1.0 - fabs(BC)) + EPS_MP);
+        const double sig_b = DV(BC, (1.0 - fabs(Ck)) * (1.0 - CC * fabs(B)) + EPS_MP) *
+                             (DV(fabs(B), 1.0 - fabs(BC) + EPS_MP) + DV(2.0 * Ck, 1.0 - CC + EPS_MP));
+        const double sig_c = DV(fabs(Ck) * BB, (1.0 - fabs(Ck)) * (1.0 - B * B * fabs(Ck)) * (1.0 - fabs(BC)) + EPS_MP);
+        const double sig_d = DV(-A, (1.0 - fabs(Ck)) * (1.0 - fabs(AC)) + EPS_MP);
+        const double sig_e = DV(AC, (1.0 - fabs(Ck)) * (1.0 - CC * fabs(A)) + EPS_MP) *
+                             (DV(fabs(A), 1.0 - fabs(AC) + EPS_MP) + DV(2.0 * Ck, 1.0 - CC + EPS_MP));
+        const double sig_f = DV(fabs(Ck) * AA, (1.0 - fabs(Ck)) * (1.0 - AA * fabs(Ck)) * (1.0 - fabs(AC)) + EPS_MP);
         const double w0 = sig_alfa * Z + sig_beta * ZZ + sig_gama * ZZ * Z + sig_a * YZ + sig_b * ZZ * Y +
                           sig_c * Z * YY + sig_d * XZ + sig_e * ZZ * X + sig_f * Z * XX;
         wa = fmin(fabs(w0), 1.0 * fabs(Wk)) * copysign(1.0, w0);
@@ -299,6 +321,8 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
     }
   }
 }
+
+#undef DV
 
 // ------------------------------------------------------ K3: beta_up/dn ----
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
@@ -484,7 +508,8 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
   hipLaunchKernelGGL(k_mp_ta, grid2d(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1), block2d(), 0, g_ctx.stream,
                      g_ctx.devc, m);
   KERNEL_CHECK("k_mp_ta");
-  hipLaunchKernelGGL(k_mp_adiff, grid2d(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1), block2d(), 0,
+  hipLaunchKernelGGL(g_ctx.p.mpdata_fast ? k_mp_adiff<true> : k_mp_adiff<false>,
+                     grid2d(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1), block2d(), 0,
                      g_ctx.stream, g_ctx.devc, m);
   KERNEL_CHECK("k_mp_adiff");
   hipLaunchKernelGGL(k_mp_beta, grid2d(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1), block2d(), 0,

@@ -17,6 +17,7 @@
 // registers / LDS; only DUon, DVom, zeta_new, zwrk live in device scratch.
 #include "roms_dev.h"
 #include <cstdlib>
+#include <map>
 
 int roms_entry_check(const char *name);
 int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DVom, const double *zeta_new,
@@ -392,13 +393,10 @@ extern "C" int roms_hip_step2d(const roms_step_idx_t *s)
   return step2d_impl(s, false);
 }
 
-// LOOP_2D of main3d.F:592-700
-extern "C" int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1)
+// LOOP_2D of main3d.F:592-700: the predictor/corrector sequencing, launches queued on the library's stream
+static int step2d_loop_body(roms_step_idx_t *s, int *indx1)
 {
-  int rc = roms_entry_check("roms_hip_step2d_loop");
-  if (rc) return rc;
-  if ((rc = check_lbc())) return rc;
-  ScopedTimer tm("step2d_loop");
+  int rc;
   const int nfast = g_ctx.p.nfast;
   int predictor = 0;
   g_flux_ready = false;
@@ -425,5 +423,55 @@ extern "C" int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1)
       if ((rc = step2d_impl(s, true))) return rc;
   }
   g_flux_ready = false;
+  return 0;
+}
+
+// One tile: the 2*nfast+1 launches of the loop are captured once per (indx1, nstp, start-up phase) into a
+// hipGraph and replayed -- the launch arguments of a replay are those of the capture, so the graphs are
+// dropped whenever bounds, parameters or a field registration change (step2d_graphs_release).  On several
+// tiles the loop contains host-side transport calls and runs eagerly.
+struct LoopGraph { hipGraphExec_t exec; int indx1_out; roms_step_idx_t s_out; };
+static std::map<int, LoopGraph> g_loop_graphs;
+
+void step2d_graphs_release()
+{
+  for (auto &kv : g_loop_graphs)
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  g_loop_graphs.clear();
+}
+
+extern "C" int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1)
+{
+  int rc = roms_entry_check("roms_hip_step2d_loop");
+  if (rc) return rc;
+  if ((rc = check_lbc())) return rc;
+  ScopedTimer tm("step2d_loop");
+  const roms_bounds_t &b = g_ctx.b;
+  const bool one_tile = b.ntileI * b.ntileJ == 1 && !g_ctx.loopback;
+  if (!one_tile) return step2d_loop_body(s, indx1);
+  const int phase = s->iic == s->ntfirst ? 0 : (s->iic == s->ntfirst + 1 ? 1 : 2);
+  const int key = ((*indx1 * 4 + s->nstp) * 4 + s->nnew) * 4 + phase;
+  auto it = g_loop_graphs.find(key);
+  if (it == g_loop_graphs.end()) {
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeThreadLocal));
+    rc = step2d_loop_body(s, indx1);
+    const hipError_t e = hipStreamEndCapture(g_ctx.stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return roms_fail("roms_hip_step2d_loop: hipStreamEndCapture", hipGetErrorString(e));
+    LoopGraph lg{nullptr, *indx1, *s};
+    const hipError_t e2 = hipGraphInstantiate(&lg.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) return roms_fail("roms_hip_step2d_loop: hipGraphInstantiate", hipGetErrorString(e2));
+    it = g_loop_graphs.emplace(key, lg).first;
+  } else {
+    // the sequencing of the loop does not depend on the data: indices as the capture left them
+    const int iic = s->iic, ntfirst = s->ntfirst;
+    *s = it->second.s_out;
+    s->iic = iic;
+    s->ntfirst = ntfirst;
+    *indx1 = it->second.indx1_out;
+  }
+  HIP_TRY(hipGraphLaunch(it->second.exec, g_ctx.stream));
   return 0;
 }

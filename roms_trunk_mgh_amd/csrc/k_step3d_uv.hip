@@ -7,12 +7,17 @@
 //                a wavefront-serial Thomas solve per column with the column
 //                state in VGPRs (:346-400, :679-735) -- and replacement of the
 //                vertical mean by DU_avg1/DV_avg1 (:466-520).
-//   k_uv_couple  one thread per column over JstrT:JendT: ubar,vbar(:,:,1:2),
-//                boundary-row mean correction and the corrected mass fluxes
-//                Huon,Hvom with DU_avg2/DV_avg2 (:997-1460); the intermediate
-//                fluxes stay in VGPRs between the two vertical passes.
-// Algorithmic traffic: read Akv,Hz,ru,rv, read+write u,v(nnew), then read
-// u,v(nnew),Hz, read+write Huon,Hvom = 14 passes.
+//                The coupling of the same column (:997-1460: ubar,vbar(:,:,1:2)
+//                and the corrected mass fluxes Huon,Hvom with DU_avg2/DV_avg2)
+//                needs nothing but the column's own final velocity, so it is
+//                done in the same thread from the registers that hold it: the
+//                Thomas arrays are dead by then and keep the layer factors and
+//                the intermediate fluxes.
+//   k_uv_couple  the columns the first kernel does not step -- boundary rows
+//                (after u3dbc/v3dbc) with their mean correction (:1087-1110) --
+//                one thread per column over IstrT:IendT, JstrT:JendT.
+// Algorithmic traffic: read Akv,Hz,ru,rv, read+write u,v(nnew), read+write
+// Huon,Hvom = 12 passes.
 #include "roms_dev.h"
 
 int roms_entry_check(const char *name);
@@ -23,7 +28,8 @@ namespace {
 template <int NMAX>
 __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
                                           gd_t vel, gcd_t rhs,
-                                          double dc0, double metric, double Davg1)
+                                          double dc0, double metric, double Davg1,
+                                          gd_t Hflx, gd_t bar, double Davg2)
 {
   const gcd_t Akv = (gcd_t)(c->F.Akv);
   const gcd_t Hz = (gcd_t)(c->F.Hz);
@@ -89,9 +95,39 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
   }
   const double cff1 = 1.0 / (sumH * metric);
   const double corr = (sumU * metric - Davg1) * cff1;
+  // final velocity; then the coupling of this column (couple_column below, fix_mean = false) from registers:
+  // CF[] now holds DC(i,k) of step3d_uv.F:1010, DC[] the intermediate flux
+  const double cffm = 0.5 * metric;
+  double DC0 = 0.0;
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      const long ck = c0 + (long)(k - 1) * nij;
+      const double uv = un[k] - corr;
+      vel[ck] = uv;
+      un[k] = uv;
+      const double dck = cffm * (Hz[ck] + Hz[ck - off]);
+      CF[k] = dck;
+      DC0 = DC0 + dck;
+    }
+  }
+  DC0 = 1.0 / DC0;
+  const double bv = DC0 * Davg1;
+  bar[c0] = bv;
+  bar[c0 + nij] = bv;
+  double FC0 = 0.0;
+#pragma unroll
+  for (int k = NMAX; k >= 1; k--) {
+    if (k <= N) {
+      const double h = 0.5 * (Hflx[c0 + (long)(k - 1) * nij] + un[k] * CF[k]);
+      DC[k] = h;
+      FC0 = FC0 + h;
+    }
+  }
+  FC0 = DC0 * (FC0 - Davg2);
 #pragma unroll
   for (int k = 1; k <= NMAX; k++)
-    if (k <= N) vel[c0 + (long)(k - 1) * nij] = un[k] - corr;
+    if (k <= N) Hflx[c0 + (long)(k - 1) * nij] = DC[k] - CF[k] * FC0;
 }
 
 template <int NMAX>
@@ -110,12 +146,12 @@ k_uv_column(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
     if (i < b.IstrU) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - 1]) * (pn[c0] + pn[c0 - 1]);
     uv_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), (gcd_t)(c->F.ru + (long)(nrhs - 1) * n3w), dc0,
-                    GF(on_u)[c0], GF(DU_avg1)[c0]);
+                    GF(on_u)[c0], GF(DU_avg1)[c0], GF(Huon), GF(ubar), GF(DU_avg2)[c0]);
   } else {
     if (j < b.JstrV) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - ni]) * (pn[c0] + pn[c0 - ni]);
     uv_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), (gcd_t)(c->F.rv + (long)(nrhs - 1) * n3w), dc0,
-                    GF(om_v)[c0], GF(DV_avg1)[c0]);
+                    GF(om_v)[c0], GF(DV_avg1)[c0], GF(Hvom), GF(vbar), GF(DV_avg2)[c0]);
   }
 }
 
@@ -181,12 +217,16 @@ k_uv_couple(const RomsDev *__restrict__ c, int nnew)
   if (i > b.IendT || j > b.JendT) return;
   const long c0 = I2(i, j);
   const bool ns_wall = !b.NSperiodic;
+  // columns stepped by k_uv_column were coupled there
+  const bool inner = i <= b.Iend && j >= b.Jstr && j <= b.Jend;
   if (XB.z == 0) {
+    if (inner && i >= b.IstrU) return;
     if (i < b.IstrP) return;
     const bool fix = ns_wall && (j == 0 || j == b.Mm + 1) && i >= b.IstrU && i <= b.Iend;
     couple_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), GF(Huon), GF(ubar), GF(on_u)[c0],
                         GF(DU_avg1)[c0], GF(DU_avg2)[c0], fix);
   } else {
+    if (inner && i >= b.Istr && j >= b.JstrV) return;
     if (j < b.Jstr) return;
     const bool fix = ns_wall && (j == 1 || j == b.Mm + 1) && i >= b.Istr && i <= b.Iend;
     couple_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), GF(Hvom), GF(vbar), GF(om_v)[c0],

@@ -199,3 +199,4 @@ void snapshot_release();                  // snapshot.hip: waits for and frees a
 void snapshot_forget(int field_id);       // snapshot.hip: the same for one field (before it is re-registered)
 void diag_release();                      // k_diag.hip: frees the buffers of roms_hip_diag
 int check_lbc();
+void step2d_graphs_release();           // k_step2d.hip: drop the captured LOOP_2D graphs (their launch arguments are stale)

@@ -56,6 +56,10 @@ def input_state(config):
 def checksum(st):
     h = hashlib.sha256()
     for name in sorted(st.arr):
+        # the land/sea masks joined the field table after these fixtures were made: an all-water mask (every
+        # value 1) is the state the fixtures were generated in and does not enter the checksum
+        if name in ("rmask", "umask", "vmask", "pmask") and not st.p.masking:
+            continue
         h.update(np.ascontiguousarray(st.arr[name]).tobytes())
     return h.hexdigest()
 

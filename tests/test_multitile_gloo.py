@@ -70,3 +70,36 @@ def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
                 iv = min(ni, rb.Lm + rb.NghostPoints - LBi + 1)
                 jv = min(nj, rb.Mm + 1 - LBj + 1)
                 assert np.array_equal(a[:iv, :jv], want[:iv, :jv]), (name, r, "ghost points differ")
+
+
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+@pytest.mark.skipif(not os.path.exists(MPIEXEC), reason="no MPI in this image")
+@pytest.mark.parametrize("ntI,ntJ,config", [(2, 2, "SEAMOUNT"), (4, 2, "BENCHMARK_TINY")])
+def test_mpi_baseline_layer_equals_single(tmp_path, ntI, ntJ, config):
+    """The arrangement bench.py's cpu_baseline leg times -- one oracle process per tile under mpiexec, halos
+    through oracle/mpi/oracle_mpi.c (mp_exchange.F:290-902 restated on MPI) -- against the one-tile run: 1 + 2
+    steps, every tile bit-equal incl. ghost points.  (4x2 = the tiling of the 8-GPU run.)"""
+    root = os.path.dirname(HERE)
+    world = ntI * ntJ
+    r = subprocess.run([MPIEXEC, "-n", str(world), sys.executable, os.path.join(root, "bench.py"), "--cpu-worker",
+                        config, "2", "0", str(ntI), str(ntJ), str(tmp_path)],
+                       env=dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    ref = _single(config, 3)
+    rb = ref.b
+    for q in range(world):
+        d = np.load(os.path.join(tmp_path, f"tile{q}.npz"))
+        Istr, Iend, Jstr, Jend, LBi, LBj = [int(x) for x in d["bounds"]]
+        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz"):
+            a = d[name]
+            ni, nj = a.shape[0], a.shape[1]
+            i0, j0 = LBi - rb.LBi, LBj - rb.LBj
+            want = ref[name][i0:i0 + ni, j0:j0 + nj]
+            own = (slice(Istr - LBi, Iend - LBi + 1), slice(Jstr - LBj, Jend - LBj + 1))
+            assert np.array_equal(a[own], want[own]), (name, q, float(np.abs(a[own] - want[own]).max()))
+            if name in ("zeta", "t", "Hz", "W"):
+                iv = min(ni, rb.Lm + rb.NghostPoints - LBi + 1)
+                jv = min(nj, rb.Mm + 1 - LBj + 1)
+                assert np.array_equal(a[:iv, :jv], want[:iv, :jv]), (name, q, "ghost points differ")

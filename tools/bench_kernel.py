@@ -16,7 +16,10 @@ def main():
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     sets = dict(a.split("=") for a in sys.argv[4:])      # e.g. uv_vis2=0 uv_adv=0
     t0 = time.time()
-    st = util.prepared_state(config)
+    if config.endswith("_MPDATA"):      # BASELINE.json configuration 5: six tracers, all MPDATA
+        st = util.prepared_state(config[:-7], NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"})
+    else:
+        st = util.prepared_state(config)
     util.hz_weighted_tnew(st)
     print(f"state built in {time.time()-t0:.1f}s", flush=True)
     for k_, v_ in sets.items():
