@@ -10,7 +10,8 @@
 #
 #   oracle/_ref/<APP>/libref.so   reference objects + our bind(C) wrapper
 #                                 (oracle/ref_wrap.F90) for APP in
-#                                 BENCHMARK, UPWELLING, SEAMOUNT
+#                                 BENCHMARK, UPWELLING, SEAMOUNT, and BENCHMARK_MASK,
+#                                 UPWELLING_MASK (= the application + -DMASKING)
 #
 # This is the reference's own recipe (makefile:207, Compilers/Linux-gfortran.mk:
 # 43-44: cpp -P -traditional then the Fortran compiler), serial build (no
@@ -38,17 +39,21 @@ FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iouni
  Utility/stats Functionals/analytical Nonlinear/wvelocity Nonlinear/diag Utility/set_scoord Utility/metrics"
 
 build_app () {
-  local APP=$1 hdr=$(echo $1 | tr A-Z a-z).h
+  # <APP>_MASK: the same application with the MASKING option added on the command line (a CPP option of the
+  # reference, globaldefs.h / mod_grid.F:322+); the wrapper then hands rmask/umask/vmask/pmask to GRID(ng)
+  local TAG=$1 APP=${1%_MASK} XDEF=""
+  [ "$TAG" != "$APP" ] && XDEF="-DMASKING"
+  local hdr=$(echo $APP | tr A-Z a-z).h
   # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
   [ "$APP" = UPWELLING ] && hdr=upwelling_nodiag.h
   # SEAMOUNT: same numerics without ANA_DIAG, whose ana_diag.h does not compile (see ref_headers/seamount_nodiag.h)
   [ "$APP" = SEAMOUNT ] && hdr=seamount_nodiag.h
-  local D=$OUT/$APP
+  local D=$OUT/$TAG
   if [ -f $D/libref.so ] && [ $D/libref.so -nt $HERE/ref_wrap.F90 ] && [ $D/libref.so -nt $HERE/build_ref.sh ]; then
     return 0
   fi
   mkdir -p $D && cd $D
-  local CPPF=(-P -traditional -w -D$APP "-DROMS_HEADER=\"$hdr\"" "-DROOT_DIR=\"$REF\"" '-DHOST_NAME="x"'
+  local CPPF=(-P -traditional -w -D$APP $XDEF "-DROMS_HEADER=\"$hdr\"" "-DROOT_DIR=\"$REF\"" '-DHOST_NAME="x"'
      '-DMY_OS="Linux"' '-DMY_CPU="x86_64"' '-DMY_FORT="flang"' '-DMY_FC="flang"' '-DMY_FFLAGS="-O2"'
      '-DSVN_URL="x"' '-DSVN_REV="x"' '-DANALYTICAL_DIR="x"' '-DHEADER_DIR="x"' "-DHEADER=\"$hdr\""
      '-DMY_ANALYTICAL_DIR="x"' '-DMY_HEADER_DIR="x"' "-DMY_HEADER=\"$hdr\"" '-DMY_ROOT_DIR="x"' '-DMY_ANALYTICAL="x"'
@@ -56,18 +61,21 @@ build_app () {
   local objs=""
   for f in $FILES; do
     local bn=$(basename $f)
+    # the MASKING variants leave analytical.F out: its ana_mask.h stops the compilation on purpose until a user
+    # fills in mask values ("no values provided for mask"); the masks reach GRID(ng) through the wrapper
+    [ -n "$XDEF" ] && [ $bn = analytical ] && continue
     cpp "${CPPF[@]}" $REF/ROMS/$f.F > $bn.f90
-    $FC $FFLAGS -c $bn.f90 -o $bn.o > $bn.log 2>&1 || { echo "[$APP] $f failed"; tail -5 $bn.log; exit 1; }
+    $FC $FFLAGS -c $bn.f90 -o $bn.o > $bn.log 2>&1 || { echo "[$TAG] $f failed"; tail -5 $bn.log; exit 1; }
     objs="$objs $bn.o"
   done
-  cpp -P -traditional -w -D$APP $HERE/ref_wrap.F90 > ref_wrap_pp.f90
-  $FC $FFLAGS -c ref_wrap_pp.f90 -o ref_wrap.o > ref_wrap.log 2>&1 || { echo "[$APP] ref_wrap failed"; tail -20 ref_wrap.log; exit 1; }
+  cpp -P -traditional -w -D$APP $XDEF $HERE/ref_wrap.F90 > ref_wrap_pp.f90
+  $FC $FFLAGS -c ref_wrap_pp.f90 -o ref_wrap.o > ref_wrap.log 2>&1 || { echo "[$TAG] ref_wrap failed"; tail -20 ref_wrap.log; exit 1; }
   $FC -shared -o libref.so $objs ref_wrap.o
   rm -f *.f90            # keep no preprocessed reference text around
-  echo "[$APP] built $D/libref.so"
+  echo "[$TAG] built $D/libref.so"
 }
 
-for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT}; do
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK}; do
   build_app $app &
 done
 wait

@@ -116,6 +116,7 @@ static double bulk_psit(double ZoL, double pi)
 
 int oracle_bulk_flux(OARGS)
 {
+  if (p->masking) return 8;      /* MASKING variant of bulk_flux.F not restated */
   ORACLE_PROLOGUE
   if (o_check_lbc(b, p)) return 8;
   const int nrhs = s->nrhs, itemp = 1, IterMax = 3;
@@ -294,6 +295,7 @@ static void o_wscale(double Ustar, double sigma, double Bf, double *wm, double *
 
 int oracle_lmd_vmix(OARGS)
 {
+  if (p->masking) return 8;      /* MASKING variant of lmd_skpp.F not restated */
   ORACLE_PROLOGUE
   if (o_check_lbc(b, p)) return 8;
   if (NAT < 2 || !p->salinity) return 8;          /* restated for the SALINITY set-up only */

@@ -22,7 +22,7 @@ def available(app):
 
 class Ref:
     def __init__(self, state):
-        app = state.cfg["app"]
+        app = state.cfg["app"] + ("_MASK" if state.p.masking else "")      # <APP>_MASK: built with -DMASKING
         self.l = C.CDLL(lib_path(app))
         self.st = state
         self.l.ref_abi_sizeof.argtypes = [C.c_int]

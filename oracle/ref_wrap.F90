@@ -282,6 +282,12 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   CALL c_f_pointer (F%pnom_p, a2, (/ni,nj/));   GRID(ng)%pnom_p = a2
   CALL c_f_pointer (F%pmon_u, a2, (/ni,nj/));   GRID(ng)%pmon_u = a2
   CALL c_f_pointer (F%pnom_v, a2, (/ni,nj/));   GRID(ng)%pnom_v = a2
+#ifdef MASKING
+  CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
+  CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
+  CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
+  CALL c_f_pointer (F%pmask, a2, (/ni,nj/));    GRID(ng)%pmask = a2
+#endif
   CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
   CALL c_f_pointer (F%Huon, a3, (/ni,nj,NN/));  GRID(ng)%Huon = a3
   CALL c_f_pointer (F%Hvom, a3, (/ni,nj,NN/));  GRID(ng)%Hvom = a3
@@ -551,6 +557,7 @@ FUNCTION ref_diagnostics (kernel, b, p, s, F) BIND(C, name='ref_diagnostics') RE
   CALL c_f_pointer (F%DV_avg1, a2, (/ni,nj/));  a2 = COUPLING(ng)%DV_avg1
 END FUNCTION ref_diagnostics
 
+#ifndef MASKING      /* analytical.F does not compile with MASKING (ana_mask.h: "no values provided for mask") */
 !-----------------------------------------------------------------------
 !  The analytic set-up of the application, through the reference's own Functionals (analytical.F) and
 !  Utility routines -- used to pin roms_trunk_mgh_amd/ana.py (the inputs of every test and of bench.py):
@@ -712,7 +719,9 @@ FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc
   CLOSE (78)
   stdout = saved_stdout
 END FUNCTION ref_ana
+#endif
 
+#ifndef MASKING      /* mpdata_adiff_tile takes the masks as extra arguments; its MASKING variant is not pinned */
 !-----------------------------------------------------------------------
 !  mpdata_adiff_tile (ROMS/Nonlinear/mpdata_adiff.F:38) on caller-held private
 !  arrays: oHz, Ta, Ua, Va are (IminS:ImaxS,JminS:JmaxS,N), Wa is (..,..,0:N),
@@ -772,3 +781,4 @@ FUNCTION ref_mpdata_adiff (b, p, F, oHz, t3, Ta, Ua, Va, Wa) BIND(C, name='ref_m
  &                        GRID(ng)%z_r, poHz, GRID(ng)%Huon, GRID(ng)%Hvom, OCEAN(ng)%W, &
  &                        pt3, pTa, pUa, pVa, pWa)
 END FUNCTION ref_mpdata_adiff
+#endif

@@ -37,8 +37,12 @@ k_t3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
   const double *__restrict__ d2 = c->F.diff2 + (long)(itrc - 1) * nij;
   const long c0 = I2(i, j);
   // face metrics: xi faces i and i+1, eta faces j and j+1
-  const double mx0 = 0.5 * (pm[c0] + pm[c0 - 1]), mx1 = 0.5 * (pm[c0 + 1] + pm[c0]);
-  const double my0 = 0.5 * (pn[c0] + pn[c0 - ni]), my1 = 0.5 * (pn[c0 + ni] + pn[c0]);
+  double mx0 = 0.5 * (pm[c0] + pm[c0 - 1]), mx1 = 0.5 * (pm[c0 + 1] + pm[c0]);
+  double my0 = 0.5 * (pn[c0] + pn[c0 - ni]), my1 = 0.5 * (pn[c0 + ni] + pn[c0]);
+  if (c->p.masking) {                                     // MASKING, t3dmix2_geo.h:228, :260
+    mx0 = mx0 * c->F.umask[c0]; mx1 = mx1 * c->F.umask[c0 + 1];
+    my0 = my0 * c->F.vmask[c0]; my1 = my1 * c->F.vmask[c0 + ni];
+  }
   const double cfx0 = 0.25 * (d2[c0] + d2[c0 - 1]) * c->F.on_u[c0];
   const double cfx1 = 0.25 * (d2[c0 + 1] + d2[c0]) * c->F.on_u[c0 + 1];
   const double cfe0 = 0.25 * (d2[c0] + d2[c0 - ni]) * c->F.om_v[c0];
@@ -149,13 +153,17 @@ k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
   const double cfe0 = 0.25 * (d2[c0] + d2[c0 - ni]) * c->F.pnom_v[c0];
   const double cfe1 = 0.25 * (d2[c0 + ni] + d2[c0]) * c->F.pnom_v[c0 + ni];
   const double cdt = c->p.dt * c->F.pm[c0] * c->F.pn[c0];
+  const bool masking = c->p.masking != 0;                 // MASKING, t3dmix2_s.h:235, :275
+  const double um0 = masking ? c->F.umask[c0] : 1.0, um1 = masking ? c->F.umask[c0 + 1] : 1.0;
+  const double vm0 = masking ? c->F.vmask[c0] : 1.0, vm1 = masking ? c->F.vmask[c0 + ni] : 1.0;
   for (int k = 1; k <= N; k++) {
     const long ck = c0 + (long)(k - 1) * nij;
     const double t0 = T[ck], h0 = Hz[ck];
-    const double FX0 = cfx0 * (h0 + Hz[ck - 1]) * (t0 - T[ck - 1]);
-    const double FX1 = cfx1 * (Hz[ck + 1] + h0) * (T[ck + 1] - t0);
-    const double FE0 = cfe0 * (h0 + Hz[ck - ni]) * (t0 - T[ck - ni]);
-    const double FE1 = cfe1 * (Hz[ck + ni] + h0) * (T[ck + ni] - t0);
+    double FX0 = cfx0 * (h0 + Hz[ck - 1]) * (t0 - T[ck - 1]);
+    double FX1 = cfx1 * (Hz[ck + 1] + h0) * (T[ck + 1] - t0);
+    double FE0 = cfe0 * (h0 + Hz[ck - ni]) * (t0 - T[ck - ni]);
+    double FE1 = cfe1 * (Hz[ck + ni] + h0) * (T[ck + ni] - t0);
+    if (masking) { FX0 = FX0 * um0; FX1 = FX1 * um1; FE0 = FE0 * vm0; FE1 = FE1 * vm1; }
     const double cff1 = cdt * (FX1 - FX0);
     const double cff2 = cdt * (FE1 - FE0);
     tn[ck] = tn[ck] + (cff1 + cff2);

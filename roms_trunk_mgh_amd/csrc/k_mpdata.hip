@@ -78,10 +78,12 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
   const double cff = dt * GF(pm)[c0] * GF(pn)[c0];
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
-  double FCm1 = 0.0;
-  for (int k = 1; k <= N; k++) {
+  {
+    const int k = blockIdx.z + 1;                                // one thread per (i,j,k)
     const long a = c0 + (long)(k - 1) * nij;
     const double t0 = t3[a];
+    // FC(k-1): the expression the level below evaluates as its FC(k)
+    const double FCm1 = (k > 1) ? upstream(Wv[a], t3[a - nij], t0) : 0.0;
     const double FXi = upstream(Huon[a], t3[a - 1], t0);
     const double FXip1 = upstream(Huon[a + 1], t0, t3[a + 1]);
     const double FEj = upstream(Hvom[a], t3[a - ni], t0);
@@ -93,7 +95,6 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
     const double FCk = (k < N) ? upstream(Wv[a + nij], t0, t3[a + nij]) : 0.0;   // :1006-1018
     const double c1 = cff * (FCk - FCm1);
     ta = (ta - c1) * (1.0 / Hz[a]);                             // :1175
-    FCm1 = FCk;
     Ta[a] = ta;
     if (s_wall) Ta[a - ni] = ta;                                // mpdata_adiff.F:193-199
     if (n_wall) Ta[a + ni] = ta;
@@ -176,7 +177,10 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
   const bool v_wall_n = b.north_edge && !b.NSperiodic && j == b.Jend + 1;   // Va(i,Jend+1) = 0, mpdata_adiff.F:694-700
   const gcd_t oHzA = (gcd_t)m.oHz, odzA = (gcd_t)m.odz;
   auto oHz = [&](long x) { return oHzA[x]; };
-  for (int k = 1; k <= N; k++) {
+  // one thread per (i,j,k): nothing is carried from level to level, and with ~1200 FP64 instructions per
+  // cell the kernel needs every wave it can get (a k-loop per column ran at two waves per SIMD)
+  {
+    const int k = blockIdx.z + 1;
     const long a = a2 + (long)(k - 1) * nij;
     const double T0 = Ta[a];
     // ---------------- XI face between (i-1,j) and (i,j) ----------------
@@ -271,7 +275,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
     if (do_w) {
       const long aw = a + nij;                 // Wa(i,j,k) in a (0:N) array
       if (k == 1) Wa[a2] = 0.0;                // Wa(i,j,0)
-      if (k == N) { Wa[aw] = 0.0; continue; }  // Wa(i,j,N)
+      if (k == N) { Wa[aw] = 0.0; return; }    // Wa(i,j,N)
       const double Tu = Ta[a + nij];
       double wa = 0.0;
       if (!((T0 <= 0.0) || (Tu <= 0.0) || (fabs(T0 - Tu) <= EPS2_MP))) {
@@ -336,7 +340,8 @@ k_mp_beta(const RomsDev *__restrict__ c, MpArgs m)
   const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (m.itrc - 1)) * n3r);
   const gd_t bup = (gd_t)m.bup, bdn = (gd_t)m.bdn;
   const long a2 = I2(i, j);
-  for (int k = 1; k <= N; k++) {
+  {
+    const int k = blockIdx.z + 1;                                // one thread per (i,j,k)
     const long a = a2 + (long)(k - 1) * nij;
     const long aw = a + nij;                                     // Wa(i,j,k); Wa(i,j,k-1) = Wa[a]
     const double T0 = Ta[a], Tw = Ta[a - 1], Te = Ta[a + 1], Ts = Ta[a - ni], Tn = Ta[a + ni];
@@ -505,15 +510,24 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
                        g_ctx.hostc.ws3[0], g_ctx.hostc.ws3[7]);
     KERNEL_CHECK("k_mp_metrics");
   }
-  hipLaunchKernelGGL(k_mp_ta, grid2d(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1), block2d(), 0, g_ctx.stream,
-                     g_ctx.devc, m);
+  {
+    dim3 g3 = grid2d(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1);
+    g3.z = b.N;
+    hipLaunchKernelGGL(k_mp_ta, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+  }
   KERNEL_CHECK("k_mp_ta");
-  hipLaunchKernelGGL(g_ctx.p.mpdata_fast ? k_mp_adiff<true> : k_mp_adiff<false>,
-                     grid2d(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1), block2d(), 0,
-                     g_ctx.stream, g_ctx.devc, m);
+  {
+    dim3 g3 = grid2d(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1);
+    g3.z = b.N;
+    hipLaunchKernelGGL(g_ctx.p.mpdata_fast ? k_mp_adiff<true> : k_mp_adiff<false>, g3, block2d(), 0,
+                       g_ctx.stream, g_ctx.devc, m);
+  }
   KERNEL_CHECK("k_mp_adiff");
-  hipLaunchKernelGGL(k_mp_beta, grid2d(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1), block2d(), 0,
-                     g_ctx.stream, g_ctx.devc, m);
+  {
+    dim3 g3 = grid2d(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1);
+    g3.z = b.N;
+    hipLaunchKernelGGL(k_mp_beta, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+  }
   KERNEL_CHECK("k_mp_beta");
   const dim3 g = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
   if (b.N <= 16) hipLaunchKernelGGL((k_mp_update<16>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);

@@ -310,6 +310,7 @@ extern "C" int roms_hip_bulk_flux(const roms_step_idx_t *s)
 {
   int rc = roms_entry_check("roms_hip_bulk_flux");
   if (rc) return rc;
+  if (g_ctx.p.masking) return roms_fail("roms_hip_bulk_flux", "MASKING is not built for bulk_flux (bulk_flux.F:486-920)");
   if ((rc = check_lbc())) return rc;
   const roms_bounds_t &b = g_ctx.b;
   double *Taux = g_ctx.hostc.ws2[6], *Tauy = g_ctx.hostc.ws2[7];
@@ -662,6 +663,7 @@ extern "C" int roms_hip_lmd_vmix(const roms_step_idx_t *s)
   if ((rc = check_lbc())) return rc;
   const roms_bounds_t &b = g_ctx.b;
   if (b.NAT < 2 || !g_ctx.p.salinity) return roms_fail("roms_hip_lmd_vmix", "built for the SALINITY set-up (NAT = 2)");
+  if (g_ctx.p.masking) return roms_fail("roms_hip_lmd_vmix", "MASKING is not built for KPP (lmd_skpp.F:272-866)");
   const long nij = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1);
   const long n3w = nij * (b.N + 1);
   {

@@ -21,7 +21,8 @@ int roms_entry_check(const char *name);
 
 namespace {
 
-template <int HADV, int VADV, int NMAX>
+// MASK: MASKING applications, first differences times umask / vmask of their face (pre_step3d.F:398, :463)
+template <int HADV, int VADV, int NMAX, bool MASK>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int itrc0, int ntr)
 {
@@ -127,10 +128,17 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
     const double yp2 = n_wall ? 0.0 : ts[ck + 2 * ni];
     const double hu0 = Huon[ck], hu1 = Huon[ck + 1];
     const double hv0 = Hvom[ck], hv1 = Hvom[ck + ni];
-    const double dxm1 = xm1 - xm2, dx0 = tk - xm1, dxp1 = xp1 - tk, dxp2 = xp2 - xp1;
-    const double dy0 = tk - ym1, dyp1 = yp1 - tk;
-    const double dym1 = s_wall ? dy0 : (ym1 - ym2);
-    const double dyp2 = n_wall ? dyp1 : (yp2 - yp1);
+    double dxm1 = xm1 - xm2, dx0 = tk - xm1, dxp1 = xp1 - tk, dxp2 = xp2 - xp1;
+    double dy0 = tk - ym1, dyp1 = yp1 - tk;
+    double dym1 = ym1 - ym2, dyp2 = yp2 - yp1;
+    if constexpr (MASK) {
+      const gcd_t um = (gcd_t)c->F.umask, vm = (gcd_t)c->F.vmask;
+      dxm1 = dxm1 * um[c0 - 1]; dx0 = dx0 * um[c0]; dxp1 = dxp1 * um[c0 + 1]; dxp2 = dxp2 * um[c0 + 2];
+      dy0 = dy0 * vm[c0]; dyp1 = dyp1 * vm[c0 + ni];
+      dym1 = dym1 * vm[c0 + (s_wall ? 0 : -ni)]; dyp2 = dyp2 * vm[c0 + (n_wall ? ni : 2 * ni)];
+    }
+    if (s_wall) dym1 = dy0;
+    if (n_wall) dyp2 = dyp1;
     const double FXi = hflux<HADV>(hu0, xm1, tk, dxm1, dx0, dxp1);
     const double FXip1 = hflux<HADV>(hu1, tk, xp1, dx0, dxp1, dxp2);
     const double FEj = hflux<HADV>(hv0, ym1, tk, dym1, dy0, dyp1);
@@ -247,14 +255,26 @@ int launch_pre_t(const roms_step_idx_t *s, int itrc0, int ntr)
   const roms_bounds_t &b = g_ctx.b;
   const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
   const int first = s->iic == s->ntfirst;
+  if (b.N > ROMS_MAXN) return roms_fail("roms_hip_pre_step3d", "N > 64 not instantiated");
+  constexpr bool maskable = HADV != ADV_MPDATA;        // the upstream predictor of MPDATA / HSIMT has no mask
+  if constexpr (maskable) {
+    if (g_ctx.p.masking) {
+      if (b.N <= 16)
+        hipLaunchKernelGGL((k_pre_t<HADV, VADV, 16, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
+      else if (b.N <= 32)
+        hipLaunchKernelGGL((k_pre_t<HADV, VADV, 32, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
+      else
+        hipLaunchKernelGGL((k_pre_t<HADV, VADV, ROMS_MAXN, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
+      KERNEL_CHECK("k_pre_t");
+      return 0;
+    }
+  }
   if (b.N <= 16)
-    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
+    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 16, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
   else if (b.N <= 32)
-    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
-  else if (b.N <= ROMS_MAXN)
-    hipLaunchKernelGGL((k_pre_t<HADV, VADV, ROMS_MAXN>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
+    hipLaunchKernelGGL((k_pre_t<HADV, VADV, 32, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
   else
-    return roms_fail("roms_hip_pre_step3d", "N > 64 not instantiated");
+    hipLaunchKernelGGL((k_pre_t<HADV, VADV, ROMS_MAXN, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, s->nnew, first, itrc0, ntr);
   KERNEL_CHECK("k_pre_t");
   return 0;
 }

@@ -100,13 +100,21 @@ k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrh
   const gcd_t Hz = (gcd_t)(c->F.Hz);
   const double eps = 1.0E-10, OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
   const double HalfGRho = 0.5 * (c->p.g / c->p.rho0);
+  const bool masking = c->p.masking != 0;
   const long ck = I3(i, j, k);
   const double r0 = rho[ck], z0 = z_r[ck], hz0 = Hz[ck], P0 = P[ck];
   if (i >= b.IstrU) {
     const double rm2 = rho[ck - 2], rm1 = rho[ck - 1], rp1 = rho[ck + 1];
     const double zm2 = z_r[ck - 2], zm1 = z_r[ck - 1], zp1 = z_r[ck + 1];
-    const double aux_m1 = zm1 - zm2, aux_0 = z0 - zm1, aux_p1 = zp1 - z0;
-    const double FC_m1 = rm1 - rm2, FC_0 = r0 - rm1, FC_p1 = rp1 - r0;
+    double aux_m1 = zm1 - zm2, aux_0 = z0 - zm1, aux_p1 = zp1 - z0;
+    double FC_m1 = rm1 - rm2, FC_0 = r0 - rm1, FC_p1 = rp1 - r0;
+    if (masking) {                                          // MASKING, prsgrd32.h:300-306
+      const gcd_t um = (gcd_t)c->F.umask;
+      const long a2 = I2(i, j);
+      const double m_m1 = um[a2 - 1], m_0 = um[a2], m_p1 = um[a2 + 1];
+      aux_m1 = aux_m1 * m_m1; aux_0 = aux_0 * m_0; aux_p1 = aux_p1 * m_p1;
+      FC_m1 = FC_m1 * m_m1; FC_0 = FC_0 * m_0; FC_p1 = FC_p1 * m_p1;
+    }
     const double dZx0 = harm_inv(aux_0, aux_p1, eps), dZxm = harm_inv(aux_m1, aux_0, eps);
     const double dRx0 = harm_inv(FC_0, FC_p1, eps), dRxm = harm_inv(FC_m1, FC_0, eps);
     const gd_t ru = (gd_t)(c->F.ru + (long)(nrhs - 1) * n3w);
@@ -121,8 +129,15 @@ k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrh
     const double zm1 = z_r[ck - ni], zp1 = z_r[ck + ni];
     // aux(j-1) needs row j-2: exists for j-1 >= JstrV-1, i.e. always here
     const double rm2 = rho[ck - 2 * ni], zm2 = z_r[ck - 2 * ni];
-    const double aux_m1 = zm1 - zm2, aux_0 = z0 - zm1, aux_p1 = zp1 - z0;
-    const double FC_m1 = rm1 - rm2, FC_0 = r0 - rm1, FC_p1 = rp1 - r0;
+    double aux_m1 = zm1 - zm2, aux_0 = z0 - zm1, aux_p1 = zp1 - z0;
+    double FC_m1 = rm1 - rm2, FC_0 = r0 - rm1, FC_p1 = rp1 - r0;
+    if (masking) {                                          // MASKING, prsgrd32.h:364-370
+      const gcd_t vm = (gcd_t)c->F.vmask;
+      const long a2 = I2(i, j);
+      const double m_m1 = vm[a2 - ni], m_0 = vm[a2], m_p1 = vm[a2 + ni];
+      aux_m1 = aux_m1 * m_m1; aux_0 = aux_0 * m_0; aux_p1 = aux_p1 * m_p1;
+      FC_m1 = FC_m1 * m_m1; FC_0 = FC_0 * m_0; FC_p1 = FC_p1 * m_p1;
+    }
     const double dZx0 = harm_inv(aux_0, aux_p1, eps), dZxm = harm_inv(aux_m1, aux_0, eps);
     const double dRx0 = harm_inv(FC_0, FC_p1, eps), dRxm = harm_inv(FC_m1, FC_0, eps);
     const gd_t rv = (gd_t)(c->F.rv + (long)(nrhs - 1) * n3w);

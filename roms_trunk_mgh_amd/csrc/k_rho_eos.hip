@@ -83,6 +83,8 @@ k_rho_eos_nonlin(const RomsDev *__restrict__ c, int nrhs)
   double rhoA = 0.0, rhoS = 0.0;
   EosPt up{};
   double zr_up = 0.0;
+  const bool masking = c->p.masking != 0;
+  const double rm = masking ? GF(rmask)[c0] : 1.0;
   for (int k = N; k >= 1; k--) {
     const long ck = c0 + (long)(k - 1) * nij;
     const double zr = z_r[ck], hz = Hz[ck];
@@ -90,6 +92,7 @@ k_rho_eos_nonlin(const RomsDev *__restrict__ c, int nrhs)
     EosPt e;
     if (k == N) {
       e = eos_point<true>(tt, ts, zr);
+      if (masking) e.den = e.den * rm;                      // MASKING, rho_eos.F:356
       // surface thermal expansion / saline contraction, rho_eos.F:480-520
       const double Tpr10 = 0.1 * zr;
       const double cff = e.bulk + Tpr10;
@@ -107,6 +110,7 @@ k_rho_eos_nonlin(const RomsDev *__restrict__ c, int nrhs)
       GF(bvf)[c0 + (long)N * nij] = 0.0;
     } else {
       e = eos_point<false>(tt, ts, zr);
+      if (masking) e.den = e.den * rm;
       const double cf1 = e.den * hz;
       rhoS = rhoS + hz * (rhoA + 0.5 * cf1);
       rhoA = rhoA + cf1;
@@ -121,7 +125,7 @@ k_rho_eos_nonlin(const RomsDev *__restrict__ c, int nrhs)
       GF(bvf)[c0 + (long)k * nij] = -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (zr_up - zr));
     }
     GF(rho)[ck] = e.den;
-    GF(pden)[ck] = e.den1 - 1000.0;
+    GF(pden)[ck] = masking ? (e.den1 - 1000.0) * rm : e.den1 - 1000.0;      // rho_eos.F:478
     up = e;
     zr_up = zr;
   }
@@ -151,6 +155,7 @@ k_rho_eos_lin(const RomsDev *__restrict__ c, int nrhs)
     double r = R0 - R0 * Tcoef * (T[ck] - T0);
     if (salt) r = r + R0 * Scoef * (S[ck] - S0);
     r = r - 1000.0;
+    if (c->p.masking) r = r * GF(rmask)[c0];                // MASKING, rho_eos.F:717
     GF(rho)[ck] = r;
     GF(pden)[ck] = r;
     const double hz = GF(Hz)[ck];

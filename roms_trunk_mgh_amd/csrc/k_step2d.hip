@@ -67,40 +67,6 @@ k2d_flux(const RomsDev *__restrict__ c, S2 s, double *__restrict__ DUon, double 
   }
 }
 
-// DUon, DVom of level `lev` on the points this tile owns (interior + physical boundary rows); the
-// ghost points then come with the end-of-call exchange.  Used inside LOOP_2D on several tiles: the
-// fluxes of the NEXT call travel in the same message as zeta, ubar, vbar of this one.
-__global__ void __launch_bounds__(BLK_X *BLK_Y)
-k2d_flux_own(const RomsDev *__restrict__ c, int lev, double *__restrict__ DUon, double *__restrict__ DVom)
-{
-  DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrR + blockIdx.y * BLK_Y + threadIdx.y;
-  if (i > b.Iend || j > b.JendR) return;
-  const gcd_t zeta = (gcd_t)(c->F.zeta + (long)(lev - 1) * nij);
-  const gcd_t h = (gcd_t)(c->F.h);
-  const long a = I2(i, j);
-  // zeta on a closed-wall row is the zero-gradient copy of the adjacent interior row (zetabc.F:48);
-  // it is read from that row directly because bc_zeta fills the wall rows of the OWN columns only and
-  // the ghost column i-1 has not been exchanged yet
-  auto zrow = [&](int jj) {
-    if (b.south_edge && !b.NSperiodic && jj < b.Jstr) return b.Jstr;
-    if (b.north_edge && !b.NSperiodic && jj > b.Jend) return b.Jend;
-    return jj;
-  };
-  const double Drhs = zeta[I2(i, zrow(j))] + h[a];
-  {
-    const double cff = 0.5 * GF(on_u)[a];
-    const double cff1 = cff * (Drhs + (zeta[I2(i - 1, zrow(j))] + h[a - 1]));
-    DUon[a] = GF(ubar)[a + (long)(lev - 1) * nij] * cff1;
-  }
-  if (j >= b.JstrV - 1 && j >= b.LBj + 1) {
-    const double cff = 0.5 * GF(om_v)[a];
-    const double cff1 = cff * (Drhs + (zeta[I2(i, zrow(j - 1))] + h[a - ni]));
-    DVom[a] = GF(vbar)[a + (long)(lev - 1) * nij] * cff1;
-  }
-}
-
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k2d_zeta(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, const double *__restrict__ DVom,
          double *__restrict__ zeta_new, double *__restrict__ zwrk)
@@ -151,7 +117,7 @@ k2d_zeta(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, c
   const bool own = i >= b.Istr && j >= b.Jstr;
   const double rhs = (DUon[a] - DUon[a + 1]) + (DVom[a] - DVom[a + ni]);
   // zeta(knew) is stored on the extended range too: the low-side ghost value computed here is, bit
-  // for bit, what the exchange delivers later, and k2d_flux_own (next call's fluxes) needs it now
+  // for bit, what the exchange delivers later
   zeta_point(c, s, rhs, zeta_new, zwrk, a, a, true, true, own, nij, ni);
 }
 
@@ -246,12 +212,14 @@ __device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const 
   if (iif == 1) {
     const double cff1 = dtfast;
     zn = zs[a] + pmn_a * pn_a * cff1 * rhs;
+    if (p.masking) zn = zn * GF(rmask)[a];                      // MASKING, step2d_LF_AM3.h:778
     zw = 0.5 * (zs[a] + zn);
   } else if (s.predictor) {
     const double cff1 = 2.0 * dtfast;
     const double cff4 = 4.0 / 25.0;
     const double cff5 = 1.0 - 2.0 * cff4;
     zn = zs[a] + pmn_a * pn_a * cff1 * rhs;
+    if (p.masking) zn = zn * GF(rmask)[a];                      // :804
     zw = cff5 * zk[a] + cff4 * (zs[a] + zn);
   } else {
     const int ptsk = 3 - s.kstp;
@@ -263,6 +231,7 @@ __device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const 
     const double cff = cff1 * rhs;
     zn = zs[a] + pmn_a * pn_a * (cff + cff2 * GF(rzeta)[a + (long)(s.kstp - 1) * nij] -
                                  cff3 * GF(rzeta)[a + (long)(ptsk - 1) * nij]);
+    if (p.masking) zn = zn * GF(rmask)[a];                      // :835
     zw = cff5 * zn + cff4 * zk[a];
   }
   if (write_scratch) { zeta_new[o] = zn; zwrk[o] = zw; }
@@ -361,24 +330,12 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, zeta_new, zwrk))) return rc;
   if ((rc = bc_u2d(s.knew))) return rc;
   if ((rc = bc_v2d(s.knew))) return rc;
-  const bool defer = in_loop && multi;
-  if (defer) {
-    hipLaunchKernelGGL(k2d_flux_own, grid2d(b.Iend - b.Istr + 1, b.JendR - b.JstrR + 1), block2d(), 0, g_ctx.stream,
-                       g_ctx.devc, s.knew, DUon, DVom);
-    KERNEL_CHECK("k2d_flux_own");
-  }
   halo_batch_begin();
   if (s.predictor) halo_exchange2d(GT_R, g_ctx.dev[FID_rzeta] + (long)(s.krhs - 1) * nij);
   halo_exchange2d(GT_R, g_ctx.dev[FID_zeta] + (long)(s.knew - 1) * nij);
   halo_exchange2d(GT_U, g_ctx.dev[FID_ubar] + (long)(s.knew - 1) * nij);
   halo_exchange2d(GT_V, g_ctx.dev[FID_vbar] + (long)(s.knew - 1) * nij);
-  if (defer) {
-    halo_exchange2d(GT_U, DUon);
-    halo_exchange2d(GT_V, DVom);
-  }
-  if ((rc = halo_batch_end())) return rc;
-  if (defer) { g_flux_ready = true; g_flux_lev = s.knew; }
-  return 0;
+  return halo_batch_end();
 }
 
 }  // namespace

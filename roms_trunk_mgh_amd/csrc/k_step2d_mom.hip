@@ -93,12 +93,14 @@ __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S
   if (s.iif == 1) {
     const double cff1 = dtfast;
     zn = zs[a] + pmn_a * pn_a * cff1 * rhs;
+    if (p.masking) zn = zn * GF(rmask)[a];                      // MASKING, step2d_LF_AM3.h:778
     zw = 0.5 * (zs[a] + zn);
   } else if (s.predictor) {
     const double cff1 = 2.0 * dtfast;
     const double cff4 = 4.0 / 25.0;
     const double cff5 = 1.0 - 2.0 * cff4;
     zn = zs[a] + pmn_a * pn_a * cff1 * rhs;
+    if (p.masking) zn = zn * GF(rmask)[a];                      // :804
     zw = cff5 * zk[a] + cff4 * (zs[a] + zn);
   } else {
     const int ptsk = 3 - s.kstp;
@@ -110,6 +112,7 @@ __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S
     const double cff = cff1 * rhs;
     zn = zs[a] + pmn_a * pn_a * (cff + cff2 * GF(rzeta)[a + (long)(s.kstp - 1) * nij] -
                                  cff3 * GF(rzeta)[a + (long)(ptsk - 1) * nij]);
+    if (p.masking) zn = zn * GF(rmask)[a];                      // :835
     zw = cff5 * zn + cff4 * zk[a];
   }
 }
@@ -224,6 +227,10 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   m.w_edge = b.west_edge && !b.EWperiodic;  m.e_edge = b.east_edge && !b.EWperiodic;
   const int t = m.at(it, j);                        // this point in the tiles
   const double fac = 1000.0 / p.rho0;
+  const bool masking = p.masking != 0;
+  // closed-wall rows under MASKING: the boundary value times the mask of the boundary point (zetabc.F:540,
+  // u2dbc_im.F:975); mk(M, q) = 1 without masks
+  auto mk = [&](gd_t M, long q) { return masking ? (double)M[q] : 1.0; };
   // ---- pressure gradient, :939-1019 ----
   if constexpr (FUSED) {
     // ---- what k2d_zeta_sm did: fast-time averages on the owned ranges and zeta(knew), rzeta(krhs) ----
@@ -263,8 +270,8 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const double zn = sZn[t];
     const gd_t zout = (gd_t)(c->F.zeta + (long)(s.knew - 1) * nij);
     put(zout, o, zn);
-    if (b.south_edge && j == b.Jstr) put(zout, o - ni, zn);         // zetabc closed: zero gradient
-    if (b.north_edge && j == b.Jend) put(zout, o + ni, zn);
+    if (b.south_edge && j == b.Jstr) put(zout, o - ni, masking ? zn * GF(rmask)[a - ni] : zn);   // zetabc closed
+    if (b.north_edge && j == b.Jend) put(zout, o + ni, masking ? zn * GF(rmask)[a + ni] : zn);
     if (s.predictor)      // at the target: ghost columns hold the periodic copy, as after the exchange
       put((gd_t)(c->F.rzeta + (long)(s.krhs - 1) * nij), o, (sDU[t] - sDU[t + 1]) + (sDV[t] - sDV[t + TP]));
   }
@@ -350,9 +357,10 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     };
     auto str_p = [&](long q, int tq) {
       const double Dp = 0.25 * (sD[tq] + sD[tq - 1] + sD[tq - TP] + sD[tq - 1 - TP]);
-      return visc2_p[q] * Dp * 0.5 *
+      const double cffp = visc2_p[q] * Dp * 0.5 *
              (pmon_p[q] * ((pn[q - ni] + pn[q]) * sV[tq] - (pn[q - 1 - ni] + pn[q - 1]) * sV[tq - 1]) +
               pnom_p[q] * ((pm[q - 1] + pm[q]) * sU[tq] - (pm[q - 1 - ni] + pm[q - ni]) * sU[tq - TP]));
+      return masking ? cffp * GF(pmask)[q] : cffp;              // MASKING, :1433
     };
     const double sr0 = str_r(a, t), sp0 = str_p(a, t);
     if (do_u) {
@@ -418,11 +426,14 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     else un = (us * (Dst0 + (zs[q] + h[q])) +
                cff * (a1 * rhs_u + a2 * GF(rubar)[a + (long)(s.kstp - 1) * nij] -
                       a3 * GF(rubar)[a + (long)(ptsk - 1) * nij])) * fc;
+    if (masking) un = un * GF(umask)[a];               // MASKING, :2120 / :2175
     put(ubn, o, un);
     if (s.predictor && owner) GF(rubar)[a + (long)(s.krhs - 1) * nij] = rhs_u;
+    const double un_s = masking ? (p.gamma2 * un) * GF(umask)[a - ni] : p.gamma2 * un;   // wall rows (u2dbc)
+    const double un_n = masking ? (p.gamma2 * un) * GF(umask)[a + ni] : p.gamma2 * un;
     if (inline_bc) {                                   // u2dbc closed walls, u2dbc_im.F:51
-      if (b.south_edge && j == b.Jstr) put(ubn, o - ni, p.gamma2 * un);
-      if (b.north_edge && j == b.Jend) put(ubn, o + ni, p.gamma2 * un);
+      if (b.south_edge && j == b.Jstr) put(ubn, o - ni, un_s);
+      if (b.north_edge && j == b.Jend) put(ubn, o + ni, un_n);
     }
     if constexpr (FUSED) {
       if (DUnext) {                                    // DUon of level knew, :509-525 (as k2d_flux)
@@ -430,9 +441,11 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
         DUnext[a] = un * ((0.5 * GF(on_u)[a]) * (Dn0 + (znw + h[q])));
         // wall rows: u = gamma2*u(adjacent row), zeta = zero-gradient copy (u2dbc_im.F:51, zetabc.F:48)
         if (b.south_edge && j == b.Jstr)
-          DUnext[a - ni] = (p.gamma2 * un) * ((0.5 * GF(on_u)[a - ni]) * ((sZn[t] + h[a - ni]) + (znw + h[q - ni])));
+          DUnext[a - ni] = un_s * ((0.5 * GF(on_u)[a - ni]) *
+                                   ((sZn[t] * mk(GF(rmask), a - ni) + h[a - ni]) + (znw * mk(GF(rmask), q - ni) + h[q - ni])));
         if (b.north_edge && j == b.Jend)
-          DUnext[a + ni] = (p.gamma2 * un) * ((0.5 * GF(on_u)[a + ni]) * ((sZn[t] + h[a + ni]) + (znw + h[q + ni])));
+          DUnext[a + ni] = un_n * ((0.5 * GF(on_u)[a + ni]) *
+                                   ((sZn[t] * mk(GF(rmask), a + ni) + h[a + ni]) + (znw * mk(GF(rmask), q + ni) + h[q + ni])));
       }
     }
   }
@@ -446,6 +459,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     else vn = (vs * (Dst0 + (zs[q] + h[q])) +
                cff * (a1 * rhs_v + a2 * GF(rvbar)[a + (long)(s.kstp - 1) * nij] -
                       a3 * GF(rvbar)[a + (long)(ptsk - 1) * nij])) * fc;
+    if (masking) vn = vn * GF(vmask)[a];               // MASKING, :2145 / :2194
     put(vbn, o, vn);
     if (s.predictor && owner) GF(rvbar)[a + (long)(s.krhs - 1) * nij] = rhs_v;
     if constexpr (FUSED) {
@@ -460,9 +474,9 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     if (DVnext) {                                      // wall rows: v = 0 there
       const double zn0 = sZn[t];
       if (b.south_edge && j == b.Jstr)
-        DVnext[a] = 0.0 * ((0.5 * GF(om_v)[a]) * ((zn0 + h[a]) + (zn0 + h[a - ni])));
+        DVnext[a] = 0.0 * ((0.5 * GF(om_v)[a]) * ((zn0 + h[a]) + (zn0 * mk(GF(rmask), a - ni) + h[a - ni])));
       if (b.north_edge && j == b.Jend)
-        DVnext[a + ni] = 0.0 * ((0.5 * GF(om_v)[a + ni]) * ((zn0 + h[a + ni]) + (zn0 + h[a])));
+        DVnext[a + ni] = 0.0 * ((0.5 * GF(om_v)[a + ni]) * ((zn0 * mk(GF(rmask), a + ni) + h[a + ni]) + (zn0 + h[a])));
     }
   }
 }

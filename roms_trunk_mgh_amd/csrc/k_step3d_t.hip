@@ -297,7 +297,10 @@ struct LevelIn {
   double tkp2, xm2, xm1, xp1, xp2, ym2, ym1, yp1, yp2, hu0, hu1, hv0, hv1, w, hz, tv, akt;
 };
 
-template <int HADV, int VADV, int NMAX>
+// MASK (MASKING applications, a second instantiation so that the unmasked kernel keeps its registers): the
+// first differences are multiplied by umask / vmask of their face (step3d_t.F:603, :667) and the result by
+// rmask (:1586-1596); the masks are read per level (cache hits) rather than held in registers.
+template <int HADV, int VADV, int NMAX, bool MASK>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
 {
@@ -404,10 +407,17 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       LevelIn nxt;
       if (k + 1 <= N) nxt = load_level(k + 1);       // in flight while level k is computed
       const double tkp2 = cur.tkp2;
-      const double dxm1 = cur.xm1 - cur.xm2, dx0 = tk - cur.xm1, dxp1 = cur.xp1 - tk, dxp2 = cur.xp2 - cur.xp1;
-      const double dy0 = tk - cur.ym1, dyp1 = cur.yp1 - tk;
-      const double dym1 = s_wall ? dy0 : (cur.ym1 - cur.ym2);
-      const double dyp2 = n_wall ? dyp1 : (cur.yp2 - cur.yp1);
+      double dxm1 = cur.xm1 - cur.xm2, dx0 = tk - cur.xm1, dxp1 = cur.xp1 - tk, dxp2 = cur.xp2 - cur.xp1;
+      double dy0 = tk - cur.ym1, dyp1 = cur.yp1 - tk;
+      double dym1 = cur.ym1 - cur.ym2, dyp2 = cur.yp2 - cur.yp1;
+      if constexpr (MASK) {
+        const gcd_t um = (gcd_t)c->F.umask, vm = (gcd_t)c->F.vmask;
+        dxm1 = dxm1 * um[c0 - 1]; dx0 = dx0 * um[c0]; dxp1 = dxp1 * um[c0 + 1]; dxp2 = dxp2 * um[c0 + 2];
+        dy0 = dy0 * vm[c0]; dyp1 = dyp1 * vm[c0 + ni];
+        dym1 = dym1 * vm[c0 + (s_wall ? 0 : -ni)]; dyp2 = dyp2 * vm[c0 + (n_wall ? ni : 2 * ni)];
+      }
+      if (s_wall) dym1 = dy0;
+      if (n_wall) dyp2 = dyp1;
       const double FXi = hflux<HADV>(cur.hu0, cur.xm1, tk, dxm1, dx0, dxp1);
       const double FXip1 = hflux<HADV>(cur.hu1, tk, cur.xp1, dx0, dxp1, dxp2);
       const double FEj = hflux<HADV>(cur.hv0, cur.ym1, tk, dym1, dy0, dyp1);
@@ -469,7 +479,8 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       const long ck = c0 + (long)kk * nij;
       const double ohz = 1.0 / hzA;
       const double cff1 = dt * ohz * (dcA_up - dcA);
-      tn_g[ck] = s_tn[kk * NTH + tid] + cff1;
+      if constexpr (MASK) tn_g[ck] = (s_tn[kk * NTH + tid] + cff1) * GF(rmask)[c0];
+      else tn_g[ck] = s_tn[kk * NTH + tid] + cff1;
       dcA_up = dcA;
       akA = akB; hzA = hzB; akB = akC; hzB = hzC;
     }
@@ -489,15 +500,22 @@ int launch_nmax(int nnew, int itrc0, int ntr)
       hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
     else
       hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 64>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+  } else if (g_ctx.p.masking) {           // software-pipelined kernel, land/sea masks applied
+    if (b.N <= 16)
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 16, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else if (b.N <= 32)
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 32, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 64, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
   } else {                                // software-pipelined kernel
     if (b.N <= 16)
-      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 16, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
     else if (b.N <= 32)
-      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 32, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
     else if (b.N <= 48)     // the column arrays then spill into AGPRs (one wave per SIMD); slower per cell, same results
-      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 48>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 48, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
     else
-      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 64>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 64, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
   }
   KERNEL_CHECK("k_step3d_t");
   return 0;
@@ -534,6 +552,7 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
       case ADV_C4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_C4, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_A4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_A4, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_HSIMT * 16 + ADV_HSIMT: {
+        if (p.masking) return roms_fail("roms_hip_step3d_t", "MASKING is not built for HSIMT tracers");
         // three-point footprint: refresh the ghost points of t(nnew) first (step3d_t.F:369-386); classic kernel
         if (b.NghostPoints != 3) return roms_fail("roms_hip_step3d_t", "HSIMT needs NghostPoints = 3 (inp_par.F:266-278)");
         const long n3r_ = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
@@ -545,6 +564,7 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
         break;
       }
       case ADV_MPDATA * 16 + ADV_MPDATA:
+        if (p.masking) return roms_fail("roms_hip_step3d_t", "MASKING is not built for MPDATA tracers (mpdata_adiff.F:290-1025)");
         // multi-pass: upstream step, anti-diffusive velocities, FCT limiter, corrected step (k_mpdata.hip)
         for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q, q == 0);
         break;

@@ -29,7 +29,7 @@ template <int NMAX>
 __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
                                           gd_t vel, gcd_t rhs,
                                           double dc0, double metric, double Davg1,
-                                          gd_t Hflx, gd_t bar, double Davg2)
+                                          gd_t Hflx, gd_t bar, double Davg2, bool masking, double msk)
 {
   const gcd_t Akv = (gcd_t)(c->F.Akv);
   const gcd_t Hz = (gcd_t)(c->F.Hz);
@@ -103,7 +103,8 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
   for (int k = 1; k <= NMAX; k++) {
     if (k <= N) {
       const long ck = c0 + (long)(k - 1) * nij;
-      const double uv = un[k] - corr;
+      double uv = un[k] - corr;
+      if (masking) uv = uv * msk;                 // MASKING, step3d_uv.F:558 / :891
       vel[ck] = uv;
       un[k] = uv;
       const double dck = cffm * (Hz[ck] + Hz[ck - off]);
@@ -141,17 +142,20 @@ k_uv_column(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
   if (i > b.Iend || j > b.Jend) return;
   const long c0 = I2(i, j);
   const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn;
+  const bool masking = c->p.masking != 0;
   // blockIdx.z selects the component so that both columns do not share VGPRs
   if (XB.z == 0) {
     if (i < b.IstrU) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - 1]) * (pn[c0] + pn[c0 - 1]);
     uv_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), (gcd_t)(c->F.ru + (long)(nrhs - 1) * n3w), dc0,
-                    GF(on_u)[c0], GF(DU_avg1)[c0], GF(Huon), GF(ubar), GF(DU_avg2)[c0]);
+                    GF(on_u)[c0], GF(DU_avg1)[c0], GF(Huon), GF(ubar), GF(DU_avg2)[c0], masking,
+                    masking ? (double)GF(umask)[c0] : 1.0);
   } else {
     if (j < b.JstrV) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - ni]) * (pn[c0] + pn[c0 - ni]);
     uv_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), (gcd_t)(c->F.rv + (long)(nrhs - 1) * n3w), dc0,
-                    GF(om_v)[c0], GF(DV_avg1)[c0], GF(Hvom), GF(vbar), GF(DV_avg2)[c0]);
+                    GF(om_v)[c0], GF(DV_avg1)[c0], GF(Hvom), GF(vbar), GF(DV_avg2)[c0], masking,
+                    masking ? (double)GF(vmask)[c0] : 1.0);
   }
 }
 
@@ -160,7 +164,7 @@ template <int NMAX>
 __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
                                               gd_t vel, gd_t Hflx,
                                               gd_t bar, double metric, double Davg1, double Davg2,
-                                              bool fix_mean)
+                                              bool fix_mean, bool masking, double msk)
 {
   const gcd_t Hz = (gcd_t)(c->F.Hz);
   const double cff = 0.5 * metric;
@@ -190,7 +194,11 @@ __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, lon
       const long ck = c0 + (long)(k - 1) * nij;
       const double dck = dc[k];
       double uv = vel[ck];
-      if (fix_mean) { uv = uv - CF0; vel[ck] = uv; }      // boundary rows, :1087-1110
+      if (fix_mean) {                                     // boundary rows, :1087-1110
+        uv = uv - CF0;
+        if (masking) uv = uv * msk;                       // MASKING, :1137 / :1166 / :1355 / :1384
+        vel[ck] = uv;
+      }
       const double h = 0.5 * (Hflx[ck] + uv * dck);
       hu[k] = h;
       FC0 = FC0 + h;
@@ -217,6 +225,7 @@ k_uv_couple(const RomsDev *__restrict__ c, int nnew)
   if (i > b.IendT || j > b.JendT) return;
   const long c0 = I2(i, j);
   const bool ns_wall = !b.NSperiodic;
+  const bool masking = c->p.masking != 0;
   // columns stepped by k_uv_column were coupled there
   const bool inner = i <= b.Iend && j >= b.Jstr && j <= b.Jend;
   if (XB.z == 0) {
@@ -224,13 +233,13 @@ k_uv_couple(const RomsDev *__restrict__ c, int nnew)
     if (i < b.IstrP) return;
     const bool fix = ns_wall && (j == 0 || j == b.Mm + 1) && i >= b.IstrU && i <= b.Iend;
     couple_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), GF(Huon), GF(ubar), GF(on_u)[c0],
-                        GF(DU_avg1)[c0], GF(DU_avg2)[c0], fix);
+                        GF(DU_avg1)[c0], GF(DU_avg2)[c0], fix, masking, masking ? (double)GF(umask)[c0] : 1.0);
   } else {
     if (inner && i >= b.Istr && j >= b.JstrV) return;
     if (j < b.Jstr) return;
     const bool fix = ns_wall && (j == 1 || j == b.Mm + 1) && i >= b.Istr && i <= b.Iend;
     couple_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), GF(Hvom), GF(vbar), GF(om_v)[c0],
-                        GF(DV_avg1)[c0], GF(DV_avg2)[c0], fix);
+                        GF(DV_avg1)[c0], GF(DV_avg2)[c0], fix, masking, masking ? (double)GF(vmask)[c0] : 1.0);
   }
 }
 

@@ -14,7 +14,7 @@
 namespace {
 
 struct RhoC { double pmon, pnom, e1, e0, n1, n0, k_x, k_e; };   // stress point at rho
-struct PsiC { double pmon, pnom, a, b, c, d, k_e, k_x; };       // stress point at psi
+struct PsiC { double pmon, pnom, a, b, c, d, k_e, k_x, mask; };  // stress point at psi (mask: pmask, 1 without MASKING)
 
 __device__ __forceinline__ RhoC rho_coef(const RomsDev *__restrict__ c, long r, long ni)
 {
@@ -42,6 +42,7 @@ __device__ __forceinline__ PsiC psi_coef(const RomsDev *__restrict__ c, long q, 
   o.d = pm[q - 1 - ni] + pm[q - ni];
   o.k_e = c->F.om_p[q] * c->F.om_p[q] * c->F.visc2_p[q];
   o.k_x = c->F.on_p[q] * c->F.on_p[q] * c->F.visc2_p[q];
+  o.mask = c->p.masking ? c->F.pmask[q] : 1.0;
   return o;
 }
 __device__ __forceinline__ double stress_r(const RhoC &m, const double *__restrict__ u, const double *__restrict__ v,
@@ -50,10 +51,11 @@ __device__ __forceinline__ double stress_r(const RhoC &m, const double *__restri
   return Hz[rk] * 0.5 * (m.pmon * (m.e1 * u[rk + 1] - m.e0 * u[rk]) - m.pnom * (m.n1 * v[rk + ni] - m.n0 * v[rk]));
 }
 __device__ __forceinline__ double stress_p(const PsiC &m, const double *__restrict__ u, const double *__restrict__ v,
-                                           const double *__restrict__ Hz, long qk, long ni)
+                                           const double *__restrict__ Hz, long qk, long ni, bool msk)
 {
-  return 0.125 * (Hz[qk - 1] + Hz[qk] + Hz[qk - 1 - ni] + Hz[qk - ni]) *
-         (m.pmon * (m.a * v[qk] - m.b * v[qk - 1]) + m.pnom * (m.c * u[qk] - m.d * u[qk - ni]));
+  const double cff = 0.125 * (Hz[qk - 1] + Hz[qk] + Hz[qk - 1 - ni] + Hz[qk - ni]) *
+                     (m.pmon * (m.a * v[qk] - m.b * v[qk - 1]) + m.pnom * (m.c * u[qk] - m.d * u[qk - ni]));
+  return msk ? cff * m.mask : cff;                        // MASKING, uv3dmix2_s.h:272
 }
 
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
@@ -65,6 +67,7 @@ k_uv3dmix2_v2(const RomsDev *__restrict__ c, int nrhs, int nnew)
   const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
   const bool do_u = i >= b.IstrU, do_v = j >= b.JstrV;
+  const bool msk = c->p.masking != 0;
   const double dt = c->p.dt;
   const double *__restrict__ u = c->F.u + (long)(nrhs - 1) * n3r;
   const double *__restrict__ v = c->F.v + (long)(nrhs - 1) * n3r;
@@ -90,10 +93,10 @@ k_uv3dmix2_v2(const RomsDev *__restrict__ c, int nrhs, int nnew)
   for (int k = 1; k <= N; k++) {
     const long ak = a + (long)(k - 1) * nij;
     const double sr0 = stress_r(r0, u, v, Hz, ak, ni);
-    const double sp0 = stress_p(p0, u, v, Hz, ak, ni);
+    const double sp0 = stress_p(p0, u, v, Hz, ak, ni, msk);
     if (do_u) {
       const double srm = stress_r(rw, u, v, Hz, ak - 1, ni);
-      const double spn = stress_p(pN, u, v, Hz, ak + ni, ni);
+      const double spn = stress_p(pN, u, v, Hz, ak + ni, ni, msk);
       const double cff1 = hn_u * (r0.k_x * sr0 - rw.k_x * srm);
       const double cff2 = hm_u * (pN.k_e * spn - p0.k_e * sp0);
       const double cff3 = cu * (cff1 + cff2);
@@ -102,7 +105,7 @@ k_uv3dmix2_v2(const RomsDev *__restrict__ c, int nrhs, int nnew)
     }
     if (do_v) {
       const double srs = stress_r(rs, u, v, Hz, ak - ni, ni);
-      const double spe = stress_p(pE, u, v, Hz, ak + 1, ni);
+      const double spe = stress_p(pE, u, v, Hz, ak + 1, ni, msk);
       const double cff1 = hn_v * (pE.k_x * spe - p0.k_x * sp0);
       const double cff2 = hm_v * (r0.k_e * sr0 - rs.k_e * srs);
       const double cff3 = cv * (cff1 - cff2);

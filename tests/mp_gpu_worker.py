@@ -22,6 +22,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     opts = set(variant.split("+")) if variant else set()
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
+    if "mask" in opts:
+        kw["mask"] = "island"
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)
     b = st.b
     ndev = torch.cuda.device_count()

@@ -23,6 +23,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
     if variant == "hsimt":
         kw = dict(overrides={"Hadv": "HSIMT", "Vadv": "HSIMT"})
+    if variant == "mask":
+        kw = dict(mask="island")
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb, **kw)
     b = st.b
     ni, nj = st.ni, st.nj

@@ -12,12 +12,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main(config):
+def main(config, mask=None):
     import oracle
     import util
     from oracle import ref
     ov = {"tnu2": 300.0, "visc2": 800.0} if config != "SEAMOUNT" else {"tnu2": 300.0}
-    st0 = util.prepared_state(config, overrides=ov)
+    st0 = util.prepared_state(config, overrides=ov, mask=mask)
     out = {}
     r = ref.Ref(st0.copy())
     bb = r.bounds()
@@ -32,6 +32,7 @@ def main(config):
         kernels.append("uv3dmix2")
     s = util.step_idx()
     out["kernels"] = {}
+    out["masking"] = int(st0.p.masking)
     for k in kernels:
         st_r, st_o = st0.copy(), st0.copy()
         # detune so that every kernel has something to do
@@ -231,5 +232,7 @@ if __name__ == "__main__":
         main_physics(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mpdata":
         main_mpdata(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "mask":
+        main(sys.argv[1], mask="island")
     else:
         main(sys.argv[1])

@@ -113,6 +113,52 @@ def test_hip_reproduces_reference_vectors(config):
         _check_diag(d, g["diag_report"])
 
 
+def _load_mask(config):
+    import importlib.util
+    sys_path_add = os.path.join(HERE, "golden")
+    import sys
+    if sys_path_add not in sys.path:
+        sys.path.insert(0, sys_path_add)
+    spec = importlib.util.spec_from_file_location("make_golden_mask", os.path.join(HERE, "golden", "make_golden_mask.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from make_golden import checksum
+    g = np.load(os.path.join(HERE, "golden", f"ref_mask_{config}.npz"))
+    st0 = mg.input_state(config)
+    assert checksum(st0) == str(g["input_sha256"]), "seeded inputs changed: regenerate the fixtures"
+    return g, st0, mg
+
+
+@pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING"])
+def test_oracle_reproduces_masked_reference_vectors(config):
+    """MASKING: outputs of the reference built with -DMASKING on a grid with an island and a headland
+    (tests/golden/make_golden_mask.py) -- rho_eos, prsgrd32, t3dmix2 (geo / s), uv3dmix2_s and the glue kernels."""
+    import oracle
+    g, st0, mg = _load_mask(config)
+    s = util.step_idx()
+    for k in mg.KERNELS:
+        st = st0.copy()
+        oracle.Oracle(st).call(k, s)
+        _check(st, st0, g, k, tol=0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING"])
+def test_hip_reproduces_masked_reference_vectors(config):
+    from roms_trunk_mgh_amd import hip
+    g, st0, mg = _load_mask(config)
+    s = util.step_idx()
+    for k in mg.KERNELS:
+        st = st0.copy()
+        h = hip.RomsHip(st)
+        try:
+            h.call(k, s)
+            h.to_host()
+        finally:
+            h.close()
+        _check(st, st0, g, k, tol=1e-13)
+
+
 def test_oracle_reproduces_reference_mpdata_adiff():
     """mpdata_adiff_tile: the committed outputs of the reference's Fortran (three levels stored,
     all elements through a SHA-256) vs the C oracle on the same deterministic inputs."""

@@ -33,6 +33,8 @@ def _single(config, nsteps, variant=""):
     from roms_trunk_mgh_amd import hip
     opts = set(variant.split("+")) if variant else set()
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
+    if "mask" in opts:
+        kw["mask"] = "island"
     st = ana.make_tile(config, perturb=1.0, **kw)
     be = hip.RomsHip(st)
     m = main3d.Main3D(be, physics=("physics" in opts), diagnostics=("physics" in opts))
@@ -51,6 +53,8 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "BENCHMARK_TINY", "mpdata"),
                                                     # bulk fluxes, KPP, wvelocity, diag on every tile
                                                     (2, 2, "BENCHMARK_TINY", "physics"),
+                                                    # MASKING: an island across the tile corner, a headland on the wall
+                                                    (2, 2, "BENCHMARK_TINY", "mask"), (2, 1, "UPWELLING", "mask"),
                                                     # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
                                                     # 512-column tiles of the 8-GPU run (4x1), both tile rows (2x2), the
                                                     # deferred-flux step2d path and, with six MPDATA tracers, three ghost points

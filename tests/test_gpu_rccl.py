@@ -55,7 +55,7 @@ def _compare(tmp_path, ref, world):
 
 
 @pytest.mark.parametrize("config,variant", [("BENCHMARK_TINY", "physics+rccl"), ("UPWELLING", "rccl"),
-                                            ("BENCHMARK_TINY", "mpdata+rccl")])
+                                            ("BENCHMARK_TINY", "mpdata+rccl"), ("SEAMOUNT", "mask+rccl")])
 def test_rccl_loopback_equals_local_periodic_copy(tmp_path, config, variant):
     nsteps = 3
     ref, _ = _single(config, nsteps, variant.replace("+rccl", "").replace("rccl", ""))

@@ -13,11 +13,12 @@ def step_idx(iic=3, ntfirst=1, nstp=1, nnew=2, nrhs=1, kstp=1, krhs=1, knew=2, i
                        krhs=krhs, knew=knew, iif=iif, predictor_2d_step=pred)
 
 
-def prepared_state(config, seed=1, NT=None, overrides=None, oracle_backend=None):
+def prepared_state(config, seed=1, NT=None, overrides=None, oracle_backend=None, mask=None):
     """A tile state with non-trivial velocities, fluxes, RHS terms and tracers at
-    all time levels.  Deterministic (seeded)."""
+    all time levels.  Deterministic (seeded).  mask = "island": a MASKING grid (ana.island_mask); the
+    prognostic fields are then zero on land, as the reference keeps them."""
     import oracle
-    st = ana.make_tile(config, perturb=1.0, NT=NT, overrides=overrides)
+    st = ana.make_tile(config, perturb=1.0, NT=NT, overrides=overrides, mask=mask)
     b = st.b
     rng = np.random.default_rng(seed)
     Lm, Mm, N = b.Lm, b.Mm, b.N
@@ -67,6 +68,22 @@ def prepared_state(config, seed=1, NT=None, overrides=None, oracle_backend=None)
     st["bvstr"][:] = 1e-5 * smooth(1, 2, 0.6)[:, :, 0]
     st["btflx"][:] = 0.0
     _ = rng
+    if mask is not None:
+        rm, um, vm = st["rmask"], st["umask"], st["vmask"]
+        st["zeta"] *= rm[:, :, None]
+        st["Zt_avg1"] *= rm
+        st["ubar"] *= um[:, :, None]
+        st["vbar"] *= vm[:, :, None]
+        st["u"] *= um[:, :, None, None]
+        st["v"] *= vm[:, :, None, None]
+        st["t"] *= rm[:, :, None, None, None]
+        for name in ("DU_avg1", "DU_avg2"):
+            st[name] *= um
+        for name in ("DV_avg1", "DV_avg2"):
+            st[name] *= vm
+        o.call("set_depth", s)
+        o.call("set_massflux", s)
+        o.call("omega", s)
     return st
 
 
