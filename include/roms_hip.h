@@ -33,7 +33,7 @@ extern "C" {
 /* ------------------------------------------------------------------ */
 enum roms_kind {
   K_2D = 0, K_2D_T2, K_2D_T3, K_2D_NT,
-  K_3DR, K_3DW, K_3DR_T2, K_3DW_T2, K_3DW_NAT, K_4DT
+  K_3DR, K_3DW, K_3DR_T2, K_3DW_T2, K_3DW_NAT, K_4DT, K_3DR_NT
 };
 
 enum roms_field_id {
@@ -83,9 +83,18 @@ typedef struct roms_bounds {
 enum roms_adv {
   ADV_C2 = 0, ADV_C4, ADV_A4, ADV_U3, ADV_SU3, ADV_SPLINES, ADV_MPDATA, ADV_HSIMT
 };
-/* Lateral boundary condition codes actually supported on this path
- * (T_LBC, mod_param.F:120-160): closed wall or periodic. */
-enum roms_lbc { LBC_PERIODIC = 0, LBC_CLOSED = 1 };
+/* Lateral boundary condition codes supported on this path (the logical records of T_LBC, mod_param.F:120-160).
+ * West and east: periodic only.  South and north, per variable (roms_params_t.lbc): closed, gradient, clamped;
+ * Chapman implicit for the free surface (zetabc.F:489); Flather for the normal 2-D velocity (v2dbc_im.F:216);
+ * radiation -- implicit upstream, without nudging and without RADIATION_2D -- for u, v and the tracers
+ * (u3dbc_im.F:381, v3dbc_im.F:97, t3dbc_im.F:364). */
+enum roms_lbc {
+  LBC_PERIODIC = 0, LBC_CLOSED = 1, LBC_GRADIENT = 2, LBC_CLAMPED = 3, LBC_CHAPMAN_IMPLICIT = 4, LBC_FLATHER = 5,
+  LBC_RADIATION = 6
+};
+/* rows of roms_params_t.lbc = the state variables of LBC(:, isFsur / isUbar / isVbar / isUvel / isVvel / isTvar, ng) */
+enum roms_lbc_var { LBV_ZETA = 0, LBV_UBAR, LBV_VBAR, LBV_U, LBV_V, LBV_T, LBV_COUNT };
+enum roms_lbc_side { LBS_WEST = 0, LBS_EAST, LBS_SOUTH, LBS_NORTH };
 
 typedef struct roms_params {
   double dt, dtfast;                 /* mod_scalars.F dt(ng), dtfast(ng)     */
@@ -121,6 +130,9 @@ typedef struct roms_params {
   int    masking;                    /* 1 = the application defines MASKING: rmask/umask/vmask/pmask are applied
                                       * where the reference applies them (e.g. step2d_LF_AM3.h:778, step3d_t.F:603) */
   int    pad_masking_;
+  /* lbc[side][variable] (enum roms_lbc_side, roms_lbc_var; every tracer shares LBV_T): 0 = take the side's
+   * lbc_west / lbc_east / lbc_south / lbc_north above, otherwise an enum roms_lbc code */
+  int    lbc[4][LBV_COUNT];
 } roms_params_t;
 
 /* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and

@@ -152,6 +152,12 @@
 #define umask(i,j)    F->umask[I2(i,j)]
 #define vmask(i,j)    F->vmask[I2(i,j)]
 #define pmask(i,j)    F->pmask[I2(i,j)]
+#define zeta_bry(i,j) F->zeta_bry[I2(i,j)]
+#define ubar_bry(i,j) F->ubar_bry[I2(i,j)]
+#define vbar_bry(i,j) F->vbar_bry[I2(i,j)]
+#define u_bry(i,j,k)  F->u_bry[I3(i,j,k)]
+#define v_bry(i,j,k)  F->v_bry[I3(i,j,k)]
+#define t_bry(i,j,k,it) F->t_bry[I3(i,j,k) + (long)((it)-1) * n3r]
 
 /* private (automatic) work arrays of the _tile routines */
 #define WS2(i,j)   ((long)((i) - IminS) + (long)((j) - JminS) * nis)   /* (IminS:ImaxS,JminS:JmaxS) */
@@ -173,6 +179,7 @@ void oracle_set_exchange_hook(o_exchange_hook_t fn);
 void o_exchange2d(const roms_bounds_t *b, int gtype, double *A);
 void o_exchange3d(const roms_bounds_t *b, int gtype, int nk, double *A);
 int  o_check_lbc(const roms_bounds_t *b, const roms_params_t *p);
+int  o_lbc(const roms_params_t *p, int side, int var);
 void o_zetabc(OARGS, int kout);
 void o_u2dbc(OARGS, int kout);
 void o_v2dbc(OARGS, int kout);

@@ -17,12 +17,27 @@ int roms_abi_sizeof(int which)
   return -1;
 }
 
-/* Only E-W periodic / N-S closed (or fully periodic E-W with closed walls) is
- * restated: all five configurations use LBC == Per Clo Per Clo. */
+/* Effective boundary-condition code (enum roms_lbc) of variable v (enum roms_lbc_var) on side sd. */
+int o_lbc(const roms_params_t *p, int sd, int v)
+{
+  if (p->lbc[sd][v]) return p->lbc[sd][v];
+  return sd == LBS_WEST ? p->lbc_west : sd == LBS_EAST ? p->lbc_east : sd == LBS_SOUTH ? p->lbc_south : p->lbc_north;
+}
+
+/* West/east periodic; south/north per variable: closed, gradient, clamped, Chapman implicit (zeta), Flather
+ * (vbar), radiation (u, v, t) -- the conditions restated below. */
 int o_check_lbc(const roms_bounds_t *b, const roms_params_t *p)
 {
   if (!b->EWperiodic || b->NSperiodic) return 1;
-  if (p->lbc_south != LBC_CLOSED || p->lbc_north != LBC_CLOSED) return 1;
+  for (int sd = LBS_SOUTH; sd <= LBS_NORTH; sd++)
+    for (int v = 0; v < LBV_COUNT; v++) {
+      const int c = o_lbc(p, sd, v);
+      int ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED;
+      if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT;
+      if (v == LBV_VBAR) ok = ok || c == LBC_FLATHER;
+      if (v >= LBV_U) ok = ok || c == LBC_RADIATION;
+      if (!ok) return 1;
+    }
   return 0;
 }
 
@@ -79,93 +94,175 @@ void o_exchange3d(const roms_bounds_t *b, int gtype, int nk, double *A)
   if (g_hook && b->ntileI * b->ntileJ > 1) g_hook(A, nk, gtype);
 }
 
-/* zetabc_tile, closed S/N walls -- ROMS/Nonlinear/zetabc.F:48 */
+/* The time level `know` and the step dt2d of the 2-D boundary conditions (zetabc.F:96-106, v2dbc_im.F:116-126) */
+static void o_know(const roms_params_t *p, const roms_step_idx_t *s, int *know, double *dt2d)
+{
+  if (s->iif == 1) { *know = s->krhs; *dt2d = p->dtfast; }
+  else if (s->predictor_2d_step) { *know = s->krhs; *dt2d = 2.0 * p->dtfast; }
+  else { *know = s->kstp; *dt2d = p->dtfast; }
+}
+
+/* zetabc_tile, S/N edges -- ROMS/Nonlinear/zetabc.F:404-700: Chapman implicit (:489, :638), clamped (:508,
+ * :657), gradient (:521, :670), closed (:534, :683); every branch ends with the MASKING multiply */
 void o_zetabc(OARGS, int kout)
 {
   ORACLE_PROLOGUE
-  (void)s;
-  const int mk = p->masking;           /* MASKING: the boundary value times the mask of the boundary point, zetabc.F:540, :689 */
-  if (south_edge) for (int i = Istr; i <= Iend; i++) {
-    zeta(i, Jstr - 1, kout) = zeta(i, Jstr, kout);
-    if (mk) zeta(i, Jstr - 1, kout) = zeta(i, Jstr - 1, kout) * rmask(i, Jstr - 1);
-  }
-  if (north_edge) for (int i = Istr; i <= Iend; i++) {
-    zeta(i, Jend + 1, kout) = zeta(i, Jend, kout);
-    if (mk) zeta(i, Jend + 1, kout) = zeta(i, Jend + 1, kout) * rmask(i, Jend + 1);
+  const int mk = p->masking;
+  int know; double dt2d;
+  o_know(p, s, &know, &dt2d);
+  for (int side = 0; side < 2; side++) {
+    if (!(side ? north_edge : south_edge)) continue;
+    const int code = o_lbc(p, side ? LBS_NORTH : LBS_SOUTH, LBV_ZETA);
+    const int jb = side ? Jend + 1 : Jstr - 1, j1 = side ? Jend : Jstr;
+    for (int i = Istr; i <= Iend; i++) {
+      if (code == LBC_CHAPMAN_IMPLICIT) {
+        const double cff = dt2d * pn(i, j1);
+        const double cff1 = sqrt(p->g * (h(i, j1) + zeta(i, j1, know)));
+        const double Ce = cff * cff1;
+        const double cff2 = 1.0 / (1.0 + Ce);
+        zeta(i, jb, kout) = cff2 * (zeta(i, jb, know) + Ce * zeta(i, j1, kout));
+      } else if (code == LBC_CLAMPED) zeta(i, jb, kout) = zeta_bry(i, jb);
+      else zeta(i, jb, kout) = zeta(i, j1, kout);                   /* gradient, closed */
+      if (mk) zeta(i, jb, kout) = zeta(i, jb, kout) * rmask(i, jb);
+    }
   }
 }
 
-/* u2dbc_tile, closed S/N -- ROMS/Nonlinear/u2dbc_im.F:51 */
+/* u2dbc_tile, S/N edges (tangential component) -- ROMS/Nonlinear/u2dbc_im.F:829-1140: clamped (:934, :1092),
+ * gradient (:947, :1105), closed = slipperiness gamma2 (:960, :1118) */
 void o_u2dbc(OARGS, int kout)
 {
   ORACLE_PROLOGUE
   (void)s;
-  const int Imin = EWperiodic ? IstrU : Istr, Imax = EWperiodic ? Iend : IendR;
-  const int mk = p->masking;           /* MASKING, u2dbc_im.F:975, :1133 */
-  if (south_edge) for (int i = Imin; i <= Imax; i++) {
-    ubar(i, Jstr - 1, kout) = p->gamma2 * ubar(i, Jstr, kout);
-    if (mk) ubar(i, Jstr - 1, kout) = ubar(i, Jstr - 1, kout) * umask(i, Jstr - 1);
-  }
-  if (north_edge) for (int i = Imin; i <= Imax; i++) {
-    ubar(i, Jend + 1, kout) = p->gamma2 * ubar(i, Jend, kout);
-    if (mk) ubar(i, Jend + 1, kout) = ubar(i, Jend + 1, kout) * umask(i, Jend + 1);
+  const int mk = p->masking;
+  for (int side = 0; side < 2; side++) {
+    if (!(side ? north_edge : south_edge)) continue;
+    const int code = o_lbc(p, side ? LBS_NORTH : LBS_SOUTH, LBV_UBAR);
+    const int jb = side ? Jend + 1 : Jstr - 1, j1 = side ? Jend : Jstr;
+    int Imin = IstrU, Imax = Iend;
+    if (code == LBC_CLOSED) { Imin = EWperiodic ? IstrU : Istr; Imax = EWperiodic ? Iend : IendR; }
+    for (int i = Imin; i <= Imax; i++) {
+      if (code == LBC_CLAMPED) ubar(i, jb, kout) = ubar_bry(i, jb);
+      else if (code == LBC_GRADIENT) ubar(i, jb, kout) = ubar(i, j1, kout);
+      else ubar(i, jb, kout) = p->gamma2 * ubar(i, j1, kout);
+      if (mk) ubar(i, jb, kout) = ubar(i, jb, kout) * umask(i, jb);
+    }
   }
 }
 
-/* v2dbc_tile, closed S/N -- ROMS/Nonlinear/v2dbc_im.F:52 */
+/* v2dbc_tile, S/N edges (normal component) -- ROMS/Nonlinear/v2dbc_im.F:134-830: Flather (:216, :565) with
+ * bry_val = BOUNDARY%vbar_south/north (no SSH_TIDES), clamped (:366, :715), gradient (:379, :728), closed
+ * (:434, :783) */
 void o_v2dbc(OARGS, int kout)
 {
   ORACLE_PROLOGUE
-  (void)p; (void)s;
-  if (south_edge) for (int i = Istr; i <= Iend; i++) vbar(i, Jstr, kout) = 0.0;
-  if (north_edge) for (int i = Istr; i <= Iend; i++) vbar(i, Jend + 1, kout) = 0.0;
+  const int mk = p->masking;
+  int know; double dt2d;
+  o_know(p, s, &know, &dt2d);
+  for (int side = 0; side < 2; side++) {
+    if (!(side ? north_edge : south_edge)) continue;
+    const int code = o_lbc(p, side ? LBS_NORTH : LBS_SOUTH, LBV_VBAR);
+    const int jb = side ? Jend + 1 : Jstr, j1 = side ? Jend : Jstr + 1;     /* boundary v-row, first interior v-row */
+    const int ja = side ? Jend : Jstr - 1, jc = side ? Jend + 1 : Jstr;     /* the two rho-rows around row jb */
+    for (int i = Istr; i <= Iend; i++) {
+      if (code == LBC_FLATHER) {
+        const double bry_val = vbar_bry(i, jb);
+        const double cff = 1.0 / (0.5 * (h(i, ja) + zeta(i, ja, know) + h(i, jc) + zeta(i, jc, know)));
+        const double Ce = sqrt(p->g * cff);
+        if (side) vbar(i, jb, kout) = bry_val + Ce * (0.5 * (zeta(i, ja, know) + zeta(i, jc, know)) - zeta_bry(i, Jend + 1));
+        else vbar(i, jb, kout) = bry_val - Ce * (0.5 * (zeta(i, ja, know) + zeta(i, jc, know)) - zeta_bry(i, Jstr - 1));
+      } else if (code == LBC_CLAMPED) vbar(i, jb, kout) = vbar_bry(i, jb);
+      else if (code == LBC_GRADIENT) vbar(i, jb, kout) = vbar(i, j1, kout);
+      else vbar(i, jb, kout) = 0.0;
+      if (mk && code != LBC_CLOSED) vbar(i, jb, kout) = vbar(i, jb, kout) * vmask(i, jb);
+    }
+  }
 }
 
-/* u3dbc_tile, closed S/N -- ROMS/Nonlinear/u3dbc_im.F:50 */
+/* Implicit upstream radiation condition on a southern / northern edge, the form shared by u3dbc_im.F:381-463 /
+ * :539-621, v3dbc_im.F:97-180 / :239-322 and t3dbc_im.F:364-443 / :498-577 without nudging and without
+ * RADIATION_2D (Cx = 0).  xb_old = X(i,jb,nstp); x1_old, x1 = X(i,j1,nstp), X(i,j1,nout); x2 = X(i,j2,nout);
+ * gL, gR = the two along-boundary differences of X(:,j1,nstp) on either side of point i. */
+static double o_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR)
+{
+  const double eps = 1.0E-20;
+  double dXdt = x1_old - x1;
+  const double dXde = x1 - x2;
+  if ((dXdt * dXde) < 0.0) dXdt = 0.0;
+  const double dXdx = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
+  const double cff = MAX(dXdx * dXdx + dXde * dXde, eps);
+  const double Ce = dXdt * dXde;
+  return (cff * xb_old + Ce * x1) / (cff + Ce);
+}
+
+/* u3dbc_tile, S/N edges -- ROMS/Nonlinear/u3dbc_im.F:379-700 */
 void o_u3dbc(OARGS, int nout)
 {
   ORACLE_PROLOGUE
-  (void)s;
-  const int Imin = EWperiodic ? IstrU : Istr, Imax = EWperiodic ? Iend : IendR;
-  const int mk = p->masking;           /* MASKING, u3dbc_im.F:520, :678 */
-  for (int k = 1; k <= N; k++) {
-    if (south_edge) for (int i = Imin; i <= Imax; i++) {
-      u(i, Jstr - 1, k, nout) = p->gamma2 * u(i, Jstr, k, nout);
-      if (mk) u(i, Jstr - 1, k, nout) = u(i, Jstr - 1, k, nout) * umask(i, Jstr - 1);
-    }
-    if (north_edge) for (int i = Imin; i <= Imax; i++) {
-      u(i, Jend + 1, k, nout) = p->gamma2 * u(i, Jend, k, nout);
-      if (mk) u(i, Jend + 1, k, nout) = u(i, Jend + 1, k, nout) * umask(i, Jend + 1);
-    }
+  const int mk = p->masking, nstp = s->nstp;
+  for (int side = 0; side < 2; side++) {
+    if (!(side ? north_edge : south_edge)) continue;
+    const int code = o_lbc(p, side ? LBS_NORTH : LBS_SOUTH, LBV_U);
+    const int jb = side ? Jend + 1 : Jstr - 1, j1 = side ? Jend : Jstr, j2 = side ? Jend - 1 : Jstr + 1;
+    int Imin = IstrU, Imax = Iend;
+    if (code == LBC_CLOSED) { Imin = EWperiodic ? IstrU : Istr; Imax = EWperiodic ? Iend : IendR; }
+    for (int k = 1; k <= N; k++)
+      for (int i = Imin; i <= Imax; i++) {
+        if (code == LBC_RADIATION)
+          u(i, jb, k, nout) = o_radiate(u(i, jb, k, nstp), u(i, j1, k, nstp), u(i, j1, k, nout), u(i, j2, k, nout),
+                                        u(i, j1, k, nstp) - u(i - 1, j1, k, nstp), u(i + 1, j1, k, nstp) - u(i, j1, k, nstp));
+        else if (code == LBC_CLAMPED) u(i, jb, k, nout) = u_bry(i, jb, k);
+        else if (code == LBC_GRADIENT) u(i, jb, k, nout) = u(i, j1, k, nout);
+        else u(i, jb, k, nout) = p->gamma2 * u(i, j1, k, nout);
+        if (mk) u(i, jb, k, nout) = u(i, jb, k, nout) * umask(i, jb);
+      }
   }
 }
 
-/* v3dbc_tile, closed S/N -- ROMS/Nonlinear/v3dbc_im.F:50 */
+/* v3dbc_tile, S/N edges -- ROMS/Nonlinear/v3dbc_im.F:95-380 */
 void o_v3dbc(OARGS, int nout)
 {
   ORACLE_PROLOGUE
-  (void)p; (void)s;
-  for (int k = 1; k <= N; k++) {
-    if (south_edge) for (int i = Istr; i <= Iend; i++) v(i, Jstr, k, nout) = 0.0;
-    if (north_edge) for (int i = Istr; i <= Iend; i++) v(i, Jend + 1, k, nout) = 0.0;
+  const int mk = p->masking, nstp = s->nstp;
+  for (int side = 0; side < 2; side++) {
+    if (!(side ? north_edge : south_edge)) continue;
+    const int code = o_lbc(p, side ? LBS_NORTH : LBS_SOUTH, LBV_V);
+    const int jb = side ? Jend + 1 : Jstr, j1 = side ? Jend : Jstr + 1, j2 = side ? Jend - 1 : Jstr + 2;
+    for (int k = 1; k <= N; k++)
+      for (int i = Istr; i <= Iend; i++) {
+        if (code == LBC_RADIATION)
+          v(i, jb, k, nout) = o_radiate(v(i, jb, k, nstp), v(i, j1, k, nstp), v(i, j1, k, nout), v(i, j2, k, nout),
+                                        v(i, j1, k, nstp) - v(i - 1, j1, k, nstp), v(i + 1, j1, k, nstp) - v(i, j1, k, nstp));
+        else if (code == LBC_CLAMPED) v(i, jb, k, nout) = v_bry(i, jb, k);
+        else if (code == LBC_GRADIENT) v(i, jb, k, nout) = v(i, j1, k, nout);
+        else v(i, jb, k, nout) = 0.0;
+        if (mk && code != LBC_CLOSED) v(i, jb, k, nout) = v(i, jb, k, nout) * vmask(i, jb);
+      }
   }
 }
 
-/* t3dbc_tile, closed S/N (zero gradient) -- ROMS/Nonlinear/t3dbc_im.F:50 */
+/* t3dbc_tile, S/N edges -- ROMS/Nonlinear/t3dbc_im.F:362-630 (MASKING: the along-boundary differences of the
+ * radiation condition are multiplied by umask, :370-379) */
 void o_t3dbc(OARGS, int nout, int itrc)
 {
   ORACLE_PROLOGUE
-  (void)s;
-  const int mk = p->masking;           /* MASKING, t3dbc_im.F:483, :617 */
-  for (int k = 1; k <= N; k++) {
-    if (south_edge) for (int i = Istr; i <= Iend; i++) {
-      t(i, Jstr - 1, k, nout, itrc) = t(i, Jstr, k, nout, itrc);
-      if (mk) t(i, Jstr - 1, k, nout, itrc) = t(i, Jstr - 1, k, nout, itrc) * rmask(i, Jstr - 1);
-    }
-    if (north_edge) for (int i = Istr; i <= Iend; i++) {
-      t(i, Jend + 1, k, nout, itrc) = t(i, Jend, k, nout, itrc);
-      if (mk) t(i, Jend + 1, k, nout, itrc) = t(i, Jend + 1, k, nout, itrc) * rmask(i, Jend + 1);
-    }
+  const int mk = p->masking, nstp = s->nstp;
+  for (int side = 0; side < 2; side++) {
+    if (!(side ? north_edge : south_edge)) continue;
+    const int code = o_lbc(p, side ? LBS_NORTH : LBS_SOUTH, LBV_T);
+    const int jb = side ? Jend + 1 : Jstr - 1, j1 = side ? Jend : Jstr, j2 = side ? Jend - 1 : Jstr + 1;
+    for (int k = 1; k <= N; k++)
+      for (int i = Istr; i <= Iend; i++) {
+        if (code == LBC_RADIATION) {
+          double gL = t(i, j1, k, nstp, itrc) - t(i - 1, j1, k, nstp, itrc);
+          double gR = t(i + 1, j1, k, nstp, itrc) - t(i, j1, k, nstp, itrc);
+          if (mk) { gL = gL * umask(i, j1); gR = gR * umask(i + 1, j1); }
+          t(i, jb, k, nout, itrc) = o_radiate(t(i, jb, k, nstp, itrc), t(i, j1, k, nstp, itrc), t(i, j1, k, nout, itrc),
+                                              t(i, j2, k, nout, itrc), gL, gR);
+        } else if (code == LBC_CLAMPED) t(i, jb, k, nout, itrc) = t_bry(i, jb, k, itrc);
+        else t(i, jb, k, nout, itrc) = t(i, j1, k, nout, itrc);          /* gradient, closed */
+        if (mk) t(i, jb, k, nout, itrc) = t(i, jb, k, nout, itrc) * rmask(i, jb);
+      }
   }
 }
 

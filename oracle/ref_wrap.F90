@@ -48,6 +48,7 @@ MODULE ref_wrap_types
     INTEGER(c_int) :: uv_drag, mpdata_fast
     REAL(c_double) :: blk_ZQ, blk_ZT, blk_ZW
     INTEGER(c_int) :: masking, pad_masking
+    INTEGER(c_int) :: lbc(6,4)          ! C: lbc[side][variable]
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -65,6 +66,7 @@ MODULE ref_wrap_types
     TYPE(c_ptr) :: lrflx, lhflx, shflx, evap, hsbl, rdrag
     TYPE(c_ptr) :: wvel, lonr, latr
     TYPE(c_ptr) :: rmask, umask, vmask, pmask
+    TYPE(c_ptr) :: zeta_bry, ubar_bry, vbar_bry, u_bry, v_bry, t_bry
   END TYPE fields_t
   LOGICAL, SAVE :: have_boundary = .FALSE.      ! allocate_boundary is done once per process
 END MODULE ref_wrap_types

@@ -16,12 +16,15 @@ ROMS_MAXNT = 16
 ROMS_MAXFAST = 256
 
 KINDS = ["K_2D", "K_2D_T2", "K_2D_T3", "K_2D_NT", "K_3DR", "K_3DW",
-         "K_3DR_T2", "K_3DW_T2", "K_3DW_NAT", "K_4DT"]
+         "K_3DR_T2", "K_3DW_T2", "K_3DW_NAT", "K_4DT", "K_3DR_NT"]
 
 # enum roms_adv (T_ADV logical records, ROMS/Modules/mod_param.F:382-394)
 ADV = {"C2": 0, "C4": 1, "A4": 2, "U3": 3, "SU3": 4, "SPLINES": 5,
        "MPDATA": 6, "HSIMT": 7}
-LBC_PERIODIC, LBC_CLOSED = 0, 1
+LBC_PERIODIC, LBC_CLOSED, LBC_GRADIENT, LBC_CLAMPED, LBC_CHAPMAN_IMPLICIT, LBC_FLATHER, LBC_RADIATION = range(7)
+LBC = {"Per": 0, "Clo": 1, "Gra": 2, "Cla": 3, "Cha": 4, "Fla": 5, "Rad": 6}      # the keywords of roms_*.in
+LBV = {"zeta": 0, "ubar": 1, "vbar": 2, "u": 3, "v": 4, "t": 5}
+LBS = {"west": 0, "east": 1, "south": 2, "north": 3}
 
 
 def _parse_fields():
@@ -45,7 +48,7 @@ def trailing_shape(kind, N, NT, NAT):
     return {
         "K_2D": (), "K_2D_T2": (2,), "K_2D_T3": (3,), "K_2D_NT": (NT,),
         "K_3DR": (N,), "K_3DW": (N + 1,), "K_3DR_T2": (N, 2),
-        "K_3DW_T2": (N + 1, 2), "K_3DW_NAT": (N + 1, NAT), "K_4DT": (N, 3, NT),
+        "K_3DW_T2": (N + 1, 2), "K_3DW_NAT": (N + 1, NAT), "K_4DT": (N, 3, NT), "K_3DR_NT": (N, NT),
     }[kind]
 
 
@@ -96,6 +99,7 @@ class Params(C.Structure):
         ("uv_drag", C.c_int), ("mpdata_fast", C.c_int),
         ("blk_ZQ", C.c_double), ("blk_ZT", C.c_double), ("blk_ZW", C.c_double),
         ("masking", C.c_int), ("pad_masking_", C.c_int),
+        ("lbc", (C.c_int * 6) * 4),
     ]
 
 

@@ -37,6 +37,7 @@ long roms_field_count(int kind, const roms_bounds_t &b)
   case K_3DW_T2:  return nij * (b.N + 1) * 2;
   case K_3DW_NAT: return nij * (b.N + 1) * b.NAT;
   case K_4DT:     return nij * b.N * 3 * b.NT;
+  case K_3DR_NT:  return nij * b.N * b.NT;
   }
   return -1;
 }

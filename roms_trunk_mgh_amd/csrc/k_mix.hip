@@ -172,11 +172,8 @@ k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
 
 }  // namespace
 
-extern "C" int roms_hip_t3dmix2(const roms_step_idx_t *s)
+static int t3dmix2_launch(const roms_step_idx_t *s)
 {
-  int rc = roms_entry_check("roms_hip_t3dmix2");
-  if (rc) return rc;
-  ScopedTimer tm("t3dmix2");
   const roms_bounds_t &b = g_ctx.b;
   const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, b.NT);
   if (g_ctx.p.mix_geo_ts)
@@ -187,4 +184,12 @@ extern "C" int roms_hip_t3dmix2(const roms_step_idx_t *s)
     return roms_fail("roms_hip_t3dmix2", "no tracer mixing option (MIX_GEO_TS / MIX_S_TS) selected");
   KERNEL_CHECK("k_t3dmix2");
   return 0;
+}
+
+extern "C" int roms_hip_t3dmix2(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_t3dmix2");
+  if (rc) return rc;
+  ScopedTimer tm("t3dmix2");
+  return t3dmix2_launch(s);
 }

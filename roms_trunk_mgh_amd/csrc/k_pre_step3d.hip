@@ -225,8 +225,14 @@ k_pre_uv(const RomsDev *__restrict__ c, int nstp, int nnew, int nrhs, int stage)
       if (k == N) FCk = dt * sstr;
       else {
         vk1 = vel[ck + nij];
-        const double cz = 1.0 / (z_r[ck + nij] + z_r[ck + nij - off] - z_r[ck] - z_r[ck - off]);
-        FCk = cff3 * cz * (vk1 - vk) * (Akv[ck + nij] + Akv[ck + nij - off]);
+        if (cff3 != 0.0) {
+          const double cz = 1.0 / (z_r[ck + nij] + z_r[ck + nij - off] - z_r[ck] - z_r[ck - off]);
+          FCk = cff3 * cz * (vk1 - vk) * (Akv[ck + nij] + Akv[ck + nij - off]);
+        } else {
+          // lambda = 1 (fully implicit vertical viscosity, every shipped application): the explicit flux is
+          // cff3 * (...) = +-0; z_r and Akv need not be read (a zero of either sign gives the same sums)
+          FCk = 0.0;
+        }
       }
       const double hzs = Hz[ck] + Hz[ck - off];
       const double d = FCk - FCprev;
@@ -281,16 +287,14 @@ int launch_pre_t(const roms_step_idx_t *s, int itrc0, int ntr)
 
 }  // namespace
 
-extern "C" int roms_hip_pre_step3d(const roms_step_idx_t *s)
+// The tracer half of pre_step3d_tile (pre_step3d.F:342-915 and the tracer part of :917-1145): t(3), t(nnew),
+// then t3dbc_tile(nout = 3) and the periodic wrap / mp_exchange4d of t(3).
+static int pre_step3d_tracers(const roms_step_idx_t *s)
 {
-  int rc = roms_entry_check("roms_hip_pre_step3d");
-  if (rc) return rc;
-  if ((rc = check_lbc())) return rc;
   const roms_bounds_t &b = g_ctx.b;
   const roms_params_t &p = g_ctx.p;
-  if (b.N < 4) return roms_fail("roms_hip_pre_step3d", "N < 4");
+  int rc = 0;
   {
-    ScopedTimer tm("pre_step3d");
     int it = 1;
     while (it <= b.NT) {
       const int ha = p.Hadv[it - 1], va = p.Vadv[it - 1];
@@ -315,10 +319,6 @@ extern "C" int roms_hip_pre_step3d(const roms_step_idx_t *s)
       if (rc) return rc;
       it += n;
     }
-    const int stage = (s->iic == s->ntfirst) ? 0 : (s->iic == s->ntfirst + 1 ? 1 : 2);
-    hipLaunchKernelGGL(k_pre_uv, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
-                       g_ctx.devc, s->nstp, s->nnew, s->nrhs, stage);
-    KERNEL_CHECK("k_pre_uv");
   }
   // t3dbc_tile(nout=3) + periodic wrap / mp_exchange4d, pre_step3d.F:1131-1145
   const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
@@ -327,4 +327,27 @@ extern "C" int roms_hip_pre_step3d(const roms_step_idx_t *s)
   halo_batch_begin();
   for (int it = 1; it <= b.NT; it++) halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + (2L + 3L * (it - 1)) * n3r);
   return halo_batch_end();
+}
+
+// The momentum half: u, v(nnew) of the predictor (pre_step3d.F:1012-1120)
+static int pre_step3d_uv(const roms_step_idx_t *s)
+{
+  const roms_bounds_t &b = g_ctx.b;
+  const int stage = (s->iic == s->ntfirst) ? 0 : (s->iic == s->ntfirst + 1 ? 1 : 2);
+  hipLaunchKernelGGL(k_pre_uv, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                     g_ctx.devc, s->nstp, s->nnew, s->nrhs, stage);
+  KERNEL_CHECK("k_pre_uv");
+  return 0;
+}
+
+extern "C" int roms_hip_pre_step3d(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_pre_step3d");
+  if (rc) return rc;
+  if ((rc = check_lbc())) return rc;
+  if (g_ctx.b.N < 4) return roms_fail("roms_hip_pre_step3d", "N < 4");
+  ScopedTimer tm("pre_step3d");
+  // (the reference does the tracers first; the two halves share no output)
+  if ((rc = pre_step3d_uv(s))) return rc;
+  return pre_step3d_tracers(s);
 }

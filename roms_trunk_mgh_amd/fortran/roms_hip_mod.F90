@@ -69,6 +69,7 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: uv_drag, mpdata_fast
     REAL(c_double) :: blk_ZQ, blk_ZT, blk_ZW
     INTEGER(c_int) :: masking, pad_masking
+    INTEGER(c_int) :: lbc(6,4)          ! C: lbc[side][variable]
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)
@@ -94,7 +95,8 @@ MODULE roms_hip_mod
  &    FID_rdrag2=68, FID_stflux=69, FID_btflux=70, FID_Uwind=71, FID_Vwind=72, FID_Tair=73,  &
  &    FID_Pair=74, FID_Hair=75, FID_rain=76, FID_cloud=77, FID_lrflx=78, FID_lhflx=79,      &
  &    FID_shflx=80, FID_evap=81, FID_hsbl=82, FID_rdrag=83, FID_wvel=84, FID_lonr=85, FID_latr=86,   &
- &    FID_rmask=87, FID_umask=88, FID_vmask=89, FID_pmask=90
+ &    FID_rmask=87, FID_umask=88, FID_vmask=89, FID_pmask=90, FID_zeta_bry=91, FID_ubar_bry=92,   &
+ &    FID_vbar_bry=93, FID_u_bry=94, FID_v_bry=95, FID_t_bry=96
 
   INTERFACE
     INTEGER(c_int) FUNCTION roms_hip_init (rank, ntileI, ntileJ, device_id, uid)            &

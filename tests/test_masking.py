@@ -115,7 +115,8 @@ def test_hip_kernels_on_masked_grid(config, kernel):
     from roms_trunk_mgh_amd import hip
     if kernel == "uv3dmix2" and config == "SEAMOUNT":
         pytest.skip("SEAMOUNT has no UV_VIS2")
-    st0 = util.prepared_state(config, mask="island")
+    # (UPWELLING and SEAMOUNT ship with TNU2 = 0: give the mixing kernel something to do)
+    st0 = util.prepared_state(config, mask="island", overrides={"tnu2": 300.0} if kernel == "t3dmix2" else None)
     if kernel == "step3d_t":
         util.hz_weighted_tnew(st0)
     if kernel in ("set_massflux", "omega", "set_depth", "set_zeta"):      # make their inputs inconsistent with their outputs
