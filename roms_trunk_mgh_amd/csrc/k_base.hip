@@ -8,60 +8,139 @@
 
 int roms_entry_check(const char *name);
 
+// Effective boundary-condition code (enum roms_lbc) of variable v (enum roms_lbc_var) on side sd.
+static int lbc_code(const roms_params_t &p, int sd, int v)
+{
+  if (p.lbc[sd][v]) return p.lbc[sd][v];
+  return sd == LBS_WEST ? p.lbc_west : sd == LBS_EAST ? p.lbc_east : sd == LBS_SOUTH ? p.lbc_south : p.lbc_north;
+}
+
+// West/east periodic; south/north per variable: closed, gradient, clamped, Chapman implicit (zeta), Flather
+// (vbar), radiation (u, v, tracers).
 int check_lbc()
 {
   const roms_bounds_t &b = g_ctx.b;
   const roms_params_t &p = g_ctx.p;
-  if (!b.EWperiodic || b.NSperiodic || p.lbc_south != LBC_CLOSED || p.lbc_north != LBC_CLOSED)
-    return roms_fail("check_lbc", "only LBC == Per Clo Per Clo is implemented on this path");
+  if (!b.EWperiodic || b.NSperiodic)
+    return roms_fail("check_lbc", "only E-W periodic grids with physical S/N edges are implemented on this path");
+  for (int sd = LBS_SOUTH; sd <= LBS_NORTH; sd++)
+    for (int v = 0; v < LBV_COUNT; v++) {
+      const int c = lbc_code(p, sd, v);
+      bool ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED;
+      if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT;
+      if (v == LBV_VBAR) ok = ok || c == LBC_FLATHER;
+      if (v >= LBV_U) ok = ok || c == LBC_RADIATION;
+      if (!ok) return roms_fail("check_lbc", "lateral boundary condition not implemented for this variable");
+    }
   return 0;
 }
 
+// every 2-D variable closed on both S/N edges: step2d may apply the conditions inside its fused kernel
+bool lbc2d_all_closed()
+{
+  const roms_params_t &p = g_ctx.p;
+  for (int sd = LBS_SOUTH; sd <= LBS_NORTH; sd++)
+    for (int v = LBV_ZETA; v <= LBV_VBAR; v++)
+      if (lbc_code(p, sd, v) != LBC_CLOSED) return false;
+  return true;
+}
+
 // ---------------------------------------------------------------------------
-// Closed S/N walls.  mode: 0 zero-gradient rho-type (zetabc.F:48, t3dbc_im.F:50,
-// bc_3d.F:588), 1 tangential u (gamma2 slip; u2dbc_im.F:51, u3dbc_im.F:50),
-// 2 normal v = 0 (v2dbc_im.F:52, v3dbc_im.F:50).  A points at the (i,j,k=first)
-// plane of the wanted time level; nk planes are processed.  masked (MASKING applications): the boundary
-// value is multiplied by the land/sea mask of the boundary point -- rmask for zeta and tracers
-// (zetabc.F:540, t3dbc_im.F:483), umask for the tangential velocity (u2dbc_im.F:975, u3dbc_im.F:520);
-// bc_w3d_tile has no mask.
+// Lateral boundary conditions on the southern / northern edge, one launch per variable:
+//   zetabc.F:404-700, u2dbc_im.F:829-1140, v2dbc_im.F:134-830, u3dbc_im.F:379-700, v3dbc_im.F:95-380,
+//   t3dbc_im.F:362-630 -- closed, gradient, clamped, Chapman implicit, Flather, radiation (implicit upstream,
+//   no nudging, no RADIATION_2D); bc_w3d_tile (bc_3d.F:588) = gradient without mask.
+// X = the (i,j,k) array of the wanted time level `out`; Xold = the same variable at the level the condition
+// reads (know for the 2-D conditions, nstp for radiation); D = boundary data (clamped, Flather).
 // ---------------------------------------------------------------------------
-__global__ void k_wall_bc(const RomsDev *__restrict__ c, double *__restrict__ A, int nk, int mode, int masked)
+struct BcArgs {
+  double *X;             // level written (kout / nout)
+  const double *Xold;    // zeta: zeta(know); radiation: X(nstp)
+  const double *D;       // boundary data of this variable (or nullptr)
+  const double *Z, *Zb;  // Flather: zeta(know), zeta_bry
+  int var;               // enum roms_lbc_var; -1 = bc_w3d (gradient, no mask)
+  int code_s, code_n;    // enum roms_lbc on the southern / northern edge
+  int nk, masked;
+  double dt2d;
+};
+
+__device__ __forceinline__ double bc_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR)
+{
+  const double eps = 1.0E-20;
+  double dXdt = x1_old - x1;
+  const double dXde = x1 - x2;
+  if ((dXdt * dXde) < 0.0) dXdt = 0.0;
+  const double dXdx = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
+  const double cff = fmax(dXdx * dXdx + dXde * dXde, eps);
+  const double Ce = dXdt * dXde;
+  return (cff * xb_old + Ce * x1) / (cff + Ce);
+}
+
+__global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
 {
   DEV_PROLOGUE(c)
   const int k = blockIdx.y;
-  if (k >= nk) return;
-  int i0, i1;
-  if (mode == 1) { i0 = b.EWperiodic ? b.IstrU : b.Istr; i1 = b.EWperiodic ? b.Iend : b.IendR; }
-  else { i0 = b.Istr; i1 = b.Iend; }
+  if (k >= a.nk) return;
+  const roms_params_t &p = c->p;
+  const int side = blockIdx.z;                      // 0 south, 1 north
+  if (!(side ? b.north_edge : b.south_edge)) return;
+  const int code = side ? a.code_n : a.code_s;
+  const bool utype = a.var == LBV_UBAR || a.var == LBV_U, vtype = a.var == LBV_VBAR || a.var == LBV_V;
+  int i0 = b.Istr, i1 = b.Iend;
+  if (utype) {
+    i0 = b.IstrU;
+    if (code == LBC_CLOSED) { i0 = b.EWperiodic ? b.IstrU : b.Istr; i1 = b.EWperiodic ? b.Iend : b.IendR; }
+  }
   const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (i > i1) return;
-  double *P = A + (long)k * nij;
-  const double g2 = c->p.gamma2;
-  const double *M = mode == 0 ? c->F.rmask : c->F.umask;
-  if (b.south_edge) {
-    const long q = I2(i, b.Jstr - 1);
-    if (mode == 0) { double x = P[I2(i, b.Jstr)]; if (masked) x = x * M[q]; P[q] = x; }
-    else if (mode == 1) { double x = g2 * P[I2(i, b.Jstr)]; if (masked) x = x * M[q]; P[q] = x; }
-    else P[I2(i, b.Jstr)] = 0.0;
+  // boundary row jb, first and second interior rows j1, j2
+  int jb, j1, j2;
+  if (vtype) { jb = side ? b.Jend + 1 : b.Jstr; j1 = side ? b.Jend : b.Jstr + 1; j2 = side ? b.Jend - 1 : b.Jstr + 2; }
+  else { jb = side ? b.Jend + 1 : b.Jstr - 1; j1 = side ? b.Jend : b.Jstr; j2 = side ? b.Jend - 1 : b.Jstr + 1; }
+  const long kb = (long)k * nij;
+  double *X = a.X + kb;
+  const long qb = I2(i, jb), q1 = I2(i, j1);
+  double x;
+  if (code == LBC_RADIATION) {
+    const double *O = a.Xold + kb;
+    double gL = O[q1] - O[q1 - 1], gR = O[q1 + 1] - O[q1];
+    if (a.masked && a.var == LBV_T) { gL = gL * c->F.umask[q1]; gR = gR * c->F.umask[q1 + 1]; }   // t3dbc_im.F:370-379
+    x = bc_radiate(O[qb], O[q1], X[q1], X[I2(i, j2)], gL, gR);
+  } else if (code == LBC_CLAMPED) {
+    x = a.D[qb + kb];
+  } else if (code == LBC_CHAPMAN_IMPLICIT) {        // zetabc.F:489-506, :638-655
+    const double cff = a.dt2d * c->F.pn[q1];
+    const double cff1 = sqrt(p.g * (c->F.h[q1] + a.Xold[q1]));
+    const double Ce = cff * cff1;
+    const double cff2 = 1.0 / (1.0 + Ce);
+    x = cff2 * (a.Xold[qb] + Ce * X[q1]);
+  } else if (code == LBC_FLATHER) {                 // v2dbc_im.F:216-286, :565-635 (bry_val = vbar_south / vbar_north)
+    const long qa = I2(i, side ? b.Jend : b.Jstr - 1), qc = I2(i, side ? b.Jend + 1 : b.Jstr);
+    const double bry_val = a.D[qb];
+    const double cff = 1.0 / (0.5 * (c->F.h[qa] + a.Z[qa] + c->F.h[qc] + a.Z[qc]));
+    const double Ce = sqrt(p.g * cff);
+    const double zb = a.Zb[side ? I2(i, b.Jend + 1) : I2(i, b.Jstr - 1)];
+    x = side ? bry_val + Ce * (0.5 * (a.Z[qa] + a.Z[qc]) - zb) : bry_val - Ce * (0.5 * (a.Z[qa] + a.Z[qc]) - zb);
+  } else if (code == LBC_GRADIENT) {
+    x = X[q1];
+  } else {                                          // closed
+    x = vtype ? 0.0 : (utype ? p.gamma2 * X[q1] : X[q1]);
   }
-  if (b.north_edge) {
-    const long q = I2(i, b.Jend + 1);
-    if (mode == 0) { double x = P[I2(i, b.Jend)]; if (masked) x = x * M[q]; P[q] = x; }
-    else if (mode == 1) { double x = g2 * P[I2(i, b.Jend)]; if (masked) x = x * M[q]; P[q] = x; }
-    else P[q] = 0.0;
+  if (a.masked && !(vtype && code == LBC_CLOSED)) {
+    const double *M = utype ? c->F.umask : (vtype ? c->F.vmask : c->F.rmask);
+    x = x * M[qb];
   }
+  X[qb] = x;
 }
 
-static int wall_bc(double *A, int nk, int mode, bool maskable = true)
+static int edge_bc(BcArgs a)
 {
   const roms_bounds_t &b = g_ctx.b;
   if (!b.south_edge && !b.north_edge) return 0;
   const int nx = b.Iend - b.Istr + 2;
-  dim3 grid((nx + 255) / 256, nk);
-  hipLaunchKernelGGL(k_wall_bc, grid, dim3(256), 0, g_ctx.stream, g_ctx.devc, A, nk, mode,
-                     (int)(maskable && g_ctx.p.masking));
-  KERNEL_CHECK("k_wall_bc");
+  dim3 grid((nx + 255) / 256, a.nk, 2);
+  hipLaunchKernelGGL(k_edge_bc, grid, dim3(256), 0, g_ctx.stream, g_ctx.devc, a);
+  KERNEL_CHECK("k_edge_bc");
   return 0;
 }
 
@@ -71,19 +150,82 @@ static inline long nij_host()
   return (long)(b.UBi - b.LBi + 1) * (long)(b.UBj - b.LBj + 1);
 }
 
-int bc_zeta(int kout) { return wall_bc(g_ctx.dev[FID_zeta] + (long)(kout - 1) * nij_host(), 1, 0); }
-int bc_u2d(int kout)  { return wall_bc(g_ctx.dev[FID_ubar] + (long)(kout - 1) * nij_host(), 1, 1); }
-int bc_v2d(int kout)  { return wall_bc(g_ctx.dev[FID_vbar] + (long)(kout - 1) * nij_host(), 1, 2); }
-int bc_u3d(int nout)  { return wall_bc(g_ctx.dev[FID_u] + (long)(nout - 1) * nij_host() * g_ctx.b.N, g_ctx.b.N, 1); }
-int bc_v3d(int nout)  { return wall_bc(g_ctx.dev[FID_v] + (long)(nout - 1) * nij_host() * g_ctx.b.N, g_ctx.b.N, 2); }
-int bc_t3d(int nout, int itrc)
+static BcArgs bc_args(int var, double *X, int nk)
+{
+  BcArgs a{};
+  a.X = X; a.var = var; a.nk = nk;
+  a.masked = g_ctx.p.masking != 0;
+  if (var >= 0) { a.code_s = lbc_code(g_ctx.p, LBS_SOUTH, var); a.code_n = lbc_code(g_ctx.p, LBS_NORTH, var); }
+  else { a.code_s = a.code_n = LBC_GRADIENT; a.masked = 0; }
+  return a;
+}
+
+// the time level `know` and the step dt2d of the 2-D conditions (zetabc.F:96-106)
+static void bc_know(const roms_step_idx_t *s, int *know, double *dt2d)
+{
+  const double dtfast = g_ctx.p.dtfast;
+  if (s->iif == 1) { *know = s->krhs; *dt2d = dtfast; }
+  else if (s->predictor_2d_step) { *know = s->krhs; *dt2d = 2.0 * dtfast; }
+  else { *know = s->kstp; *dt2d = dtfast; }
+}
+
+int bc_zeta(int kout, const roms_step_idx_t *s)
+{
+  BcArgs a = bc_args(LBV_ZETA, g_ctx.dev[FID_zeta] + (long)(kout - 1) * nij_host(), 1);
+  int know = kout; double dt2d = 0.0;
+  if (s) bc_know(s, &know, &dt2d);
+  else if (a.code_s == LBC_CHAPMAN_IMPLICIT || a.code_n == LBC_CHAPMAN_IMPLICIT)
+    return roms_fail("bc_zeta", "the Chapman condition needs the barotropic time indices");
+  a.Xold = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
+  a.D = g_ctx.dev[FID_zeta_bry];
+  a.dt2d = dt2d;
+  return edge_bc(a);
+}
+int bc_u2d(int kout)
+{
+  BcArgs a = bc_args(LBV_UBAR, g_ctx.dev[FID_ubar] + (long)(kout - 1) * nij_host(), 1);
+  a.D = g_ctx.dev[FID_ubar_bry];
+  return edge_bc(a);
+}
+int bc_v2d(int kout, const roms_step_idx_t *s)
+{
+  BcArgs a = bc_args(LBV_VBAR, g_ctx.dev[FID_vbar] + (long)(kout - 1) * nij_host(), 1);
+  int know = kout; double dt2d = 0.0;
+  if (s) bc_know(s, &know, &dt2d);
+  else if (a.code_s == LBC_FLATHER || a.code_n == LBC_FLATHER)
+    return roms_fail("bc_v2d", "the Flather condition needs the barotropic time indices");
+  a.D = g_ctx.dev[FID_vbar_bry];
+  a.Z = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
+  a.Zb = g_ctx.dev[FID_zeta_bry];
+  return edge_bc(a);
+}
+int bc_u3d(int nout, int nstp)
 {
   const long n3r = nij_host() * g_ctx.b.N;
-  return wall_bc(g_ctx.dev[FID_t] + ((long)(nout - 1) + 3L * (itrc - 1)) * n3r, g_ctx.b.N, 0);
+  BcArgs a = bc_args(LBV_U, g_ctx.dev[FID_u] + (long)(nout - 1) * n3r, g_ctx.b.N);
+  a.Xold = g_ctx.dev[FID_u] + (long)(nstp - 1) * n3r;
+  a.D = g_ctx.dev[FID_u_bry];
+  return edge_bc(a);
+}
+int bc_v3d(int nout, int nstp)
+{
+  const long n3r = nij_host() * g_ctx.b.N;
+  BcArgs a = bc_args(LBV_V, g_ctx.dev[FID_v] + (long)(nout - 1) * n3r, g_ctx.b.N);
+  a.Xold = g_ctx.dev[FID_v] + (long)(nstp - 1) * n3r;
+  a.D = g_ctx.dev[FID_v_bry];
+  return edge_bc(a);
+}
+int bc_t3d(int nout, int itrc, int nstp)
+{
+  const long n3r = nij_host() * g_ctx.b.N;
+  BcArgs a = bc_args(LBV_T, g_ctx.dev[FID_t] + ((long)(nout - 1) + 3L * (itrc - 1)) * n3r, g_ctx.b.N);
+  a.Xold = g_ctx.dev[FID_t] + ((long)(nstp - 1) + 3L * (itrc - 1)) * n3r;
+  a.D = g_ctx.dev[FID_t_bry] + (long)(itrc - 1) * n3r;
+  return edge_bc(a);
 }
 int bc_w3d(double *A)
 {
-  int rc = wall_bc(A, g_ctx.b.N + 1, 0, false);
+  int rc = edge_bc(bc_args(-1, A, g_ctx.b.N + 1));
   if (rc) return rc;
   return halo_exchange3d(GT_R, g_ctx.b.N + 1, A);
 }

@@ -323,7 +323,7 @@ static int pre_step3d_tracers(const roms_step_idx_t *s)
   // t3dbc_tile(nout=3) + periodic wrap / mp_exchange4d, pre_step3d.F:1131-1145
   const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
   for (int it = 1; it <= b.NT; it++)
-    if ((rc = bc_t3d(3, it))) return rc;
+    if ((rc = bc_t3d(3, it, s->nstp))) return rc;
   halo_batch_begin();
   for (int it = 1; it <= b.NT; it++) halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + (2L + 3L * (it - 1)) * n3r);
   return halo_batch_end();

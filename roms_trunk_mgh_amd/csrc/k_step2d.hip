@@ -258,7 +258,10 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   // the first predictor of a step: there the momentum kernel read-modify-writes
   // rufrc and ru(:,:,0,nstp) at the source points (:1884-2037), which ghost-point
   // threads would race with.
-  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.loopback;
+  // (the fused kernels apply the closed-wall conditions themselves; open S/N edges take the general path below,
+  // whose boundary conditions are separate launches)
+  const bool walls = lbc2d_all_closed();
+  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.loopback && walls;
   if (sm) {
     if (s.iif <= p.nfast) {
       // ONE launch: free surface, fast-time averages and momentum (k2d_mom_lds<true>)
@@ -297,7 +300,7 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
     if ((rc = halo_batch_end())) return rc;
   }
   g_flux_ready = false;
-  if (in_loop && multi && s.iif <= p.nfast) {
+  if (in_loop && multi && walls && s.iif <= p.nfast) {
     // ONE compute launch + ONE exchange per call
     s.sm = 3;
     if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, nullptr, nullptr, DUnext, DVnext))) return rc;
@@ -326,10 +329,10 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
     if ((rc = halo_batch_end())) return rc;
   }
   if (s.iif > p.nfast) return 0;
-  if ((rc = bc_zeta(s.knew))) return rc;
+  if ((rc = bc_zeta(s.knew, si))) return rc;
   if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, zeta_new, zwrk))) return rc;
   if ((rc = bc_u2d(s.knew))) return rc;
-  if ((rc = bc_v2d(s.knew))) return rc;
+  if ((rc = bc_v2d(s.knew, si))) return rc;
   halo_batch_begin();
   if (s.predictor) halo_exchange2d(GT_R, g_ctx.dev[FID_rzeta] + (long)(s.krhs - 1) * nij);
   halo_exchange2d(GT_R, g_ctx.dev[FID_zeta] + (long)(s.knew - 1) * nij);

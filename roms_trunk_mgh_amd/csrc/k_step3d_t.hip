@@ -577,7 +577,7 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
   }
   // t3dbc_tile + periodic wrap / mp_exchange4d, step3d_t.F:1564-1626
   for (int it = 1; it <= b.NT; it++)
-    if ((rc = bc_t3d(s->nnew, it))) return rc;
+    if ((rc = bc_t3d(s->nnew, it, s->nstp))) return rc;
   const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
   halo_batch_begin();
   for (int it = 1; it <= b.NT; it++)

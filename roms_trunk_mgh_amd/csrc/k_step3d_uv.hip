@@ -266,8 +266,8 @@ extern "C" int roms_hip_step3d_uv(const roms_step_idx_t *s)
     else if (b.N <= ROMS_MAXN) hipLaunchKernelGGL(k_uv_column<ROMS_MAXN>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
     else return roms_fail("roms_hip_step3d_uv", "N > 64 not instantiated");
     KERNEL_CHECK("k_uv_column");
-    if ((rc = bc_u3d(s->nnew))) return rc;
-    if ((rc = bc_v3d(s->nnew))) return rc;
+    if ((rc = bc_u3d(s->nnew, s->nstp))) return rc;
+    if ((rc = bc_v3d(s->nnew, s->nstp))) return rc;
     dim3 grid2 = grid2d(b.IendT - b.IstrT + 1, b.JendT - b.JstrT + 1);
     grid2.z = 2;
     if (b.N <= 16) hipLaunchKernelGGL(k_uv_couple<16>, grid2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nnew);

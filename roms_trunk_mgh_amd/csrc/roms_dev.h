@@ -188,12 +188,15 @@ int halo_exchange2d(int gtype, double *A, int nfields_stride_unused = 0);
 int halo_exchange3d(int gtype, int nk, double *A);
 void halo_batch_begin();                  // record the exchanges that follow ...
 int halo_batch_end();                     // ... and run them as one message per neighbour and phase
-int bc_zeta(int kout);
+// lateral boundary conditions on the S/N edges (k_base.hip); s = the barotropic time indices (Chapman, Flather),
+// nstp = the time level the radiation condition compares with
+int bc_zeta(int kout, const roms_step_idx_t *s);
 int bc_u2d(int kout);
-int bc_v2d(int kout);
-int bc_u3d(int nout);
-int bc_v3d(int nout);
-int bc_t3d(int nout, int itrc);
+int bc_v2d(int kout, const roms_step_idx_t *s);
+int bc_u3d(int nout, int nstp);
+int bc_v3d(int nout, int nstp);
+int bc_t3d(int nout, int itrc, int nstp);
+bool lbc2d_all_closed();
 int bc_w3d(double *A);
 void snapshot_release();                  // snapshot.hip: waits for and frees an in-flight snapshot
 void snapshot_forget(int field_id);       // snapshot.hip: the same for one field (before it is re-registered)

@@ -12,14 +12,23 @@ pytestmark = pytest.mark.gpu
 
 def test_unsupported_boundary_condition_is_refused():
     st = ana.make_tile("UPWELLING", perturb=1.0)
-    st.p.lbc_south = 7                                     # neither LBC_CLOSED nor LBC_PERIODIC (an open-boundary code)
+    st.p.lbc_south = 7                                     # no such code (enum roms_lbc ends at LBC_RADIATION = 6)
     h = hip.RomsHip(st)
     try:
         with pytest.raises(RuntimeError) as e:
             h.call("pre_step3d", util.step_idx())
-        assert "Per Clo Per Clo" in str(e.value)
+        assert "not implemented" in str(e.value)
         with pytest.raises(RuntimeError):
             h.call("step3d_t", util.step_idx())
+    finally:
+        h.close()
+    # a condition that exists, for a variable it is not defined for: Flather on the free surface
+    st = ana.make_tile("UPWELLING", perturb=1.0)
+    st.p.lbc[abi.LBS["north"]][abi.LBV["zeta"]] = abi.LBC["Fla"]
+    h = hip.RomsHip(st)
+    try:
+        with pytest.raises(RuntimeError):
+            h.call("step2d", util.step_idx())
     finally:
         h.close()
 
