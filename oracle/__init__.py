@@ -94,6 +94,17 @@ class Oracle:
             raise RuntimeError(f"oracle_diag returned {rc}")
         return out
 
+    def bc(self, kind, s, nout, itrc=1):
+        """One lateral boundary-condition routine (zetabc, u2dbc, v2dbc, u3dbc, v3dbc, t3dbc) on its own."""
+        fn = getattr(self.l, "oracle_bc")
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.StepIdx), C.POINTER(abi.Fields),
+                       C.c_int, C.c_int, C.c_int]
+        kid = {"zetabc": 1, "u2dbc": 2, "v2dbc": 3, "u3dbc": 4, "v3dbc": 5, "t3dbc": 6}[kind]
+        rc = fn(C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F), kid, int(nout), int(itrc))
+        if rc != 0:
+            raise RuntimeError(f"oracle_bc {kind} returned {rc}")
+
     def step2d_loop(self, s, indx1):
         ii = C.c_int(indx1)
         rc = self.l.oracle_step2d_loop(C.byref(self.st.b), C.byref(self.st.p), C.byref(s),

@@ -266,6 +266,22 @@ void o_t3dbc(OARGS, int nout, int itrc)
   }
 }
 
+/* one boundary-condition routine on its own (tests/test_ref_pinning.py pins each against the reference) */
+int oracle_bc(OARGS, int kind, int nout, int itrc)
+{
+  if (o_check_lbc(b, p)) return 8;
+  switch (kind) {
+  case 1: o_zetabc(b, p, s, F, nout); break;
+  case 2: o_u2dbc(b, p, s, F, nout); break;
+  case 3: o_v2dbc(b, p, s, F, nout); break;
+  case 4: o_u3dbc(b, p, s, F, nout); break;
+  case 5: o_v3dbc(b, p, s, F, nout); break;
+  case 6: o_t3dbc(b, p, s, F, nout, itrc); break;
+  default: return 2;
+  }
+  return 0;
+}
+
 /* bc_w3d_tile (gradient walls + periodic wrap) -- ROMS/Nonlinear/bc_3d.F:588 */
 void o_bc_w3d(const roms_bounds_t *b, double *A)
 {

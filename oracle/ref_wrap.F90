@@ -784,3 +784,145 @@ FUNCTION ref_mpdata_adiff (b, p, F, oHz, t3, Ta, Ua, Va, Wa) BIND(C, name='ref_m
  &                        pt3, pTa, pUa, pVa, pWa)
 END FUNCTION ref_mpdata_adiff
 #endif
+
+!-----------------------------------------------------------------------
+!  The lateral boundary-condition routines of the reference on the S/N edges, through their own _tile
+!  procedures: kind 1 zetabc_tile, 2 u2dbc_tile, 3 v2dbc_tile, 4 u3dbc_tile, 5 v3dbc_tile, 6 t3dbc_tile (tracer
+!  itrc).  LBC(:, isFsur..isTvar, ng) is filled from p%lbc (codes of enum roms_lbc), the BOUNDARY(ng)%*_south /
+!  *_north vectors from the *_bry fields (the value of a boundary point sits at that point, roms_fields.def).
+FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
+  USE ref_wrap_types
+  USE mod_param
+  USE mod_scalars
+  USE mod_stepping
+  USE mod_ncparam
+  USE mod_grid
+  USE mod_ocean
+  USE mod_boundary
+  USE zetabc_mod, ONLY : zetabc_tile
+  USE u2dbc_mod,  ONLY : u2dbc_tile
+  USE v2dbc_mod,  ONLY : v2dbc_tile
+  USE u3dbc_mod,  ONLY : u3dbc_tile
+  USE v3dbc_mod,  ONLY : v3dbc_tile
+  USE t3dbc_mod,  ONLY : t3dbc_tile
+  INTEGER(c_int), VALUE :: kind, nout, itrc
+  TYPE(bounds_t), INTENT(in) :: b
+  TYPE(params_t), INTENT(in) :: p
+  TYPE(stepidx_t), INTENT(in) :: s
+  TYPE(fields_t), INTENT(in) :: F
+  INTEGER(c_int) :: rc
+  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT, sd, v, code, side(2), ivar, i, k, it
+  INTEGER :: IminS, ImaxS, JminS, JmaxS, Jstr, Jend
+  REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:), a5(:,:,:,:,:)
+  ng = 1; tile = 0
+  LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
+  ni = UBi-LBi+1; nj = UBj-LBj+1; NN = b%N; NTT = b%NT
+  Jstr = b%Jstr; Jend = b%Jend
+  IminS = b%Istr-3; ImaxS = b%Iend+3; JminS = b%Jstr-3; JmaxS = b%Jend+3
+  rc = 0
+  IF (.NOT. have_boundary) THEN
+    CALL allocate_boundary (ng)
+    have_boundary = .TRUE.
+  END IF
+  IF (.NOT. allocated(isTvar)) THEN
+    allocate ( isTvar(MT) )
+    DO it = 1, MT
+      isTvar(it) = 5 + it                     ! mod_ncparam.F:1196-1203
+    END DO
+  END IF
+  nstp(ng) = s%nstp; nnew(ng) = s%nnew; nrhs(ng) = s%nrhs
+  kstp(ng) = s%kstp; krhs(ng) = s%krhs; knew(ng) = s%knew
+  iif(ng) = s%iif; iic(ng) = s%iic; ntfirst(ng) = s%ntfirst
+  PREDICTOR_2D_STEP(ng) = s%predictor /= 0
+  dt(ng) = p%dt; dtfast(ng) = p%dtfast
+  g = p%g; rho0 = p%rho0; gamma2(ng) = p%gamma2
+  side(1) = isouth; side(2) = inorth
+  DO sd = 1, 2
+    DO v = 1, 6
+      code = p%lbc(v, sd+2)
+      IF (code == 0) THEN
+        IF (sd == 1) code = p%lbc_south
+        IF (sd == 2) code = p%lbc_north
+      END IF
+      DO it = 1, MERGE(NTT, 1, v == 6)
+        ivar = v
+        IF (v == 6) ivar = isTvar(it)
+        LBC(side(sd), ivar, ng)%closed = code == 1
+        LBC(side(sd), ivar, ng)%gradient = code == 2
+        LBC(side(sd), ivar, ng)%clamped = code == 3
+        LBC(side(sd), ivar, ng)%Chapman_implicit = code == 4
+        LBC(side(sd), ivar, ng)%Flather = code == 5
+        LBC(side(sd), ivar, ng)%radiation = code == 6
+        LBC(side(sd), ivar, ng)%Chapman_explicit = .FALSE.
+        LBC(side(sd), ivar, ng)%nudging = .FALSE.
+        LBC(side(sd), ivar, ng)%nested = .FALSE.
+        LBC(side(sd), ivar, ng)%reduced = .FALSE.
+        LBC(side(sd), ivar, ng)%Shchepetkin = .FALSE.
+        LBC(side(sd), ivar, ng)%periodic = .FALSE.
+        LBC(side(sd), ivar, ng)%acquire = .FALSE.
+      END DO
+    END DO
+  END DO
+  ! ---- grid, masks, state ----
+  CALL c_f_pointer (F%h, a2, (/ni,nj/));        GRID(ng)%h = a2
+  CALL c_f_pointer (F%f, a2, (/ni,nj/));        GRID(ng)%f = a2
+  CALL c_f_pointer (F%pm, a2, (/ni,nj/));       GRID(ng)%pm = a2
+  CALL c_f_pointer (F%pn, a2, (/ni,nj/));       GRID(ng)%pn = a2
+  CALL c_f_pointer (F%om_u, a2, (/ni,nj/));     GRID(ng)%om_u = a2
+  CALL c_f_pointer (F%on_u, a2, (/ni,nj/));     GRID(ng)%on_u = a2
+  CALL c_f_pointer (F%om_v, a2, (/ni,nj/));     GRID(ng)%om_v = a2
+  CALL c_f_pointer (F%on_v, a2, (/ni,nj/));     GRID(ng)%on_v = a2
+#ifdef MASKING
+  CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
+  CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
+  CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
+#endif
+  CALL c_f_pointer (F%zeta, a3, (/ni,nj,3/));   OCEAN(ng)%zeta = a3
+  CALL c_f_pointer (F%ubar, a3, (/ni,nj,3/));   OCEAN(ng)%ubar = a3
+  CALL c_f_pointer (F%vbar, a3, (/ni,nj,3/));   OCEAN(ng)%vbar = a3
+  CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   OCEAN(ng)%u = a4
+  CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   OCEAN(ng)%v = a4
+  CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); OCEAN(ng)%t = a5
+  ! ---- boundary data: edge vectors from the rows of the *_bry fields ----
+  IF (.NOT. associated(BOUNDARY(ng)%zeta_south)) THEN
+    allocate ( BOUNDARY(ng)%zeta_south(LBi:UBi), BOUNDARY(ng)%zeta_north(LBi:UBi) )
+    allocate ( BOUNDARY(ng)%ubar_south(LBi:UBi), BOUNDARY(ng)%ubar_north(LBi:UBi) )
+    allocate ( BOUNDARY(ng)%vbar_south(LBi:UBi), BOUNDARY(ng)%vbar_north(LBi:UBi) )
+    allocate ( BOUNDARY(ng)%u_south(LBi:UBi,NN), BOUNDARY(ng)%u_north(LBi:UBi,NN) )
+    allocate ( BOUNDARY(ng)%v_south(LBi:UBi,NN), BOUNDARY(ng)%v_north(LBi:UBi,NN) )
+    allocate ( BOUNDARY(ng)%t_south(LBi:UBi,NN,NTT), BOUNDARY(ng)%t_north(LBi:UBi,NN,NTT) )
+  END IF
+  CALL c_f_pointer (F%zeta_bry, a2, (/ni,nj/))
+  BOUNDARY(ng)%zeta_south(LBi:UBi) = a2(:, Jstr-1-LBj+1); BOUNDARY(ng)%zeta_north(LBi:UBi) = a2(:, Jend+1-LBj+1)
+  CALL c_f_pointer (F%ubar_bry, a2, (/ni,nj/))
+  BOUNDARY(ng)%ubar_south(LBi:UBi) = a2(:, Jstr-1-LBj+1); BOUNDARY(ng)%ubar_north(LBi:UBi) = a2(:, Jend+1-LBj+1)
+  CALL c_f_pointer (F%vbar_bry, a2, (/ni,nj/))
+  BOUNDARY(ng)%vbar_south(LBi:UBi) = a2(:, Jstr-LBj+1);   BOUNDARY(ng)%vbar_north(LBi:UBi) = a2(:, Jend+1-LBj+1)
+  CALL c_f_pointer (F%u_bry, a3, (/ni,nj,NN/))
+  BOUNDARY(ng)%u_south(LBi:UBi,1:NN) = a3(:, Jstr-1-LBj+1, :); BOUNDARY(ng)%u_north(LBi:UBi,1:NN) = a3(:, Jend+1-LBj+1, :)
+  CALL c_f_pointer (F%v_bry, a3, (/ni,nj,NN/))
+  BOUNDARY(ng)%v_south(LBi:UBi,1:NN) = a3(:, Jstr-LBj+1, :);   BOUNDARY(ng)%v_north(LBi:UBi,1:NN) = a3(:, Jend+1-LBj+1, :)
+  CALL c_f_pointer (F%t_bry, a4, (/ni,nj,NN,NTT/))
+  BOUNDARY(ng)%t_south(LBi:UBi,1:NN,1:NTT) = a4(:, Jstr-1-LBj+1, :, :)
+  BOUNDARY(ng)%t_north(LBi:UBi,1:NN,1:NTT) = a4(:, Jend+1-LBj+1, :, :)
+  ! ---- the reference procedure ----
+  SELECT CASE (kind)
+  CASE (1); CALL zetabc_tile (ng, tile, LBi, UBi, LBj, UBj, IminS, ImaxS, JminS, JmaxS, s%krhs, s%kstp, nout, OCEAN(ng)%zeta)
+  CASE (2); CALL u2dbc_tile (ng, tile, LBi, UBi, LBj, UBj, IminS, ImaxS, JminS, JmaxS, s%krhs, s%kstp, nout,       &
+ &                           OCEAN(ng)%ubar, OCEAN(ng)%vbar, OCEAN(ng)%zeta)
+  CASE (3); CALL v2dbc_tile (ng, tile, LBi, UBi, LBj, UBj, IminS, ImaxS, JminS, JmaxS, s%krhs, s%kstp, nout,       &
+ &                           OCEAN(ng)%ubar, OCEAN(ng)%vbar, OCEAN(ng)%zeta)
+  CASE (4); CALL u3dbc_tile (ng, tile, LBi, UBi, LBj, UBj, NN, IminS, ImaxS, JminS, JmaxS, s%nstp, nout, OCEAN(ng)%u)
+  CASE (5); CALL v3dbc_tile (ng, tile, LBi, UBi, LBj, UBj, NN, IminS, ImaxS, JminS, JmaxS, s%nstp, nout, OCEAN(ng)%v)
+  CASE (6); CALL t3dbc_tile (ng, tile, itrc, 0, LBi, UBi, LBj, UBj, NN, NTT, IminS, ImaxS, JminS, JmaxS,        &
+ &                           s%nstp, nout, OCEAN(ng)%t)
+  CASE DEFAULT; rc = 2
+  END SELECT
+  ! ---- copy out ----
+  CALL c_f_pointer (F%zeta, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%zeta
+  CALL c_f_pointer (F%ubar, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%ubar
+  CALL c_f_pointer (F%vbar, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%vbar
+  CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   a4 = OCEAN(ng)%u
+  CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   a4 = OCEAN(ng)%v
+  CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); a5 = OCEAN(ng)%t
+END FUNCTION ref_bc

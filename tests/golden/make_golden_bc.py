@@ -1,0 +1,88 @@
+"""Generates tests/golden/ref_bc_<CONFIG>.npz from the REFERENCE's own boundary-condition routines (zetabc_tile,
+u2dbc_tile, v2dbc_tile, u3dbc_tile, v3dbc_tile, t3dbc_tile of oracle/_ref, built by oracle/build_ref.sh): for
+every condition the library offers on the S/N edges and the three states of the barotropic stepping, the three
+boundary rows (Jstr-1, Jstr, Jend+1) of the variable after the call.  Run in this container:
+
+    python tests/golden/make_golden_bc.py
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+
+CONFIGS = [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)]
+TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla"]),
+         "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
+         "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad"])}
+
+
+def tag(config, mask):
+    return config + ("_MASK" if mask else "")
+
+
+def input_state(config, mask):
+    import util
+    st0 = util.prepared_state(config, mask=mask)
+    rng = np.random.default_rng(11)
+    for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
+        st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
+    st0["t_bry"][:] = st0["t"][:, :, :, 0, :] * (1.0 + 1.0e-3 * rng.standard_normal(st0["t_bry"].shape))
+    b = st0.b
+    for name in ("zeta", "ubar", "vbar", "u", "v", "t"):
+        a = st0[name]
+        for j in (b.Jstr - 1, b.Jstr, b.Jend + 1):
+            row = a[:, j - b.LBj]
+            row += 1.0e-3 * (1.0 + np.abs(row)) * rng.standard_normal(row.shape)
+    return st0
+
+
+def steps():
+    import util
+    return [util.step_idx(iic=5, iif=1, pred=1, kstp=1, krhs=1, knew=3), util.step_idx(iic=5, iif=3, pred=1, kstp=2, krhs=1, knew=3),
+            util.step_idx(iic=5, iif=3, pred=0, kstp=1, krhs=3, knew=2)]
+
+
+def cases(st0):
+    """(key, kind, variable, state with the condition set, step indices, nout, itrc)"""
+    from roms_trunk_mgh_amd import abi
+    for kind, (var, codes) in TABLE.items():
+        for code in codes:
+            for q, s in enumerate(steps() if kind in ("zetabc", "u2dbc", "v2dbc") else steps()[:1]):
+                st = st0.copy()
+                st.p = type(st0.p).from_buffer_copy(st0.p)
+                for sd in ("south", "north"):
+                    st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+                nout = s.knew if kind in ("zetabc", "u2dbc", "v2dbc") else s.nnew
+                yield f"{kind}__{code}__{q}", kind, var, st, s, nout, st0.b.NT
+
+
+def rows(st, var):
+    b = st.b
+    return np.stack([st[var][:, j - b.LBj] for j in (b.Jstr - 1, b.Jstr, b.Jend + 1)])
+
+
+def child(config, mask):
+    from make_golden import checksum
+    from oracle import ref
+    st0 = input_state(config, mask)
+    out = {"input_sha256": np.array(checksum(st0))}
+    for key, kind, var, st, s, nout, itrc in cases(st0):
+        ref.Ref(st).bc(kind, s, nout, itrc)
+        out[key] = rows(st, var)
+    np.savez_compressed(os.path.join(HERE, f"ref_bc_{tag(config, mask)}.npz"), **out)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        child(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None)
+    else:
+        for c, m in CONFIGS:
+            subprocess.run([sys.executable, os.path.abspath(__file__), c, m or "-"], check=True)
+            print(tag(c, m), os.path.getsize(os.path.join(HERE, f"ref_bc_{tag(c, m)}.npz")) // 1024, "KiB")

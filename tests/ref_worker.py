@@ -49,6 +49,51 @@ def main(config, mask=None):
     print(json.dumps(out))
 
 
+def main_bc(config, mask=None):
+    """The six lateral boundary-condition routines on the S/N edges, every condition the library offers, for the
+    three states of the barotropic stepping (first, predictor, corrector): reference Fortran vs C oracle."""
+    import oracle
+    import util
+    from oracle import ref
+    from roms_trunk_mgh_amd import abi
+    st0 = util.prepared_state(config, mask=mask)
+    rng = np.random.default_rng(11)
+    for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
+        st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
+    st0["t_bry"][:] = st0["t"][:, :, :, 0, :] * (1.0 + 1.0e-3 * rng.standard_normal(st0["t_bry"].shape))
+    # boundary rows that do not already satisfy any of the conditions
+    b = st0.b
+    for name in ("zeta", "ubar", "vbar", "u", "v", "t"):
+        a = st0[name]
+        for j in (b.Jstr - 1, b.Jstr, b.Jend + 1):
+            row = a[:, j - b.LBj]
+            row += 1.0e-3 * (1.0 + np.abs(row)) * rng.standard_normal(row.shape)
+    out = {"masking": int(st0.p.masking), "cases": {}}
+    table = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla"]),
+             "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
+             "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad"])}
+    steps = [util.step_idx(iic=5, iif=1, pred=1, kstp=1, krhs=1, knew=3), util.step_idx(iic=5, iif=3, pred=1, kstp=2, krhs=1, knew=3),
+             util.step_idx(iic=5, iif=3, pred=0, kstp=1, krhs=3, knew=2)]
+    for kind, (var, codes) in table.items():
+        for code in codes:
+            for q, s in enumerate(steps if kind in ("zetabc", "u2dbc", "v2dbc") else steps[:1]):
+                st_r, st_o = st0.copy(), st0.copy()
+                for st in (st_r, st_o):
+                    st.p = type(st0.p).from_buffer_copy(st0.p)
+                    for sd in ("south", "north"):
+                        st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+                        # Flather reads the free surface of the boundary row: give zeta an open condition too
+                nout = s.knew if kind in ("zetabc", "u2dbc", "v2dbc") else s.nnew
+                itrc = st0.b.NT
+                ref.Ref(st_r).bc(kind, s, nout, itrc)
+                oracle.Oracle(st_o).bc(kind, s, nout, itrc)
+                diffs = util.compare_states(st_o, st_r)
+                changed = util.compare_states(st_r, st0)
+                out["cases"][f"{kind}:{code}:{q}"] = {"max_rel_diff": max(diffs.values()) if diffs else 0.0,
+                                                     "changed": sorted(changed)}
+    print(json.dumps(out))
+
+
 def main_mpdata(config):
     """mpdata_adiff_tile: reference Fortran vs C oracle on the same private arrays, with the
     3-ghost-point bounds an MPDATA run uses (also pins get_bounds for NghostPoints = 3)."""
@@ -234,5 +279,7 @@ if __name__ == "__main__":
         main_mpdata(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mask":
         main(sys.argv[1], mask="island")
+    elif len(sys.argv) > 2 and sys.argv[2] in ("bc", "bc_mask"):
+        main_bc(sys.argv[1], mask="island" if sys.argv[2] == "bc_mask" else None)
     else:
         main(sys.argv[1])

@@ -159,6 +159,31 @@ def test_hip_reproduces_masked_reference_vectors(config):
         _check(st, st0, g, k, tol=1e-13)
 
 
+@pytest.mark.parametrize("config,mask", [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)])
+def test_oracle_reproduces_reference_boundary_conditions(config, mask):
+    """The boundary rows the reference's zetabc / u2dbc / v2dbc / u3dbc / v3dbc / t3dbc _tile left (45 cases:
+    closed, gradient, clamped, Chapman implicit, Flather, radiation; tests/golden/make_golden_bc.py) vs the oracle."""
+    import importlib.util
+    import sys
+    import oracle
+    gd = os.path.join(HERE, "golden")
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    spec = importlib.util.spec_from_file_location("make_golden_bc", os.path.join(gd, "make_golden_bc.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from make_golden import checksum
+    g = np.load(os.path.join(gd, f"ref_bc_{mg.tag(config, mask)}.npz"))
+    st0 = mg.input_state(config, mask)
+    assert checksum(st0) == str(g["input_sha256"]), "seeded inputs changed: regenerate the fixtures"
+    n = 0
+    for key, kind, var, st, s, nout, itrc in mg.cases(st0):
+        oracle.Oracle(st).bc(kind, s, nout, itrc)
+        assert np.array_equal(mg.rows(st, var), g[key]), key
+        n += 1
+    assert n == 45
+
+
 def test_oracle_reproduces_reference_mpdata_adiff():
     """mpdata_adiff_tile: the committed outputs of the reference's Fortran (three levels stored,
     all elements through a SHA-256) vs the C oracle on the same deterministic inputs."""
