@@ -26,7 +26,21 @@ def _stale(src, obj, deps):
     return any(os.path.getmtime(d) > mt for d in [src] + deps)
 
 
-def build(verbose=False, force=False):
+def build(verbose=False, force=False, variant=None, extra=()):
+    """variant / extra: developer A/B builds -- objects in csrc/_obj_<variant>, library libroms_hip_<variant>.so,
+    compiled with the extra flags (e.g. -DUVCOL_FLAT); the product build is variant=None."""
+    global OBJ, LIB
+    obj0, lib0 = OBJ, LIB
+    if variant:
+        OBJ = os.path.join(HERE, "csrc", "_obj_" + variant)
+        LIB = os.path.join(HERE, f"libroms_hip_{variant}.so")
+    try:
+        return _build(verbose, force, list(extra))
+    finally:
+        OBJ, LIB = obj0, lib0
+
+
+def _build(verbose, force, extra):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -40,7 +54,7 @@ def build(verbose=False, force=False):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -64,4 +78,8 @@ def build(verbose=False, force=False):
 
 
 if __name__ == "__main__":
-    print(build(verbose=True, force="--force" in sys.argv))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    if args:      # python -m roms_trunk_mgh_amd._build <variant> [-DFLAG ...]
+        print(build(verbose=False, force="--force" in sys.argv, variant=args[0], extra=args[1:]))
+    else:
+        print(build(verbose=True, force="--force" in sys.argv))
