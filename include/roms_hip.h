@@ -83,11 +83,12 @@ typedef struct roms_bounds {
 enum roms_adv {
   ADV_C2 = 0, ADV_C4, ADV_A4, ADV_U3, ADV_SU3, ADV_SPLINES, ADV_MPDATA, ADV_HSIMT
 };
-/* Lateral boundary condition codes supported on this path (the logical records of T_LBC, mod_param.F:120-160).
- * West and east: periodic only.  South and north, per variable (roms_params_t.lbc): closed, gradient, clamped;
- * Chapman implicit for the free surface (zetabc.F:489); Flather for the normal 2-D velocity (v2dbc_im.F:216);
- * radiation -- implicit upstream, without nudging and without RADIATION_2D -- for u, v and the tracers
- * (u3dbc_im.F:381, v3dbc_im.F:97, t3dbc_im.F:364). */
+/* Lateral boundary condition codes supported on this path (the logical records of T_LBC, mod_param.F:348-363).
+ * West and east: periodic only.  South and north, per variable (roms_params_t.lbc): closed, gradient, clamped,
+ * radiation (implicit upstream, zetabc.F:408 / u2dbc_im.F:833 / v2dbc_im.F:138 / u3dbc_im.F:381 / v3dbc_im.F:97 /
+ * t3dbc_im.F:364; no nudging, RADIATION_2D off) for every variable; Chapman implicit for zeta (zetabc.F:489);
+ * Flather for vbar (v2dbc_im.F:216) and ubar (u2dbc_im.F:912: the Chapman-type rule the reference gives the
+ * tangential component of a Flather edge).  Anything else is refused by every entry that applies conditions. */
 enum roms_lbc {
   LBC_PERIODIC = 0, LBC_CLOSED = 1, LBC_GRADIENT = 2, LBC_CLAMPED = 3, LBC_CHAPMAN_IMPLICIT = 4, LBC_FLATHER = 5,
   LBC_RADIATION = 6
@@ -196,6 +197,13 @@ int roms_hip_omega(const roms_step_idx_t *s);
 int roms_hip_set_zeta(const roms_step_idx_t *s);
 /* set_depth(ng,tile,model)         ROMS/Nonlinear/set_depth.F:33     */
 int roms_hip_set_depth(const roms_step_idx_t *s);
+/* ini_zeta(ng,tile,model)          ROMS/Nonlinear/ini_fields.F:780
+ * ini_fields(ng,tile,model)        ROMS/Nonlinear/ini_fields.F:27
+ * The first-step initialisation of main3d.F:269-283 (ini_zeta, set_depth, ini_fields, in this order): other
+ * time levels loaded from the initial state, MASKING multiplies, lateral boundary conditions, ubar/vbar = the
+ * vertical means of u/v, Zt_avg1 = the initial free surface.  Uses s->kstp, knew, nstp, nnew. */
+int roms_hip_ini_zeta(const roms_step_idx_t *s);
+int roms_hip_ini_fields(const roms_step_idx_t *s);
 /* rhs3d(ng,tile) -> pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2
  *                                  ROMS/Nonlinear/rhs3d.F:25         */
 int roms_hip_rhs3d(const roms_step_idx_t *s);

@@ -35,6 +35,7 @@ FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iouni
   Nonlinear/set_massflux Nonlinear/rho_eos Nonlinear/set_zeta Nonlinear/mpdata_adiff
  Nonlinear/bc_2d Nonlinear/set_vbc Nonlinear/bulk_flux
  Nonlinear/zetabc Nonlinear/u2dbc_im Nonlinear/v2dbc_im Nonlinear/u3dbc_im Nonlinear/v3dbc_im Nonlinear/t3dbc_im
+ Nonlinear/ini_fields
  Nonlinear/bc_3d Utility/shapiro Nonlinear/lmd_swfrac Nonlinear/lmd_skpp Nonlinear/lmd_vmix
 
  Utility/stats Functionals/analytical Nonlinear/wvelocity Nonlinear/diag Utility/set_scoord Utility/metrics"

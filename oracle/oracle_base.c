@@ -24,8 +24,9 @@ int o_lbc(const roms_params_t *p, int sd, int v)
   return sd == LBS_WEST ? p->lbc_west : sd == LBS_EAST ? p->lbc_east : sd == LBS_SOUTH ? p->lbc_south : p->lbc_north;
 }
 
-/* West/east periodic; south/north per variable: closed, gradient, clamped, Chapman implicit (zeta), Flather
- * (vbar), radiation (u, v, t) -- the conditions restated below. */
+/* West/east periodic; south/north per variable: closed, gradient, clamped, radiation (all six), Chapman implicit
+ * (zeta), Flather (vbar: the normal component; ubar: the reference applies a Chapman-type condition to the
+ * tangential component of a Flather edge) -- the conditions restated below. */
 int o_check_lbc(const roms_bounds_t *b, const roms_params_t *p)
 {
   if (!b->EWperiodic || b->NSperiodic) return 1;
@@ -33,9 +34,9 @@ int o_check_lbc(const roms_bounds_t *b, const roms_params_t *p)
     for (int v = 0; v < LBV_COUNT; v++) {
       const int c = o_lbc(p, sd, v);
       int ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED;
+      ok = ok || c == LBC_RADIATION;
       if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT;
-      if (v == LBV_VBAR) ok = ok || c == LBC_FLATHER;
-      if (v >= LBV_U) ok = ok || c == LBC_RADIATION;
+      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER;
       if (!ok) return 1;
     }
   return 0;
@@ -102,8 +103,28 @@ static void o_know(const roms_params_t *p, const roms_step_idx_t *s, int *know, 
   else { *know = s->kstp; *dt2d = p->dtfast; }
 }
 
-/* zetabc_tile, S/N edges -- ROMS/Nonlinear/zetabc.F:404-700: Chapman implicit (:489, :638), clamped (:508,
- * :657), gradient (:521, :670), closed (:534, :683); every branch ends with the MASKING multiply */
+/* Implicit upstream radiation condition on a southern / northern edge, the form shared by u3dbc_im.F:381-463 /
+ * :539-621, v3dbc_im.F:97-180 / :239-322 and t3dbc_im.F:364-443 / :498-577 without nudging and without
+ * RADIATION_2D (Cx = 0); the 2-D conditions (zetabc.F:408-470, u2dbc_im.F:833-908, v2dbc_im.F:138-214) have the
+ * same form with the levels know / kout in place of nstp / nout.  xb_old = X(i,jb,nstp); x1_old, x1 = X(i,j1,nstp), X(i,j1,nout); x2 = X(i,j2,nout);
+ * gL, gR = the two along-boundary differences of X(:,j1,nstp) on either side of point i. */
+static double o_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR)
+{
+  const double eps = 1.0E-20;
+  double dXdt = x1_old - x1;
+  const double dXde = x1 - x2;
+  if ((dXdt * dXde) < 0.0) dXdt = 0.0;
+  const double dXdx = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
+  const double cff = MAX(dXdx * dXdx + dXde * dXde, eps);
+  const double Ce = dXdt * dXde;
+  return (cff * xb_old + Ce * x1) / (cff + Ce);
+}
+
+/* zetabc_tile, S/N edges -- ROMS/Nonlinear/zetabc.F:404-700: radiation (:408, :557), Chapman implicit (:489, :638),
+ * clamped (:508, :657), gradient (:521, :670), closed (:534, :683); every branch ends with the MASKING multiply.
+ * Radiation on the SOUTHERN edge takes its normal difference as zeta(i,Jstr,kout)-zeta(i,Jstr-1,kout), i.e. towards
+ * the boundary row (:424; the northern edge, :573, and the other variables look into the interior) -- restated as
+ * written. */
 void o_zetabc(OARGS, int kout)
 {
   ORACLE_PROLOGUE
@@ -115,7 +136,12 @@ void o_zetabc(OARGS, int kout)
     const int code = o_lbc(p, side ? LBS_NORTH : LBS_SOUTH, LBV_ZETA);
     const int jb = side ? Jend + 1 : Jstr - 1, j1 = side ? Jend : Jstr;
     for (int i = Istr; i <= Iend; i++) {
-      if (code == LBC_CHAPMAN_IMPLICIT) {
+      if (code == LBC_RADIATION) {
+        const int j2 = side ? Jend - 1 : Jstr - 1;
+        double gL = zeta(i, j1, know) - zeta(i - 1, j1, know), gR = zeta(i + 1, j1, know) - zeta(i, j1, know);
+        if (mk) { gL = gL * umask(i, j1); gR = gR * umask(i + 1, j1); }
+        zeta(i, jb, kout) = o_radiate(zeta(i, jb, know), zeta(i, j1, know), zeta(i, j1, kout), zeta(i, j2, kout), gL, gR);
+      } else if (code == LBC_CHAPMAN_IMPLICIT) {
         const double cff = dt2d * pn(i, j1);
         const double cff1 = sqrt(p->g * (h(i, j1) + zeta(i, j1, know)));
         const double Ce = cff * cff1;
@@ -128,13 +154,15 @@ void o_zetabc(OARGS, int kout)
   }
 }
 
-/* u2dbc_tile, S/N edges (tangential component) -- ROMS/Nonlinear/u2dbc_im.F:829-1140: clamped (:934, :1092),
- * gradient (:947, :1105), closed = slipperiness gamma2 (:960, :1118) */
+/* u2dbc_tile, S/N edges (tangential component) -- ROMS/Nonlinear/u2dbc_im.F:829-1140: radiation (:833, :991),
+ * the Chapman-type condition of a Flather edge (:912, :1070), clamped (:934, :1092), gradient (:947, :1105),
+ * closed = slipperiness gamma2 (:960, :1118) */
 void o_u2dbc(OARGS, int kout)
 {
   ORACLE_PROLOGUE
-  (void)s;
   const int mk = p->masking;
+  int know; double dt2d;
+  o_know(p, s, &know, &dt2d);
   for (int side = 0; side < 2; side++) {
     if (!(side ? north_edge : south_edge)) continue;
     const int code = o_lbc(p, side ? LBS_NORTH : LBS_SOUTH, LBV_UBAR);
@@ -142,7 +170,17 @@ void o_u2dbc(OARGS, int kout)
     int Imin = IstrU, Imax = Iend;
     if (code == LBC_CLOSED) { Imin = EWperiodic ? IstrU : Istr; Imax = EWperiodic ? Iend : IendR; }
     for (int i = Imin; i <= Imax; i++) {
-      if (code == LBC_CLAMPED) ubar(i, jb, kout) = ubar_bry(i, jb);
+      if (code == LBC_RADIATION) {
+        const int j2 = side ? Jend - 1 : Jstr + 1;
+        const double gL = ubar(i, j1, know) - ubar(i - 1, j1, know), gR = ubar(i + 1, j1, know) - ubar(i, j1, know);
+        ubar(i, jb, kout) = o_radiate(ubar(i, jb, know), ubar(i, j1, know), ubar(i, j1, kout), ubar(i, j2, kout), gL, gR);
+      } else if (code == LBC_FLATHER) {
+        const double cff = dt2d * 0.5 * (pn(i - 1, j1) + pn(i, j1));
+        const double cff1 = sqrt(p->g * 0.5 * (h(i - 1, j1) + zeta(i - 1, j1, know) + h(i, j1) + zeta(i, j1, know)));
+        const double Ce = cff * cff1;
+        const double cff2 = 1.0 / (1.0 + Ce);
+        ubar(i, jb, kout) = cff2 * (ubar(i, jb, know) + Ce * ubar(i, j1, kout));
+      } else if (code == LBC_CLAMPED) ubar(i, jb, kout) = ubar_bry(i, jb);
       else if (code == LBC_GRADIENT) ubar(i, jb, kout) = ubar(i, j1, kout);
       else ubar(i, jb, kout) = p->gamma2 * ubar(i, j1, kout);
       if (mk) ubar(i, jb, kout) = ubar(i, jb, kout) * umask(i, jb);
@@ -150,7 +188,7 @@ void o_u2dbc(OARGS, int kout)
   }
 }
 
-/* v2dbc_tile, S/N edges (normal component) -- ROMS/Nonlinear/v2dbc_im.F:134-830: Flather (:216, :565) with
+/* v2dbc_tile, S/N edges (normal component) -- ROMS/Nonlinear/v2dbc_im.F:134-830: radiation (:138, :487), Flather (:216, :565) with
  * bry_val = BOUNDARY%vbar_south/north (no SSH_TIDES), clamped (:366, :715), gradient (:379, :728), closed
  * (:434, :783) */
 void o_v2dbc(OARGS, int kout)
@@ -165,7 +203,11 @@ void o_v2dbc(OARGS, int kout)
     const int jb = side ? Jend + 1 : Jstr, j1 = side ? Jend : Jstr + 1;     /* boundary v-row, first interior v-row */
     const int ja = side ? Jend : Jstr - 1, jc = side ? Jend + 1 : Jstr;     /* the two rho-rows around row jb */
     for (int i = Istr; i <= Iend; i++) {
-      if (code == LBC_FLATHER) {
+      if (code == LBC_RADIATION) {
+        const int j2 = side ? Jend - 1 : Jstr + 2;
+        const double gL = vbar(i, j1, know) - vbar(i - 1, j1, know), gR = vbar(i + 1, j1, know) - vbar(i, j1, know);
+        vbar(i, jb, kout) = o_radiate(vbar(i, jb, know), vbar(i, j1, know), vbar(i, j1, kout), vbar(i, j2, kout), gL, gR);
+      } else if (code == LBC_FLATHER) {
         const double bry_val = vbar_bry(i, jb);
         const double cff = 1.0 / (0.5 * (h(i, ja) + zeta(i, ja, know) + h(i, jc) + zeta(i, jc, know)));
         const double Ce = sqrt(p->g * cff);
@@ -177,22 +219,6 @@ void o_v2dbc(OARGS, int kout)
       if (mk && code != LBC_CLOSED) vbar(i, jb, kout) = vbar(i, jb, kout) * vmask(i, jb);
     }
   }
-}
-
-/* Implicit upstream radiation condition on a southern / northern edge, the form shared by u3dbc_im.F:381-463 /
- * :539-621, v3dbc_im.F:97-180 / :239-322 and t3dbc_im.F:364-443 / :498-577 without nudging and without
- * RADIATION_2D (Cx = 0).  xb_old = X(i,jb,nstp); x1_old, x1 = X(i,j1,nstp), X(i,j1,nout); x2 = X(i,j2,nout);
- * gL, gR = the two along-boundary differences of X(:,j1,nstp) on either side of point i. */
-static double o_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR)
-{
-  const double eps = 1.0E-20;
-  double dXdt = x1_old - x1;
-  const double dXde = x1 - x2;
-  if ((dXdt * dXde) < 0.0) dXdt = 0.0;
-  const double dXdx = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
-  const double cff = MAX(dXdx * dXdx + dXde * dXde, eps);
-  const double Ce = dXdt * dXde;
-  return (cff * xb_old + Ce * x1) / (cff + Ce);
 }
 
 /* u3dbc_tile, S/N edges -- ROMS/Nonlinear/u3dbc_im.F:379-700 */

@@ -66,7 +66,8 @@ class Ref:
     def bc(self, kind, s, nout, itrc=1):
         """zetabc / u2dbc / v2dbc / u3dbc / v3dbc / t3dbc _tile of the reference on the S/N edges, with LBC(...) from
         the state's lbc table and BOUNDARY(ng)%*_south/_north from its *_bry fields (ref_bc in ref_wrap.F90)."""
-        kid = {"zetabc": 1, "u2dbc": 2, "v2dbc": 3, "u3dbc": 4, "v3dbc": 5, "t3dbc": 6}[kind]
+        kid = {"zetabc": 1, "u2dbc": 2, "v2dbc": 3, "u3dbc": 4, "v3dbc": 5, "t3dbc": 6,
+               "ini_zeta": 7, "ini_fields": 8}[kind]          # 7, 8: ini_fields.F, the first-step initialisation
         self.l.ref_bc.argtypes = [C.c_int, C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.StepIdx),
                                   C.POINTER(abi.Fields), C.c_int, C.c_int]
         rc = self.l.ref_bc(kid, C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F), int(nout), int(itrc))

@@ -788,7 +788,8 @@ END FUNCTION ref_mpdata_adiff
 !-----------------------------------------------------------------------
 !  The lateral boundary-condition routines of the reference on the S/N edges, through their own _tile
 !  procedures: kind 1 zetabc_tile, 2 u2dbc_tile, 3 v2dbc_tile, 4 u3dbc_tile, 5 v3dbc_tile, 6 t3dbc_tile (tracer
-!  itrc).  LBC(:, isFsur..isTvar, ng) is filled from p%lbc (codes of enum roms_lbc), the BOUNDARY(ng)%*_south /
+!  itrc); 7 ini_zeta, 8 ini_fields (ini_fields.F:780, :27 -- the first-step initialisation of main3d.F:269-283,
+!  which applies those conditions).  LBC(:, isFsur..isTvar, ng) is filled from p%lbc (codes of enum roms_lbc), the BOUNDARY(ng)%*_south /
 !  *_north vectors from the *_bry fields (the value of a boundary point sits at that point, roms_fields.def).
 FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   USE ref_wrap_types
@@ -805,6 +806,8 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   USE u3dbc_mod,  ONLY : u3dbc_tile
   USE v3dbc_mod,  ONLY : v3dbc_tile
   USE t3dbc_mod,  ONLY : t3dbc_tile
+  USE ini_fields_mod, ONLY : ini_fields, ini_zeta
+  USE mod_coupling
   INTEGER(c_int), VALUE :: kind, nout, itrc
   TYPE(bounds_t), INTENT(in) :: b
   TYPE(params_t), INTENT(in) :: p
@@ -836,6 +839,15 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   PREDICTOR_2D_STEP(ng) = s%predictor /= 0
   dt(ng) = p%dt; dtfast(ng) = p%dtfast
   g = p%g; rho0 = p%rho0; gamma2(ng) = p%gamma2
+  PerfectRST(ng) = .FALSE.
+  ! western / eastern edges: periodic (the only case of this path); every other switch off
+  DO v = 1, 5 + NTT
+    LBC(iwest, v, ng)%periodic = .TRUE.;  LBC(ieast, v, ng)%periodic = .TRUE.
+    LBC(iwest, v, ng)%radiation = .FALSE.; LBC(ieast, v, ng)%radiation = .FALSE.
+    LBC(iwest, v, ng)%Flather = .FALSE.;   LBC(ieast, v, ng)%Flather = .FALSE.
+    LBC(iwest, v, ng)%Chapman_implicit = .FALSE.; LBC(ieast, v, ng)%Chapman_implicit = .FALSE.
+    LBC(iwest, v, ng)%Chapman_explicit = .FALSE.; LBC(ieast, v, ng)%Chapman_explicit = .FALSE.
+  END DO
   side(1) = isouth; side(2) = inorth
   DO sd = 1, 2
     DO v = 1, 6
@@ -883,6 +895,8 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   OCEAN(ng)%u = a4
   CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   OCEAN(ng)%v = a4
   CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); OCEAN(ng)%t = a5
+  CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
+  CALL c_f_pointer (F%Zt_avg1, a2, (/ni,nj/));  COUPLING(ng)%Zt_avg1 = a2
   ! ---- boundary data: edge vectors from the rows of the *_bry fields ----
   IF (.NOT. associated(BOUNDARY(ng)%zeta_south)) THEN
     allocate ( BOUNDARY(ng)%zeta_south(LBi:UBi), BOUNDARY(ng)%zeta_north(LBi:UBi) )
@@ -916,9 +930,12 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   CASE (5); CALL v3dbc_tile (ng, tile, LBi, UBi, LBj, UBj, NN, IminS, ImaxS, JminS, JmaxS, s%nstp, nout, OCEAN(ng)%v)
   CASE (6); CALL t3dbc_tile (ng, tile, itrc, 0, LBi, UBi, LBj, UBj, NN, NTT, IminS, ImaxS, JminS, JmaxS,        &
  &                           s%nstp, nout, OCEAN(ng)%t)
+  CASE (7); CALL ini_zeta (ng, tile, iNLM)                 ! main3d.F:275
+  CASE (8); CALL ini_fields (ng, tile, iNLM)               ! main3d.F:282
   CASE DEFAULT; rc = 2
   END SELECT
   ! ---- copy out ----
+  CALL c_f_pointer (F%Zt_avg1, a2, (/ni,nj/));  a2 = COUPLING(ng)%Zt_avg1
   CALL c_f_pointer (F%zeta, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%zeta
   CALL c_f_pointer (F%ubar, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%ubar
   CALL c_f_pointer (F%vbar, a3, (/ni,nj,3/));   a3 = OCEAN(ng)%vbar

@@ -49,18 +49,17 @@ ScopedTimer::ScopedTimer(const char *n) : name(n)
 {
   if (!g_ctx.timing) return;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
-  hipEventRecord(e0, g_ctx.stream);
+  (void)hipEventRecord(e0, g_ctx.stream);
 }
 ScopedTimer::~ScopedTimer()
 {
   if (!e0) return;
-  hipEventRecord(e1, g_ctx.stream);
-  hipEventSynchronize(e1);
   float ms = 0.f;
-  hipEventElapsedTime(&ms, e0, e1);
-  g_last_ms[name] = ms;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  if (hipEventRecord(e1, g_ctx.stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+      hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+    g_last_ms[name] = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
 }
 
 extern "C" int roms_hip_timing_enable(int on) { g_ctx.timing = on != 0; return 0; }

@@ -9,7 +9,7 @@
 int roms_entry_check(const char *name);
 
 // Effective boundary-condition code (enum roms_lbc) of variable v (enum roms_lbc_var) on side sd.
-static int lbc_code(const roms_params_t &p, int sd, int v)
+int lbc_code(const roms_params_t &p, int sd, int v)
 {
   if (p.lbc[sd][v]) return p.lbc[sd][v];
   return sd == LBS_WEST ? p.lbc_west : sd == LBS_EAST ? p.lbc_east : sd == LBS_SOUTH ? p.lbc_south : p.lbc_north;
@@ -27,9 +27,9 @@ int check_lbc()
     for (int v = 0; v < LBV_COUNT; v++) {
       const int c = lbc_code(p, sd, v);
       bool ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED;
+      ok = ok || c == LBC_RADIATION;
       if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT;
-      if (v == LBV_VBAR) ok = ok || c == LBC_FLATHER;
-      if (v >= LBV_U) ok = ok || c == LBC_RADIATION;
+      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER;   // ubar: Chapman-type rule of a Flather edge
       if (!ok) return roms_fail("check_lbc", "lateral boundary condition not implemented for this variable");
     }
   return 0;
@@ -55,9 +55,9 @@ bool lbc2d_all_closed()
 // ---------------------------------------------------------------------------
 struct BcArgs {
   double *X;             // level written (kout / nout)
-  const double *Xold;    // zeta: zeta(know); radiation: X(nstp)
+  const double *Xold;    // 2-D conditions: X(know); 3-D radiation: X(nstp)
   const double *D;       // boundary data of this variable (or nullptr)
-  const double *Z, *Zb;  // Flather: zeta(know), zeta_bry
+  const double *Z, *Zb;  // Flather (ubar, vbar): zeta(know), zeta_bry
   int var;               // enum roms_lbc_var; -1 = bc_w3d (gradient, no mask)
   int code_s, code_n;    // enum roms_lbc on the southern / northern edge
   int nk, masked;
@@ -104,13 +104,24 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
   if (code == LBC_RADIATION) {
     const double *O = a.Xold + kb;
     double gL = O[q1] - O[q1 - 1], gR = O[q1 + 1] - O[q1];
-    if (a.masked && a.var == LBV_T) { gL = gL * c->F.umask[q1]; gR = gR * c->F.umask[q1 + 1]; }   // t3dbc_im.F:370-379
+    if (a.masked && (a.var == LBV_T || a.var == LBV_ZETA)) {      // t3dbc_im.F:370-379, zetabc.F:412-419
+      gL = gL * c->F.umask[q1];
+      gR = gR * c->F.umask[q1 + 1];
+    }
+    // zetabc.F:424 -- on the southern edge the free surface takes its normal difference towards the boundary row
+    if (a.var == LBV_ZETA && !side) j2 = jb;
     x = bc_radiate(O[qb], O[q1], X[q1], X[I2(i, j2)], gL, gR);
   } else if (code == LBC_CLAMPED) {
     x = a.D[qb + kb];
   } else if (code == LBC_CHAPMAN_IMPLICIT) {        // zetabc.F:489-506, :638-655
     const double cff = a.dt2d * c->F.pn[q1];
     const double cff1 = sqrt(p.g * (c->F.h[q1] + a.Xold[q1]));
+    const double Ce = cff * cff1;
+    const double cff2 = 1.0 / (1.0 + Ce);
+    x = cff2 * (a.Xold[qb] + Ce * X[q1]);
+  } else if (code == LBC_FLATHER && utype) {        // u2dbc_im.F:912-932, :1070-1090: tangential component, Chapman type
+    const double cff = a.dt2d * 0.5 * (c->F.pn[q1 - 1] + c->F.pn[q1]);
+    const double cff1 = sqrt(p.g * 0.5 * (c->F.h[q1 - 1] + a.Z[q1 - 1] + c->F.h[q1] + a.Z[q1]));
     const double Ce = cff * cff1;
     const double cff2 = 1.0 / (1.0 + Ce);
     x = cff2 * (a.Xold[qb] + Ce * X[q1]);
@@ -169,22 +180,33 @@ static void bc_know(const roms_step_idx_t *s, int *know, double *dt2d)
   else { *know = s->kstp; *dt2d = dtfast; }
 }
 
+static bool needs_know(const BcArgs &a)
+{
+  auto tl = [](int c) { return c == LBC_RADIATION || c == LBC_FLATHER || c == LBC_CHAPMAN_IMPLICIT; };
+  return tl(a.code_s) || tl(a.code_n);
+}
+
 int bc_zeta(int kout, const roms_step_idx_t *s)
 {
   BcArgs a = bc_args(LBV_ZETA, g_ctx.dev[FID_zeta] + (long)(kout - 1) * nij_host(), 1);
   int know = kout; double dt2d = 0.0;
   if (s) bc_know(s, &know, &dt2d);
-  else if (a.code_s == LBC_CHAPMAN_IMPLICIT || a.code_n == LBC_CHAPMAN_IMPLICIT)
-    return roms_fail("bc_zeta", "the Chapman condition needs the barotropic time indices");
+  else if (needs_know(a)) return roms_fail("bc_zeta", "this condition needs the barotropic time indices");
   a.Xold = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
   a.D = g_ctx.dev[FID_zeta_bry];
   a.dt2d = dt2d;
   return edge_bc(a);
 }
-int bc_u2d(int kout)
+int bc_u2d(int kout, const roms_step_idx_t *s)
 {
   BcArgs a = bc_args(LBV_UBAR, g_ctx.dev[FID_ubar] + (long)(kout - 1) * nij_host(), 1);
+  int know = kout; double dt2d = 0.0;
+  if (s) bc_know(s, &know, &dt2d);
+  else if (needs_know(a)) return roms_fail("bc_u2d", "this condition needs the barotropic time indices");
+  a.Xold = g_ctx.dev[FID_ubar] + (long)(know - 1) * nij_host();
   a.D = g_ctx.dev[FID_ubar_bry];
+  a.Z = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
+  a.dt2d = dt2d;
   return edge_bc(a);
 }
 int bc_v2d(int kout, const roms_step_idx_t *s)
@@ -192,8 +214,8 @@ int bc_v2d(int kout, const roms_step_idx_t *s)
   BcArgs a = bc_args(LBV_VBAR, g_ctx.dev[FID_vbar] + (long)(kout - 1) * nij_host(), 1);
   int know = kout; double dt2d = 0.0;
   if (s) bc_know(s, &know, &dt2d);
-  else if (a.code_s == LBC_FLATHER || a.code_n == LBC_FLATHER)
-    return roms_fail("bc_v2d", "the Flather condition needs the barotropic time indices");
+  else if (needs_know(a)) return roms_fail("bc_v2d", "this condition needs the barotropic time indices");
+  a.Xold = g_ctx.dev[FID_vbar] + (long)(know - 1) * nij_host();
   a.D = g_ctx.dev[FID_vbar_bry];
   a.Z = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
   a.Zb = g_ctx.dev[FID_zeta_bry];

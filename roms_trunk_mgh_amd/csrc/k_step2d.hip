@@ -331,7 +331,7 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   if (s.iif > p.nfast) return 0;
   if ((rc = bc_zeta(s.knew, si))) return rc;
   if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, zeta_new, zwrk))) return rc;
-  if ((rc = bc_u2d(s.knew))) return rc;
+  if ((rc = bc_u2d(s.knew, si))) return rc;
   if ((rc = bc_v2d(s.knew, si))) return rc;
   halo_batch_begin();
   if (s.predictor) halo_exchange2d(GT_R, g_ctx.dev[FID_rzeta] + (long)(s.krhs - 1) * nij);

@@ -191,12 +191,13 @@ int halo_batch_end();                     // ... and run them as one message per
 // lateral boundary conditions on the S/N edges (k_base.hip); s = the barotropic time indices (Chapman, Flather),
 // nstp = the time level the radiation condition compares with
 int bc_zeta(int kout, const roms_step_idx_t *s);
-int bc_u2d(int kout);
+int bc_u2d(int kout, const roms_step_idx_t *s);
 int bc_v2d(int kout, const roms_step_idx_t *s);
 int bc_u3d(int nout, int nstp);
 int bc_v3d(int nout, int nstp);
 int bc_t3d(int nout, int itrc, int nstp);
 bool lbc2d_all_closed();
+int lbc_code(const roms_params_t &p, int sd, int v);   // effective enum roms_lbc of variable v on side sd
 int bc_w3d(double *A);
 void snapshot_release();                  // snapshot.hip: waits for and frees an in-flight snapshot
 void snapshot_forget(int field_id);       // snapshot.hip: the same for one field (before it is re-registered)

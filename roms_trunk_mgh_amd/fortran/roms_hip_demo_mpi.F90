@@ -108,6 +108,11 @@ PROGRAM roms_hip_demo_mpi
     s%nstp = 1 + MOD(iic-ntstart, 2)
     s%nnew = 3 - s%nstp
     s%nrhs = s%nstp
+    IF (iic == ntstart) THEN                  ! main3d.F:269-283
+      CALL check (roms_hip_ini_zeta (s), 'ini_zeta')
+      CALL check (roms_hip_set_depth (s), 'set_depth')
+      CALL check (roms_hip_ini_fields (s), 'ini_fields')
+    END IF
     CALL check (roms_hip_set_massflux (s), 'set_massflux')
     CALL check (roms_hip_rho_eos (s), 'rho_eos')
     CALL check (roms_hip_omega (s), 'omega')

@@ -190,6 +190,14 @@ MODULE roms_hip_mod
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
     END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_ini_zeta (s) BIND(C, name='roms_hip_ini_zeta')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_ini_fields (s) BIND(C, name='roms_hip_ini_fields')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
     INTEGER(c_int) FUNCTION roms_hip_rhs3d (s) BIND(C, name='roms_hip_rhs3d')
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
@@ -253,6 +261,7 @@ MODULE roms_hip_mod
   PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
   PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc, roms_hip_lmd_vmix
   PUBLIC :: roms_hip_ana_srflux, roms_hip_wvelocity, roms_hip_diag, roms_hip_snapshot_begin, roms_hip_snapshot_end
+  PUBLIC :: roms_hip_ini_zeta, roms_hip_ini_fields
   PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
 
 CONTAINS

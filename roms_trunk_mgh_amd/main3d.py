@@ -8,6 +8,7 @@ because the full Fortran executable cannot be linked in this environment
 against either backend (`hip.RomsHip` = the product, or the CPU oracle in tests):
 
     main3d.F:189-191  nstp/nnew/nrhs rotation
+    main3d.F:269-283  first step only: ini_zeta, set_depth, ini_fields
     main3d.F:307-314  set_massflux, rho_eos, diag      (diag: diagnostics=True, every ninfo steps)
     main3d.F:280      set_data -> ana_srflux           (physics=True, BENCHMARK: shortwave flux of the hour)
     main3d.F:388-394  bulk_flux, set_vbc               (physics=True; else fixed forcing inputs)
@@ -80,6 +81,10 @@ class Main3D:
         be, s = self.be, self
         self._rotate()
         s = self.s
+        if self.iic == self.ntstart:          # main3d.F:269-283: all time levels and the other initial fields
+            be.call("ini_zeta", s)
+            be.call("set_depth", s)
+            be.call("ini_fields", s)
         be.call("set_massflux", s)
         be.call("rho_eos", s)
         if self.diagnostics and (self.iic - 1) % self.ninfo == 0:

@@ -18,8 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
 
 CONFIGS = [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)]
-TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla"]),
-         "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
+TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad"]),
+         "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
          "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad"])}
 
 

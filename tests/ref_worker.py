@@ -69,8 +69,8 @@ def main_bc(config, mask=None):
             row = a[:, j - b.LBj]
             row += 1.0e-3 * (1.0 + np.abs(row)) * rng.standard_normal(row.shape)
     out = {"masking": int(st0.p.masking), "cases": {}}
-    table = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla"]),
-             "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
+    table = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad"]),
+             "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
              "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad"])}
     steps = [util.step_idx(iic=5, iif=1, pred=1, kstp=1, krhs=1, knew=3), util.step_idx(iic=5, iif=3, pred=1, kstp=2, krhs=1, knew=3),
              util.step_idx(iic=5, iif=3, pred=0, kstp=1, krhs=3, knew=2)]
@@ -91,6 +91,56 @@ def main_bc(config, mask=None):
                 changed = util.compare_states(st_r, st0)
                 out["cases"][f"{kind}:{code}:{q}"] = {"max_rel_diff": max(diffs.values()) if diffs else 0.0,
                                                      "changed": sorted(changed)}
+    print(json.dumps(out))
+
+
+INI_TABLES = {"closed": None,
+              "cha_fla_rad": {"zeta": "Cha", "ubar": "Fla", "vbar": "Fla", "u": "Rad", "v": "Rad", "t": "Rad"},
+              "gradient": {v: "Gra" for v in ("zeta", "ubar", "vbar", "u", "v", "t")},
+              "clamped": {v: "Cla" for v in ("zeta", "ubar", "vbar", "u", "v", "t")},
+              "radiation": {v: "Rad" for v in ("zeta", "ubar", "vbar", "u", "v", "t")}}
+
+
+def ini_cases(config, mask):
+    """(key, state, step indices) of the first-step initialisation cases: every boundary-condition table, with the
+    time indices of the reference's first step (kstp = knew = 1, nstp = 1, nnew = 2; initial.F:133-143,
+    main3d.F:189-191) and with knew = 2 (the routine's other branch of "knew /= kstp")."""
+    import util
+    from roms_trunk_mgh_amd import abi
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_bc import input_state
+    st0 = input_state(config, mask)
+    rng = np.random.default_rng(23)
+    st0["u"][:, :, :, 0] += 0.01 * rng.standard_normal(st0["u"][:, :, :, 0].shape)      # so that ubar, vbar change
+    st0["v"][:, :, :, 0] += 0.01 * rng.standard_normal(st0["v"][:, :, :, 0].shape)
+    for name, table in INI_TABLES.items():
+        for knew in (1, 2):
+            st = st0.copy()
+            st.p = type(st0.p).from_buffer_copy(st0.p)
+            if table:
+                for sd in ("south", "north"):
+                    for var, code in table.items():
+                        st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+            s = util.step_idx(iic=1, iif=1, pred=0, kstp=1, krhs=1, knew=knew)
+            s.nstp, s.nnew, s.nrhs = 1, 2, 1
+            yield f"{name}:{knew}", st, s
+
+
+def main_ini(config, mask=None):
+    """ini_zeta + ini_fields (ini_fields.F; main3d.F:269-283): reference Fortran vs C oracle."""
+    import oracle
+    import util
+    from oracle import ref
+    out = {"cases": {}}
+    for key, st, s in ini_cases(config, mask):
+        out["masking"] = int(st.p.masking)
+        st0, st_r, st_o = st.copy(), st.copy(), st
+        for kind in ("ini_zeta", "ini_fields"):
+            ref.Ref(st_r).bc(kind, s, 0, 0)
+            oracle.Oracle(st_o).call(kind, s)
+        diffs = util.compare_states(st_o, st_r)
+        changed = util.compare_states(st_r, st0)
+        out["cases"][key] = {"max_rel_diff": max(diffs.values()) if diffs else 0.0, "changed": sorted(changed)}
     print(json.dumps(out))
 
 
@@ -279,6 +329,8 @@ if __name__ == "__main__":
         main_mpdata(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mask":
         main(sys.argv[1], mask="island")
+    elif len(sys.argv) > 2 and sys.argv[2] in ("ini", "ini_mask"):
+        main_ini(sys.argv[1], mask="island" if sys.argv[2] == "ini_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] in ("bc", "bc_mask"):
         main_bc(sys.argv[1], mask="island" if sys.argv[2] == "bc_mask" else None)
     else:

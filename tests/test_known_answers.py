@@ -1,7 +1,7 @@
 """Known-answer tests that do NOT come from reading the reference's Fortran: analytic solutions of the
 equations the path discretises, run through the whole step (main3d sequencing) on a flat-bottom, uniform-
 density periodic channel.  They are independent evidence for the routines whose oracle is parity-unpinned
-against reference output (step2d, pre_step3d, rhs3d_tile, step3d_uv, omega) -- a
+against reference output (step2d, pre_step3d, rhs3d_tile, step3d_uv, step3d_t, omega) -- a
 misread coefficient in the C restatement AND in the HIP kernel (written from the same Fortran) would pass
 every HIP-vs-oracle test and fail here.
 
@@ -16,6 +16,9 @@ every HIP-vs-oracle test and fail here.
 * momentum diffusion: a cosine mode of u(z) with no stress at top and bottom decays as
   exp(-Akv m^2 t) -- constrains the spline-form implicit operator of step3d_uv.F:346-400
   (FC/CF/BC with Hz/6, Hz/3 and dt*Akv/Hz).
+* tracer wave in a uniform current: translated at U, damped at the rate of the third-order upstream scheme's own
+  symbol, damping ~ k^4 -- constrains the U3 fluxes and time stepping of pre_step3d.F / step3d_t.F and the mass
+  fluxes of step3d_uv.F.
 Each test runs on the oracle (CPU) and, with -m gpu, on the HIP path."""
 import math
 
@@ -175,3 +178,63 @@ def test_vertical_momentum_diffusion_mode(kind):
     # the shape is preserved (it is an eigenmode), nothing leaks into v or the free surface
     assert float(np.abs(ui - ratio * p0).max()) < 2.0e-3 * 0.1
     assert float(np.abs(st.interior("v")).max()) < 1e-10
+
+
+def _u3_symbol(theta):
+    """Eigenvalue (times dx/U) of the third-order upstream-biased flux-form advection operator for the mode
+    exp(i k x), U > 0: face value (-S[i-1] + 5 S[i] + 2 S[i+1]) / 6 = centred average minus one sixth of the
+    upstream curvature (Shchepetkin & McWilliams 1998, the scheme TS_U3HADVECTION names)."""
+    e = complex(math.cos(theta), math.sin(theta))
+    face = 0.5 * (1.0 + e) - (e - 2.0 + 1.0 / e) / 6.0
+    return -(1.0 - 1.0 / e) * face
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_tracer_wave_in_uniform_flow_u3(kind):
+    """A passive tracer wave S = S0 + A cos(k x) in a uniform zonal current U (flat channel, f = 0, no stress: a
+    steady state of the momentum equations) is translated at speed U and, with third-order upstream advection,
+    damped at the rate of the scheme's own symbol, Re(lambda) = -(U/dx) theta^4/12 (1 + O(theta^2)) -- constrains
+    the 1/6 curvature weights and the upstream selection of the U3 fluxes in pre_step3d.F:364-420 and
+    step3d_t.F:596-700, the LF-TR/AB3 time-stepping weights (their error enters at O((U dt/dx)^2) of this), and
+    the mass fluxes Huon handed from step3d_uv to the tracers (a wrong flux moves the wave at another speed).
+    Two wavelengths give the order: damping over a fixed time scales with k^4."""
+    U, A = 0.5, 1.0
+    dt, ndtfast, nsteps = 100.0, 20, 120
+    out = {}
+    for mode in (1, 2):
+        st = _channel(dt, ndtfast)
+        st.p.Scoef = 0.0                                   # salinity does not enter the density: passive
+        b = st.b
+        dx = 1.0 / float(st["pm"][3, 3])
+        theta = 2.0 * math.pi * mode / b.Lm
+        xr = (np.arange(b.LBi, b.UBi + 1) - 0.5) * dx     # rho-points
+        k = theta / dx
+        S = 35.0 + A * np.cos(k * xr)
+        st["t"][:, :, :, :, 1] = S[:, None, None, None]
+        st["u"][:] = U
+        st["ubar"][:] = U
+        be = _backend(kind, st)
+        m = main3d.Main3D(be)
+        m.initial()
+        m.run(nsteps)
+        if kind == "hip":
+            be.to_host()
+            be.close()
+        T = nsteps * dt
+        Si = st.interior("t")[:, :, :, m.s.nnew - 1, 1]
+        xi = xr[st.I(b.Istr, b.Iend)]
+        # nothing else moved: the current is steady, the wave stays independent of y and z
+        assert float(np.abs(st.interior("u")[..., m.s.nnew - 1] - U).max()) < 1e-9
+        assert float(np.abs(Si - Si[:, :1, :1]).max()) < 1e-9
+        s1 = Si[:, 3, 5] - 35.0
+        c = 2.0 * np.mean(s1 * np.cos(k * xi)), 2.0 * np.mean(s1 * np.sin(k * xi))
+        amp, phase = math.hypot(*c), math.atan2(c[1], c[0])
+        lam = _u3_symbol(theta) * U / dx
+        out[mode] = (-math.log(amp / A) / T, phase / (k * T), lam)
+        # translated at the phase speed of the scheme (= U up to its fourth-order dispersion)
+        assert abs(phase / T / (-lam.imag) - 1.0) < 1.0e-3, (phase / T, -lam.imag)
+        assert abs(phase / (k * T) / U - 1.0) < 1.0e-3
+        # damped at the rate of the third-order scheme
+        assert abs(out[mode][0] / (-lam.real) - 1.0) < 3.0e-2, (out[mode][0], -lam.real)
+    order = math.log2(out[2][0] / out[1][0])
+    assert 3.8 < order < 4.05, (order, out)

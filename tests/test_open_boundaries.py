@@ -1,7 +1,8 @@
 """Open boundary conditions on the southern / northern edges: Chapman implicit for the
-free surface (zetabc.F:489, :638), Flather for the normal barotropic velocity (v2dbc_im.F:216, :565), gradient and
-clamped for every variable, implicit upstream radiation for u, v and the tracers (u3dbc_im.F:381, v3dbc_im.F:97,
-t3dbc_im.F:364), selected per variable and side through roms_params_t.lbc as LBC(:,isFsur..isTvar,ng) does.
+free surface (zetabc.F:489, :638), Flather for the normal barotropic velocity (v2dbc_im.F:216, :565) with the
+Chapman-type rule the reference gives the tangential one on such an edge (u2dbc_im.F:912, :1070), gradient, clamped
+and implicit upstream radiation for every variable (zetabc.F:408, u2dbc_im.F:833, v2dbc_im.F:138, u3dbc_im.F:381,
+v3dbc_im.F:97, t3dbc_im.F:364), selected per variable and side through roms_params_t.lbc as LBC(:,isFsur..isTvar,ng) does.
 
 CPU (oracle): a free-surface bump in a flat channel leaves through Chapman / Flather edges and is kept by closed
 walls; clamped edges hold the prescribed values.  GPU (-m gpu): the same runs and every boundary kernel, HIP
@@ -15,7 +16,9 @@ import util
 from roms_trunk_mgh_amd import abi, ana, main3d
 
 H0 = 150.0
-OPEN = {"zeta": "Cha", "ubar": "Gra", "vbar": "Fla", "u": "Rad", "v": "Rad", "t": "Rad"}
+# the usual open-ocean set of roms_*.in: LBC(isFsur) = Cha, LBC(isUbar) = LBC(isVbar) = Fla, 3-D variables Rad
+OPEN = {"zeta": "Cha", "ubar": "Fla", "vbar": "Fla", "u": "Rad", "v": "Rad", "t": "Rad"}
+RADI = {v: "Rad" for v in OPEN}               # implicit upstream radiation for every variable
 GRAD = {v: "Gra" for v in OPEN}
 CLAMP = {v: "Cla" for v in OPEN}
 
@@ -68,19 +71,22 @@ BACKENDS = ["oracle", pytest.param("hip", marks=pytest.mark.gpu)]
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
-def test_wave_leaves_through_open_edges(kind):
+@pytest.mark.parametrize("which", ["cha_fla_rad", "radiation"])
+def test_wave_leaves_through_open_edges(kind, which):
     """c = sqrt(g H) = 38 m/s: the two waves need 40 km / c = 1040 s to reach the edges; after 2400 s an open
     channel is (almost) at rest, a closed one still holds the energy."""
     nsteps = 24
     left = {}
-    for name, table in (("open", OPEN), ("closed", None)):
+    for name, table in (("open", OPEN if which == "cha_fla_rad" else RADI), ("closed", None)):
         st = _bump_channel(table)
         e0 = float((st.interior("Zt_avg1") ** 2).sum())
         _run(kind, st, nsteps)
         left[name] = float((st.interior("Zt_avg1") ** 2).sum()) / e0
         assert np.isfinite(st["zeta"]).all() and np.isfinite(st["u"]).all()
     assert left["closed"] > 0.3, left
-    assert left["open"] < 0.02 * left["closed"], left
+    # Chapman + Flather absorb the wave almost completely; radiation alone (no RADIATION_2D, and the free surface
+    # of the southern edge differenced towards the boundary row, zetabc.F:424) lets about a quarter back
+    assert left["open"] < (0.02 if which == "cha_fla_rad" else 0.35) * left["closed"], left
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
@@ -114,7 +120,7 @@ def test_clamped_edges_hold_the_boundary_data(kind):
 # -------------------------------------------------------------------------------------------- GPU parity
 @pytest.mark.gpu
 @pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING", "SEAMOUNT"])
-@pytest.mark.parametrize("table", [OPEN, GRAD, CLAMP], ids=["cha_fla_rad", "gradient", "clamped"])
+@pytest.mark.parametrize("table", [OPEN, RADI, GRAD, CLAMP], ids=["cha_fla_rad", "radiation", "gradient", "clamped"])
 @pytest.mark.parametrize("kernel", ["step2d", "step3d_uv", "step3d_t", "pre_step3d"])
 def test_hip_kernels_with_open_edges(config, table, kernel):
     import oracle
