@@ -83,6 +83,10 @@ typedef struct roms_bounds {
 enum roms_adv {
   ADV_C2 = 0, ADV_C4, ADV_A4, ADV_U3, ADV_SU3, ADV_SPLINES, ADV_MPDATA, ADV_HSIMT
 };
+/* Pressure-gradient algorithm (the CPP choice of ROMS/Nonlinear/prsgrd.F:16-26): DJ_GRADPS = prsgrd32.h (the three
+ * application headers of BASELINE.json define it), none of the options = prsgrd31.h (standard density Jacobian, the
+ * reference's default), WJ_GRADP = prsgrd31.h with the weighted Jacobian of Song (1998). */
+enum roms_pgf { PGF_DJ_GRADPS = 0, PGF_STANDARD = 1, PGF_WJ_GRADP = 2 };
 /* Lateral boundary condition codes supported on this path (the logical records of T_LBC, mod_param.F:348-363).
  * West and east: periodic only.  South and north, per variable (roms_params_t.lbc): closed, gradient, clamped,
  * radiation (implicit upstream, zetabc.F:408 / u2dbc_im.F:833 / v2dbc_im.F:138 / u3dbc_im.F:381 / v3dbc_im.F:97 /
@@ -130,7 +134,7 @@ typedef struct roms_params {
   double blk_ZQ, blk_ZT, blk_ZW;     /* measurement heights of bulk_flux.F (roms_*.in BLK_ZQ/ZT/ZW) */
   int    masking;                    /* 1 = the application defines MASKING: rmask/umask/vmask/pmask are applied
                                       * where the reference applies them (e.g. step2d_LF_AM3.h:778, step3d_t.F:603) */
-  int    pad_masking_;
+  int    pgf;                        /* enum roms_pgf: the pressure-gradient algorithm prsgrd.F:16-26 selects */
   /* lbc[side][variable] (enum roms_lbc_side, roms_lbc_var; every tracer shares LBV_T): 0 = take the side's
    * lbc_west / lbc_east / lbc_south / lbc_north above, otherwise an enum roms_lbc code */
   int    lbc[4][LBV_COUNT];

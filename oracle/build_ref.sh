@@ -10,8 +10,10 @@
 #
 #   oracle/_ref/<APP>/libref.so   reference objects + our bind(C) wrapper
 #                                 (oracle/ref_wrap.F90) for APP in
-#                                 BENCHMARK, UPWELLING, SEAMOUNT, and BENCHMARK_MASK,
-#                                 UPWELLING_MASK (= the application + -DMASKING)
+#                                 BENCHMARK, UPWELLING, SEAMOUNT; BENCHMARK_MASK, UPWELLING_MASK
+#                                 (= the application + -DMASKING); UPWELLING_PG31, UPWELLING_WJ,
+#                                 SEAMOUNT_PG31, SEAMOUNT_WJ (= the application with prsgrd31.h, plain
+#                                 and with WJ_GRADP, instead of prsgrd32.h)
 #
 # This is the reference's own recipe (makefile:207, Compilers/Linux-gfortran.mk:
 # 43-44: cpp -P -traditional then the Fortran compiler), serial build (no
@@ -43,13 +45,15 @@ FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iouni
 build_app () {
   # <APP>_MASK: the same application with the MASKING option added on the command line (a CPP option of the
   # reference, globaldefs.h / mod_grid.F:322+); the wrapper then hands rmask/umask/vmask/pmask to GRID(ng)
-  local TAG=$1 APP=${1%_MASK} XDEF=""
-  [ "$TAG" != "$APP" ] && XDEF="-DMASKING"
+  # <APP>_PG31 / <APP>_WJ (UPWELLING, SEAMOUNT): the application's options with DJ_GRADPS taken out / replaced by
+  # WJ_GRADP, so that prsgrd.F selects prsgrd31.h (ref_headers/*_pg31.h, *_wj.h)
+  local TAG=$1 APP=${1%%_*} XDEF="" VAR=nodiag
+  case $TAG in *_MASK) XDEF="-DMASKING";; *_PG31) VAR=pg31;; *_WJ) VAR=wj;; esac
   local hdr=$(echo $APP | tr A-Z a-z).h
   # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
-  [ "$APP" = UPWELLING ] && hdr=upwelling_nodiag.h
+  [ "$APP" = UPWELLING ] && hdr=upwelling_$VAR.h
   # SEAMOUNT: same numerics without ANA_DIAG, whose ana_diag.h does not compile (see ref_headers/seamount_nodiag.h)
-  [ "$APP" = SEAMOUNT ] && hdr=seamount_nodiag.h
+  [ "$APP" = SEAMOUNT ] && hdr=seamount_$VAR.h
   local D=$OUT/$TAG
   if [ -f $D/libref.so ] && [ $D/libref.so -nt $HERE/ref_wrap.F90 ] && [ $D/libref.so -nt $HERE/build_ref.sh ]; then
     return 0
@@ -77,7 +81,7 @@ build_app () {
   echo "[$TAG] built $D/libref.so"
 }
 
-for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK}; do
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ}; do
   build_app $app &
 done
 wait

@@ -6,8 +6,66 @@
  */
 #include "oracle.h"
 
+/* prsgrd31_tile -- ROMS/Nonlinear/prsgrd31.h:97-364: the standard density Jacobian (the reference's default when no
+ * pressure-gradient option is defined, prsgrd.F:24-25), optionally the weighted Jacobian of Song 1998 (WJ_GRADP).
+ * RHO_SURF is always defined (globaldefs.h:130); no ATM_PRESS, no TIDE_GENERATING_FORCES, no WET_DRY.  The routine
+ * has no MASKING blocks.  Pinned against builds of the reference without DJ_GRADPS (oracle/_ref/UPWELLING_PG31,
+ * UPWELLING_WJ). */
+static int oracle_prsgrd31(OARGS)
+{
+  ORACLE_PROLOGUE
+  const int nrhs = s->nrhs, wj = p->pgf == PGF_WJ_GRADP;
+  const double g = p->g, rho0 = p->rho0;
+  const double fac1 = 0.5 * g / rho0, fac2 = 1000.0 * g / rho0, fac3 = 0.25 * g / rho0;
+  double *phi = walloc(nis);
+  for (int j = Jstr; j <= Jend; j++) {
+    for (int dir = 0; dir < 2; dir++) {               /* 0: XI-component (:196-268), 1: ETA-component (:276-352) */
+      if (dir == 1 && j < JstrV) continue;
+      const int di = dir ? 0 : 1, dj = dir ? 1 : 0;
+      for (int i = (dir ? Istr : IstrU); i <= Iend; i++) {
+        const int im = i - di, jm = j - dj;
+        double cff1 = z_w(i, j, N) - z_r(i, j, N) + z_w(im, jm, N) - z_r(im, jm, N);
+        double ph = fac1 * (rho(i, j, N) - rho(im, jm, N)) * cff1;
+        ph = ph + (fac2 + fac1 * (rho(i, j, N) + rho(im, jm, N))) * (z_w(i, j, N) - z_w(im, jm, N));
+        phi[i - IminS] = ph;
+        const double r = -0.5 * (Hz(i, j, N) + Hz(im, jm, N)) * ph * (dir ? om_v(i, j) : on_u(i, j));
+        if (dir) rv(i, j, N, nrhs) = r; else ru(i, j, N, nrhs) = r;
+      }
+      for (int k = N - 1; k >= 1; k--)
+        for (int i = (dir ? Istr : IstrU); i <= Iend; i++) {
+          const int im = i - di, jm = j - dj;
+          double cff1, cff2, cff3, cff4;
+          if (wj) {
+            cff1 = 1.0 / ((z_r(i, j, k + 1) - z_r(i, j, k)) * (z_r(im, jm, k + 1) - z_r(im, jm, k)));
+            cff2 = z_r(i, j, k) - z_r(im, jm, k) + z_r(i, j, k + 1) - z_r(im, jm, k + 1);
+            cff3 = z_r(i, j, k + 1) - z_r(i, j, k) - z_r(im, jm, k + 1) + z_r(im, jm, k);
+            const double gamma = 0.125 * cff1 * cff2 * cff3;
+            cff1 = (1.0 + gamma) * (rho(i, j, k + 1) - rho(im, jm, k + 1)) + (1.0 - gamma) * (rho(i, j, k) - rho(im, jm, k));
+            cff2 = rho(i, j, k + 1) + rho(im, jm, k + 1) - rho(i, j, k) - rho(im, jm, k);
+            cff3 = z_r(i, j, k + 1) + z_r(im, jm, k + 1) - z_r(i, j, k) - z_r(im, jm, k);
+            cff4 = (1.0 + gamma) * (z_r(i, j, k + 1) - z_r(im, jm, k + 1)) + (1.0 - gamma) * (z_r(i, j, k) - z_r(im, jm, k));
+          } else {
+            cff1 = rho(i, j, k + 1) - rho(im, jm, k + 1) + rho(i, j, k) - rho(im, jm, k);
+            cff2 = rho(i, j, k + 1) + rho(im, jm, k + 1) - rho(i, j, k) - rho(im, jm, k);
+            cff3 = z_r(i, j, k + 1) + z_r(im, jm, k + 1) - z_r(i, j, k) - z_r(im, jm, k);
+            cff4 = z_r(i, j, k + 1) - z_r(im, jm, k + 1) + z_r(i, j, k) - z_r(im, jm, k);
+          }
+          phi[i - IminS] = phi[i - IminS] + fac3 * (cff1 * cff3 - cff2 * cff4);
+          const double r = -0.5 * (Hz(i, j, k) + Hz(im, jm, k)) * phi[i - IminS] * (dir ? om_v(i, j) : on_u(i, j));
+          if (dir) rv(i, j, k, nrhs) = r; else ru(i, j, k, nrhs) = r;
+        }
+    }
+  }
+  free(phi);
+  return 0;
+}
+
 int oracle_prsgrd(OARGS)
 {
+  if (p->pgf != PGF_DJ_GRADPS) {
+    if (p->pgf != PGF_STANDARD && p->pgf != PGF_WJ_GRADP) return 8;
+    return oracle_prsgrd31(b, p, s, F);
+  }
   ORACLE_PROLOGUE
   const int nrhs = s->nrhs;
   const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0, eps = 1.0E-10;

@@ -23,6 +23,7 @@ def available(app):
 class Ref:
     def __init__(self, state):
         app = state.cfg["app"] + ("_MASK" if state.p.masking else "")      # <APP>_MASK: built with -DMASKING
+        app += {0: "", 1: "_PG31", 2: "_WJ"}[int(state.p.pgf)]             # prsgrd31.h builds (plain / WJ_GRADP)
         self.l = C.CDLL(lib_path(app))
         self.st = state
         self.l.ref_abi_sizeof.argtypes = [C.c_int]

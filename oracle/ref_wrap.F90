@@ -47,7 +47,7 @@ MODULE ref_wrap_types
     REAL(c_double) :: swfrac_mu1, swfrac_mu2, swfrac_r1
     INTEGER(c_int) :: uv_drag, mpdata_fast
     REAL(c_double) :: blk_ZQ, blk_ZT, blk_ZW
-    INTEGER(c_int) :: masking, pad_masking
+    INTEGER(c_int) :: masking, pgf
     INTEGER(c_int) :: lbc(6,4)          ! C: lbc[side][variable]
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t

@@ -467,6 +467,8 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
     for name in ("rmask", "umask", "vmask", "pmask"):
         A[name][:] = 1.0
     p.masking = 0
+    # pressure-gradient algorithm (prsgrd.F:16-26): the three application headers define DJ_GRADPS
+    p.pgf = abi.PGF[cfg.get("pgf", "DJ_GRADPS")]
     if mask == "island":
         set_masks(st, island_mask(cfg, b))
         # masked initial state, as the reference's ini_fields / ana_initial leave it

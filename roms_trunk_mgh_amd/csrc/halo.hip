@@ -152,8 +152,8 @@ int halo_init()
 
 int halo_finalize()
 {
-  for (auto &p : g_buf) { if (p) hipFree(p); p = nullptr; }
-  for (auto &p : g_hbuf) { if (p) hipHostFree(p); p = nullptr; }
+  for (auto &p : g_buf) { if (p) (void)hipFree(p); p = nullptr; }
+  for (auto &p : g_hbuf) { if (p) (void)hipHostFree(p); p = nullptr; }
   g_buf_doubles = g_hbuf_doubles = 0;
   g_have_neigh = false;
   g_have_plan = false;

@@ -250,8 +250,8 @@ long g_diag_rows_n = 0;
 
 void diag_release()
 {
-  if (g_diag_dev) hipFree(g_diag_dev);
-  if (g_diag_rows) hipFree(g_diag_rows);
+  if (g_diag_dev) (void)hipFree(g_diag_dev);
+  if (g_diag_rows) (void)hipFree(g_diag_rows);
   g_diag_dev = g_diag_rows = nullptr;
   g_diag_rows_n = 0;
 }

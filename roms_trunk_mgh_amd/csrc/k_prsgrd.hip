@@ -149,6 +149,76 @@ k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrh
   }
 }
 
+// prsgrd31_tile (ROMS/Nonlinear/prsgrd31.h:97-364): the standard density Jacobian -- the reference's default when no
+// pressure-gradient option is defined (prsgrd.F:24-25) -- and, WJ = true, the weighted Jacobian of Song 1998
+// (WJ_GRADP).  One thread per column marches down from the surface with the two running sums phix, phie in
+// registers and the (k+1) values of rho, z_r of its three columns kept from the previous level: every field is
+// read once per point it is needed at, nothing goes through scratch (5 field passes: rho, z_r, Hz in; ru, rv out).
+// RHO_SURF is always on (globaldefs.h:130); the routine has no MASKING blocks.
+template <bool WJ>
+__global__ void __launch_bounds__(BLK_X *BLK_Y) k_prsgrd31(const RomsDev *__restrict__ c, int nrhs)
+{
+  DEV_PROLOGUE(c)
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x, j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.Jend) return;
+  const bool do_u = i >= b.IstrU, do_v = j >= b.JstrV;
+  const gcd_t rho = (gcd_t)(c->F.rho), z_r = (gcd_t)(c->F.z_r), Hz = (gcd_t)(c->F.Hz);
+  const gd_t ru = (gd_t)(c->F.ru + (long)(nrhs - 1) * n3w), rv = (gd_t)(c->F.rv + (long)(nrhs - 1) * n3w);
+  const double g = c->p.g, rho0 = c->p.rho0;
+  const double fac1 = 0.5 * g / rho0, fac2 = 1000.0 * g / rho0, fac3 = 0.25 * g / rho0;
+  const long a = I2(i, j), aw = do_u ? a - 1 : a, as = do_v ? a - ni : a;   // neighbours only where they are used
+  const double onu = GF(on_u)[a], omv = GF(om_v)[a];
+  // surface level, :196-226 and :276-306
+  long q = a + (long)(N - 1) * nij, qw = aw + (long)(N - 1) * nij, qs = as + (long)(N - 1) * nij;
+  double r1 = rho[q], z1 = z_r[q], r1w = rho[qw], z1w = z_r[qw], r1s = rho[qs], z1s = z_r[qs];
+  const gcd_t zw = (gcd_t)(c->F.z_w);
+  const double zw0 = zw[a + (long)N * nij], zww = zw[aw + (long)N * nij], zws = zw[as + (long)N * nij];
+  double phix, phie;
+  {
+    const double cff1 = zw0 - z1 + zww - z1w;
+    phix = fac1 * (r1 - r1w) * cff1;
+    phix = phix + (fac2 + fac1 * (r1 + r1w)) * (zw0 - zww);
+    const double cff1e = zw0 - z1 + zws - z1s;
+    phie = fac1 * (r1 - r1s) * cff1e;
+    phie = phie + (fac2 + fac1 * (r1 + r1s)) * (zw0 - zws);
+    const double hz = Hz[q];
+    if (do_u) ru[I3W(i, j, N)] = -0.5 * (hz + Hz[qw]) * phix * onu;
+    if (do_v) rv[I3W(i, j, N)] = -0.5 * (hz + Hz[qs]) * phie * omv;
+  }
+  // interior: differentiate, then integrate downwards, :232-268 and :312-352
+  auto jac = [&](double rk1, double rk1m, double rk, double rkm, double zk1, double zk1m, double zk, double zkm) {
+    double cff1, cff2, cff3, cff4;
+    if (WJ) {
+      cff1 = 1.0 / ((zk1 - zk) * (zk1m - zkm));
+      cff2 = zk - zkm + zk1 - zk1m;
+      cff3 = zk1 - zk - zk1m + zkm;
+      const double gamma = 0.125 * cff1 * cff2 * cff3;
+      cff1 = (1.0 + gamma) * (rk1 - rk1m) + (1.0 - gamma) * (rk - rkm);
+      cff2 = rk1 + rk1m - rk - rkm;
+      cff3 = zk1 + zk1m - zk - zkm;
+      cff4 = (1.0 + gamma) * (zk1 - zk1m) + (1.0 - gamma) * (zk - zkm);
+    } else {
+      cff1 = rk1 - rk1m + rk - rkm;
+      cff2 = rk1 + rk1m - rk - rkm;
+      cff3 = zk1 + zk1m - zk - zkm;
+      cff4 = zk1 - zk1m + zk - zkm;
+    }
+    return fac3 * (cff1 * cff3 - cff2 * cff4);
+  };
+#pragma unroll 2
+  for (int k = N - 1; k >= 1; k--) {
+    q -= nij; qw -= nij; qs -= nij;
+    const double r0 = rho[q], z0 = z_r[q], r0w = rho[qw], z0w = z_r[qw], r0s = rho[qs], z0s = z_r[qs];
+    const double hz = Hz[q], hzw = Hz[qw], hzs = Hz[qs];
+    phix = phix + jac(r1, r1w, r0, r0w, z1, z1w, z0, z0w);
+    phie = phie + jac(r1, r1s, r0, r0s, z1, z1s, z0, z0s);
+    if (do_u) ru[I3W(i, j, k)] = -0.5 * (hz + hzw) * phix * onu;
+    if (do_v) rv[I3W(i, j, k)] = -0.5 * (hz + hzs) * phie * omv;
+    r1 = r0; z1 = z0; r1w = r0w; z1w = z0w; r1s = r0s; z1s = z0s;
+  }
+}
+
 }  // namespace
 
 extern "C" int roms_hip_prsgrd(const roms_step_idx_t *s)
@@ -158,6 +228,17 @@ extern "C" int roms_hip_prsgrd(const roms_step_idx_t *s)
   if ((rc = check_lbc())) return rc;
   ScopedTimer tm("prsgrd");
   const roms_bounds_t &b = g_ctx.b;
+  if (g_ctx.p.pgf != PGF_DJ_GRADPS) {                   // prsgrd31.h: one launch, no scratch
+    if (g_ctx.p.pgf != PGF_STANDARD && g_ctx.p.pgf != PGF_WJ_GRADP)
+      return roms_fail("roms_hip_prsgrd", "unknown pressure-gradient algorithm (enum roms_pgf)");
+    const dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
+    if (g_ctx.p.pgf == PGF_WJ_GRADP)
+      hipLaunchKernelGGL(k_prsgrd31<true>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs);
+    else
+      hipLaunchKernelGGL(k_prsgrd31<false>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs);
+    KERNEL_CHECK("k_prsgrd31");
+    return 0;
+  }
   if (b.N < 3) return roms_fail("roms_hip_prsgrd", "N < 3");
   double *P = g_ctx.hostc.ws3[0];
   hipLaunchKernelGGL(k_prsgrd_P, grid2d(b.Iend - (b.IstrU - 1) + 1, b.Jend - (b.JstrV - 1) + 1), block2d(), 0,

@@ -12,13 +12,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main(config, mask=None):
+def main(config, mask=None, pgf=0):
     import oracle
     import util
     from oracle import ref
     ov = {"tnu2": 300.0, "visc2": 800.0} if config != "SEAMOUNT" else {"tnu2": 300.0}
     st0 = util.prepared_state(config, overrides=ov, mask=mask)
-    out = {}
+    st0.p.pgf = pgf                      # 1, 2: the reference built with prsgrd31.h (plain / WJ_GRADP)
+    out = {"pgf": int(st0.p.pgf)}
     r = ref.Ref(st0.copy())
     bb = r.bounds()
     mine = st0.b.as_dict()
@@ -329,6 +330,8 @@ if __name__ == "__main__":
         main_mpdata(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mask":
         main(sys.argv[1], mask="island")
+    elif len(sys.argv) > 2 and sys.argv[2] in ("pg31", "wj"):
+        main(sys.argv[1], pgf=1 if sys.argv[2] == "pg31" else 2)
     elif len(sys.argv) > 2 and sys.argv[2] in ("ini", "ini_mask"):
         main_ini(sys.argv[1], mask="island" if sys.argv[2] == "ini_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] in ("bc", "bc_mask"):

@@ -234,6 +234,46 @@ def test_hip_reproduces_reference_first_step_initialisation(config, mask):
             assert (str(val) == str(want)) if name.endswith("_sha256") else np.array_equal(val, want), (key, name)
 
 
+def _pgf_check(config, backend):
+    import sys
+    import util
+    gd = os.path.join(HERE, "golden")
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    import make_golden_pgf as mp
+    g = np.load(os.path.join(gd, f"ref_pgf_{config}.npz"))
+    s = util.step_idx()
+    for variant in mp.VARIANTS:
+        st = mp.input_state(config, variant)
+        backend(st, s)
+        for k, v in mp.results(st, s).items():
+            want = g[f"{variant}__{k}"]
+            assert (str(v) == str(want)) if k.endswith("_sha256") else np.array_equal(v, want), (variant, k)
+
+
+@pytest.mark.parametrize("config", ["UPWELLING", "SEAMOUNT"])
+def test_oracle_reproduces_reference_prsgrd31(config):
+    """prsgrd31_tile of the reference (standard and weighted Jacobian; tests/golden/make_golden_pgf.py) vs the oracle."""
+    import oracle
+    _pgf_check(config, lambda st, s: oracle.Oracle(st).call("prsgrd", s))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["UPWELLING", "SEAMOUNT"])
+def test_hip_reproduces_reference_prsgrd31(config):
+    """k_prsgrd31 against the committed outputs of the reference's prsgrd31.h, bit for bit."""
+    from roms_trunk_mgh_amd import hip
+
+    def run(st, s):
+        h = hip.RomsHip(st)
+        try:
+            h.call("prsgrd", s)
+            h.to_host()
+        finally:
+            h.close()
+    _pgf_check(config, run)
+
+
 def test_oracle_reproduces_reference_mpdata_adiff():
     """mpdata_adiff_tile: the committed outputs of the reference's Fortran (three levels stored,
     all elements through a SHA-256) vs the C oracle on the same deterministic inputs."""

@@ -79,6 +79,17 @@ def test_prsgrd(config):
 
 
 @pytest.mark.parametrize("config", CONFIGS)
+@pytest.mark.parametrize("pgf", ["STANDARD", "WJ_GRADP"])
+def test_prsgrd31(config, pgf):
+    """prsgrd31.h (standard / weighted density Jacobian, prsgrd.F:24-25) instead of prsgrd32.h; N = 40 as well."""
+    for ov in ({"pgf": pgf}, {"pgf": pgf, "N": 40}):
+        st_h, st_o, st0 = _run_pair(config, "prsgrd", util.step_idx(), overrides=ov)
+        diffs = util.compare_states(st_h, st_o)
+        assert all(v <= TOL for v in diffs.values()), diffs
+        assert util.max_rel_diff(st_o["ru"], st0["ru"]) > 1e-6 and util.max_rel_diff(st_o["rv"], st0["rv"]) > 1e-6
+
+
+@pytest.mark.parametrize("config", CONFIGS)
 def test_rho_eos(config):
     st_h, st_o, st0 = _run_pair(config, "rho_eos", util.step_idx())
     diffs = util.compare_states(st_h, st_o)

@@ -16,9 +16,9 @@ TOL = 1e-10
 FLOOR = {"zeta": 1e-3, "ubar": 1e-4, "vbar": 1e-4, "u": 1e-4, "v": 1e-4, "t": 1e-3}
 
 
-def _run(config, nsteps, perturb, physics=False):
+def _run(config, nsteps, perturb, physics=False, overrides=None):
     import oracle
-    st_o = ana.make_tile(config, perturb=perturb)
+    st_o = ana.make_tile(config, perturb=perturb, overrides=overrides)
     st_h = st_o.copy()
     mo = main3d.Main3D(oracle.Oracle(st_o), physics=physics, diagnostics=physics)
     mo.initial()
@@ -38,9 +38,14 @@ def _run(config, nsteps, perturb, physics=False):
 @pytest.mark.parametrize("config,perturb,physics", [("UPWELLING", 1.0, False), ("SEAMOUNT", 0.0, False),
                                                     ("BENCHMARK_TINY", 1.0, False),
                                                     # with bulk_flux + set_vbc recomputed every step on the device
-                                                    ("BENCHMARK_TINY", 1.0, True), ("UPWELLING", 1.0, True)])
+                                                    ("BENCHMARK_TINY", 1.0, True), ("UPWELLING", 1.0, True),
+                                                    # the reference's default pressure gradient (prsgrd31.h)
+                                                    ("SEAMOUNT", 0.0, "STANDARD"), ("UPWELLING", 1.0, "WJ_GRADP")])
 def test_100_steps(config, perturb, physics):
-    st_h, st_o, mo = _run(config, 100, perturb, physics)
+    ov = None
+    if isinstance(physics, str):
+        ov, physics = {"pgf": physics}, False
+    st_h, st_o, mo = _run(config, 100, perturb, physics, overrides=ov)
     s = mo.s
     out = {}
     out["zeta"] = rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], FLOOR["zeta"])
