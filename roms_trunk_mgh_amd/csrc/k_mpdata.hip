@@ -66,8 +66,11 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrUm2 + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrVm2 + blockIdx.y * BLK_Y + threadIdx.y;
+  // level fastest inside an XCD: the planes k-1, k, k+1 of a tile meet in one L2
+  const TileLv XB = decode_tile_level(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1, N);
+  if (!XB.valid) return;
+  const int i = b.IstrUm2 + XB.bx * BLK_X + threadIdx.x;
+  const int j = b.JstrVm2 + XB.by * BLK_Y + threadIdx.y;
   if (i > b.Iendp2i || j > b.Jendp2i) return;
   const double dt = c->p.dt;
   const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (m.itrc - 1)) * n3r);
@@ -79,7 +82,7 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
   {
-    const int k = blockIdx.z + 1;                                // one thread per (i,j,k)
+    const int k = XB.k0 + 1;                                      // one thread per (i,j,k)
     const long a = c0 + (long)(k - 1) * nij;
     const double t0 = t3[a];
     // FC(k-1): the expression the level below evaluates as its FC(k)
@@ -161,8 +164,11 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
 {
   DEV_PROLOGUE(c)
   // union of the three ranges: i = IstrU-1 : Iendp2, j = JstrV-1 : Jendp2
-  const int i = b.IstrU - 1 + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrV - 1 + blockIdx.y * BLK_Y + threadIdx.y;
+  // level fastest inside an XCD (see k_mp_ta)
+  const TileLv XB = decode_tile_level(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1, N);
+  if (!XB.valid) return;
+  const int i = b.IstrU - 1 + XB.bx * BLK_X + threadIdx.x;
+  const int j = b.JstrV - 1 + XB.by * BLK_Y + threadIdx.y;
   if (i > b.Iendp2 || j > b.Jendp2) return;
   const bool do_u = j <= b.Jendp1;                                  // Ua: j = JstrV-1:Jendp1, i = IstrU-1:Iendp2
   const bool do_v = j >= b.JstrVm1 && i <= b.Iendp1;                // Va: j = JstrVm1:Jendp2, i = IstrU-1:Iendp1
@@ -180,7 +186,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
   // one thread per (i,j,k): nothing is carried from level to level, and with ~1200 FP64 instructions per
   // cell the kernel needs every wave it can get (a k-loop per column ran at two waves per SIMD)
   {
-    const int k = blockIdx.z + 1;
+    const int k = XB.k0 + 1;
     const long a = a2 + (long)(k - 1) * nij;
     const double T0 = Ta[a];
     // ---------------- XI face between (i-1,j) and (i,j) ----------------
@@ -333,15 +339,17 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_mp_beta(const RomsDev *__restrict__ c, MpArgs m)
 {
   DEV_PROLOGUE(c)
-  const int i = b.IstrU - 1 + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.JstrV - 1 + blockIdx.y * BLK_Y + threadIdx.y;
+  const TileLv XB = decode_tile_level(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1, N);
+  if (!XB.valid) return;
+  const int i = b.IstrU - 1 + XB.bx * BLK_X + threadIdx.x;
+  const int j = b.JstrV - 1 + XB.by * BLK_Y + threadIdx.y;
   if (i > b.Iendp1 || j > b.Jendp1) return;
   const gcd_t Ta = (gcd_t)m.Ta, Ua = (gcd_t)m.Ua, Va = (gcd_t)m.Va, Wa = (gcd_t)m.Wa;
   const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (m.itrc - 1)) * n3r);
   const gd_t bup = (gd_t)m.bup, bdn = (gd_t)m.bdn;
   const long a2 = I2(i, j);
   {
-    const int k = blockIdx.z + 1;                                // one thread per (i,j,k)
+    const int k = XB.k0 + 1;                                     // one thread per (i,j,k)
     const long a = a2 + (long)(k - 1) * nij;
     const long aw = a + nij;                                     // Wa(i,j,k); Wa(i,j,k-1) = Wa[a]
     const double T0 = Ta[a], Tw = Ta[a - 1], Te = Ta[a + 1], Ts = Ta[a - ni], Tn = Ta[a + ni];
@@ -381,8 +389,9 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
 {
   DEV_PROLOGUE(c)
-  const int i = b.Istr + blockIdx.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + blockIdx.y * BLK_Y + threadIdx.y;
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
   if (i > b.Iend || j > b.Jend) return;
   const double dt = c->p.dt;
   const gcd_t Ta = (gcd_t)m.Ta, Ua = (gcd_t)m.Ua, Va = (gcd_t)m.Va, Wa = (gcd_t)m.Wa;
@@ -511,21 +520,18 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
     KERNEL_CHECK("k_mp_metrics");
   }
   {
-    dim3 g3 = grid2d(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1);
-    g3.z = b.N;
+    dim3 g3 = grid_tile_level(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1, b.N);
     hipLaunchKernelGGL(k_mp_ta, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
   }
   KERNEL_CHECK("k_mp_ta");
   {
-    dim3 g3 = grid2d(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1);
-    g3.z = b.N;
+    dim3 g3 = grid_tile_level(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1, b.N);
     hipLaunchKernelGGL(g_ctx.p.mpdata_fast ? k_mp_adiff<true> : k_mp_adiff<false>, g3, block2d(), 0,
                        g_ctx.stream, g_ctx.devc, m);
   }
   KERNEL_CHECK("k_mp_adiff");
   {
-    dim3 g3 = grid2d(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1);
-    g3.z = b.N;
+    dim3 g3 = grid_tile_level(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1, b.N);
     hipLaunchKernelGGL(k_mp_beta, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
   }
   KERNEL_CHECK("k_mp_beta");

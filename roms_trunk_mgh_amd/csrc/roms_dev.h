@@ -139,6 +139,29 @@ static inline dim3 grid2d(int nx, int ny) {
   return dim3((unsigned)((nx + BLK_X - 1) / BLK_X), (unsigned)((ny + BLK_Y - 1) / BLK_Y), 1);
 }
 static inline dim3 block2d() { return dim3(BLK_X, BLK_Y, 1); }
+// (tile, level) decode of a 1-D grid for kernels with one thread per cell: consecutive workgroups of an XCD take the
+// SAME horizontal tile at consecutive levels, so the planes k-1, k, k+1 a vertical stencil reads meet in one L2
+// (with the level in gridDim.z they are thousands of workgroups apart and on other XCDs); tiles are dealt to the
+// XCDs round-robin, which balances any tile count.  Launch with grid_tile_level(); check .valid.
+struct TileLv { int bx, by, k0; bool valid; };
+#ifdef __HIPCC__
+__device__ __forceinline__ TileLv decode_tile_level(int nx, int ny, int nz)
+{
+  const int nbx = (nx + BLK_X - 1) / BLK_X, nby = (ny + BLK_Y - 1) / BLK_Y;
+  const int B = blockIdx.x, xcd = B & 7, q = B >> 3;
+  TileLv r;
+  r.k0 = q % nz;
+  const int tl = (q / nz) * 8 + xcd;
+  r.valid = tl < nbx * nby;
+  r.bx = tl % nbx;
+  r.by = tl / nbx;
+  return r;
+}
+#endif
+static inline dim3 grid_tile_level(int nx, int ny, int nz) {
+  const int nbx = (nx + BLK_X - 1) / BLK_X, nby = (ny + BLK_Y - 1) / BLK_Y;
+  return dim3((unsigned)(((nbx * nby + 7) / 8) * 8 * nz), 1, 1);
+}
 
 // XCD-aware (tile, tracer) decode of a 1-D grid.  Workgroups B and B+8 run on the same
 // XCD (round-robin dispatch over the 8 XCDs, MI355X_MICROARCH.md); each XCD has its own
