@@ -201,6 +201,11 @@ int roms_hip_omega(const roms_step_idx_t *s);
 int roms_hip_set_zeta(const roms_step_idx_t *s);
 /* set_depth(ng,tile,model)         ROMS/Nonlinear/set_depth.F:33     */
 int roms_hip_set_depth(const roms_step_idx_t *s);
+/* Informational: how the barotropic kernel reads the fifteen grid-metric arrays (pm, pn, on_u, om_v, fomn, dndx,
+ * dmde, pmon_r, pnom_r, pmon_p, pnom_p, om_r, on_r, om_p, on_p).  0 = not examined since their last upload;
+ * 1 = all of them are independent of i on this tile (checked bit for bit on the device: a zonally uniform grid) and
+ * the kernel takes them from a per-row table; 2 = they are not, and it reads the arrays.  Same results either way. */
+int roms_hip_row_metrics_state(void);
 /* ini_zeta(ng,tile,model)          ROMS/Nonlinear/ini_fields.F:780
  * ini_fields(ng,tile,model)        ROMS/Nonlinear/ini_fields.F:27
  * The first-step initialisation of main3d.F:269-283 (ini_zeta, set_depth, ini_fields, in this order): other

@@ -226,6 +226,7 @@ extern "C" int roms_hip_finalize(void)
   if (!g_ctx.inited) return 0;
   (void)hipStreamSynchronize(g_ctx.stream);
   step2d_graphs_release();
+  roms_rowm_release();
   snapshot_release();
   halo_finalize();
   diag_release();
@@ -252,6 +253,7 @@ extern "C" int roms_hip_set_bounds(const roms_bounds_t *b)
   if (b->ntileI != g_ctx.ntileI || b->ntileJ != g_ctx.ntileJ)
     return roms_fail("roms_hip_set_bounds", "tiling differs from roms_hip_init");
   step2d_graphs_release();
+  roms_rowm_release();
   g_ctx.b = *b;
   g_ctx.hostc.b = *b;
   g_ctx.have_bounds = true;
@@ -313,6 +315,7 @@ extern "C" int roms_hip_register_field(int id, double *host_ptr, long n_doubles)
     return roms_fail("roms_hip_register_field", msg);
   }
   step2d_graphs_release();
+  roms_rowm_invalidate();
   snapshot_forget(id);          // staging / page-lock of a previous registration (other size or host array)
   guarded_free(&g_ctx.dev[id], &g_ctx.dev_base[id]);
   {
@@ -332,6 +335,7 @@ extern "C" int roms_hip_sync_to_device(int id)
   if (id < 0 || id >= FID_COUNT || !g_ctx.dev[id]) return roms_fail("roms_hip_sync_to_device", "field not registered");
   HIP_TRY(hipMemcpyAsync(g_ctx.dev[id], g_ctx.host[id], sizeof(double) * g_ctx.count[id], hipMemcpyHostToDevice, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  if (k_field_kind[id] == K_2D) roms_rowm_invalidate();          // a metric array may have changed
   return 0;
 }
 
@@ -349,6 +353,7 @@ extern "C" int roms_hip_sync_all_to_device(void)
     if (g_ctx.dev[id])
       HIP_TRY(hipMemcpyAsync(g_ctx.dev[id], g_ctx.host[id], sizeof(double) * g_ctx.count[id], hipMemcpyHostToDevice, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  roms_rowm_invalidate();
   return 0;
 }
 

@@ -348,6 +348,7 @@ extern "C" int roms_hip_step2d(const roms_step_idx_t *s)
   int rc = roms_entry_check("roms_hip_step2d");
   if (rc) return rc;
   if ((rc = check_lbc())) return rc;
+  if ((rc = roms_rowm_prepare())) return rc;
   ScopedTimer tm("step2d");
   g_flux_ready = false;
   return step2d_impl(s, false);
@@ -405,6 +406,7 @@ extern "C" int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1)
   int rc = roms_entry_check("roms_hip_step2d_loop");
   if (rc) return rc;
   if ((rc = check_lbc())) return rc;
+  if ((rc = roms_rowm_prepare())) return rc;          // before any capture: it synchronises when it has work
   ScopedTimer tm("step2d_loop");
   const roms_bounds_t &b = g_ctx.b;
   const bool one_tile = b.ntileI * b.ntileJ == 1 && !g_ctx.loopback;

@@ -23,6 +23,29 @@ struct S2 {
   int krhs, kstp, knew, nstp, nnew, iif, iic, ntfirst, predictor, sm;
 };
 
+// Row-uniform metrics.  On a zonally uniform grid (a Cartesian channel, a longitude-latitude grid: every
+// configuration of BASELINE.json) the fifteen metric arrays below do not depend on i.  roms_rowm_prepare() checks
+// that bit for bit on the device whenever one of them has been uploaded and, if it holds for all of them, leaves
+// one value per row in a small table; the one-tile kernel then takes its metrics from the table (ROWM = true):
+// all lanes of a wave read the same address, fifteen 2-D fields (65 MB of 183 MB per call on BENCHMARK3) no longer
+// stream through the fabric and ~60 of the ~100 vector loads per point become broadcasts.  Same values, same
+// arithmetic, same results; any i-dependence in any of the arrays selects the general kernel.
+enum { RM_pm = 0, RM_pn, RM_on_u, RM_om_v, RM_fomn, RM_dndx, RM_dmde, RM_pmon_r, RM_pnom_r, RM_pmon_p, RM_pnom_p,
+       RM_om_r, RM_on_r, RM_om_p, RM_on_p, RM_COUNT };
+
+template <bool ROWM>
+struct Met {
+  gcd_t tab;      // RM_COUNT rows of nj doubles
+  int nj, LBj;
+  // element q (flat index, row jr) of metric array A
+  __device__ __forceinline__ double get(gcd_t A, int f, long q, int jr) const
+  {
+    if constexpr (ROWM) return tab[f * nj + (jr - LBj)];
+    else return A[q];
+  }
+};
+#define MT(name, q, jr) met.get((gcd_t)c->F.name, RM_##name, (q), (jr))
+
 #define TP (BLK_X + 4)       // tile pitch (i)
 #define TJ (BLK_Y + 4)       // tile rows  (j)
 #define C6 (1.0 / 6.0)
@@ -83,13 +106,12 @@ __device__ __forceinline__ int wrap_i(const roms_bounds_t &b, int i)
 // One free-surface point (step2d_LF_AM3.h:770-868) evaluated at source index a: the new free surface zn
 // and the time-weighted zw the pressure gradient uses.  Same expressions as zeta_point (k_step2d.hip).
 __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S2 &s, const double rhs, long a, long nij,
-                                          double &zn, double &zw)
+                                          const double pmn_a, const double pn_a, double &zn, double &zw)
 {
   const roms_params_t &p = c->p;
   const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
   const gcd_t zs = (gcd_t)(c->F.zeta + (long)(s.kstp - 1) * nij);
   const double dtfast = p.dtfast;
-  const double pmn_a = GF(pm)[a], pn_a = GF(pn)[a];
   if (s.iif == 1) {
     const double cff1 = dtfast;
     zn = zs[a] + pmn_a * pn_a * cff1 * rhs;
@@ -121,7 +143,7 @@ __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S
 // of k2d_zeta_sm are done here as well -- zeta_new and zwrk are evaluated from the staged DUon/DVom
 // tiles for the (65 x 5) points this workgroup's momentum stencil touches and kept in LDS, so one
 // step2d call is ONE launch and the zeta_new/zwrk scratch round trip disappears.
-template <bool FUSED>
+template <bool FUSED, bool ROWM = false>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, const double *__restrict__ DVom,
             const double *__restrict__ zeta_new, const double *__restrict__ zwrk, double *__restrict__ DUnext,
@@ -129,6 +151,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
 {
   DEV_PROLOGUE(c)
   const roms_params_t &p = c->p;
+  const Met<ROWM> met{(gcd_t)c->rowm, (int)nj, LBj};
   // DUnext != nullptr (FUSED on several tiles, inside LOOP_2D): the closed-wall conditions are applied here
   // and DUon/DVom of the NEXT call (level knew) are left in DUnext/DVnext on the points this tile owns,
   // so that one exchange per call moves everything the next call needs
@@ -170,10 +193,10 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       } else {
         // DUon, DVom evaluated in place (:509-544), identical expression to k2d_flux; the
         // ghost columns/rows they reach hold exact copies, so no separate flux pass is needed
-        const double cu = 0.5 * GF(on_u)[g];
+        const double cu = 0.5 * MT(on_u, g, gj);
         sDU[e] = ug * (cu * (Dg + (zk[g - 1] + h[g - 1])));
         if (gj >= b.LBj + 1) {
-          const double cv = 0.5 * GF(om_v)[g];
+          const double cv = 0.5 * MT(om_v, g, gj);
           sDV[e] = vg * (cv * (Dg + (zk[g - ni] + h[g - ni])));
         } else sDV[e] = 0.0;
       }
@@ -193,7 +216,8 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
       const double rhs = (sDU[e] - sDU[e + 1]) + (sDV[e] - sDV[e + TP]);
       double zn, zw;
-      zeta_eval(c, s, rhs, I2(gi, gj), nij, zn, zw);
+      const long gq = I2(gi, gj);
+      zeta_eval(c, s, rhs, gq, nij, MT(pm, gq, gj), MT(pn, gq, gj), zn, zw);
       sZn[e] = zn;
       sZw[e] = zw;
     }
@@ -216,8 +240,6 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const long o = I2(it, j);                         // target index
   const gcd_t rhoA = (gcd_t)(c->F.rhoA);
   const gcd_t rhoS = (gcd_t)(c->F.rhoS);
-  const gcd_t pm = (gcd_t)(c->F.pm);
-  const gcd_t pn = (gcd_t)(c->F.pn);
   const gcd_t zs = (gcd_t)(c->F.zeta + (long)(s.kstp - 1) * nij);
   T2 m;
   m.ub = sU; m.vb = sV; m.DU = sDU; m.DV = sDV; m.D = sD;
@@ -283,7 +305,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const long q = a - 1;
     const double zw = FUSED ? sZw[t - 1] : zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
-    rhs_u = cg * GF(on_u)[a] *
+    rhs_u = cg * MT(on_u, a, j) *
             ((h[q] + h[a]) * (gz - gz0) +
              (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
              (gz2 - gz20));
@@ -292,7 +314,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const long q = a - ni;
     const double zw = FUSED ? sZw[t - TP] : zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
-    rhs_v = cg * GF(om_v)[a] *
+    rhs_v = cg * MT(om_v, a, j) *
             ((h[q] + h[a]) * (gz - gz0) +
              (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
              (gz2 - gz20));
@@ -313,70 +335,69 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const double D0 = sD[t], Dw = sD[t - 1], Ds = sD[t - TP];
   // ---- Coriolis, :1291-1325 ----
   if (p.uv_cor) {
-    const gcd_t fomn = (gcd_t)(c->F.fomn);
-    const double cf0 = 0.5 * D0 * fomn[a];
+    const double cf0 = 0.5 * D0 * MT(fomn, a, j);
     const double UFx0 = cf0 * (sV[t] + sV[t + TP]);
     const double VFe0 = cf0 * (sU[t] + sU[t + 1]);
     if (do_u) {
-      const double cfw = 0.5 * Dw * fomn[a - 1];
+      const double cfw = 0.5 * Dw * MT(fomn, a - 1, j);
       const double UFxw = cfw * (sV[t - 1] + sV[t - 1 + TP]);
       rhs_u = rhs_u + 0.5 * (UFx0 + UFxw);
     }
     if (do_v) {
-      const double cfs = 0.5 * Ds * fomn[a - ni];
+      const double cfs = 0.5 * Ds * MT(fomn, a - ni, j - 1);
       const double VFes = cfs * (sU[t - TP] + sU[t - TP + 1]);
       rhs_v = rhs_v - 0.5 * (VFe0 + VFes);
     }
   }
   // ---- curvilinear terms, :1333-1382 ----
   if (p.curvgrid && p.uv_adv) {
-    const gcd_t dndx = (gcd_t)c->F.dndx, dmde = (gcd_t)c->F.dmde;
-    auto cell = [&](long q, int tq, double D, double &ufx, double &vfe) {
+    auto cell = [&](long q, int jq, int tq, double D, double &ufx, double &vfe) {
       const double cff1 = 0.5 * (sV[tq] + sV[tq + TP]);
       const double cff2 = 0.5 * (sU[tq] + sU[tq + 1]);
-      const double cff3 = cff1 * dndx[q];
-      const double cff4 = cff2 * dmde[q];
+      const double cff3 = cff1 * MT(dndx, q, jq);
+      const double cff4 = cff2 * MT(dmde, q, jq);
       const double cff = D * (cff3 - cff4);
       ufx = cff * cff1;
       vfe = cff * cff2;
     };
     double u0, v0, u1, v1;
-    cell(a, t, D0, u0, v0);
-    if (do_u) { cell(a - 1, t - 1, Dw, u1, v1); rhs_u = rhs_u + 0.5 * (u0 + u1); }
-    if (do_v) { cell(a - ni, t - TP, Ds, u1, v1); rhs_v = rhs_v - 0.5 * (v0 + v1); }
+    cell(a, j, t, D0, u0, v0);
+    if (do_u) { cell(a - 1, j, t - 1, Dw, u1, v1); rhs_u = rhs_u + 0.5 * (u0 + u1); }
+    if (do_v) { cell(a - ni, j - 1, t - TP, Ds, u1, v1); rhs_v = rhs_v - 0.5 * (v0 + v1); }
   }
   // ---- harmonic viscosity, :1394-1471 ----
   if (p.uv_vis2) {
     const gcd_t visc2_r = (gcd_t)c->F.visc2_r, visc2_p = (gcd_t)c->F.visc2_p;
-    const gcd_t pmon_r = (gcd_t)c->F.pmon_r, pnom_r = (gcd_t)c->F.pnom_r, pmon_p = (gcd_t)c->F.pmon_p, pnom_p = (gcd_t)c->F.pnom_p;
-    const gcd_t om_r = (gcd_t)c->F.om_r, on_r = (gcd_t)c->F.on_r, om_p = (gcd_t)c->F.om_p, on_p = (gcd_t)c->F.on_p;
-    auto str_r = [&](long q, int tq) {
+    // q = flat index of the stress point, jq = its row
+    auto str_r = [&](long q, int jq, int tq) {
       return visc2_r[q] * sD[tq] * 0.5 *
-             (pmon_r[q] * ((pn[q] + pn[q + 1]) * sU[tq + 1] - (pn[q - 1] + pn[q]) * sU[tq]) -
-              pnom_r[q] * ((pm[q] + pm[q + ni]) * sV[tq + TP] - (pm[q - ni] + pm[q]) * sV[tq]));
+             (MT(pmon_r, q, jq) * ((MT(pn, q, jq) + MT(pn, q + 1, jq)) * sU[tq + 1] - (MT(pn, q - 1, jq) + MT(pn, q, jq)) * sU[tq]) -
+              MT(pnom_r, q, jq) * ((MT(pm, q, jq) + MT(pm, q + ni, jq + 1)) * sV[tq + TP] - (MT(pm, q - ni, jq - 1) + MT(pm, q, jq)) * sV[tq]));
     };
-    auto str_p = [&](long q, int tq) {
+    auto str_p = [&](long q, int jq, int tq) {
       const double Dp = 0.25 * (sD[tq] + sD[tq - 1] + sD[tq - TP] + sD[tq - 1 - TP]);
       const double cffp = visc2_p[q] * Dp * 0.5 *
-             (pmon_p[q] * ((pn[q - ni] + pn[q]) * sV[tq] - (pn[q - 1 - ni] + pn[q - 1]) * sV[tq - 1]) +
-              pnom_p[q] * ((pm[q - 1] + pm[q]) * sU[tq] - (pm[q - 1 - ni] + pm[q - ni]) * sU[tq - TP]));
+             (MT(pmon_p, q, jq) * ((MT(pn, q - ni, jq - 1) + MT(pn, q, jq)) * sV[tq] - (MT(pn, q - 1 - ni, jq - 1) + MT(pn, q - 1, jq)) * sV[tq - 1]) +
+              MT(pnom_p, q, jq) * ((MT(pm, q - 1, jq) + MT(pm, q, jq)) * sU[tq] - (MT(pm, q - 1 - ni, jq - 1) + MT(pm, q - ni, jq - 1)) * sU[tq - TP]));
       return masking ? cffp * GF(pmask)[q] : cffp;              // MASKING, :1433
     };
-    const double sr0 = str_r(a, t), sp0 = str_p(a, t);
+    const double sr0 = str_r(a, j, t), sp0 = str_p(a, j, t);
     if (do_u) {
-      const double srw = str_r(a - 1, t - 1), spn = str_p(a + ni, t + TP);
-      const double UFx0 = on_r[a] * on_r[a] * sr0, UFxw = on_r[a - 1] * on_r[a - 1] * srw;
-      const double UFe0 = om_p[a] * om_p[a] * sp0, UFen = om_p[a + ni] * om_p[a + ni] * spn;
-      const double cff1 = 0.5 * (pn[a - 1] + pn[a]) * (UFx0 - UFxw);
-      const double cff2 = 0.5 * (pm[a - 1] + pm[a]) * (UFen - UFe0);
+      const double srw = str_r(a - 1, j, t - 1), spn = str_p(a + ni, j + 1, t + TP);
+      const double onr0 = MT(on_r, a, j), onrw = MT(on_r, a - 1, j), omp0 = MT(om_p, a, j), ompn = MT(om_p, a + ni, j + 1);
+      const double UFx0 = onr0 * onr0 * sr0, UFxw = onrw * onrw * srw;
+      const double UFe0 = omp0 * omp0 * sp0, UFen = ompn * ompn * spn;
+      const double cff1 = 0.5 * (MT(pn, a - 1, j) + MT(pn, a, j)) * (UFx0 - UFxw);
+      const double cff2 = 0.5 * (MT(pm, a - 1, j) + MT(pm, a, j)) * (UFen - UFe0);
       rhs_u = rhs_u + (cff1 + cff2);
     }
     if (do_v) {
-      const double srs = str_r(a - ni, t - TP), spe = str_p(a + 1, t + 1);
-      const double VFx0 = on_p[a] * on_p[a] * sp0, VFxe = on_p[a + 1] * on_p[a + 1] * spe;
-      const double VFe0 = om_r[a] * om_r[a] * sr0, VFes = om_r[a - ni] * om_r[a - ni] * srs;
-      const double cff1 = 0.5 * (pn[a - ni] + pn[a]) * (VFxe - VFx0);
-      const double cff2 = 0.5 * (pm[a - ni] + pm[a]) * (VFe0 - VFes);
+      const double srs = str_r(a - ni, j - 1, t - TP), spe = str_p(a + 1, j, t + 1);
+      const double onp0 = MT(on_p, a, j), onpe = MT(on_p, a + 1, j), omr0 = MT(om_r, a, j), omrs = MT(om_r, a - ni, j - 1);
+      const double VFx0 = onp0 * onp0 * sp0, VFxe = onpe * onpe * spe;
+      const double VFe0 = omr0 * omr0 * sr0, VFes = omrs * omrs * srs;
+      const double cff1 = 0.5 * (MT(pn, a - ni, j - 1) + MT(pn, a, j)) * (VFxe - VFx0);
+      const double cff2 = 0.5 * (MT(pm, a - ni, j - 1) + MT(pm, a, j)) * (VFe0 - VFes);
       rhs_v = rhs_v + (cff1 - cff2);
     }
   }
@@ -418,7 +439,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const gd_t vbn = (gd_t)(c->F.vbar + (long)(s.knew - 1) * nij);
   if (do_u) {
     const long q = a - 1;
-    const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
+    const double cff = (MT(pm, a, j) + MT(pm, q, j)) * (MT(pn, a, j) + MT(pn, q, j));
     const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - 1] : zeta_new[q]) + h[q]));
     const double us = GF(ubar)[a + (long)(s.kstp - 1) * nij];
     double un;
@@ -438,20 +459,20 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     if constexpr (FUSED) {
       if (DUnext) {                                    // DUon of level knew, :509-525 (as k2d_flux)
         const double znw = sZn[t - 1];
-        DUnext[a] = un * ((0.5 * GF(on_u)[a]) * (Dn0 + (znw + h[q])));
+        DUnext[a] = un * ((0.5 * MT(on_u, a, j)) * (Dn0 + (znw + h[q])));
         // wall rows: u = gamma2*u(adjacent row), zeta = zero-gradient copy (u2dbc_im.F:51, zetabc.F:48)
         if (b.south_edge && j == b.Jstr)
-          DUnext[a - ni] = un_s * ((0.5 * GF(on_u)[a - ni]) *
+          DUnext[a - ni] = un_s * ((0.5 * MT(on_u, a - ni, j - 1)) *
                                    ((sZn[t] * mk(GF(rmask), a - ni) + h[a - ni]) + (znw * mk(GF(rmask), q - ni) + h[q - ni])));
         if (b.north_edge && j == b.Jend)
-          DUnext[a + ni] = un_n * ((0.5 * GF(on_u)[a + ni]) *
+          DUnext[a + ni] = un_n * ((0.5 * MT(on_u, a + ni, j + 1)) *
                                    ((sZn[t] * mk(GF(rmask), a + ni) + h[a + ni]) + (znw * mk(GF(rmask), q + ni) + h[q + ni])));
       }
     }
   }
   if (do_v) {
     const long q = a - ni;
-    const double cff = (pm[a] + pm[q]) * (pn[a] + pn[q]);
+    const double cff = (MT(pm, a, j) + MT(pm, q, j - 1)) * (MT(pn, a, j) + MT(pn, q, j - 1));
     const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - TP] : zeta_new[q]) + h[q]));
     const double vs = GF(vbar)[a + (long)(s.kstp - 1) * nij];
     double vn;
@@ -463,7 +484,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     put(vbn, o, vn);
     if (s.predictor && owner) GF(rvbar)[a + (long)(s.krhs - 1) * nij] = rhs_v;
     if constexpr (FUSED) {
-      if (DVnext) DVnext[a] = vn * ((0.5 * GF(om_v)[a]) * (Dn0 + (sZn[t - TP] + h[q])));   // :527-544
+      if (DVnext) DVnext[a] = vn * ((0.5 * MT(om_v, a, j)) * (Dn0 + (sZn[t - TP] + h[q])));   // :527-544
     }
   }
   if (inline_bc) {                                     // v2dbc closed walls, v2dbc_im.F:52
@@ -474,14 +495,87 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     if (DVnext) {                                      // wall rows: v = 0 there
       const double zn0 = sZn[t];
       if (b.south_edge && j == b.Jstr)
-        DVnext[a] = 0.0 * ((0.5 * GF(om_v)[a]) * ((zn0 + h[a]) + (zn0 * mk(GF(rmask), a - ni) + h[a - ni])));
+        DVnext[a] = 0.0 * ((0.5 * MT(om_v, a, j)) * ((zn0 + h[a]) + (zn0 * mk(GF(rmask), a - ni) + h[a - ni])));
       if (b.north_edge && j == b.Jend)
-        DVnext[a + ni] = 0.0 * ((0.5 * GF(om_v)[a + ni]) * ((zn0 * mk(GF(rmask), a + ni) + h[a + ni]) + (zn0 + h[a])));
+        DVnext[a + ni] = 0.0 * ((0.5 * MT(om_v, a + ni, j + 1)) * ((zn0 * mk(GF(rmask), a + ni) + h[a + ni]) + (zn0 + h[a])));
     }
   }
 }
 
+// One workgroup per (row, metric array): is the row constant in i (bit for bit) over LBi:UBi?  Lane 0 stores the
+// row's value in the table; any difference raises the flag.
+__global__ void k_rowm_build(const RomsDev *__restrict__ c, double *__restrict__ tab, int *__restrict__ flag)
+{
+  DEV_PROLOGUE(c)
+  const int jr = blockIdx.x, f = blockIdx.y;
+  const double *const A[RM_COUNT] = {c->F.pm, c->F.pn, c->F.on_u, c->F.om_v, c->F.fomn, c->F.dndx, c->F.dmde,
+                                     c->F.pmon_r, c->F.pnom_r, c->F.pmon_p, c->F.pnom_p, c->F.om_r, c->F.on_r,
+                                     c->F.om_p, c->F.on_p};
+  const double *a = A[f];
+  if (!a) {                           // array not registered: never read by a kernel either
+    if (threadIdx.x == 0) tab[(long)f * nj + jr] = 0.0;
+    return;
+  }
+  // the columns a kernel can read: the tile's own and two on either side (ghost columns; the reference's padding
+  // column beyond them is never read and need not be filled)
+  const int i0 = (b.Istr - 2 > b.LBi) ? b.Istr - 2 : b.LBi, i1 = (b.Iend + 2 < b.UBi) ? b.Iend + 2 : b.UBi;
+  const unsigned long long *row = reinterpret_cast<const unsigned long long *>(a + (long)jr * ni) - LBi;
+  const unsigned long long v0 = row[b.Istr];
+  bool differs = false;
+  for (int i = i0 + (int)threadIdx.x; i <= i1; i += (int)blockDim.x) differs |= row[i] != v0;
+  if (differs) atomicOr(flag, 1);
+  if (threadIdx.x == 0) tab[(long)f * nj + jr] = a[(long)jr * ni + (b.Istr - LBi)];
+}
+
 }  // namespace
+
+// 0 = not examined yet, 1 = the metric arrays are independent of i (row table in use), 2 = they are not
+extern "C" int roms_hip_row_metrics_state(void) { return g_ctx.rowm_state; }
+
+void roms_rowm_invalidate()
+{
+  if (g_ctx.rowm_state) step2d_graphs_release();     // the captured launches chose their kernel by the old state
+  g_ctx.rowm_state = 0;
+}
+
+void roms_rowm_release()
+{
+  if (g_ctx.rowm_dev) (void)hipFree(g_ctx.rowm_dev);
+  g_ctx.rowm_dev = nullptr;
+  g_ctx.rowm_nj = 0;
+  g_ctx.rowm_state = 0;
+  g_ctx.hostc.rowm = nullptr;
+}
+
+int roms_rowm_prepare()
+{
+  if (g_ctx.rowm_state) return 0;
+  const roms_bounds_t &b = g_ctx.b;
+  const long nj = b.UBj - b.LBj + 1;
+  if (g_ctx.rowm_nj != nj) {
+    roms_rowm_release();
+    HIP_TRY(hipMalloc(&g_ctx.rowm_dev, sizeof(double) * (RM_COUNT * nj + 1)));   // + one word for the flag
+    g_ctx.rowm_nj = nj;
+  }
+  int *flag = reinterpret_cast<int *>(g_ctx.rowm_dev + RM_COUNT * nj);
+  int rc = roms_flush_consts();
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(flag, 0, sizeof(double), g_ctx.stream));
+  hipLaunchKernelGGL(k_rowm_build, dim3((unsigned)nj, RM_COUNT), dim3(256), 0, g_ctx.stream, g_ctx.devc,
+                     g_ctx.rowm_dev, flag);
+  KERNEL_CHECK("k_rowm_build");
+  int differs = 0;
+  HIP_TRY(hipMemcpyAsync(&differs, flag, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  g_ctx.rowm_state = differs ? 2 : 1;
+  const double *want = differs ? nullptr : g_ctx.rowm_dev;
+  if (g_ctx.hostc.rowm != want) {
+    g_ctx.hostc.rowm = want;
+    g_ctx.devc_dirty = true;
+    if ((rc = roms_flush_consts())) return rc;
+  }
+  return 0;
+}
 
 // Launcher used by step2d_impl (k_step2d.hip); s10 = the ten ints of its S2.
 int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DVom, const double *zeta_new,
@@ -492,15 +586,24 @@ int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DV
   const int nx = (s.sm == 1) ? (b.UBi - b.LBi + 1) : (b.Iend - b.Istr + 1);
   if (s.sm == 2) {      // fused free-surface + momentum call (source-mapped, fluxes in place)
     s.sm = 1;
-    hipLaunchKernelGGL(k2d_mom_lds<true>, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
-                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
-                       (const double *)nullptr, (double *)nullptr, (double *)nullptr);
+    if (g_ctx.rowm_state == 1)        // metrics independent of i: row table instead of fifteen 2-D arrays
+      hipLaunchKernelGGL((k2d_mom_lds<true, true>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                         g_ctx.devc, s, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
+                         (const double *)nullptr, (double *)nullptr, (double *)nullptr);
+    else
+      hipLaunchKernelGGL((k2d_mom_lds<true, false>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                         g_ctx.devc, s, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
+                         (const double *)nullptr, (double *)nullptr, (double *)nullptr);
   } else if (s.sm == 3) {   // fused call on several tiles: exchanged DUon/DVom in, next call's fluxes out
     s.sm = 0;
-    hipLaunchKernelGGL(k2d_mom_lds<true>, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
-                       DUon, DVom, (const double *)nullptr, (const double *)nullptr, DUnext, DVnext);
+    if (g_ctx.rowm_state == 1)
+      hipLaunchKernelGGL((k2d_mom_lds<true, true>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                         g_ctx.devc, s, DUon, DVom, (const double *)nullptr, (const double *)nullptr, DUnext, DVnext);
+    else
+      hipLaunchKernelGGL((k2d_mom_lds<true, false>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                         g_ctx.devc, s, DUon, DVom, (const double *)nullptr, (const double *)nullptr, DUnext, DVnext);
   } else
-    hipLaunchKernelGGL(k2d_mom_lds<false>, grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
+    hipLaunchKernelGGL((k2d_mom_lds<false, false>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
                        DUon, DVom, zeta_new, zwrk, (double *)nullptr, (double *)nullptr);
   KERNEL_CHECK("k2d_mom_lds");
   return 0;

@@ -21,6 +21,7 @@ struct RomsDev {
   // device scratch = the _tile routines' automatic work arrays
   double *ws3[8];       // 3-D scratch, each nij*(N+1) doubles
   double *ws2[32];      // 2-D scratch, each nij doubles
+  const double *rowm;   // row table of the i-uniform metric arrays (k_step2d_mom.hip), or nullptr
 };
 
 struct RomsCtx {
@@ -50,6 +51,11 @@ struct RomsCtx {
   // itself (W and E neighbour = own rank) instead of the local copy kernel, and every kernel takes its
   // multi-tile branch.  Same results; lets a one-GPU box execute the RCCL leg (tests/test_gpu_rccl.py).
   bool loopback = false;
+  // row-uniform metrics (k_step2d_mom.hip): 0 = not examined since the last upload of a metric array,
+  // 1 = all fifteen arrays are independent of i (table valid), 2 = not
+  int rowm_state = 0;
+  double *rowm_dev = nullptr;
+  long rowm_nj = 0;
 };
 
 extern RomsCtx g_ctx;
@@ -226,4 +232,7 @@ void snapshot_release();                  // snapshot.hip: waits for and frees a
 void snapshot_forget(int field_id);       // snapshot.hip: the same for one field (before it is re-registered)
 void diag_release();                      // k_diag.hip: frees the buffers of roms_hip_diag
 int check_lbc();
+int roms_rowm_prepare();               // k_step2d_mom.hip: examine the metric arrays if needed (synchronises once)
+void roms_rowm_invalidate();            // a metric array may have changed
+void roms_rowm_release();
 void step2d_graphs_release();           // k_step2d.hip: drop the captured LOOP_2D graphs (their launch arguments are stale)
