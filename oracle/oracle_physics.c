@@ -3,7 +3,8 @@
  * Per-step physics between the hot kernels:
  *   set_vbc_tile    ROMS/Nonlinear/set_vbc.F:104   (SOLVE3D; UV_QDRAG or UV_LDRAG; SALINITY, no EMINUSP)
  *   bulk_flux_tile  ROMS/Nonlinear/bulk_flux.F:146 (COARE 3.0; LONGWAVE = Berliand formula; no COOL_SKIN,
- *                                                   no EMINUSP, no WIND_MINUS_CURRENT, no masking)
+ *                                                   no EMINUSP, no WIND_MINUS_CURRENT; MASKING: the
+ *                                                   multiplies of bulk_flux.F:486-920)
  * Both reference files compile stand-alone and are compared with this restatement in
  * tests/test_ref_pinning.py (bulk_flux to a few ulp: LOG/EXP/ATAN/pow come from different math
  * libraries).
@@ -116,10 +117,9 @@ static double bulk_psit(double ZoL, double pi)
 
 int oracle_bulk_flux(OARGS)
 {
-  if (p->masking) return 8;      /* MASKING variant of bulk_flux.F not restated */
   ORACLE_PROLOGUE
   if (o_check_lbc(b, p)) return 8;
-  const int nrhs = s->nrhs, itemp = 1, IterMax = 3;
+  const int nrhs = s->nrhs, itemp = 1, IterMax = 3, mk = p->masking;
   /* mod_scalars.F:431-444, :1415-1421 */
   const double Cp = 3985.0, StefBo = 5.67E-8, emmiss = 0.97, rhow = 1000.0, vonKar = 0.41;
   const double blk_Cpa = 1004.67, blk_Cpw = 4000.0, blk_Rgas = 287.1, blk_Zabl = 600.0, blk_beta = 1.2;
@@ -154,6 +154,7 @@ int oracle_bulk_flux(OARGS)
       LRad(i, j) = -emmiss * StefBo *
                    (cff1 * (0.39 - 0.05 * sqrt(vap_p)) * (1.0 - 0.6823 * cloud(i, j) * cloud(i, j)) +
                     cff2 * 4.0 * (TseaK - TairK));
+      if (mk) LRad(i, j) = LRad(i, j) * rmask(i, j);                          /* MASKING, bulk_flux.F:486 */
       /* specific humidities, :486-520 */
       cff = (1.0007 + 3.46E-6 * PairM) * 6.1121 * exp(17.502 * TairC / (240.97 + TairC));
       const double Qair = 0.62197 * (cff / (PairM - 0.378 * cff));
@@ -229,14 +230,18 @@ int oracle_bulk_flux(OARGS)
       const double wet_bulb = 1.0 / (1.0 + 0.622 * (cff * Hlv * diffw) / (blk_Cpa * diffh));
       const double Hsr = rain(i, j) * wet_bulb * blk_Cpw * ((TseaC - TairC) + (Qsea - Q) * Hlv / blk_Cpa);
       SHeat(i, j) = (Hs + Hsr);
+      if (mk) SHeat(i, j) = SHeat(i, j) * rmask(i, j);                        /* :790 */
       const double Hl = -Hlv * rhoAir * Wstar * Qstar;
       const double upvel = -1.61 * Wstar * Qstar - (1.0 + 1.61 * Q) * Wstar * Tstar / TairK;
       const double Hlw = rhoAir * Hlv * upvel * Q;
       LHeat(i, j) = (Hl + Hlw);
+      if (mk) LHeat(i, j) = LHeat(i, j) * rmask(i, j);                        /* :809 */
       const double Taur = 0.85 * rain(i, j) * Wmag;
       cff = rhoAir * Cd * Wspeed;
       Taux(i, j) = (cff * Ua + Taur * copysign(1.0, Ua));
+      if (mk) Taux(i, j) = Taux(i, j) * rmask(i, j);                          /* :824 */
       Tauy(i, j) = (cff * Va + Taur * copysign(1.0, Va));
+      if (mk) Tauy(i, j) = Tauy(i, j) * rmask(i, j);                          /* :831 */
     }
   /* kinematic fluxes, :790-860 */
   Hscale = 1.0 / (rho0 * Cp);
@@ -246,12 +251,19 @@ int oracle_bulk_flux(OARGS)
       lhflx(i, j) = -LHeat(i, j) * Hscale;
       shflx(i, j) = -SHeat(i, j) * Hscale;
       stflux(i, j, itemp) = (srflx(i, j) + lrflx(i, j) + lhflx(i, j) + shflx(i, j));
+      if (mk) stflux(i, j, itemp) = stflux(i, j, itemp) * rmask(i, j);        /* :877 */
     }
   const double cffs = 0.5 / rho0;
   for (int j = JstrR; j <= JendR; j++)
-    for (int i = Istr; i <= IendR; i++) F->sustr[I2(i, j)] = cffs * (Taux(i - 1, j) + Taux(i, j));
+    for (int i = Istr; i <= IendR; i++) {
+      F->sustr[I2(i, j)] = cffs * (Taux(i - 1, j) + Taux(i, j));
+      if (mk) F->sustr[I2(i, j)] = F->sustr[I2(i, j)] * umask(i, j);          /* :908 */
+    }
   for (int j = Jstr; j <= JendR; j++)
-    for (int i = IstrR; i <= IendR; i++) F->svstr[I2(i, j)] = cffs * (Tauy(i, j - 1) + Tauy(i, j));
+    for (int i = IstrR; i <= IendR; i++) {
+      F->svstr[I2(i, j)] = cffs * (Tauy(i, j - 1) + Tauy(i, j));
+      if (mk) F->svstr[I2(i, j)] = F->svstr[I2(i, j)] * vmask(i, j);          /* :919 */
+    }
   o_exchange2d(b, GT_R, F->lrflx);
   o_exchange2d(b, GT_R, F->lhflx);
   o_exchange2d(b, GT_R, F->shflx);
@@ -266,7 +278,7 @@ int oracle_bulk_flux(OARGS)
  * lmd_vmix = lmd_vmix_tile + lmd_skpp_tile + lmd_finish_tile: Large/McWilliams/Doney K-profile
  * vertical mixing (ROMS/Nonlinear/lmd_vmix.F:99/465, lmd_skpp.F:98, lmd_swfrac.F:6) with the
  * BENCHMARK option set: LMD_RIMIX + RI_SPLINES, LMD_CONVEC, LMD_SKPP, LMD_NONLOCAL, SALINITY;
- * no LMD_DDMIX, LMD_SHAPIRO, LMD_BKPP, masking, WET_DRY.  Uniform Jerlov water type.
+ * no LMD_DDMIX, LMD_SHAPIRO, LMD_BKPP, WET_DRY; MASKING: the multiplies of lmd_skpp.F:272-866.  Uniform Jerlov water type.
  * --------------------------------------------------------------------------------------------- */
 static double o_swfrac(const roms_params_t *p, double Zscale, double Z)   /* lmd_swfrac.F:60-75 */
 {
@@ -295,11 +307,10 @@ static void o_wscale(double Ustar, double sigma, double Bf, double *wm, double *
 
 int oracle_lmd_vmix(OARGS)
 {
-  if (p->masking) return 8;      /* MASKING variant of lmd_skpp.F not restated */
   ORACLE_PROLOGUE
   if (o_check_lbc(b, p)) return 8;
   if (NAT < 2 || !p->salinity) return 8;          /* restated for the SALINITY set-up only */
-  const int nstp = s->nstp, itemp = 1, isalt = 2;
+  const int nstp = s->nstp, itemp = 1, isalt = 2, mk = p->masking;   /* MASKING: the multiplies of lmd_skpp.F:272-866 */
   const double g = p->g, vonKar = 0.41;
   /* mod_scalars.F:1552-1629 */
   const double lmd_Ri0 = 0.7, lmd_bvfcon = -2.0E-5, lmd_nu0c = 0.01, lmd_nu0m = 10.0E-4, lmd_nu0s = 10.0E-4;
@@ -397,6 +408,7 @@ int oracle_lmd_vmix(OARGS)
       for (int i = Istr; i <= Iend; i++) {
         const double a1 = 0.5 * (sustr(i, j) + sustr(i + 1, j)), a2 = 0.5 * (svstr(i, j) + svstr(i, j + 1));
         Ustar(i, j) = sqrt(sqrt(a1 * a1 + a2 * a2));
+        if (mk) Ustar(i, j) = Ustar(i, j) * rmask(i, j);                       /* :272 */
       }
     for (int j = Jstr; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -408,6 +420,7 @@ int oracle_lmd_vmix(OARGS)
         for (int i = Istr; i <= Iend; i++) {
           const double swdk = o_swfrac(p, -1.0, z_w(i, j, N) - z_w(i, j, k));
           Bflux(i, j, k) = (Bo(i, j) + Bosol(i, j) * (1.0 - swdk));
+          if (mk) Bflux(i, j, k) = Bflux(i, j, k) * rmask(i, j);               /* :316 */
           const double cff = 1.0 - (0.5 + copysign(0.5, Bflux(i, j, k)));
           ghats(i, j, k, itemp) = -cff * (stflx(i, j, itemp) - srflx(i, j) + srflx(i, j) * (1.0 - swdk));
           ghats(i, j, k, isalt) = cff * stflx(i, j, isalt);
@@ -464,8 +477,11 @@ int oracle_lmd_vmix(OARGS)
     }
     for (int j = Jstr; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
-        const double swdk = o_swfrac(p, -1.0, z_w(i, j, N) - hsbl(i, j));
+        double zgrid = z_w(i, j, N) - hsbl(i, j);
+        if (mk) zgrid = zgrid * rmask(i, j);                                   /* :562 */
+        const double swdk = o_swfrac(p, -1.0, zgrid);
         Bfsfc(i, j) = (Bo(i, j) + Bosol(i, j) * (1.0 - swdk));
+        if (mk) Bfsfc(i, j) = Bfsfc(i, j) * rmask(i, j);                       /* :574 */
       }
     for (int j = Jstr; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -476,6 +492,7 @@ int oracle_lmd_vmix(OARGS)
         }
         hsbl(i, j) = MIN(hsbl(i, j), z_w(i, j, N));
         hsbl(i, j) = MAX(hsbl(i, j), z_w(i, j, 0));
+        if (mk) hsbl(i, j) = hsbl(i, j) * rmask(i, j);                         /* :595 */
       }
     /* bc_r2d_tile (closed walls: zero gradient) + periodic / tile exchange, :640-652 */
     if (south_edge) for (int i = Istr; i <= Iend; i++) hsbl(i, Jstr - 1) = hsbl(i, Jstr);
@@ -489,8 +506,11 @@ int oracle_lmd_vmix(OARGS)
       }
     for (int j = Jstr; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
-        const double swdk = o_swfrac(p, -1.0, z_w(i, j, N) - hsbl(i, j));
+        double zgrid = z_w(i, j, N) - hsbl(i, j);
+        if (mk) zgrid = zgrid * rmask(i, j);                                   /* :669 */
+        const double swdk = o_swfrac(p, -1.0, zgrid);
         Bfsfc(i, j) = (Bo(i, j) + Bosol(i, j) * (1.0 - swdk));
+        if (mk) Bfsfc(i, j) = Bfsfc(i, j) * rmask(i, j);                       /* :681 */
       }
     for (int j = Jstr; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -515,24 +535,30 @@ int oracle_lmd_vmix(OARGS)
           double K_bl = cff_dn * Akv(i, j, k) + cff_up * Akv(i, j, k - 1);
           double dK_bl = cff * (Akv(i, j, k) - Akv(i, j, k - 1));
           Gm1(i, j) = K_bl / (zbl * wm(i, j) + eps);
+          if (mk) Gm1(i, j) = Gm1(i, j) * rmask(i, j);                         /* :754 */
           dGm1dS(i, j) = MIN(0.0, -dK_bl / (wm(i, j) + eps) - K_bl * f1(i, j));
           K_bl = cff_dn * Akt(i, j, k, itemp) + cff_up * Akt(i, j, k - 1, itemp);
           dK_bl = cff * (Akt(i, j, k, itemp) - Akt(i, j, k - 1, itemp));
           Gt1(i, j) = K_bl / (zbl * ws(i, j) + eps);
+          if (mk) Gt1(i, j) = Gt1(i, j) * rmask(i, j);                         /* :765 */
           dGt1dS(i, j) = MIN(0.0, -dK_bl / (ws(i, j) + eps) - K_bl * f1(i, j));
           K_bl = cff_dn * Akt(i, j, k, isalt) + cff_up * Akt(i, j, k - 1, isalt);
           dK_bl = cff * (Akt(i, j, k, isalt) - Akt(i, j, k - 1, isalt));
           Gs1(i, j) = K_bl / (zbl * ws(i, j) + eps);
+          if (mk) Gs1(i, j) = Gs1(i, j) * rmask(i, j);                         /* :777 */
           dGs1dS(i, j) = MIN(0.0, -dK_bl / (ws(i, j) + eps) - K_bl * f1(i, j));
         } else {
           ksbl(i, j) = 0;
           const double b1 = 0.5 * (bustr(i, j) + bustr(i + 1, j)), b2 = 0.5 * (bvstr(i, j) + bvstr(i, j + 1));
-          const double Ustarb = sqrt(sqrt(b1 * b1 + b2 * b2));
+          double Ustarb = sqrt(sqrt(b1 * b1 + b2 * b2));
+          if (mk) Ustarb = Ustarb * rmask(i, j);                               /* :793 */
           const double dK_bl = vonKar * Ustarb;
           const double K_bl = dK_bl * (hsbl(i, j) - z_w(i, j, 0));
           Gm1(i, j) = K_bl / (zbl * wm(i, j) + eps);
+          if (mk) Gm1(i, j) = Gm1(i, j) * rmask(i, j);                         /* :799 */
           dGm1dS(i, j) = MIN(0.0, -dK_bl / (wm(i, j) + eps) - K_bl * f1(i, j));
           Gt1(i, j) = K_bl / (zbl * ws(i, j) + eps);
+          if (mk) Gt1(i, j) = Gt1(i, j) * rmask(i, j);                         /* :808 */
           dGt1dS(i, j) = MIN(0.0, -dK_bl / (ws(i, j) + eps) - K_bl * f1(i, j));
           Gs1(i, j) = Gt1(i, j);
           dGs1dS(i, j) = dGt1dS(i, j);
@@ -551,6 +577,7 @@ int oracle_lmd_vmix(OARGS)
             o_wscale(Ustar(i, j), sigma, Bflux(i, j, k), &wmk, &wsk);
             wm(i, j) = wmk; ws(i, j) = wsk;
             sigma = depth / (zbl + eps);
+            if (mk) sigma = sigma * rmask(i, j);                               /* :866 */
             const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
             const double Gm = a1 + a2 * Gm1(i, j) + a3 * dGm1dS(i, j);
             const double Gt = a1 + a2 * Gt1(i, j) + a3 * dGt1dS(i, j);

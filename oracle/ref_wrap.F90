@@ -415,6 +415,11 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   OCEAN(ng)%v = a4
   CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); OCEAN(ng)%t = a5
   CALL c_f_pointer (F%rho, a3, (/ni,nj,NN/));   OCEAN(ng)%rho = a3
+#ifdef MASKING
+  CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
+  CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
+  CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
+#endif
 #if defined BENCHMARK || defined SEAMOUNT
   CALL c_f_pointer (F%rdrag2, a2, (/ni,nj/));   GRID(ng)%rdrag2 = a2
 #endif

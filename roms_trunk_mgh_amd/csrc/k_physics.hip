@@ -2,7 +2,7 @@
 // device so that the state never crosses PCIe inside a step:
 //   roms_hip_set_vbc    set_vbc_tile   ROMS/Nonlinear/set_vbc.F:104   (UV_QDRAG / UV_LDRAG, SALINITY)
 //   roms_hip_bulk_flux  bulk_flux_tile ROMS/Nonlinear/bulk_flux.F:146 (COARE 3.0 with the Berliand
-//                       longwave formula; no COOL_SKIN / EMINUSP / WIND_MINUS_CURRENT / masking)
+//                       longwave formula; no COOL_SKIN / EMINUSP / WIND_MINUS_CURRENT; MASKING multiplies)
 // Both are point-local (bulk_flux: three fixed iterations per point); one thread per (i,j).
 // bulk_flux uses device log/exp/pow/atan: results agree with the host libraries to a few ulp, not
 // bit for bit (the tests state the tolerance).
@@ -132,8 +132,12 @@ k_bulk_flux(const RomsDev *__restrict__ c, int nrhs, double *__restrict__ Taux, 
   const double vap_p = e_sat * RH;
   double cff2 = TairK * TairK * TairK;
   double cff1 = cff2 * TairK;
-  const double LRad = -emmiss * StefBo *
-                      (cff1 * (0.39 - 0.05 * sqrt(vap_p)) * (1.0 - 0.6823 * cl * cl) + cff2 * 4.0 * (TseaK - TairK));
+  // MASKING (bulk_flux.F:486, :790, :809, :824, :831, :877): the five fluxes and stflux times rmask; mr = 1 without
+  const bool masking = c->p.masking != 0;
+  const double mr = masking ? (double)GF(rmask)[a] : 1.0;
+  double LRad = -emmiss * StefBo *
+                (cff1 * (0.39 - 0.05 * sqrt(vap_p)) * (1.0 - 0.6823 * cl * cl) + cff2 * 4.0 * (TseaK - TairK));
+  if (masking) LRad = LRad * mr;
   cff = (1.0007 + 3.46E-6 * PairM) * 6.1121 * exp(17.502 * TairC / (240.97 + TairC));
   const double Qair = 0.62197 * (cff / (PairM - 0.378 * cff));
   double Q;
@@ -204,15 +208,19 @@ k_bulk_flux(const RomsDev *__restrict__ c, int nrhs, double *__restrict__ Taux, 
   cff = Qair * Hlv / (blk_Rgas * TairK * TairK);
   const double wet_bulb = 1.0 / (1.0 + 0.622 * (cff * Hlv * diffw) / (blk_Cpa * diffh));
   const double Hsr = rn * wet_bulb * blk_Cpw * ((TseaC - TairC) + (Qsea - Q) * Hlv / blk_Cpa);
-  const double SHeat = (Hs + Hsr);
+  double SHeat = (Hs + Hsr);
+  if (masking) SHeat = SHeat * mr;
   const double Hl = -Hlv * rhoAir * Wstar * Qstar;
   const double upvel = -1.61 * Wstar * Qstar - (1.0 + 1.61 * Q) * Wstar * Tstar / TairK;
   const double Hlw = rhoAir * Hlv * upvel * Q;
-  const double LHeat = (Hl + Hlw);
+  double LHeat = (Hl + Hlw);
+  if (masking) LHeat = LHeat * mr;
   const double Taur = 0.85 * rn * Wmag;
   cff = rhoAir * Cd * Wspeed;
-  Taux[a] = (cff * Ua + Taur * copysign(1.0, Ua));
-  Tauy[a] = (cff * Va + Taur * copysign(1.0, Va));
+  double tx = (cff * Ua + Taur * copysign(1.0, Ua)), ty = (cff * Va + Taur * copysign(1.0, Va));
+  if (masking) { tx = tx * mr; ty = ty * mr; }
+  Taux[a] = tx;
+  Tauy[a] = ty;
   // kinematic heat fluxes on the owned range, bulk_flux.F:790-812
   if (i >= b.IstrR && j >= b.JstrR) {
     const double Hscale = 1.0 / (rho0 * Cp);
@@ -220,7 +228,9 @@ k_bulk_flux(const RomsDev *__restrict__ c, int nrhs, double *__restrict__ Taux, 
     GF(lrflx)[a] = lr;
     GF(lhflx)[a] = lh;
     GF(shflx)[a] = sh;
-    GF(stflux)[a] = (GF(srflx)[a] + lr + lh + sh);
+    double stf = (GF(srflx)[a] + lr + lh + sh);
+    if (masking) stf = stf * mr;
+    GF(stflux)[a] = stf;
   }
 }
 
@@ -234,8 +244,15 @@ k_bulk_stress(const RomsDev *__restrict__ c, const double *__restrict__ Taux, co
   if (i > b.IendR || j > b.JendR) return;
   const long a = I2(i, j);
   const double cff = 0.5 / c->p.rho0;
-  if (i >= b.Istr) GF(sustr)[a] = cff * (Taux[a - 1] + Taux[a]);
-  if (j >= b.Jstr) GF(svstr)[a] = cff * (Tauy[a - ni] + Tauy[a]);
+  const bool masking = c->p.masking != 0;                          // bulk_flux.F:908, :919
+  if (i >= b.Istr) {
+    const double su = cff * (Taux[a - 1] + Taux[a]);
+    GF(sustr)[a] = masking ? su * GF(umask)[a] : su;
+  }
+  if (j >= b.Jstr) {
+    const double sv = cff * (Tauy[a - ni] + Tauy[a]);
+    GF(svstr)[a] = masking ? sv * GF(vmask)[a] : sv;
+  }
 }
 
 }  // namespace
@@ -310,7 +327,6 @@ extern "C" int roms_hip_bulk_flux(const roms_step_idx_t *s)
 {
   int rc = roms_entry_check("roms_hip_bulk_flux");
   if (rc) return rc;
-  if (g_ctx.p.masking) return roms_fail("roms_hip_bulk_flux", "MASKING is not built for bulk_flux (bulk_flux.F:486-920)");
   if ((rc = check_lbc())) return rc;
   const roms_bounds_t &b = g_ctx.b;
   double *Taux = g_ctx.hostc.ws2[6], *Tauy = g_ctx.hostc.ws2[7];
@@ -426,7 +442,11 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   double hsbl = GF(hsbl)[a];
   double sl_dpth = lmd_epsilon * (zwN - hsbl);
   const double s1 = 0.5 * (GF(sustr)[a] + GF(sustr)[a + 1]), s2 = 0.5 * (GF(svstr)[a] + GF(svstr)[a + ni]);
-  const double Ustar = sqrt(sqrt(s1 * s1 + s2 * s2));
+  // MASKING (lmd_skpp.F:272-866): mr = rmask, applied where the reference applies it
+  const bool masking = p.masking != 0;
+  const double mr = masking ? (double)GF(rmask)[a] : 1.0;
+  double Ustar = sqrt(sqrt(s1 * s1 + s2 * s2));
+  if (masking) Ustar = Ustar * mr;                               // :272
   const double alpha = GF(alpha)[a], beta = GF(beta)[a], srflx = GF(srflx)[a];
   const double stT = GF(stflx)[a], stS = GF(stflx)[a + nij];
   const double Bo = g * (alpha * (stT - srflx) - beta * stS);
@@ -435,7 +455,8 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   // (two exp per call) instead of being stored and re-read
   auto bflux_z = [&](double zwk, double &gT, double &gS) {
     const double swdk = swfrac(p, zwN - zwk);
-    const double bf = (Bo + Bosol * (1.0 - swdk));
+    double bf = (Bo + Bosol * (1.0 - swdk));
+    if (masking) bf = bf * mr;                                   // :316
     const double cff = 1.0 - (0.5 + copysign(0.5, bf));
     gT = -cff * (stT - srflx + srflx * (1.0 - swdk));
     gS = cff * stS;
@@ -520,7 +541,15 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
       fc = n_fc; dr = n_dr; du = n_du; dv = n_dv; bvm = n_bvm; zwm = n_zwm;
     }
   }
-  double Bfsfc = (Bo + Bosol * (1.0 - swfrac(p, zwN - hsbl)));
+  // buoyancy flux at the boundary-layer depth; MASKING: depth and flux times rmask (:562, :574 and :669, :681)
+  auto bfsfc_at = [&](double hs) {
+    double zgrid = zwN - hs;
+    if (masking) zgrid = zgrid * mr;
+    double bf = (Bo + Bosol * (1.0 - swfrac(p, zgrid)));
+    if (masking) bf = bf * mr;
+    return bf;
+  };
+  double Bfsfc = bfsfc_at(hsbl);
   if ((Ustar > 0.0) && (Bfsfc > 0.0)) {
     const double hekman = lmd_cekman * Ustar / fmax(fabs(GF(f)[a]), eps);
     const double hmonob = lmd_cmonob * Ustar * Ustar * Ustar / fmax(vonKar * Bfsfc, eps);
@@ -528,6 +557,7 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   }
   hsbl = fmin(hsbl, zwN);
   hsbl = fmax(hsbl, z_w[w3i(0)]);
+  if (masking) hsbl = hsbl * mr;                                 // :595
   GF(hsbl)[a] = hsbl;
   if (!b.NSperiodic) {                                           // bc_r2d_tile: zero gradient at closed walls
     if (b.south_edge && j == b.Jstr) GF(hsbl)[a - ni] = hsbl;
@@ -536,7 +566,7 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   ksbl = 1;
   for (int k = N; k >= 2; k--)
     if ((ksbl == 1) && (z_w[w3i(k - 1)] < hsbl)) ksbl = k;
-  Bfsfc = (Bo + Bosol * (1.0 - swfrac(p, zwN - hsbl)));
+  Bfsfc = bfsfc_at(hsbl);
   sl_dpth = lmd_epsilon * (zwN - hsbl);
   double wm, ws;
   {
@@ -554,24 +584,30 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
     double K_bl = cff_dn * Akv[w3i(k)] + cff_up * Akv[w3i(k - 1)];
     double dK_bl = cff * (Akv[w3i(k)] - Akv[w3i(k - 1)]);
     Gm1 = K_bl / (zbl * wm + eps);
+    if (masking) Gm1 = Gm1 * mr;                                 // :754
     dGm1dS = fmin(0.0, -dK_bl / (wm + eps) - K_bl * f1);
     K_bl = cff_dn * AkT[w3i(k)] + cff_up * AkT[w3i(k - 1)];
     dK_bl = cff * (AkT[w3i(k)] - AkT[w3i(k - 1)]);
     Gt1 = K_bl / (zbl * ws + eps);
+    if (masking) Gt1 = Gt1 * mr;                                 // :765
     dGt1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
     K_bl = cff_dn * AkS[w3i(k)] + cff_up * AkS[w3i(k - 1)];
     dK_bl = cff * (AkS[w3i(k)] - AkS[w3i(k - 1)]);
     Gs1 = K_bl / (zbl * ws + eps);
+    if (masking) Gs1 = Gs1 * mr;                                 // :777
     dGs1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
   } else {
     ksbl = 0;
     const double b1 = 0.5 * (GF(bustr)[a] + GF(bustr)[a + 1]), b2 = 0.5 * (GF(bvstr)[a] + GF(bvstr)[a + ni]);
-    const double Ustarb = sqrt(sqrt(b1 * b1 + b2 * b2));
+    double Ustarb = sqrt(sqrt(b1 * b1 + b2 * b2));
+    if (masking) Ustarb = Ustarb * mr;                           // :793
     const double dK_bl = vonKar * Ustarb;
     const double K_bl = dK_bl * (hsbl - z_w[w3i(0)]);
     Gm1 = K_bl / (zbl * wm + eps);
+    if (masking) Gm1 = Gm1 * mr;                                 // :799
     dGm1dS = fmin(0.0, -dK_bl / (wm + eps) - K_bl * f1);
     Gt1 = K_bl / (zbl * ws + eps);
+    if (masking) Gt1 = Gt1 * mr;                                 // :808
     dGt1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
     Gs1 = Gt1;
     dGs1dS = dGt1dS;
@@ -591,6 +627,7 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
       double wmk, wsk;
       wscale(Ustar, sigma, bf, wmk, wsk);
       sigma = depth / (zbl + eps);
+      if (masking) sigma = sigma * mr;                           // :866
       const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
       const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
       const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
@@ -663,7 +700,6 @@ extern "C" int roms_hip_lmd_vmix(const roms_step_idx_t *s)
   if ((rc = check_lbc())) return rc;
   const roms_bounds_t &b = g_ctx.b;
   if (b.NAT < 2 || !g_ctx.p.salinity) return roms_fail("roms_hip_lmd_vmix", "built for the SALINITY set-up (NAT = 2)");
-  if (g_ctx.p.masking) return roms_fail("roms_hip_lmd_vmix", "MASKING is not built for KPP (lmd_skpp.F:272-866)");
   const long nij = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1);
   const long n3w = nij * (b.N + 1);
   {

@@ -172,16 +172,16 @@ def main_mpdata(config):
     print(json.dumps(out))
 
 
-def main_physics(config):
+def main_physics(config, mask=None):
     """set_vbc (all applications) and bulk_flux (BENCHMARK: the BULK_FLUXES application): reference
     Fortran vs C oracle.  set_vbc has only +,*,sqrt: bit for bit; bulk_flux calls log/exp/pow/atan
-    from two different math libraries: relative difference reported."""
+    from two different math libraries: relative difference reported.  mask = "island": the MASKING builds."""
     import oracle
     import util
     from oracle import ref
-    st0 = util.prepared_state(config)
+    st0 = util.prepared_state(config, mask=mask)
     s = util.step_idx()
-    out = {}
+    out = {"masking": int(st0.p.masking)}
     kernels = ["set_vbc"] + (["bulk_flux", "lmd_vmix"] if config.startswith("BENCHMARK") else [])
     for k in kernels:
         st_r, st_o = st0.copy(), st0.copy()
@@ -201,6 +201,10 @@ def main_physics(config):
         changed = [n for n in names if not np.array_equal(st_r[n], st0[n])]
         out[k] = {"max_rel_diff": max(diffs.values()), "diffs": diffs, "changed": changed,
                   "amax": {n: float(np.abs(st_r[n]).max()) for n in names}}
+        if mask:                                    # land points of the masked outputs are zero in the reference
+            land = st0["rmask"] == 0.0
+            out[k]["land_zero"] = bool(all(not st_r[n][land].any() for n in names
+                                           if n in ("lrflx", "lhflx", "shflx", "hsbl")))
     print(json.dumps(out))
 
 
@@ -324,8 +328,8 @@ if __name__ == "__main__":
         main_ana(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "diag":
         main_diag(sys.argv[1])
-    elif len(sys.argv) > 2 and sys.argv[2] == "physics":
-        main_physics(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] in ("physics", "physics_mask"):
+        main_physics(sys.argv[1], mask="island" if sys.argv[2] == "physics_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] == "mpdata":
         main_mpdata(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mask":

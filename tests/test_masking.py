@@ -2,8 +2,8 @@
 applies them -- step2d_LF_AM3.h:778-836, 1433, 2120-2245; pre_step3d.F:398, 463; step3d_t.F:603, 667,
 1586-1596; prsgrd32.h:300-306, 364-370; t3dmix2_geo.h:228, 260; t3dmix2_s.h:235, 275; uv3dmix2_s.h:272;
 rho_eos.F:356, 478, 717; step3d_uv.F:558, 891, 1137-1384; the closed-wall conditions of zetabc.F, u2dbc_im.F,
-u3dbc_im.F, t3dbc_im.F.  (Not built: the MASKING variants of mpdata_adiff, HSIMT on the device, lmd_skpp and
-bulk_flux -- the entries refuse them.)
+u3dbc_im.F, t3dbc_im.F; bulk_flux.F:486-920; lmd_skpp.F:272-866.  (Not built: the MASKING variants of mpdata_adiff
+and of HSIMT -- the entries refuse them.)
 
 CPU: properties of the masked discretisation on the oracle -- land stays land, volume and tracer content are
 conserved around an island and a headland, and every tiling gives the same answer.  GPU (-m gpu): every
@@ -192,3 +192,65 @@ def test_hip_100_steps_on_masked_grid(config):
     assert np.isfinite(st_h["t"]).all()
     assert all(v <= 1e-10 for v in out.values()), out          # north-star bound; observed: 0
     assert np.all(st_h.interior("u")[st_h.interior("umask") == 0][..., s.nnew - 1] == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["bulk_flux", "lmd_vmix"])
+def test_hip_physics_on_masked_grid(kernel):
+    """bulk_flux (bulk_flux.F:486-920) and KPP (lmd_skpp.F:272-866) with their MASKING multiplies, BENCHMARK
+    application: HIP vs the oracle (itself pinned against the reference built with -DMASKING); transcendental
+    functions of the device differ from the host's in the last bits, hence the tolerances of the unmasked tests."""
+    import oracle
+    from roms_trunk_mgh_amd import hip
+    st0 = util.prepared_state("BENCHMARK_TINY", mask="island")
+    st0["Vwind"] += 0.3 * st0["Uwind"] - 2.0
+    st0["rain"] += 2.0e-5
+    st_o, st_h = st0.copy(), st0.copy()
+    s = util.step_idx()
+    oracle.Oracle(st_o).call(kernel, s)
+    h = hip.RomsHip(st_h)
+    try:
+        h.call(kernel, s)
+        h.to_host()
+    finally:
+        h.close()
+    names = {"bulk_flux": ["sustr", "svstr", "lrflx", "lhflx", "shflx", "stflux"],
+             "lmd_vmix": ["Akv", "Akt", "ghats", "hsbl"]}[kernel]
+    tol = 1e-11 if kernel == "bulk_flux" else 1e-10
+    for n in names:
+        assert util.max_rel_diff(st_h[n], st_o[n]) <= tol, n
+        assert not np.array_equal(st_o[n], st0[n]), n
+    land = st0["rmask"] == 0.0
+    for n in ("lrflx", "lhflx", "shflx", "hsbl"):
+        if n in names:
+            assert not st_h[n][land].any(), n
+
+
+@pytest.mark.gpu
+def test_hip_100_steps_with_physics_on_masked_grid():
+    """the complete BENCHMARK step (bulk fluxes, KPP, diagnostics) on the island grid, HIP vs oracle."""
+    import oracle
+    from roms_trunk_mgh_amd import hip
+    from roms_trunk_mgh_amd.state import rel_rms
+    st_o = ana.make_tile("BENCHMARK_TINY", perturb=1.0, mask="island")
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o), physics=True, diagnostics=True)
+    mo.initial()
+    mo.run(100)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be, physics=True, diagnostics=True)
+        mh.initial()
+        mh.run(100)
+        be.to_host()
+    finally:
+        be.close()
+    s = mo.s
+    out = {"zeta": rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], 1e-3)}
+    for name in ("u", "v"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], 1e-4)
+    for it in range(st_o.b.NT):
+        out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
+    assert np.isfinite(st_h["t"]).all() and np.isfinite(st_h["Akv"]).all()
+    assert all(v <= 1e-10 for v in out.values()), out
+    assert float(np.abs(st_o["Akv"]).max()) > 1e-4
