@@ -275,6 +275,10 @@ def main():
     ap.add_argument("--mpdata-exact", action="store_true",
                     help="MPDATA configurations: IEEE divisions in mpdata_adiff (bit-identical to the oracle) instead of "
                          "the refined reciprocals (within 1e-10 relative RMS of it, the default)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="N = 1 only: hand the library an RCCL id so that the tile is its own western / eastern neighbour "
+                         "and every periodic exchange of the step travels through pack -> ncclSend/ncclRecv -> unpack "
+                         "(what a tile of an N-GPU run executes, measured on one GPU; not the headline configuration)")
     ap.add_argument("--no-physics", dest="physics", action="store_false",
                     help="keep the outputs of bulk_flux + set_vbc fixed instead of recomputing them on the "
                          "device every step (SURVEY 8f-1); default: recompute, as the reference's step does")
@@ -399,6 +403,14 @@ def main():
                 selftest = "ok"
     elif world > 1:
         transport = "relay"
+    if be is None and world == 1 and args.loopback:
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        if hip.load().roms_hip_get_unique_id(buf) != 0:
+            raise SystemExit("--loopback: RCCL is not available")
+        tick("backend (loopback)", 120.0)
+        be = hip.RomsHip(st, rank=0, device=device, nccl_unique_id=bytes(buf.raw))
+        transport = "rccl-loopback"
     if be is None:
         tick("backend", 120.0)
         be = hip.RomsHip(st, rank=rank, device=device, nccl_unique_id=None)
