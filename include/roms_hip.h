@@ -183,7 +183,9 @@ int roms_hip_sync_all_to_host(void);
  * begin().  One snapshot in flight at a time; the host arrays must not be read or written in between. */
 int roms_hip_snapshot_begin(const int *field_ids, int n);
 int roms_hip_snapshot_end(void);
-/* Device address of a field mirror (for zero-copy consumers); NULL if none. */
+/* Device address of a field mirror (for zero-copy consumers); NULL if none.  The grid-metric arrays are taken to
+ * be constant between uploads (roms_hip_row_metrics_state below): a consumer that WRITES one of them through this
+ * pointer must upload or re-register the field afterwards. */
 double *roms_hip_device_ptr(int field_id);
 int roms_hip_device_synchronize(void);
 const char *roms_hip_last_error(void);
