@@ -14,6 +14,7 @@ int oracle_step3d_t(OARGS)
 {
   ORACLE_PROLOGUE
   if (o_check_lbc(b, p)) return 8;
+  if (!p->splines_vdiff) return 8;        /* only the SPLINES_VDIFF operator (step3d_t.F:1363-1430) is restated */
   const int nnew = s->nnew;
   const double dt = p->dt;
   const double eps = 1.0E-16;

@@ -11,6 +11,7 @@ int oracle_step3d_uv(OARGS)
 {
   ORACLE_PROLOGUE
   if (o_check_lbc(b, p)) return 8;
+  if (!p->splines_vvisc) return 8;        /* only the SPLINES_VVISC operator (step3d_uv.F:303-398) is restated */
   const int nrhs = s->nrhs, nnew = s->nnew;
   const int iic = s->iic, ntfirst = s->ntfirst;
   const double dt = p->dt;

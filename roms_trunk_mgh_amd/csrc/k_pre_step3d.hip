@@ -117,7 +117,7 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
   double FCprev = 0.0;                                        // advective FC(k-1)
   double FDprev = dt * GF(btflx)[c0 + (long)(itrc - 1) * nij]; // diffusive FC(0)
   double w_km1 = Wv[c0];
-  double zr_k = z_r[c0];
+  double zr_k = (cff3 != 0.0) ? z_r[c0] : 0.0;
   for (int k = 1; k <= N; k++) {
     const long ck = c0 + (long)(k - 1) * nij;
     tkp2 = (k + 2 <= N) ? ts[ck + 2 * nij] : 0.0;
@@ -164,16 +164,22 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
     double FDk;
     if (k == N) FDk = dt * GF(stflx)[c0 + (long)(itrc - 1) * nij];
     else {
-      const double zr_k1 = z_r[ck + nij];
-      const double cz = 1.0 / (zr_k1 - zr_k);
-      FDk = cff3 * cz * Akt[ck + nij] * (tkp1 - tk);
+      if (cff3 != 0.0) {
+        const double zr_k1 = z_r[ck + nij];
+        const double cz = 1.0 / (zr_k1 - zr_k);
+        FDk = cff3 * cz * Akt[ck + nij] * (tkp1 - tk);
+        zr_k = zr_k1;
+      } else {
+        // lambda = 1 (fully implicit vertical diffusion, every shipped application): the explicit flux is
+        // cff3 * (...) = +-0; z_r, the division and (without the non-local term) Akt are not needed
+        FDk = 0.0;
+      }
       if (nonlocal) FDk = FDk - dt * AktN[ck + nij] * ghats[ck + nij];
       if (solar) {
         const double Z = zwN - z_w[ck + nij];
         const double swdk = exp(Z * fac1) * fac3 + exp(Z * fac2) * (1.0 - fac3);
         FDk = FDk + dt * srf * swdk;
       }
-      zr_k = zr_k1;
     }
     tn[ck] = hz * tk + (FDk - FDprev);
     FDprev = FDk;

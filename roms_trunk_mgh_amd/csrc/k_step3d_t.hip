@@ -531,6 +531,9 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
   const roms_bounds_t &b = g_ctx.b;
   const roms_params_t &p = g_ctx.p;
   if (b.N < 4) return roms_fail("roms_hip_step3d_t", "N < 4");
+  if (!p.splines_vdiff)
+    return roms_fail("roms_hip_step3d_t", "only the spline-form implicit vertical diffusion (SPLINES_VDIFF, "
+                                          "step3d_t.F:1363-1430) is implemented");
   {
     ScopedTimer tm("step3d_t");
     // one launch per run of consecutive tracers sharing a scheme pair (run-time

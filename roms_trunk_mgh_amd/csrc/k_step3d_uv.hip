@@ -250,6 +250,9 @@ extern "C" int roms_hip_step3d_uv(const roms_step_idx_t *s)
   int rc = roms_entry_check("roms_hip_step3d_uv");
   if (rc) return rc;
   if ((rc = check_lbc())) return rc;
+  if (!g_ctx.p.splines_vvisc)
+    return roms_fail("roms_hip_step3d_uv", "only the spline-form implicit vertical viscosity (SPLINES_VVISC, "
+                                           "step3d_uv.F:303-398) is implemented");
   const roms_bounds_t &b = g_ctx.b;
   const double dt = g_ctx.p.dt;
   double cff;

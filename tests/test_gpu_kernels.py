@@ -327,3 +327,31 @@ def test_step2d_loop_reads_metric_arrays_when_they_depend_on_i(config):
         diffs = util.compare_states(st_h, st_o)
         assert all(v <= TOL for v in diffs.values()), (perturbed, diffs)
         assert util.compare_states(st_o, st0)
+
+
+@pytest.mark.parametrize("config,kernel,mpdata", [("BENCHMARK_TINY", "pre_step3d", False), ("UPWELLING", "pre_step3d", False),
+                                                  ("SEAMOUNT", "pre_step3d", False), ("UPWELLING", "step3d_t", True)])
+def test_semi_implicit_vertical_mixing(config, kernel, mpdata):
+    """lambda < 1 (mod_scalars.F:724-729; the shipped applications use 1): the explicit share dt (1 - lambda) of the
+    vertical viscous / diffusive fluxes in pre_step3d.F:838, :918, :1023 -- with lambda = 1 the predictor kernels skip
+    that flux altogether, this is the other branch -- and the implicit share lambda dt of the classic tridiagonal
+    MPDATA tracers keep (step3d_t.F:1436; the spline-form operators of SPLINES_VDIFF / SPLINES_VVISC, which all three
+    applications define, do not contain lambda)."""
+    import oracle
+    ov = {"Hadv": "MPDATA", "Vadv": "MPDATA"} if mpdata else None
+
+    def prep(st):
+        st.p = type(st.p).from_buffer_copy(st.p)
+        st.p.lambda_ = 0.75
+        if kernel == "step3d_t":
+            util.hz_weighted_tnew(st)
+    st_h, st_o, st0 = _run_pair(config, kernel, util.step_idx(iic=5), prep=prep, overrides=ov)
+    assert st_o.p.lambda_ == 0.75
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+    # and it is a different answer from lambda = 1
+    st_1 = st0.copy()
+    st_1.p = type(st0.p).from_buffer_copy(st0.p)          # copy() shares the parameter block
+    st_1.p.lambda_ = 1.0
+    oracle.Oracle(st_1).call(kernel, util.step_idx(iic=5))
+    assert util.compare_states(st_o, st_1)
