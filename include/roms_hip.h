@@ -206,7 +206,9 @@ int roms_hip_set_depth(const roms_step_idx_t *s);
 /* Informational: how the barotropic kernel reads the fifteen grid-metric arrays (pm, pn, on_u, om_v, fomn, dndx,
  * dmde, pmon_r, pnom_r, pmon_p, pnom_p, om_r, on_r, om_p, on_p).  0 = not examined since their last upload;
  * 1 = all of them are independent of i on this tile (checked bit for bit on the device: a zonally uniform grid) and
- * the kernel takes them from a per-row table; 2 = they are not, and it reads the arrays.  Same results either way. */
+ * the kernel takes them from a per-row table; 2 = they are not, and it reads the arrays; 3 = as 1, and the resting
+ * depth h and the viscosity coefficients visc2_r, visc2_p are independent of i as well (flat or zonally uniform
+ * bathymetry) and come from the table too.  Same results in every case. */
 int roms_hip_row_metrics_state(void);
 /* ini_zeta(ng,tile,model)          ROMS/Nonlinear/ini_fields.F:780
  * ini_fields(ng,tile,model)        ROMS/Nonlinear/ini_fields.F:27

@@ -31,7 +31,11 @@ struct S2 {
 // stream through the fabric and ~60 of the ~100 vector loads per point become broadcasts.  Same values, same
 // arithmetic, same results; any i-dependence in any of the arrays selects the general kernel.
 enum { RM_pm = 0, RM_pn, RM_on_u, RM_om_v, RM_fomn, RM_dndx, RM_dmde, RM_pmon_r, RM_pnom_r, RM_pmon_p, RM_pnom_p,
-       RM_om_r, RM_on_r, RM_om_p, RM_on_p, RM_COUNT };
+       RM_om_r, RM_on_r, RM_om_p, RM_on_p,
+       // second group, examined on its own: the resting depth and the viscosity coefficients (flat or zonally uniform
+       // bathymetry, uniform or grid-scaled viscosity) -- used from the table only when the first group is
+       RM_h, RM_visc2_r, RM_visc2_p, RM_COUNT };
+#define RM_FIRST_GROUP RM_h
 
 template <bool ROWM>
 struct Met {
@@ -45,6 +49,7 @@ struct Met {
   }
 };
 #define MT(name, q, jr) met.get((gcd_t)c->F.name, RM_##name, (q), (jr))
+#define HT(name, q, jr) meth.get((gcd_t)c->F.name, RM_##name, (q), (jr))
 
 #define TP (BLK_X + 4)       // tile pitch (i)
 #define TJ (BLK_Y + 4)       // tile rows  (j)
@@ -143,7 +148,7 @@ __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S
 // of k2d_zeta_sm are done here as well -- zeta_new and zwrk are evaluated from the staged DUon/DVom
 // tiles for the (65 x 5) points this workgroup's momentum stencil touches and kept in LDS, so one
 // step2d call is ONE launch and the zeta_new/zwrk scratch round trip disappears.
-template <bool FUSED, bool ROWM = false>
+template <bool FUSED, bool ROWM = false, bool ROWH = false>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, const double *__restrict__ DVom,
             const double *__restrict__ zeta_new, const double *__restrict__ zwrk, double *__restrict__ DUnext,
@@ -152,6 +157,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   DEV_PROLOGUE(c)
   const roms_params_t &p = c->p;
   const Met<ROWM> met{(gcd_t)c->rowm, (int)nj, LBj};
+  const Met<ROWH> meth{(gcd_t)c->rowm, (int)nj, LBj};
   // DUnext != nullptr (FUSED on several tiles, inside LOOP_2D): the closed-wall conditions are applied here
   // and DUon/DVom of the NEXT call (level knew) are left in DUnext/DVnext on the points this tile owns,
   // so that one exchange per call moves everything the next call needs
@@ -172,7 +178,6 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const gcd_t ubk = (gcd_t)(c->F.ubar + (long)(s.krhs - 1) * nij);
   const gcd_t vbk = (gcd_t)(c->F.vbar + (long)(s.krhs - 1) * nij);
   const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
-  const gcd_t h = (gcd_t)(c->F.h);
   // ---- stage the stencil fields (target coordinates it0-2.., j0-2..) ----
   {
     const int tid = threadIdx.y * BLK_X + threadIdx.x;
@@ -183,7 +188,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       else gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
       gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
       const long g = I2(gi, gj);
-      const double ug = ubk[g], vg = vbk[g], Dg = zk[g] + h[g];
+      const double ug = ubk[g], vg = vbk[g], Dg = zk[g] + HT(h, g, gj);
       sU[e] = ug;
       sV[e] = vg;
       sD[e] = Dg;
@@ -194,10 +199,10 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
         // DUon, DVom evaluated in place (:509-544), identical expression to k2d_flux; the
         // ghost columns/rows they reach hold exact copies, so no separate flux pass is needed
         const double cu = 0.5 * MT(on_u, g, gj);
-        sDU[e] = ug * (cu * (Dg + (zk[g - 1] + h[g - 1])));
+        sDU[e] = ug * (cu * (Dg + (zk[g - 1] + HT(h, g - 1, gj))));
         if (gj >= b.LBj + 1) {
           const double cv = 0.5 * MT(om_v, g, gj);
-          sDV[e] = vg * (cv * (Dg + (zk[g - ni] + h[g - ni])));
+          sDV[e] = vg * (cv * (Dg + (zk[g - ni] + HT(h, g - ni, gj - 1))));
         } else sDV[e] = 0.0;
       }
     }
@@ -297,6 +302,8 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     if (s.predictor)      // at the target: ghost columns hold the periodic copy, as after the exchange
       put((gd_t)(c->F.rzeta + (long)(s.krhs - 1) * nij), o, (sDU[t] - sDU[t + 1]) + (sDV[t] - sDV[t + TP]));
   }
+  // resting depth at the point, its western and its southern neighbour (rows j, j, j-1: always inside the array)
+  const double h0 = HT(h, a, j), hw = HT(h, a - 1, j), hs = HT(h, a - ni, j - 1);
   const double zw0 = FUSED ? sZw[t] : zwrk[a];
   const double gz0 = (fac + rhoS[a]) * zw0, gz20 = gz0 * zw0, gsa0 = zw0 * (rhoS[a] - rhoA[a]);
   const double cg = 0.5 * p.g, c3 = 1.0 / 3.0;
@@ -306,8 +313,8 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const double zw = FUSED ? sZw[t - 1] : zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
     rhs_u = cg * MT(on_u, a, j) *
-            ((h[q] + h[a]) * (gz - gz0) +
-             (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
+            ((hw + h0) * (gz - gz0) +
+             (hw - h0) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
              (gz2 - gz20));
   }
   if (do_v) {
@@ -315,8 +322,8 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const double zw = FUSED ? sZw[t - TP] : zwrk[q];
     const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
     rhs_v = cg * MT(om_v, a, j) *
-            ((h[q] + h[a]) * (gz - gz0) +
-             (h[q] - h[a]) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
+            ((hs + h0) * (gz - gz0) +
+             (hs - h0) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
              (gz2 - gz20));
   }
   // ---- advection, :1079-1283 ----
@@ -367,16 +374,15 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   }
   // ---- harmonic viscosity, :1394-1471 ----
   if (p.uv_vis2) {
-    const gcd_t visc2_r = (gcd_t)c->F.visc2_r, visc2_p = (gcd_t)c->F.visc2_p;
     // q = flat index of the stress point, jq = its row
     auto str_r = [&](long q, int jq, int tq) {
-      return visc2_r[q] * sD[tq] * 0.5 *
+      return HT(visc2_r, q, jq) * sD[tq] * 0.5 *
              (MT(pmon_r, q, jq) * ((MT(pn, q, jq) + MT(pn, q + 1, jq)) * sU[tq + 1] - (MT(pn, q - 1, jq) + MT(pn, q, jq)) * sU[tq]) -
               MT(pnom_r, q, jq) * ((MT(pm, q, jq) + MT(pm, q + ni, jq + 1)) * sV[tq + TP] - (MT(pm, q - ni, jq - 1) + MT(pm, q, jq)) * sV[tq]));
     };
     auto str_p = [&](long q, int jq, int tq) {
       const double Dp = 0.25 * (sD[tq] + sD[tq - 1] + sD[tq - TP] + sD[tq - 1 - TP]);
-      const double cffp = visc2_p[q] * Dp * 0.5 *
+      const double cffp = HT(visc2_p, q, jq) * Dp * 0.5 *
              (MT(pmon_p, q, jq) * ((MT(pn, q - ni, jq - 1) + MT(pn, q, jq)) * sV[tq] - (MT(pn, q - 1 - ni, jq - 1) + MT(pn, q - 1, jq)) * sV[tq - 1]) +
               MT(pnom_p, q, jq) * ((MT(pm, q - 1, jq) + MT(pm, q, jq)) * sU[tq] - (MT(pm, q - 1 - ni, jq - 1) + MT(pm, q - ni, jq - 1)) * sU[tq - TP]));
       return masking ? cffp * GF(pmask)[q] : cffp;              // MASKING, :1433
@@ -430,7 +436,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   }
   // ---- time step, :2098-2255 ----
   const double dtfast = p.dtfast;
-  const double Dn0 = (FUSED ? sZn[t] : zeta_new[a]) + h[a], Dst0 = zs[a] + h[a];
+  const double Dn0 = (FUSED ? sZn[t] : zeta_new[a]) + h0, Dst0 = zs[a] + h0;
   const int ptsk = 3 - s.kstp;
   const bool am3 = !(s.iif == 1 || s.predictor);
   const double c1 = (s.iif == 1) ? 0.5 * dtfast : dtfast;
@@ -440,11 +446,11 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   if (do_u) {
     const long q = a - 1;
     const double cff = (MT(pm, a, j) + MT(pm, q, j)) * (MT(pn, a, j) + MT(pn, q, j));
-    const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - 1] : zeta_new[q]) + h[q]));
+    const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - 1] : zeta_new[q]) + hw));
     const double us = GF(ubar)[a + (long)(s.kstp - 1) * nij];
     double un;
-    if (!am3) un = (us * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_u) * fc;
-    else un = (us * (Dst0 + (zs[q] + h[q])) +
+    if (!am3) un = (us * (Dst0 + (zs[q] + hw)) + cff * c1 * rhs_u) * fc;
+    else un = (us * (Dst0 + (zs[q] + hw)) +
                cff * (a1 * rhs_u + a2 * GF(rubar)[a + (long)(s.kstp - 1) * nij] -
                       a3 * GF(rubar)[a + (long)(ptsk - 1) * nij])) * fc;
     if (masking) un = un * GF(umask)[a];               // MASKING, :2120 / :2175
@@ -459,32 +465,32 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     if constexpr (FUSED) {
       if (DUnext) {                                    // DUon of level knew, :509-525 (as k2d_flux)
         const double znw = sZn[t - 1];
-        DUnext[a] = un * ((0.5 * MT(on_u, a, j)) * (Dn0 + (znw + h[q])));
+        DUnext[a] = un * ((0.5 * MT(on_u, a, j)) * (Dn0 + (znw + hw)));
         // wall rows: u = gamma2*u(adjacent row), zeta = zero-gradient copy (u2dbc_im.F:51, zetabc.F:48)
         if (b.south_edge && j == b.Jstr)
           DUnext[a - ni] = un_s * ((0.5 * MT(on_u, a - ni, j - 1)) *
-                                   ((sZn[t] * mk(GF(rmask), a - ni) + h[a - ni]) + (znw * mk(GF(rmask), q - ni) + h[q - ni])));
+                                   ((sZn[t] * mk(GF(rmask), a - ni) + hs) + (znw * mk(GF(rmask), q - ni) + HT(h, q - ni, j - 1))));
         if (b.north_edge && j == b.Jend)
           DUnext[a + ni] = un_n * ((0.5 * MT(on_u, a + ni, j + 1)) *
-                                   ((sZn[t] * mk(GF(rmask), a + ni) + h[a + ni]) + (znw * mk(GF(rmask), q + ni) + h[q + ni])));
+                                   ((sZn[t] * mk(GF(rmask), a + ni) + HT(h, a + ni, j + 1)) + (znw * mk(GF(rmask), q + ni) + HT(h, q + ni, j + 1))));
       }
     }
   }
   if (do_v) {
     const long q = a - ni;
     const double cff = (MT(pm, a, j) + MT(pm, q, j - 1)) * (MT(pn, a, j) + MT(pn, q, j - 1));
-    const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - TP] : zeta_new[q]) + h[q]));
+    const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - TP] : zeta_new[q]) + hs));
     const double vs = GF(vbar)[a + (long)(s.kstp - 1) * nij];
     double vn;
-    if (!am3) vn = (vs * (Dst0 + (zs[q] + h[q])) + cff * c1 * rhs_v) * fc;
-    else vn = (vs * (Dst0 + (zs[q] + h[q])) +
+    if (!am3) vn = (vs * (Dst0 + (zs[q] + hs)) + cff * c1 * rhs_v) * fc;
+    else vn = (vs * (Dst0 + (zs[q] + hs)) +
                cff * (a1 * rhs_v + a2 * GF(rvbar)[a + (long)(s.kstp - 1) * nij] -
                       a3 * GF(rvbar)[a + (long)(ptsk - 1) * nij])) * fc;
     if (masking) vn = vn * GF(vmask)[a];               // MASKING, :2145 / :2194
     put(vbn, o, vn);
     if (s.predictor && owner) GF(rvbar)[a + (long)(s.krhs - 1) * nij] = rhs_v;
     if constexpr (FUSED) {
-      if (DVnext) DVnext[a] = vn * ((0.5 * MT(om_v, a, j)) * (Dn0 + (sZn[t - TP] + h[q])));   // :527-544
+      if (DVnext) DVnext[a] = vn * ((0.5 * MT(om_v, a, j)) * (Dn0 + (sZn[t - TP] + hs)));   // :527-544
     }
   }
   if (inline_bc) {                                     // v2dbc closed walls, v2dbc_im.F:52
@@ -495,9 +501,9 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     if (DVnext) {                                      // wall rows: v = 0 there
       const double zn0 = sZn[t];
       if (b.south_edge && j == b.Jstr)
-        DVnext[a] = 0.0 * ((0.5 * MT(om_v, a, j)) * ((zn0 + h[a]) + (zn0 * mk(GF(rmask), a - ni) + h[a - ni])));
+        DVnext[a] = 0.0 * ((0.5 * MT(om_v, a, j)) * ((zn0 + h0) + (zn0 * mk(GF(rmask), a - ni) + hs)));
       if (b.north_edge && j == b.Jend)
-        DVnext[a + ni] = 0.0 * ((0.5 * MT(om_v, a + ni, j + 1)) * ((zn0 * mk(GF(rmask), a + ni) + h[a + ni]) + (zn0 + h[a])));
+        DVnext[a + ni] = 0.0 * ((0.5 * MT(om_v, a + ni, j + 1)) * ((zn0 * mk(GF(rmask), a + ni) + HT(h, a + ni, j + 1)) + (zn0 + h0)));
     }
   }
 }
@@ -510,7 +516,7 @@ __global__ void k_rowm_build(const RomsDev *__restrict__ c, double *__restrict__
   const int jr = blockIdx.x, f = blockIdx.y;
   const double *const A[RM_COUNT] = {c->F.pm, c->F.pn, c->F.on_u, c->F.om_v, c->F.fomn, c->F.dndx, c->F.dmde,
                                      c->F.pmon_r, c->F.pnom_r, c->F.pmon_p, c->F.pnom_p, c->F.om_r, c->F.on_r,
-                                     c->F.om_p, c->F.on_p};
+                                     c->F.om_p, c->F.on_p, c->F.h, c->F.visc2_r, c->F.visc2_p};
   const double *a = A[f];
   if (!a) {                           // array not registered: never read by a kernel either
     if (threadIdx.x == 0) tab[(long)f * nj + jr] = 0.0;
@@ -523,14 +529,15 @@ __global__ void k_rowm_build(const RomsDev *__restrict__ c, double *__restrict__
   const unsigned long long v0 = row[b.Istr];
   bool differs = false;
   for (int i = i0 + (int)threadIdx.x; i <= i1; i += (int)blockDim.x) differs |= row[i] != v0;
-  if (differs) atomicOr(flag, 1);
+  if (differs) atomicOr(flag + (f >= RM_FIRST_GROUP ? 1 : 0), 1);     // one flag per group
   if (threadIdx.x == 0) tab[(long)f * nj + jr] = a[(long)jr * ni + (b.Istr - LBi)];
 }
 
 }  // namespace
 
-// 0 = not examined yet, 1 = the metric arrays are independent of i (row table in use), 2 = they are not
-extern "C" int roms_hip_row_metrics_state(void) { return g_ctx.rowm_state; }
+// 0 = not examined yet, 1 = the metric arrays are independent of i (row table in use), 2 = they are not,
+// 3 = as 1 and h, visc2_r, visc2_p are independent of i too
+extern "C" int roms_hip_row_metrics_state(void) { return g_ctx.rowm_state == 1 && g_ctx.rowh ? 3 : g_ctx.rowm_state; }
 
 void roms_rowm_invalidate()
 {
@@ -564,11 +571,12 @@ int roms_rowm_prepare()
   hipLaunchKernelGGL(k_rowm_build, dim3((unsigned)nj, RM_COUNT), dim3(256), 0, g_ctx.stream, g_ctx.devc,
                      g_ctx.rowm_dev, flag);
   KERNEL_CHECK("k_rowm_build");
-  int differs = 0;
-  HIP_TRY(hipMemcpyAsync(&differs, flag, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
+  int differs[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(differs, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-  g_ctx.rowm_state = differs ? 2 : 1;
-  const double *want = differs ? nullptr : g_ctx.rowm_dev;
+  g_ctx.rowm_state = differs[0] ? 2 : 1;
+  g_ctx.rowh = !differs[0] && !differs[1];
+  const double *want = differs[0] ? nullptr : g_ctx.rowm_dev;
   if (g_ctx.hostc.rowm != want) {
     g_ctx.hostc.rowm = want;
     g_ctx.devc_dirty = true;
@@ -586,7 +594,11 @@ int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DV
   const int nx = (s.sm == 1) ? (b.UBi - b.LBi + 1) : (b.Iend - b.Istr + 1);
   if (s.sm == 2) {      // fused free-surface + momentum call (source-mapped, fluxes in place)
     s.sm = 1;
-    if (g_ctx.rowm_state == 1)        // metrics independent of i: row table instead of fifteen 2-D arrays
+    if (g_ctx.rowm_state == 1 && g_ctx.rowh)   // ... and depth and viscosity coefficients as well
+      hipLaunchKernelGGL((k2d_mom_lds<true, true, true>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                         g_ctx.devc, s, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
+                         (const double *)nullptr, (double *)nullptr, (double *)nullptr);
+    else if (g_ctx.rowm_state == 1)   // metrics independent of i: row table instead of fifteen 2-D arrays
       hipLaunchKernelGGL((k2d_mom_lds<true, true>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
                          g_ctx.devc, s, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
                          (const double *)nullptr, (double *)nullptr, (double *)nullptr);
@@ -596,7 +608,10 @@ int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DV
                          (const double *)nullptr, (double *)nullptr, (double *)nullptr);
   } else if (s.sm == 3) {   // fused call on several tiles: exchanged DUon/DVom in, next call's fluxes out
     s.sm = 0;
-    if (g_ctx.rowm_state == 1)
+    if (g_ctx.rowm_state == 1 && g_ctx.rowh)
+      hipLaunchKernelGGL((k2d_mom_lds<true, true, true>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                         g_ctx.devc, s, DUon, DVom, (const double *)nullptr, (const double *)nullptr, DUnext, DVnext);
+    else if (g_ctx.rowm_state == 1)
       hipLaunchKernelGGL((k2d_mom_lds<true, true>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
                          g_ctx.devc, s, DUon, DVom, (const double *)nullptr, (const double *)nullptr, DUnext, DVnext);
     else

@@ -54,6 +54,7 @@ struct RomsCtx {
   // row-uniform metrics (k_step2d_mom.hip): 0 = not examined since the last upload of a metric array,
   // 1 = all fifteen arrays are independent of i (table valid), 2 = not
   int rowm_state = 0;
+  bool rowh = false;             // ... and h, visc2_r, visc2_p as well (second group of the table)
   double *rowm_dev = nullptr;
   long rowm_nj = 0;
 };

@@ -305,14 +305,15 @@ def test_more_than_32_levels(kernel, N):
 @pytest.mark.parametrize("config", CONFIGS)
 def test_step2d_loop_reads_metric_arrays_when_they_depend_on_i(config):
     """The barotropic kernel takes its grid metrics from a per-row table when all fifteen arrays are independent of
-    i (every analytic grid of this repository) and from the arrays otherwise: one perturbed value of pm must select
-    the general kernel, and both must agree with the oracle bit for bit."""
+    i (every analytic grid of this repository) and from the arrays otherwise -- likewise, as a second group, the
+    resting depth and the viscosity coefficients: one perturbed value of pm must select the general kernel, one of h
+    the metrics-only kernel, and all of them must agree with the oracle bit for bit."""
     import oracle
     from roms_trunk_mgh_amd import hip, main3d
-    for perturbed in (False, True):
+    for perturbed in (None, "pm", "h"):
         st0 = util.prepared_state(config)
         if perturbed:
-            st0["pm"][st0.I(7, 7), st0.J(9, 9)] *= 1.0 + 1.0e-6
+            st0[perturbed][st0.I(7, 7), st0.J(9, 9)] *= 1.0 + 1.0e-6
         st_o, st_h = st0.copy(), st0.copy()
         s_o, s_h = util.step_idx(iic=5), util.step_idx(iic=5)
         oracle.Oracle(st_o).step2d_loop(s_o, 1)
@@ -323,7 +324,10 @@ def test_step2d_loop_reads_metric_arrays_when_they_depend_on_i(config):
             h.to_host()
         finally:
             h.close()
-        assert state == (2 if perturbed else 1)
+        # 3: metrics, depth and viscosity from the row table; 1: metrics only (SEAMOUNT's depth depends on i);
+        # 2: the arrays
+        want = {None: 1 if config == "SEAMOUNT" else 3, "pm": 2, "h": 1}[perturbed]
+        assert state == want, (perturbed, state)
         diffs = util.compare_states(st_h, st_o)
         assert all(v <= TOL for v in diffs.values()), (perturbed, diffs)
         assert util.compare_states(st_o, st0)
