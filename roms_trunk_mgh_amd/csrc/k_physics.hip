@@ -510,9 +510,9 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
         cff = 1.0 / sqrt(fmax(bv, 1.0E-7));
         const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
         Akv[w3i(k)] = lmd_iwm + lmd_nu0m * nu_sx;
-        const double at = lmd_iws + lmd_nu0s * nu_sx;
-        AkT[w3i(k)] = at;
-        AkS[w3i(k)] = at;
+        // Akt(itemp) = Akt(isalt) here (lmd_vmix.F:296-297): one store; the sweeps below read AkT for both and the
+        // last one writes the final AkS of every interior level
+        AkT[w3i(k)] = lmd_iws + lmd_nu0s * nu_sx;
       }
       // (b) bulk Richardson function at W-level k-1
       const double depth = zwN - zwm;
@@ -591,8 +591,10 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
     Gt1 = K_bl / (zbl * ws + eps);
     if (masking) Gt1 = Gt1 * mr;                                 // :765
     dGt1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
-    K_bl = cff_dn * AkS[w3i(k)] + cff_up * AkS[w3i(k - 1)];
-    dK_bl = cff * (AkS[w3i(k)] - AkS[w3i(k - 1)]);
+    // salinity: interior levels hold the temperature values (see above); level N was not touched
+    const double aks_k = (k <= N - 1) ? AkT[w3i(k)] : AkS[w3i(k)], aks_km1 = AkT[w3i(k - 1)];
+    K_bl = cff_dn * aks_k + cff_up * aks_km1;
+    dK_bl = cff * (aks_k - aks_km1);
     Gs1 = K_bl / (zbl * ws + eps);
     if (masking) Gs1 = Gs1 * mr;                                 // :777
     dGs1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
@@ -613,12 +615,12 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
     dGs1dS = dGt1dS;
   }
   long q3 = w3i(1);
-  double n_akv = Akv[q3], n_akt = AkT[q3], n_aks = AkS[q3], n_zw = z_w[q3], n_bv = bvf[q3];
+  double n_akv = Akv[q3], n_akt = AkT[q3], n_zw = z_w[q3], n_bv = bvf[q3];
   for (int k = 1; k <= N - 1; k++) {
-    double akv = n_akv, akt = n_akt, aks = n_aks;
+    double akv = n_akv, akt = n_akt, aks = n_akt;
     const double zwk = n_zw, bvk = n_bv;
     q3 = w3i(k + 1 <= N - 1 ? k + 1 : k);                      // next level, in flight during this one
-    n_akv = Akv[q3]; n_akt = AkT[q3]; n_aks = AkS[q3]; n_zw = z_w[q3]; n_bv = bvf[q3];
+    n_akv = Akv[q3]; n_akt = AkT[q3]; n_zw = z_w[q3]; n_bv = bvf[q3];
     if (k > ksbl) {
       const double depth = zwN - zwk;
       double gT, gS;

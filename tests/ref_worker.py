@@ -205,6 +205,23 @@ def main_physics(config, mask=None):
             land = st0["rmask"] == 0.0
             out[k]["land_zero"] = bool(all(not st_r[n][land].any() for n in names
                                            if n in ("lrflx", "lhflx", "shflx", "hsbl")))
+    if config.startswith("BENCHMARK"):
+        # KPP on a stratified state (prepared_state leaves pden, bvf, alpha, beta zero): util.kpp_state
+        st0 = util.kpp_state(config, mask=mask)
+        st_r, st_o = st0.copy(), st0.copy()
+        ref.Ref(st_r).physics("lmd_vmix", s)
+        oracle.Oracle(st_o).call("lmd_vmix", s)
+        names = ["Akv", "Akt", "ghats", "hsbl"]
+        diffs = {n: util.max_rel_diff(st_o[n], st_r[n]) for n in names}
+        hs, zw = st_r.interior("hsbl"), st_r.interior("z_w")
+        wet = st_r.interior("rmask") > 0.0
+        out["lmd_vmix_stratified"] = {
+            "max_rel_diff": max(diffs.values()), "diffs": diffs,
+            "changed": [n for n in names if not np.array_equal(st_r[n], st0[n])],
+            "amax": {n: float(np.abs(st_r[n]).max()) for n in names},
+            "frac_in_top_layer": float((hs[wet] > zw[:, :, -2][wet]).mean()),
+            "frac_below_level_Nm3": float((hs[wet] < zw[:, :, -4][wet]).mean()),
+            "land_zero": bool(not st_r["hsbl"][st0["rmask"] == 0.0].any()) if mask else None}
     print(json.dumps(out))
 
 

@@ -274,6 +274,52 @@ def test_hip_reproduces_reference_prsgrd31(config):
     _pgf_check(config, run)
 
 
+def _kpp_check(mask, backend, tol):
+    import sys
+    import util
+    gd = os.path.join(HERE, "golden")
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    import make_golden_kpp as mk
+    g = np.load(os.path.join(gd, f"ref_kpp_{mk.tag(mask)}.npz"))
+    st = util.kpp_state("BENCHMARK_TINY", mask=mask)
+    backend(st, util.step_idx())
+    for k, v in mk.results(st).items():
+        want = g[k]
+        if k.endswith("_sha256"):
+            if tol == 0.0:
+                assert str(v) == str(want), k
+        else:
+            scale = max(float(np.abs(want).max()), 1e-300)
+            assert float(np.abs(v - want).max()) <= tol * scale, (k, float(np.abs(v - want).max()) / scale)
+    hs = st.interior("hsbl")
+    assert float(hs.max()) > -1.0 and float(hs.min()) < -100.0          # shallow and deep boundary layers
+
+
+@pytest.mark.parametrize("mask", [None, "island"])
+def test_oracle_reproduces_reference_kpp_on_stratified_state(mask):
+    """lmd_vmix of the reference on util.kpp_state (tests/golden/make_golden_kpp.py), with and without MASKING, vs
+    the oracle: bit for bit on this host (same libm)."""
+    import oracle
+    _kpp_check(mask, lambda st, s: oracle.Oracle(st).call("lmd_vmix", s), 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mask", [None, "island"])
+def test_hip_reproduces_reference_kpp_on_stratified_state(mask):
+    """k_lmd_vmix against the reference's vectors directly (device pow / exp: 1e-10 of each field's maximum)."""
+    from roms_trunk_mgh_amd import hip
+
+    def run(st, s):
+        h = hip.RomsHip(st)
+        try:
+            h.call("lmd_vmix", s)
+            h.to_host()
+        finally:
+            h.close()
+    _kpp_check(mask, run, 1e-10)
+
+
 def test_oracle_reproduces_reference_mpdata_adiff():
     """mpdata_adiff_tile: the committed outputs of the reference's Fortran (three levels stored,
     all elements through a SHA-256) vs the C oracle on the same deterministic inputs."""

@@ -202,9 +202,12 @@ def test_hip_physics_on_masked_grid(kernel):
     functions of the device differ from the host's in the last bits, hence the tolerances of the unmasked tests."""
     import oracle
     from roms_trunk_mgh_amd import hip
-    st0 = util.prepared_state("BENCHMARK_TINY", mask="island")
-    st0["Vwind"] += 0.3 * st0["Uwind"] - 2.0
-    st0["rain"] += 2.0e-5
+    if kernel == "lmd_vmix":            # stratified, shallow and deep boundary layers (util.kpp_state)
+        st0 = util.kpp_state("BENCHMARK_TINY", mask="island")
+    else:
+        st0 = util.prepared_state("BENCHMARK_TINY", mask="island")
+        st0["Vwind"] += 0.3 * st0["Uwind"] - 2.0
+        st0["rain"] += 2.0e-5
     st_o, st_h = st0.copy(), st0.copy()
     s = util.step_idx()
     oracle.Oracle(st_o).call(kernel, s)

@@ -87,6 +87,37 @@ def prepared_state(config, seed=1, NT=None, overrides=None, oracle_backend=None,
     return st
 
 
+def kpp_state(config="BENCHMARK_TINY", mask=None):
+    """prepared_state made into a meaningful input of KPP (lmd_vmix): density, buoyancy frequency, expansion
+    coefficients from the (pinned) oracle rho_eos instead of the zeros prepared_state leaves; surface forcing that
+    gives shallow boundary layers (ending inside the top layer: ksbl = N) in the western half of the domain and deep
+    ones in the eastern half; surface / bottom diffusivities of salinity different from the temperature's (the routine
+    leaves levels 0 and N alone and reads level N when ksbl = N)."""
+    import oracle
+    st = prepared_state(config, mask=mask)
+    oracle.Oracle(st).call("rho_eos", step_idx())
+    b = st.b
+    st["stflux"][:, :, 0] += 1.0e-6
+    if b.NT > 1:
+        st["stflux"][:, :, 1] = 2.0e-8
+        st["btflx"][:, :, 1] = 1.0e-9
+        st["stflx"][:, :, 1] = 1.0e-7
+    west = (np.arange(b.LBi, b.UBi + 1) <= b.Lm // 2)[:, None]
+    st["stflx"][:, :, 0] = np.where(west, 2.0e-4, -3.0e-5 + st["stflx"][:, :, 0])   # strong heating / cooling ...
+    st["srflx"][:] = np.where(west, 1.0e-4, st["srflx"])
+    for name in ("sustr", "svstr"):                                          # ... under a weak / a strong wind
+        st[name][:] = np.where(west, 0.03 * st[name], 6.0 * st[name])
+    st["Akt"][:, :, 0, 1] *= 1.9
+    st["Akt"][:, :, -1, 1] = 1.7 * st["Akt"][:, :, -1, 0] + 3.0e-5
+    if mask is not None:
+        for name in ("stflx", "btflx"):
+            st[name] *= st["rmask"][:, :, None]
+        st["srflx"] *= st["rmask"]
+        st["sustr"] *= st["umask"]
+        st["svstr"] *= st["vmask"]
+    return st
+
+
 def hz_weighted_tnew(st, nnew=2):
     """pre_step3d leaves t(nnew) multiplied by Hz; reproduce that for isolated
     step3d_t tests."""
