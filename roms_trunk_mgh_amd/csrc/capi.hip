@@ -315,7 +315,7 @@ extern "C" int roms_hip_register_field(int id, double *host_ptr, long n_doubles)
     return roms_fail("roms_hip_register_field", msg);
   }
   step2d_graphs_release();
-  roms_rowm_invalidate();
+  if (roms_rowm_is_table_field(id)) roms_rowm_invalidate();
   snapshot_forget(id);          // staging / page-lock of a previous registration (other size or host array)
   guarded_free(&g_ctx.dev[id], &g_ctx.dev_base[id]);
   {
@@ -335,7 +335,7 @@ extern "C" int roms_hip_sync_to_device(int id)
   if (id < 0 || id >= FID_COUNT || !g_ctx.dev[id]) return roms_fail("roms_hip_sync_to_device", "field not registered");
   HIP_TRY(hipMemcpyAsync(g_ctx.dev[id], g_ctx.host[id], sizeof(double) * g_ctx.count[id], hipMemcpyHostToDevice, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-  if (k_field_kind[id] == K_2D) roms_rowm_invalidate();          // a metric array may have changed
+  if (roms_rowm_is_table_field(id)) roms_rowm_invalidate();      // a grid-metric array may have changed
   return 0;
 }
 

@@ -539,6 +539,16 @@ __global__ void k_rowm_build(const RomsDev *__restrict__ c, double *__restrict__
 // 3 = as 1 and h, visc2_r, visc2_p are independent of i too
 extern "C" int roms_hip_row_metrics_state(void) { return g_ctx.rowm_state == 1 && g_ctx.rowh ? 3 : g_ctx.rowm_state; }
 
+bool roms_rowm_is_table_field(int id)
+{
+  static const int ids[RM_COUNT] = {FID_pm, FID_pn, FID_on_u, FID_om_v, FID_fomn, FID_dndx, FID_dmde, FID_pmon_r,
+                                    FID_pnom_r, FID_pmon_p, FID_pnom_p, FID_om_r, FID_on_r, FID_om_p, FID_on_p,
+                                    FID_h, FID_visc2_r, FID_visc2_p};
+  for (int q = 0; q < RM_COUNT; q++)
+    if (ids[q] == id) return true;
+  return false;
+}
+
 void roms_rowm_invalidate()
 {
   if (g_ctx.rowm_state) step2d_graphs_release();     // the captured launches chose their kernel by the old state

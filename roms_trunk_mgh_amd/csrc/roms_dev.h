@@ -235,5 +235,6 @@ void diag_release();                      // k_diag.hip: frees the buffers of ro
 int check_lbc();
 int roms_rowm_prepare();               // k_step2d_mom.hip: examine the metric arrays if needed (synchronises once)
 void roms_rowm_invalidate();            // a metric array may have changed
+bool roms_rowm_is_table_field(int id);  // is field `id` one of the arrays the row table is built from?
 void roms_rowm_release();
 void step2d_graphs_release();           // k_step2d.hip: drop the captured LOOP_2D graphs (their launch arguments are stale)

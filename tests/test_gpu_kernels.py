@@ -144,7 +144,21 @@ def _idx2d(iif, pred, iic, first=False):
 @pytest.mark.parametrize("config", CONFIGS)
 @pytest.mark.parametrize("iif,pred,iic", [(1, 1, 1), (1, 1, 2), (1, 1, 7), (1, 0, 7), (5, 1, 7), (5, 0, 7)])
 def test_step2d(config, iif, pred, iic):
-    st_h, st_o, st0 = _run_pair(config, "step2d", _idx2d(iif, pred, iic))
+    def prep(st):
+        # prepared_state leaves the AM3 history terms and the 3-D forcing of the barotropic mode at zero: give the
+        # corrector's 8/12 and 1/12 weights (step2d_LF_AM3.h:823-836, :2150-2255) and the coupling (:1884-2065)
+        # something to act on
+        b = st.b
+        ii = np.arange(b.LBi, b.UBi + 1, dtype=np.float64)[:, None]
+        jj = np.arange(b.LBj, b.UBj + 1, dtype=np.float64)[None, :]
+        w = np.sin(2.0 * np.pi * 3 * ii / b.Lm + 0.4) * np.cos(np.pi * 2 * jj / b.Mm)
+        for lev in range(2):
+            st["rzeta"][:, :, lev] = (1.0 + 0.3 * lev) * 1.0e-2 * w
+            st["rubar"][:, :, lev] = (1.0 - 0.2 * lev) * 3.0e-1 * w
+            st["rvbar"][:, :, lev] = (1.0 + 0.1 * lev) * 2.0e-1 * np.roll(w, 5, axis=0)
+        st["rufrc"][:] = 4.0e-1 * np.roll(w, 3, axis=0)
+        st["rvfrc"][:] = 2.5e-1 * np.roll(w, 9, axis=0)
+    st_h, st_o, st0 = _run_pair(config, "step2d", _idx2d(iif, pred, iic), prep=prep)
     diffs = util.compare_states(st_h, st_o)
     assert all(v <= TOL for v in diffs.values()), diffs
     assert util.max_rel_diff(st_o["ubar"], st0["ubar"]) > 1e-9
