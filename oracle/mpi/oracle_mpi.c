@@ -108,6 +108,7 @@ void oracle_mpi_exchange(double *A, int nk, int gtype)
   (void)gtype;
   const int nj = B.UBj - B.LBj + 1, ni = B.UBi - B.LBi + 1;
   MPI_Request req[4];
+  MPI_Status stat[4];
   int nreq;
   /* ---- phase 1: western and eastern edges, every row of the array (mp_exchange.F:395-560) ---- */
   if (Wtile >= 0 || Etile >= 0) {
@@ -123,7 +124,7 @@ void oracle_mpi_exchange(double *A, int nk, int gtype)
       pack(A, nk, B.Iend - GsendE + 1, GsendE, B.LBj, nj, g_buf[3], 0);
       MPI_Isend(g_buf[3], nk * nj * GsendE, MPI_DOUBLE, Etile, 2, MPI_COMM_WORLD, &req[nreq++]);
     }
-    MPI_Waitall(nreq, req, MPI_STATUSES_IGNORE);
+    MPI_Waitall(nreq, req, stat);        /* (MPI_STATUSES_IGNORE trips gcc's -Wstringop-overflow with this mpi.h) */
     if (Wtile >= 0) pack(A, nk, B.Istr - GrecvW, GrecvW, B.LBj, nj, g_buf[0], 1);
     if (Etile >= 0) pack(A, nk, B.Iend + 1, GrecvE, B.LBj, nj, g_buf[1], 1);
   }
@@ -141,7 +142,7 @@ void oracle_mpi_exchange(double *A, int nk, int gtype)
       pack(A, nk, B.LBi, ni, B.Jend - GsendN + 1, GsendN, g_buf[3], 0);
       MPI_Isend(g_buf[3], nk * ni * GsendN, MPI_DOUBLE, Ntile, 4, MPI_COMM_WORLD, &req[nreq++]);
     }
-    MPI_Waitall(nreq, req, MPI_STATUSES_IGNORE);
+    MPI_Waitall(nreq, req, stat);        /* (MPI_STATUSES_IGNORE trips gcc's -Wstringop-overflow with this mpi.h) */
     if (Stile >= 0) pack(A, nk, B.LBi, ni, B.Jstr - GrecvS, GrecvS, g_buf[0], 1);
     if (Ntile >= 0) pack(A, nk, B.LBi, ni, B.Jend + 1, GrecvN, g_buf[1], 1);
   }
