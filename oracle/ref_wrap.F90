@@ -819,13 +819,13 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   TYPE(stepidx_t), INTENT(in) :: s
   TYPE(fields_t), INTENT(in) :: F
   INTEGER(c_int) :: rc
-  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT, sd, v, code, side(2), ivar, i, k, it
-  INTEGER :: IminS, ImaxS, JminS, JmaxS, Jstr, Jend
+  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT, sd, v, code, side(4), ivar, i, k, it
+  INTEGER :: IminS, ImaxS, JminS, JmaxS, Jstr, Jend, Istr, Iend
   REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:), a5(:,:,:,:,:)
   ng = 1; tile = 0
   LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
   ni = UBi-LBi+1; nj = UBj-LBj+1; NN = b%N; NTT = b%NT
-  Jstr = b%Jstr; Jend = b%Jend
+  Jstr = b%Jstr; Jend = b%Jend; Istr = b%Istr; Iend = b%Iend
   IminS = b%Istr-3; ImaxS = b%Iend+3; JminS = b%Jstr-3; JmaxS = b%Jend+3
   rc = 0
   IF (.NOT. have_boundary) THEN
@@ -845,25 +845,22 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   dt(ng) = p%dt; dtfast(ng) = p%dtfast
   g = p%g; rho0 = p%rho0; gamma2(ng) = p%gamma2
   PerfectRST(ng) = .FALSE.
-  ! western / eastern edges: periodic (the only case of this path); every other switch off
-  DO v = 1, 5 + NTT
-    LBC(iwest, v, ng)%periodic = .TRUE.;  LBC(ieast, v, ng)%periodic = .TRUE.
-    LBC(iwest, v, ng)%radiation = .FALSE.; LBC(ieast, v, ng)%radiation = .FALSE.
-    LBC(iwest, v, ng)%Flather = .FALSE.;   LBC(ieast, v, ng)%Flather = .FALSE.
-    LBC(iwest, v, ng)%Chapman_implicit = .FALSE.; LBC(ieast, v, ng)%Chapman_implicit = .FALSE.
-    LBC(iwest, v, ng)%Chapman_explicit = .FALSE.; LBC(ieast, v, ng)%Chapman_explicit = .FALSE.
-  END DO
-  side(1) = isouth; side(2) = inorth
-  DO sd = 1, 2
+  ! LBC(side, variable): columns 1..4 of p%lbc = west, east, south, north (enum roms_lbc_side + 1); code 0 = the
+  ! side's lbc_west / lbc_east / lbc_south / lbc_north, whose value 0 means periodic
+  side(1) = iwest; side(2) = ieast; side(3) = isouth; side(4) = inorth
+  DO sd = 1, 4
     DO v = 1, 6
-      code = p%lbc(v, sd+2)
+      code = p%lbc(v, sd)
       IF (code == 0) THEN
-        IF (sd == 1) code = p%lbc_south
-        IF (sd == 2) code = p%lbc_north
+        IF (sd == 1) code = p%lbc_west
+        IF (sd == 2) code = p%lbc_east
+        IF (sd == 3) code = p%lbc_south
+        IF (sd == 4) code = p%lbc_north
       END IF
       DO it = 1, MERGE(NTT, 1, v == 6)
         ivar = v
         IF (v == 6) ivar = isTvar(it)
+        LBC(side(sd), ivar, ng)%periodic = code == 0
         LBC(side(sd), ivar, ng)%closed = code == 1
         LBC(side(sd), ivar, ng)%gradient = code == 2
         LBC(side(sd), ivar, ng)%clamped = code == 3
@@ -875,7 +872,6 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
         LBC(side(sd), ivar, ng)%nested = .FALSE.
         LBC(side(sd), ivar, ng)%reduced = .FALSE.
         LBC(side(sd), ivar, ng)%Shchepetkin = .FALSE.
-        LBC(side(sd), ivar, ng)%periodic = .FALSE.
         LBC(side(sd), ivar, ng)%acquire = .FALSE.
       END DO
     END DO
@@ -910,6 +906,12 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
     allocate ( BOUNDARY(ng)%u_south(LBi:UBi,NN), BOUNDARY(ng)%u_north(LBi:UBi,NN) )
     allocate ( BOUNDARY(ng)%v_south(LBi:UBi,NN), BOUNDARY(ng)%v_north(LBi:UBi,NN) )
     allocate ( BOUNDARY(ng)%t_south(LBi:UBi,NN,NTT), BOUNDARY(ng)%t_north(LBi:UBi,NN,NTT) )
+    allocate ( BOUNDARY(ng)%zeta_west(LBj:UBj), BOUNDARY(ng)%zeta_east(LBj:UBj) )
+    allocate ( BOUNDARY(ng)%ubar_west(LBj:UBj), BOUNDARY(ng)%ubar_east(LBj:UBj) )
+    allocate ( BOUNDARY(ng)%vbar_west(LBj:UBj), BOUNDARY(ng)%vbar_east(LBj:UBj) )
+    allocate ( BOUNDARY(ng)%u_west(LBj:UBj,NN), BOUNDARY(ng)%u_east(LBj:UBj,NN) )
+    allocate ( BOUNDARY(ng)%v_west(LBj:UBj,NN), BOUNDARY(ng)%v_east(LBj:UBj,NN) )
+    allocate ( BOUNDARY(ng)%t_west(LBj:UBj,NN,NTT), BOUNDARY(ng)%t_east(LBj:UBj,NN,NTT) )
   END IF
   CALL c_f_pointer (F%zeta_bry, a2, (/ni,nj/))
   BOUNDARY(ng)%zeta_south(LBi:UBi) = a2(:, Jstr-1-LBj+1); BOUNDARY(ng)%zeta_north(LBi:UBi) = a2(:, Jend+1-LBj+1)
@@ -924,6 +926,21 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   CALL c_f_pointer (F%t_bry, a4, (/ni,nj,NN,NTT/))
   BOUNDARY(ng)%t_south(LBi:UBi,1:NN,1:NTT) = a4(:, Jstr-1-LBj+1, :, :)
   BOUNDARY(ng)%t_north(LBi:UBi,1:NN,1:NTT) = a4(:, Jend+1-LBj+1, :, :)
+  ! western / eastern edge vectors: the boundary column of each field (rho- and v-type: Istr-1 / Iend+1, u-type:
+  ! Istr / Iend+1)
+  CALL c_f_pointer (F%zeta_bry, a2, (/ni,nj/))
+  BOUNDARY(ng)%zeta_west(LBj:UBj) = a2(Istr-1-LBi+1, :); BOUNDARY(ng)%zeta_east(LBj:UBj) = a2(Iend+1-LBi+1, :)
+  CALL c_f_pointer (F%ubar_bry, a2, (/ni,nj/))
+  BOUNDARY(ng)%ubar_west(LBj:UBj) = a2(Istr-LBi+1, :);   BOUNDARY(ng)%ubar_east(LBj:UBj) = a2(Iend+1-LBi+1, :)
+  CALL c_f_pointer (F%vbar_bry, a2, (/ni,nj/))
+  BOUNDARY(ng)%vbar_west(LBj:UBj) = a2(Istr-1-LBi+1, :); BOUNDARY(ng)%vbar_east(LBj:UBj) = a2(Iend+1-LBi+1, :)
+  CALL c_f_pointer (F%u_bry, a3, (/ni,nj,NN/))
+  BOUNDARY(ng)%u_west(LBj:UBj,1:NN) = a3(Istr-LBi+1, :, :);   BOUNDARY(ng)%u_east(LBj:UBj,1:NN) = a3(Iend+1-LBi+1, :, :)
+  CALL c_f_pointer (F%v_bry, a3, (/ni,nj,NN/))
+  BOUNDARY(ng)%v_west(LBj:UBj,1:NN) = a3(Istr-1-LBi+1, :, :); BOUNDARY(ng)%v_east(LBj:UBj,1:NN) = a3(Iend+1-LBi+1, :, :)
+  CALL c_f_pointer (F%t_bry, a4, (/ni,nj,NN,NTT/))
+  BOUNDARY(ng)%t_west(LBj:UBj,1:NN,1:NTT) = a4(Istr-1-LBi+1, :, :, :)
+  BOUNDARY(ng)%t_east(LBj:UBj,1:NN,1:NTT) = a4(Iend+1-LBi+1, :, :, :)
   ! ---- the reference procedure ----
   SELECT CASE (kind)
   CASE (1); CALL zetabc_tile (ng, tile, LBi, UBi, LBj, UBj, IminS, ImaxS, JminS, JmaxS, s%krhs, s%kstp, nout, OCEAN(ng)%zeta)

@@ -180,7 +180,9 @@ def make_params(cfg, NT):
     for it in range(NT):
         p.Hadv[it] = abi.ADV[cfg.get("Hadv_list", [cfg["Hadv"]] * NT)[it]]
         p.Vadv[it] = abi.ADV[cfg.get("Vadv_list", [cfg["Vadv"]] * NT)[it]]
-    p.lbc_west = p.lbc_east = abi.LBC_PERIODIC
+    # the shipped applications are zonal channels (LBC = Per Clo Per Clo); "EWperiodic": False closes the
+    # western / eastern edges as well (a basin), per-variable conditions then go into p.lbc
+    p.lbc_west = p.lbc_east = abi.LBC_PERIODIC if cfg.get("EWperiodic", True) else abi.LBC_CLOSED
     p.lbc_south = p.lbc_north = abi.LBC_CLOSED
     app = cfg["app"]
     p.R0, p.T0, p.S0 = 1027.0, {"BENCHMARK": 10.0, "UPWELLING": 14.0, "SEAMOUNT": 10.0}[app], \
@@ -375,7 +377,7 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
     adv = {cfg["Hadv"], cfg["Vadv"]} | set(cfg.get("Hadv_list", [])) | set(cfg.get("Vadv_list", []))
     nghost = 3 if adv & {"MPDATA", "HSIMT"} else 2          # inp_par.F:266-278
     b = make_bounds(cfg["Lm"], cfg["Mm"], cfg["N"], NT, NAT, ntileI, ntileJ, tile,
-                    EWperiodic=True, NSperiodic=False, NghostPoints=nghost)
+                    EWperiodic=bool(cfg.get("EWperiodic", True)), NSperiodic=False, NghostPoints=nghost)
     p = make_params(cfg, NT)
     st = TileState(b, p)
     st.cfg = cfg

@@ -95,6 +95,82 @@ def main_bc(config, mask=None):
     print(json.dumps(out))
 
 
+def basin_state(config, mask=None):
+    """prepared_state of `config` as a basin: no periodic direction, physical edges on all four sides (LBC of
+    the western / eastern edge = closed unless a case sets lbc), boundary data and boundary lines / corners that
+    satisfy none of the conditions already."""
+    import util
+    st0 = util.prepared_state(config, overrides={"EWperiodic": False}, mask=mask)
+    rng = np.random.default_rng(17)
+    for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
+        st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
+    st0["t_bry"][:] = st0["t"][:, :, :, 0, :] * (1.0 + 1.0e-3 * rng.standard_normal(st0["t_bry"].shape))
+    b = st0.b
+    for name in ("zeta", "ubar", "vbar", "u", "v", "t"):
+        a = st0[name]
+        for j in (b.Jstr - 1, b.Jstr, b.Jend + 1):
+            row = a[:, j - b.LBj]
+            row += 1.0e-3 * (1.0 + np.abs(row)) * rng.standard_normal(row.shape)
+        for i in (b.Istr - 1, b.Istr, b.Iend + 1):
+            col = a[i - b.LBi]
+            col += 1.0e-3 * (1.0 + np.abs(col)) * rng.standard_normal(col.shape)
+    return st0
+
+
+BC_TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad"]),
+            "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
+            "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad"])}
+
+
+def basin_cases(st0):
+    """(key, kind, variable, state, step indices, nout, itrc): every condition on all four edges at once (the
+    western / eastern edges then run the transposed code of each routine, and the four corners are set)."""
+    import util
+    from roms_trunk_mgh_amd import abi
+    steps = [util.step_idx(iic=5, iif=1, pred=1, kstp=1, krhs=1, knew=3), util.step_idx(iic=5, iif=3, pred=1, kstp=2, krhs=1, knew=3),
+             util.step_idx(iic=5, iif=3, pred=0, kstp=1, krhs=3, knew=2)]
+    for kind, (var, codes) in BC_TABLE.items():
+        for code in codes:
+            for q, s in enumerate(steps if kind in ("zetabc", "u2dbc", "v2dbc") else steps[:1]):
+                st = st0.copy()
+                st.p = type(st0.p).from_buffer_copy(st0.p)
+                for sd in ("west", "east", "south", "north"):
+                    st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+                nout = s.knew if kind in ("zetabc", "u2dbc", "v2dbc") else s.nnew
+                yield f"{kind}:{code}:{q}", kind, var, st, s, nout, st0.b.NT
+
+
+def main_bc4(config, mask=None):
+    """The six boundary-condition routines on a basin (four physical edges + corners): reference vs oracle."""
+    import oracle
+    import util
+    from oracle import ref
+    st0 = basin_state(config, mask)
+    out = {"masking": int(st0.p.masking), "EWperiodic": int(st0.b.EWperiodic), "cases": {}}
+    bb = ref.Ref(st0.copy()).bounds()
+    mine = st0.b.as_dict()
+    out["bounds_mismatch"] = {k: (v, mine[k]) for k, v in bb.items() if mine[k] != v}
+    for key, kind, var, st, s, nout, itrc in basin_cases(st0):
+        st_r, st_o = st.copy(), st
+        ref.Ref(st_r).bc(kind, s, nout, itrc)
+        oracle.Oracle(st_o).bc(kind, s, nout, itrc)
+        diffs = util.compare_states(st_o, st_r)
+        b = st0.b
+        a_r, a_0 = st_r[var], st0[var]
+        # all four edges and all four corners must have been written
+        iw = b.Istr if var in ("ubar", "u") else b.Istr - 1
+        js = b.Jstr if var in ("vbar", "v") else b.Jstr - 1
+        lines = {"west": (a_r[iw - b.LBi, 3 - b.LBj:6 - b.LBj], a_0[iw - b.LBi, 3 - b.LBj:6 - b.LBj]),
+                 "east": (a_r[b.Iend + 1 - b.LBi, 3 - b.LBj:6 - b.LBj], a_0[b.Iend + 1 - b.LBi, 3 - b.LBj:6 - b.LBj]),
+                 "south": (a_r[3 - b.LBi:6 - b.LBi, js - b.LBj], a_0[3 - b.LBi:6 - b.LBi, js - b.LBj]),
+                 "north": (a_r[3 - b.LBi:6 - b.LBi, b.Jend + 1 - b.LBj], a_0[3 - b.LBi:6 - b.LBi, b.Jend + 1 - b.LBj]),
+                 "corner_sw": (a_r[iw - b.LBi, js - b.LBj], a_0[iw - b.LBi, js - b.LBj]),
+                 "corner_ne": (a_r[b.Iend + 1 - b.LBi, b.Jend + 1 - b.LBj], a_0[b.Iend + 1 - b.LBi, b.Jend + 1 - b.LBj])}
+        out["cases"][key] = {"max_rel_diff": max(diffs.values()) if diffs else 0.0,
+                             "unchanged": [k for k, (x, y) in lines.items() if np.array_equal(x, y)]}
+    print(json.dumps(out))
+
+
 INI_TABLES = {"closed": None,
               "cha_fla_rad": {"zeta": "Cha", "ubar": "Fla", "vbar": "Fla", "u": "Rad", "v": "Rad", "t": "Rad"},
               "gradient": {v: "Gra" for v in ("zeta", "ubar", "vbar", "u", "v", "t")},
@@ -355,6 +431,8 @@ if __name__ == "__main__":
         main(sys.argv[1], pgf=1 if sys.argv[2] == "pg31" else 2)
     elif len(sys.argv) > 2 and sys.argv[2] in ("ini", "ini_mask"):
         main_ini(sys.argv[1], mask="island" if sys.argv[2] == "ini_mask" else None)
+    elif len(sys.argv) > 2 and sys.argv[2] in ("bc4", "bc4_mask"):
+        main_bc4(sys.argv[1], mask="island" if sys.argv[2] == "bc4_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] in ("bc", "bc_mask"):
         main_bc(sys.argv[1], mask="island" if sys.argv[2] == "bc_mask" else None)
     else:

@@ -320,6 +320,29 @@ def test_hip_reproduces_reference_kpp_on_stratified_state(mask):
     _kpp_check(mask, run, 1e-10)
 
 
+@pytest.mark.parametrize("config,mask", [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)])
+def test_oracle_reproduces_reference_boundary_conditions_on_a_basin(config, mask):
+    """The boundary lines (columns, rows, corners) the reference's six routines left on a grid without a periodic
+    direction, every condition on all four edges at once (tests/golden/make_golden_bc4.py) vs the oracle."""
+    import sys
+    import oracle
+    gd = os.path.join(HERE, "golden")
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    import make_golden_bc4 as mb
+    from ref_worker import basin_state, basin_cases
+    g = np.load(os.path.join(gd, f"ref_bc4_{mb.tag(config, mask)}.npz"))
+    n = 0
+    for key, kind, var, st, s, nout, itrc in basin_cases(basin_state(config, mask)):
+        oracle.Oracle(st).bc(kind, s, nout, itrc)
+        cols, rows, sha = mb.lines(st, var)
+        k = key.replace(":", "__")
+        assert np.array_equal(cols, g[k + "__cols"]) and np.array_equal(rows, g[k + "__rows"]), key
+        assert sha == str(g[k + "__sha256"]), key
+        n += 1
+    assert n == 57
+
+
 def test_oracle_reproduces_reference_mpdata_adiff():
     """mpdata_adiff_tile: the committed outputs of the reference's Fortran (three levels stored,
     all elements through a SHA-256) vs the C oracle on the same deterministic inputs."""
