@@ -180,6 +180,8 @@ void o_exchange2d(const roms_bounds_t *b, int gtype, double *A);
 void o_exchange3d(const roms_bounds_t *b, int gtype, int nk, double *A);
 int  o_check_lbc(const roms_bounds_t *b, const roms_params_t *p);
 int  o_lbc(const roms_params_t *p, int side, int var);
+void o_bc_generic(const roms_bounds_t *b, const roms_params_t *p, const roms_fields_t *F, int gtype, int lbv, double *A,
+                  int nk);        /* bc_2d.F / bc_3d.F */
 void o_zetabc(OARGS, int kout);
 void o_u2dbc(OARGS, int kout);
 void o_v2dbc(OARGS, int kout);

@@ -100,19 +100,29 @@ void o_exchange3d(const roms_bounds_t *b, int gtype, int nk, double *A)
   if (g_hook && b->ntileI * b->ntileJ > 1) g_hook(A, nk, gtype);
 }
 
-/* bc_w3d_tile (gradient walls + periodic wrap) -- ROMS/Nonlinear/bc_3d.F:588 */
+/* bc_w3d_tile (zero-gradient on every physical edge, corners, then the periodic wrap / tile exchange) --
+ * ROMS/Nonlinear/bc_3d.F:588-725 */
 void o_bc_w3d(const roms_bounds_t *b, double *A)
 {
   const int LBi = b->LBi, LBj = b->LBj, N = b->N;
   const long ni = b->UBi - b->LBi + 1, nij = ni * (b->UBj - b->LBj + 1);
 #define A3(i,j,k) A[(long)((i) - LBi) + (long)((j) - LBj) * ni + (long)(k) * nij]
-  if (!b->NSperiodic) {
-    if (b->north_edge)
-      for (int k = 0; k <= N; k++)
-        for (int i = b->Istr; i <= b->Iend; i++) A3(i, b->Jend + 1, k) = A3(i, b->Jend, k);
-    if (b->south_edge)
-      for (int k = 0; k <= N; k++)
-        for (int i = b->Istr; i <= b->Iend; i++) A3(i, b->Jstr - 1, k) = A3(i, b->Jstr, k);
+  for (int k = 0; k <= N; k++) {
+    if (!b->EWperiodic) {
+      if (b->east_edge) for (int j = b->Jstr; j <= b->Jend; j++) A3(b->Iend + 1, j, k) = A3(b->Iend, j, k);
+      if (b->west_edge) for (int j = b->Jstr; j <= b->Jend; j++) A3(b->Istr - 1, j, k) = A3(b->Istr, j, k);
+    }
+    if (!b->NSperiodic) {
+      if (b->north_edge) for (int i = b->Istr; i <= b->Iend; i++) A3(i, b->Jend + 1, k) = A3(i, b->Jend, k);
+      if (b->south_edge) for (int i = b->Istr; i <= b->Iend; i++) A3(i, b->Jstr - 1, k) = A3(i, b->Jstr, k);
+    }
+    if (!b->EWperiodic && !b->NSperiodic) {
+      const int iw = b->Istr - 1, ie = b->Iend + 1, js = b->Jstr - 1, jn = b->Jend + 1;
+      if (b->south_edge && b->west_edge) A3(iw, js, k) = 0.5 * (A3(iw + 1, js, k) + A3(iw, js + 1, k));
+      if (b->south_edge && b->east_edge) A3(ie, js, k) = 0.5 * (A3(ie - 1, js, k) + A3(ie, js + 1, k));
+      if (b->north_edge && b->west_edge) A3(iw, jn, k) = 0.5 * (A3(iw, jn - 1, k) + A3(iw + 1, jn, k));
+      if (b->north_edge && b->east_edge) A3(ie, jn, k) = 0.5 * (A3(ie, jn - 1, k) + A3(ie - 1, jn, k));
+    }
   }
 #undef A3
   o_exchange3d(b, GT_R, N + 1, A);

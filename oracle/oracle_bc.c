@@ -156,6 +156,37 @@ static void bc_corners(const roms_bounds_t *b, int gtype, double *X, int nk)
   }
 }
 
+/* bc_r2d_tile / bc_u2d_tile / bc_v2d_tile (bc_2d.F:45/184/386) and bc_r3d / bc_u3d / bc_v3d / bc_w3d_tile (bc_3d.F):
+ * the generic conditions the reference applies to derived fields (stresses, boundary-layer depth, omega, mixing
+ * coefficients ...) -- on an edge where variable `lbv` is closed: zero normal velocity, gamma2 * (inner value)
+ * for the tangential one (times the mask under MASKING), zero gradient for rho-type fields; on any other physical
+ * edge: zero gradient; then the corners.  No periodic wrap here (the caller exchanges). */
+void o_bc_generic(const roms_bounds_t *b, const roms_params_t *p, const roms_fields_t *F, int gtype, int lbv, double *A,
+                  int nk)
+{
+  const int LBi = b->LBi, LBj = b->LBj;
+  const long ni = b->UBi - b->LBi + 1, nij = ni * (b->UBj - b->LBj + 1);
+  const double *mask = gtype == GT_U ? F->umask : F->vmask;
+  for (int side = LBS_WEST; side <= LBS_NORTH; side++) {
+    const int closed = o_lbc(p, side, lbv) == LBC_CLOSED;
+    Edge e;
+    if (!edge_of(b, side, gtype, closed, &e)) continue;
+    const int normal = (gtype == GT_U && e.we) || (gtype == GT_V && !e.we);
+    for (int k = 0; k < nk; k++) {
+      double *Ak = A + (long)k * nij;
+      for (int a = e.a0; a <= e.a1; a++) {
+        const long B = I2(e.we ? e.bi : a, e.we ? a : e.bj), P1 = B + e.sn;
+        if (closed && normal) Ak[B] = 0.0;
+        else if (closed && gtype != GT_R) {
+          Ak[B] = p->gamma2 * Ak[P1];
+          if (p->masking) Ak[B] = Ak[B] * mask[B];
+        } else Ak[B] = Ak[P1];
+      }
+    }
+  }
+  bc_corners(b, gtype, A, nk);
+}
+
 /* order of the edges as in the reference: west, east, south, north, then the corners */
 static const int SIDES[4] = {LBS_WEST, LBS_EAST, LBS_SOUTH, LBS_NORTH};
 

@@ -11,27 +11,6 @@
  */
 #include "oracle.h"
 
-/* generic closed-wall conditions of bc_2d.F (bc_u2d_tile :205, bc_v2d_tile :400) for a 2-D array */
-static void o_bc_u2d_generic(const roms_bounds_t *b, const roms_params_t *p, double *A)
-{
-  const int LBi = b->LBi, LBj = b->LBj;
-  const long ni = b->UBi - b->LBi + 1;
-  const int Imin = b->EWperiodic ? b->IstrU : b->Istr, Imax = b->EWperiodic ? b->Iend : b->IendR;
-  if (!b->NSperiodic) {
-    if (b->north_edge) for (int i = Imin; i <= Imax; i++) A[I2(i, b->Jend + 1)] = p->gamma2 * A[I2(i, b->Jend)];
-    if (b->south_edge) for (int i = Imin; i <= Imax; i++) A[I2(i, b->Jstr - 1)] = p->gamma2 * A[I2(i, b->Jstr)];
-  }
-}
-static void o_bc_v2d_generic(const roms_bounds_t *b, double *A)
-{
-  const int LBi = b->LBi, LBj = b->LBj;
-  const long ni = b->UBi - b->LBi + 1;
-  if (!b->NSperiodic) {
-    if (b->north_edge) for (int i = b->Istr; i <= b->Iend; i++) A[I2(i, b->Jend + 1)] = 0.0;
-    if (b->south_edge) for (int i = b->Istr; i <= b->Iend; i++) A[I2(i, b->Jstr)] = 0.0;
-  }
-}
-
 int oracle_set_vbc(OARGS)
 {
   ORACLE_PROLOGUE
@@ -74,8 +53,9 @@ int oracle_set_vbc(OARGS)
         F->bvstr[I2(i, j)] = 0.5 * (rdrag(i, j - 1) + rdrag(i, j)) * v(i, j, 1, nrhs);
   } else return 8;
   /* boundary conditions + periodic / tile exchange, :472-500 */
-  o_bc_u2d_generic(b, p, F->bustr);
-  o_bc_v2d_generic(b, F->bvstr);
+  /* bc_u2d_tile / bc_v2d_tile with isBu2d = isUbar, isBv2d = isVbar (bc_2d.F:184, :386; mod_ncparam.F:1229) */
+  o_bc_generic(b, p, F, GT_U, LBV_UBAR, F->bustr, 1);
+  o_bc_generic(b, p, F, GT_V, LBV_VBAR, F->bvstr, 1);
   o_exchange2d(b, GT_U, F->bustr);
   o_exchange2d(b, GT_V, F->bvstr);
   return 0;
@@ -495,8 +475,7 @@ int oracle_lmd_vmix(OARGS)
         if (mk) hsbl(i, j) = hsbl(i, j) * rmask(i, j);                         /* :595 */
       }
     /* bc_r2d_tile (closed walls: zero gradient) + periodic / tile exchange, :640-652 */
-    if (south_edge) for (int i = Istr; i <= Iend; i++) hsbl(i, Jstr - 1) = hsbl(i, Jstr);
-    if (north_edge) for (int i = Istr; i <= Iend; i++) hsbl(i, Jend + 1) = hsbl(i, Jend);
+    o_bc_generic(b, p, F, GT_R, LBV_ZETA, F->hsbl, 1);
     o_exchange2d(b, GT_R, F->hsbl);
     for (int j = Jstr; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {

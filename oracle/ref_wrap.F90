@@ -404,10 +404,15 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   LBC(inorth, isBr2d, ng)%closed = p%lbc_north == 1
   LBC(isouth, isBw3d, ng)%closed = p%lbc_south == 1
   LBC(inorth, isBw3d, ng)%closed = p%lbc_north == 1
+  LBC(iwest, isBw3d, ng)%closed = p%lbc_west == 1;  LBC(ieast, isBw3d, ng)%closed = p%lbc_east == 1
   LBC(isouth, isBu2d, ng)%closed = p%lbc_south == 1
   LBC(inorth, isBu2d, ng)%closed = p%lbc_north == 1
   LBC(isouth, isBv2d, ng)%closed = p%lbc_south == 1
   LBC(inorth, isBv2d, ng)%closed = p%lbc_north == 1
+  LBC(iwest, isBr2d, ng)%closed = p%lbc_west == 1;  LBC(ieast, isBr2d, ng)%closed = p%lbc_east == 1
+  LBC(iwest, isBw3d, ng)%closed = p%lbc_west == 1;  LBC(ieast, isBw3d, ng)%closed = p%lbc_east == 1
+  LBC(iwest, isBu2d, ng)%closed = p%lbc_west == 1;  LBC(ieast, isBu2d, ng)%closed = p%lbc_east == 1
+  LBC(iwest, isBv2d, ng)%closed = p%lbc_west == 1;  LBC(ieast, isBv2d, ng)%closed = p%lbc_east == 1
   CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
   CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
   CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); GRID(ng)%z_w = a3
@@ -528,6 +533,7 @@ FUNCTION ref_diagnostics (kernel, b, p, s, F) BIND(C, name='ref_diagnostics') RE
   isBw3d = 6
   LBC(isouth, isBw3d, ng)%closed = p%lbc_south == 1
   LBC(inorth, isBw3d, ng)%closed = p%lbc_north == 1
+  LBC(iwest, isBw3d, ng)%closed = p%lbc_west == 1;  LBC(ieast, isBw3d, ng)%closed = p%lbc_east == 1
   CALL c_f_pointer (F%h, a2, (/ni,nj/));        GRID(ng)%h = a2
   CALL c_f_pointer (F%pm, a2, (/ni,nj/));       GRID(ng)%pm = a2
   CALL c_f_pointer (F%pn, a2, (/ni,nj/));       GRID(ng)%pn = a2
@@ -765,6 +771,7 @@ FUNCTION ref_mpdata_adiff (b, p, F, oHz, t3, Ta, Ua, Va, Wa) BIND(C, name='ref_m
   LBC(ieast , isBu3d, ng)%closed = p%lbc_east  == 1
   LBC(isouth, isBv3d, ng)%closed = p%lbc_south == 1
   LBC(inorth, isBv3d, ng)%closed = p%lbc_north == 1
+  LBC(iwest, isBv3d, ng)%closed = p%lbc_west == 1;  LBC(ieast, isBv3d, ng)%closed = p%lbc_east == 1
   CALL c_f_pointer (F%pm, a2, (/ni,nj/));       GRID(ng)%pm = a2
   CALL c_f_pointer (F%pn, a2, (/ni,nj/));       GRID(ng)%pn = a2
   CALL c_f_pointer (F%omn, a2, (/ni,nj/));      GRID(ng)%omn = a2

@@ -25,6 +25,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
         kw = dict(overrides={"Hadv": "HSIMT", "Vadv": "HSIMT"})
     if variant == "mask":
         kw = dict(mask="island")
+    if variant == "basin":               # no periodic direction
+        kw = dict(overrides={"EWperiodic": False})
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb, **kw)
     b = st.b
     ni, nj = st.ni, st.nj

@@ -12,14 +12,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main(config, mask=None, pgf=0):
+def main(config, mask=None, pgf=0, basin=False):
     import oracle
     import util
     from oracle import ref
     ov = {"tnu2": 300.0, "visc2": 800.0} if config != "SEAMOUNT" else {"tnu2": 300.0}
+    if basin:                                # no periodic direction: western / eastern edges closed as well
+        ov["EWperiodic"] = False
     st0 = util.prepared_state(config, overrides=ov, mask=mask)
     st0.p.pgf = pgf                      # 1, 2: the reference built with prsgrd31.h (plain / WJ_GRADP)
-    out = {"pgf": int(st0.p.pgf)}
+    out = {"pgf": int(st0.p.pgf), "EWperiodic": int(st0.b.EWperiodic)}
     r = ref.Ref(st0.copy())
     bb = r.bounds()
     mine = st0.b.as_dict()
@@ -248,16 +250,16 @@ def main_mpdata(config):
     print(json.dumps(out))
 
 
-def main_physics(config, mask=None):
+def main_physics(config, mask=None, basin=False):
     """set_vbc (all applications) and bulk_flux (BENCHMARK: the BULK_FLUXES application): reference
     Fortran vs C oracle.  set_vbc has only +,*,sqrt: bit for bit; bulk_flux calls log/exp/pow/atan
     from two different math libraries: relative difference reported.  mask = "island": the MASKING builds."""
     import oracle
     import util
     from oracle import ref
-    st0 = util.prepared_state(config, mask=mask)
+    st0 = util.prepared_state(config, mask=mask, overrides={"EWperiodic": False} if basin else None)
     s = util.step_idx()
-    out = {"masking": int(st0.p.masking)}
+    out = {"masking": int(st0.p.masking), "EWperiodic": int(st0.b.EWperiodic)}
     kernels = ["set_vbc"] + (["bulk_flux", "lmd_vmix"] if config.startswith("BENCHMARK") else [])
     for k in kernels:
         st_r, st_o = st0.copy(), st0.copy()
@@ -281,7 +283,7 @@ def main_physics(config, mask=None):
             land = st0["rmask"] == 0.0
             out[k]["land_zero"] = bool(all(not st_r[n][land].any() for n in names
                                            if n in ("lrflx", "lhflx", "shflx", "hsbl")))
-    if config.startswith("BENCHMARK"):
+    if config.startswith("BENCHMARK") and not basin:
         # KPP on a stratified state (prepared_state leaves pden, bvf, alpha, beta zero): util.kpp_state
         st0 = util.kpp_state(config, mask=mask)
         st_r, st_o = st0.copy(), st0.copy()
@@ -421,8 +423,11 @@ if __name__ == "__main__":
         main_ana(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "diag":
         main_diag(sys.argv[1])
-    elif len(sys.argv) > 2 and sys.argv[2] in ("physics", "physics_mask"):
-        main_physics(sys.argv[1], mask="island" if sys.argv[2] == "physics_mask" else None)
+    elif len(sys.argv) > 2 and sys.argv[2] in ("physics", "physics_mask", "physics_basin"):
+        main_physics(sys.argv[1], mask="island" if sys.argv[2] == "physics_mask" else None,
+                     basin=sys.argv[2] == "physics_basin")
+    elif len(sys.argv) > 2 and sys.argv[2] == "basin":
+        main(sys.argv[1], basin=True)
     elif len(sys.argv) > 2 and sys.argv[2] == "mpdata":
         main_mpdata(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mask":

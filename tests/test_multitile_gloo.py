@@ -29,6 +29,8 @@ def _single(config, nsteps, variant=""):
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
     if variant == "hsimt":
         kw = dict(overrides={"Hadv": "HSIMT", "Vadv": "HSIMT"})
+    if variant == "basin":
+        kw = dict(overrides={"EWperiodic": False})
     st = ana.make_tile(config, perturb=1.0, **kw)
     m = main3d.Main3D(oracle.Oracle(st))
     m.initial()
@@ -41,7 +43,9 @@ def _single(config, nsteps, variant=""):
                                                     # MPDATA on 6 tracers: three ghost points, extended flux ranges
                                                     (2, 2, "BENCHMARK_TINY", "mpdata"),
                                                     # HSIMT: three ghost points, limiter reaching two faces upwind
-                                                    (2, 2, "BENCHMARK_TINY", "hsimt")])
+                                                    (2, 2, "BENCHMARK_TINY", "hsimt"),
+                                                    # a basin: physical edges on all four sides, corners
+                                                    (2, 2, "UPWELLING", "basin"), (2, 1, "BENCHMARK_TINY", "basin")])
 def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     nsteps = 3
     world = ntI * ntJ

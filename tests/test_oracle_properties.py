@@ -30,23 +30,28 @@ def _run(config, nsteps, prep=None, perturb=1.0, overrides=None, NT=None):
     return st, m
 
 
-@pytest.mark.parametrize("config", ["UPWELLING", "BENCHMARK_TINY"])
-def test_constancy_preservation(config):
+BASIN = {"EWperiodic": False}         # no periodic direction: western / eastern walls as well
+
+
+@pytest.mark.parametrize("config,ov", [("UPWELLING", None), ("BENCHMARK_TINY", None), ("UPWELLING", BASIN),
+                                       ("BENCHMARK_TINY", BASIN)])
+def test_constancy_preservation(config, ov):
     def prep(st):
         st["t"][:, :, :, :, 1] = 35.0          # salinity uniform
         st["stflx"][:, :, 1] = 0.0
         st["btflx"][:, :, 1] = 0.0
         st["ghats"][:, :, :, 1] = 0.0
-    st, m = _run(config, 25, prep)
+    st, m = _run(config, 25, prep, overrides=ov)
     S = st.interior("t")[:, :, :, m.s.nnew - 1, 1]
     assert float(np.abs(st["u"]).max()) > 1e-3      # the flow is not trivial
     assert float(np.abs(S - 35.0).max()) < 5e-11, float(np.abs(S - 35.0).max())
 
 
-@pytest.mark.parametrize("config", ["UPWELLING", "BENCHMARK_TINY"])
-def test_volume_and_tracer_conservation(config):
+@pytest.mark.parametrize("config,ov", [("UPWELLING", None), ("BENCHMARK_TINY", None), ("UPWELLING", BASIN),
+                                       ("BENCHMARK_TINY", BASIN)])
+def test_volume_and_tracer_conservation(config, ov):
     import oracle
-    st = ana.make_tile(config, perturb=1.0)
+    st = ana.make_tile(config, perturb=1.0, overrides=ov)
     st["stflx"][:] = 0.0
     st["srflx"][:] = 0.0
     st["ghats"][:] = 0.0
