@@ -169,8 +169,14 @@ int oracle_step3d_uv(OARGS)
       ubar(i, j, 2) = ubar(i, j, 1);
     }
     if (!EWperiodic) {
-      if (west_edge) for (int k = 1; k <= N; k++) u(Istr, j, k, nnew) = u(Istr, j, k, nnew) - CF(Istr, 0);
-      if (east_edge) for (int k = 1; k <= N; k++) u(Iend + 1, j, k, nnew) = u(Iend + 1, j, k, nnew) - CF(Iend + 1, 0);
+      if (west_edge) for (int k = 1; k <= N; k++) {
+        u(Istr, j, k, nnew) = u(Istr, j, k, nnew) - CF(Istr, 0);
+        if (p->masking) u(Istr, j, k, nnew) = u(Istr, j, k, nnew) * umask(Istr, j);               /* :1081-1084 */
+      }
+      if (east_edge) for (int k = 1; k <= N; k++) {
+        u(Iend + 1, j, k, nnew) = u(Iend + 1, j, k, nnew) - CF(Iend + 1, 0);
+        if (p->masking) u(Iend + 1, j, k, nnew) = u(Iend + 1, j, k, nnew) * umask(Iend + 1, j);   /* :1108-1111 */
+      }
     }
     if (!NSperiodic) {
       if (j == 0)
@@ -211,8 +217,14 @@ int oracle_step3d_uv(OARGS)
         vbar(i, j, 2) = vbar(i, j, 1);
       }
       if (!EWperiodic) {
-        if (west_edge) for (int k = 1; k <= N; k++) v(Istr - 1, j, k, nnew) = v(Istr - 1, j, k, nnew) - CF(Istr - 1, 0);
-        if (east_edge) for (int k = 1; k <= N; k++) v(Iend + 1, j, k, nnew) = v(Iend + 1, j, k, nnew) - CF(Iend + 1, 0);
+        if (west_edge) for (int k = 1; k <= N; k++) {
+          v(Istr - 1, j, k, nnew) = v(Istr - 1, j, k, nnew) - CF(Istr - 1, 0);
+          if (p->masking) v(Istr - 1, j, k, nnew) = v(Istr - 1, j, k, nnew) * vmask(Istr - 1, j);   /* :1297-1301 */
+        }
+        if (east_edge) for (int k = 1; k <= N; k++) {
+          v(Iend + 1, j, k, nnew) = v(Iend + 1, j, k, nnew) - CF(Iend + 1, 0);
+          if (p->masking) v(Iend + 1, j, k, nnew) = v(Iend + 1, j, k, nnew) * vmask(Iend + 1, j);
+        }
       }
       if (!NSperiodic) {
         if (j == 1)

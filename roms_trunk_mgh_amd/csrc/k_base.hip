@@ -15,30 +15,38 @@ int lbc_code(const roms_params_t &p, int sd, int v)
   return sd == LBS_WEST ? p.lbc_west : sd == LBS_EAST ? p.lbc_east : sd == LBS_SOUTH ? p.lbc_south : p.lbc_north;
 }
 
-// West/east periodic; south/north per variable: closed, gradient, clamped, Chapman implicit (zeta), Flather
-// (vbar), radiation (u, v, tracers).
+// Which conditions are implemented, per variable: closed, gradient, clamped, radiation (all six), Chapman implicit
+// (zeta), Flather (ubar, vbar: the normal component; the tangential one gets the reference's Chapman-type rule).
+// A periodic direction is periodic on both sides; a physical edge takes one of the conditions above.
 int check_lbc()
 {
   const roms_bounds_t &b = g_ctx.b;
   const roms_params_t &p = g_ctx.p;
-  if (!b.EWperiodic || b.NSperiodic)
-    return roms_fail("check_lbc", "only E-W periodic grids with physical S/N edges are implemented on this path");
-  for (int sd = LBS_SOUTH; sd <= LBS_NORTH; sd++)
+  if (b.NSperiodic)
+    return roms_fail("check_lbc", "N-S periodic grids are not implemented on this path");
+  for (int sd = LBS_WEST; sd <= LBS_NORTH; sd++) {
+    const bool periodic = (sd <= LBS_EAST) ? b.EWperiodic != 0 : b.NSperiodic != 0;
     for (int v = 0; v < LBV_COUNT; v++) {
       const int c = lbc_code(p, sd, v);
-      bool ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED;
-      ok = ok || c == LBC_RADIATION;
+      if (periodic) {
+        if (c != LBC_PERIODIC) return roms_fail("check_lbc", "a periodic direction needs LBC = Per on both of its sides");
+        continue;
+      }
+      bool ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED || c == LBC_RADIATION;
       if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT;
-      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER;   // ubar: Chapman-type rule of a Flather edge
+      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER;
       if (!ok) return roms_fail("check_lbc", "lateral boundary condition not implemented for this variable");
     }
+  }
   return 0;
 }
 
-// every 2-D variable closed on both S/N edges: step2d may apply the conditions inside its fused kernel
+// every 2-D variable closed on its physical S/N edges and the E-W direction periodic: step2d may apply the
+// conditions inside its fused kernel
 bool lbc2d_all_closed()
 {
   const roms_params_t &p = g_ctx.p;
+  if (!g_ctx.b.EWperiodic) return false;
   for (int sd = LBS_SOUTH; sd <= LBS_NORTH; sd++)
     for (int v = LBV_ZETA; v <= LBV_VBAR; v++)
       if (lbc_code(p, sd, v) != LBC_CLOSED) return false;
@@ -46,12 +54,15 @@ bool lbc2d_all_closed()
 }
 
 // ---------------------------------------------------------------------------
-// Lateral boundary conditions on the southern / northern edge, one launch per variable:
-//   zetabc.F:404-700, u2dbc_im.F:829-1140, v2dbc_im.F:134-830, u3dbc_im.F:379-700, v3dbc_im.F:95-380,
-//   t3dbc_im.F:362-630 -- closed, gradient, clamped, Chapman implicit, Flather, radiation (implicit upstream,
-//   no nudging, no RADIATION_2D); bc_w3d_tile (bc_3d.F:588) = gradient without mask.
-// X = the (i,j,k) array of the wanted time level `out`; Xold = the same variable at the level the condition
-// reads (know for the 2-D conditions, nstp for radiation); D = boundary data (clamped, Flather).
+// Lateral boundary conditions, one launch per variable: zetabc.F:48, u2dbc_im.F:51, v2dbc_im.F:52, u3dbc_im.F:50,
+// v3dbc_im.F:50, t3dbc_im.F:50 on all four edges + the corner rule (e.g. zetabc.F:699-731); bc_w3d_tile
+// (bc_3d.F:588) = gradient without mask.  The reference writes each edge out; its western / eastern blocks are the
+// transposes of the southern / northern ones (pm <-> pn, umask <-> vmask), so a thread works in "edge
+// coordinates": B = boundary point, P1 / P2 = first / second point inward along the normal, +-T = neighbours along
+// the edge.  closed, gradient, clamped, Chapman implicit, Flather, radiation (implicit upstream, no nudging, no
+// RADIATION_2D).
+// X = the (i,j,k) array of the wanted time level; Xold = the same variable at the level the condition reads (know
+// for the 2-D conditions, nstp for 3-D radiation); D = boundary data; Z, Zb = zeta(know), zeta_bry.
 // ---------------------------------------------------------------------------
 struct BcArgs {
   double *X;             // level written (kout / nout)
@@ -59,7 +70,7 @@ struct BcArgs {
   const double *D;       // boundary data of this variable (or nullptr)
   const double *Z, *Zb;  // Flather (ubar, vbar): zeta(know), zeta_bry
   int var;               // enum roms_lbc_var; -1 = bc_w3d (gradient, no mask)
-  int code_s, code_n;    // enum roms_lbc on the southern / northern edge
+  int code[4];           // enum roms_lbc on the western / eastern / southern / northern edge
   int nk, masked;
   double dt2d;
 };
@@ -68,90 +79,132 @@ __device__ __forceinline__ double bc_radiate(double xb_old, double x1_old, doubl
 {
   const double eps = 1.0E-20;
   double dXdt = x1_old - x1;
-  const double dXde = x1 - x2;
-  if ((dXdt * dXde) < 0.0) dXdt = 0.0;
-  const double dXdx = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
-  const double cff = fmax(dXdx * dXdx + dXde * dXde, eps);
-  const double Ce = dXdt * dXde;
-  return (cff * xb_old + Ce * x1) / (cff + Ce);
+  const double dXdn = x1 - x2;
+  if ((dXdt * dXdn) < 0.0) dXdt = 0.0;
+  const double dXds = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
+  const double cff = fmax(dXds * dXds + dXdn * dXdn, eps);
+  const double Cn = dXdt * dXdn;
+  return (cff * xb_old + Cn * x1) / (cff + Cn);
 }
 
+// grid: x = position along the edge, y = level, z = edge (0 W, 1 E, 2 S, 3 N)
 __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
 {
   DEV_PROLOGUE(c)
   const int k = blockIdx.y;
   if (k >= a.nk) return;
   const roms_params_t &p = c->p;
-  const int side = blockIdx.z;                      // 0 south, 1 north
-  if (!(side ? b.north_edge : b.south_edge)) return;
-  const int code = side ? a.code_n : a.code_s;
+  const int side = blockIdx.z;
+  const bool we = side <= LBS_EAST, hi = side == LBS_EAST || side == LBS_NORTH;
+  if (!(side == LBS_WEST ? b.west_edge : side == LBS_EAST ? b.east_edge : side == LBS_SOUTH ? b.south_edge : b.north_edge)) return;
+  if (we ? b.EWperiodic : b.NSperiodic) return;
+  const int code = a.code[side];
   const bool utype = a.var == LBV_UBAR || a.var == LBV_U, vtype = a.var == LBV_VBAR || a.var == LBV_V;
-  int i0 = b.Istr, i1 = b.Iend;
-  if (utype) {
-    i0 = b.IstrU;
-    if (code == LBC_CLOSED) { i0 = b.EWperiodic ? b.IstrU : b.Istr; i1 = b.EWperiodic ? b.Iend : b.IendR; }
+  const bool normal = (utype && we) || (vtype && !we);
+  // along-edge range (tangential components: u2dbc_im.F:829-1140, v2dbc_im.F:812-1120)
+  int a0, a1, bi = 0, bj = 0;
+  if (we) {
+    bi = hi ? b.Iend + 1 : (utype ? b.Istr : b.Istr - 1);
+    a0 = b.Jstr; a1 = b.Jend;
+    if (vtype) {
+      a0 = b.JstrV;
+      if (code == LBC_CLOSED) { a0 = b.NSperiodic ? b.JstrV : b.Jstr; a1 = b.NSperiodic ? b.Jend : b.JendR; }
+    }
+  } else {
+    bj = hi ? b.Jend + 1 : (vtype ? b.Jstr : b.Jstr - 1);
+    a0 = b.Istr; a1 = b.Iend;
+    if (utype) {
+      a0 = b.IstrU;
+      if (code == LBC_CLOSED) { a0 = b.EWperiodic ? b.IstrU : b.Istr; a1 = b.EWperiodic ? b.Iend : b.IendR; }
+    }
   }
-  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > i1) return;
-  // boundary row jb, first and second interior rows j1, j2
-  int jb, j1, j2;
-  if (vtype) { jb = side ? b.Jend + 1 : b.Jstr; j1 = side ? b.Jend : b.Jstr + 1; j2 = side ? b.Jend - 1 : b.Jstr + 2; }
-  else { jb = side ? b.Jend + 1 : b.Jstr - 1; j1 = side ? b.Jend : b.Jstr; j2 = side ? b.Jend - 1 : b.Jstr + 1; }
+  const int al = a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (al > a1) return;
+  const long sn = (we ? 1 : ni) * (hi ? -1 : 1), st = we ? ni : 1;
+  const long B = I2(we ? bi : al, we ? al : bj), P1 = B + sn, P2 = P1 + sn;
   const long kb = (long)k * nij;
   double *X = a.X + kb;
-  const long qb = I2(i, jb), q1 = I2(i, j1);
   double x;
   if (code == LBC_RADIATION) {
     const double *O = a.Xold + kb;
-    double gL = O[q1] - O[q1 - 1], gR = O[q1 + 1] - O[q1];
-    if (a.masked && (a.var == LBV_T || a.var == LBV_ZETA)) {      // t3dbc_im.F:370-379, zetabc.F:412-419
-      gL = gL * c->F.umask[q1];
-      gR = gR * c->F.umask[q1 + 1];
+    double gL = O[P1] - O[P1 - st], gR = O[P1 + st] - O[P1];
+    if (a.masked && (a.var == LBV_T || a.var == LBV_ZETA)) {      // zetabc.F:112-120, t3dbc_im.F:370-379
+      const double *gm = we ? c->F.vmask : c->F.umask;
+      gL = gL * gm[P1];
+      gR = gR * gm[P1 + st];
     }
     // zetabc.F:424 -- on the southern edge the free surface takes its normal difference towards the boundary row
-    if (a.var == LBV_ZETA && !side) j2 = jb;
-    x = bc_radiate(O[qb], O[q1], X[q1], X[I2(i, j2)], gL, gR);
+    const long Q2 = (a.var == LBV_ZETA && side == LBS_SOUTH) ? B : P2;
+    x = bc_radiate(O[B], O[P1], X[P1], X[Q2], gL, gR);
   } else if (code == LBC_CLAMPED) {
-    x = a.D[qb + kb];
-  } else if (code == LBC_CHAPMAN_IMPLICIT) {        // zetabc.F:489-506, :638-655
-    const double cff = a.dt2d * c->F.pn[q1];
-    const double cff1 = sqrt(p.g * (c->F.h[q1] + a.Xold[q1]));
-    const double Ce = cff * cff1;
-    const double cff2 = 1.0 / (1.0 + Ce);
-    x = cff2 * (a.Xold[qb] + Ce * X[q1]);
-  } else if (code == LBC_FLATHER && utype) {        // u2dbc_im.F:912-932, :1070-1090: tangential component, Chapman type
-    const double cff = a.dt2d * 0.5 * (c->F.pn[q1 - 1] + c->F.pn[q1]);
-    const double cff1 = sqrt(p.g * 0.5 * (c->F.h[q1 - 1] + a.Z[q1 - 1] + c->F.h[q1] + a.Z[q1]));
-    const double Ce = cff * cff1;
-    const double cff2 = 1.0 / (1.0 + Ce);
-    x = cff2 * (a.Xold[qb] + Ce * X[q1]);
-  } else if (code == LBC_FLATHER) {                 // v2dbc_im.F:216-286, :565-635 (bry_val = vbar_south / vbar_north)
-    const long qa = I2(i, side ? b.Jend : b.Jstr - 1), qc = I2(i, side ? b.Jend + 1 : b.Jstr);
-    const double bry_val = a.D[qb];
+    x = a.D[B + kb];
+  } else if (code == LBC_CHAPMAN_IMPLICIT) {        // zetabc.F:193-220, :342, :491, :640
+    const double cff = a.dt2d * (we ? c->F.pm : c->F.pn)[P1];
+    const double cff1 = sqrt(p.g * (c->F.h[P1] + a.Xold[P1]));
+    const double Cn = cff * cff1;
+    const double cff2 = 1.0 / (1.0 + Cn);
+    x = cff2 * (a.Xold[B] + Cn * X[P1]);
+  } else if (code == LBC_FLATHER && normal) {       // u2dbc_im.F:214-300, v2dbc_im.F:216-286 (bry_val = boundary data)
+    const long qa = B - (we ? 1 : ni), qc = B;      // the two rho-points around the velocity point, lower index first
+    const double bry_val = a.D[B];
     const double cff = 1.0 / (0.5 * (c->F.h[qa] + a.Z[qa] + c->F.h[qc] + a.Z[qc]));
-    const double Ce = sqrt(p.g * cff);
-    const double zb = a.Zb[side ? I2(i, b.Jend + 1) : I2(i, b.Jstr - 1)];
-    x = side ? bry_val + Ce * (0.5 * (a.Z[qa] + a.Z[qc]) - zb) : bry_val - Ce * (0.5 * (a.Z[qa] + a.Z[qc]) - zb);
+    const double Cn = sqrt(p.g * cff);
+    const double zb = a.Zb[hi ? qc : qa];
+    x = hi ? bry_val + Cn * (0.5 * (a.Z[qa] + a.Z[qc]) - zb) : bry_val - Cn * (0.5 * (a.Z[qa] + a.Z[qc]) - zb);
+  } else if (code == LBC_FLATHER) {                 // tangential component, Chapman type: u2dbc_im.F:912-932, v2dbc_im.F:886-906
+    const double *pmn = we ? c->F.pm : c->F.pn;
+    const double cff = a.dt2d * 0.5 * (pmn[P1 - st] + pmn[P1]);
+    const double cff1 = sqrt(p.g * 0.5 * (c->F.h[P1 - st] + a.Z[P1 - st] + c->F.h[P1] + a.Z[P1]));
+    const double Cn = cff * cff1;
+    const double cff2 = 1.0 / (1.0 + Cn);
+    x = cff2 * (a.Xold[B] + Cn * X[P1]);
   } else if (code == LBC_GRADIENT) {
-    x = X[q1];
+    x = X[P1];
   } else {                                          // closed
-    x = vtype ? 0.0 : (utype ? p.gamma2 * X[q1] : X[q1]);
+    x = normal ? 0.0 : ((utype || vtype) ? p.gamma2 * X[P1] : X[P1]);
   }
-  if (a.masked && !(vtype && code == LBC_CLOSED)) {
+  // masked = 1: every branch but the closed normal one ends with the mask of the boundary point (the six
+  // boundary-condition routines); masked = 2: only the closed tangential branch does (bc_2d.F / bc_3d.F)
+  const bool do_mask = a.masked == 1 ? !(normal && code == LBC_CLOSED)
+                                     : (a.masked == 2 && code == LBC_CLOSED && !normal && (utype || vtype));
+  if (do_mask) {
     const double *M = utype ? c->F.umask : (vtype ? c->F.vmask : c->F.rmask);
-    x = x * M[qb];
+    x = x * M[B];
   }
-  X[qb] = x;
+  X[B] = x;
+}
+
+// corners when neither direction is periodic, e.g. zetabc.F:699-731: the mean of the two neighbouring boundary
+// points; one thread per (corner, level), after the edges
+__global__ void k_corner_bc(const RomsDev *__restrict__ c, double *A, int gtype, int nk)
+{
+  DEV_PROLOGUE(c)
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (k >= nk) return;
+  const int iw = gtype == GT_U ? b.Istr : b.Istr - 1, ie = b.Iend + 1;
+  const int js = gtype == GT_V ? b.Jstr : b.Jstr - 1, jn = b.Jend + 1;
+  double *X = A + (long)k * nij;
+  if (q == 0 && b.south_edge && b.west_edge) X[I2(iw, js)] = 0.5 * (X[I2(iw + 1, js)] + X[I2(iw, js + 1)]);
+  if (q == 1 && b.south_edge && b.east_edge) X[I2(ie, js)] = 0.5 * (X[I2(ie - 1, js)] + X[I2(ie, js + 1)]);
+  if (q == 2 && b.north_edge && b.west_edge) X[I2(iw, jn)] = 0.5 * (X[I2(iw, jn - 1)] + X[I2(iw + 1, jn)]);
+  if (q == 3 && b.north_edge && b.east_edge) X[I2(ie, jn)] = 0.5 * (X[I2(ie, jn - 1)] + X[I2(ie - 1, jn)]);
 }
 
 static int edge_bc(BcArgs a)
 {
   const roms_bounds_t &b = g_ctx.b;
-  if (!b.south_edge && !b.north_edge) return 0;
-  const int nx = b.Iend - b.Istr + 2;
-  dim3 grid((nx + 255) / 256, a.nk, 2);
+  const bool any_edge = (!b.EWperiodic && (b.west_edge || b.east_edge)) || (!b.NSperiodic && (b.south_edge || b.north_edge));
+  if (!any_edge) return 0;
+  const int nx = b.Iend - b.Istr + 3, ny = b.Jend - b.Jstr + 3;
+  const int nmax = nx > ny ? nx : ny;
+  dim3 grid((nmax + 255) / 256, a.nk, 4);
   hipLaunchKernelGGL(k_edge_bc, grid, dim3(256), 0, g_ctx.stream, g_ctx.devc, a);
   KERNEL_CHECK("k_edge_bc");
+  if (!b.EWperiodic && !b.NSperiodic && (b.west_edge || b.east_edge) && (b.south_edge || b.north_edge)) {
+    const int gtype = (a.var == LBV_UBAR || a.var == LBV_U) ? GT_U : (a.var == LBV_VBAR || a.var == LBV_V) ? GT_V : GT_R;
+    hipLaunchKernelGGL(k_corner_bc, dim3((a.nk + 63) / 64, 4), dim3(64), 0, g_ctx.stream, g_ctx.devc, a.X, gtype, a.nk);
+    KERNEL_CHECK("k_corner_bc");
+  }
   return 0;
 }
 
@@ -166,9 +219,25 @@ static BcArgs bc_args(int var, double *X, int nk)
   BcArgs a{};
   a.X = X; a.var = var; a.nk = nk;
   a.masked = g_ctx.p.masking != 0;
-  if (var >= 0) { a.code_s = lbc_code(g_ctx.p, LBS_SOUTH, var); a.code_n = lbc_code(g_ctx.p, LBS_NORTH, var); }
-  else { a.code_s = a.code_n = LBC_GRADIENT; a.masked = 0; }
+  for (int sd = 0; sd < 4; sd++) a.code[sd] = var >= 0 ? lbc_code(g_ctx.p, sd, var) : LBC_GRADIENT;
+  if (var < 0) a.masked = 0;
   return a;
+}
+
+// bc_r2d / bc_u2d / bc_v2d / bc_w3d_tile ... (bc_2d.F, bc_3d.F): the generic conditions of derived fields --
+// where variable `lbv` is closed: zero normal velocity, gamma2 * (inner value) for the tangential one (times the
+// mask under MASKING), zero gradient for rho-type fields; on any other physical edge zero gradient without mask;
+// then the corners.  Expressed through the edge kernel: closed stays closed, everything else becomes "gradient";
+// gtype_var = LBV_ZETA / LBV_UBAR / LBV_VBAR selects the point type.
+int bc_generic(int gtype_var, int lbv, double *A, int nk)
+{
+  BcArgs a = bc_args(gtype_var, A, nk);
+  for (int sd = 0; sd < 4; sd++) a.code[sd] = lbc_code(g_ctx.p, sd, lbv) == LBC_CLOSED ? LBC_CLOSED : LBC_GRADIENT;
+  // bc_2d.F multiplies by the mask only in the closed tangential branch; the edge kernel masks every branch but the
+  // closed normal one: identical for closed edges, and a gradient edge copies an already masked inner value ...
+  // except that the copy is not re-masked in the reference -- keep that: no mask on gradient edges
+  a.masked = g_ctx.p.masking != 0 ? 2 : 0;          // 2 = "closed tangential branch only"
+  return edge_bc(a);
 }
 
 // the time level `know` and the step dt2d of the 2-D conditions (zetabc.F:96-106)
@@ -182,8 +251,9 @@ static void bc_know(const roms_step_idx_t *s, int *know, double *dt2d)
 
 static bool needs_know(const BcArgs &a)
 {
-  auto tl = [](int c) { return c == LBC_RADIATION || c == LBC_FLATHER || c == LBC_CHAPMAN_IMPLICIT; };
-  return tl(a.code_s) || tl(a.code_n);
+  for (int sd = 0; sd < 4; sd++)
+    if (a.code[sd] == LBC_RADIATION || a.code[sd] == LBC_FLATHER || a.code[sd] == LBC_CHAPMAN_IMPLICIT) return true;
+  return false;
 }
 
 int bc_zeta(int kout, const roms_step_idx_t *s)
@@ -206,6 +276,7 @@ int bc_u2d(int kout, const roms_step_idx_t *s)
   a.Xold = g_ctx.dev[FID_ubar] + (long)(know - 1) * nij_host();
   a.D = g_ctx.dev[FID_ubar_bry];
   a.Z = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
+  a.Zb = g_ctx.dev[FID_zeta_bry];
   a.dt2d = dt2d;
   return edge_bc(a);
 }
@@ -219,6 +290,7 @@ int bc_v2d(int kout, const roms_step_idx_t *s)
   a.D = g_ctx.dev[FID_vbar_bry];
   a.Z = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
   a.Zb = g_ctx.dev[FID_zeta_bry];
+  a.dt2d = dt2d;
   return edge_bc(a);
 }
 int bc_u3d(int nout, int nstp)

@@ -316,6 +316,13 @@ extern "C" int roms_hip_set_vbc(const roms_step_idx_t *s)
     hipLaunchKernelGGL(k_set_vbc, grid2d(b.IendR - b.IstrR + 1, b.JendR - b.JstrR + 1), block2d(), 0, g_ctx.stream,
                        g_ctx.devc, s->nrhs);
     KERNEL_CHECK("k_set_vbc");
+    // bc_u2d_tile / bc_v2d_tile (bc_2d.F:184, :386; isBu2d = isUbar, isBv2d = isVbar): the kernel applied the
+    // closed-wall rule of an E-W periodic channel on its own rows; everything else -- western / eastern edges,
+    // corners, open edges (zero gradient), the mask of the wall points -- through the generic edge kernel
+    if (!b.EWperiodic || g_ctx.p.masking || !lbc2d_all_closed()) {
+      if ((rc = bc_generic(LBV_UBAR, LBV_UBAR, g_ctx.dev[FID_bustr], 1))) return rc;
+      if ((rc = bc_generic(LBV_VBAR, LBV_VBAR, g_ctx.dev[FID_bvstr], 1))) return rc;
+    }
   }
   halo_batch_begin();
   halo_exchange2d(GT_U, g_ctx.dev[FID_bustr]);
@@ -724,7 +731,9 @@ extern "C" int roms_hip_lmd_vmix(const roms_step_idx_t *s)
       hipLaunchKernelGGL(k_lmd_edges, dim3(1, b.N + 1), dim3(64), 0, g_ctx.stream, g_ctx.devc, 2);
     KERNEL_CHECK("k_lmd_edges");
   }
-  // bc_r2d_tile(hsbl) exchange; bc_w3d_tile(Akv), bc_w3d_tile(Akt(:,:,:,itrc)): wall rows + exchange
+  // bc_r2d_tile(hsbl) (the kernel wrote the wall rows of a channel; western / eastern edges and corners through the
+  // generic edge kernel) + exchange; bc_w3d_tile(Akv), bc_w3d_tile(Akt(:,:,:,itrc)): wall rows + exchange
+  if (!b.EWperiodic && (rc = bc_generic(LBV_ZETA, LBV_ZETA, g_ctx.dev[FID_hsbl], 1))) return rc;
   if ((rc = halo_exchange2d(GT_R, g_ctx.dev[FID_hsbl]))) return rc;
   if ((rc = bc_w3d(g_ctx.dev[FID_Akv]))) return rc;
   for (int it = 0; it < b.NAT; it++)

@@ -49,6 +49,9 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
   const long c0 = I2(i, j);
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
+  // physical western / eastern edges (pre_step3d.F:401-412: FX(Istr-1) = FX(Istr), FX(Iend+2) = FX(Iend+1))
+  const bool w_wall = b.west_edge && !b.EWperiodic && i == b.Istr;
+  const bool e_wall = b.east_edge && !b.EWperiodic && i == b.Iend;
   // time-stepping weights, pre_step3d.F:586-600
   // (MPDATA tracers use Gamma = 1/2, :557-563 and :793-799; H and V scheme are both MPDATA or neither)
   const double Gamma = (HADV == ADV_MPDATA) ? 0.5 : 1.0 / 6.0;
@@ -122,7 +125,9 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
     const long ck = c0 + (long)(k - 1) * nij;
     tkp2 = (k + 2 <= N) ? ts[ck + 2 * nij] : 0.0;
     // ---- horizontal fluxes of t(nstp) ----
-    const double xm2 = ts[ck - 2], xm1 = ts[ck - 1], xp1 = ts[ck + 1], xp2 = ts[ck + 2];
+    const double xm1 = ts[ck - 1], xp1 = ts[ck + 1];
+    const double xm2 = w_wall ? 0.0 : ts[ck - 2];
+    const double xp2 = e_wall ? 0.0 : ts[ck + 2];
     const double ym1 = ts[ck - ni], yp1 = ts[ck + ni];
     const double ym2 = s_wall ? 0.0 : ts[ck - 2 * ni];
     const double yp2 = n_wall ? 0.0 : ts[ck + 2 * ni];
@@ -133,12 +138,15 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
     double dym1 = ym1 - ym2, dyp2 = yp2 - yp1;
     if constexpr (MASK) {
       const gcd_t um = (gcd_t)c->F.umask, vm = (gcd_t)c->F.vmask;
-      dxm1 = dxm1 * um[c0 - 1]; dx0 = dx0 * um[c0]; dxp1 = dxp1 * um[c0 + 1]; dxp2 = dxp2 * um[c0 + 2];
+      dxm1 = dxm1 * um[c0 + (w_wall ? 0 : -1)]; dx0 = dx0 * um[c0]; dxp1 = dxp1 * um[c0 + 1];
+      dxp2 = dxp2 * um[c0 + (e_wall ? 1 : 2)];
       dy0 = dy0 * vm[c0]; dyp1 = dyp1 * vm[c0 + ni];
       dym1 = dym1 * vm[c0 + (s_wall ? 0 : -ni)]; dyp2 = dyp2 * vm[c0 + (n_wall ? ni : 2 * ni)];
     }
     if (s_wall) dym1 = dy0;
     if (n_wall) dyp2 = dyp1;
+    if (w_wall) dxm1 = dx0;
+    if (e_wall) dxp2 = dxp1;
     const double FXi = hflux<HADV>(hu0, xm1, tk, dxm1, dx0, dxp1);
     const double FXip1 = hflux<HADV>(hu1, tk, xp1, dx0, dxp1, dxp2);
     const double FEj = hflux<HADV>(hv0, ym1, tk, dym1, dy0, dyp1);

@@ -134,6 +134,10 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   const long c0 = I2(i, j);
   // wall rows: the outer stencil point is not used (:741-760); read a valid address instead
   const long oym2 = s_wall ? 0 : -2 * ni, oyp2 = n_wall ? 0 : 2 * ni;
+  // physical western / eastern edges (:700-715: FX(Istr-1) = FX(Istr), FX(Iend+2) = FX(Iend+1))
+  const bool w_wall = b.west_edge && !b.EWperiodic && i == b.Istr;
+  const bool e_wall = b.east_edge && !b.EWperiodic && i == b.Iend;
+  const long oxm2 = w_wall ? 0 : -2, oxp2 = e_wall ? 0 : 2;
 
   double tn[NMAX + 1], CF[NMAX + 1], DC[NMAX + 1];
   CF[0] = 0.0;
@@ -203,13 +207,14 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       const double wtop = Wv[ck + nij];
       tkp2 = (k + 2 <= N) ? t3[ck + 2 * nij] : 0.0;
       // ---- horizontal fluxes, step3d_t.F:596-828 ----
-      const double xm2 = t3[ck - 2], xm1 = t3[ck - 1], xp1 = t3[ck + 1], xp2 = t3[ck + 2];
+      const double xm2 = t3[ck + oxm2], xm1 = t3[ck - 1], xp1 = t3[ck + 1], xp2 = t3[ck + oxp2];
       const double ym1 = t3[ck - ni], yp1 = t3[ck + ni];
       const double ym2 = t3[ck + oym2];
       const double yp2 = t3[ck + oyp2];
       const double hu0 = Huon[ck], hu1 = Huon[ck + 1];
       const double hv0 = Hvom[ck], hv1 = Hvom[ck + ni];
-      const double dxm1 = xm1 - xm2, dx0 = tk - xm1, dxp1 = xp1 - tk, dxp2 = xp2 - xp1;
+      const double dx0 = tk - xm1, dxp1 = xp1 - tk;
+      const double dxm1 = w_wall ? dx0 : (xm1 - xm2), dxp2 = e_wall ? dxp1 : (xp2 - xp1);
       const double dy0 = tk - ym1, dyp1 = yp1 - tk;
       const double dym1 = s_wall ? dy0 : (ym1 - ym2);
       const double dyp2 = n_wall ? dyp1 : (yp2 - yp1);
@@ -328,6 +333,10 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
   const long c0 = I2(i, j);
   const long oym2 = s_wall ? 0 : -2 * ni, oyp2 = n_wall ? 0 : 2 * ni;
+  // physical western / eastern edges (step3d_t.F:700-715: FX(Istr-1) = FX(Istr), FX(Iend+2) = FX(Iend+1))
+  const bool w_wall = b.west_edge && !b.EWperiodic && i == b.Istr;
+  const bool e_wall = b.east_edge && !b.EWperiodic && i == b.Iend;
+  const long oxm2 = w_wall ? 0 : -2, oxp2 = e_wall ? 0 : 2;
 
   double CF[NMAX + 1], DC[NMAX + 1];
   CF[0] = 0.0;
@@ -387,7 +396,7 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
     L.akt = Akt[ck + nij];
     L.w = Wv[ck + nij];
     L.tkp2 = (k + 2 <= N) ? t3[ck + 2 * nij] : 0.0;
-    L.xm2 = t3[ck - 2]; L.xm1 = t3[ck - 1]; L.xp1 = t3[ck + 1]; L.xp2 = t3[ck + 2];
+    L.xm2 = t3[ck + oxm2]; L.xm1 = t3[ck - 1]; L.xp1 = t3[ck + 1]; L.xp2 = t3[ck + oxp2];
     L.ym1 = t3[ck - ni]; L.yp1 = t3[ck + ni];
     L.ym2 = t3[ck + oym2];
     L.yp2 = t3[ck + oyp2];
@@ -412,12 +421,15 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       double dym1 = cur.ym1 - cur.ym2, dyp2 = cur.yp2 - cur.yp1;
       if constexpr (MASK) {
         const gcd_t um = (gcd_t)c->F.umask, vm = (gcd_t)c->F.vmask;
-        dxm1 = dxm1 * um[c0 - 1]; dx0 = dx0 * um[c0]; dxp1 = dxp1 * um[c0 + 1]; dxp2 = dxp2 * um[c0 + 2];
+        dxm1 = dxm1 * um[c0 + (w_wall ? 0 : -1)]; dx0 = dx0 * um[c0]; dxp1 = dxp1 * um[c0 + 1];
+        dxp2 = dxp2 * um[c0 + (e_wall ? 1 : 2)];
         dy0 = dy0 * vm[c0]; dyp1 = dyp1 * vm[c0 + ni];
         dym1 = dym1 * vm[c0 + (s_wall ? 0 : -ni)]; dyp2 = dyp2 * vm[c0 + (n_wall ? ni : 2 * ni)];
       }
       if (s_wall) dym1 = dy0;
       if (n_wall) dyp2 = dyp1;
+      if (w_wall) dxm1 = dx0;
+      if (e_wall) dxp2 = dxp1;
       const double FXi = hflux<HADV>(cur.hu0, cur.xm1, tk, dxm1, dx0, dxp1);
       const double FXip1 = hflux<HADV>(cur.hu1, tk, cur.xp1, dx0, dxp1, dxp2);
       const double FEj = hflux<HADV>(cur.hv0, cur.ym1, tk, dym1, dy0, dyp1);
@@ -556,6 +568,7 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
       case ADV_A4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_A4, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_HSIMT * 16 + ADV_HSIMT: {
         if (p.masking) return roms_fail("roms_hip_step3d_t", "MASKING is not built for HSIMT tracers");
+        if (!b.EWperiodic) return roms_fail("roms_hip_step3d_t", "HSIMT is built for E-W periodic grids only");
         // three-point footprint: refresh the ghost points of t(nnew) first (step3d_t.F:369-386); classic kernel
         if (b.NghostPoints != 3) return roms_fail("roms_hip_step3d_t", "HSIMT needs NghostPoints = 3 (inp_par.F:266-278)");
         const long n3r_ = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
@@ -568,6 +581,7 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
       }
       case ADV_MPDATA * 16 + ADV_MPDATA:
         if (p.masking) return roms_fail("roms_hip_step3d_t", "MASKING is not built for MPDATA tracers (mpdata_adiff.F:290-1025)");
+        if (!b.EWperiodic) return roms_fail("roms_hip_step3d_t", "MPDATA is built for E-W periodic grids only");
         // multi-pass: upstream step, anti-diffusive velocities, FCT limiter, corrected step (k_mpdata.hip)
         for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q, q == 0);
         break;

@@ -231,13 +231,17 @@ k_uv_couple(const RomsDev *__restrict__ c, int nnew)
   if (XB.z == 0) {
     if (inner && i >= b.IstrU) return;
     if (i < b.IstrP) return;
-    const bool fix = ns_wall && (j == 0 || j == b.Mm + 1) && i >= b.IstrU && i <= b.Iend;
+    // boundary points whose vertical mean is replaced after the boundary conditions: the wall rows (:1131-1190) and,
+    // without E-W periodicity, the western / eastern boundary columns (:1075-1125)
+    const bool fix = (ns_wall && (j == 0 || j == b.Mm + 1) && i >= b.IstrU && i <= b.Iend) ||
+                     (!b.EWperiodic && ((b.west_edge && i == b.Istr) || (b.east_edge && i == b.Iend + 1)));
     couple_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), GF(Huon), GF(ubar), GF(on_u)[c0],
                         GF(DU_avg1)[c0], GF(DU_avg2)[c0], fix, masking, masking ? (double)GF(umask)[c0] : 1.0);
   } else {
     if (inner && i >= b.Istr && j >= b.JstrV) return;
     if (j < b.Jstr) return;
-    const bool fix = ns_wall && (j == 1 || j == b.Mm + 1) && i >= b.Istr && i <= b.Iend;
+    const bool fix = (ns_wall && (j == 1 || j == b.Mm + 1) && i >= b.Istr && i <= b.Iend) ||
+                     (!b.EWperiodic && ((b.west_edge && i == b.Istr - 1) || (b.east_edge && i == b.Iend + 1)));
     couple_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), GF(Hvom), GF(vbar), GF(om_v)[c0],
                         GF(DV_avg1)[c0], GF(DV_avg2)[c0], fix, masking, masking ? (double)GF(vmask)[c0] : 1.0);
   }

@@ -229,6 +229,7 @@ int bc_t3d(int nout, int itrc, int nstp);
 bool lbc2d_all_closed();
 int lbc_code(const roms_params_t &p, int sd, int v);   // effective enum roms_lbc of variable v on side sd
 int bc_w3d(double *A);
+int bc_generic(int gtype_var, int lbv, double *A, int nk);   // bc_2d.F / bc_3d.F rules for derived fields
 void snapshot_release();                  // snapshot.hip: waits for and frees an in-flight snapshot
 void snapshot_forget(int field_id);       // snapshot.hip: the same for one field (before it is re-registered)
 void diag_release();                      // k_diag.hip: frees the buffers of roms_hip_diag

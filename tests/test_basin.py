@@ -1,0 +1,128 @@
+"""Grids without a periodic direction: physical edges on all four sides -- closed walls
+(a basin) or open conditions -- and the corners.  The reference's non-periodic branches of every routine of the path
+(edge treatment of the advection stencils, mean replacement on the boundary columns, bc_2d / bc_3d rules, the
+western / eastern blocks of the six boundary-condition routines).
+
+CPU: the oracle on a basin is pinned against the reference build where it compiles (tests/test_ref_pinning.py) and
+checked for conservation / tiling invariance (tests/test_oracle_properties.py, tests/test_multitile_gloo.py).
+GPU (-m gpu): every kernel and whole runs, HIP against the oracle."""
+import numpy as np
+import pytest
+
+import util
+from roms_trunk_mgh_amd import abi, ana, main3d
+
+pytestmark = pytest.mark.gpu
+BASIN = {"EWperiodic": False}
+CONFIGS = ["BENCHMARK_TINY", "UPWELLING", "SEAMOUNT"]
+KERNELS = ["set_depth", "set_massflux", "omega", "set_zeta", "rho_eos", "prsgrd", "t3dmix2", "uv3dmix2", "rhs3d_tile",
+           "pre_step3d", "rhs3d", "step2d", "step3d_uv", "step3d_t", "set_vbc", "wvelocity", "ini_zeta", "ini_fields"]
+OPEN = {"zeta": "Cha", "ubar": "Fla", "vbar": "Fla", "u": "Rad", "v": "Rad", "t": "Rad"}
+
+
+def _open_all(st, table=OPEN):
+    st.p = type(st.p).from_buffer_copy(st.p)
+    for sd in ("west", "east", "south", "north"):
+        for var, code in table.items():
+            st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+
+
+def _state(config, kernel, open_edges):
+    ov = dict(BASIN)
+    if kernel in ("t3dmix2", "uv3dmix2", "rhs3d"):
+        ov.update({"tnu2": 300.0} if config == "SEAMOUNT" else {"tnu2": 300.0, "visc2": 800.0})
+    st0 = util.prepared_state(config, overrides=ov)
+    if open_edges:
+        _open_all(st0)
+        rng = np.random.default_rng(5)
+        for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
+            st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
+        st0["t_bry"][:] = st0["t"][:, :, :, 0, :] * (1.0 + 1.0e-3 * rng.standard_normal(st0["t_bry"].shape))
+    if kernel == "step3d_t":
+        util.hz_weighted_tnew(st0)
+    if kernel in ("set_massflux", "omega", "set_depth", "set_zeta"):
+        st0["Zt_avg1"] *= 1.3
+        st0["u"] *= 1.1
+        st0["v"] *= 0.9
+        st0["Huon"] *= 1.05
+        st0["Hvom"] *= 0.95
+    return st0
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+@pytest.mark.parametrize("open_edges", [False, True], ids=["closed", "open"])
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_hip_kernels_on_a_basin(config, kernel, open_edges):
+    import oracle
+    from roms_trunk_mgh_amd import hip
+    if kernel == "uv3dmix2" and config == "SEAMOUNT":
+        pytest.skip("SEAMOUNT has no UV_VIS2")
+    st0 = _state(config, kernel, open_edges)
+    assert st0.b.EWperiodic == 0
+    st_o, st_h = st0.copy(), st0.copy()
+    preds = [(5, 1, 0)] if kernel != "step2d" else [(5, 1, 1), (5, 2, 1), (5, 2, 0)]
+    for iic, iif, pred in preds:
+        s = util.step_idx(iic=iic, iif=iif, pred=pred, knew=3 if pred else 2, krhs=1 if pred else 3)
+        if kernel in ("ini_zeta", "ini_fields"):
+            s = util.step_idx(iic=1, iif=1, pred=0, kstp=1, krhs=1, knew=1)
+        oracle.Oracle(st_o).call(kernel, s)
+        h = hip.RomsHip(st_h)
+        try:
+            h.call(kernel, s)
+            h.to_host()
+        finally:
+            h.close()
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= 1e-12 for v in diffs.values()), diffs
+    if not (kernel == "ini_zeta" and open_edges):      # (Chapman edges: ini_zeta applies no condition, nothing to change)
+        assert util.compare_states(st_o, st0), "kernel did not modify anything: test is vacuous"
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+def test_hip_step2d_loop_on_a_basin(config):
+    import oracle
+    from roms_trunk_mgh_amd import hip
+    st0 = util.prepared_state(config, overrides=BASIN)
+    st_o, st_h = st0.copy(), st0.copy()
+    s1, s2 = util.step_idx(iic=4), util.step_idx(iic=4)
+    i_o = oracle.Oracle(st_o).step2d_loop(s1, 1)
+    h = hip.RomsHip(st_h)
+    try:
+        i_h = h.step2d_loop(s2, 1)
+        h.to_host()
+    finally:
+        h.close()
+    assert i_o == i_h
+    assert all(v <= 1e-11 for v in util.compare_states(st_h, st_o).values())
+
+
+@pytest.mark.parametrize("config,physics,open_edges", [("UPWELLING", False, False), ("BENCHMARK_TINY", True, False),
+                                                        ("SEAMOUNT", False, False), ("UPWELLING", False, True)])
+def test_hip_100_steps_on_a_basin(config, physics, open_edges):
+    import oracle
+    from roms_trunk_mgh_amd import hip
+    from roms_trunk_mgh_amd.state import rel_rms
+    st_o = ana.make_tile(config, perturb=1.0 if config != "SEAMOUNT" else 0.0, overrides=BASIN)
+    if open_edges:
+        _open_all(st_o)
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o), physics=physics, diagnostics=physics)
+    mo.initial()
+    mo.run(100)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be, physics=physics, diagnostics=physics)
+        mh.initial()
+        mh.run(100)
+        be.to_host()
+    finally:
+        be.close()
+    s = mo.s
+    out = {"zeta": rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], 1e-3)}
+    for name in ("u", "v"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], 1e-4)
+    for it in range(st_o.b.NT):
+        out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
+    assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
+    assert all(v <= 1e-10 for v in out.values()), out
+    assert float(np.abs(st_o["u"]).max()) > 1e-6
