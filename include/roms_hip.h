@@ -88,11 +88,13 @@ enum roms_adv {
  * reference's default), WJ_GRADP = prsgrd31.h with the weighted Jacobian of Song (1998). */
 enum roms_pgf { PGF_DJ_GRADPS = 0, PGF_STANDARD = 1, PGF_WJ_GRADP = 2 };
 /* Lateral boundary condition codes supported on this path (the logical records of T_LBC, mod_param.F:348-363).
- * West and east: periodic only.  South and north, per variable (roms_params_t.lbc): closed, gradient, clamped,
- * radiation (implicit upstream, zetabc.F:408 / u2dbc_im.F:833 / v2dbc_im.F:138 / u3dbc_im.F:381 / v3dbc_im.F:97 /
- * t3dbc_im.F:364; no nudging, RADIATION_2D off) for every variable; Chapman implicit for zeta (zetabc.F:489);
- * Flather for vbar (v2dbc_im.F:216) and ubar (u2dbc_im.F:912: the Chapman-type rule the reference gives the
- * tangential component of a Flather edge).  Anything else is refused by every entry that applies conditions. */
+ * A periodic direction (E-W) has LBC_PERIODIC on both of its sides; a physical edge (any of the four) takes, per
+ * variable (roms_params_t.lbc): closed, gradient, clamped, radiation (implicit upstream, zetabc.F:108 /
+ * u2dbc_im.F:135 / v2dbc_im.F:136 / u3dbc_im.F:131 / v3dbc_im.F:97 / t3dbc_im.F:128 and the other edges' blocks; no
+ * nudging, RADIATION_2D off) for every variable; Chapman implicit for zeta (zetabc.F:193); Flather for ubar and
+ * vbar (u2dbc_im.F:214, v2dbc_im.F:216 for the normal component, the Chapman-type rule of u2dbc_im.F:912 /
+ * v2dbc_im.F:886 for the tangential one); then the corner rule (zetabc.F:699).  Anything else is refused by every
+ * entry that applies conditions; N-S periodic grids are refused. */
 enum roms_lbc {
   LBC_PERIODIC = 0, LBC_CLOSED = 1, LBC_GRADIENT = 2, LBC_CLAMPED = 3, LBC_CHAPMAN_IMPLICIT = 4, LBC_FLATHER = 5,
   LBC_RADIATION = 6

@@ -24,6 +24,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
     if "mask" in opts:
         kw["mask"] = "island"
+    if "basin" in opts:
+        kw.setdefault("overrides", {})["EWperiodic"] = False
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)
     b = st.b
     ndev = torch.cuda.device_count()

@@ -35,6 +35,8 @@ def _single(config, nsteps, variant=""):
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
     if "mask" in opts:
         kw["mask"] = "island"
+    if "basin" in opts:
+        kw.setdefault("overrides", {})["EWperiodic"] = False
     st = ana.make_tile(config, perturb=1.0, **kw)
     be = hip.RomsHip(st)
     m = main3d.Main3D(be, physics=("physics" in opts), diagnostics=("physics" in opts))
@@ -55,6 +57,8 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "BENCHMARK_TINY", "physics"),
                                                     # MASKING: an island across the tile corner, a headland on the wall
                                                     (2, 2, "BENCHMARK_TINY", "mask"), (2, 1, "UPWELLING", "mask"),
+                                                    # no periodic direction: physical edges on the outer tile sides, corners
+                                                    (2, 2, "UPWELLING", "basin"), (2, 1, "BENCHMARK_TINY", "basin+physics"),
                                                     # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
                                                     # 512-column tiles of the 8-GPU run (4x1), both tile rows (2x2), the
                                                     # deferred-flux step2d path and, with six MPDATA tracers, three ghost points
