@@ -92,12 +92,13 @@ enum roms_pgf { PGF_DJ_GRADPS = 0, PGF_STANDARD = 1, PGF_WJ_GRADP = 2 };
  * variable (roms_params_t.lbc): closed, gradient, clamped, radiation (implicit upstream, zetabc.F:108 /
  * u2dbc_im.F:135 / v2dbc_im.F:136 / u3dbc_im.F:131 / v3dbc_im.F:97 / t3dbc_im.F:128 and the other edges' blocks; no
  * nudging, RADIATION_2D off) for every variable; Chapman implicit for zeta (zetabc.F:193); Flather for ubar and
- * vbar (u2dbc_im.F:214, v2dbc_im.F:216 for the normal component, the Chapman-type rule of u2dbc_im.F:912 /
+ * vbar (u2dbc_im.F:214, v2dbc_im.F:216 for the normal component,
+ * [radiation + nudging towards the boundary data, "RadNud", for every variable: e.g. t3dbc_im.F:138-152, :183-188] the Chapman-type rule of u2dbc_im.F:912 /
  * v2dbc_im.F:886 for the tangential one); then the corner rule (zetabc.F:699).  Anything else is refused by every
  * entry that applies conditions; N-S periodic grids are refused. */
 enum roms_lbc {
   LBC_PERIODIC = 0, LBC_CLOSED = 1, LBC_GRADIENT = 2, LBC_CLAMPED = 3, LBC_CHAPMAN_IMPLICIT = 4, LBC_FLATHER = 5,
-  LBC_RADIATION = 6
+  LBC_RADIATION = 6, LBC_RADIATION_NUDGING = 7
 };
 /* rows of roms_params_t.lbc = the state variables of LBC(:, isFsur / isUbar / isVbar / isUvel / isVvel / isTvar, ng) */
 enum roms_lbc_var { LBV_ZETA = 0, LBV_UBAR, LBV_VBAR, LBV_U, LBV_V, LBV_T, LBV_COUNT };
@@ -140,6 +141,10 @@ typedef struct roms_params {
   /* lbc[side][variable] (enum roms_lbc_side, roms_lbc_var; every tracer shares LBV_T): 0 = take the side's
    * lbc_west / lbc_east / lbc_south / lbc_north above, otherwise an enum roms_lbc code */
   int    lbc[4][LBV_COUNT];
+  /* LBC_RADIATION_NUDGING ("RadNud"): nudging coefficients (1/s) of the boundary point towards the boundary data,
+   * per side and variable -- FSobc_out/in (zeta), M2obc_out/in (ubar, vbar), M3obc_out/in (u, v), Tobc_out/in (t; one
+   * value for all tracers) of mod_scalars.F:1336-1365, i.e. 1/(xNUDG*86400) and OBCFAC times that */
+  double obc_out[4][LBV_COUNT], obc_in[4][LBV_COUNT];
 } roms_params_t;
 
 /* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and

@@ -38,7 +38,7 @@ int o_check_lbc(const roms_bounds_t *b, const roms_params_t *p)
         if (c != LBC_PERIODIC) return 1;
         continue;
       }
-      int ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED || c == LBC_RADIATION;
+      int ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED || c == LBC_RADIATION || c == LBC_RADIATION_NUDGING;
       if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT;
       if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER;
       if (!ok) return 1;

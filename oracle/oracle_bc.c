@@ -25,11 +25,12 @@ static void o_know(const roms_params_t *p, const roms_step_idx_t *s, int *know, 
 /* Implicit upstream radiation with Cx (or Ce) of the tangential direction = 0 (no RADIATION_2D), e.g.
  * zetabc.F:123-160: xb_old = X(B) at the old level; x1_old, x1 = X(P1) at the old / new level; x2 = X(P2) at the new
  * level; gL, gR = the two along-edge differences of X(old) at P1 on either side of the point. */
-static double o_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR)
+static double o_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR, int *inward)
 {
   const double eps = 1.0E-20;
   double dXdt = x1_old - x1;
   const double dXdn = x1 - x2;
+  *inward = (dXdt * dXdn) < 0.0;                 /* selects the nudging time scale, e.g. t3dbc_im.F:138-146 */
   if ((dXdt * dXdn) < 0.0) dXdt = 0.0;
   const double dXds = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
   const double cff = MAX(dXdn * dXdn + dXds * dXds, eps);
@@ -97,13 +98,19 @@ static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_f
     for (int a = e.a0; a <= e.a1; a++) {
       const long B = I2(e.we ? e.bi : a, e.we ? a : e.bj), P1 = B + e.sn, P2 = P1 + e.sn;
       double x;
-      if (code == LBC_RADIATION) {
+      if (code == LBC_RADIATION || code == LBC_RADIATION_NUDGING) {
         double gL = Ok[P1] - Ok[P1 - e.st], gR = Ok[P1 + e.st] - Ok[P1];
         if (mk && gtype == GT_R) { gL = gL * gmask[P1]; gR = gR * gmask[P1 + e.st]; }       /* zetabc.F:112-120, t3dbc_im.F */
         /* zetabc.F:424 -- on the SOUTHERN edge the free surface takes its normal difference towards the boundary
          * row (the other edges, :126, :275, :573, and every other variable look into the interior) */
         const long Q2 = (var == LBV_ZETA && side == LBS_SOUTH) ? B : P2;
-        x = o_radiate(Ok[B], Ok[P1], Xk[P1], Xk[Q2], gL, gR);
+        int inward;
+        x = o_radiate(Ok[B], Ok[P1], Xk[P1], Xk[Q2], gL, gR, &inward);
+        if (code == LBC_RADIATION_NUDGING) {                    /* explicit nudging, zetabc.F:128-135/:162-166 ... */
+          double tau = inward ? p->obc_in[side][var] : p->obc_out[side][var];
+          tau = tau * (nk == 1 && var <= LBV_VBAR ? dt2d : p->dt);
+          x = x + tau * (D[B + (long)k * nij] - Ok[B]);
+        }
       } else if (code == LBC_CLAMPED) {
         x = D[B + (long)k * nij];
       } else if (code == LBC_CHAPMAN_IMPLICIT) {                /* zetabc.F:193-220, :342, :491, :640 */

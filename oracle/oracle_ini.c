@@ -14,6 +14,7 @@ static int any_lbc(const roms_params_t *p, int v, int c1, int c2)
   for (int sd = 0; sd < 4; sd++) {
     const int c = o_lbc(p, sd, v);
     if (c == c1 || c == c2) return 1;
+    if (c1 == LBC_RADIATION && c == LBC_RADIATION_NUDGING) return 1;      /* RadNud sets LBC%radiation too */
   }
   return 0;
 }

@@ -49,6 +49,7 @@ MODULE ref_wrap_types
     REAL(c_double) :: blk_ZQ, blk_ZT, blk_ZW
     INTEGER(c_int) :: masking, pgf
     INTEGER(c_int) :: lbc(6,4)          ! C: lbc[side][variable]
+    REAL(c_double) :: obc_out(6,4), obc_in(6,4)   ! nudging coefficients of RadNud edges (1/s)
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -873,14 +874,29 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
         LBC(side(sd), ivar, ng)%clamped = code == 3
         LBC(side(sd), ivar, ng)%Chapman_implicit = code == 4
         LBC(side(sd), ivar, ng)%Flather = code == 5
-        LBC(side(sd), ivar, ng)%radiation = code == 6
+        LBC(side(sd), ivar, ng)%radiation = code == 6 .OR. code == 7
         LBC(side(sd), ivar, ng)%Chapman_explicit = .FALSE.
-        LBC(side(sd), ivar, ng)%nudging = .FALSE.
+        LBC(side(sd), ivar, ng)%nudging = code == 7                 ! "RadNud"
         LBC(side(sd), ivar, ng)%nested = .FALSE.
         LBC(side(sd), ivar, ng)%reduced = .FALSE.
         LBC(side(sd), ivar, ng)%Shchepetkin = .FALSE.
         LBC(side(sd), ivar, ng)%acquire = .FALSE.
       END DO
+    END DO
+  END DO
+  ! nudging coefficients of RadNud edges (constant ones: no climatology nudging coefficients)
+  LnudgeM2CLM(ng) = .FALSE.; LnudgeM3CLM(ng) = .FALSE.
+  DO it = 1, NTT
+    LnudgeTCLM(it,ng) = .FALSE.
+  END DO
+  DO sd = 1, 4
+    FSobc_out(ng,side(sd)) = p%obc_out(1,sd); FSobc_in(ng,side(sd)) = p%obc_in(1,sd)
+    ! (the reference has ONE pair for both components of the 2-D / 3-D momentum; the library's table has a column per
+    ! variable: take the column of the routine that is being called)
+    M2obc_out(ng,side(sd)) = p%obc_out(MERGE(3, 2, kind == 3),sd); M2obc_in(ng,side(sd)) = p%obc_in(MERGE(3, 2, kind == 3),sd)
+    M3obc_out(ng,side(sd)) = p%obc_out(MERGE(5, 4, kind == 5),sd); M3obc_in(ng,side(sd)) = p%obc_in(MERGE(5, 4, kind == 5),sd)
+    DO it = 1, NTT
+      Tobc_out(it,ng,side(sd)) = p%obc_out(6,sd); Tobc_in(it,ng,side(sd)) = p%obc_in(6,sd)
     END DO
   END DO
   ! ---- grid, masks, state ----

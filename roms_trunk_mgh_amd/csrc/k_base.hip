@@ -32,7 +32,7 @@ int check_lbc()
         if (c != LBC_PERIODIC) return roms_fail("check_lbc", "a periodic direction needs LBC = Per on both of its sides");
         continue;
       }
-      bool ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED || c == LBC_RADIATION;
+      bool ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED || c == LBC_RADIATION || c == LBC_RADIATION_NUDGING;
       if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT;
       if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER;
       if (!ok) return roms_fail("check_lbc", "lateral boundary condition not implemented for this variable");
@@ -75,11 +75,13 @@ struct BcArgs {
   double dt2d;
 };
 
-__device__ __forceinline__ double bc_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR)
+__device__ __forceinline__ double bc_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR,
+                                             bool &inward)
 {
   const double eps = 1.0E-20;
   double dXdt = x1_old - x1;
   const double dXdn = x1 - x2;
+  inward = (dXdt * dXdn) < 0.0;                    // selects the nudging time scale (RadNud), t3dbc_im.F:138-146
   if ((dXdt * dXdn) < 0.0) dXdt = 0.0;
   const double dXds = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
   const double cff = fmax(dXds * dXds + dXdn * dXdn, eps);
@@ -125,7 +127,7 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
   const long kb = (long)k * nij;
   double *X = a.X + kb;
   double x;
-  if (code == LBC_RADIATION) {
+  if (code == LBC_RADIATION || code == LBC_RADIATION_NUDGING) {
     const double *O = a.Xold + kb;
     double gL = O[P1] - O[P1 - st], gR = O[P1 + st] - O[P1];
     if (a.masked && (a.var == LBV_T || a.var == LBV_ZETA)) {      // zetabc.F:112-120, t3dbc_im.F:370-379
@@ -135,7 +137,13 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
     }
     // zetabc.F:424 -- on the southern edge the free surface takes its normal difference towards the boundary row
     const long Q2 = (a.var == LBV_ZETA && side == LBS_SOUTH) ? B : P2;
-    x = bc_radiate(O[B], O[P1], X[P1], X[Q2], gL, gR);
+    bool inward;
+    x = bc_radiate(O[B], O[P1], X[P1], X[Q2], gL, gR, inward);
+    if (code == LBC_RADIATION_NUDGING) {            // explicit nudging towards the boundary data, zetabc.F:162-166 ...
+      double tau = inward ? p.obc_in[side][a.var] : p.obc_out[side][a.var];
+      tau = tau * (a.var <= LBV_VBAR ? a.dt2d : p.dt);
+      x = x + tau * (a.D[B + kb] - O[B]);
+    }
   } else if (code == LBC_CLAMPED) {
     x = a.D[B + kb];
   } else if (code == LBC_CHAPMAN_IMPLICIT) {        // zetabc.F:193-220, :342, :491, :640
@@ -252,7 +260,9 @@ static void bc_know(const roms_step_idx_t *s, int *know, double *dt2d)
 static bool needs_know(const BcArgs &a)
 {
   for (int sd = 0; sd < 4; sd++)
-    if (a.code[sd] == LBC_RADIATION || a.code[sd] == LBC_FLATHER || a.code[sd] == LBC_CHAPMAN_IMPLICIT) return true;
+    if (a.code[sd] == LBC_RADIATION || a.code[sd] == LBC_RADIATION_NUDGING || a.code[sd] == LBC_FLATHER ||
+        a.code[sd] == LBC_CHAPMAN_IMPLICIT)
+      return true;
   return false;
 }
 

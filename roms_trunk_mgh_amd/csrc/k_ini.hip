@@ -108,6 +108,7 @@ bool any_lbc(int v, int c1, int c2)
   for (int sd = 0; sd < 4; sd++) {
     const int c = lbc_code(g_ctx.p, sd, v);
     if (c == c1 || c == c2) return true;
+    if (c1 == LBC_RADIATION && c == LBC_RADIATION_NUDGING) return true;     // RadNud sets LBC%radiation too
   }
   return false;
 }

@@ -70,6 +70,7 @@ MODULE roms_hip_mod
     REAL(c_double) :: blk_ZQ, blk_ZT, blk_ZW
     INTEGER(c_int) :: masking, pgf
     INTEGER(c_int) :: lbc(6,4)          ! C: lbc[side][variable]
+    REAL(c_double) :: obc_out(6,4), obc_in(6,4)   ! nudging coefficients of RadNud edges (1/s)
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)

@@ -18,9 +18,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
 
 CONFIGS = [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)]
-TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad"]),
-         "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
-         "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad"])}
+TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]),
+         "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
+         "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad", "RadNud"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad", "RadNud"])}
 
 
 def tag(config, mask):
@@ -59,6 +59,8 @@ def cases(st0):
                 st.p = type(st0.p).from_buffer_copy(st0.p)
                 for sd in ("south", "north"):
                     st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+                    st.p.obc_out[abi.LBS[sd]][abi.LBV[var]] = 2.0e-4          # RadNud: passive / active nudging (1/s)
+                    st.p.obc_in[abi.LBS[sd]][abi.LBV[var]] = 1.5e-3
                 nout = s.knew if kind in ("zetabc", "u2dbc", "v2dbc") else s.nnew
                 yield f"{kind}__{code}__{q}", kind, var, st, s, nout, st0.b.NT
 

@@ -72,9 +72,9 @@ def main_bc(config, mask=None):
             row = a[:, j - b.LBj]
             row += 1.0e-3 * (1.0 + np.abs(row)) * rng.standard_normal(row.shape)
     out = {"masking": int(st0.p.masking), "cases": {}}
-    table = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad"]),
-             "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
-             "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad"])}
+    table = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]),
+             "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
+             "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad", "RadNud"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad", "RadNud"])}
     steps = [util.step_idx(iic=5, iif=1, pred=1, kstp=1, krhs=1, knew=3), util.step_idx(iic=5, iif=3, pred=1, kstp=2, krhs=1, knew=3),
              util.step_idx(iic=5, iif=3, pred=0, kstp=1, krhs=3, knew=2)]
     for kind, (var, codes) in table.items():
@@ -85,7 +85,8 @@ def main_bc(config, mask=None):
                     st.p = type(st0.p).from_buffer_copy(st0.p)
                     for sd in ("south", "north"):
                         st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
-                        # Flather reads the free surface of the boundary row: give zeta an open condition too
+                        st.p.obc_out[abi.LBS[sd]][abi.LBV[var]] = 2.0e-4      # RadNud: passive / active nudging (1/s)
+                        st.p.obc_in[abi.LBS[sd]][abi.LBV[var]] = 1.5e-3
                 nout = s.knew if kind in ("zetabc", "u2dbc", "v2dbc") else s.nnew
                 itrc = st0.b.NT
                 ref.Ref(st_r).bc(kind, s, nout, itrc)
@@ -119,9 +120,9 @@ def basin_state(config, mask=None):
     return st0
 
 
-BC_TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad"]),
-            "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad"]),
-            "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad"])}
+BC_TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]),
+            "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
+            "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad", "RadNud"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad", "RadNud"])}
 
 
 def basin_cases(st0):
@@ -138,6 +139,8 @@ def basin_cases(st0):
                 st.p = type(st0.p).from_buffer_copy(st0.p)
                 for sd in ("west", "east", "south", "north"):
                     st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+                    st.p.obc_out[abi.LBS[sd]][abi.LBV[var]] = 2.0e-4          # RadNud: passive / active nudging (1/s)
+                    st.p.obc_in[abi.LBS[sd]][abi.LBV[var]] = 1.5e-3
                 nout = s.knew if kind in ("zetabc", "u2dbc", "v2dbc") else s.nnew
                 yield f"{kind}:{code}:{q}", kind, var, st, s, nout, st0.b.NT
 

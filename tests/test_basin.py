@@ -18,6 +18,9 @@ CONFIGS = ["BENCHMARK_TINY", "UPWELLING", "SEAMOUNT"]
 KERNELS = ["set_depth", "set_massflux", "omega", "set_zeta", "rho_eos", "prsgrd", "t3dmix2", "uv3dmix2", "rhs3d_tile",
            "pre_step3d", "rhs3d", "step2d", "step3d_uv", "step3d_t", "set_vbc", "wvelocity", "ini_zeta", "ini_fields"]
 OPEN = {"zeta": "Cha", "ubar": "Fla", "vbar": "Fla", "u": "Rad", "v": "Rad", "t": "Rad"}
+# the usual realistic set: radiation with nudging towards the boundary data for the 3-D variables (and here for the
+# 2-D ones as well, so that every routine's nudging branch runs)
+RADNUD = {v: "RadNud" for v in OPEN}
 
 
 def _open_all(st, table=OPEN):
@@ -25,6 +28,8 @@ def _open_all(st, table=OPEN):
     for sd in ("west", "east", "south", "north"):
         for var, code in table.items():
             st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+            st.p.obc_out[abi.LBS[sd]][abi.LBV[var]] = 2.0e-4          # 1/s (RadNud edges only)
+            st.p.obc_in[abi.LBS[sd]][abi.LBV[var]] = 1.5e-3
 
 
 def _state(config, kernel, open_edges):
@@ -33,7 +38,7 @@ def _state(config, kernel, open_edges):
         ov.update({"tnu2": 300.0} if config == "SEAMOUNT" else {"tnu2": 300.0, "visc2": 800.0})
     st0 = util.prepared_state(config, overrides=ov)
     if open_edges:
-        _open_all(st0)
+        _open_all(st0, RADNUD if open_edges == "radnud" else OPEN)
         rng = np.random.default_rng(5)
         for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
             st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
@@ -50,7 +55,7 @@ def _state(config, kernel, open_edges):
 
 
 @pytest.mark.parametrize("config", CONFIGS)
-@pytest.mark.parametrize("open_edges", [False, True], ids=["closed", "open"])
+@pytest.mark.parametrize("open_edges", [False, True, "radnud"], ids=["closed", "open", "radnud"])
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_hip_kernels_on_a_basin(config, kernel, open_edges):
     import oracle
@@ -74,7 +79,7 @@ def test_hip_kernels_on_a_basin(config, kernel, open_edges):
             h.close()
     diffs = util.compare_states(st_h, st_o)
     assert all(v <= 1e-12 for v in diffs.values()), diffs
-    if not (kernel == "ini_zeta" and open_edges):      # (Chapman edges: ini_zeta applies no condition, nothing to change)
+    if not (kernel == "ini_zeta" and open_edges):      # (Chapman / radiation edges: ini_zeta applies no condition)
         assert util.compare_states(st_o, st0), "kernel did not modify anything: test is vacuous"
 
 
@@ -97,14 +102,18 @@ def test_hip_step2d_loop_on_a_basin(config):
 
 
 @pytest.mark.parametrize("config,physics,open_edges", [("UPWELLING", False, False), ("BENCHMARK_TINY", True, False),
-                                                        ("SEAMOUNT", False, False), ("UPWELLING", False, True)])
+                                                        ("SEAMOUNT", False, False), ("UPWELLING", False, True),
+                                                        ("UPWELLING", False, "radnud")])
 def test_hip_100_steps_on_a_basin(config, physics, open_edges):
     import oracle
     from roms_trunk_mgh_amd import hip
     from roms_trunk_mgh_amd.state import rel_rms
     st_o = ana.make_tile(config, perturb=1.0 if config != "SEAMOUNT" else 0.0, overrides=BASIN)
     if open_edges:
-        _open_all(st_o)
+        _open_all(st_o, RADNUD if open_edges == "radnud" else OPEN)
+        if open_edges == "radnud":          # boundary data to nudge towards: the initial state
+            for name, src in (("zeta_bry", st_o["zeta"][:, :, 0]), ("t_bry", st_o["t"][:, :, :, 0, :])):
+                st_o[name][:] = src
     st_h = st_o.copy()
     mo = main3d.Main3D(oracle.Oracle(st_o), physics=physics, diagnostics=physics)
     mo.initial()
