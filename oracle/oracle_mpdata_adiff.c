@@ -25,6 +25,15 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
   (void)s;
   const double dt = p->dt;
   const double eps = 1.0E-18, eps2 = 1.0E-10, fac = 1.0;
+  const int mk = p->masking;
+  /* MASKING: face / point masks as multipliers (exactly 1 without the option: x * 1.0 = x bit for bit) */
+#define UM(i,j) (mk ? umask(i,j) : 1.0)
+#define VM(i,j) (mk ? vmask(i,j) : 1.0)
+  /* limiter masks, mpdata_adiff.F:826-835: land values do not enter Tmax, and Tmin takes a huge value there */
+  const double Large = 1.0E+20;
+#define MUP(i,j) (mk ? rmask(i,j) : 1.0)
+#define MDN(i,j) (mk ? MAX(1.0, MIN(Large, (1.0 - rmask(i,j)) * Large)) : 1.0)
+
   double *C_ = walloc(nis * (N + 1)), *Wm_ = walloc(nis * (N + 1));
   double *beta_dn_ = walloc(nis * njs * N), *beta_up_ = walloc(nis * njs * N), *odz_ = walloc(nis * njs * N);
 #define Ta(i,j,k)  Ta_[WS3(i,j,k)]
@@ -126,11 +135,12 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
         } else {
           const double Ck = C(i, k), Wk = Wm(i, k);
           double A = (Ta(i, j, k) - Ta(i - 1, j, k)) / (Ta(i, j, k) + Ta(i - 1, j, k) + eps);
+          /* MASKING (mpdata_adiff.F:288-297): each difference times the mask of its face; VM / UM = 1 without */
           double B = 0.03125 *
-                     ((Ta(i, j + 1, k) - Ta(i, j, k)) * (pn(i, j) + pn(i, j + 1)) +
-                      (Ta(i, j, k) - Ta(i, j - 1, k)) * (pn(i, j - 1) + pn(i, j)) +
-                      (Ta(i - 1, j + 1, k) - Ta(i - 1, j, k)) * (pn(i - 1, j) + pn(i - 1, j + 1)) +
-                      (Ta(i - 1, j, k) - Ta(i - 1, j - 1, k)) * (pn(i - 1, j - 1) + pn(i - 1, j)));
+                     ((Ta(i, j + 1, k) - Ta(i, j, k)) * (pn(i, j) + pn(i, j + 1)) * VM(i, j + 1) +
+                      (Ta(i, j, k) - Ta(i, j - 1, k)) * (pn(i, j - 1) + pn(i, j)) * VM(i, j) +
+                      (Ta(i - 1, j + 1, k) - Ta(i - 1, j, k)) * (pn(i - 1, j) + pn(i - 1, j + 1)) * VM(i - 1, j + 1) +
+                      (Ta(i - 1, j, k) - Ta(i - 1, j - 1, k)) * (pn(i - 1, j - 1) + pn(i - 1, j)) * VM(i - 1, j));
           B = B * (on_v(i, j) + on_v(i, j + 1) + on_v(i - 1, j) + on_v(i - 1, j + 1)) /
               (Ta(i - 1, j, k) + Ta(i, j, k) + eps);
           const double Um = 0.125 * Huon(i, j, k) * dt * (pm(i, j) + pm(i - 1, j)) * (pn(i, j) + pn(i - 1, j)) *
@@ -163,6 +173,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
           double ua = sig_alfa * X + sig_beta * XX + sig_gama * XX * X + sig_a * XY + sig_b * XX * Y +
                       sig_c * X * YY + sig_d * XZ + sig_e * XX * Z + sig_f * X * ZZ;
           Ua(i, j, k) = MIN(fabs(ua), fac * fabs(Um)) * copysign(1.0, ua);
+          if (mk) Ua(i, j, k) = Ua(i, j, k) * umask(i, j);                    /* :395 */
         }
       }
   }
@@ -216,11 +227,11 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
           Va(i, j, k) = 0.0;
         } else {
           const double Ck = C(i, k), Wk = Wm(i, k);
-          double A = 0.03125 *
-                     ((Ta(i + 1, j, k) - Ta(i, j, k)) * (pm(i + 1, j) + pm(i, j)) +
-                      (Ta(i, j, k) - Ta(i - 1, j, k)) * (pm(i - 1, j) + pm(i, j)) +
-                      (Ta(i + 1, j - 1, k) - Ta(i, j - 1, k)) * (pm(i + 1, j - 1) + pm(i, j - 1)) +
-                      (Ta(i, j - 1, k) - Ta(i - 1, j - 1, k)) * (pm(i - 1, j - 1) + pm(i, j - 1)));
+          double A = 0.03125 *                                                  /* MASKING, :458-467 */
+                     ((Ta(i + 1, j, k) - Ta(i, j, k)) * (pm(i + 1, j) + pm(i, j)) * UM(i + 1, j) +
+                      (Ta(i, j, k) - Ta(i - 1, j, k)) * (pm(i - 1, j) + pm(i, j)) * UM(i, j) +
+                      (Ta(i + 1, j - 1, k) - Ta(i, j - 1, k)) * (pm(i + 1, j - 1) + pm(i, j - 1)) * UM(i + 1, j - 1) +
+                      (Ta(i, j - 1, k) - Ta(i - 1, j - 1, k)) * (pm(i - 1, j - 1) + pm(i, j - 1)) * UM(i, j - 1));
           A = A * (om_u(i, j) + om_u(i + 1, j) + om_u(i, j - 1) + om_u(i + 1, j - 1)) /
               (Ta(i, j - 1, k) + Ta(i, j, k) + eps);
           const double B = (Ta(i, j, k) - Ta(i, j - 1, k)) / (Ta(i, j, k) + Ta(i, j - 1, k) + eps);
@@ -254,6 +265,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
           double va = sig_alfa * Y + sig_beta * YY + sig_gama * YY * Y + sig_a * XY + sig_b * Y * XX +
                       sig_c * YY * X + sig_d * YZ + sig_e * YY * Z + sig_f * Y * ZZ;
           Va(i, j, k) = MIN(fabs(va), fac * fabs(Vm)) * copysign(1.0, va);
+          if (mk) Va(i, j, k) = Va(i, j, k) * vmask(i, j);                    /* :568 */
         }
       }
   }
@@ -290,16 +302,16 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
         } else {
           C(i, k) = (Ta(i, j, k + 1) - Ta(i, j, k)) / (Ta(i, j, k + 1) + Ta(i, j, k) + eps);
           const double Ck = C(i, k);
-          double A = 0.0625 *
-                     ((Ta(i + 1, j, k + 1) - Ta(i, j, k + 1)) * (pm(i + 1, j) + pm(i, j)) +
-                      (Ta(i, j, k + 1) - Ta(i - 1, j, k + 1)) * (pm(i, j) + pm(i - 1, j)) +
-                      (Ta(i + 1, j, k) - Ta(i, j, k)) * (pm(i + 1, j) + pm(i, j)) +
-                      (Ta(i, j, k) - Ta(i - 1, j, k)) * (pm(i, j) + pm(i - 1, j)));
+          double A = 0.0625 *                                                   /* MASKING, :662-679 */
+                     ((Ta(i + 1, j, k + 1) - Ta(i, j, k + 1)) * (pm(i + 1, j) + pm(i, j)) * UM(i + 1, j) +
+                      (Ta(i, j, k + 1) - Ta(i - 1, j, k + 1)) * (pm(i, j) + pm(i - 1, j)) * UM(i, j) +
+                      (Ta(i + 1, j, k) - Ta(i, j, k)) * (pm(i + 1, j) + pm(i, j)) * UM(i + 1, j) +
+                      (Ta(i, j, k) - Ta(i - 1, j, k)) * (pm(i, j) + pm(i - 1, j)) * UM(i, j));
           double B = 0.0625 *
-                     ((Ta(i, j + 1, k + 1) - Ta(i, j, k + 1)) * (pn(i, j + 1) + pn(i, j)) +
-                      (Ta(i, j, k + 1) - Ta(i, j - 1, k + 1)) * (pn(i, j) + pn(i, j - 1)) +
-                      (Ta(i, j + 1, k) - Ta(i, j, k)) * (pn(i, j + 1) + pn(i, j)) +
-                      (Ta(i, j, k) - Ta(i, j - 1, k)) * (pn(i, j) + pn(i, j - 1)));
+                     ((Ta(i, j + 1, k + 1) - Ta(i, j, k + 1)) * (pn(i, j + 1) + pn(i, j)) * VM(i, j + 1) +
+                      (Ta(i, j, k + 1) - Ta(i, j - 1, k + 1)) * (pn(i, j) + pn(i, j - 1)) * VM(i, j) +
+                      (Ta(i, j + 1, k) - Ta(i, j, k)) * (pn(i, j + 1) + pn(i, j)) * VM(i, j + 1) +
+                      (Ta(i, j, k) - Ta(i, j - 1, k)) * (pn(i, j) + pn(i, j - 1)) * VM(i, j));
           A = A * (om_u(i + 1, j) + om_u(i, j)) / (Ta(i, j, k + 1) + Ta(i, j, k) + eps);
           B = B * (on_v(i, j + 1) + on_v(i, j)) / (Ta(i, j, k + 1) + Ta(i, j, k) + eps);
           const double Um = 0.03125 * dt *
@@ -342,6 +354,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
           double wa = sig_alfa * Z + sig_beta * ZZ + sig_gama * ZZ * Z + sig_a * YZ + sig_b * ZZ * Y +
                       sig_c * Z * YY + sig_d * XZ + sig_e * ZZ * X + sig_f * Z * XX;
           Wa(i, j, k) = MIN(fabs(wa), fac * fabs(Wk)) * copysign(1.0, wa);
+          if (mk) Wa(i, j, k) = Wa(i, j, k) * rmask(i, j);                    /* :801 */
         }
       }
     for (int i = IstrU - 1; i <= Iendp1; i++) {
@@ -354,20 +367,29 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
   for (int j = JstrV - 1; j <= Jendp1; j++) {
     for (int k = 1; k <= N; k++)
       for (int i = IstrU - 1; i <= Iendp1; i++) {
+        /* extrema over the point, its four horizontal neighbours and the level(s) above / below, of Ta and of
+         * t(:,:,:,3) -- :842-925; the list has 12 terms at k = 1 and k = N, 14 in between; the order of a MAX / MIN
+         * list does not matter.  MASKING: every term times mask_up (land values out of Tmax) / mask_dn (huge on
+         * land, out of Tmin), :826-835; both are exactly 1 without the option */
         double Tmax, Tmin;
-        if (k == 1 || k == N) {      /* no level below k = 1 / above k = N: 12-term lists */
-          const int kv = (k == 1) ? k + 1 : k - 1;
-          Tmax = MAX12(Ta(i - 1, j, k), t3(i - 1, j, k), Ta(i, j, k), t3(i, j, k), Ta(i + 1, j, k), t3(i + 1, j, k),
-                       Ta(i, j - 1, k), t3(i, j - 1, k), Ta(i, j + 1, k), t3(i, j + 1, k), Ta(i, j, kv), t3(i, j, kv));
-          Tmin = MIN12(Ta(i - 1, j, k), t3(i - 1, j, k), Ta(i, j, k), t3(i, j, k), Ta(i + 1, j, k), t3(i + 1, j, k),
-                       Ta(i, j - 1, k), t3(i, j - 1, k), Ta(i, j + 1, k), t3(i, j + 1, k), Ta(i, j, kv), t3(i, j, kv));
-        } else {
-          Tmax = MAX(MAX(MAX12(Ta(i - 1, j, k), t3(i - 1, j, k), Ta(i, j, k), t3(i, j, k), Ta(i + 1, j, k),
-                               t3(i + 1, j, k), Ta(i, j - 1, k), t3(i, j - 1, k), Ta(i, j + 1, k), t3(i, j + 1, k),
-                               Ta(i, j, k - 1), t3(i, j, k - 1)), Ta(i, j, k + 1)), t3(i, j, k + 1));
-          Tmin = MIN(MIN(MIN12(Ta(i - 1, j, k), t3(i - 1, j, k), Ta(i, j, k), t3(i, j, k), Ta(i + 1, j, k),
-                               t3(i + 1, j, k), Ta(i, j - 1, k), t3(i, j - 1, k), Ta(i, j + 1, k), t3(i, j + 1, k),
-                               Ta(i, j, k - 1), t3(i, j, k - 1)), Ta(i, j, k + 1)), t3(i, j, k + 1));
+        {
+          const int pi[5] = {i - 1, i, i + 1, i, i}, pj[5] = {j, j, j, j - 1, j + 1};
+          Tmax = Ta(pi[0], pj[0], k) * MUP(pi[0], pj[0]);
+          Tmin = Ta(pi[0], pj[0], k) * MDN(pi[0], pj[0]);
+          for (int q = 0; q < 5; q++) {
+            const double mu = MUP(pi[q], pj[q]), md = MDN(pi[q], pj[q]);
+            Tmax = MAX(Tmax, Ta(pi[q], pj[q], k) * mu); Tmax = MAX(Tmax, t3(pi[q], pj[q], k) * mu);
+            Tmin = MIN(Tmin, Ta(pi[q], pj[q], k) * md); Tmin = MIN(Tmin, t3(pi[q], pj[q], k) * md);
+          }
+          const double mu = MUP(i, j), md = MDN(i, j);
+          if (k > 1) {
+            Tmax = MAX(Tmax, Ta(i, j, k - 1) * mu); Tmax = MAX(Tmax, t3(i, j, k - 1) * mu);
+            Tmin = MIN(Tmin, Ta(i, j, k - 1) * md); Tmin = MIN(Tmin, t3(i, j, k - 1) * md);
+          }
+          if (k < N) {
+            Tmax = MAX(Tmax, Ta(i, j, k + 1) * mu); Tmax = MAX(Tmax, t3(i, j, k + 1) * mu);
+            Tmin = MIN(Tmin, Ta(i, j, k + 1) * md); Tmin = MIN(Tmin, t3(i, j, k + 1) * md);
+          }
         }
         double cff1, cff2;
         if (k == 1) {
@@ -404,12 +426,14 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
         const double cff1 = MIN(MIN(beta_dn(i - 1, j, k), beta_up(i, j, k)), 1.0);
         const double cff2 = MIN(MIN(beta_up(i - 1, j, k), beta_dn(i, j, k)), 1.0);
         Ua(i, j, k) = (cff1 * MAX(0.0, Ua(i, j, k)) + cff2 * MIN(0.0, Ua(i, j, k))) * cff * om_u(i, j);
+        if (mk) Ua(i, j, k) = Ua(i, j, k) * umask(i, j);                      /* :991 */
       }
     for (int j = JstrV; j <= Jendp1; j++)
       for (int i = Istr; i <= Iend; i++) {
         const double cff1 = MIN(MIN(beta_dn(i, j - 1, k), beta_up(i, j, k)), 1.0);
         const double cff2 = MIN(MIN(beta_up(i, j - 1, k), beta_dn(i, j, k)), 1.0);
         Va(i, j, k) = (cff1 * MAX(0.0, Va(i, j, k)) + cff2 * MIN(0.0, Va(i, j, k))) * cff * on_v(i, j);
+        if (mk) Va(i, j, k) = Va(i, j, k) * vmask(i, j);                      /* :1006 */
       }
     if (k < N)
       for (int j = Jstr; j <= Jend; j++)
@@ -418,6 +442,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
           const double cff2 = MIN(MIN(beta_up(i, j, k), beta_dn(i, j, k + 1)), 1.0);
           Wa(i, j, k) = (cff1 * MAX(0.0, Wa(i, j, k)) + cff2 * MIN(0.0, Wa(i, j, k))) * cff * omn(i, j) *
                         (z_r(i, j, k + 1) - z_r(i, j, k));
+          if (mk) Wa(i, j, k) = Wa(i, j, k) * rmask(i, j);                    /* :1022 */
         }
   }
 

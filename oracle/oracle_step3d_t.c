@@ -69,7 +69,6 @@ int oracle_step3d_t(OARGS)
   for (int itrc = 1; itrc <= NT; itrc++) {
     const int ha = p->Hadv[itrc - 1];
     /* three-point footprint: refresh the ghost points of t(nnew) first, :369-386 */
-    if (p->masking && ha == ADV_MPDATA) return 8;      /* MASKING variant of mpdata_adiff.F not restated */
     if (ha == ADV_MPDATA || ha == ADV_HSIMT) o_exchange3d(b, GT_R, N, &t(LBi, LBj, 1, nnew, itrc));
     for (int k = 1; k <= N; k++) {
       if (ha == ADV_MPDATA) {

@@ -735,7 +735,6 @@ FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc
 END FUNCTION ref_ana
 #endif
 
-#ifndef MASKING      /* mpdata_adiff_tile takes the masks as extra arguments; its MASKING variant is not pinned */
 !-----------------------------------------------------------------------
 !  mpdata_adiff_tile (ROMS/Nonlinear/mpdata_adiff.F:38) on caller-held private
 !  arrays: oHz, Ta, Ua, Va are (IminS:ImaxS,JminS:JmaxS,N), Wa is (..,..,0:N),
@@ -791,12 +790,19 @@ FUNCTION ref_mpdata_adiff (b, p, F, oHz, t3, Ta, Ua, Va, Wa) BIND(C, name='ref_m
   CALL c_f_pointer (Ua,  pUa,  (/nis,njs,NN/))
   CALL c_f_pointer (Va,  pVa,  (/nis,njs,NN/))
   CALL c_f_pointer (Wa,  pWa,  (/nis,njs,NN+1/))
+#ifdef MASKING
+  CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
+  CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
+  CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
+#endif
   CALL mpdata_adiff_tile (ng, tile, LBi, UBi, LBj, UBj, IminS, ImaxS, JminS, JmaxS,   &
+#ifdef MASKING
+ &                        GRID(ng)%rmask, GRID(ng)%umask, GRID(ng)%vmask, &
+#endif
  &                        GRID(ng)%pm, GRID(ng)%pn, GRID(ng)%omn, GRID(ng)%om_u, GRID(ng)%on_v, &
  &                        GRID(ng)%z_r, poHz, GRID(ng)%Huon, GRID(ng)%Hvom, OCEAN(ng)%W, &
  &                        pt3, pTa, pUa, pVa, pWa)
 END FUNCTION ref_mpdata_adiff
-#endif
 
 !-----------------------------------------------------------------------
 !  The lateral boundary-condition routines of the reference on the S/N edges, through their own _tile

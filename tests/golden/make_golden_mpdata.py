@@ -2,7 +2,8 @@
 (ROMS/Nonlinear/mpdata_adiff.F compiled with flang into oracle/_ref, see oracle/build_ref.sh).
 Inputs: tests/util.prepared_state + util.mpdata_private_arrays (deterministic).  Stored: the
 reference outputs Ua, Va, Wa at three levels (bottom, middle, top) and the SHA-256 of the full
-output arrays, so the fixture stays small while every element is still checked.
+output arrays, so the fixture stays small while every element is still checked.  A second fixture
+(ref_mpdata_<CONFIG>_MASK.npz) comes from the MASKING build on the island grid.
 
     python tests/golden/make_golden_mpdata.py
 """
@@ -26,10 +27,10 @@ def sha(*arrays):
     return h.hexdigest()
 
 
-def main():
+def main(mask=None):
     import util
     from oracle import ref
-    st = util.prepared_state(CONFIG, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"})
+    st = util.prepared_state(CONFIG, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}, mask=mask)
     oHz, Ta0, t3 = util.mpdata_private_arrays(st)
     nis, njs, N = Ta0.shape
     Ta = Ta0.copy(order="F")
@@ -38,11 +39,16 @@ def main():
     Wa = np.zeros((nis, njs, N + 1), order="F")
     ref.Ref(st).mpdata_adiff(oHz, t3, Ta, Ua, Va, Wa)
     ks = [0, N // 2, N - 2]
-    np.savez_compressed(os.path.join(HERE, f"ref_mpdata_{CONFIG}.npz"),
+    np.savez_compressed(os.path.join(HERE, f"ref_mpdata_{CONFIG}{'_MASK' if mask else ''}.npz"),
                         input_sha256=np.array(sha(oHz, Ta0, t3)), levels=np.array(ks),
                         Ua=Ua[:, :, ks], Va=Va[:, :, ks], Wa=Wa[:, :, [k + 1 for k in ks]], Ta=Ta[:, :, ks],
                         output_sha256=np.array(sha(Ta, Ua, Va, Wa)))
 
 
 if __name__ == "__main__":
-    main()
+    import subprocess
+    if len(sys.argv) > 1:
+        main(None if sys.argv[1] == "-" else sys.argv[1])
+    else:                       # one process per build of the reference (it keeps module state)
+        for m in ("-", "island"):
+            subprocess.run([sys.executable, os.path.abspath(__file__), m], check=True)

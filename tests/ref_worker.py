@@ -226,14 +226,15 @@ def main_ini(config, mask=None):
     print(json.dumps(out))
 
 
-def main_mpdata(config):
+def main_mpdata(config, mask=None):
     """mpdata_adiff_tile: reference Fortran vs C oracle on the same private arrays, with the
-    3-ghost-point bounds an MPDATA run uses (also pins get_bounds for NghostPoints = 3)."""
+    3-ghost-point bounds an MPDATA run uses (also pins get_bounds for NghostPoints = 3).  mask = "island": the
+    MASKING build (face masks in the cross terms, land out of the limiter's extrema, masked transports)."""
     import util
     from oracle import ref
-    st = util.prepared_state(config, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"})
+    st = util.prepared_state(config, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}, mask=mask)
     b = st.b
-    out = {"NghostPoints": int(b.NghostPoints)}
+    out = {"NghostPoints": int(b.NghostPoints), "masking": int(st.p.masking)}
     r = ref.Ref(st)
     bb = r.bounds()
     mine = b.as_dict()
@@ -431,8 +432,8 @@ if __name__ == "__main__":
                      basin=sys.argv[2] == "physics_basin")
     elif len(sys.argv) > 2 and sys.argv[2] == "basin":
         main(sys.argv[1], basin=True)
-    elif len(sys.argv) > 2 and sys.argv[2] == "mpdata":
-        main_mpdata(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] in ("mpdata", "mpdata_mask"):
+        main_mpdata(sys.argv[1], mask="island" if sys.argv[2] == "mpdata_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] == "mask":
         main(sys.argv[1], mask="island")
     elif len(sys.argv) > 2 and sys.argv[2] in ("pg31", "wj"):

@@ -343,12 +343,14 @@ def test_oracle_reproduces_reference_boundary_conditions_on_a_basin(config, mask
     assert n == 69
 
 
-def test_oracle_reproduces_reference_mpdata_adiff():
+@pytest.mark.parametrize("mask", [None, "island"])
+def test_oracle_reproduces_reference_mpdata_adiff(mask):
     """mpdata_adiff_tile: the committed outputs of the reference's Fortran (three levels stored,
-    all elements through a SHA-256) vs the C oracle on the same deterministic inputs."""
+    all elements through a SHA-256) vs the C oracle on the same deterministic inputs; the second fixture is the
+    MASKING build on the island grid."""
     import hashlib
     import util
-    path = os.path.join(HERE, "golden", "ref_mpdata_BENCHMARK_TINY.npz")
+    path = os.path.join(HERE, "golden", f"ref_mpdata_BENCHMARK_TINY{'_MASK' if mask else ''}.npz")
     g = np.load(path)
 
     def sha(*arrays):
@@ -357,7 +359,7 @@ def test_oracle_reproduces_reference_mpdata_adiff():
             h.update(np.ascontiguousarray(a + 0.0).tobytes())
         return h.hexdigest()
 
-    st = util.prepared_state("BENCHMARK_TINY", overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"})
+    st = util.prepared_state("BENCHMARK_TINY", overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}, mask=mask)
     oHz, Ta0, t3 = util.mpdata_private_arrays(st)
     assert sha(oHz, Ta0, t3) == str(g["input_sha256"]), "fixture inputs changed: regenerate with make_golden_mpdata.py"
     Ta, Ua, Va, Wa = util.oracle_mpdata_adiff(st, oHz, Ta0, t3)

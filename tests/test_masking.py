@@ -34,10 +34,12 @@ def test_mask_set_follows_reference_rules():
     assert np.all(pk[1:, 1:][nl == 0] == 1.0) and np.all(pk[1:, 1:][nl >= 3] == 0.0)
 
 
-@pytest.mark.parametrize("config", CONFIGS)
-def test_oracle_land_stays_land_and_content_is_conserved(config):
+@pytest.mark.parametrize("config,adv", [(c, None) for c in CONFIGS] + [("BENCHMARK_TINY", "MPDATA"), ("UPWELLING", "MPDATA")])
+def test_oracle_land_stays_land_and_content_is_conserved(config, adv):
+    """(adv = "MPDATA": all tracers with MPDATA -- mpdata_adiff.F's masked cross terms, limiter extrema without land
+    values and masked transports, pinned against the reference built with -DMASKING.)"""
     import oracle
-    st = ana.make_tile(config, perturb=1.0, mask="island")
+    st = ana.make_tile(config, perturb=1.0, mask="island", overrides={"Hadv": adv, "Vadv": adv} if adv else None)
     b = st.b
     if b.NT > 1:
         zz = (st.z_r0 - st.z_r0.min()) / (st.z_r0.max() - st.z_r0.min())
