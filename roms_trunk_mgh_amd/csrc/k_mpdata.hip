@@ -158,7 +158,10 @@ __device__ __forceinline__ void face_CW(const gcd_t Ta, const gcd_t z_r, const g
 // One launch for the three faces (they share the Ta, Huon, Hvom, oHz loads): 208 VGPRs, two waves per SIMD.
 // The kernel is FP64-issue bound (per cell and level ~1800 VALU instructions, 49 divisions among them); one
 // launch per face raises the occupancy to 3-4 waves but repeats the shared loads and was 20 % slower.
-template <bool FAST>
+// MASK (MASKING applications, separate instantiations so that the unmasked kernel keeps its code): the horizontal
+// differences of the cross terms times the mask of their face (mpdata_adiff.F:288-297, :470-480, :640-660) and
+// the clamped velocities times umask / vmask / rmask (:395, :568, :801).
+template <bool FAST, bool MASK>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
 {
@@ -183,6 +186,9 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
   const bool v_wall_n = b.north_edge && !b.NSperiodic && j == b.Jend + 1;   // Va(i,Jend+1) = 0, mpdata_adiff.F:694-700
   const gcd_t oHzA = (gcd_t)m.oHz, odzA = (gcd_t)m.odz;
   auto oHz = [&](long x) { return oHzA[x]; };
+  const gcd_t umk = (gcd_t)c->F.umask, vmk = (gcd_t)c->F.vmask, rmk = (gcd_t)c->F.rmask;
+  auto UM = [&](double x, long q) { if constexpr (MASK) return x * umk[q]; else return x; };   // x * umask(q)
+  auto VM = [&](double x, long q) { if constexpr (MASK) return x * vmk[q]; else return x; };
   // one thread per (i,j,k): nothing is carried from level to level, and with ~1200 FP64 instructions per
   // cell the kernel needs every wave it can get (a k-loop per column ran at two waves per SIMD)
   {
@@ -198,9 +204,9 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         face_CW<FAST>(Ta, z_r, odzA, Wv, pm, pn, a2, a, -1, nij, k, N, dt, Ck, Wk);
         const double A = DV(T0 - Tw, T0 + Tw + EPS_MP);
         double B = 0.03125 *
-                   ((Ta[a + ni] - T0) * (pn[a2] + pn[a2 + ni]) + (T0 - Ta[a - ni]) * (pn[a2 - ni] + pn[a2]) +
-                    (Ta[a - 1 + ni] - Tw) * (pn[a2 - 1] + pn[a2 - 1 + ni]) +
-                    (Tw - Ta[a - 1 - ni]) * (pn[a2 - 1 - ni] + pn[a2 - 1]));
+                   (VM((Ta[a + ni] - T0) * (pn[a2] + pn[a2 + ni]), a2 + ni) + VM((T0 - Ta[a - ni]) * (pn[a2 - ni] + pn[a2]), a2) +
+                    VM((Ta[a - 1 + ni] - Tw) * (pn[a2 - 1] + pn[a2 - 1 + ni]), a2 - 1 + ni) +
+                    VM((Tw - Ta[a - 1 - ni]) * (pn[a2 - 1 - ni] + pn[a2 - 1]), a2 - 1));
         B = DV(B * (on_v[a2] + on_v[a2 + ni] + on_v[a2 - 1] + on_v[a2 - 1 + ni]), Tw + T0 + EPS_MP);
         const double Um = 0.125 * Huon[a] * dt * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a - 1) + oHz(a));
         const double Vm = 0.03125 * dt *
@@ -229,6 +235,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         const double u0 = sig_alfa * X + sig_beta * XX + sig_gama * XX * X + sig_a * XY + sig_b * XX * Y +
                           sig_c * X * YY + sig_d * XZ + sig_e * XX * Z + sig_f * X * ZZ;
         ua = fmin(fabs(u0), 1.0 * fabs(Um)) * copysign(1.0, u0);
+        ua = UM(ua, a2);
       }
       Ua[a] = ua;
     }
@@ -240,9 +247,9 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         double Ck, Wk;
         face_CW<FAST>(Ta, z_r, odzA, Wv, pm, pn, a2, a, -ni, nij, k, N, dt, Ck, Wk);
         double A = 0.03125 *
-                   ((Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]) + (T0 - Ta[a - 1]) * (pm[a2 - 1] + pm[a2]) +
-                    (Ta[a + 1 - ni] - Ts) * (pm[a2 + 1 - ni] + pm[a2 - ni]) +
-                    (Ts - Ta[a - 1 - ni]) * (pm[a2 - 1 - ni] + pm[a2 - ni]));
+                   (UM((Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]), a2 + 1) + UM((T0 - Ta[a - 1]) * (pm[a2 - 1] + pm[a2]), a2) +
+                    UM((Ta[a + 1 - ni] - Ts) * (pm[a2 + 1 - ni] + pm[a2 - ni]), a2 + 1 - ni) +
+                    UM((Ts - Ta[a - 1 - ni]) * (pm[a2 - 1 - ni] + pm[a2 - ni]), a2 - ni));
         A = DV(A * (om_u[a2] + om_u[a2 + 1] + om_u[a2 - ni] + om_u[a2 + 1 - ni]), Ts + T0 + EPS_MP);
         const double B = DV(T0 - Ts, T0 + Ts + EPS_MP);
         const double Um = 0.03125 * dt *
@@ -272,6 +279,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         const double v0 = sig_alfa * Y + sig_beta * YY + sig_gama * YY * Y + sig_a * XY + sig_b * Y * XX +
                           sig_c * YY * X + sig_d * YZ + sig_e * YY * Z + sig_f * Y * ZZ;
         va = fmin(fabs(v0), 1.0 * fabs(Vm)) * copysign(1.0, v0);
+        va = VM(va, a2);
       }
       Va[a] = va;
       // closed southern wall: Va(i,Jstr) = 0 (:683-689); row Jstr is below this kernel's Va range
@@ -287,11 +295,11 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
       if (!((T0 <= 0.0) || (Tu <= 0.0) || (fabs(T0 - Tu) <= EPS2_MP))) {
         const double Ck = DV(Tu - T0, Tu + T0 + EPS_MP);
         double A = 0.0625 *
-                   ((Ta[a + 1 + nij] - Tu) * (pm[a2 + 1] + pm[a2]) + (Tu - Ta[a - 1 + nij]) * (pm[a2] + pm[a2 - 1]) +
-                    (Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]) + (T0 - Ta[a - 1]) * (pm[a2] + pm[a2 - 1]));
+                   (UM((Ta[a + 1 + nij] - Tu) * (pm[a2 + 1] + pm[a2]), a2 + 1) + UM((Tu - Ta[a - 1 + nij]) * (pm[a2] + pm[a2 - 1]), a2) +
+                    UM((Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]), a2 + 1) + UM((T0 - Ta[a - 1]) * (pm[a2] + pm[a2 - 1]), a2));
         double B = 0.0625 *
-                   ((Ta[a + ni + nij] - Tu) * (pn[a2 + ni] + pn[a2]) + (Tu - Ta[a - ni + nij]) * (pn[a2] + pn[a2 - ni]) +
-                    (Ta[a + ni] - T0) * (pn[a2 + ni] + pn[a2]) + (T0 - Ta[a - ni]) * (pn[a2] + pn[a2 - ni]));
+                   (VM((Ta[a + ni + nij] - Tu) * (pn[a2 + ni] + pn[a2]), a2 + ni) + VM((Tu - Ta[a - ni + nij]) * (pn[a2] + pn[a2 - ni]), a2) +
+                    VM((Ta[a + ni] - T0) * (pn[a2 + ni] + pn[a2]), a2 + ni) + VM((T0 - Ta[a - ni]) * (pn[a2] + pn[a2 - ni]), a2));
         A = DV(A * (om_u[a2 + 1] + om_u[a2]), Tu + T0 + EPS_MP);
         B = DV(B * (on_v[a2 + ni] + on_v[a2]), Tu + T0 + EPS_MP);
         const double Um = 0.03125 * dt *
@@ -326,6 +334,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         const double w0 = sig_alfa * Z + sig_beta * ZZ + sig_gama * ZZ * Z + sig_a * YZ + sig_b * ZZ * Y +
                           sig_c * Z * YY + sig_d * XZ + sig_e * ZZ * X + sig_f * Z * XX;
         wa = fmin(fabs(w0), 1.0 * fabs(Wk)) * copysign(1.0, w0);
+        if constexpr (MASK) wa = wa * rmk[a2];
       }
       Wa[aw] = wa;
     }
@@ -335,6 +344,9 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
 #undef DV
 
 // ------------------------------------------------------ K3: beta_up/dn ----
+// MASK: every term of the extrema times mask_up = rmask (land values out of Tmax) / mask_dn = 1 on water, 1e20 on
+// land (out of Tmin) of its column, mpdata_adiff.F:826-835.
+template <bool MASK>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_mp_beta(const RomsDev *__restrict__ c, MpArgs m)
 {
@@ -353,17 +365,39 @@ k_mp_beta(const RomsDev *__restrict__ c, MpArgs m)
     const long a = a2 + (long)(k - 1) * nij;
     const long aw = a + nij;                                     // Wa(i,j,k); Wa(i,j,k-1) = Wa[a]
     const double T0 = Ta[a], Tw = Ta[a - 1], Te = Ta[a + 1], Ts = Ta[a - ni], Tn = Ta[a + ni];
-    double Tmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
-                                 t3[a - ni]), Tn), t3[a + ni]);
-    double Tmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
-                                 t3[a - ni]), Tn), t3[a + ni]);
-    if (k > 1) {
-      Tmax = fmax(fmax(Tmax, Ta[a - nij]), t3[a - nij]);
-      Tmin = fmin(fmin(Tmin, Ta[a - nij]), t3[a - nij]);
-    }
-    if (k < N) {
-      Tmax = fmax(fmax(Tmax, Ta[a + nij]), t3[a + nij]);
-      Tmin = fmin(fmin(Tmin, Ta[a + nij]), t3[a + nij]);
+    double Tmax, Tmin;
+    if constexpr (!MASK) {
+      Tmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
+                            t3[a - ni]), Tn), t3[a + ni]);
+      Tmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
+                            t3[a - ni]), Tn), t3[a + ni]);
+      if (k > 1) {
+        Tmax = fmax(fmax(Tmax, Ta[a - nij]), t3[a - nij]);
+        Tmin = fmin(fmin(Tmin, Ta[a - nij]), t3[a - nij]);
+      }
+      if (k < N) {
+        Tmax = fmax(fmax(Tmax, Ta[a + nij]), t3[a + nij]);
+        Tmin = fmin(fmin(Tmin, Ta[a + nij]), t3[a + nij]);
+      }
+    } else {
+      const gcd_t rmk = (gcd_t)c->F.rmask;
+      const double Large = 1.0E+20;
+      auto mdn = [&](double r) { return fmax(1.0, fmin(Large, (1.0 - r) * Large)); };
+      const double mu0 = rmk[a2], md0 = mdn(mu0);
+      Tmax = T0 * mu0;
+      Tmin = T0 * md0;
+      auto take = [&](double mu, double md, double x) { Tmax = fmax(Tmax, x * mu); Tmin = fmin(Tmin, x * md); };
+      take(mu0, md0, t3[a]);
+      const long dq[4] = {-1, 1, -(long)ni, (long)ni};
+      const double Tq[4] = {Tw, Te, Ts, Tn};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double mu = rmk[a2 + dq[q]], md = mdn(mu);
+        take(mu, md, Tq[q]);
+        take(mu, md, t3[a + dq[q]]);
+      }
+      if (k > 1) { take(mu0, md0, Ta[a - nij]); take(mu0, md0, t3[a - nij]); }
+      if (k < N) { take(mu0, md0, Ta[a + nij]); take(mu0, md0, t3[a + nij]); }
     }
     const double ua0 = Ua[a], ua1 = Ua[a + 1], va0 = Va[a], va1 = Va[a + ni];
     double cff1 = Tw * fmax(0.0, ua0) - Te * fmin(0.0, ua1) + Ts * fmax(0.0, va0) - Tn * fmin(0.0, va1);
@@ -384,7 +418,9 @@ k_mp_beta(const RomsDev *__restrict__ c, MpArgs m)
 }
 
 // -------------------------- K4: limited transports, update, tridiagonal ----
-template <int NMAX>
+// MASK: the limited transports times umask / vmask / rmask (mpdata_adiff.F:991, :1006, :1022) and the new tracer
+// times rmask (step3d_t.F:1586-1596).
+template <int NMAX, bool MASK>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
 {
@@ -419,6 +455,10 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
     const double cff2 = fmin(fmin(bup[x - ni], bdn[x]), 1.0);
     return (cff1 * fmax(0.0, Va[x]) + cff2 * fmin(0.0, Va[x])) * cffa * on;
   };
+  double um0 = 1.0, um1 = 1.0, vm0 = 1.0, vm1 = 1.0, rm0 = 1.0;
+  if constexpr (MASK) {
+    um0 = GF(umask)[a2]; um1 = GF(umask)[a2 + 1]; vm0 = GF(vmask)[a2]; vm1 = GF(vmask)[a2 + ni]; rm0 = GF(rmask)[a2];
+  }
   double DCm[NMAX + 1];      // right-hand side / solution
   double CFm[NMAX + 1];
   double FCm1 = 0.0;         // corrected vertical flux through the bottom face
@@ -427,9 +467,11 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
     if (k <= N) {
       const long a = a2 + (long)(k - 1) * nij;
       const double T0 = Ta[a], hz = Hz[a];
-      const double u0 = lim_u(a, omu0), u1 = lim_u(a + 1, omu1);
-      const double v0 = v0_wall ? 0.0 : lim_v(a, onv0);
-      const double v1 = v1_wall ? 0.0 : lim_v(a + ni, onv1);
+      double u0 = lim_u(a, omu0), u1 = lim_u(a + 1, omu1);
+      double v0 = lim_v(a, onv0), v1 = lim_v(a + ni, onv1);
+      if constexpr (MASK) { u0 = u0 * um0; u1 = u1 * um1; v0 = v0 * vm0; v1 = v1 * vm1; }
+      if (v0_wall) v0 = 0.0;
+      if (v1_wall) v1 = 0.0;
       // corrected horizontal fluxes, step3d_t.F:1238-1255
       const double FXi = (fmax(u0, 0.0) * Ta[a - 1] + fmin(u0, 0.0) * T0) * 0.5 * (hz + Hz[a - 1]) * onu0;
       const double FXip1 = (fmax(u1, 0.0) * T0 + fmin(u1, 0.0) * Ta[a + 1]) * 0.5 * (Hz[a + 1] + hz) * onu1;
@@ -445,7 +487,8 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
         const long aw = a + nij;
         const double c1 = fmin(fmin(bdn[a], bup[a + nij]), 1.0);
         const double c2 = fmin(fmin(bup[a], bdn[a + nij]), 1.0);
-        const double w = (c1 * fmax(0.0, Wa[aw]) + c2 * fmin(0.0, Wa[aw])) * cffa * omn * (z_r[a + nij] - z_r[a]);
+        double w = (c1 * fmax(0.0, Wa[aw]) + c2 * fmin(0.0, Wa[aw])) * cffa * omn * (z_r[a + nij] - z_r[a]);
+        if constexpr (MASK) w = w * rm0;
         FCk = fmax(w, 0.0) * T0 + fmin(w, 0.0) * Ta[a + nij];
       }
       tv = tv - cpp * (FCk - FCm1);                               // :1305 (m Tunits)
@@ -492,6 +535,7 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
       if (k == N) v = DCm[k];
       else v = DCm[k] - CFm[k] * up;
       up = v;
+      if constexpr (MASK) v = v * rm0;
       tn[a] = v;
     }
   }
@@ -526,19 +570,24 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
   KERNEL_CHECK("k_mp_ta");
   {
     dim3 g3 = grid_tile_level(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1, b.N);
-    hipLaunchKernelGGL(g_ctx.p.mpdata_fast ? k_mp_adiff<true> : k_mp_adiff<false>, g3, block2d(), 0,
-                       g_ctx.stream, g_ctx.devc, m);
+    void (*kern)(const RomsDev *, MpArgs) = g_ctx.p.masking ? (g_ctx.p.mpdata_fast ? k_mp_adiff<true, true> : k_mp_adiff<false, true>)
+                                : (g_ctx.p.mpdata_fast ? k_mp_adiff<true, false> : k_mp_adiff<false, false>);
+    hipLaunchKernelGGL(kern, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
   }
   KERNEL_CHECK("k_mp_adiff");
   {
     dim3 g3 = grid_tile_level(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1, b.N);
-    hipLaunchKernelGGL(k_mp_beta, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+    void (*beta)(const RomsDev *, MpArgs) = g_ctx.p.masking ? k_mp_beta<true> : k_mp_beta<false>;
+    hipLaunchKernelGGL(beta, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
   }
   KERNEL_CHECK("k_mp_beta");
   const dim3 g = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
-  if (b.N <= 16) hipLaunchKernelGGL((k_mp_update<16>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
-  else if (b.N <= 32) hipLaunchKernelGGL((k_mp_update<32>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
-  else hipLaunchKernelGGL((k_mp_update<ROMS_MAXN>), g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+  const bool mk = g_ctx.p.masking != 0;
+  void (*upd)(const RomsDev *, MpArgs);
+  if (b.N <= 16) upd = mk ? k_mp_update<16, true> : k_mp_update<16, false>;
+  else if (b.N <= 32) upd = mk ? k_mp_update<32, true> : k_mp_update<32, false>;
+  else upd = mk ? k_mp_update<ROMS_MAXN, true> : k_mp_update<ROMS_MAXN, false>;
+  hipLaunchKernelGGL(upd, g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
   KERNEL_CHECK("k_mp_update");
   return 0;
 }

@@ -580,7 +580,6 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
         break;
       }
       case ADV_MPDATA * 16 + ADV_MPDATA:
-        if (p.masking) return roms_fail("roms_hip_step3d_t", "MASKING is not built for MPDATA tracers (mpdata_adiff.F:290-1025)");
         if (!b.EWperiodic) return roms_fail("roms_hip_step3d_t", "MPDATA is built for E-W periodic grids only");
         // multi-pass: upstream step, anti-diffusive velocities, FCT limiter, corrected step (k_mpdata.hip)
         for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q, q == 0);

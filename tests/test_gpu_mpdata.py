@@ -17,9 +17,9 @@ MP = {"Hadv": "MPDATA", "Vadv": "MPDATA"}
 MIXED = {"Hadv": "U3", "Vadv": "C4", "Hadv_list": ["U3", "U3"] + ["MPDATA"] * 4, "Vadv_list": ["C4", "C4"] + ["MPDATA"] * 4}
 
 
-def _pair(config, kernel, s, overrides, prep=None):
+def _pair(config, kernel, s, overrides, prep=None, mask=None):
     import oracle
-    st0 = util.prepared_state(config, NT=6, overrides=overrides)
+    st0 = util.prepared_state(config, NT=6, overrides=overrides, mask=mask)
     assert st0.b.NghostPoints == 3
     if prep:
         prep(st0)
@@ -44,6 +44,19 @@ def test_step3d_t_mpdata(config, ov):
 
 
 @pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING"])
+@pytest.mark.parametrize("ov", [MP, MIXED], ids=["all6", "mixed"])
+def test_step3d_t_mpdata_masked(config, ov):
+    """MASKING (island grid): masked cross terms, land out of the limiter's extrema, masked transports
+    (mpdata_adiff.F:288-1025); the oracle's mpdata_adiff is pinned against the reference's MASKING build."""
+    st_h, st_o, st0 = _pair(config, "step3d_t", util.step_idx(), ov, prep=util.hz_weighted_tnew, mask="island")
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= TOL for v in diffs.values()), diffs
+    assert util.max_rel_diff(st_o["t"][..., 5], st0["t"][..., 5]) > 1e-6
+    land = st0["rmask"] == 0
+    assert land.any() and np.all(st_h["t"][..., 1, :][land] == 0.0)
+
+
+@pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING"])
 @pytest.mark.parametrize("iic", [1, 5])
 def test_pre_step3d_mpdata(config, iic):
     st_h, st_o, st0 = _pair(config, "pre_step3d", util.step_idx(iic=iic), MP)
@@ -59,14 +72,15 @@ def test_other_kernels_with_three_ghost_points(kernel):
     assert all(v <= TOL for v in diffs.values()), diffs
 
 
-@pytest.mark.parametrize("fast", [0, 1], ids=["ieee_div", "refined_rcp"])
-def test_100_steps_mpdata(fast):
+@pytest.mark.parametrize("fast,mask", [(0, None), (1, None), (0, "island"), (1, "island")],
+                         ids=["ieee_div", "refined_rcp", "ieee_div_masked", "refined_rcp_masked"])
+def test_100_steps_mpdata(fast, mask):
     """configuration 5 in small: BENCHMARK physics, T/S + 4 passive tracers, all MPDATA.  fast = 1: the
     quotients of mpdata_adiff as refined reciprocals (roms_params_t.mpdata_fast, the variant bench.py times on
     configuration 5) -- not bit-identical to the oracle, held to the same north-star bound, 1e-10 relative RMS
-    after 100 steps."""
+    after 100 steps.  mask: the same on the island grid (MASKING)."""
     import oracle
-    st_o = ana.make_tile("BENCHMARK_TINY", NT=6, overrides=MP, perturb=1.0)
+    st_o = ana.make_tile("BENCHMARK_TINY", NT=6, overrides=MP, perturb=1.0, mask=mask)
     st_h = st_o.copy()
     st_h.p = type(st_o.p).from_buffer_copy(st_o.p)
     st_h.p.mpdata_fast = fast
@@ -90,7 +104,12 @@ def test_100_steps_mpdata(fast):
     assert np.isfinite(st_h["t"]).all()
     assert all(v <= 1e-10 for v in out.values()), out
     # MPDATA keeps the positive-definite passive tracers positive
-    assert float(st_h.interior("t")[..., s.nnew - 1, 2:].min()) > 0.0
+    tp = st_h.interior("t")[..., s.nnew - 1, 2:]
+    if mask is None:
+        assert float(tp.min()) > 0.0
+    else:
+        water = st_h.interior("rmask") == 1
+        assert float(tp[water].min()) > 0.0 and np.all(tp[~water] == 0.0)
 
 
 # ---- HSIMT (the other three-ghost-point scheme of step3d_t.F): same structure of tests ----
