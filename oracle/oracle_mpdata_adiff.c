@@ -270,26 +270,27 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
       }
   }
 
-  /* closed / gradient walls for the horizontal pair, :642-712 */
+  /* closed / gradient walls for the horizontal pair, :577-640: the rule follows LBC(side, isBu3d = isUvel / isBv3d =
+   * isVvel)%closed (mod_ncparam.F:1235-1236), the 3-D momentum's condition on that side */
   if (!EWperiodic) {
     if (west_edge)
       for (int k = 1; k <= N; k++)
         for (int j = Jstrm1; j <= Jendp1; j++)
-          Ua(Istr, j, k) = (p->lbc_west == LBC_CLOSED) ? 0.0 : Ua(Istr + 1, j, k);
+          Ua(Istr, j, k) = (o_lbc(p, LBS_WEST, LBV_U) == LBC_CLOSED) ? 0.0 : Ua(Istr + 1, j, k);
     if (east_edge)
       for (int k = 1; k <= N; k++)
         for (int j = Jstrm1; j <= Jendp1; j++)
-          Ua(Iend + 1, j, k) = (p->lbc_east == LBC_CLOSED) ? 0.0 : Ua(Iend, j, k);
+          Ua(Iend + 1, j, k) = (o_lbc(p, LBS_EAST, LBV_U) == LBC_CLOSED) ? 0.0 : Ua(Iend, j, k);
   }
   if (!NSperiodic) {
     if (south_edge)
       for (int k = 1; k <= N; k++)
         for (int i = Istrm1; i <= Iendp1; i++)
-          Va(i, Jstr, k) = (p->lbc_south == LBC_CLOSED) ? 0.0 : Va(i, Jstr + 1, k);
+          Va(i, Jstr, k) = (o_lbc(p, LBS_SOUTH, LBV_V) == LBC_CLOSED) ? 0.0 : Va(i, Jstr + 1, k);
     if (north_edge)
       for (int k = 1; k <= N; k++)
         for (int i = Istrm1; i <= Iendp1; i++)
-          Va(i, Jend + 1, k) = (p->lbc_north == LBC_CLOSED) ? 0.0 : Va(i, Jend, k);
+          Va(i, Jend + 1, k) = (o_lbc(p, LBS_NORTH, LBV_V) == LBC_CLOSED) ? 0.0 : Va(i, Jend, k);
   }
 
   /* ---- anti-diffusive velocity in the vertical, :714-840 ---- */
@@ -451,21 +452,21 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
     if (west_edge)
       for (int k = 1; k <= N; k++)
         for (int j = Jstr; j <= Jend; j++)
-          Ua(Istr, j, k) = (p->lbc_west == LBC_CLOSED) ? 0.0 : Ua(Istr + 1, j, k);
+          Ua(Istr, j, k) = (o_lbc(p, LBS_WEST, LBV_U) == LBC_CLOSED) ? 0.0 : Ua(Istr + 1, j, k);
     if (east_edge)
       for (int k = 1; k <= N; k++)
         for (int j = Jstr; j <= Jend; j++)
-          Ua(Iend + 1, j, k) = (p->lbc_east == LBC_CLOSED) ? 0.0 : Ua(Iend, j, k);
+          Ua(Iend + 1, j, k) = (o_lbc(p, LBS_EAST, LBV_U) == LBC_CLOSED) ? 0.0 : Ua(Iend, j, k);
   }
   if (!NSperiodic) {
     if (south_edge)
       for (int k = 1; k <= N; k++)
         for (int i = Istr; i <= Iend; i++)
-          Va(i, Jstr, k) = (p->lbc_south == LBC_CLOSED) ? 0.0 : Va(i, Jstr + 1, k);
+          Va(i, Jstr, k) = (o_lbc(p, LBS_SOUTH, LBV_V) == LBC_CLOSED) ? 0.0 : Va(i, Jstr + 1, k);
     if (north_edge)
       for (int k = 1; k <= N; k++)
         for (int i = Istr; i <= Iend; i++)
-          Va(i, Jend + 1, k) = (p->lbc_north == LBC_CLOSED) ? 0.0 : Va(i, Jend, k);
+          Va(i, Jend + 1, k) = (o_lbc(p, LBS_NORTH, LBV_V) == LBC_CLOSED) ? 0.0 : Va(i, Jend, k);
   }
   free(C_); free(Wm_); free(beta_dn_); free(beta_up_); free(odz_);
   return 0;

@@ -767,11 +767,16 @@ FUNCTION ref_mpdata_adiff (b, p, F, oHz, t3, Ta, Ua, Va, Wa) BIND(C, name='ref_m
   !  the generic LBC indices initialize_ncparam would set (mod_ncparam.F:1235-1236)
   isBu3d = isUvel
   isBv3d = isVvel
-  LBC(iwest , isBu3d, ng)%closed = p%lbc_west  == 1
-  LBC(ieast , isBu3d, ng)%closed = p%lbc_east  == 1
-  LBC(isouth, isBv3d, ng)%closed = p%lbc_south == 1
-  LBC(inorth, isBv3d, ng)%closed = p%lbc_north == 1
-  LBC(iwest, isBv3d, ng)%closed = p%lbc_west == 1;  LBC(ieast, isBv3d, ng)%closed = p%lbc_east == 1
+  !  (the routine asks whether the 3-D momentum's condition on the side is "closed"; p%lbc rows 4, 5 = u, v; 0 = the
+  !  side's lbc_west / ... / lbc_north)
+  LBC(iwest , isBu3d, ng)%closed = MERGE(p%lbc(4,1), p%lbc_west,  p%lbc(4,1) /= 0) == 1
+  LBC(ieast , isBu3d, ng)%closed = MERGE(p%lbc(4,2), p%lbc_east,  p%lbc(4,2) /= 0) == 1
+  LBC(isouth, isBu3d, ng)%closed = MERGE(p%lbc(4,3), p%lbc_south, p%lbc(4,3) /= 0) == 1
+  LBC(inorth, isBu3d, ng)%closed = MERGE(p%lbc(4,4), p%lbc_north, p%lbc(4,4) /= 0) == 1
+  LBC(iwest , isBv3d, ng)%closed = MERGE(p%lbc(5,1), p%lbc_west,  p%lbc(5,1) /= 0) == 1
+  LBC(ieast , isBv3d, ng)%closed = MERGE(p%lbc(5,2), p%lbc_east,  p%lbc(5,2) /= 0) == 1
+  LBC(isouth, isBv3d, ng)%closed = MERGE(p%lbc(5,3), p%lbc_south, p%lbc(5,3) /= 0) == 1
+  LBC(inorth, isBv3d, ng)%closed = MERGE(p%lbc(5,4), p%lbc_north, p%lbc(5,4) /= 0) == 1
   CALL c_f_pointer (F%pm, a2, (/ni,nj/));       GRID(ng)%pm = a2
   CALL c_f_pointer (F%pn, a2, (/ni,nj/));       GRID(ng)%pn = a2
   CALL c_f_pointer (F%omn, a2, (/ni,nj/));      GRID(ng)%omn = a2

@@ -29,6 +29,10 @@ struct MpArgs {
   double *Ta, *Ua, *Va, *Wa, *bup, *bdn;   // scratch, module horizontal extents
   const double *oHz, *odz;                 // 1/Hz and 1/(z_r(k+1)-z_r(k)), k_mp_metrics (once per step3d_t call)
   int nnew, itrc;
+  // the wall rule of the anti-diffusive velocities on a physical edge (mpdata_adiff.F:577-640, :1031-1100): zero where
+  // the 3-D momentum's condition is closed (LBC(side, isBu3d = isUvel / isBv3d = isVvel)%closed), the neighbouring
+  // face's value otherwise; [LBS_WEST .. LBS_NORTH]
+  int closed[4];
 };
 
 __device__ __forceinline__ double upstream(double flx, double a, double b)
@@ -81,6 +85,8 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
   const double cff = dt * GF(pm)[c0] * GF(pn)[c0];
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
+  const bool w_wall = b.west_edge && !b.EWperiodic && i == b.Istr;
+  const bool e_wall = b.east_edge && !b.EWperiodic && i == b.Iend;
   {
     const int k = XB.k0 + 1;                                      // one thread per (i,j,k)
     const long a = c0 + (long)(k - 1) * nij;
@@ -99,8 +105,15 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
     const double c1 = cff * (FCk - FCm1);
     ta = (ta - c1) * (1.0 / Hz[a]);                             // :1175
     Ta[a] = ta;
-    if (s_wall) Ta[a - ni] = ta;                                // mpdata_adiff.F:193-199
+    if (w_wall) Ta[a - 1] = ta;                                 // mpdata_adiff.F:160-176
+    if (e_wall) Ta[a + 1] = ta;
+    if (s_wall) Ta[a - ni] = ta;                                // mpdata_adiff.F:177-199
     if (n_wall) Ta[a + ni] = ta;
+    // corners, :201-240: the mean of the two neighbouring boundary values, both copies of this cell
+    if (s_wall && w_wall) Ta[a - ni - 1] = 0.5 * (ta + ta);
+    if (s_wall && e_wall) Ta[a - ni + 1] = 0.5 * (ta + ta);
+    if (n_wall && w_wall) Ta[a + ni - 1] = 0.5 * (ta + ta);
+    if (n_wall && e_wall) Ta[a + ni + 1] = 0.5 * (ta + ta);
   }
 }
 
@@ -183,7 +196,11 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
   const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn, on_v = (gcd_t)c->F.on_v, om_u = (gcd_t)c->F.om_u;
   const gd_t Ua = (gd_t)m.Ua, Va = (gd_t)m.Va, Wa = (gd_t)m.Wa;
   const long a2 = I2(i, j);
-  const bool v_wall_n = b.north_edge && !b.NSperiodic && j == b.Jend + 1;   // Va(i,Jend+1) = 0, mpdata_adiff.F:694-700
+  // faces on a physical edge, mpdata_adiff.F:577-640: zero (closed) or the value of the next face inside, which the
+  // thread of that face stores
+  const bool v_wall_n = b.north_edge && !b.NSperiodic && j == b.Jend + 1;
+  const bool u_wall_w = b.west_edge && !b.EWperiodic && i == b.Istr;
+  const bool u_wall_e = b.east_edge && !b.EWperiodic && i == b.Iend + 1;
   const gcd_t oHzA = (gcd_t)m.oHz, odzA = (gcd_t)m.odz;
   auto oHz = [&](long x) { return oHzA[x]; };
   const gcd_t umk = (gcd_t)c->F.umask, vmk = (gcd_t)c->F.vmask, rmk = (gcd_t)c->F.rmask;
@@ -199,7 +216,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
     if (do_u) {
       const double Tw = Ta[a - 1];
       double ua = 0.0;
-      if (!((Tw <= 0.0) || (T0 <= 0.0) || (fabs(Tw - T0) <= EPS2_MP))) {
+      if (!u_wall_w && !u_wall_e && !((Tw <= 0.0) || (T0 <= 0.0) || (fabs(Tw - T0) <= EPS2_MP))) {
         double Ck, Wk;
         face_CW<FAST>(Ta, z_r, odzA, Wv, pm, pn, a2, a, -1, nij, k, N, dt, Ck, Wk);
         const double A = DV(T0 - Tw, T0 + Tw + EPS_MP);
@@ -237,7 +254,13 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         ua = fmin(fabs(u0), 1.0 * fabs(Um)) * copysign(1.0, u0);
         ua = UM(ua, a2);
       }
-      Ua[a] = ua;
+      if (u_wall_w) { if (m.closed[LBS_WEST]) Ua[a] = 0.0; }
+      else if (u_wall_e) { if (m.closed[LBS_EAST]) Ua[a] = 0.0; }
+      else {
+        Ua[a] = ua;
+        if (b.west_edge && !b.EWperiodic && i == b.Istr + 1 && !m.closed[LBS_WEST]) Ua[a - 1] = ua;
+        if (b.east_edge && !b.EWperiodic && i == b.Iend && !m.closed[LBS_EAST]) Ua[a + 1] = ua;
+      }
     }
     // ---------------- ETA face between (i,j-1) and (i,j) ----------------
     if (do_v) {
@@ -281,9 +304,13 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
         va = fmin(fabs(v0), 1.0 * fabs(Vm)) * copysign(1.0, v0);
         va = VM(va, a2);
       }
-      Va[a] = va;
-      // closed southern wall: Va(i,Jstr) = 0 (:683-689); row Jstr is below this kernel's Va range
-      if (b.south_edge && !b.NSperiodic && j == b.Jstr + 1) Va[a - ni] = 0.0;
+      if (v_wall_n) { if (m.closed[LBS_NORTH]) Va[a] = 0.0; }
+      else {
+        Va[a] = va;
+        // southern edge: Va(i,Jstr) (:612-625); row Jstr is below this kernel's Va range
+        if (b.south_edge && !b.NSperiodic && j == b.Jstr + 1) Va[a - ni] = m.closed[LBS_SOUTH] ? 0.0 : va;
+        if (b.north_edge && !b.NSperiodic && j == b.Jend && !m.closed[LBS_NORTH]) Va[a + ni] = va;
+      }
     }
     // ---------------- W face between levels k and k+1 ----------------
     if (do_w) {
@@ -442,9 +469,12 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
   const double omu0 = GF(om_u)[a2], omu1 = GF(om_u)[a2 + 1], onv0 = GF(on_v)[a2], onv1 = GF(on_v)[a2 + ni];
   const double onu0 = GF(on_u)[a2], onu1 = GF(on_u)[a2 + 1], omv0 = GF(om_v)[a2], omv1 = GF(om_v)[a2 + ni];
   const double omn = GF(omn)[a2];
-  // walls of the limited transports, mpdata_adiff.F:1068-1100 (E-W periodic, closed N-S)
-  const bool v0_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;       // Va(i,Jstr) = 0
-  const bool v1_wall = b.north_edge && !b.NSperiodic && j == b.Jend;       // Va(i,Jend+1) = 0
+  // physical edges of the limited transports, mpdata_adiff.F:1031-1100: zero (closed) or the limited transport of the
+  // next face inside -- the other face of this cell
+  const bool v0_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;       // Va(i,Jstr)
+  const bool v1_wall = b.north_edge && !b.NSperiodic && j == b.Jend;       // Va(i,Jend+1)
+  const bool u0_wall = b.west_edge && !b.EWperiodic && i == b.Istr;        // Ua(Istr,j)
+  const bool u1_wall = b.east_edge && !b.EWperiodic && i == b.Iend;        // Ua(Iend+1,j)
   auto lim_u = [&](long x, double om) {       // limited Ua at index x (face between x-1 and x), :1034-1040
     const double cff1 = fmin(fmin(bdn[x - 1], bup[x]), 1.0);
     const double cff2 = fmin(fmin(bup[x - 1], bdn[x]), 1.0);
@@ -470,8 +500,13 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
       double u0 = lim_u(a, omu0), u1 = lim_u(a + 1, omu1);
       double v0 = lim_v(a, onv0), v1 = lim_v(a + ni, onv1);
       if constexpr (MASK) { u0 = u0 * um0; u1 = u1 * um1; v0 = v0 * vm0; v1 = v1 * vm1; }
-      if (v0_wall) v0 = 0.0;
-      if (v1_wall) v1 = 0.0;
+      {
+        const double u0i = u0, u1i = u1, v0i = v0, v1i = v1;
+        if (u0_wall) u0 = m.closed[LBS_WEST] ? 0.0 : u1i;
+        if (u1_wall) u1 = m.closed[LBS_EAST] ? 0.0 : u0i;
+        if (v0_wall) v0 = m.closed[LBS_SOUTH] ? 0.0 : v1i;
+        if (v1_wall) v1 = m.closed[LBS_NORTH] ? 0.0 : v0i;
+      }
       // corrected horizontal fluxes, step3d_t.F:1238-1255
       const double FXi = (fmax(u0, 0.0) * Ta[a - 1] + fmin(u0, 0.0) * T0) * 0.5 * (hz + Hz[a - 1]) * onu0;
       const double FXip1 = (fmax(u1, 0.0) * T0 + fmin(u1, 0.0) * Ta[a + 1]) * 0.5 * (Hz[a + 1] + hz) * onu1;
@@ -558,6 +593,10 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
   m.bup = g_ctx.hostc.ws3[5]; m.bdn = g_ctx.hostc.ws3[6];
   m.oHz = g_ctx.hostc.ws3[0]; m.odz = g_ctx.hostc.ws3[7];
   m.nnew = nnew; m.itrc = itrc;
+  m.closed[LBS_WEST] = lbc_code(g_ctx.p, LBS_WEST, LBV_U) == LBC_CLOSED;
+  m.closed[LBS_EAST] = lbc_code(g_ctx.p, LBS_EAST, LBV_U) == LBC_CLOSED;
+  m.closed[LBS_SOUTH] = lbc_code(g_ctx.p, LBS_SOUTH, LBV_V) == LBC_CLOSED;
+  m.closed[LBS_NORTH] = lbc_code(g_ctx.p, LBS_NORTH, LBV_V) == LBC_CLOSED;
   if (first) {
     hipLaunchKernelGGL(k_mp_metrics, grid2d(b.UBi - b.LBi + 1, b.UBj - b.LBj + 1), block2d(), 0, g_ctx.stream, g_ctx.devc,
                        g_ctx.hostc.ws3[0], g_ctx.hostc.ws3[7]);

@@ -61,12 +61,19 @@ __device__ __forceinline__ double hsimt_limited(double g0, double gn, double k0,
   return 0.5 * fmax(0.0, fmin(fmin(2.0, 2.0 * r * rka), beta)) * g0 * k0;
 }
 // horizontal face between cell (a - off) and cell a; off = 1 (xi, Huon) or ni (eta, Hvom).
-// lo_zero / hi_zero: the closed-wall rule of :451-464 / :527-540 applies to the neighbour face used.
+// lo_zero / hi_zero: the wall rule of :451-464 / :527-540 applies to the neighbour face used.
+// MASKING (fmask = umask / vmask of the direction, null without the option): the differences and Ka times the
+// mask of their face (:448, :523) and the limited correction times rmask two cells upstream of the face,
+// rmask(MAX(i-2,0)) or rmask(MIN(i+1,Lm+1)) (:487, :506, :562, :581); idx = the face's global i (j), idxmax = Lm+1 (Mm+1).
 template <int DIR>
 __device__ __forceinline__ double hsimt_hface(gcd_t t3, gcd_t H, gcd_t Hz, gcd_t pm, gcd_t pn, long a, long a2, long off,
-                                              double dt, bool lo_zero, bool hi_zero)
+                                              double dt, bool lo_zero, bool hi_zero, gcd_t fmask, gcd_t rmask, int idx,
+                                              int idxmax)
 {
-  auto grad = [&](long x) { return t3[x] - t3[x - off]; };
+  auto grad = [&](long x, long x2) {
+    const double g = t3[x] - t3[x - off];
+    return fmask ? g * fmask[x2] : g;
+  };
   auto Ka = [&](long x, long x2) {
     double cff;
     if constexpr (DIR == 0) cff = 0.125 * (pm[x2 - off] + pm[x2]) * (pn[x2 - off] + pn[x2]) * dt;
@@ -74,18 +81,23 @@ __device__ __forceinline__ double hsimt_hface(gcd_t t3, gcd_t H, gcd_t Hz, gcd_t
     double cff1;
     if constexpr (DIR == 0) cff1 = cff * (1.0 / Hz[x - off] + 1.0 / Hz[x]);
     else cff1 = cff * (1.0 / Hz[x] + 1.0 / Hz[x - off]);
-    return 1.0 - fabs(H[x] * cff1);
+    const double ka = 1.0 - fabs(H[x] * cff1);
+    return fmask ? ka * fmask[x2] : ka;
   };
   const double Hf = H[a];
-  const double g0 = grad(a), k0 = Ka(a, a2);
+  const double g0 = grad(a, a2), k0 = Ka(a, a2);
   const double ok0 = (k0 <= HS_EPS1) ? 0.0 : 1.0 / fmax(k0, HS_EPS1);
   double sw;
   if (Hf >= 0.0) {
-    const double gn = lo_zero ? 0.0 : grad(a - off), kn = lo_zero ? 0.0 : Ka(a - off, a2 - off);
-    sw = t3[a - off] + hsimt_limited(g0, gn, k0, kn, ok0);
+    const double gn = lo_zero ? 0.0 : grad(a - off, a2 - off), kn = lo_zero ? 0.0 : Ka(a - off, a2 - off);
+    double cff = hsimt_limited(g0, gn, k0, kn, ok0);
+    if (fmask) cff = cff * rmask[a2 + (long)((idx - 2 > 0 ? idx - 2 : 0) - idx) * off];
+    sw = t3[a - off] + cff;
   } else {
-    const double gn = hi_zero ? 0.0 : grad(a + off), kn = hi_zero ? 0.0 : Ka(a + off, a2 + off);
-    sw = t3[a] - hsimt_limited(g0, gn, k0, kn, ok0);
+    const double gn = hi_zero ? 0.0 : grad(a + off, a2 + off), kn = hi_zero ? 0.0 : Ka(a + off, a2 + off);
+    double cff = hsimt_limited(g0, gn, k0, kn, ok0);
+    if (fmask) cff = cff * rmask[a2 + (long)((idx + 1 < idxmax ? idx + 1 : idxmax) - idx) * off];
+    sw = t3[a] - cff;
   }
   return sw * Hf;
 }
@@ -221,11 +233,15 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       double FXi, FXip1, FEj, FEjp1;
       if constexpr (HADV == ADV_HSIMT) {
         const gcd_t pmg = (gcd_t)c->F.pm, png = (gcd_t)c->F.pn;
-        FXi = hsimt_hface<0>(t3, Huon, Hz, pmg, png, ck, c0, 1, dt, false, false);
-        FXip1 = hsimt_hface<0>(t3, Huon, Hz, pmg, png, ck + 1, c0 + 1, 1, dt, false, false);
-        // closed walls: the face below Jstr (above Jend+1) enters only through its zeroed gradient, :527-540
-        FEj = hsimt_hface<1>(t3, Hvom, Hz, pmg, png, ck, c0, ni, dt, s_wall, false);
-        FEjp1 = hsimt_hface<1>(t3, Hvom, Hz, pmg, png, ck + ni, c0 + ni, ni, dt, false, n_wall);
+        const bool mk = c->p.masking != 0;
+        const gcd_t um = mk ? (gcd_t)c->F.umask : (gcd_t) nullptr, vm = mk ? (gcd_t)c->F.vmask : (gcd_t) nullptr;
+        const gcd_t rm = (gcd_t)c->F.rmask;
+        // physical edges: the face outside Istr / Jstr (Iend+1 / Jend+1) enters only through its zeroed gradient,
+        // :451-464, :527-540
+        FXi = hsimt_hface<0>(t3, Huon, Hz, pmg, png, ck, c0, 1, dt, w_wall, false, um, rm, i, b.Lm + 1);
+        FXip1 = hsimt_hface<0>(t3, Huon, Hz, pmg, png, ck + 1, c0 + 1, 1, dt, false, e_wall, um, rm, i + 1, b.Lm + 1);
+        FEj = hsimt_hface<1>(t3, Hvom, Hz, pmg, png, ck, c0, ni, dt, s_wall, false, vm, rm, j, b.Mm + 1);
+        FEjp1 = hsimt_hface<1>(t3, Hvom, Hz, pmg, png, ck + ni, c0 + ni, ni, dt, false, n_wall, vm, rm, j + 1, b.Mm + 1);
       } else {
         FXi = hflux<HADV>(hu0, xm1, tk, dxm1, dx0, dxp1);
         FXip1 = hflux<HADV>(hu1, tk, xp1, dx0, dxp1, dxp2);
@@ -285,7 +301,10 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       const long ck = c0 + (long)kk * nij;        // level kk+1
       const double ohz = 1.0 / Hz[ck];
       const double cff1 = dt * ohz * (dcA_up - dcA);
-      tn_g[ck] = tn[kk + 1] + cff1;
+      double tv = tn[kk + 1] + cff1;
+      if constexpr (HADV == ADV_HSIMT)          // (the only pair this kernel is instantiated for) step3d_t.F:1586-1596
+        if (c->p.masking) tv = tv * GF(rmask)[c0];
+      tn_g[ck] = tv;
       dcA_up = dcA;
     }
   }
@@ -567,8 +586,6 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
       case ADV_C4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_C4, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_A4 * 16 + ADV_SPLINES: rc = launch_nmax<ADV_A4, ADV_SPLINES>(s->nnew, it, n); break;
       case ADV_HSIMT * 16 + ADV_HSIMT: {
-        if (p.masking) return roms_fail("roms_hip_step3d_t", "MASKING is not built for HSIMT tracers");
-        if (!b.EWperiodic) return roms_fail("roms_hip_step3d_t", "HSIMT is built for E-W periodic grids only");
         // three-point footprint: refresh the ghost points of t(nnew) first (step3d_t.F:369-386); classic kernel
         if (b.NghostPoints != 3) return roms_fail("roms_hip_step3d_t", "HSIMT needs NghostPoints = 3 (inp_par.F:266-278)");
         const long n3r_ = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
@@ -580,7 +597,6 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
         break;
       }
       case ADV_MPDATA * 16 + ADV_MPDATA:
-        if (!b.EWperiodic) return roms_fail("roms_hip_step3d_t", "MPDATA is built for E-W periodic grids only");
         // multi-pass: upstream step, anti-diffusive velocities, FCT limiter, corrected step (k_mpdata.hip)
         for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q, q == 0);
         break;

@@ -226,13 +226,23 @@ def main_ini(config, mask=None):
     print(json.dumps(out))
 
 
-def main_mpdata(config, mask=None):
+def main_mpdata(config, mask=None, basin=None):
     """mpdata_adiff_tile: reference Fortran vs C oracle on the same private arrays, with the
     3-ghost-point bounds an MPDATA run uses (also pins get_bounds for NghostPoints = 3).  mask = "island": the
-    MASKING build (face masks in the cross terms, land out of the limiter's extrema, masked transports)."""
+    MASKING build (face masks in the cross terms, land out of the limiter's extrema, masked transports).
+    basin = "closed" / "open": no periodic direction -- the boundary values and corners of Ta, and the wall rule of
+    Ua / Va on the four edges: zero where the 3-D momentum's condition is closed, the neighbour's value otherwise."""
     import util
     from oracle import ref
-    st = util.prepared_state(config, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}, mask=mask)
+    from roms_trunk_mgh_amd import abi
+    ov = {"Hadv": "MPDATA", "Vadv": "MPDATA"}
+    if basin:
+        ov["EWperiodic"] = False
+    st = util.prepared_state(config, overrides=ov, mask=mask)
+    if basin == "open":
+        for sd in ("west", "east", "south", "north"):
+            for var in ("u", "v"):
+                st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC["Gra"]
     b = st.b
     out = {"NghostPoints": int(b.NghostPoints), "masking": int(st.p.masking)}
     r = ref.Ref(st)
@@ -434,6 +444,8 @@ if __name__ == "__main__":
         main(sys.argv[1], basin=True)
     elif len(sys.argv) > 2 and sys.argv[2] in ("mpdata", "mpdata_mask"):
         main_mpdata(sys.argv[1], mask="island" if sys.argv[2] == "mpdata_mask" else None)
+    elif len(sys.argv) > 2 and sys.argv[2] in ("mpdata_closed", "mpdata_open", "mpdata_mask_open"):
+        main_mpdata(sys.argv[1], mask="island" if "mask" in sys.argv[2] else None, basin=sys.argv[2].split("_")[-1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mask":
         main(sys.argv[1], mask="island")
     elif len(sys.argv) > 2 and sys.argv[2] in ("pg31", "wj"):

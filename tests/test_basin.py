@@ -135,3 +135,64 @@ def test_hip_100_steps_on_a_basin(config, physics, open_edges):
     assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
     assert all(v <= 1e-10 for v in out.values()), out
     assert float(np.abs(st_o["u"]).max()) > 1e-6
+
+
+# ---- the three-ghost-point tracer schemes (MPDATA, HSIMT) on a basin, with and without land ----
+@pytest.mark.parametrize("scheme", ["MPDATA", "HSIMT"])
+@pytest.mark.parametrize("open_edges", [False, True], ids=["closed", "open"])
+@pytest.mark.parametrize("mask", [None, "island"], ids=["water", "island"])
+@pytest.mark.parametrize("kernel", ["pre_step3d", "step3d_t"])
+def test_hip_mpdata_hsimt_on_a_basin(scheme, open_edges, mask, kernel):
+    """mpdata_adiff.F:160-240 (boundary values and corners of Ta), :577-640 / :1031-1100 (Ua / Va on the edges: zero
+    where the 3-D momentum's condition is closed, the neighbouring face's value otherwise); step3d_t.F:451-464 (HSIMT:
+    the face outside a western / eastern edge enters through a zeroed gradient); MASKING in both (:448-581)."""
+    import oracle
+    from roms_trunk_mgh_amd import hip
+    ov = dict(BASIN, Hadv=scheme, Vadv=scheme)
+    for config in ("BENCHMARK_TINY", "UPWELLING"):
+        st0 = util.prepared_state(config, overrides=ov, mask=mask)
+        assert st0.b.EWperiodic == 0 and st0.b.NghostPoints == 3
+        if open_edges:
+            _open_all(st0)
+        if kernel == "step3d_t":
+            util.hz_weighted_tnew(st0)
+        st_o, st_h = st0.copy(), st0.copy()
+        s = util.step_idx(iic=5)
+        oracle.Oracle(st_o).call(kernel, s)
+        h = hip.RomsHip(st_h)
+        try:
+            h.call(kernel, s)
+            h.to_host()
+        finally:
+            h.close()
+        diffs = util.compare_states(st_h, st_o)
+        assert all(v <= 1e-12 for v in diffs.values()), (config, diffs)
+        assert util.max_rel_diff(st_o["t"], st0["t"]) > 1e-6
+
+
+@pytest.mark.parametrize("scheme,mask", [("MPDATA", None), ("MPDATA", "island"), ("HSIMT", "island")])
+def test_hip_100_steps_mpdata_hsimt_on_a_basin(scheme, mask):
+    import oracle
+    from roms_trunk_mgh_amd import hip
+    from roms_trunk_mgh_amd.state import rel_rms
+    st_o = ana.make_tile("BENCHMARK_TINY", perturb=1.0, NT=4, overrides=dict(BASIN, Hadv=scheme, Vadv=scheme), mask=mask)
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o))
+    mo.initial()
+    mo.run(100)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be)
+        mh.initial()
+        mh.run(100)
+        be.to_host()
+    finally:
+        be.close()
+    s = mo.s
+    out = {"zeta": rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], 1e-3)}
+    for name in ("u", "v"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], 1e-4)
+    for it in range(st_o.b.NT):
+        out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
+    assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
+    assert all(v <= 1e-10 for v in out.values()), out

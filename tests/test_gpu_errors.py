@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def test_unsupported_boundary_condition_is_refused():
     st = ana.make_tile("UPWELLING", perturb=1.0)
-    st.p.lbc_south = 7                                     # no such code (enum roms_lbc ends at LBC_RADIATION = 6)
+    st.p.lbc_south = 9                                     # no such code (enum roms_lbc ends at LBC_RADIATION_NUDGING = 7)
     h = hip.RomsHip(st)
     try:
         with pytest.raises(RuntimeError) as e:
