@@ -145,6 +145,11 @@ typedef struct roms_params {
    * per side and variable -- FSobc_out/in (zeta), M2obc_out/in (ubar, vbar), M3obc_out/in (u, v), Tobc_out/in (t; one
    * value for all tracers) of mod_scalars.F:1336-1365, i.e. 1/(xNUDG*86400) and OBCFAC times that */
   double obc_out[4][LBV_COUNT], obc_in[4][LBV_COUNT];
+  /* biharmonic lateral mixing (TS_DIF4, UV_VIS4 of the application header; coefficients diff4, visc4_r, visc4_p =
+   * the square roots the reference stores, inp_par.F:986, read_phypar.F:6905).  Tracers: along s-surfaces (mix_s_ts,
+   * t3dmix4_s.h:23) or geopotentials (mix_geo_ts, t3dmix4_geo.h:23); momentum: along s-surfaces (uv3dmix4_s.h:23)
+   * and the 2-D operator of step2d_LF_AM3.h:1494-1740.  TS_DIF2 and TS_DIF4 (UV_VIS2 and UV_VIS4) may both be set. */
+  int    ts_dif4, uv_vis4;
 } roms_params_t;
 
 /* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and
@@ -224,7 +229,8 @@ int roms_hip_row_metrics_state(void);
  * vertical means of u/v, Zt_avg1 = the initial free surface.  Uses s->kstp, knew, nstp, nnew. */
 int roms_hip_ini_zeta(const roms_step_idx_t *s);
 int roms_hip_ini_fields(const roms_step_idx_t *s);
-/* rhs3d(ng,tile) -> pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2
+/* rhs3d(ng,tile) -> pre_step3d, prsgrd, t3dmix2, t3dmix4, rhs3d_tile, uv3dmix2, uv3dmix4 (each mixing call
+ * under its switch ts_dif2 / ts_dif4 / uv_vis2 / uv_vis4)
  *                                  ROMS/Nonlinear/rhs3d.F:25         */
 int roms_hip_rhs3d(const roms_step_idx_t *s);
 /* the pieces of rhs3d, exported for per-kernel parity tests */
@@ -233,6 +239,8 @@ int roms_hip_prsgrd(const roms_step_idx_t *s);      /* prsgrd32.h:40     */
 int roms_hip_t3dmix2(const roms_step_idx_t *s);     /* t3dmix2_geo.h:23  */
 int roms_hip_rhs3d_tile(const roms_step_idx_t *s);  /* rhs3d.F:174       */
 int roms_hip_uv3dmix2(const roms_step_idx_t *s);    /* uv3dmix2_s.h:42   */
+int roms_hip_t3dmix4(const roms_step_idx_t *s);     /* t3dmix4_s.h:23, t3dmix4_geo.h:23 (TS_DIF4) */
+int roms_hip_uv3dmix4(const roms_step_idx_t *s);    /* uv3dmix4_s.h:43 (UV_VIS4; three ghost points, inp_par.F:268) */
 /* step2d(ng,tile)                  ROMS/Nonlinear/step2d_LF_AM3.h:18 */
 int roms_hip_step2d(const roms_step_idx_t *s);
 /* step3d_uv(ng,tile)               ROMS/Nonlinear/step3d_uv.F:27     */

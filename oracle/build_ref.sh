@@ -13,7 +13,8 @@
 #                                 BENCHMARK, UPWELLING, SEAMOUNT; BENCHMARK_MASK, UPWELLING_MASK
 #                                 (= the application + -DMASKING); UPWELLING_PG31, UPWELLING_WJ,
 #                                 SEAMOUNT_PG31, SEAMOUNT_WJ (= the application with prsgrd31.h, plain
-#                                 and with WJ_GRADP, instead of prsgrd32.h)
+#                                 and with WJ_GRADP, instead of prsgrd32.h); UPWELLING_DIF4, SEAMOUNT_DIF4
+#                                 (= the application plus TS_DIF4 and UV_VIS4), UPWELLING_MASK_DIF4
 #
 # This is the reference's own recipe (makefile:207, Compilers/Linux-gfortran.mk:
 # 43-44: cpp -P -traditional then the Fortran compiler), serial build (no
@@ -47,8 +48,11 @@ build_app () {
   # reference, globaldefs.h / mod_grid.F:322+); the wrapper then hands rmask/umask/vmask/pmask to GRID(ng)
   # <APP>_PG31 / <APP>_WJ (UPWELLING, SEAMOUNT): the application's options with DJ_GRADPS taken out / replaced by
   # WJ_GRADP, so that prsgrd.F selects prsgrd31.h (ref_headers/*_pg31.h, *_wj.h)
-  local TAG=$1 APP=${1%%_*} XDEF="" VAR=nodiag
-  case $TAG in *_MASK) XDEF="-DMASKING";; *_PG31) VAR=pg31;; *_WJ) VAR=wj;; esac
+  # <APP>_DIF4 (UPWELLING, SEAMOUNT): the application's options plus TS_DIF4 and UV_VIS4 (ref_headers/*_dif4.h); the
+  # wrapper then also binds t3dmix4 / uv3dmix4 (-DREF_DIF4 reaches the wrapper only)
+  local TAG=$1 APP=${1%%_*} XDEF="" WDEF="" VAR=nodiag
+  case $TAG in *_MASK*) XDEF="-DMASKING";; esac
+  case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; esac
   local hdr=$(echo $APP | tr A-Z a-z).h
   # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
   [ "$APP" = UPWELLING ] && hdr=upwelling_$VAR.h
@@ -74,14 +78,14 @@ build_app () {
     $FC $FFLAGS -c $bn.f90 -o $bn.o > $bn.log 2>&1 || { echo "[$TAG] $f failed"; tail -5 $bn.log; exit 1; }
     objs="$objs $bn.o"
   done
-  cpp -P -traditional -w -D$APP $XDEF $HERE/ref_wrap.F90 > ref_wrap_pp.f90
+  cpp -P -traditional -w -D$APP $XDEF $WDEF $HERE/ref_wrap.F90 > ref_wrap_pp.f90
   $FC $FFLAGS -c ref_wrap_pp.f90 -o ref_wrap.o > ref_wrap.log 2>&1 || { echo "[$TAG] ref_wrap failed"; tail -20 ref_wrap.log; exit 1; }
   $FC -shared -o libref.so $objs ref_wrap.o
   rm -f *.f90            # keep no preprocessed reference text around
   echo "[$TAG] built $D/libref.so"
 }
 
-for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ}; do
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4}; do
   build_app $app &
 done
 wait

@@ -199,6 +199,8 @@ int oracle_rho_eos(OARGS);
 int oracle_pre_step3d(OARGS);
 int oracle_prsgrd(OARGS);
 int oracle_t3dmix2(OARGS);
+int oracle_t3dmix4(OARGS);       /* oracle_mix4.c */
+int oracle_uv3dmix4(OARGS);
 int oracle_rhs3d_tile(OARGS);
 int oracle_uv3dmix2(OARGS);
 int oracle_rhs3d(OARGS);

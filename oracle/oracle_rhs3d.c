@@ -233,15 +233,17 @@ int oracle_rhs3d_tile(OARGS)
   return 0;
 }
 
-/* rhs3d(ng,tile) driver -- rhs3d.F:25-170: pre_step3d, prsgrd, t3dmix2,
- * rhs3d_tile, uv3dmix2 in this order. */
+/* rhs3d(ng,tile) driver -- rhs3d.F:25-170: pre_step3d, prsgrd, t3dmix2, t3dmix4,
+ * rhs3d_tile, uv3dmix2, uv3dmix4 in this order. */
 int oracle_rhs3d(OARGS)
 {
   int rc;
   if ((rc = oracle_pre_step3d(b, p, s, F))) return rc;
   if ((rc = oracle_prsgrd(b, p, s, F))) return rc;
   if (p->ts_dif2 && (rc = oracle_t3dmix2(b, p, s, F))) return rc;
+  if (p->ts_dif4 && (rc = oracle_t3dmix4(b, p, s, F))) return rc;
   if ((rc = oracle_rhs3d_tile(b, p, s, F))) return rc;
   if (p->uv_vis2 && (rc = oracle_uv3dmix2(b, p, s, F))) return rc;
+  if (p->uv_vis4 && (rc = oracle_uv3dmix4(b, p, s, F))) return rc;
   return 0;
 }

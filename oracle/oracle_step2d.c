@@ -281,11 +281,12 @@ int oracle_step2d(OARGS)
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) { fac1 = 0.5 * (VFe(i, j) + VFe(i, j - 1)); rhs_vbar(i, j) = rhs_vbar(i, j) - fac1; }
   }
-  if (p->uv_vis2) {
-    /* harmonic viscosity, :1394-1471 */
+  if (p->uv_vis2 || p->uv_vis4)          /* total depth at psi-points, :1380-1390 */
     for (int j = Jstr; j <= Jend + 1; j++)
       for (int i = Istr; i <= Iend + 1; i++)
         Drhs_p(i, j) = 0.25 * (Drhs(i, j) + Drhs(i - 1, j) + Drhs(i, j - 1) + Drhs(i - 1, j - 1));
+  if (p->uv_vis2) {
+    /* harmonic viscosity, :1394-1471 */
     for (int j = JstrV - 1; j <= Jend; j++)
       for (int i = IstrU - 1; i <= Iend; i++) {
         cff = visc2_r(i, j) * Drhs(i, j) * 0.5 *
@@ -317,6 +318,120 @@ int oracle_step2d(OARGS)
         fac = cff1 - cff2;
         rhs_vbar(i, j) = rhs_vbar(i, j) + fac;
       }
+  }
+
+  if (p->uv_vis4) {
+    /* biharmonic viscosity, :1474-1740: the harmonic operator without the depth (m s^-3/2) on a range one point
+     * wider, its rule on physical edges and corners, then the operator with the depth */
+    const double gamma2 = p->gamma2;
+    double *LapU_ = walloc(nij), *LapV_ = walloc(nij);
+#define LapU(i,j) LapU_[I2(i,j)]
+#define LapV(i,j) LapV_[I2(i,j)]
+#define visc4_p(i,j) F->visc4_p[I2(i,j)]
+#define visc4_r(i,j) F->visc4_r[I2(i,j)]
+    for (int j = JstrVm2; j <= Jendp1; j++)
+      for (int i = IstrUm2; i <= Iendp1; i++) {
+        cff = visc4_r(i, j) * 0.5 *
+              (pmon_r(i, j) * ((pn(i, j) + pn(i + 1, j)) * ubar(i + 1, j, krhs) - (pn(i - 1, j) + pn(i, j)) * ubar(i, j, krhs)) -
+               pnom_r(i, j) * ((pm(i, j) + pm(i, j + 1)) * vbar(i, j + 1, krhs) - (pm(i, j - 1) + pm(i, j)) * vbar(i, j, krhs)));
+        UFx(i, j) = on_r(i, j) * on_r(i, j) * cff;
+        VFe(i, j) = om_r(i, j) * om_r(i, j) * cff;
+      }
+    for (int j = Jstrm1; j <= Jendp2; j++)
+      for (int i = Istrm1; i <= Iendp2; i++) {
+        cff = visc4_p(i, j) * 0.5 *
+              (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * vbar(i, j, krhs) - (pn(i - 1, j - 1) + pn(i - 1, j)) * vbar(i - 1, j, krhs)) +
+               pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * ubar(i, j, krhs) - (pm(i - 1, j - 1) + pm(i, j - 1)) * ubar(i, j - 1, krhs)));
+        if (p->masking) cff = cff * pmask(i, j);
+        UFe(i, j) = om_p(i, j) * om_p(i, j) * cff;
+        VFx(i, j) = on_p(i, j) * on_p(i, j) * cff;
+      }
+    for (int j = Jstrm1; j <= Jendp1; j++)
+      for (int i = IstrUm1; i <= Iendp1; i++)
+        LapU(i, j) = 0.125 * (pm(i - 1, j) + pm(i, j)) * (pn(i - 1, j) + pn(i, j)) *
+                     ((pn(i - 1, j) + pn(i, j)) * (UFx(i, j) - UFx(i - 1, j)) +
+                      (pm(i - 1, j) + pm(i, j)) * (UFe(i, j + 1) - UFe(i, j)));
+    for (int j = JstrVm1; j <= Jendp1; j++)
+      for (int i = Istrm1; i <= Iendp1; i++)
+        LapV(i, j) = 0.125 * (pm(i, j) + pm(i, j - 1)) * (pn(i, j) + pn(i, j - 1)) *
+                     ((pn(i, j - 1) + pn(i, j)) * (VFx(i + 1, j) - VFx(i, j)) -
+                      (pm(i, j - 1) + pm(i, j)) * (VFe(i, j) - VFe(i, j - 1)));
+    if (!EWperiodic) {
+      if (west_edge) {
+        const int cu = o_lbc(p, LBS_WEST, LBV_UBAR) == LBC_CLOSED, cv = o_lbc(p, LBS_WEST, LBV_VBAR) == LBC_CLOSED;
+        for (int j = Jstrm1; j <= Jendp1; j++) LapU(IstrU - 1, j) = cu ? 0.0 : LapU(IstrU, j);
+        for (int j = JstrVm1; j <= Jendp1; j++) LapV(Istr - 1, j) = cv ? gamma2 * LapV(Istr, j) : 0.0;
+      }
+      if (east_edge) {
+        const int cu = o_lbc(p, LBS_EAST, LBV_UBAR) == LBC_CLOSED, cv = o_lbc(p, LBS_EAST, LBV_VBAR) == LBC_CLOSED;
+        for (int j = Jstrm1; j <= Jendp1; j++) LapU(Iend + 1, j) = cu ? 0.0 : LapU(Iend, j);
+        for (int j = JstrVm1; j <= Jendp1; j++) LapV(Iend + 1, j) = cv ? gamma2 * LapV(Iend, j) : 0.0;
+      }
+    }
+    if (!NSperiodic) {
+      if (south_edge) {
+        const int cu = o_lbc(p, LBS_SOUTH, LBV_UBAR) == LBC_CLOSED, cv = o_lbc(p, LBS_SOUTH, LBV_VBAR) == LBC_CLOSED;
+        for (int i = IstrUm1; i <= Iendp1; i++) LapU(i, Jstr - 1) = cu ? gamma2 * LapU(i, Jstr) : 0.0;
+        for (int i = Istrm1; i <= Iendp1; i++) LapV(i, JstrV - 1) = cv ? 0.0 : LapV(i, JstrV);
+      }
+      if (north_edge) {
+        const int cu = o_lbc(p, LBS_NORTH, LBV_UBAR) == LBC_CLOSED, cv = o_lbc(p, LBS_NORTH, LBV_VBAR) == LBC_CLOSED;
+        for (int i = IstrUm1; i <= Iendp1; i++) LapU(i, Jend + 1) = cu ? gamma2 * LapU(i, Jend) : 0.0;
+        for (int i = Istrm1; i <= Iendp1; i++) LapV(i, Jend + 1) = cv ? 0.0 : LapV(i, Jend);
+      }
+    }
+    if (!(NSperiodic || EWperiodic)) {
+      if (south_edge && west_edge) {
+        LapU(Istr, Jstr - 1) = 0.5 * (LapU(Istr + 1, Jstr - 1) + LapU(Istr, Jstr));
+        LapV(Istr - 1, Jstr) = 0.5 * (LapV(Istr - 1, Jstr + 1) + LapV(Istr, Jstr));
+      }
+      if (south_edge && east_edge) {
+        LapU(Iend + 1, Jstr - 1) = 0.5 * (LapU(Iend, Jstr - 1) + LapU(Iend + 1, Jstr));
+        LapV(Iend + 1, Jstr) = 0.5 * (LapV(Iend, Jstr) + LapV(Iend + 1, Jstr + 1));
+      }
+      if (north_edge && west_edge) {
+        LapU(Istr, Jend + 1) = 0.5 * (LapU(Istr + 1, Jend + 1) + LapU(Istr, Jend));
+        LapV(Istr - 1, Jend + 1) = 0.5 * (LapV(Istr, Jend + 1) + LapV(Istr - 1, Jend));
+      }
+      if (north_edge && east_edge) {
+        LapU(Iend + 1, Jend + 1) = 0.5 * (LapU(Iend, Jend + 1) + LapU(Iend + 1, Jend));
+        LapV(Iend + 1, Jend + 1) = 0.5 * (LapV(Iend, Jend + 1) + LapV(Iend + 1, Jend));
+      }
+    }
+    for (int j = JstrV - 1; j <= Jend; j++)
+      for (int i = IstrU - 1; i <= Iend; i++) {
+        cff = visc4_r(i, j) * Drhs(i, j) * 0.5 *
+              (pmon_r(i, j) * ((pn(i, j) + pn(i + 1, j)) * LapU(i + 1, j) - (pn(i - 1, j) + pn(i, j)) * LapU(i, j)) -
+               pnom_r(i, j) * ((pm(i, j) + pm(i, j + 1)) * LapV(i, j + 1) - (pm(i, j - 1) + pm(i, j)) * LapV(i, j)));
+        UFx(i, j) = on_r(i, j) * on_r(i, j) * cff;
+        VFe(i, j) = om_r(i, j) * om_r(i, j) * cff;
+      }
+    for (int j = Jstr; j <= Jend + 1; j++)
+      for (int i = Istr; i <= Iend + 1; i++) {
+        cff = visc4_p(i, j) * Drhs_p(i, j) * 0.5 *
+              (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * LapV(i, j) - (pn(i - 1, j - 1) + pn(i - 1, j)) * LapV(i - 1, j)) +
+               pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * LapU(i, j) - (pm(i - 1, j - 1) + pm(i, j - 1)) * LapU(i, j - 1)));
+        if (p->masking) cff = cff * pmask(i, j);
+        UFe(i, j) = om_p(i, j) * om_p(i, j) * cff;
+        VFx(i, j) = on_p(i, j) * on_p(i, j) * cff;
+      }
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = IstrU; i <= Iend; i++) {
+        cff1 = 0.5 * (pn(i - 1, j) + pn(i, j)) * (UFx(i, j) - UFx(i - 1, j));
+        cff2 = 0.5 * (pm(i - 1, j) + pm(i, j)) * (UFe(i, j + 1) - UFe(i, j));
+        fac = cff1 + cff2;
+        rhs_ubar(i, j) = rhs_ubar(i, j) - fac;
+      }
+    for (int j = JstrV; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        cff1 = 0.5 * (pn(i, j - 1) + pn(i, j)) * (VFx(i + 1, j) - VFx(i, j));
+        cff2 = 0.5 * (pm(i, j - 1) + pm(i, j)) * (VFe(i, j) - VFe(i, j - 1));
+        fac = cff1 - cff2;
+        rhs_vbar(i, j) = rhs_vbar(i, j) - fac;
+      }
+    free(LapU_); free(LapV_);
+#undef LapU
+#undef LapV
   }
 
   /* coupling between 2-D and 3-D equations, :1884-2065 */

@@ -9,7 +9,7 @@ from roms_trunk_mgh_amd import abi
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 KERNEL_ID = {"set_depth": 1, "set_massflux": 2, "set_zeta": 3, "rho_eos": 4, "prsgrd": 5,
-             "t3dmix2": 6, "uv3dmix2": 7}
+             "t3dmix2": 6, "uv3dmix2": 7, "t3dmix4": 8, "uv3dmix4": 9}
 
 
 def lib_path(app):
@@ -24,6 +24,8 @@ class Ref:
     def __init__(self, state):
         app = state.cfg["app"] + ("_MASK" if state.p.masking else "")      # <APP>_MASK: built with -DMASKING
         app += {0: "", 1: "_PG31", 2: "_WJ"}[int(state.p.pgf)]             # prsgrd31.h builds (plain / WJ_GRADP)
+        if state.p.ts_dif4 or state.p.uv_vis4:
+            app += "_DIF4"                                                 # built with TS_DIF4 and UV_VIS4 added
         self.l = C.CDLL(lib_path(app))
         self.st = state
         self.l.ref_abi_sizeof.argtypes = [C.c_int]

@@ -50,6 +50,7 @@ MODULE ref_wrap_types
     INTEGER(c_int) :: masking, pgf
     INTEGER(c_int) :: lbc(6,4)          ! C: lbc[side][variable]
     REAL(c_double) :: obc_out(6,4), obc_in(6,4)   ! nudging coefficients of RadNud edges (1/s)
+    INTEGER(c_int) :: ts_dif4, uv_vis4
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -68,6 +69,7 @@ MODULE ref_wrap_types
     TYPE(c_ptr) :: wvel, lonr, latr
     TYPE(c_ptr) :: rmask, umask, vmask, pmask
     TYPE(c_ptr) :: zeta_bry, ubar_bry, vbar_bry, u_bry, v_bry, t_bry
+    TYPE(c_ptr) :: visc4_p, visc4_r, diff4
   END TYPE fields_t
   LOGICAL, SAVE :: have_boundary = .FALSE.      ! allocate_boundary is done once per process
 END MODULE ref_wrap_types
@@ -249,6 +251,11 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   USE prsgrd_mod,       ONLY : prsgrd
   USE t3dmix2_mod,      ONLY : t3dmix2
   USE uv3dmix2_mod,     ONLY : uv3dmix2
+#ifdef REF_DIF4
+  USE t3dmix4_mod,      ONLY : t3dmix4
+  USE uv3dmix4_mod,     ONLY : uv3dmix4
+  USE mod_ncparam
+#endif
   INTEGER(c_int), VALUE :: kernel
   TYPE(bounds_t), INTENT(in) :: b
   TYPE(params_t), INTENT(in) :: p
@@ -256,6 +263,7 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   TYPE(fields_t), INTENT(in) :: F
   INTEGER(c_int) :: rc
   INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT
+  INTEGER :: side4(4), sd4, v4, code4, it4
   REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:), a5(:,:,:,:,:)
   ng = 1; tile = 0
   LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
@@ -314,6 +322,39 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   CALL c_f_pointer (F%visc2_r, a2, (/ni,nj/));  MIXING(ng)%visc2_r = a2
 #endif
   CALL c_f_pointer (F%diff2, a3, (/ni,nj,NTT/)); MIXING(ng)%diff2 = a3
+#ifdef REF_DIF4
+  CALL c_f_pointer (F%visc4_p, a2, (/ni,nj/));  MIXING(ng)%visc4_p = a2
+  CALL c_f_pointer (F%visc4_r, a2, (/ni,nj/));  MIXING(ng)%visc4_r = a2
+  CALL c_f_pointer (F%diff4, a3, (/ni,nj,NTT/)); MIXING(ng)%diff4 = a3
+  gamma2(ng) = p%gamma2
+  !  the biharmonic operators ask whether the condition of the variable on a physical edge is "closed"
+  !  (t3dmix4_s.h:353, uv3dmix4_s.h:392): LBC from p%lbc (rows 4, 5, 6 = u, v, tracers; 0 = the side's lbc_west ...)
+  IF (.NOT. allocated(isTvar)) THEN
+    allocate ( isTvar(MT) )
+    DO it4 = 1, MT
+      isTvar(it4) = 5 + it4                     ! mod_ncparam.F:1196-1203
+    END DO
+  END IF
+  side4(1) = iwest; side4(2) = ieast; side4(3) = isouth; side4(4) = inorth
+  DO sd4 = 1, 4
+    DO v4 = 4, 6
+      code4 = p%lbc(v4, sd4)
+      IF (code4 == 0) THEN
+        IF (sd4 == 1) code4 = p%lbc_west
+        IF (sd4 == 2) code4 = p%lbc_east
+        IF (sd4 == 3) code4 = p%lbc_south
+        IF (sd4 == 4) code4 = p%lbc_north
+      END IF
+      IF (v4 < 6) THEN
+        LBC(side4(sd4), v4, ng)%closed = code4 == 1
+      ELSE
+        DO it4 = 1, NTT
+          LBC(side4(sd4), isTvar(it4), ng)%closed = code4 == 1
+        END DO
+      END IF
+    END DO
+  END DO
+#endif
 #ifdef BENCHMARK
   CALL c_f_pointer (F%bvf, a3, (/ni,nj,NN+1/)); MIXING(ng)%bvf = a3
   CALL c_f_pointer (F%alpha, a2, (/ni,nj/));    MIXING(ng)%alpha = a2
@@ -329,6 +370,10 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   CASE (6); CALL t3dmix2 (ng, tile)
 #if defined BENCHMARK || defined UPWELLING
   CASE (7); CALL uv3dmix2 (ng, tile)
+#endif
+#ifdef REF_DIF4
+  CASE (8); CALL t3dmix4 (ng, tile)
+  CASE (9); CALL uv3dmix4 (ng, tile)
 #endif
   CASE DEFAULT; rc = 2
   END SELECT

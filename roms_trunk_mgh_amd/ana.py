@@ -195,7 +195,9 @@ def make_params(cfg, NT):
     p.uv_vis2 = int(app in ("BENCHMARK", "UPWELLING"))
     p.curvgrid = int(app == "BENCHMARK")
     p.var_rho_2d = 1                      # globaldefs.h:491-495, always with SOLVE3D
-    p.ts_dif2 = 1
+    p.ts_dif2 = int(cfg.get("ts_dif2", 1))
+    p.ts_dif4 = int(cfg.get("ts_dif4", 0))
+    p.uv_vis4 = int(cfg.get("uv_vis4", 0))
     p.mix_geo_ts = int(app in ("BENCHMARK", "SEAMOUNT"))
     p.mix_s_ts = int(app == "UPWELLING")
     p.salinity = int(app in ("BENCHMARK", "UPWELLING"))
@@ -305,6 +307,10 @@ def _grid_global(cfg, b, st):
     A["visc2_r"][:] = cfg["visc2"]
     A["visc2_p"][:] = cfg["visc2"]
     A["diff2"][:] = cfg["tnu2"]
+    # biharmonic coefficients: the reference stores the square root (inp_par.F:986, read_phypar.F:6905)
+    A["visc4_r"][:] = math.sqrt(abs(cfg.get("visc4", 0.0)))
+    A["visc4_p"][:] = math.sqrt(abs(cfg.get("visc4", 0.0)))
+    A["diff4"][:] = math.sqrt(abs(cfg.get("tnu4", 0.0)))
 
 
 def set_masks(st, rmask):
@@ -375,7 +381,7 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
     NAT = cfg["NAT"]
     NT = NT or NAT
     adv = {cfg["Hadv"], cfg["Vadv"]} | set(cfg.get("Hadv_list", [])) | set(cfg.get("Vadv_list", []))
-    nghost = 3 if adv & {"MPDATA", "HSIMT"} else 2          # inp_par.F:266-278
+    nghost = 3 if (adv & {"MPDATA", "HSIMT"}) or cfg.get("uv_vis4") else 2          # inp_par.F:264-278
     b = make_bounds(cfg["Lm"], cfg["Mm"], cfg["N"], NT, NAT, ntileI, ntileJ, tile,
                     EWperiodic=bool(cfg.get("EWperiodic", True)), NSperiodic=False, NghostPoints=nghost)
     p = make_params(cfg, NT)

@@ -333,6 +333,7 @@ extern "C" int roms_hip_register_field(int id, double *host_ptr, long n_doubles)
 extern "C" int roms_hip_sync_to_device(int id)
 {
   if (id < 0 || id >= FID_COUNT || !g_ctx.dev[id]) return roms_fail("roms_hip_sync_to_device", "field not registered");
+  if (!g_ctx.host[id]) return roms_fail("roms_hip_sync_to_device", "field is kept by the library (no host array registered)");
   HIP_TRY(hipMemcpyAsync(g_ctx.dev[id], g_ctx.host[id], sizeof(double) * g_ctx.count[id], hipMemcpyHostToDevice, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   if (roms_rowm_is_table_field(id)) roms_rowm_invalidate();      // a grid-metric array may have changed
@@ -342,6 +343,7 @@ extern "C" int roms_hip_sync_to_device(int id)
 extern "C" int roms_hip_sync_to_host(int id)
 {
   if (id < 0 || id >= FID_COUNT || !g_ctx.dev[id]) return roms_fail("roms_hip_sync_to_host", "field not registered");
+  if (!g_ctx.host[id]) return roms_fail("roms_hip_sync_to_host", "field is kept by the library (no host array registered)");
   HIP_TRY(hipMemcpyAsync(g_ctx.host[id], g_ctx.dev[id], sizeof(double) * g_ctx.count[id], hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return 0;
@@ -350,7 +352,7 @@ extern "C" int roms_hip_sync_to_host(int id)
 extern "C" int roms_hip_sync_all_to_device(void)
 {
   for (int id = 0; id < FID_COUNT; id++)
-    if (g_ctx.dev[id])
+    if (g_ctx.dev[id] && g_ctx.host[id])
       HIP_TRY(hipMemcpyAsync(g_ctx.dev[id], g_ctx.host[id], sizeof(double) * g_ctx.count[id], hipMemcpyHostToDevice, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   roms_rowm_invalidate();
@@ -360,7 +362,7 @@ extern "C" int roms_hip_sync_all_to_device(void)
 extern "C" int roms_hip_sync_all_to_host(void)
 {
   for (int id = 0; id < FID_COUNT; id++)
-    if (g_ctx.dev[id])
+    if (g_ctx.dev[id] && g_ctx.host[id])
       HIP_TRY(hipMemcpyAsync(g_ctx.host[id], g_ctx.dev[id], sizeof(double) * g_ctx.count[id], hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return 0;
@@ -379,6 +381,22 @@ extern "C" int roms_hip_device_synchronize(void)
   return 0;
 }
 
+// Fields an application without the option does not have: the land/sea masks without MASKING, the biharmonic
+// coefficients without UV_VIS4 / TS_DIF4.  Left unregistered they are kept by the library -- all water / zero --
+// so that every kernel still finds an array; the value is never used by the arithmetic (masking = 0 selects code
+// without mask loads, the biharmonic operators are not called).
+static int library_default(int id, double *value)
+{
+  const roms_params_t &p = g_ctx.p;
+  switch (id) {
+  case FID_rmask: case FID_umask: case FID_vmask: case FID_pmask:
+    *value = 1.0; return !p.masking;
+  case FID_visc4_p: case FID_visc4_r: *value = 0.0; return !p.uv_vis4;
+  case FID_diff4: *value = 0.0; return !p.ts_dif4;
+  default: return 0;
+  }
+}
+
 // Every kernel entry calls this first.
 int roms_entry_check(const char *name)
 {
@@ -386,6 +404,19 @@ int roms_entry_check(const char *name)
   if (!g_ctx.have_bounds || !g_ctx.have_params) return roms_fail(name, "bounds/params not set");
   for (int id = 0; id < FID_COUNT; id++)
     if (!g_ctx.dev[id]) {
+      double value;
+      if (library_default(id, &value)) {
+        const long want = roms_field_count(k_field_kind[id], g_ctx.b);
+        int rc = guarded_alloc(&g_ctx.dev[id], &g_ctx.dev_base[id], want);
+        if (rc) return rc;
+        std::vector<double> fill((size_t)want, value);
+        HIP_TRY(hipMemcpy(g_ctx.dev[id], fill.data(), sizeof(double) * want, hipMemcpyHostToDevice));
+        g_ctx.host[id] = nullptr;
+        g_ctx.count[id] = want;
+        *(reinterpret_cast<double **>(&g_ctx.hostc.F) + id) = g_ctx.dev[id];
+        g_ctx.devc_dirty = true;
+        continue;
+      }
       std::string m = std::string("field not registered: ") + k_field_name[id];
       return roms_fail(name, m.c_str());
     }

@@ -1,8 +1,11 @@
-// k_mix.hip -- harmonic lateral mixing on the 3-D step:
+// k_mix.hip -- harmonic and biharmonic lateral mixing of tracers on the 3-D step:
 //   t3dmix2_geo_tile  ROMS/Nonlinear/t3dmix2_geo.h:90-424  (rotated to
 //                     geopotentials, two-slab k-recursion)
 //   t3dmix2_s_tile    ROMS/Nonlinear/t3dmix2_s.h:89-306    (along s-surfaces)
-// (uv3dmix2_s_tile is in k_uv3dmix2.hip)
+//   t3dmix4_geo_tile  ROMS/Nonlinear/t3dmix4_geo.h:104-784 \ the same operators applied twice (MODE 1: tracer ->
+//   t3dmix4_s_tile    ROMS/Nonlinear/t3dmix4_s.h:100-480   /  LapT on a range one point wider, with the reference's
+//                     rule for LapT outside a physical edge; MODE 2: LapT -> tracer), coefficient diff4
+// (uv3dmix2_s_tile / uv3dmix4_s_tile are in k_uv3dmix2.hip)
 //
 // One thread per (i,j) column sweeping k upward.  The reference's two-slab
 // buffers (level k and k+1 of dZdx,dTdx,dZde,dTde, W-levels k-1 and k of dTdz,
@@ -17,24 +20,54 @@ namespace {
 __device__ __forceinline__ double dmin0(double a) { return a < 0.0 ? a : 0.0; }   // MIN(a,0)
 __device__ __forceinline__ double dmax0(double a) { return a > 0.0 ? a : 0.0; }   // MAX(a,0)
 
+// The range and the edge rule of the first biharmonic operator (t3dmix4_s.h:262-275, :347-405): one point beyond the
+// tile inside the grid; outside a physical edge LapT is zero where the tracer's condition is closed, a copy of the
+// first inside value otherwise.  (The corner values the reference also sets are never read by the second operator.)
+struct Lap4 {
+  double *lap;                  // LapT of one tracer, module extents
+  int i0, i1, j0, j1;           // Imin:Imax, Jmin:Jmax
+  int closed[4];                // [LBS_WEST .. LBS_NORTH]
+  int itrc;
+};
+
+template <int MODE>
+__device__ __forceinline__ void lap4_store(const roms_bounds_t &b, const Lap4 &L, long ni, int i, int j, long a, double val)
+{
+  const gd_t lap = (gd_t)L.lap;
+  lap[a] = val;
+  if (!b.EWperiodic) {
+    if (b.west_edge && i == b.Istr) lap[a - 1] = L.closed[LBS_WEST] ? 0.0 : val;
+    if (b.east_edge && i == b.Iend) lap[a + 1] = L.closed[LBS_EAST] ? 0.0 : val;
+  }
+  if (!b.NSperiodic) {
+    if (b.south_edge && j == b.Jstr) lap[a - ni] = L.closed[LBS_SOUTH] ? 0.0 : val;
+    if (b.north_edge && j == b.Jend) lap[a + ni] = L.closed[LBS_NORTH] ? 0.0 : val;
+  }
+}
+
+// MODE 0: t3dmix2_geo (all tracers of the launch).  MODE 1 / 2: first / second operator of t3dmix4_geo for tracer
+// L.itrc -- the arithmetic of the three blocks of the reference is the same.
+template <int MODE>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
-k_t3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
+k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
 {
   DEV_PROLOGUE(c)
-  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, b.NT);
+  const int ilo = MODE == 1 ? L.i0 : b.Istr, ihi = MODE == 1 ? L.i1 : b.Iend;
+  const int jlo = MODE == 1 ? L.j0 : b.Jstr, jhi = MODE == 1 ? L.j1 : b.Jend;
+  const TileTr tt = decode_tile_tracer(ihi - ilo + 1, jhi - jlo + 1, MODE == 0 ? b.NT : 1);
   if (!tt.valid) return;
-  const int i = b.Istr + tt.bx * BLK_X + threadIdx.x;
-  const int j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
-  const int itrc = 1 + tt.itr;
-  if (i > b.Iend || j > b.Jend) return;
+  const int i = ilo + tt.bx * BLK_X + threadIdx.x;
+  const int j = jlo + tt.by * BLK_Y + threadIdx.y;
+  const int itrc = MODE == 0 ? 1 + tt.itr : L.itrc;
+  if (i > ihi || j > jhi) return;
   const double dt = c->p.dt;
-  const double *__restrict__ T = c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
+  const double *__restrict__ T = MODE == 2 ? L.lap : c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
   double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
   const double *__restrict__ z_r = c->F.z_r;
   const double *__restrict__ Hz = c->F.Hz;
   const double *__restrict__ pm = c->F.pm;
   const double *__restrict__ pn = c->F.pn;
-  const double *__restrict__ d2 = c->F.diff2 + (long)(itrc - 1) * nij;
+  const double *__restrict__ d2 = (MODE == 0 ? c->F.diff2 : c->F.diff4) + (long)(itrc - 1) * nij;
   const long c0 = I2(i, j);
   // face metrics: xi faces i and i+1, eta faces j and j+1
   double mx0 = 0.5 * (pm[c0] + pm[c0 - 1]), mx1 = 0.5 * (pm[c0 + 1] + pm[c0]);
@@ -122,11 +155,18 @@ k_t3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
       FS_b = FS_b + cfs * (c1 * (c1 * dz0_b - te0_a) + c2 * (c2 * dz0_b - te1_b) +
                            c3 * (c3 * dz0_b - te0_b) + c4 * (c4 * dz0_b - te1_a));
     } else FS_b = 0.0;
-    const double cff1 = cdt * (FX1 - FX0);
-    const double cff2 = cdt * (FE1 - FE0);
-    const double cff3 = dt * (FS_b - FS_a);
-    const double cff4 = cff1 + cff2 + cff3;
-    gtn[ck] = cur.tn + cff4;
+    if constexpr (MODE == 1) {                 // t3dmix4_geo.h:445-455
+      const double cff = pm[c0] * pn[c0];
+      const double cff1 = 1.0 / hz0;
+      lap4_store<MODE>(b, L, ni, i, j, ck, cff1 * (cff * (FX1 - FX0 + FE1 - FE0) + (FS_b - FS_a)));
+    } else {
+      const double cff1 = cdt * (FX1 - FX0);
+      const double cff2 = cdt * (FE1 - FE0);
+      const double cff3 = dt * (FS_b - FS_a);
+      const double cff4 = cff1 + cff2 + cff3;
+      if constexpr (MODE == 0) gtn[ck] = cur.tn + cff4;
+      else gtn[ck] = cur.tn - cff4;            // t3dmix4_geo.h:767
+    }
     cur = nxt;
     dzm_a = dzm_b; dz0_a = dz0_b; dzp_a = dzp_b; dzs_a = dzs_b; dzn_a = dzn_b;
     FS_a = FS_b;
@@ -170,6 +210,56 @@ k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
   }
 }
 
+// t3dmix4_s_tile, first operator (MODE 1, :281-345) and second operator with the time step (MODE 2, :407-475)
+template <int MODE>
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_t3dmix4_s(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
+{
+  DEV_PROLOGUE(c)
+  const int ilo = MODE == 1 ? L.i0 : b.Istr, ihi = MODE == 1 ? L.i1 : b.Iend;
+  const int jlo = MODE == 1 ? L.j0 : b.Jstr, jhi = MODE == 1 ? L.j1 : b.Jend;
+  const TileTr tt = decode_tile_tracer(ihi - ilo + 1, jhi - jlo + 1, 1);
+  if (!tt.valid) return;
+  const int i = ilo + tt.bx * BLK_X + threadIdx.x;
+  const int j = jlo + tt.by * BLK_Y + threadIdx.y;
+  const int itrc = L.itrc;
+  if (i > ihi || j > jhi) return;
+  const double *__restrict__ T = MODE == 2 ? L.lap : c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
+  double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
+  const double *__restrict__ Hz = c->F.Hz;
+  const double *__restrict__ d4 = c->F.diff4 + (long)(itrc - 1) * nij;
+  const long c0 = I2(i, j);
+  double cfx0 = 0.25 * (d4[c0] + d4[c0 - 1]) * c->F.pmon_u[c0];
+  double cfx1 = 0.25 * (d4[c0 + 1] + d4[c0]) * c->F.pmon_u[c0 + 1];
+  double cfe0 = 0.25 * (d4[c0] + d4[c0 - ni]) * c->F.pnom_v[c0];
+  double cfe1 = 0.25 * (d4[c0 + ni] + d4[c0]) * c->F.pnom_v[c0 + ni];
+  const bool masking = c->p.masking != 0;
+  const double um0 = masking ? c->F.umask[c0] : 1.0, um1 = masking ? c->F.umask[c0 + 1] : 1.0;
+  const double vm0 = masking ? c->F.vmask[c0] : 1.0, vm1 = masking ? c->F.vmask[c0 + ni] : 1.0;
+  if (MODE == 1 && masking) {                            // the first operator masks the coefficient, :296, :326
+    cfx0 = cfx0 * um0; cfx1 = cfx1 * um1; cfe0 = cfe0 * vm0; cfe1 = cfe1 * vm1;
+  }
+  const double pmn = c->F.pm[c0] * c->F.pn[c0];
+  const double cdt = c->p.dt * c->F.pm[c0] * c->F.pn[c0];
+  for (int k = 1; k <= N; k++) {
+    const long ck = c0 + (long)(k - 1) * nij;
+    const double t0 = T[ck], h0 = Hz[ck];
+    double FX0 = cfx0 * (h0 + Hz[ck - 1]) * (t0 - T[ck - 1]);
+    double FX1 = cfx1 * (Hz[ck + 1] + h0) * (T[ck + 1] - t0);
+    double FE0 = cfe0 * (h0 + Hz[ck - ni]) * (t0 - T[ck - ni]);
+    double FE1 = cfe1 * (Hz[ck + ni] + h0) * (T[ck + ni] - t0);
+    if constexpr (MODE == 1) {
+      const double cff = 1.0 / h0;
+      lap4_store<MODE>(b, L, ni, i, j, ck, pmn * cff * (FX1 - FX0 + FE1 - FE0));
+    } else {
+      if (masking) { FX0 = FX0 * um0; FX1 = FX1 * um1; FE0 = FE0 * vm0; FE1 = FE1 * vm1; }   // the second the flux, :425, :446
+      const double cff1 = cdt * (FX1 - FX0);
+      const double cff2 = cdt * (FE1 - FE0);
+      tn[ck] = tn[ck] - (cff1 + cff2);
+    }
+  }
+}
+
 }  // namespace
 
 static int t3dmix2_launch(const roms_step_idx_t *s)
@@ -177,7 +267,7 @@ static int t3dmix2_launch(const roms_step_idx_t *s)
   const roms_bounds_t &b = g_ctx.b;
   const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, b.NT);
   if (g_ctx.p.mix_geo_ts)
-    hipLaunchKernelGGL(k_t3dmix2_geo, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew);
+    hipLaunchKernelGGL(k_t3dmix_geo<0>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, Lap4{});
   else if (g_ctx.p.mix_s_ts)
     hipLaunchKernelGGL(k_t3dmix2_s, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew);
   else
@@ -192,4 +282,37 @@ extern "C" int roms_hip_t3dmix2(const roms_step_idx_t *s)
   if (rc) return rc;
   ScopedTimer tm("t3dmix2");
   return t3dmix2_launch(s);
+}
+
+extern "C" int roms_hip_t3dmix4(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_t3dmix4");
+  if (rc) return rc;
+  const roms_bounds_t &b = g_ctx.b;
+  const roms_params_t &p = g_ctx.p;
+  if (!p.ts_dif4) return roms_fail("roms_hip_t3dmix4", "TS_DIF4 is not set (roms_params_t.ts_dif4)");
+  if (!p.mix_geo_ts && !p.mix_s_ts)
+    return roms_fail("roms_hip_t3dmix4", "no tracer mixing option (MIX_GEO_TS / MIX_S_TS) selected");
+  ScopedTimer tm("t3dmix4");
+  Lap4 L;
+  L.lap = g_ctx.hostc.ws3[1];
+  if (b.EWperiodic) { L.i0 = b.Istr - 1; L.i1 = b.Iend + 1; }
+  else { L.i0 = b.Istr - 1 > 1 ? b.Istr - 1 : 1; L.i1 = b.Iend + 1 < b.Lm ? b.Iend + 1 : b.Lm; }
+  if (b.NSperiodic) { L.j0 = b.Jstr - 1; L.j1 = b.Jend + 1; }
+  else { L.j0 = b.Jstr - 1 > 1 ? b.Jstr - 1 : 1; L.j1 = b.Jend + 1 < b.Mm ? b.Jend + 1 : b.Mm; }
+  for (int sd = 0; sd < 4; sd++) L.closed[sd] = lbc_code(p, sd, LBV_T) == LBC_CLOSED;
+  const dim3 g1 = grid_tile_tracer(L.i1 - L.i0 + 1, L.j1 - L.j0 + 1, 1);
+  const dim3 g2 = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, 1);
+  for (int itrc = 1; itrc <= b.NT; itrc++) {
+    L.itrc = itrc;
+    if (p.mix_geo_ts) {
+      hipLaunchKernelGGL(k_t3dmix_geo<1>, g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      hipLaunchKernelGGL(k_t3dmix_geo<2>, g2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+    } else {
+      hipLaunchKernelGGL(k_t3dmix4_s<1>, g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      hipLaunchKernelGGL(k_t3dmix4_s<2>, g2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+    }
+    KERNEL_CHECK("k_t3dmix4");
+  }
+  return 0;
 }

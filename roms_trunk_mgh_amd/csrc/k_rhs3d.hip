@@ -296,14 +296,16 @@ extern "C" int roms_hip_rhs3d_tile(const roms_step_idx_t *s)
   return 0;
 }
 
-// rhs3d(ng,tile) -- rhs3d.F:25-170: pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2
+// rhs3d(ng,tile) -- rhs3d.F:25-170: pre_step3d, prsgrd, t3dmix2, t3dmix4, rhs3d_tile, uv3dmix2, uv3dmix4
 extern "C" int roms_hip_rhs3d(const roms_step_idx_t *s)
 {
   int rc;
   if ((rc = roms_hip_pre_step3d(s))) return rc;
   if ((rc = roms_hip_prsgrd(s))) return rc;
   if (g_ctx.p.ts_dif2 && (rc = roms_hip_t3dmix2(s))) return rc;
+  if (g_ctx.p.ts_dif4 && (rc = roms_hip_t3dmix4(s))) return rc;
   if ((rc = roms_hip_rhs3d_tile(s))) return rc;
   if (g_ctx.p.uv_vis2 && (rc = roms_hip_uv3dmix2(s))) return rc;
+  if (g_ctx.p.uv_vis4 && (rc = roms_hip_uv3dmix4(s))) return rc;
   return 0;
 }

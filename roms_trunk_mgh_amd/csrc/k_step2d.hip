@@ -20,6 +20,7 @@
 #include <map>
 
 int roms_entry_check(const char *name);
+int roms_launch_step2d_visc4(int krhs);      // k_uv3dmix2.hip
 int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DVom, const double *zeta_new,
                             const double *zwrk, double *DUnext = nullptr, double *DVnext = nullptr);   // k_step2d_mom.hip
 
@@ -261,7 +262,8 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   // (the fused kernels apply the closed-wall conditions themselves; open S/N edges take the general path below,
   // whose boundary conditions are separate launches)
   const bool walls = lbc2d_all_closed();
-  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.loopback && walls;
+  // (UV_VIS4: the biharmonic term is a pass of its own in front of the momentum kernel -- general path only)
+  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.loopback && walls && !p.uv_vis4;
   if (sm) {
     if (s.iif <= p.nfast) {
       // ONE launch: free surface, fast-time averages and momentum (k2d_mom_lds<true>)
@@ -300,7 +302,7 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
     if ((rc = halo_batch_end())) return rc;
   }
   g_flux_ready = false;
-  if (in_loop && multi && walls && s.iif <= p.nfast) {
+  if (in_loop && multi && walls && s.iif <= p.nfast && !p.uv_vis4) {
     // ONE compute launch + ONE exchange per call
     s.sm = 3;
     if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, nullptr, nullptr, DUnext, DVnext))) return rc;
@@ -330,6 +332,7 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   }
   if (s.iif > p.nfast) return 0;
   if ((rc = bc_zeta(s.knew, si))) return rc;
+  if (p.uv_vis4 && (rc = roms_launch_step2d_visc4(s.krhs))) return rc;
   if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, zeta_new, zwrk))) return rc;
   if ((rc = bc_u2d(s.knew, si))) return rc;
   if ((rc = bc_v2d(s.knew, si))) return rc;

@@ -407,6 +407,12 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       rhs_v = rhs_v + (cff1 - cff2);
     }
   }
+  // ---- biharmonic viscosity, :1474-1740: evaluated by the pass in front of this kernel (roms_launch_step2d_visc4,
+  // k_uv3dmix2.hip); UV_VIS4 runs take the general path, so `a` is this thread's own point ----
+  if (p.uv_vis4) {
+    if (do_u) rhs_u = rhs_u - c->ws2[22][a];
+    if (do_v) rhs_v = rhs_v - c->ws2[23][a];
+  }
   // ---- coupling between 2-D and 3-D equations, :1884-2065 ----
   if (s.iif == 1 && s.predictor) {
     // never source-mapped (step2d_impl), so owner is always true here

@@ -63,6 +63,9 @@ def checksum(st):
         # likewise the open-boundary data arrays (all zero unless a clamped / Flather condition is tested)
         if name.endswith("_bry") and not st.arr[name].any():
             continue
+        # and the biharmonic coefficients (all zero unless TS_DIF4 / UV_VIS4 is tested)
+        if name in ("visc4_p", "visc4_r", "diff4") and not st.arr[name].any():
+            continue
         h.update(np.ascontiguousarray(st.arr[name]).tobytes())
     return h.hexdigest()
 

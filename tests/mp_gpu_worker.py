@@ -24,6 +24,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
     if "mask" in opts:
         kw["mask"] = "island"
+    if "dif4" in opts:                   # biharmonic mixing (three ghost points with UV_VIS4)
+        kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:
         kw.setdefault("overrides", {})["EWperiodic"] = False
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)

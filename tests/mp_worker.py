@@ -20,13 +20,16 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
-    if variant == "hsimt":
+    opts = set(variant.split("+")) if variant else set()
+    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
+    if "hsimt" in opts:
         kw = dict(overrides={"Hadv": "HSIMT", "Vadv": "HSIMT"})
-    if variant == "mask":
-        kw = dict(mask="island")
-    if variant == "basin":               # no periodic direction
-        kw = dict(overrides={"EWperiodic": False})
+    if "mask" in opts:
+        kw["mask"] = "island"
+    if "dif4" in opts:                   # biharmonic mixing (three ghost points with UV_VIS4)
+        kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
+    if "basin" in opts:                  # no periodic direction
+        kw.setdefault("overrides", {})["EWperiodic"] = False
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb, **kw)
     b = st.b
     ni, nj = st.ni, st.nj

@@ -52,6 +52,41 @@ def main(config, mask=None, pgf=0, basin=False):
     print(json.dumps(out))
 
 
+DIF4 = {"ts_dif4": 1, "uv_vis4": 1, "tnu4": 2.0e7, "visc4": 4.0e7}
+
+
+def main_dif4(config, basin=None, mask=None):
+    """The biharmonic operators t3dmix4 (UPWELLING: along s-surfaces, SEAMOUNT: along geopotentials) and uv3dmix4
+    (along s-surfaces): reference Fortran (built with TS_DIF4 and UV_VIS4 added) vs C oracle.  basin = "closed" /
+    "open": no periodic direction -- the rule for the first operator's result on the four edges and the corners
+    (zero / gamma2-slip where the variable's condition is closed, a copy / zero otherwise)."""
+    import oracle
+    import util
+    from oracle import ref
+    from roms_trunk_mgh_amd import abi
+    ov = dict(DIF4)
+    if basin:
+        ov["EWperiodic"] = False
+    st0 = util.prepared_state(config, overrides=ov, mask=mask)
+    assert st0.b.NghostPoints == 3 and st0.p.ts_dif4 == 1 and st0.p.uv_vis4 == 1
+    if basin == "open":
+        for sd in ("west", "east", "south", "north"):
+            for var in ("u", "v", "t"):
+                st0.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC["Gra"]
+    out = {"EWperiodic": int(st0.b.EWperiodic), "masking": int(st0.p.masking), "kernels": {}}
+    s = util.step_idx()
+    for k in ("t3dmix4", "uv3dmix4"):
+        st_r, st_o = st0.copy(), st0.copy()
+        ref.Ref(st_r).call(k, s)
+        oracle.Oracle(st_o).call(k, s)
+        diffs = util.compare_states(st_o, st_r)
+        changed = util.compare_states(st_r, st0)
+        out["kernels"][k] = {"max_rel_diff": max(diffs.values()) if diffs else 0.0, "fields_diff": sorted(diffs),
+                             "changed": sorted(changed),
+                             "change": max(util.max_rel_diff(st_r[n], st0[n]) for n in ("t", "u", "v"))}
+    print(json.dumps(out))
+
+
 def main_bc(config, mask=None):
     """The six lateral boundary-condition routines on the S/N edges, every condition the library offers, for the
     three states of the barotropic stepping (first, predictor, corrector): reference Fortran vs C oracle."""
@@ -442,6 +477,9 @@ if __name__ == "__main__":
                      basin=sys.argv[2] == "physics_basin")
     elif len(sys.argv) > 2 and sys.argv[2] == "basin":
         main(sys.argv[1], basin=True)
+    elif len(sys.argv) > 2 and sys.argv[2] in ("dif4", "dif4_closed", "dif4_open", "dif4_mask", "dif4_mask_open"):
+        m = sys.argv[2].split("_")
+        main_dif4(sys.argv[1], basin=m[-1] if m[-1] in ("closed", "open") else None, mask="island" if "mask" in m else None)
     elif len(sys.argv) > 2 and sys.argv[2] in ("mpdata", "mpdata_mask"):
         main_mpdata(sys.argv[1], mask="island" if sys.argv[2] == "mpdata_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] in ("mpdata_closed", "mpdata_open", "mpdata_mask_open"):

@@ -1,0 +1,113 @@
+"""-m gpu: biharmonic lateral mixing (TS_DIF4, UV_VIS4; SURVEY.md section 8f-4 "other selectable numerics").  HIP
+against the CPU oracle through the C ABI; the oracle's t3dmix4 / uv3dmix4 are pinned bit for bit against the
+reference's Fortran (tests/test_ref_pinning.py, tests/test_golden.py); the 2-D operator inside step2d
+(step2d_LF_AM3.h:1474-1740) belongs to an unpinned routine and is checked against the oracle only."""
+import numpy as np
+import pytest
+
+import util
+from roms_trunk_mgh_amd import abi, ana, hip, main3d
+from roms_trunk_mgh_amd.state import rel_rms
+
+pytestmark = pytest.mark.gpu
+DIF4 = {"UPWELLING": {"ts_dif4": 1, "uv_vis4": 1, "tnu4": 2.0e7, "visc4": 4.0e7},          # t3dmix4_s
+        "SEAMOUNT": {"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e8, "visc4": 1.0e8},           # t3dmix4_geo
+        "BENCHMARK_TINY": {"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10}}   # t3dmix4_geo, curvilinear terms
+
+
+def _state(config, variant):
+    ov = dict(DIF4[config])
+    if variant in ("closed", "open"):
+        ov["EWperiodic"] = False
+    st = util.prepared_state(config, overrides=ov, mask="island" if variant == "mask" else None)
+    if variant == "open":
+        for sd in ("west", "east", "south", "north"):
+            for var in ("ubar", "vbar", "u", "v", "t"):
+                st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC["Gra"]
+    assert st.b.NghostPoints == 3
+    return st
+
+
+@pytest.mark.parametrize("config", ["UPWELLING", "SEAMOUNT", "BENCHMARK_TINY"])
+@pytest.mark.parametrize("variant", ["periodic", "closed", "open", "mask"])
+@pytest.mark.parametrize("kernel", ["t3dmix4", "uv3dmix4", "rhs3d", "step2d"])
+def test_biharmonic_kernels(config, variant, kernel):
+    import oracle
+    st0 = _state(config, variant)
+    st_o, st_h = st0.copy(), st0.copy()
+    preds = [(5, 1, 0)] if kernel != "step2d" else [(5, 1, 1), (5, 2, 1), (5, 2, 0)]
+    for iic, iif, pred in preds:
+        s = util.step_idx(iic=iic, iif=iif, pred=pred, knew=3 if pred else 2, krhs=1 if pred else 3)
+        oracle.Oracle(st_o).call(kernel, s)
+        h = hip.RomsHip(st_h)
+        try:
+            h.call(kernel, s)
+            h.to_host()
+        finally:
+            h.close()
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= 1e-12 for v in diffs.values()), diffs
+    assert util.compare_states(st_o, st0)
+
+
+def test_biharmonic_term_is_in_step2d():
+    """the 2-D operator changes the barotropic right-hand side: the same call without UV_VIS4 gives another ubar"""
+    import oracle
+    st4 = _state("UPWELLING", "periodic")
+    st2 = st4.copy()
+    st2.p = type(st4.p).from_buffer_copy(st4.p)
+    st2.p.uv_vis4 = 0
+    s = util.step_idx(iic=5, iif=2, pred=1, knew=3, krhs=1)
+    out = []
+    for st in (st4, st2):
+        h = hip.RomsHip(st)
+        try:
+            h.call("step2d", s)
+            h.to_host()
+        finally:
+            h.close()
+        out.append(st["ubar"][:, :, 2].copy())
+    assert util.max_rel_diff(out[0], out[1]) > 1e-9
+
+
+def test_uv_vis4_needs_three_ghost_points():
+    st = ana.make_tile("UPWELLING", perturb=1.0)           # two ghost points
+    st.p.uv_vis4 = 1
+    h = hip.RomsHip(st)
+    try:
+        with pytest.raises(RuntimeError) as e:
+            h.call("uv3dmix4", util.step_idx())
+        assert "NghostPoints = 3" in str(e.value)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("config,variant", [("UPWELLING", "periodic"), ("SEAMOUNT", "periodic"), ("UPWELLING", "closed"),
+                                            ("BENCHMARK_TINY", "mask")])
+def test_100_steps_with_biharmonic_mixing(config, variant):
+    import oracle
+    ov = dict(DIF4[config])
+    if variant == "closed":
+        ov["EWperiodic"] = False
+    st_o = ana.make_tile(config, perturb=1.0 if config != "SEAMOUNT" else 0.0, overrides=ov,
+                         mask="island" if variant == "mask" else None)
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o))
+    mo.initial()
+    mo.run(100)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be)
+        mh.initial()
+        mh.run(100)
+        be.to_host()
+    finally:
+        be.close()
+    s = mo.s
+    out = {"zeta": rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], 1e-3)}
+    for name in ("u", "v"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], 1e-4)
+    for it in range(st_o.b.NT):
+        out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
+    assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
+    assert all(v <= 1e-10 for v in out.values()), out          # north-star bound

@@ -35,6 +35,8 @@ def _single(config, nsteps, variant=""):
     kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
     if "mask" in opts:
         kw["mask"] = "island"
+    if "dif4" in opts:                   # biharmonic mixing (three ghost points with UV_VIS4)
+        kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:
         kw.setdefault("overrides", {})["EWperiodic"] = False
     st = ana.make_tile(config, perturb=1.0, **kw)
@@ -59,6 +61,10 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "BENCHMARK_TINY", "mask"), (2, 1, "UPWELLING", "mask"),
                                                     # no periodic direction: physical edges on the outer tile sides, corners
                                                     (2, 2, "UPWELLING", "basin"), (2, 1, "BENCHMARK_TINY", "basin+physics"),
+                                                    # MPDATA on a basin with land, across tile edges
+                                                    (2, 2, "BENCHMARK_TINY", "mpdata+basin+mask"),
+                                                    # biharmonic mixing across tile edges
+                                                    (2, 2, "BENCHMARK_TINY", "dif4"), (2, 2, "BENCHMARK_TINY", "dif4+basin+mask"),
                                                     # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
                                                     # 512-column tiles of the 8-GPU run (4x1), both tile rows (2x2), the
                                                     # deferred-flux step2d path and, with six MPDATA tracers, three ghost points

@@ -26,11 +26,16 @@ def _free_port():
 
 def _single(config, nsteps, variant=""):
     import oracle
-    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if variant == "mpdata" else {}
-    if variant == "hsimt":
+    opts = set(variant.split("+")) if variant else set()
+    kw = dict(NT=6, overrides={"Hadv": "MPDATA", "Vadv": "MPDATA"}) if "mpdata" in opts else {}
+    if "hsimt" in opts:
         kw = dict(overrides={"Hadv": "HSIMT", "Vadv": "HSIMT"})
-    if variant == "basin":
-        kw = dict(overrides={"EWperiodic": False})
+    if "mask" in opts:
+        kw["mask"] = "island"
+    if "dif4" in opts:                   # biharmonic mixing (three ghost points with UV_VIS4)
+        kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
+    if "basin" in opts:                  # no periodic direction
+        kw.setdefault("overrides", {})["EWperiodic"] = False
     st = ana.make_tile(config, perturb=1.0, **kw)
     m = main3d.Main3D(oracle.Oracle(st))
     m.initial()
@@ -45,7 +50,14 @@ def _single(config, nsteps, variant=""):
                                                     # HSIMT: three ghost points, limiter reaching two faces upwind
                                                     (2, 2, "BENCHMARK_TINY", "hsimt"),
                                                     # a basin: physical edges on all four sides, corners
-                                                    (2, 2, "UPWELLING", "basin"), (2, 1, "BENCHMARK_TINY", "basin")])
+                                                    (2, 2, "UPWELLING", "basin"), (2, 1, "BENCHMARK_TINY", "basin"),
+                                                    # MPDATA / HSIMT on a basin with land: Ta's boundary values and
+                                                    # corners, the edge rule of Ua / Va, masks -- across tile edges
+                                                    (2, 2, "BENCHMARK_TINY", "mpdata+basin+mask"),
+                                                    (2, 2, "BENCHMARK_TINY", "hsimt+basin+mask"),
+                                                    # biharmonic mixing: the first operator's one-point-wider range
+                                                    # and its edge rule across tile edges, channel and basin
+                                                    (2, 2, "BENCHMARK_TINY", "dif4"), (2, 2, "BENCHMARK_TINY", "dif4+basin+mask")])
 def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     nsteps = 3
     world = ntI * ntJ
