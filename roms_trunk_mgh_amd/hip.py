@@ -109,7 +109,9 @@ class RomsHip:
     name = "hip"
     _live = None
 
-    def __init__(self, state, rank=0, device=0, nccl_unique_id=None):
+    def __init__(self, state, rank=0, device=0, nccl_unique_id=None, leave_unregistered=()):
+        """leave_unregistered: names of fields an application without the option does not have (the land/sea masks
+        without MASKING, visc4_p / visc4_r / diff4 without UV_VIS4 / TS_DIF4): the library keeps defaults for them."""
         self.st = state
         self.l = load()
         if RomsHip._live is not None:
@@ -124,6 +126,8 @@ class RomsHip:
         self._chk(self.l.roms_hip_set_bounds(C.byref(b)), "set_bounds")
         self._chk(self.l.roms_hip_set_params(C.byref(state.p)), "set_params")
         for name, _, _ in abi.FIELDS:
+            if name in leave_unregistered:
+                continue
             a = state.arr[name]
             self._chk(self.l.roms_hip_register_field(abi.FIELD_ID[name], a.ctypes.data, a.size),
                       "register_field " + name)

@@ -86,3 +86,34 @@ def test_snapshot_of_unknown_field_and_double_begin_are_refused():
         h.snapshot_end()
     finally:
         h.close()
+
+
+def test_fields_of_absent_options_may_stay_unregistered():
+    """An application without MASKING / TS_DIF4 / UV_VIS4 has no masks and no biharmonic coefficients: the library
+    keeps all-water masks and zero coefficients and the step is the same, bit for bit.
+    With the option set the field is required."""
+    import numpy as np
+    from roms_trunk_mgh_amd import main3d
+    absent = ("rmask", "umask", "vmask", "pmask", "visc4_p", "visc4_r", "diff4")
+    out = []
+    for leave in ((), absent):
+        st = ana.make_tile("UPWELLING", perturb=1.0)
+        h = hip.RomsHip(st, leave_unregistered=leave)
+        try:
+            m = main3d.Main3D(h)
+            m.initial()
+            m.run(3)
+            h.to_host()
+        finally:
+            h.close()
+        out.append(st)
+    for name in ("zeta", "u", "v", "t"):
+        assert np.array_equal(out[0][name], out[1][name]), name
+    st = ana.make_tile("UPWELLING", perturb=1.0, mask="island")
+    h = hip.RomsHip(st, leave_unregistered=("umask",))
+    try:
+        with pytest.raises(RuntimeError) as e:
+            h.call("set_depth", util.step_idx())
+        assert "field not registered: umask" in str(e.value)
+    finally:
+        h.close()
