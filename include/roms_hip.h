@@ -150,6 +150,9 @@ typedef struct roms_params {
    * t3dmix4_s.h:23) or geopotentials (mix_geo_ts, t3dmix4_geo.h:23); momentum: along s-surfaces (uv3dmix4_s.h:23)
    * and the 2-D operator of step2d_LF_AM3.h:1494-1740.  TS_DIF2 and TS_DIF4 (UV_VIS2 and UV_VIS4) may both be set. */
   int    ts_dif4, uv_vis4;
+  /* MIX_ISO_TS: tracer mixing along isopycnals (t3dmix2_iso.h:23, t3dmix4_iso.h:23) -- reads pden of rho_eos; takes
+   * precedence over mix_geo_ts / mix_s_ts.  The default slope treatment (none of TS_MIX_MAX_SLOPE, TS_MIX_MIN_STRAT). */
+  int    mix_iso_ts, pad_iso;
 } roms_params_t;
 
 /* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and

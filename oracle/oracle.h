@@ -201,6 +201,7 @@ int oracle_prsgrd(OARGS);
 int oracle_t3dmix2(OARGS);
 int oracle_t3dmix4(OARGS);       /* oracle_mix4.c */
 int oracle_uv3dmix4(OARGS);
+int oracle_t3dmix2_iso(OARGS);
 int oracle_rhs3d_tile(OARGS);
 int oracle_uv3dmix2(OARGS);
 int oracle_rhs3d(OARGS);

@@ -156,6 +156,7 @@ static int t3dmix2_s(OARGS)
 
 int oracle_t3dmix2(OARGS)
 {
+  if (p->mix_iso_ts) return oracle_t3dmix2_iso(b, p, s, F);      /* oracle_mix4.c */
   if (p->mix_geo_ts) return t3dmix2_geo(b, p, s, F);
   if (p->mix_s_ts) return t3dmix2_s(b, p, s, F);
   return 8;

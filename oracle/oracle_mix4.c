@@ -6,7 +6,11 @@
  *   t3dmix4_s_tile    ROMS/Nonlinear/t3dmix4_s.h:100-480   (MIX_S_TS)
  *   t3dmix4_geo_tile  ROMS/Nonlinear/t3dmix4_geo.h:104-784 (MIX_GEO_TS)
  *   uv3dmix4_s_tile   ROMS/Nonlinear/uv3dmix4_s.h:120-629  (MIX_S_UV)
- * All three reference files compile stand-alone; pinned against oracle/_ref/<APP>_DIF4.
+ * and the isopycnal variants of the tracer operators (MIX_ISO_TS; default slope treatment, i.e. none of
+ * TS_MIX_MAX_SLOPE / TS_MIX_MIN_STRAT / TS_MIX_STABILITY / TS_MIX_CLIMA):
+ *   t3dmix2_iso_tile  ROMS/Nonlinear/t3dmix2_iso.h:100-443
+ *   t3dmix4_iso_tile  ROMS/Nonlinear/t3dmix4_iso.h:104-814
+ * All reference files compile stand-alone; pinned against oracle/_ref/<APP>_DIF4 and <APP>_ISO.
  */
 #include "oracle.h"
 #include <stdlib.h>
@@ -228,7 +232,166 @@ static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const r
 #undef dZde
 }
 
-static int t3dmix4_geo(OARGS)
+/* The isopycnal operator on the 3-D array S (private extents) over (i0:i1, j0:j1).  mode 0: t3dmix2_iso.h:193-437
+ * (coefficient diff2, t(nnew) = t(nnew) + ...); mode 1 / 2: the two blocks of t3dmix4_iso.h (:262-500 -> LapT,
+ * :610-805 t(nnew) = t(nnew) - ...; coefficient diff4 folded into the vertical flux term by term).  Horizontal
+ * differences of the potential density take the place of the geopotential operator's dZdx / dZde, the vertical tracer
+ * difference is scaled by -1 / MAX(pden(k) - pden(k+1), eps), and MIN / MAX change places. */
+static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_step_idx_t *s, roms_fields_t *F,
+                     int itrc, const double *S_, double *out_, int i0, int i1, int j0, int j1, int mode)
+{
+  ORACLE_PROLOGUE
+  const int nnew = s->nnew;
+  const double dt = p->dt;
+  const double eps = 0.5;
+  double cff, cff1, cff2, cff3, cff4;
+  const long n2 = nis * njs;
+  double *FE_ = walloc(n2), *FX_ = walloc(n2), *FS_ = walloc(2 * n2);
+  double *dTdr_ = walloc(2 * n2), *dTdx_ = walloc(2 * n2), *dTde_ = walloc(2 * n2);
+  double *dRdx_ = walloc(2 * n2), *dRde_ = walloc(2 * n2);
+#define S(i,j,k) S_[WS3(i,j,k)]
+#define OUT(i,j,k) out_[WS3(i,j,k)]
+#define FE(i,j) FE_[WS2(i,j)]
+#define FX(i,j) FX_[WS2(i,j)]
+#define FS(i,j,k) FS_[WS2(i,j) + ((k)-1) * n2]
+#define dTdr(i,j,k) dTdr_[WS2(i,j) + ((k)-1) * n2]
+#define dTdx(i,j,k) dTdx_[WS2(i,j) + ((k)-1) * n2]
+#define dTde(i,j,k) dTde_[WS2(i,j) + ((k)-1) * n2]
+#define dRdx(i,j,k) dRdx_[WS2(i,j) + ((k)-1) * n2]
+#define dRde(i,j,k) dRde_[WS2(i,j) + ((k)-1) * n2]
+#define DIF(i,j) (mode == 0 ? diff2(i, j, itrc) : diff4(i, j, itrc))
+  int k1, k2 = 1;
+  for (int k = 0; k <= N; k++) {
+    k1 = k2;
+    k2 = 3 - k1;
+    if (k < N) {
+      for (int j = j0; j <= j1; j++)
+        for (int i = i0; i <= i1 + 1; i++) {
+          cff = 0.5 * (pm(i, j) + pm(i - 1, j));
+          if (p->masking) cff = cff * umask(i, j);
+          dRdx(i, j, k2) = cff * (pden(i, j, k + 1) - pden(i - 1, j, k + 1));
+          dTdx(i, j, k2) = cff * (S(i, j, k + 1) - S(i - 1, j, k + 1));
+        }
+      for (int j = j0; j <= j1 + 1; j++)
+        for (int i = i0; i <= i1; i++) {
+          cff = 0.5 * (pn(i, j) + pn(i, j - 1));
+          if (p->masking) cff = cff * vmask(i, j);
+          dRde(i, j, k2) = cff * (pden(i, j, k + 1) - pden(i, j - 1, k + 1));
+          dTde(i, j, k2) = cff * (S(i, j, k + 1) - S(i, j - 1, k + 1));
+        }
+    }
+    if (k == 0 || k == N) {
+      for (int j = j0 - 1; j <= j1 + 1; j++)
+        for (int i = i0 - 1; i <= i1 + 1; i++) { dTdr(i, j, k2) = 0.0; FS(i, j, k2) = 0.0; }
+    } else {
+      for (int j = j0 - 1; j <= j1 + 1; j++)
+        for (int i = i0 - 1; i <= i1 + 1; i++) {
+          cff1 = MAX(pden(i, j, k) - pden(i, j, k + 1), eps);
+          cff = -1.0 / cff1;
+          dTdr(i, j, k2) = cff * (S(i, j, k + 1) - S(i, j, k));
+          FS(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i, j, k));
+        }
+    }
+    if (k > 0) {
+      for (int j = j0; j <= j1; j++)
+        for (int i = i0; i <= i1 + 1; i++) {
+          cff = 0.25 * (DIF(i, j) + DIF(i - 1, j)) * on_u(i, j);
+          FX(i, j) = cff * (Hz(i, j, k) + Hz(i - 1, j, k)) *
+                     (dTdx(i, j, k1) -
+                      0.5 * (MAX(dRdx(i, j, k1), 0.0) * (dTdr(i - 1, j, k1) + dTdr(i, j, k2)) +
+                             MIN(dRdx(i, j, k1), 0.0) * (dTdr(i - 1, j, k2) + dTdr(i, j, k1))));
+        }
+      for (int j = j0; j <= j1 + 1; j++)
+        for (int i = i0; i <= i1; i++) {
+          cff = 0.25 * (DIF(i, j) + DIF(i, j - 1)) * om_v(i, j);
+          FE(i, j) = cff * (Hz(i, j, k) + Hz(i, j - 1, k)) *
+                     (dTde(i, j, k1) -
+                      0.5 * (MAX(dRde(i, j, k1), 0.0) * (dTdr(i, j - 1, k1) + dTdr(i, j, k2)) +
+                             MIN(dRde(i, j, k1), 0.0) * (dTdr(i, j - 1, k2) + dTdr(i, j, k1))));
+        }
+      if (k < N) {
+        for (int j = j0; j <= j1; j++)
+          for (int i = i0; i <= i1; i++) {
+            const double r = dTdr(i, j, k2);
+            cff1 = MAX(dRdx(i, j, k1), 0.0);
+            cff2 = MAX(dRdx(i + 1, j, k2), 0.0);
+            cff3 = MIN(dRdx(i, j, k2), 0.0);
+            cff4 = MIN(dRdx(i + 1, j, k1), 0.0);
+            if (mode == 0) {                     /* t3dmix2_iso.h:395-417: one running sum, the coefficient last */
+              cff = cff1 * (cff1 * r - dTdx(i, j, k1)) + cff2 * (cff2 * r - dTdx(i + 1, j, k2)) +
+                    cff3 * (cff3 * r - dTdx(i, j, k2)) + cff4 * (cff4 * r - dTdx(i + 1, j, k1));
+              cff1 = MAX(dRde(i, j, k1), 0.0);
+              cff2 = MAX(dRde(i, j + 1, k2), 0.0);
+              cff3 = MIN(dRde(i, j, k2), 0.0);
+              cff4 = MIN(dRde(i, j + 1, k1), 0.0);
+              cff = cff + cff1 * (cff1 * r - dTde(i, j, k1)) + cff2 * (cff2 * r - dTde(i, j + 1, k2)) +
+                    cff3 * (cff3 * r - dTde(i, j, k2)) + cff4 * (cff4 * r - dTde(i, j + 1, k1));
+              FS(i, j, k2) = 0.5 * cff * diff2(i, j, itrc) * FS(i, j, k2);
+            } else {                             /* t3dmix4_iso.h:443-480: each direction times its coefficient */
+              const double difx = 0.5 * diff4(i, j, itrc), dife = difx;
+              cff = difx * (cff1 * (cff1 * r - dTdx(i, j, k1)) + cff2 * (cff2 * r - dTdx(i + 1, j, k2)) +
+                            cff3 * (cff3 * r - dTdx(i, j, k2)) + cff4 * (cff4 * r - dTdx(i + 1, j, k1)));
+              cff1 = MAX(dRde(i, j, k1), 0.0);
+              cff2 = MAX(dRde(i, j + 1, k2), 0.0);
+              cff3 = MIN(dRde(i, j, k2), 0.0);
+              cff4 = MIN(dRde(i, j + 1, k1), 0.0);
+              cff = cff + dife * (cff1 * (cff1 * r - dTde(i, j, k1)) + cff2 * (cff2 * r - dTde(i, j + 1, k2)) +
+                                  cff3 * (cff3 * r - dTde(i, j, k2)) + cff4 * (cff4 * r - dTde(i, j + 1, k1)));
+              FS(i, j, k2) = cff * FS(i, j, k2);
+            }
+          }
+      }
+      for (int j = j0; j <= j1; j++)
+        for (int i = i0; i <= i1; i++) {
+          if (mode == 1) {
+            cff = pm(i, j) * pn(i, j);
+            cff1 = 1.0 / Hz(i, j, k);
+            OUT(i, j, k) = cff1 * (cff * (FX(i + 1, j) - FX(i, j) + FE(i, j + 1) - FE(i, j)) + (FS(i, j, k2) - FS(i, j, k1)));
+          } else {
+            cff = dt * pm(i, j) * pn(i, j);
+            cff1 = cff * (FX(i + 1, j) - FX(i, j));
+            cff2 = cff * (FE(i, j + 1) - FE(i, j));
+            cff3 = dt * (FS(i, j, k2) - FS(i, j, k1));
+            cff4 = cff1 + cff2 + cff3;
+            if (mode == 0) t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) + cff4;
+            else t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) - cff4;
+          }
+        }
+    }
+  }
+  free(FE_); free(FX_); free(FS_); free(dTdr_); free(dTdx_); free(dTde_); free(dRdx_); free(dRde_);
+#undef S
+#undef OUT
+#undef FE
+#undef FX
+#undef FS
+#undef dTdr
+#undef dTdx
+#undef dTde
+#undef dRdx
+#undef dRde
+#undef DIF
+}
+
+/* t3dmix2_iso_tile */
+int oracle_t3dmix2_iso(OARGS)
+{
+  ORACLE_PROLOGUE
+  const int nrhs = s->nrhs;
+  double *T_ = walloc(nis * njs * N);
+  for (int itrc = 1; itrc <= NT; itrc++) {
+    for (int k = 1; k <= N; k++)
+      for (int j = MAX(JminS, LBj); j <= MIN(JmaxS, UBj); j++)
+        for (int i = MAX(IminS, LBi); i <= MIN(ImaxS, UBi); i++) T_[WS3(i, j, k)] = t(i, j, k, nrhs, itrc);
+    iso_pass(b, p, s, F, itrc, T_, NULL, Istr, Iend, Jstr, Jend, 0);
+  }
+  free(T_);
+  return 0;
+}
+
+/* t3dmix4_geo_tile (iso = 0) and t3dmix4_iso_tile (iso = 1): the two operators with the edge / corner rule of the
+ * first result in between (t3dmix4_geo.h:457-575 = t3dmix4_iso.h:502-608) */
+static int t3dmix4_rot(OARGS, int iso)
 {
   ORACLE_PROLOGUE
   const int nrhs = s->nrhs;
@@ -241,7 +404,8 @@ static int t3dmix4_geo(OARGS)
     for (int k = 1; k <= N; k++)
       for (int j = MAX(JminS, LBj); j <= MIN(JmaxS, UBj); j++)
         for (int i = MAX(IminS, LBi); i <= MIN(ImaxS, UBi); i++) T_[WS3(i, j, k)] = t(i, j, k, nrhs, itrc);
-    rotated_pass(b, p, s, F, itrc, T_, LapT_, Imin, Imax, Jmin, Jmax, 1);
+    if (iso) iso_pass(b, p, s, F, itrc, T_, LapT_, Imin, Imax, Jmin, Jmax, 1);
+    else rotated_pass(b, p, s, F, itrc, T_, LapT_, Imin, Imax, Jmin, Jmax, 1);
     /* physical edges and corners of the first result, :457-575 */
     if (!EWperiodic) {
       if (west_edge) {
@@ -275,7 +439,8 @@ static int t3dmix4_geo(OARGS)
         if (north_edge && east_edge) LapT(Iend + 1, Jend + 1, k) = 0.5 * (LapT(Iend, Jend + 1, k) + LapT(Iend + 1, Jend, k));
       }
     }
-    rotated_pass(b, p, s, F, itrc, LapT_, NULL, Istr, Iend, Jstr, Jend, 0);
+    if (iso) iso_pass(b, p, s, F, itrc, LapT_, NULL, Istr, Iend, Jstr, Jend, 2);
+    else rotated_pass(b, p, s, F, itrc, LapT_, NULL, Istr, Iend, Jstr, Jend, 0);
   }
   free(T_); free(LapT_);
 #undef LapT
@@ -284,7 +449,8 @@ static int t3dmix4_geo(OARGS)
 
 int oracle_t3dmix4(OARGS)
 {
-  if (p->mix_geo_ts) return t3dmix4_geo(b, p, s, F);
+  if (p->mix_iso_ts) return t3dmix4_rot(b, p, s, F, 1);
+  if (p->mix_geo_ts) return t3dmix4_rot(b, p, s, F, 0);
   if (p->mix_s_ts) return t3dmix4_s(b, p, s, F);
   return 8;
 }

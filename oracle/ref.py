@@ -24,7 +24,9 @@ class Ref:
     def __init__(self, state):
         app = state.cfg["app"] + ("_MASK" if state.p.masking else "")      # <APP>_MASK: built with -DMASKING
         app += {0: "", 1: "_PG31", 2: "_WJ"}[int(state.p.pgf)]             # prsgrd31.h builds (plain / WJ_GRADP)
-        if state.p.ts_dif4 or state.p.uv_vis4:
+        if state.p.mix_iso_ts:
+            app += "_ISO"                                                  # ... and MIX_ISO_TS as the tracer mixing choice
+        elif state.p.ts_dif4 or state.p.uv_vis4:
             app += "_DIF4"                                                 # built with TS_DIF4 and UV_VIS4 added
         self.l = C.CDLL(lib_path(app))
         self.st = state

@@ -198,8 +198,9 @@ def make_params(cfg, NT):
     p.ts_dif2 = int(cfg.get("ts_dif2", 1))
     p.ts_dif4 = int(cfg.get("ts_dif4", 0))
     p.uv_vis4 = int(cfg.get("uv_vis4", 0))
-    p.mix_geo_ts = int(app in ("BENCHMARK", "SEAMOUNT"))
-    p.mix_s_ts = int(app == "UPWELLING")
+    p.mix_iso_ts = int(cfg.get("mix_iso_ts", 0))
+    p.mix_geo_ts = int(app in ("BENCHMARK", "SEAMOUNT") and not p.mix_iso_ts)
+    p.mix_s_ts = int(app == "UPWELLING" and not p.mix_iso_ts)
     p.salinity = int(app in ("BENCHMARK", "UPWELLING"))
     p.lmd_nonlocal = int(app == "BENCHMARK")
     p.solar_source = int(app == "BENCHMARK")

@@ -47,7 +47,10 @@ __device__ __forceinline__ void lap4_store(const roms_bounds_t &b, const Lap4 &L
 
 // MODE 0: t3dmix2_geo (all tracers of the launch).  MODE 1 / 2: first / second operator of t3dmix4_geo for tracer
 // L.itrc -- the arithmetic of the three blocks of the reference is the same.
-template <int MODE>
+// ISO (MIX_ISO_TS): t3dmix2_iso.h:193-437 / t3dmix4_iso.h:262-805 -- the same sweep with the horizontal differences
+// of the potential density in the place of those of z_r, the vertical tracer difference scaled by
+// -1 / MAX(pden(k) - pden(k+1), eps), MIN and MAX exchanged, and the vertical flux times that scale times dz.
+template <int MODE, bool ISO>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
 {
@@ -63,11 +66,19 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   const double dt = c->p.dt;
   const double *__restrict__ T = MODE == 2 ? L.lap : c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
   double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
-  const double *__restrict__ z_r = c->F.z_r;
+  const double *__restrict__ z_r = ISO ? c->F.pden : c->F.z_r;      // the field whose horizontal differences give the slopes
+  const double *__restrict__ zz = c->F.z_r;                          // ISO: depths of the own column
   const double *__restrict__ Hz = c->F.Hz;
   const double *__restrict__ pm = c->F.pm;
   const double *__restrict__ pn = c->F.pn;
   const double *__restrict__ d2 = (MODE == 0 ? c->F.diff2 : c->F.diff4) + (long)(itrc - 1) * nij;
+  // the vertical scale of a column between levels k (a) and k+1 (b): 1/dz, or -1/MAX(drho, eps) (t3dmix2_iso.h:299-301)
+  auto vscale = [](double a, double b) {
+    if constexpr (ISO) return -1.0 / fmax(a - b, 0.5);
+    else return 1.0 / (b - a);
+  };
+  auto f1 = [](double a) { if constexpr (ISO) return dmax0(a); else return dmin0(a); };
+  auto f2 = [](double a) { if constexpr (ISO) return dmin0(a); else return dmax0(a); };
   const long c0 = I2(i, j);
   // face metrics: xi faces i and i+1, eta faces j and j+1
   double mx0 = 0.5 * (pm[c0] + pm[c0 - 1]), mx1 = 0.5 * (pm[c0 + 1] + pm[c0]);
@@ -89,10 +100,11 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   double dzm_a = 0.0, dz0_a = 0.0, dzp_a = 0.0, dzs_a = 0.0, dzn_a = 0.0;
   double dzm_b, dz0_b, dzp_b, dzs_b, dzn_b;
   double FS_a = 0.0, FS_b;
+  double fsf_b = 0.0;                      // ISO: FS(i,j,k2) = scale * dz before the flux is formed (:303)
   // Software pipeline (cf. k_step3d_t_pipe): the 16 loads an iteration consumes -- T and z_r of level
   // k+1 at the five columns, Hz of level k at the five columns, t(nnew) of level k -- are issued one
   // iteration ahead, so their latency overlaps the arithmetic of the previous level.
-  struct LvIn { double Tm1, T01, Tp1, Ts1, Tn1, Zm1, Z01, Zp1, Zs1, Zn1, hz0, hzm, hzp, hzs, hzn, tn; };
+  struct LvIn { double Tm1, T01, Tp1, Ts1, Tn1, Zm1, Z01, Zp1, Zs1, Zn1, hz0, hzm, hzp, hzs, hzn, tn, zz1; };
   const gcd_t gT = (gcd_t)T, gZ = (gcd_t)z_r, gHz = (gcd_t)Hz;
   const gd_t gtn = (gd_t)tn;
   auto load_level = [&](int k) {
@@ -103,11 +115,13 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
     L.Zm1 = gZ[cu - 1]; L.Z01 = gZ[cu]; L.Zp1 = gZ[cu + 1]; L.Zs1 = gZ[cu - ni]; L.Zn1 = gZ[cu + ni];
     L.hz0 = gHz[ck]; L.hzm = gHz[ck - 1]; L.hzp = gHz[ck + 1]; L.hzs = gHz[ck - ni]; L.hzn = gHz[ck + ni];
     L.tn = gtn[ck];
+    if constexpr (ISO) L.zz1 = ((gcd_t)zz)[cu]; else L.zz1 = 0.0;
     return L;
   };
   // values of level k carried for the vertical differences
   double Tm = T[c0 - 1], T0 = T[c0], Tp = T[c0 + 1], Ts = T[c0 - ni], Tn = T[c0 + ni];
   double Zm = z_r[c0 - 1], Z0 = z_r[c0], Zp = z_r[c0 + 1], Zs = z_r[c0 - ni], Zn = z_r[c0 + ni];
+  double zzc = ISO ? zz[c0] : 0.0;
   // level 1 slabs (iteration k=0 of the reference)
   zx0_b = mx0 * (Z0 - Zm); tx0_b = mx0 * (T0 - Tm);
   zx1_b = mx1 * (Zp - Z0); tx1_b = mx1 * (Tp - T0);
@@ -127,11 +141,12 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
       zx1_b = mx1 * (Zp1 - Z01); tx1_b = mx1 * (Tp1 - T01);
       ze0_b = my0 * (Z01 - Zs1); te0_b = my0 * (T01 - Ts1);
       ze1_b = my1 * (Zn1 - Z01); te1_b = my1 * (Tn1 - T01);
-      { const double q = 1.0 / (Zm1 - Zm); dzm_b = q * (Tm1 - Tm); }
-      { const double q = 1.0 / (Z01 - Z0); dz0_b = q * (T01 - T0); }
-      { const double q = 1.0 / (Zp1 - Zp); dzp_b = q * (Tp1 - Tp); }
-      { const double q = 1.0 / (Zs1 - Zs); dzs_b = q * (Ts1 - Ts); }
-      { const double q = 1.0 / (Zn1 - Zn); dzn_b = q * (Tn1 - Tn); }
+      { const double q = vscale(Zm, Zm1); dzm_b = q * (Tm1 - Tm); }
+      { const double q = vscale(Z0, Z01); dz0_b = q * (T01 - T0);
+        if constexpr (ISO) { fsf_b = q * (cur.zz1 - zzc); zzc = cur.zz1; } }
+      { const double q = vscale(Zp, Zp1); dzp_b = q * (Tp1 - Tp); }
+      { const double q = vscale(Zs, Zs1); dzs_b = q * (Ts1 - Ts); }
+      { const double q = vscale(Zn, Zn1); dzn_b = q * (Tn1 - Tn); }
       Tm = Tm1; T0 = T01; Tp = Tp1; Ts = Ts1; Tn = Tn1;
       Zm = Zm1; Z0 = Z01; Zp = Zp1; Zs = Zs1; Zn = Zn1;
     } else {
@@ -140,20 +155,36 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
     const double hz0 = cur.hz0, hzm = cur.hzm, hzp = cur.hzp, hzs = cur.hzs, hzn = cur.hzn;
     // FX(i), FX(i+1), FE(j), FE(j+1): t3dmix2_geo.h:268-310
     const double FX0 = cfx0 * (hz0 + hzm) *
-        (tx0_a - 0.5 * (dmin0(zx0_a) * (dzm_a + dz0_b) + dmax0(zx0_a) * (dzm_b + dz0_a)));
+        (tx0_a - 0.5 * (f1(zx0_a) * (dzm_a + dz0_b) + f2(zx0_a) * (dzm_b + dz0_a)));
     const double FX1 = cfx1 * (hzp + hz0) *
-        (tx1_a - 0.5 * (dmin0(zx1_a) * (dz0_a + dzp_b) + dmax0(zx1_a) * (dz0_b + dzp_a)));
+        (tx1_a - 0.5 * (f1(zx1_a) * (dz0_a + dzp_b) + f2(zx1_a) * (dz0_b + dzp_a)));
     const double FE0 = cfe0 * (hz0 + hzs) *
-        (te0_a - 0.5 * (dmin0(ze0_a) * (dzs_a + dz0_b) + dmax0(ze0_a) * (dzs_b + dz0_a)));
+        (te0_a - 0.5 * (f1(ze0_a) * (dzs_a + dz0_b) + f2(ze0_a) * (dzs_b + dz0_a)));
     const double FE1 = cfe1 * (hzn + hz0) *
-        (te1_a - 0.5 * (dmin0(ze1_a) * (dz0_a + dzn_b) + dmax0(ze1_a) * (dz0_b + dzn_a)));
+        (te1_a - 0.5 * (f1(ze1_a) * (dz0_a + dzn_b) + f2(ze1_a) * (dz0_b + dzn_a)));
     if (k < N) {
-      double c1 = dmin0(zx0_a), c2 = dmin0(zx1_b), c3 = dmax0(zx0_b), c4 = dmax0(zx1_a);
-      FS_b = cfs * (c1 * (c1 * dz0_b - tx0_a) + c2 * (c2 * dz0_b - tx1_b) +
-                    c3 * (c3 * dz0_b - tx0_b) + c4 * (c4 * dz0_b - tx1_a));
-      c1 = dmin0(ze0_a); c2 = dmin0(ze1_b); c3 = dmax0(ze0_b); c4 = dmax0(ze1_a);
-      FS_b = FS_b + cfs * (c1 * (c1 * dz0_b - te0_a) + c2 * (c2 * dz0_b - te1_b) +
+      double c1 = f1(zx0_a), c2 = f1(zx1_b), c3 = f2(zx0_b), c4 = f2(zx1_a);
+      if constexpr (!ISO) {
+        FS_b = cfs * (c1 * (c1 * dz0_b - tx0_a) + c2 * (c2 * dz0_b - tx1_b) +
+                      c3 * (c3 * dz0_b - tx0_b) + c4 * (c4 * dz0_b - tx1_a));
+        c1 = f1(ze0_a); c2 = f1(ze1_b); c3 = f2(ze0_b); c4 = f2(ze1_a);
+        FS_b = FS_b + cfs * (c1 * (c1 * dz0_b - te0_a) + c2 * (c2 * dz0_b - te1_b) +
+                             c3 * (c3 * dz0_b - te0_b) + c4 * (c4 * dz0_b - te1_a));
+      } else if constexpr (MODE == 0) {          // t3dmix2_iso.h:395-417: one running sum, then 0.5 * cff * diff2 * FS
+        double cff = c1 * (c1 * dz0_b - tx0_a) + c2 * (c2 * dz0_b - tx1_b) +
+                     c3 * (c3 * dz0_b - tx0_b) + c4 * (c4 * dz0_b - tx1_a);
+        c1 = f1(ze0_a); c2 = f1(ze1_b); c3 = f2(ze0_b); c4 = f2(ze1_a);
+        cff = cff + c1 * (c1 * dz0_b - te0_a) + c2 * (c2 * dz0_b - te1_b) +
+              c3 * (c3 * dz0_b - te0_b) + c4 * (c4 * dz0_b - te1_a);
+        FS_b = 0.5 * cff * d2[c0] * fsf_b;
+      } else {                                   // t3dmix4_iso.h:443-480: each direction times 0.5 * diff4
+        double cff = cfs * (c1 * (c1 * dz0_b - tx0_a) + c2 * (c2 * dz0_b - tx1_b) +
+                            c3 * (c3 * dz0_b - tx0_b) + c4 * (c4 * dz0_b - tx1_a));
+        c1 = f1(ze0_a); c2 = f1(ze1_b); c3 = f2(ze0_b); c4 = f2(ze1_a);
+        cff = cff + cfs * (c1 * (c1 * dz0_b - te0_a) + c2 * (c2 * dz0_b - te1_b) +
                            c3 * (c3 * dz0_b - te0_b) + c4 * (c4 * dz0_b - te1_a));
+        FS_b = cff * fsf_b;
+      }
     } else FS_b = 0.0;
     if constexpr (MODE == 1) {                 // t3dmix4_geo.h:445-455
       const double cff = pm[c0] * pn[c0];
@@ -266,12 +297,14 @@ static int t3dmix2_launch(const roms_step_idx_t *s)
 {
   const roms_bounds_t &b = g_ctx.b;
   const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, b.NT);
-  if (g_ctx.p.mix_geo_ts)
-    hipLaunchKernelGGL(k_t3dmix_geo<0>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, Lap4{});
+  if (g_ctx.p.mix_iso_ts)
+    hipLaunchKernelGGL((k_t3dmix_geo<0, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, Lap4{});
+  else if (g_ctx.p.mix_geo_ts)
+    hipLaunchKernelGGL((k_t3dmix_geo<0, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, Lap4{});
   else if (g_ctx.p.mix_s_ts)
     hipLaunchKernelGGL(k_t3dmix2_s, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew);
   else
-    return roms_fail("roms_hip_t3dmix2", "no tracer mixing option (MIX_GEO_TS / MIX_S_TS) selected");
+    return roms_fail("roms_hip_t3dmix2", "no tracer mixing option (MIX_ISO_TS / MIX_GEO_TS / MIX_S_TS) selected");
   KERNEL_CHECK("k_t3dmix2");
   return 0;
 }
@@ -291,8 +324,8 @@ extern "C" int roms_hip_t3dmix4(const roms_step_idx_t *s)
   const roms_bounds_t &b = g_ctx.b;
   const roms_params_t &p = g_ctx.p;
   if (!p.ts_dif4) return roms_fail("roms_hip_t3dmix4", "TS_DIF4 is not set (roms_params_t.ts_dif4)");
-  if (!p.mix_geo_ts && !p.mix_s_ts)
-    return roms_fail("roms_hip_t3dmix4", "no tracer mixing option (MIX_GEO_TS / MIX_S_TS) selected");
+  if (!p.mix_iso_ts && !p.mix_geo_ts && !p.mix_s_ts)
+    return roms_fail("roms_hip_t3dmix4", "no tracer mixing option (MIX_ISO_TS / MIX_GEO_TS / MIX_S_TS) selected");
   ScopedTimer tm("t3dmix4");
   Lap4 L;
   L.lap = g_ctx.hostc.ws3[1];
@@ -305,9 +338,12 @@ extern "C" int roms_hip_t3dmix4(const roms_step_idx_t *s)
   const dim3 g2 = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, 1);
   for (int itrc = 1; itrc <= b.NT; itrc++) {
     L.itrc = itrc;
-    if (p.mix_geo_ts) {
-      hipLaunchKernelGGL(k_t3dmix_geo<1>, g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
-      hipLaunchKernelGGL(k_t3dmix_geo<2>, g2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+    if (p.mix_iso_ts) {
+      hipLaunchKernelGGL((k_t3dmix_geo<1, true>), g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      hipLaunchKernelGGL((k_t3dmix_geo<2, true>), g2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+    } else if (p.mix_geo_ts) {
+      hipLaunchKernelGGL((k_t3dmix_geo<1, false>), g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      hipLaunchKernelGGL((k_t3dmix_geo<2, false>), g2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
     } else {
       hipLaunchKernelGGL(k_t3dmix4_s<1>, g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
       hipLaunchKernelGGL(k_t3dmix4_s<2>, g2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);

@@ -72,6 +72,7 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: lbc(6,4)          ! C: lbc[side][variable]
     REAL(c_double) :: obc_out(6,4), obc_in(6,4)   ! nudging coefficients of RadNud edges (1/s)
     INTEGER(c_int) :: ts_dif4, uv_vis4            ! TS_DIF4, UV_VIS4 (biharmonic mixing)
+    INTEGER(c_int) :: mix_iso_ts, pad_iso         ! MIX_ISO_TS
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)

@@ -87,6 +87,54 @@ def main_dif4(config, basin=None, mask=None):
     print(json.dumps(out))
 
 
+def iso_state(config, basin=None, mask=None):
+    """prepared_state with MIX_ISO_TS (and the biharmonic options): potential density from the (pinned) rho_eos, made
+    weakly stratified in one band of columns and strongly in another so that both branches of
+    MAX(pden(k) - pden(k+1), eps) are taken."""
+    import oracle
+    import util
+    from roms_trunk_mgh_amd import abi
+    ov = dict(DIF4, mix_iso_ts=1, tnu2=300.0)
+    if basin:
+        ov["EWperiodic"] = False
+    st0 = util.prepared_state(config, overrides=ov, mask=mask)
+    oracle.Oracle(st0).call("rho_eos", util.step_idx())
+    b = st0.b
+    pd = st0["pden"]
+    mid = pd[:, :, b.N // 2][:, :, None]
+    band = slice(b.Lm // 3 - b.LBi, b.Lm // 2 - b.LBi)
+    pd[band] = mid[band] + 0.02 * (pd[band] - mid[band])
+    strong = slice(b.Lm // 2 - b.LBi, 3 * b.Lm // 4 - b.LBi)           # ... and strongly (differences above eps = 0.5) in another
+    pd[strong] = mid[strong] + 60.0 * (pd[strong] - mid[strong])
+    if basin == "open":
+        for sd in ("west", "east", "south", "north"):
+            st0.p.lbc[abi.LBS[sd]][abi.LBV["t"]] = abi.LBC["Gra"]
+    return st0
+
+
+def main_iso(config, basin=None, mask=None):
+    """t3dmix2_iso and t3dmix4_iso (MIX_ISO_TS): reference Fortran (the application with MIX_ISO_TS, TS_DIF2 and
+    TS_DIF4) vs C oracle."""
+    import oracle
+    import util
+    from oracle import ref
+    st0 = iso_state(config, basin, mask)
+    assert st0.p.mix_iso_ts == 1 and st0.p.mix_geo_ts == 0 and st0.p.mix_s_ts == 0
+    d = st0["pden"][:, :, :-1] - st0["pden"][:, :, 1:]
+    out = {"EWperiodic": int(st0.b.EWperiodic), "masking": int(st0.p.masking), "kernels": {},
+           "frac_below_eps": float((d < 0.5).mean())}
+    s = util.step_idx()
+    for k in ("t3dmix2", "t3dmix4"):
+        st_r, st_o = st0.copy(), st0.copy()
+        ref.Ref(st_r).call(k, s)
+        oracle.Oracle(st_o).call(k, s)
+        diffs = util.compare_states(st_o, st_r)
+        out["kernels"][k] = {"max_rel_diff": max(diffs.values()) if diffs else 0.0, "fields_diff": sorted(diffs),
+                             "changed": sorted(util.compare_states(st_r, st0)),
+                             "change": util.max_rel_diff(st_r["t"], st0["t"])}
+    print(json.dumps(out))
+
+
 def main_bc(config, mask=None):
     """The six lateral boundary-condition routines on the S/N edges, every condition the library offers, for the
     three states of the barotropic stepping (first, predictor, corrector): reference Fortran vs C oracle."""
@@ -477,6 +525,9 @@ if __name__ == "__main__":
                      basin=sys.argv[2] == "physics_basin")
     elif len(sys.argv) > 2 and sys.argv[2] == "basin":
         main(sys.argv[1], basin=True)
+    elif len(sys.argv) > 2 and sys.argv[2] in ("iso", "iso_closed", "iso_open", "iso_mask", "iso_mask_open"):
+        m = sys.argv[2].split("_")
+        main_iso(sys.argv[1], basin=m[-1] if m[-1] in ("closed", "open") else None, mask="island" if "mask" in m else None)
     elif len(sys.argv) > 2 and sys.argv[2] in ("dif4", "dif4_closed", "dif4_open", "dif4_mask", "dif4_mask_open"):
         m = sys.argv[2].split("_")
         main_dif4(sys.argv[1], basin=m[-1] if m[-1] in ("closed", "open") else None, mask="island" if "mask" in m else None)

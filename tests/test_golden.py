@@ -316,6 +316,47 @@ def test_hip_reproduces_reference_biharmonic_mixing(config):
     _dif4_check(config, run)
 
 
+def _iso_check(config, backend):
+    import sys
+    import util
+    gd = os.path.join(HERE, "golden")
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    import make_golden_iso as mi
+    g = np.load(os.path.join(gd, f"ref_iso_{config}.npz"))
+    s = util.step_idx()
+    for variant in mi.CONFIGS[config]:
+        for kernel in mi.KERNELS:
+            st = mi.input_state(config, variant)
+            backend(st, s, kernel)
+            for k, v in mi.results(st, s, kernel).items():
+                want = g[f"{variant}__{kernel}__{k}"]
+                assert (str(v) == str(want)) if k.endswith("_sha256") else np.array_equal(v, want), (variant, kernel, k)
+
+
+@pytest.mark.parametrize("config", ["UPWELLING", "SEAMOUNT"])
+def test_oracle_reproduces_reference_isopycnal_mixing(config):
+    """t3dmix2_iso / t3dmix4_iso of the reference (tests/golden/make_golden_iso.py) vs the oracle, bit for bit."""
+    import oracle
+    _iso_check(config, lambda st, s, kernel: oracle.Oracle(st).call(kernel, s))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["UPWELLING", "SEAMOUNT"])
+def test_hip_reproduces_reference_isopycnal_mixing(config):
+    """k_t3dmix_geo<MODE, ISO> against the committed outputs of the reference's t3dmix2_iso.h / t3dmix4_iso.h."""
+    from roms_trunk_mgh_amd import hip
+
+    def run(st, s, kernel):
+        h = hip.RomsHip(st)
+        try:
+            h.call(kernel, s)
+            h.to_host()
+        finally:
+            h.close()
+    _iso_check(config, run)
+
+
 def _kpp_check(mask, backend, tol):
     import sys
     import util

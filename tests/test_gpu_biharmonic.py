@@ -111,3 +111,58 @@ def test_100_steps_with_biharmonic_mixing(config, variant):
         out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
     assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
     assert all(v <= 1e-10 for v in out.values()), out          # north-star bound
+
+
+# ---- MIX_ISO_TS: tracer mixing along isopycnals, harmonic and biharmonic (t3dmix2_iso.h, t3dmix4_iso.h) ----
+@pytest.mark.parametrize("config", ["UPWELLING", "SEAMOUNT", "BENCHMARK_TINY"])
+@pytest.mark.parametrize("variant", ["periodic", "closed", "open", "mask"])
+@pytest.mark.parametrize("kernel", ["t3dmix2", "t3dmix4", "rhs3d"])
+def test_isopycnal_kernels(config, variant, kernel):
+    import oracle
+    import ref_worker
+    st0 = ref_worker.iso_state(config, basin=variant if variant in ("closed", "open") else None,
+                               mask="island" if variant == "mask" else None)
+    st_o, st_h = st0.copy(), st0.copy()
+    s = util.step_idx(iic=5)
+    oracle.Oracle(st_o).call(kernel, s)
+    h = hip.RomsHip(st_h)
+    try:
+        h.call(kernel, s)
+        h.to_host()
+    finally:
+        h.close()
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= 1e-12 for v in diffs.values()), diffs
+    assert util.max_rel_diff(st_o["t"], st0["t"]) > 1e-6
+
+
+@pytest.mark.parametrize("config,dif4", [("BENCHMARK_TINY", False), ("UPWELLING", True)])
+def test_100_steps_with_isopycnal_mixing(config, dif4):
+    import oracle
+    ov = {"mix_iso_ts": 1}
+    if dif4:
+        ov.update(DIF4[config])
+    else:
+        ov["tnu2"] = 200.0
+    st_o = ana.make_tile(config, perturb=1.0, overrides=ov)
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o))
+    mo.initial()
+    mo.run(100)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be)
+        mh.initial()
+        mh.run(100)
+        be.to_host()
+    finally:
+        be.close()
+    s = mo.s
+    out = {"zeta": rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], 1e-3)}
+    for name in ("u", "v"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], 1e-4)
+    for it in range(st_o.b.NT):
+        out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
+    assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
+    assert all(v <= 1e-10 for v in out.values()), out
+    assert float(np.abs(st_o["pden"]).max()) > 0.0
