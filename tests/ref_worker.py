@@ -87,7 +87,7 @@ def main_dif4(config, basin=None, mask=None):
     print(json.dumps(out))
 
 
-def iso_state(config, basin=None, mask=None):
+def iso_state(config, basin=None, mask=None, extra=None):
     """prepared_state with MIX_ISO_TS (and the biharmonic options): potential density from the (pinned) rho_eos, made
     weakly stratified in one band of columns and strongly in another so that both branches of
     MAX(pden(k) - pden(k+1), eps) are taken."""
@@ -95,6 +95,8 @@ def iso_state(config, basin=None, mask=None):
     import util
     from roms_trunk_mgh_amd import abi
     ov = dict(DIF4, mix_iso_ts=1, tnu2=300.0)
+    if extra:
+        ov.update(extra)
     if basin:
         ov["EWperiodic"] = False
     st0 = util.prepared_state(config, overrides=ov, mask=mask)

@@ -121,7 +121,7 @@ def test_isopycnal_kernels(config, variant, kernel):
     import oracle
     import ref_worker
     st0 = ref_worker.iso_state(config, basin=variant if variant in ("closed", "open") else None,
-                               mask="island" if variant == "mask" else None)
+                               mask="island" if variant == "mask" else None, extra=DIF4[config])
     st_o, st_h = st0.copy(), st0.copy()
     s = util.step_idx(iic=5)
     oracle.Oracle(st_o).call(kernel, s)
