@@ -80,7 +80,8 @@ static int edge_of(const roms_bounds_t *b, int side, int gtype, int closed, Edge
 /* One variable on one edge.  X = plane(s) of the level written, O = the same variable at the level the condition
  * compares with (know / nstp), D = boundary data, Z = zeta(know), Zb = zeta_bry; nk planes of stride nij. */
 static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_fields_t *F, int side, int var, int code,
-                    double *X, const double *O, const double *D, const double *Z, const double *Zb, int nk, double dt2d)
+                    double *X, const double *O, const double *D, const double *Z, const double *Zb, const double *Zn, int nk,
+                    double dt2d)
 {
   const int LBi = b->LBi, LBj = b->LBj;
   const long ni = b->UBi - b->LBi + 1, nij = ni * (b->UBj - b->LBj + 1);
@@ -119,6 +120,28 @@ static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_f
         const double Cn = cff * cff1;
         const double cff2 = 1.0 / (1.0 + Cn);
         x = cff2 * (O[B] + Cn * Xk[P1]);
+      } else if (code == LBC_CHAPMAN_EXPLICIT) {                /* zetabc.F:175-190, :324, :473, :622 */
+        const double cff = dt2d * pmn[P1];
+        const double cff1 = sqrt(p->g * (F->h[P1] + O[P1]));
+        const double Cn = cff * cff1;
+        x = (1.0 - Cn) * O[B] + Cn * O[P1];
+      } else if (code == LBC_SHCHEPETKIN && normal) {           /* u2dbc_im.F:288-362, :636-710; v2dbc_im.F:290-364, :639-713 */
+        /* (Mason et al., 2010; no SSH_TIDES: bry_val = the boundary data.)  qi / qo = the rho-points inside / outside
+         * the boundary velocity point; Zn = zeta at the level being written */
+        const long lo = B - (e.we ? 1 : ni), qi = e.hi ? lo : B, qo = e.hi ? B : lo;
+        const double Co = 1.0 / (2.0 + sqrt(2.0));              /* mod_scalars.F:4175 */
+        const double bry_val = D[B];
+        const double cff = 0.5 * (F->h[lo] + F->h[B]);
+        const double cff1 = sqrt(p->g / cff);
+        const double Cn = dt2d * cff1 * cff * 0.5 * (pmn[lo] + pmn[B]);
+        double Zx = (0.5 + Cn) * Z[qi] + (0.5 - Cn) * Z[qo];
+        if (Cn > Co) {
+          const double cff2 = (1.0 - Co / Cn) * (1.0 - Co / Cn);
+          const double cff3 = Zn[qi] + Cn * Z[qo] - (1.0 + Cn) * Z[qi];
+          Zx = Zx + cff2 * cff3;
+        }
+        x = e.hi ? 0.5 * ((1.0 - Cn) * O[B] + Cn * O[P1] + bry_val + cff1 * (Zx - Zb[qo]))
+                 : 0.5 * ((1.0 - Cn) * O[B] + Cn * O[P1] + bry_val - cff1 * (Zx - Zb[qo]));
       } else if (code == LBC_FLATHER && normal) {               /* u2dbc_im.F:214-300, v2dbc_im.F:216-286 */
         /* the two rho-points around the boundary velocity point, lower index first: u(i,j) lies between
          * rho(i-1,j) and rho(i,j), v(i,j) between rho(i,j-1) and rho(i,j) */
@@ -128,7 +151,7 @@ static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_f
         const double Cn = sqrt(p->g * cff);
         const double zb = Zb[e.hi ? qc : qa];                   /* zeta_west(j) = the rho boundary point */
         x = e.hi ? bry_val + Cn * (0.5 * (Z[qa] + Z[qc]) - zb) : bry_val - Cn * (0.5 * (Z[qa] + Z[qc]) - zb);
-      } else if (code == LBC_FLATHER) {                         /* tangential: u2dbc_im.F:912-932, v2dbc_im.F:886-906 */
+      } else if (code == LBC_FLATHER || code == LBC_SHCHEPETKIN) {   /* tangential: u2dbc_im.F:912-932, v2dbc_im.F:886-906 */
         const double cff = dt2d * 0.5 * (pmn[P1 - e.st] + pmn[P1]);
         const double cff1 = sqrt(p->g * 0.5 * (F->h[P1 - e.st] + Z[P1 - e.st] + F->h[P1] + Z[P1]));
         const double Cn = cff * cff1;
@@ -204,7 +227,7 @@ void o_zetabc(OARGS, int kout)
   o_know(p, s, &know, &dt2d);
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_ZETA, o_lbc(p, SIDES[q], LBV_ZETA), &zeta(LBi, LBj, kout), &zeta(LBi, LBj, know),
-            F->zeta_bry, &zeta(LBi, LBj, know), F->zeta_bry, 1, dt2d);
+            F->zeta_bry, &zeta(LBi, LBj, know), F->zeta_bry, NULL, 1, dt2d);
   bc_corners(b, GT_R, &zeta(LBi, LBj, kout), 1);
 }
 
@@ -215,7 +238,7 @@ void o_u2dbc(OARGS, int kout)
   o_know(p, s, &know, &dt2d);
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_UBAR, o_lbc(p, SIDES[q], LBV_UBAR), &ubar(LBi, LBj, kout), &ubar(LBi, LBj, know),
-            F->ubar_bry, &zeta(LBi, LBj, know), F->zeta_bry, 1, dt2d);
+            F->ubar_bry, &zeta(LBi, LBj, know), F->zeta_bry, &zeta(LBi, LBj, kout), 1, dt2d);
   bc_corners(b, GT_U, &ubar(LBi, LBj, kout), 1);
 }
 
@@ -226,7 +249,7 @@ void o_v2dbc(OARGS, int kout)
   o_know(p, s, &know, &dt2d);
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_VBAR, o_lbc(p, SIDES[q], LBV_VBAR), &vbar(LBi, LBj, kout), &vbar(LBi, LBj, know),
-            F->vbar_bry, &zeta(LBi, LBj, know), F->zeta_bry, 1, dt2d);
+            F->vbar_bry, &zeta(LBi, LBj, know), F->zeta_bry, &zeta(LBi, LBj, kout), 1, dt2d);
   bc_corners(b, GT_V, &vbar(LBi, LBj, kout), 1);
 }
 
@@ -235,7 +258,7 @@ void o_u3dbc(OARGS, int nout)
   ORACLE_PROLOGUE
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_U, o_lbc(p, SIDES[q], LBV_U), &u(LBi, LBj, 1, nout), &u(LBi, LBj, 1, s->nstp),
-            F->u_bry, NULL, NULL, N, 0.0);
+            F->u_bry, NULL, NULL, NULL, N, 0.0);
   bc_corners(b, GT_U, &u(LBi, LBj, 1, nout), N);
 }
 
@@ -244,7 +267,7 @@ void o_v3dbc(OARGS, int nout)
   ORACLE_PROLOGUE
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_V, o_lbc(p, SIDES[q], LBV_V), &v(LBi, LBj, 1, nout), &v(LBi, LBj, 1, s->nstp),
-            F->v_bry, NULL, NULL, N, 0.0);
+            F->v_bry, NULL, NULL, NULL, N, 0.0);
   bc_corners(b, GT_V, &v(LBi, LBj, 1, nout), N);
 }
 
@@ -253,7 +276,7 @@ void o_t3dbc(OARGS, int nout, int itrc)
   ORACLE_PROLOGUE
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_T, o_lbc(p, SIDES[q], LBV_T), &t(LBi, LBj, 1, nout, itrc), &t(LBi, LBj, 1, s->nstp, itrc),
-            F->t_bry + (long)(itrc - 1) * n3r, NULL, NULL, N, 0.0);
+            F->t_bry + (long)(itrc - 1) * n3r, NULL, NULL, NULL, N, 0.0);
   bc_corners(b, GT_R, &t(LBi, LBj, 1, nout, itrc), N);
 }
 

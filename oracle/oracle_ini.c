@@ -15,6 +15,7 @@ static int any_lbc(const roms_params_t *p, int v, int c1, int c2)
     const int c = o_lbc(p, sd, v);
     if (c == c1 || c == c2) return 1;
     if (c1 == LBC_RADIATION && c == LBC_RADIATION_NUDGING) return 1;      /* RadNud sets LBC%radiation too */
+    if (c2 == LBC_CHAPMAN_IMPLICIT && c == LBC_CHAPMAN_EXPLICIT) return 1; /* ini_fields.F:932-934 names both */
   }
   return 0;
 }

@@ -909,6 +909,7 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   PREDICTOR_2D_STEP(ng) = s%predictor /= 0
   dt(ng) = p%dt; dtfast(ng) = p%dtfast
   g = p%g; rho0 = p%rho0; gamma2(ng) = p%gamma2
+  Co = 1.0_c_double/(2.0_c_double+SQRT(2.0_c_double))      ! as initialize_scalars sets it (mod_scalars.F:4175)
   PerfectRST(ng) = .FALSE.
   ! LBC(side, variable): columns 1..4 of p%lbc = west, east, south, north (enum roms_lbc_side + 1); code 0 = the
   ! side's lbc_west / lbc_east / lbc_south / lbc_north, whose value 0 means periodic
@@ -932,11 +933,11 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
         LBC(side(sd), ivar, ng)%Chapman_implicit = code == 4
         LBC(side(sd), ivar, ng)%Flather = code == 5
         LBC(side(sd), ivar, ng)%radiation = code == 6 .OR. code == 7
-        LBC(side(sd), ivar, ng)%Chapman_explicit = .FALSE.
+        LBC(side(sd), ivar, ng)%Chapman_explicit = code == 8
         LBC(side(sd), ivar, ng)%nudging = code == 7                 ! "RadNud"
         LBC(side(sd), ivar, ng)%nested = .FALSE.
         LBC(side(sd), ivar, ng)%reduced = .FALSE.
-        LBC(side(sd), ivar, ng)%Shchepetkin = .FALSE.
+        LBC(side(sd), ivar, ng)%Shchepetkin = code == 9
         LBC(side(sd), ivar, ng)%acquire = .FALSE.
       END DO
     END DO

@@ -33,8 +33,8 @@ int check_lbc()
         continue;
       }
       bool ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED || c == LBC_RADIATION || c == LBC_RADIATION_NUDGING;
-      if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT;
-      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER;
+      if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT || c == LBC_CHAPMAN_EXPLICIT;
+      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER || c == LBC_SHCHEPETKIN;
       if (!ok) return roms_fail("check_lbc", "lateral boundary condition not implemented for this variable");
     }
   }
@@ -68,7 +68,8 @@ struct BcArgs {
   double *X;             // level written (kout / nout)
   const double *Xold;    // 2-D conditions: X(know); 3-D radiation: X(nstp)
   const double *D;       // boundary data of this variable (or nullptr)
-  const double *Z, *Zb;  // Flather (ubar, vbar): zeta(know), zeta_bry
+  const double *Z, *Zb;  // Flather, Shchepetkin (ubar, vbar): zeta(know), zeta_bry
+  const double *Zn;      // Shchepetkin: zeta at the level being written
   int var;               // enum roms_lbc_var; -1 = bc_w3d (gradient, no mask)
   int code[4];           // enum roms_lbc on the western / eastern / southern / northern edge
   int nk, masked;
@@ -152,6 +153,27 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
     const double Cn = cff * cff1;
     const double cff2 = 1.0 / (1.0 + Cn);
     x = cff2 * (a.Xold[B] + Cn * X[P1]);
+  } else if (code == LBC_CHAPMAN_EXPLICIT) {        // zetabc.F:175-190, :324, :473, :622
+    const double cff = a.dt2d * (we ? c->F.pm : c->F.pn)[P1];
+    const double cff1 = sqrt(p.g * (c->F.h[P1] + a.Xold[P1]));
+    const double Cn = cff * cff1;
+    x = (1.0 - Cn) * a.Xold[B] + Cn * a.Xold[P1];
+  } else if (code == LBC_SHCHEPETKIN && normal) {   // u2dbc_im.F:288-362, :636-710; v2dbc_im.F:290-364, :639-713 (no SSH_TIDES)
+    const double *pmn = we ? c->F.pm : c->F.pn;
+    const long lo = B - (we ? 1 : ni), qi = hi ? lo : B, qo = hi ? B : lo;     // rho-points inside / outside
+    const double Co = 1.0 / (2.0 + sqrt(2.0));      // mod_scalars.F:4175
+    const double bry_val = a.D[B];
+    const double cff = 0.5 * (c->F.h[lo] + c->F.h[B]);
+    const double cff1 = sqrt(p.g / cff);
+    const double Cn = a.dt2d * cff1 * cff * 0.5 * (pmn[lo] + pmn[B]);
+    double Zx = (0.5 + Cn) * a.Z[qi] + (0.5 - Cn) * a.Z[qo];
+    if (Cn > Co) {
+      const double cff2 = (1.0 - Co / Cn) * (1.0 - Co / Cn);
+      const double cff3 = a.Zn[qi] + Cn * a.Z[qo] - (1.0 + Cn) * a.Z[qi];
+      Zx = Zx + cff2 * cff3;
+    }
+    x = hi ? 0.5 * ((1.0 - Cn) * a.Xold[B] + Cn * a.Xold[P1] + bry_val + cff1 * (Zx - a.Zb[qo]))
+           : 0.5 * ((1.0 - Cn) * a.Xold[B] + Cn * a.Xold[P1] + bry_val - cff1 * (Zx - a.Zb[qo]));
   } else if (code == LBC_FLATHER && normal) {       // u2dbc_im.F:214-300, v2dbc_im.F:216-286 (bry_val = boundary data)
     const long qa = B - (we ? 1 : ni), qc = B;      // the two rho-points around the velocity point, lower index first
     const double bry_val = a.D[B];
@@ -159,7 +181,7 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
     const double Cn = sqrt(p.g * cff);
     const double zb = a.Zb[hi ? qc : qa];
     x = hi ? bry_val + Cn * (0.5 * (a.Z[qa] + a.Z[qc]) - zb) : bry_val - Cn * (0.5 * (a.Z[qa] + a.Z[qc]) - zb);
-  } else if (code == LBC_FLATHER) {                 // tangential component, Chapman type: u2dbc_im.F:912-932, v2dbc_im.F:886-906
+  } else if (code == LBC_FLATHER || code == LBC_SHCHEPETKIN) {   // tangential component, Chapman type: u2dbc_im.F:912-932, v2dbc_im.F:886-906
     const double *pmn = we ? c->F.pm : c->F.pn;
     const double cff = a.dt2d * 0.5 * (pmn[P1 - st] + pmn[P1]);
     const double cff1 = sqrt(p.g * 0.5 * (c->F.h[P1 - st] + a.Z[P1 - st] + c->F.h[P1] + a.Z[P1]));
@@ -261,7 +283,7 @@ static bool needs_know(const BcArgs &a)
 {
   for (int sd = 0; sd < 4; sd++)
     if (a.code[sd] == LBC_RADIATION || a.code[sd] == LBC_RADIATION_NUDGING || a.code[sd] == LBC_FLATHER ||
-        a.code[sd] == LBC_CHAPMAN_IMPLICIT)
+        a.code[sd] == LBC_CHAPMAN_IMPLICIT || a.code[sd] == LBC_CHAPMAN_EXPLICIT || a.code[sd] == LBC_SHCHEPETKIN)
       return true;
   return false;
 }
@@ -287,6 +309,7 @@ int bc_u2d(int kout, const roms_step_idx_t *s)
   a.D = g_ctx.dev[FID_ubar_bry];
   a.Z = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
   a.Zb = g_ctx.dev[FID_zeta_bry];
+  a.Zn = g_ctx.dev[FID_zeta] + (long)(kout - 1) * nij_host();
   a.dt2d = dt2d;
   return edge_bc(a);
 }
@@ -298,6 +321,7 @@ int bc_v2d(int kout, const roms_step_idx_t *s)
   else if (needs_know(a)) return roms_fail("bc_v2d", "this condition needs the barotropic time indices");
   a.Xold = g_ctx.dev[FID_vbar] + (long)(know - 1) * nij_host();
   a.D = g_ctx.dev[FID_vbar_bry];
+  a.Zn = g_ctx.dev[FID_zeta] + (long)(kout - 1) * nij_host();
   a.Z = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
   a.Zb = g_ctx.dev[FID_zeta_bry];
   a.dt2d = dt2d;

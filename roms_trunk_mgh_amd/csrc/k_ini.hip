@@ -109,6 +109,7 @@ bool any_lbc(int v, int c1, int c2)
     const int c = lbc_code(g_ctx.p, sd, v);
     if (c == c1 || c == c2) return true;
     if (c1 == LBC_RADIATION && c == LBC_RADIATION_NUDGING) return true;     // RadNud sets LBC%radiation too
+    if (c2 == LBC_CHAPMAN_IMPLICIT && c == LBC_CHAPMAN_EXPLICIT) return true;   // ini_fields.F:932-934 names both
   }
   return false;
 }
@@ -149,8 +150,8 @@ extern "C" int roms_hip_ini_zeta(const roms_step_idx_t *s)
   hipLaunchKernelGGL(k_ini_zeta, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, a);
   KERNEL_CHECK("k_ini_zeta");
   if (!open) {
-    if ((rc = bc_zeta(s->kstp, nullptr))) return rc;
-    if ((rc = bc_zeta(s->knew, nullptr))) return rc;
+    if ((rc = bc_zeta(s->kstp, s))) return rc;
+    if ((rc = bc_zeta(s->knew, s))) return rc;
   }
   halo_batch_begin();
   halo_exchange2d(GT_R, g_ctx.dev[FID_zeta] + (long)(s->kstp - 1) * nij);
@@ -197,8 +198,10 @@ extern "C" int roms_hip_ini_fields(const roms_step_idx_t *s)
   hipLaunchKernelGGL(k_ini_bar, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, a);
   KERNEL_CHECK("k_ini_bar");
   if (!any_lbc(LBV_UBAR, LBC_RADIATION, LBC_FLATHER) && !any_lbc(LBV_VBAR, LBC_RADIATION, LBC_FLATHER)) {   // :434-460
-    if ((rc = bc_u2d(s->kstp, nullptr)) || (rc = bc_v2d(s->kstp, nullptr))) return rc;
-    if ((rc = bc_u2d(s->knew, nullptr)) || (rc = bc_v2d(s->knew, nullptr))) return rc;
+    // (with the step's barotropic indices, as the reference's u2dbc_tile reads them from mod_stepping: a Shchepetkin
+    // edge is not in the exclusion list above)
+    if ((rc = bc_u2d(s->kstp, s)) || (rc = bc_v2d(s->kstp, s))) return rc;
+    if ((rc = bc_u2d(s->knew, s)) || (rc = bc_v2d(s->knew, s))) return rc;
   }
   halo_batch_begin();
   halo_exchange2d(GT_U, g_ctx.dev[FID_ubar] + (long)(s->kstp - 1) * nij);

@@ -18,8 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
 
 CONFIGS = [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)]
-TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]),
-         "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
+TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Che", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]),
+         "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
          "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad", "RadNud"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad", "RadNud"])}
 
 

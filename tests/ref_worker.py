@@ -157,8 +157,8 @@ def main_bc(config, mask=None):
             row = a[:, j - b.LBj]
             row += 1.0e-3 * (1.0 + np.abs(row)) * rng.standard_normal(row.shape)
     out = {"masking": int(st0.p.masking), "cases": {}}
-    table = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]),
-             "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
+    table = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Che", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]),
+             "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
              "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad", "RadNud"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad", "RadNud"])}
     steps = [util.step_idx(iic=5, iif=1, pred=1, kstp=1, krhs=1, knew=3), util.step_idx(iic=5, iif=3, pred=1, kstp=2, krhs=1, knew=3),
              util.step_idx(iic=5, iif=3, pred=0, kstp=1, krhs=3, knew=2)]
@@ -205,8 +205,8 @@ def basin_state(config, mask=None):
     return st0
 
 
-BC_TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]),
-            "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
+BC_TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Che", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]),
+            "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
             "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad", "RadNud"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad", "RadNud"])}
 
 

@@ -21,6 +21,8 @@ OPEN = {"zeta": "Cha", "ubar": "Fla", "vbar": "Fla", "u": "Rad", "v": "Rad", "t"
 # the usual realistic set: radiation with nudging towards the boundary data for the 3-D variables (and here for the
 # 2-D ones as well, so that every routine's nudging branch runs)
 RADNUD = {v: "RadNud" for v in OPEN}
+CHE_SHC = {"zeta": "Che", "ubar": "Shc", "vbar": "Shc", "u": "Rad", "v": "Rad", "t": "Rad"}
+TABLES = {True: OPEN, "radnud": RADNUD, "che_shc": CHE_SHC}
 
 
 def _open_all(st, table=OPEN):
@@ -38,7 +40,7 @@ def _state(config, kernel, open_edges):
         ov.update({"tnu2": 300.0} if config == "SEAMOUNT" else {"tnu2": 300.0, "visc2": 800.0})
     st0 = util.prepared_state(config, overrides=ov)
     if open_edges:
-        _open_all(st0, RADNUD if open_edges == "radnud" else OPEN)
+        _open_all(st0, TABLES[open_edges])
         rng = np.random.default_rng(5)
         for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
             st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
@@ -55,7 +57,7 @@ def _state(config, kernel, open_edges):
 
 
 @pytest.mark.parametrize("config", CONFIGS)
-@pytest.mark.parametrize("open_edges", [False, True, "radnud"], ids=["closed", "open", "radnud"])
+@pytest.mark.parametrize("open_edges", [False, True, "radnud", "che_shc"], ids=["closed", "open", "radnud", "che_shc"])
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_hip_kernels_on_a_basin(config, kernel, open_edges):
     import oracle
@@ -103,14 +105,14 @@ def test_hip_step2d_loop_on_a_basin(config):
 
 @pytest.mark.parametrize("config,physics,open_edges", [("UPWELLING", False, False), ("BENCHMARK_TINY", True, False),
                                                         ("SEAMOUNT", False, False), ("UPWELLING", False, True),
-                                                        ("UPWELLING", False, "radnud")])
+                                                        ("UPWELLING", False, "radnud"), ("UPWELLING", False, "che_shc")])
 def test_hip_100_steps_on_a_basin(config, physics, open_edges):
     import oracle
     from roms_trunk_mgh_amd import hip
     from roms_trunk_mgh_amd.state import rel_rms
     st_o = ana.make_tile(config, perturb=1.0 if config != "SEAMOUNT" else 0.0, overrides=BASIN)
     if open_edges:
-        _open_all(st_o, RADNUD if open_edges == "radnud" else OPEN)
+        _open_all(st_o, TABLES[open_edges])
         if open_edges == "radnud":          # boundary data to nudge towards: the initial state
             for name, src in (("zeta_bry", st_o["zeta"][:, :, 0]), ("t_bry", st_o["t"][:, :, :, 0, :])):
                 st_o[name][:] = src

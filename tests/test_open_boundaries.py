@@ -19,6 +19,8 @@ H0 = 150.0
 # the usual open-ocean set of roms_*.in: LBC(isFsur) = Cha, LBC(isUbar) = LBC(isVbar) = Fla, 3-D variables Rad
 OPEN = {"zeta": "Cha", "ubar": "Fla", "vbar": "Fla", "u": "Rad", "v": "Rad", "t": "Rad"}
 RADI = {v: "Rad" for v in OPEN}               # implicit upstream radiation for every variable
+# explicit Chapman for the free surface with the Shchepetkin (Mason et al., 2010) condition for the barotropic velocity
+CHE_SHC = {"zeta": "Che", "ubar": "Shc", "vbar": "Shc", "u": "Rad", "v": "Rad", "t": "Rad"}
 GRAD = {v: "Gra" for v in OPEN}
 CLAMP = {v: "Cla" for v in OPEN}
 
@@ -71,13 +73,14 @@ BACKENDS = ["oracle", pytest.param("hip", marks=pytest.mark.gpu)]
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
-@pytest.mark.parametrize("which", ["cha_fla_rad", "radiation"])
+@pytest.mark.parametrize("which", ["cha_fla_rad", "radiation", "che_shc_rad"])
 def test_wave_leaves_through_open_edges(kind, which):
     """c = sqrt(g H) = 38 m/s: the two waves need 40 km / c = 1040 s to reach the edges; after 2400 s an open
     channel is (almost) at rest, a closed one still holds the energy."""
     nsteps = 24
     left = {}
-    for name, table in (("open", OPEN if which == "cha_fla_rad" else RADI), ("closed", None)):
+    tables = {"cha_fla_rad": OPEN, "radiation": RADI, "che_shc_rad": CHE_SHC}
+    for name, table in (("open", tables[which]), ("closed", None)):
         st = _bump_channel(table)
         e0 = float((st.interior("Zt_avg1") ** 2).sum())
         _run(kind, st, nsteps)
@@ -86,7 +89,8 @@ def test_wave_leaves_through_open_edges(kind, which):
     assert left["closed"] > 0.3, left
     # Chapman + Flather absorb the wave almost completely; radiation alone (no RADIATION_2D, and the free surface
     # of the southern edge differenced towards the boundary row, zetabc.F:424) lets about a quarter back
-    assert left["open"] < (0.02 if which == "cha_fla_rad" else 0.35) * left["closed"], left
+    # Chapman explicit + Shchepetkin absorb it as well
+    assert left["open"] < {"cha_fla_rad": 0.02, "radiation": 0.35, "che_shc_rad": 0.05}[which] * left["closed"], left
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
@@ -120,7 +124,7 @@ def test_clamped_edges_hold_the_boundary_data(kind):
 # -------------------------------------------------------------------------------------------- GPU parity
 @pytest.mark.gpu
 @pytest.mark.parametrize("config", ["BENCHMARK_TINY", "UPWELLING", "SEAMOUNT"])
-@pytest.mark.parametrize("table", [OPEN, RADI, GRAD, CLAMP], ids=["cha_fla_rad", "radiation", "gradient", "clamped"])
+@pytest.mark.parametrize("table", [OPEN, RADI, GRAD, CLAMP, CHE_SHC], ids=["cha_fla_rad", "radiation", "gradient", "clamped", "che_shc_rad"])
 @pytest.mark.parametrize("kernel", ["step2d", "step3d_uv", "step3d_t", "pre_step3d"])
 def test_hip_kernels_with_open_edges(config, table, kernel):
     import oracle
