@@ -131,7 +131,7 @@ typedef struct roms_params {
   /* Jerlov water type constants of lmd_swfrac.F:6 (mod_scalars.F:1502-1512), uniform WTYPE */
   double swfrac_mu1, swfrac_mu2, swfrac_r1;
   /* per-step physics between the hot kernels */
-  int    uv_drag;                    /* bottom stress law of set_vbc.F: 1 = UV_LDRAG, 2 = UV_QDRAG */
+  int    uv_drag;                    /* bottom stress law of set_vbc.F: 1 = UV_LDRAG, 2 = UV_QDRAG, 3 = UV_LOGDRAG */
   int    mpdata_fast;                /* library switch (no reference counterpart): 1 = the anti-diffusive
                                       * velocities of mpdata_adiff use refined reciprocals instead of IEEE
                                       * divisions (results within the 1e-10 relative-RMS bound of the exact
@@ -155,6 +155,9 @@ typedef struct roms_params {
   /* MIX_ISO_TS: tracer mixing along isopycnals (t3dmix2_iso.h:23, t3dmix4_iso.h:23) -- reads pden of rho_eos; takes
    * precedence over mix_geo_ts / mix_s_ts.  The default slope treatment (none of TS_MIX_MAX_SLOPE, TS_MIX_MIN_STRAT). */
   int    mix_iso_ts, pad_iso;
+  /* UV_LOGDRAG (uv_drag = 3): limits of the drag coefficient of the logarithmic bottom layer, roms_*.in Cdb_min /
+   * Cdb_max (mod_scalars.F:747-748); the roughness length is the field ZoBot */
+  double Cdb_min, Cdb_max;
 } roms_params_t;
 
 /* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and

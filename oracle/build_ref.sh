@@ -15,7 +15,8 @@
 #                                 SEAMOUNT_PG31, SEAMOUNT_WJ (= the application with prsgrd31.h, plain
 #                                 and with WJ_GRADP, instead of prsgrd32.h); UPWELLING_DIF4, SEAMOUNT_DIF4
 #                                 (= the application plus TS_DIF4 and UV_VIS4), UPWELLING_MASK_DIF4; UPWELLING_ISO, SEAMOUNT_ISO,
-#                                 UPWELLING_MASK_ISO (= the _DIF4 options with MIX_ISO_TS as the tracer mixing choice)
+#                                 UPWELLING_MASK_ISO (= the _DIF4 options with MIX_ISO_TS as the tracer mixing choice); UPWELLING_LOGDRAG
+#                                 (UV_LOGDRAG instead of UV_LDRAG)
 #
 # This is the reference's own recipe (makefile:207, Compilers/Linux-gfortran.mk:
 # 43-44: cpp -P -traditional then the Fortran compiler), serial build (no
@@ -53,7 +54,7 @@ build_app () {
   # wrapper then also binds t3dmix4 / uv3dmix4 (-DREF_DIF4 reaches the wrapper only)
   local TAG=$1 APP=${1%%_*} XDEF="" WDEF="" VAR=nodiag
   case $TAG in *_MASK*) XDEF="-DMASKING";; esac
-  case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; esac
+  case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; *_LOGDRAG) VAR=logdrag; WDEF="-DREF_LOGDRAG";; esac
   local hdr=$(echo $APP | tr A-Z a-z).h
   # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
   [ "$APP" = UPWELLING ] && hdr=upwelling_$VAR.h
@@ -86,7 +87,7 @@ build_app () {
   echo "[$TAG] built $D/libref.so"
 }
 
-for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO}; do
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG}; do
   build_app $app &
 done
 wait

@@ -51,6 +51,30 @@ int oracle_set_vbc(OARGS)
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++)
         F->bvstr[I2(i, j)] = 0.5 * (rdrag(i, j - 1) + rdrag(i, j)) * v(i, j, 1, nrhs);
+  } else if (p->uv_drag == 3) {     /* UV_LOGDRAG, :542-580: Cd = (vonKar / LOG(dz/ZoBot))^2 within [Cdb_min, Cdb_max] */
+    const double vonKar = 0.41;      /* mod_scalars.F:444 */
+    double *wrk_ = walloc(nis * njs);
+#define wrk(i,j) wrk_[WS2(i,j)]
+    for (int j = JstrV - 1; j <= Jend; j++)
+      for (int i = IstrU - 1; i <= Iend; i++) {
+        const double cff1 = 1.0 / log((z_r(i, j, 1) - z_w(i, j, 0)) / F->ZoBot[I2(i, j)]);
+        const double cff2 = vonKar * vonKar * cff1 * cff1;
+        wrk(i, j) = MIN(p->Cdb_max, MAX(p->Cdb_min, cff2));
+      }
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = IstrU; i <= Iend; i++) {
+        const double cff1 = 0.25 * (v(i, j, 1, nrhs) + v(i, j + 1, 1, nrhs) + v(i - 1, j, 1, nrhs) + v(i - 1, j + 1, 1, nrhs));
+        const double cff2 = sqrt(u(i, j, 1, nrhs) * u(i, j, 1, nrhs) + cff1 * cff1);
+        F->bustr[I2(i, j)] = 0.5 * (wrk(i - 1, j) + wrk(i, j)) * u(i, j, 1, nrhs) * cff2;
+      }
+    for (int j = JstrV; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        const double cff1 = 0.25 * (u(i, j, 1, nrhs) + u(i + 1, j, 1, nrhs) + u(i, j - 1, 1, nrhs) + u(i + 1, j - 1, 1, nrhs));
+        const double cff2 = sqrt(cff1 * cff1 + v(i, j, 1, nrhs) * v(i, j, 1, nrhs));
+        F->bvstr[I2(i, j)] = 0.5 * (wrk(i, j - 1) + wrk(i, j)) * v(i, j, 1, nrhs) * cff2;
+      }
+    free(wrk_);
+#undef wrk
   } else return 8;
   /* boundary conditions + periodic / tile exchange, :472-500 */
   /* bc_u2d_tile / bc_v2d_tile with isBu2d = isUbar, isBv2d = isVbar (bc_2d.F:184, :386; mod_ncparam.F:1229) */

@@ -24,6 +24,8 @@ class Ref:
     def __init__(self, state):
         app = state.cfg["app"] + ("_MASK" if state.p.masking else "")      # <APP>_MASK: built with -DMASKING
         app += {0: "", 1: "_PG31", 2: "_WJ"}[int(state.p.pgf)]             # prsgrd31.h builds (plain / WJ_GRADP)
+        if state.p.uv_drag == 3:
+            app += "_LOGDRAG"                                              # UV_LOGDRAG instead of the application's law
         if state.p.mix_iso_ts:
             app += "_ISO"                                                  # ... and MIX_ISO_TS as the tracer mixing choice
         elif state.p.ts_dif4 or state.p.uv_vis4:

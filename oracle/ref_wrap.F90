@@ -52,6 +52,7 @@ MODULE ref_wrap_types
     REAL(c_double) :: obc_out(6,4), obc_in(6,4)   ! nudging coefficients of RadNud edges (1/s)
     INTEGER(c_int) :: ts_dif4, uv_vis4
     INTEGER(c_int) :: mix_iso_ts, pad_iso
+    REAL(c_double) :: Cdb_min, Cdb_max
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -71,6 +72,7 @@ MODULE ref_wrap_types
     TYPE(c_ptr) :: rmask, umask, vmask, pmask
     TYPE(c_ptr) :: zeta_bry, ubar_bry, vbar_bry, u_bry, v_bry, t_bry
     TYPE(c_ptr) :: visc4_p, visc4_r, diff4
+    TYPE(c_ptr) :: ZoBot
   END TYPE fields_t
   LOGICAL, SAVE :: have_boundary = .FALSE.      ! allocate_boundary is done once per process
 END MODULE ref_wrap_types
@@ -475,8 +477,12 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
 #if defined BENCHMARK || defined SEAMOUNT
   CALL c_f_pointer (F%rdrag2, a2, (/ni,nj/));   GRID(ng)%rdrag2 = a2
 #endif
-#ifdef UPWELLING
+#if defined UPWELLING && !defined REF_LOGDRAG
   CALL c_f_pointer (F%rdrag, a2, (/ni,nj/));    GRID(ng)%rdrag = a2
+#endif
+#ifdef REF_LOGDRAG
+  CALL c_f_pointer (F%ZoBot, a2, (/ni,nj/));    GRID(ng)%ZoBot = a2
+  Cdb_min = p%Cdb_min; Cdb_max = p%Cdb_max
 #endif
   CALL c_f_pointer (F%bustr, a2, (/ni,nj/));    FORCES(ng)%bustr = a2
   CALL c_f_pointer (F%bvstr, a2, (/ni,nj/));    FORCES(ng)%bvstr = a2

@@ -211,7 +211,8 @@ def make_params(cfg, NT):
     # WTYPE == 1 (roms_benchmark*.in:392): mod_scalars.F:1502-1512
     p.swfrac_mu1, p.swfrac_mu2, p.swfrac_r1 = 0.35, 23.0, 0.58
     # set_vbc.F: BENCHMARK and SEAMOUNT have UV_QDRAG (rdrg2 = 3.0d-03), UPWELLING UV_LDRAG (rdrg = 3.0d-04)
-    p.uv_drag = 1 if cfg["app"] == "UPWELLING" else 2
+    p.uv_drag = int(cfg.get("uv_drag", 1 if cfg["app"] == "UPWELLING" else 2))      # 3 = UV_LOGDRAG
+    p.Cdb_min, p.Cdb_max = 1.0e-6, 0.5                                  # mod_scalars.F:747-748
     p.blk_ZQ = p.blk_ZT = p.blk_ZW = 10.0       # roms_*.in:382-384
     return p
 
@@ -452,6 +453,7 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
     # ---- inputs of the per-step physics (set_vbc, bulk_flux): roms_*.in and ana_*.h of the app ----
     A["rdrag2"][:] = 3.0e-3                       # RDRG2 (roms_benchmark*.in)
     A["rdrag"][:] = 3.0e-4                        # RDRG
+    A["ZoBot"][:] = 0.02                          # Zob (m)
     A["stflux"][:] = A["stflx"]                   # raw surface tracer fluxes (ana_stflux.h: 0; heat: fixed profile)
     A["btflux"][:] = A["btflx"]
     if app == "BENCHMARK":

@@ -393,6 +393,7 @@ static int library_default(int id, double *value)
     *value = 1.0; return !p.masking;
   case FID_visc4_p: case FID_visc4_r: *value = 0.0; return !p.uv_vis4;
   case FID_diff4: *value = 0.0; return !p.ts_dif4;
+  case FID_ZoBot: *value = 1.0; return p.uv_drag != 3;
   default: return 0;
   }
 }

@@ -52,6 +52,27 @@ k_set_vbc(const RomsDev *__restrict__ c, int nrhs)
       const double cff2 = sqrt(cff1 * cff1 + v[a] * v[a]);
       GF(bvstr)[a] = 0.5 * (r2[a - ni] + r2[a]) * v[a] * cff2;
     }
+  } else if (p.uv_drag == 3) {      // UV_LOGDRAG, set_vbc.F:542-580
+    const gcd_t zr = (gcd_t)c->F.z_r, zw = (gcd_t)c->F.z_w, zo = (gcd_t)c->F.ZoBot;
+    auto cd = [&](long q) {          // wrk(i,j): (vonKar / LOG(dz/ZoBot))^2 within [Cdb_min, Cdb_max]
+      const double vonKar = 0.41;
+      const double cff1 = 1.0 / log((zr[q] - zw[q]) / zo[q]);
+      const double cff2 = vonKar * vonKar * cff1 * cff1;
+      return fmin(p.Cdb_max, fmax(p.Cdb_min, cff2));
+    };
+    if (on_u) {
+      const double cff1 = 0.25 * (v[a] + v[a + ni] + v[a - 1] + v[a - 1 + ni]);
+      const double cff2 = sqrt(u[a] * u[a] + cff1 * cff1);
+      const double bu = 0.5 * (cd(a - 1) + cd(a)) * u[a] * cff2;
+      GF(bustr)[a] = bu;
+      if (b.south_edge && !b.NSperiodic && j == b.Jstr) GF(bustr)[a - ni] = p.gamma2 * bu;   // bc_u2d_tile
+      if (b.north_edge && !b.NSperiodic && j == b.Jend) GF(bustr)[a + ni] = p.gamma2 * bu;
+    }
+    if (on_v) {
+      const double cff1 = 0.25 * (u[a] + u[a + 1] + u[a - ni] + u[a + 1 - ni]);
+      const double cff2 = sqrt(cff1 * cff1 + v[a] * v[a]);
+      GF(bvstr)[a] = 0.5 * (cd(a - ni) + cd(a)) * v[a] * cff2;
+    }
   } else {
     const gcd_t r1 = (gcd_t)(c->F.rdrag);
     if (on_u) {
@@ -309,7 +330,7 @@ extern "C" int roms_hip_set_vbc(const roms_step_idx_t *s)
   if (rc) return rc;
   if ((rc = check_lbc())) return rc;
   const roms_bounds_t &b = g_ctx.b;
-  if (g_ctx.p.uv_drag != 1 && g_ctx.p.uv_drag != 2)
+  if (g_ctx.p.uv_drag < 1 || g_ctx.p.uv_drag > 3)
     return roms_fail("roms_hip_set_vbc", "bottom drag law not implemented (UV_LDRAG / UV_QDRAG only)");
   {
     ScopedTimer tm("set_vbc");

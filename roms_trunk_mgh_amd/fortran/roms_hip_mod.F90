@@ -73,6 +73,7 @@ MODULE roms_hip_mod
     REAL(c_double) :: obc_out(6,4), obc_in(6,4)   ! nudging coefficients of RadNud edges (1/s)
     INTEGER(c_int) :: ts_dif4, uv_vis4            ! TS_DIF4, UV_VIS4 (biharmonic mixing)
     INTEGER(c_int) :: mix_iso_ts, pad_iso         ! MIX_ISO_TS
+    REAL(c_double) :: Cdb_min, Cdb_max            ! UV_LOGDRAG limits
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)
@@ -100,7 +101,7 @@ MODULE roms_hip_mod
  &    FID_shflx=80, FID_evap=81, FID_hsbl=82, FID_rdrag=83, FID_wvel=84, FID_lonr=85, FID_latr=86,   &
  &    FID_rmask=87, FID_umask=88, FID_vmask=89, FID_pmask=90, FID_zeta_bry=91, FID_ubar_bry=92,   &
  &    FID_vbar_bry=93, FID_u_bry=94, FID_v_bry=95, FID_t_bry=96,                                  &
- &    FID_visc4_p=97, FID_visc4_r=98, FID_diff4=99
+ &    FID_visc4_p=97, FID_visc4_r=98, FID_diff4=99, FID_ZoBot=100
 
   INTERFACE
     INTEGER(c_int) FUNCTION roms_hip_init (rank, ntileI, ntileJ, device_id, uid)            &

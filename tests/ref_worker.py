@@ -349,6 +349,42 @@ def main_mpdata(config, mask=None, basin=None):
     print(json.dumps(out))
 
 
+def logdrag_state(config="UPWELLING"):
+    """prepared_state with UV_LOGDRAG: a roughness length varying over two decades, so large in one corner that the drag
+    coefficient runs into Cdb_max, so small in another that it runs into a raised Cdb_min."""
+    import util
+    st = util.prepared_state(config, overrides={"uv_drag": 3})
+    b = st.b
+    ii = np.arange(b.LBi, b.UBi + 1, dtype=np.float64)[:, None] / b.Lm
+    jj = np.arange(b.LBj, b.UBj + 1, dtype=np.float64)[None, :] / b.Mm
+    st["ZoBot"][:] = 1.0e-4 * 10.0 ** (2.0 * ii + 1.5 * jj)
+    st["ZoBot"][-6:, -6:] = 0.6 * (st["z_r"][-6:, -6:, 0] - st["z_w"][-6:, -6:, 0])
+    st.p.Cdb_min = 1.5e-3
+    return st
+
+
+def main_logdrag(config):
+    """set_vbc with UV_LOGDRAG (set_vbc.F:542-580): reference Fortran (UPWELLING with UV_LOGDRAG in the place of
+    UV_LDRAG) vs C oracle; LOG comes from two math libraries, the relative difference is reported."""
+    import oracle
+    import util
+    from oracle import ref
+    st0 = logdrag_state(config)
+    s = util.step_idx()
+    st_r, st_o = st0.copy(), st0.copy()
+    ref.Ref(st_r).physics("set_vbc", s)
+    oracle.Oracle(st_o).call("set_vbc", s)
+    names = ["bustr", "bvstr"]
+    dz = st0["z_r"][:, :, 0] - st0["z_w"][:, :, 0]
+    cd = (0.41 / np.log(dz / st0["ZoBot"])) ** 2
+    out = {"set_vbc": {"diffs": {n: util.max_rel_diff(st_o[n], st_r[n]) for n in names},
+                       "changed": [n for n in names if not np.array_equal(st_r[n], st0[n])],
+                       "amax": {n: float(np.abs(st_r[n]).max()) for n in names}},
+           "frac_at_max": float((cd > st0.p.Cdb_max).mean()), "frac_at_min": float((cd < st0.p.Cdb_min).mean())}
+    out["set_vbc"]["max_rel_diff"] = max(out["set_vbc"]["diffs"].values())
+    print(json.dumps(out))
+
+
 def main_physics(config, mask=None, basin=False):
     """set_vbc (all applications) and bulk_flux (BENCHMARK: the BULK_FLUXES application): reference
     Fortran vs C oracle.  set_vbc has only +,*,sqrt: bit for bit; bulk_flux calls log/exp/pow/atan
@@ -527,6 +563,8 @@ if __name__ == "__main__":
                      basin=sys.argv[2] == "physics_basin")
     elif len(sys.argv) > 2 and sys.argv[2] == "basin":
         main(sys.argv[1], basin=True)
+    elif len(sys.argv) > 2 and sys.argv[2] == "logdrag":
+        main_logdrag(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] in ("iso", "iso_closed", "iso_open", "iso_mask", "iso_mask_open"):
         m = sys.argv[2].split("_")
         main_iso(sys.argv[1], basin=m[-1] if m[-1] in ("closed", "open") else None, mask="island" if "mask" in m else None)

@@ -384,3 +384,24 @@ def test_semi_implicit_vertical_mixing(config, kernel, mpdata):
     st_1.p.lambda_ = 1.0
     oracle.Oracle(st_1).call(kernel, util.step_idx(iic=5))
     assert util.compare_states(st_o, st_1)
+
+
+@pytest.mark.gpu
+def test_set_vbc_log_layer_drag():
+    """UV_LOGDRAG (roms_params_t.uv_drag = 3): HIP vs oracle; the device log() is not the host's: 1e-14."""
+    import oracle
+    import ref_worker
+    from roms_trunk_mgh_amd import hip
+    st0 = ref_worker.logdrag_state("UPWELLING")
+    st_o, st_h = st0.copy(), st0.copy()
+    s = util.step_idx()
+    oracle.Oracle(st_o).call("set_vbc", s)
+    h = hip.RomsHip(st_h)
+    try:
+        h.call("set_vbc", s)
+        h.to_host()
+    finally:
+        h.close()
+    for n in ("bustr", "bvstr", "stflx", "btflx"):
+        assert util.max_rel_diff(st_h[n], st_o[n]) <= 1e-14, n
+    assert util.max_rel_diff(st_o["bustr"], st0["bustr"]) > 1e-3
