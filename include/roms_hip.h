@@ -86,7 +86,7 @@ enum roms_adv {
 /* Pressure-gradient algorithm (the CPP choice of ROMS/Nonlinear/prsgrd.F:16-26): DJ_GRADPS = prsgrd32.h (the three
  * application headers of BASELINE.json define it), none of the options = prsgrd31.h (standard density Jacobian, the
  * reference's default), WJ_GRADP = prsgrd31.h with the weighted Jacobian of Song (1998). */
-enum roms_pgf { PGF_DJ_GRADPS = 0, PGF_STANDARD = 1, PGF_WJ_GRADP = 2 };
+enum roms_pgf { PGF_DJ_GRADPS = 0, PGF_STANDARD = 1, PGF_WJ_GRADP = 2, PGF_PJ_GRADP = 3 /* prsgrd40.h: finite-volume pressure Jacobian */ };
 /* Lateral boundary condition codes supported on this path (the logical records of T_LBC, mod_param.F:348-363).
  * A periodic direction (E-W) has LBC_PERIODIC on both of its sides; a physical edge (any of the four) takes, per
  * variable (roms_params_t.lbc): closed, gradient, clamped, radiation (implicit upstream, zetabc.F:108 /

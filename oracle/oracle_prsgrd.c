@@ -60,8 +60,57 @@ static int oracle_prsgrd31(OARGS)
   return 0;
 }
 
+/* prsgrd40_tile -- prsgrd40.h:170-268 (PJ_GRADP: finite-volume pressure Jacobian, Lin 1997).  No ATM_PRESS, no
+ * TIDE_GENERATING_FORCES; the file has no MASKING blocks.  Pinned against oracle/_ref/<APP>_PJ. */
+static int oracle_prsgrd40(OARGS)
+{
+  ORACLE_PROLOGUE
+  const int nrhs = s->nrhs;
+  const double g = p->g, rho0 = p->rho0;
+  double *FC_ = walloc(nis * (N + 1)), *FX_ = walloc(nis * njs * N), *P_ = walloc(nis * njs * (N + 1));
+#define FCk(i,k) FC_[(long)((i) - IminS) + (long)(k) * nis]
+#define FXk(i,j,k) FX_[WS3(i,j,k)]
+#define Pk(i,j,k) P_[WS2(i,j) + (long)(k) * nis * njs]
+  for (int j = JstrV - 1; j <= Jend; j++) {
+    for (int i = IstrU - 1; i <= Iend; i++) Pk(i, j, N) = 0.0;
+    for (int k = N; k >= 1; k--)
+      for (int i = IstrU - 1; i <= Iend; i++) {
+        Pk(i, j, k - 1) = Pk(i, j, k) + Hz(i, j, k) * rho(i, j, k);
+        FXk(i, j, k) = 0.5 * Hz(i, j, k) * (Pk(i, j, k) + Pk(i, j, k - 1));
+      }
+    if (j >= Jstr) {
+      for (int i = IstrU; i <= Iend; i++) FCk(i, N) = 0.0;
+      const double cff = 0.5 * g, cff1 = g / rho0;
+      for (int k = N; k >= 1; k--)
+        for (int i = IstrU; i <= Iend; i++) {
+          const double dh = z_w(i, j, k - 1) - z_w(i - 1, j, k - 1);
+          FCk(i, k - 1) = 0.5 * dh * (Pk(i, j, k - 1) + Pk(i - 1, j, k - 1));
+          ru(i, j, k, nrhs) = (cff * (Hz(i - 1, j, k) + Hz(i, j, k)) * (z_w(i - 1, j, N) - z_w(i, j, N)) +
+                               cff1 * (FXk(i - 1, j, k) - FXk(i, j, k) + FCk(i, k) - FCk(i, k - 1))) * on_u(i, j);
+        }
+    }
+    if (j >= JstrV) {
+      for (int i = Istr; i <= Iend; i++) FCk(i, N) = 0.0;
+      const double cff = 0.5 * g, cff1 = g / rho0;
+      for (int k = N; k >= 1; k--)
+        for (int i = Istr; i <= Iend; i++) {
+          const double dh = z_w(i, j, k - 1) - z_w(i, j - 1, k - 1);
+          FCk(i, k - 1) = 0.5 * dh * (Pk(i, j, k - 1) + Pk(i, j - 1, k - 1));
+          rv(i, j, k, nrhs) = (cff * (Hz(i, j - 1, k) + Hz(i, j, k)) * (z_w(i, j - 1, N) - z_w(i, j, N)) +
+                               cff1 * (FXk(i, j - 1, k) - FXk(i, j, k) + FCk(i, k) - FCk(i, k - 1))) * om_v(i, j);
+        }
+    }
+  }
+  free(FC_); free(FX_); free(P_);
+#undef FCk
+#undef FXk
+#undef Pk
+  return 0;
+}
+
 int oracle_prsgrd(OARGS)
 {
+  if (p->pgf == PGF_PJ_GRADP) return oracle_prsgrd40(b, p, s, F);
   if (p->pgf != PGF_DJ_GRADPS) {
     if (p->pgf != PGF_STANDARD && p->pgf != PGF_WJ_GRADP) return 8;
     return oracle_prsgrd31(b, p, s, F);

@@ -1,0 +1,28 @@
+/*
+** oracle/ref_headers/upwelling_pj.h -- application option list used ONLY by
+** oracle/build_ref.sh (test infrastructure): the options of upwelling_nodiag.h
+** (= the numerical options of ROMS/Include/upwelling.h) with DJ_GRADPS replaced
+** by PJ_GRADP,
+** so that prsgrd.F selects the finite-volume pressure Jacobian prsgrd40.h (prsgrd.F:20-21).
+** An application header is user configuration in ROMS (cppdefs.h:655-668).
+*/
+#define UV_ADV
+#define UV_COR
+#define UV_LDRAG
+#define UV_VIS2
+#define MIX_S_UV
+#define PJ_GRADP
+#define SPLINES_VDIFF
+#define SPLINES_VVISC
+#define TS_DIF2
+#define MIX_S_TS
+#define SALINITY
+#define SOLVE3D
+#define ANA_GRID
+#define ANA_INITIAL
+#define ANA_SMFLUX
+#define ANA_STFLUX
+#define ANA_SSFLUX
+#define ANA_BTFLUX
+#define ANA_BSFLUX
+#define ANA_VMIX

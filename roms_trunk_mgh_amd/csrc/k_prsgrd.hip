@@ -219,6 +219,47 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y) k_prsgrd31(const RomsDev *__rest
   }
 }
 
+// prsgrd40_tile (prsgrd40.h:170-268, PJ_GRADP): the hydrostatic pressure integral P of the own column and of the
+// western / southern neighbour march downwards together in registers -- one launch, no scratch
+__global__ void __launch_bounds__(BLK_X *BLK_Y) k_prsgrd40(const RomsDev *__restrict__ c, int nrhs)
+{
+  DEV_PROLOGUE(c)
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x, j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.Jend) return;
+  const bool do_u = i >= b.IstrU, do_v = j >= b.JstrV;
+  const gcd_t rho = (gcd_t)(c->F.rho), zw = (gcd_t)(c->F.z_w), Hz = (gcd_t)(c->F.Hz);
+  const gd_t ru = (gd_t)(c->F.ru + (long)(nrhs - 1) * n3w), rv = (gd_t)(c->F.rv + (long)(nrhs - 1) * n3w);
+  const double cff = 0.5 * c->p.g, cff1 = c->p.g / c->p.rho0;
+  const long a = I2(i, j), aw = do_u ? a - 1 : a, as = do_v ? a - ni : a;
+  const double onu = GF(on_u)[a], omv = GF(om_v)[a];
+  const double dzx = zw[aw + (long)N * nij] - zw[a + (long)N * nij];      // z_w(i-1,j,N) - z_w(i,j,N)
+  const double dze = zw[as + (long)N * nij] - zw[a + (long)N * nij];
+  double P0 = 0.0, Pw = 0.0, Ps = 0.0;        // P(.,.,k) of the three columns
+  double FCx = 0.0, FCe = 0.0;                // FC(i,k) of the two components
+  for (int k = N; k >= 1; k--) {
+    const long q = a + (long)(k - 1) * nij, qw = aw + (long)(k - 1) * nij, qs = as + (long)(k - 1) * nij;
+    const double h0 = Hz[q], hw = Hz[qw], hs = Hz[qs];
+    const double P0m = P0 + h0 * rho[q], Pwm = Pw + hw * rho[qw], Psm = Ps + hs * rho[qs];    // P(k-1)
+    const double FX0 = 0.5 * h0 * (P0 + P0m);
+    if (do_u) {
+      const double FXw = 0.5 * hw * (Pw + Pwm);
+      const double dh = zw[q] - zw[qw];                                   // z_w(i,j,k-1) - z_w(i-1,j,k-1)
+      const double FCm = 0.5 * dh * (P0m + Pwm);
+      ru[I3W(i, j, k)] = (cff * (hw + h0) * dzx + cff1 * (FXw - FX0 + FCx - FCm)) * onu;
+      FCx = FCm;
+    }
+    if (do_v) {
+      const double FXs = 0.5 * hs * (Ps + Psm);
+      const double dh = zw[q] - zw[qs];
+      const double FCm = 0.5 * dh * (P0m + Psm);
+      rv[I3W(i, j, k)] = (cff * (hs + h0) * dze + cff1 * (FXs - FX0 + FCe - FCm)) * omv;
+      FCe = FCm;
+    }
+    P0 = P0m; Pw = Pwm; Ps = Psm;
+  }
+}
+
 }  // namespace
 
 extern "C" int roms_hip_prsgrd(const roms_step_idx_t *s)
@@ -228,6 +269,12 @@ extern "C" int roms_hip_prsgrd(const roms_step_idx_t *s)
   if ((rc = check_lbc())) return rc;
   ScopedTimer tm("prsgrd");
   const roms_bounds_t &b = g_ctx.b;
+  if (g_ctx.p.pgf == PGF_PJ_GRADP) {
+    hipLaunchKernelGGL(k_prsgrd40, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                       g_ctx.devc, s->nrhs);
+    KERNEL_CHECK("k_prsgrd40");
+    return 0;
+  }
   if (g_ctx.p.pgf != PGF_DJ_GRADPS) {                   // prsgrd31.h: one launch, no scratch
     if (g_ctx.p.pgf != PGF_STANDARD && g_ctx.p.pgf != PGF_WJ_GRADP)
       return roms_fail("roms_hip_prsgrd", "unknown pressure-gradient algorithm (enum roms_pgf)");

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CONFIGS = ["UPWELLING", "SEAMOUNT"]
-VARIANTS = {"STANDARD": 1, "WJ_GRADP": 2}
+VARIANTS = {"STANDARD": 1, "WJ_GRADP": 2, "PJ_GRADP": 3}
 
 
 def input_state(config, variant):

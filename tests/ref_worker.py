@@ -577,8 +577,8 @@ if __name__ == "__main__":
         main_mpdata(sys.argv[1], mask="island" if "mask" in sys.argv[2] else None, basin=sys.argv[2].split("_")[-1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mask":
         main(sys.argv[1], mask="island")
-    elif len(sys.argv) > 2 and sys.argv[2] in ("pg31", "wj"):
-        main(sys.argv[1], pgf=1 if sys.argv[2] == "pg31" else 2)
+    elif len(sys.argv) > 2 and sys.argv[2] in ("pg31", "wj", "pj"):
+        main(sys.argv[1], pgf={"pg31": 1, "wj": 2, "pj": 3}[sys.argv[2]])
     elif len(sys.argv) > 2 and sys.argv[2] in ("ini", "ini_mask"):
         main_ini(sys.argv[1], mask="island" if sys.argv[2] == "ini_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] in ("bc4", "bc4_mask"):

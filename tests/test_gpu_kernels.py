@@ -79,9 +79,9 @@ def test_prsgrd(config):
 
 
 @pytest.mark.parametrize("config", CONFIGS)
-@pytest.mark.parametrize("pgf", ["STANDARD", "WJ_GRADP"])
+@pytest.mark.parametrize("pgf", ["STANDARD", "WJ_GRADP", "PJ_GRADP"])
 def test_prsgrd31(config, pgf):
-    """prsgrd31.h (standard / weighted density Jacobian, prsgrd.F:24-25) instead of prsgrd32.h; N = 40 as well."""
+    """prsgrd31.h (standard / weighted density Jacobian, prsgrd.F:24-25) or prsgrd40.h (PJ_GRADP) instead of prsgrd32.h; N = 40 as well."""
     for ov in ({"pgf": pgf}, {"pgf": pgf, "N": 40}):
         st_h, st_o, st0 = _run_pair(config, "prsgrd", util.step_idx(), overrides=ov)
         diffs = util.compare_states(st_h, st_o)

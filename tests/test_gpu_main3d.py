@@ -40,7 +40,9 @@ def _run(config, nsteps, perturb, physics=False, overrides=None):
                                                     # with bulk_flux + set_vbc recomputed every step on the device
                                                     ("BENCHMARK_TINY", 1.0, True), ("UPWELLING", 1.0, True),
                                                     # the reference's default pressure gradient (prsgrd31.h)
-                                                    ("SEAMOUNT", 0.0, "STANDARD"), ("UPWELLING", 1.0, "WJ_GRADP")])
+                                                    ("SEAMOUNT", 0.0, "STANDARD"), ("UPWELLING", 1.0, "WJ_GRADP"),
+                                                    # the finite-volume pressure Jacobian (prsgrd40.h)
+                                                    ("SEAMOUNT", 0.0, "PJ_GRADP")])
 def test_100_steps(config, perturb, physics):
     ov = None
     if isinstance(physics, str):
