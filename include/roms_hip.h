@@ -154,7 +154,10 @@ typedef struct roms_params {
   int    ts_dif4, uv_vis4;
   /* MIX_ISO_TS: tracer mixing along isopycnals (t3dmix2_iso.h:23, t3dmix4_iso.h:23) -- reads pden of rho_eos; takes
    * precedence over mix_geo_ts / mix_s_ts.  The default slope treatment (none of TS_MIX_MAX_SLOPE, TS_MIX_MIN_STRAT). */
-  int    mix_iso_ts, pad_iso;
+  int    mix_iso_ts;
+  /* RADIATION_2D: the radiation conditions (LBC_RADIATION, LBC_RADIATION_NUDGING; 2-D and 3-D variables) include the
+   * tangential phase speed Ce (e.g. zetabc.F:141-147, t3dbc_im.F:151-165) */
+  int    radiation_2d;
   /* UV_LOGDRAG (uv_drag = 3): limits of the drag coefficient of the logarithmic bottom layer, roms_*.in Cdb_min /
    * Cdb_max (mod_scalars.F:747-748); the roughness length is the field ZoBot */
   double Cdb_min, Cdb_max;

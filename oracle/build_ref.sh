@@ -16,7 +16,8 @@
 #                                 and with WJ_GRADP, instead of prsgrd32.h); UPWELLING_DIF4, SEAMOUNT_DIF4
 #                                 (= the application plus TS_DIF4 and UV_VIS4), UPWELLING_MASK_DIF4; UPWELLING_ISO, SEAMOUNT_ISO,
 #                                 UPWELLING_MASK_ISO (= the _DIF4 options with MIX_ISO_TS as the tracer mixing choice); UPWELLING_LOGDRAG
-#                                 (UV_LOGDRAG instead of UV_LDRAG); UPWELLING_PJ, SEAMOUNT_PJ (PJ_GRADP: prsgrd40.h)
+#                                 (UV_LOGDRAG instead of UV_LDRAG); UPWELLING_PJ, SEAMOUNT_PJ (PJ_GRADP: prsgrd40.h); UPWELLING_RAD2D,
+#                                 UPWELLING_MASK_RAD2D, BENCHMARK_RAD2D (+ -DRADIATION_2D)
 #
 # This is the reference's own recipe (makefile:207, Compilers/Linux-gfortran.mk:
 # 43-44: cpp -P -traditional then the Fortran compiler), serial build (no
@@ -54,6 +55,9 @@ build_app () {
   # wrapper then also binds t3dmix4 / uv3dmix4 (-DREF_DIF4 reaches the wrapper only)
   local TAG=$1 APP=${1%%_*} XDEF="" WDEF="" VAR=nodiag
   case $TAG in *_MASK*) XDEF="-DMASKING";; esac
+  # <APP>[_MASK]_RAD2D: the application with the RADIATION_2D option added on the command line (the tangential phase
+  # speed in the radiation conditions of zetabc.F, u2dbc_im.F ... t3dbc_im.F)
+  case $TAG in *_RAD2D) XDEF="$XDEF -DRADIATION_2D";; esac
   case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_PJ) VAR=pj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; *_LOGDRAG) VAR=logdrag; WDEF="-DREF_LOGDRAG";; esac
   local hdr=$(echo $APP | tr A-Z a-z).h
   # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
@@ -75,7 +79,7 @@ build_app () {
     local bn=$(basename $f)
     # the MASKING variants leave analytical.F out: its ana_mask.h stops the compilation on purpose until a user
     # fills in mask values ("no values provided for mask"); the masks reach GRID(ng) through the wrapper
-    [ -n "$XDEF" ] && [ $bn = analytical ] && continue
+    case "$XDEF" in *MASKING*) [ $bn = analytical ] && continue;; esac
     cpp "${CPPF[@]}" $REF/ROMS/$f.F > $bn.f90
     $FC $FFLAGS -c $bn.f90 -o $bn.o > $bn.log 2>&1 || { echo "[$TAG] $f failed"; tail -5 $bn.log; exit 1; }
     objs="$objs $bn.o"
@@ -87,7 +91,7 @@ build_app () {
   echo "[$TAG] built $D/libref.so"
 }
 
-for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ}; do
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ UPWELLING_RAD2D UPWELLING_MASK_RAD2D BENCHMARK_RAD2D}; do
   build_app $app &
 done
 wait

@@ -25,7 +25,8 @@ static void o_know(const roms_params_t *p, const roms_step_idx_t *s, int *know, 
 /* Implicit upstream radiation with Cx (or Ce) of the tangential direction = 0 (no RADIATION_2D), e.g.
  * zetabc.F:123-160: xb_old = X(B) at the old level; x1_old, x1 = X(P1) at the old / new level; x2 = X(P2) at the new
  * level; gL, gR = the two along-edge differences of X(old) at P1 on either side of the point. */
-static double o_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR, int *inward)
+static double o_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR, int *inward,
+                        int rad2d, double gLb, double gRb)
 {
   const double eps = 1.0E-20;
   double dXdt = x1_old - x1;
@@ -35,6 +36,10 @@ static double o_radiate(double xb_old, double x1_old, double x1, double x2, doub
   const double dXds = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
   const double cff = MAX(dXdn * dXdn + dXds * dXds, eps);
   const double Cn = dXdt * dXdn;
+  /* RADIATION_2D: the tangential phase speed with the upstream along-edge difference of the boundary row itself
+   * (gLb, gRb), e.g. zetabc.F:141-160 */
+  const double Ct = rad2d ? MIN(cff, MAX(dXdt * dXds, -cff)) : 0.0;
+  if (rad2d) return (cff * xb_old + Cn * x1 - MAX(Ct, 0.0) * gLb - MIN(Ct, 0.0) * gRb) / (cff + Cn);
   return (cff * xb_old + Cn * x1) / (cff + Cn);
 }
 
@@ -106,7 +111,11 @@ static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_f
          * row (the other edges, :126, :275, :573, and every other variable look into the interior) */
         const long Q2 = (var == LBV_ZETA && side == LBS_SOUTH) ? B : P2;
         int inward;
-        x = o_radiate(Ok[B], Ok[P1], Xk[P1], Xk[Q2], gL, gR, &inward);
+        double gLb = Ok[B] - Ok[B - e.st], gRb = Ok[B + e.st] - Ok[B];
+        if (mk && gtype == GT_R) { gLb = gLb * gmask[B]; gRb = gRb * gmask[B + e.st]; }
+        /* zetabc.F:455-456 -- and the same edge takes the along-edge differences of the first INSIDE row there */
+        if (var == LBV_ZETA && side == LBS_SOUTH) { gLb = gL; gRb = gR; }
+        x = o_radiate(Ok[B], Ok[P1], Xk[P1], Xk[Q2], gL, gR, &inward, p->radiation_2d, gLb, gRb);
         if (code == LBC_RADIATION_NUDGING) {                    /* explicit nudging, zetabc.F:128-135/:162-166 ... */
           double tau = inward ? p->obc_in[side][var] : p->obc_out[side][var];
           tau = tau * (nk == 1 && var <= LBV_VBAR ? dt2d : p->dt);

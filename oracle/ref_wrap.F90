@@ -51,7 +51,7 @@ MODULE ref_wrap_types
     INTEGER(c_int) :: lbc(6,4)          ! C: lbc[side][variable]
     REAL(c_double) :: obc_out(6,4), obc_in(6,4)   ! nudging coefficients of RadNud edges (1/s)
     INTEGER(c_int) :: ts_dif4, uv_vis4
-    INTEGER(c_int) :: mix_iso_ts, pad_iso
+    INTEGER(c_int) :: mix_iso_ts, radiation_2d
     REAL(c_double) :: Cdb_min, Cdb_max
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t

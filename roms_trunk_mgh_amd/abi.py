@@ -102,7 +102,7 @@ class Params(C.Structure):
         ("masking", C.c_int), ("pgf", C.c_int),
         ("lbc", (C.c_int * 6) * 4),
         ("obc_out", (C.c_double * 6) * 4), ("obc_in", (C.c_double * 6) * 4),
-        ("ts_dif4", C.c_int), ("uv_vis4", C.c_int), ("mix_iso_ts", C.c_int), ("pad_iso", C.c_int),
+        ("ts_dif4", C.c_int), ("uv_vis4", C.c_int), ("mix_iso_ts", C.c_int), ("radiation_2d", C.c_int),
         ("Cdb_min", C.c_double), ("Cdb_max", C.c_double),
     ]
 

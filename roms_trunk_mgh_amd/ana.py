@@ -199,6 +199,7 @@ def make_params(cfg, NT):
     p.ts_dif4 = int(cfg.get("ts_dif4", 0))
     p.uv_vis4 = int(cfg.get("uv_vis4", 0))
     p.mix_iso_ts = int(cfg.get("mix_iso_ts", 0))
+    p.radiation_2d = int(cfg.get("radiation_2d", 0))
     p.mix_geo_ts = int(app in ("BENCHMARK", "SEAMOUNT") and not p.mix_iso_ts)
     p.mix_s_ts = int(app == "UPWELLING" and not p.mix_iso_ts)
     p.salinity = int(app in ("BENCHMARK", "UPWELLING"))

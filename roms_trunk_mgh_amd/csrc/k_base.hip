@@ -77,7 +77,7 @@ struct BcArgs {
 };
 
 __device__ __forceinline__ double bc_radiate(double xb_old, double x1_old, double x1, double x2, double gL, double gR,
-                                             bool &inward)
+                                             bool &inward, bool rad2d, double gLb, double gRb)
 {
   const double eps = 1.0E-20;
   double dXdt = x1_old - x1;
@@ -87,6 +87,10 @@ __device__ __forceinline__ double bc_radiate(double xb_old, double x1_old, doubl
   const double dXds = ((dXdt * (gL + gR)) > 0.0) ? gL : gR;
   const double cff = fmax(dXds * dXds + dXdn * dXdn, eps);
   const double Cn = dXdt * dXdn;
+  if (rad2d) {                                     // RADIATION_2D: tangential phase speed, e.g. zetabc.F:141-160
+    const double Ct = fmin(cff, fmax(dXdt * dXds, -cff));
+    return (cff * xb_old + Cn * x1 - fmax(Ct, 0.0) * gLb - fmin(Ct, 0.0) * gRb) / (cff + Cn);
+  }
   return (cff * xb_old + Cn * x1) / (cff + Cn);
 }
 
@@ -139,7 +143,15 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
     // zetabc.F:424 -- on the southern edge the free surface takes its normal difference towards the boundary row
     const long Q2 = (a.var == LBV_ZETA && side == LBS_SOUTH) ? B : P2;
     bool inward;
-    x = bc_radiate(O[B], O[P1], X[P1], X[Q2], gL, gR, inward);
+    double gLb = O[B] - O[B - st], gRb = O[B + st] - O[B];        // along-edge differences of the boundary row
+    if (a.masked && (a.var == LBV_T || a.var == LBV_ZETA)) {
+      const double *gm = we ? c->F.vmask : c->F.umask;
+      gLb = gLb * gm[B];
+      gRb = gRb * gm[B + st];
+    }
+    // zetabc.F:455-456 -- ... and the along-edge differences of the first inside row in the tangential term
+    if (a.var == LBV_ZETA && side == LBS_SOUTH) { gLb = gL; gRb = gR; }
+    x = bc_radiate(O[B], O[P1], X[P1], X[Q2], gL, gR, inward, p.radiation_2d != 0, gLb, gRb);
     if (code == LBC_RADIATION_NUDGING) {            // explicit nudging towards the boundary data, zetabc.F:162-166 ...
       double tau = inward ? p.obc_in[side][a.var] : p.obc_out[side][a.var];
       tau = tau * (a.var <= LBV_VBAR ? a.dt2d : p.dt);

@@ -72,7 +72,7 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: lbc(6,4)          ! C: lbc[side][variable]
     REAL(c_double) :: obc_out(6,4), obc_in(6,4)   ! nudging coefficients of RadNud edges (1/s)
     INTEGER(c_int) :: ts_dif4, uv_vis4            ! TS_DIF4, UV_VIS4 (biharmonic mixing)
-    INTEGER(c_int) :: mix_iso_ts, pad_iso         ! MIX_ISO_TS
+    INTEGER(c_int) :: mix_iso_ts, radiation_2d    ! MIX_ISO_TS, RADIATION_2D
     REAL(c_double) :: Cdb_min, Cdb_max            ! UV_LOGDRAG limits
   END TYPE roms_params_t
 

@@ -137,7 +137,7 @@ def main_iso(config, basin=None, mask=None):
     print(json.dumps(out))
 
 
-def main_bc(config, mask=None):
+def main_bc(config, mask=None, rad2d=False):
     """The six lateral boundary-condition routines on the S/N edges, every condition the library offers, for the
     three states of the barotropic stepping (first, predictor, corrector): reference Fortran vs C oracle."""
     import oracle
@@ -145,6 +145,7 @@ def main_bc(config, mask=None):
     from oracle import ref
     from roms_trunk_mgh_amd import abi
     st0 = util.prepared_state(config, mask=mask)
+    st0.p.radiation_2d = int(rad2d)
     rng = np.random.default_rng(11)
     for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
         st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
@@ -230,13 +231,14 @@ def basin_cases(st0):
                 yield f"{kind}:{code}:{q}", kind, var, st, s, nout, st0.b.NT
 
 
-def main_bc4(config, mask=None):
+def main_bc4(config, mask=None, rad2d=False):
     """The six boundary-condition routines on a basin (four physical edges + corners): reference vs oracle."""
     import oracle
     import util
     from oracle import ref
     st0 = basin_state(config, mask)
-    out = {"masking": int(st0.p.masking), "EWperiodic": int(st0.b.EWperiodic), "cases": {}}
+    st0.p.radiation_2d = int(rad2d)
+    out = {"masking": int(st0.p.masking), "EWperiodic": int(st0.b.EWperiodic), "cases": {}, "radiation_2d": int(rad2d)}
     bb = ref.Ref(st0.copy()).bounds()
     mine = st0.b.as_dict()
     out["bounds_mismatch"] = {k: (v, mine[k]) for k, v in bb.items() if mine[k] != v}
@@ -554,6 +556,7 @@ GRID2D = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", 
 
 
 if __name__ == "__main__":
+    RAD2D = len(sys.argv) > 3 and sys.argv[3] == "rad2d"      # the builds with -DRADIATION_2D (bc, bc4 modes)
     if len(sys.argv) > 2 and sys.argv[2] == "ana":
         main_ana(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "diag":
@@ -582,8 +585,8 @@ if __name__ == "__main__":
     elif len(sys.argv) > 2 and sys.argv[2] in ("ini", "ini_mask"):
         main_ini(sys.argv[1], mask="island" if sys.argv[2] == "ini_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] in ("bc4", "bc4_mask"):
-        main_bc4(sys.argv[1], mask="island" if sys.argv[2] == "bc4_mask" else None)
+        main_bc4(sys.argv[1], mask="island" if sys.argv[2] == "bc4_mask" else None, rad2d=RAD2D)
     elif len(sys.argv) > 2 and sys.argv[2] in ("bc", "bc_mask"):
-        main_bc(sys.argv[1], mask="island" if sys.argv[2] == "bc_mask" else None)
+        main_bc(sys.argv[1], mask="island" if sys.argv[2] == "bc_mask" else None, rad2d=RAD2D)
     else:
         main(sys.argv[1])

@@ -198,3 +198,39 @@ def test_hip_100_steps_mpdata_hsimt_on_a_basin(scheme, mask):
         out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
     assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
     assert all(v <= 1e-10 for v in out.values()), out
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+@pytest.mark.parametrize("table", ["open", "radnud"])
+@pytest.mark.parametrize("kernel", ["step2d", "step3d_uv", "step3d_t"])
+def test_hip_kernels_with_radiation_2d(config, table, kernel):
+    """RADIATION_2D (roms_params_t.radiation_2d): the tangential phase speed in every radiation condition, all four
+    edges; the oracle's six routines are pinned against the reference built with the option."""
+    import oracle
+    from roms_trunk_mgh_amd import hip
+    st0 = _state(config, kernel, True if table == "open" else "radnud")
+    st0.p.radiation_2d = 1
+    for var in ("zeta", "ubar", "vbar"):          # radiation for the 2-D variables as well
+        for sd in ("west", "east", "south", "north"):
+            st0.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC["Rad" if table == "open" else "RadNud"]
+    st_o, st_h = st0.copy(), st0.copy()
+    preds = [(5, 1, 0)] if kernel != "step2d" else [(5, 1, 1), (5, 2, 1), (5, 2, 0)]
+    for iic, iif, pred in preds:
+        s = util.step_idx(iic=iic, iif=iif, pred=pred, knew=3 if pred else 2, krhs=1 if pred else 3)
+        if kernel == "ini_fields":
+            s = util.step_idx(iic=1, iif=1, pred=0, kstp=1, krhs=1, knew=1)
+        oracle.Oracle(st_o).call(kernel, s)
+        h = hip.RomsHip(st_h)
+        try:
+            h.call(kernel, s)
+            h.to_host()
+        finally:
+            h.close()
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= 1e-12 for v in diffs.values()), diffs
+    # the option changes the result
+    st_n = st0.copy()
+    st_n.p = type(st0.p).from_buffer_copy(st0.p)
+    st_n.p.radiation_2d = 0
+    oracle.Oracle(st_n).call(kernel, s)
+    assert util.compare_states(st_n, st_o), "RADIATION_2D made no difference: test is vacuous"
