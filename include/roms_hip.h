@@ -100,7 +100,9 @@ enum roms_lbc {
   LBC_PERIODIC = 0, LBC_CLOSED = 1, LBC_GRADIENT = 2, LBC_CLAMPED = 3, LBC_CHAPMAN_IMPLICIT = 4, LBC_FLATHER = 5,
   LBC_RADIATION = 6, LBC_RADIATION_NUDGING = 7,
   LBC_CHAPMAN_EXPLICIT = 8,          /* "Che", free surface only: zetabc.F:175-190 */
-  LBC_SHCHEPETKIN = 9                /* "Shc", ubar / vbar only: u2dbc_im.F:288-362, v2dbc_im.F:290-364 (bry_val = the boundary data) */
+  LBC_SHCHEPETKIN = 9,               /* "Shc", ubar / vbar only: u2dbc_im.F:288-362, v2dbc_im.F:290-364 (bry_val = the boundary data) */
+  LBC_REDUCED = 10                   /* "Red", ubar / vbar only: reduced physics (pressure gradient, Coriolis, surface and
+                                      * bottom stress), u2dbc_im.F:392-432, v2dbc_im.F:394-436 */
 };
 /* rows of roms_params_t.lbc = the state variables of LBC(:, isFsur / isUbar / isVbar / isUvel / isVvel / isTvar, ng) */
 enum roms_lbc_var { LBV_ZETA = 0, LBV_UBAR, LBV_VBAR, LBV_U, LBV_V, LBV_T, LBV_COUNT };

@@ -40,7 +40,7 @@ int o_check_lbc(const roms_bounds_t *b, const roms_params_t *p)
       }
       int ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED || c == LBC_RADIATION || c == LBC_RADIATION_NUDGING;
       if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT || c == LBC_CHAPMAN_EXPLICIT;
-      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER || c == LBC_SHCHEPETKIN;
+      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER || c == LBC_SHCHEPETKIN || c == LBC_REDUCED;
       if (!ok) return 1;
     }
   }

@@ -86,7 +86,7 @@ static int edge_of(const roms_bounds_t *b, int side, int gtype, int closed, Edge
  * compares with (know / nstp), D = boundary data, Z = zeta(know), Zb = zeta_bry; nk planes of stride nij. */
 static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_fields_t *F, int side, int var, int code,
                     double *X, const double *O, const double *D, const double *Z, const double *Zb, const double *Zn, int nk,
-                    double dt2d)
+                    double dt2d, const double *T)
 {
   const int LBi = b->LBi, LBj = b->LBj;
   const long ni = b->UBi - b->LBi + 1, nij = ni * (b->UBj - b->LBj + 1);
@@ -151,6 +151,24 @@ static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_f
         }
         x = e.hi ? 0.5 * ((1.0 - Cn) * O[B] + Cn * O[P1] + bry_val + cff1 * (Zx - Zb[qo]))
                  : 0.5 * ((1.0 - Cn) * O[B] + Cn * O[P1] + bry_val - cff1 * (Zx - Zb[qo]));
+      } else if (code == LBC_REDUCED && normal) {               /* u2dbc_im.F:392-432, :740-780; v2dbc_im.F:394-436, :743-785 */
+        /* T = the other barotropic component at know; acquire: boundary data of the free surface exist on this side
+         * (inp_decode.F:1620-1655, no FSOBC_REDUCED) */
+        const long un = e.we ? 1 : ni, lo = B - un, qi = e.hi ? lo : B, qo = e.hi ? B : lo;
+        const int zc = o_lbc(p, side, LBV_ZETA), uc = o_lbc(p, side, LBV_UBAR), vc = o_lbc(p, side, LBV_VBAR);
+        const int acquire = zc == LBC_CLAMPED || zc == LBC_RADIATION_NUDGING || uc == LBC_FLATHER || uc == LBC_SHCHEPETKIN ||
+                            vc == LBC_FLATHER || vc == LBC_SHCHEPETKIN;
+        double bry_pgr, bry_cor = 0.0;
+        if (acquire) bry_pgr = e.hi ? -p->g * (Zb[qo] - Z[qi]) * 0.5 * pmn[qi] : -p->g * (Z[qi] - Zb[qo]) * 0.5 * pmn[qi];
+        else bry_pgr = -p->g * (Z[B] - Z[lo]) * 0.5 * (pmn[lo] + pmn[B]);
+        if (p->uv_cor) {
+          const long ut = e.we ? ni : 1;                        /* step along the edge */
+          bry_cor = 0.125 * (T[lo] + T[lo + ut] + T[B] + T[B + ut]) * (F->f[lo] + F->f[B]);
+          if (!e.we) bry_cor = -bry_cor;
+        }
+        const double cff = 1.0 / (0.5 * (F->h[lo] + Z[lo] + F->h[B] + Z[B]));
+        const double bry_str = cff * ((e.we ? F->sustr : F->svstr)[B] - (e.we ? F->bustr : F->bvstr)[B]);
+        x = O[B] + dt2d * (bry_pgr + bry_cor + bry_str);
       } else if (code == LBC_FLATHER && normal) {               /* u2dbc_im.F:214-300, v2dbc_im.F:216-286 */
         /* the two rho-points around the boundary velocity point, lower index first: u(i,j) lies between
          * rho(i-1,j) and rho(i,j), v(i,j) between rho(i,j-1) and rho(i,j) */
@@ -160,7 +178,7 @@ static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_f
         const double Cn = sqrt(p->g * cff);
         const double zb = Zb[e.hi ? qc : qa];                   /* zeta_west(j) = the rho boundary point */
         x = e.hi ? bry_val + Cn * (0.5 * (Z[qa] + Z[qc]) - zb) : bry_val - Cn * (0.5 * (Z[qa] + Z[qc]) - zb);
-      } else if (code == LBC_FLATHER || code == LBC_SHCHEPETKIN) {   /* tangential: u2dbc_im.F:912-932, v2dbc_im.F:886-906 */
+      } else if (code == LBC_FLATHER || code == LBC_SHCHEPETKIN || code == LBC_REDUCED) {   /* tangential: u2dbc_im.F:912-932, v2dbc_im.F:886-906 */
         const double cff = dt2d * 0.5 * (pmn[P1 - e.st] + pmn[P1]);
         const double cff1 = sqrt(p->g * 0.5 * (F->h[P1 - e.st] + Z[P1 - e.st] + F->h[P1] + Z[P1]));
         const double Cn = cff * cff1;
@@ -236,7 +254,7 @@ void o_zetabc(OARGS, int kout)
   o_know(p, s, &know, &dt2d);
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_ZETA, o_lbc(p, SIDES[q], LBV_ZETA), &zeta(LBi, LBj, kout), &zeta(LBi, LBj, know),
-            F->zeta_bry, &zeta(LBi, LBj, know), F->zeta_bry, NULL, 1, dt2d);
+            F->zeta_bry, &zeta(LBi, LBj, know), F->zeta_bry, NULL, 1, dt2d, NULL);
   bc_corners(b, GT_R, &zeta(LBi, LBj, kout), 1);
 }
 
@@ -247,7 +265,7 @@ void o_u2dbc(OARGS, int kout)
   o_know(p, s, &know, &dt2d);
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_UBAR, o_lbc(p, SIDES[q], LBV_UBAR), &ubar(LBi, LBj, kout), &ubar(LBi, LBj, know),
-            F->ubar_bry, &zeta(LBi, LBj, know), F->zeta_bry, &zeta(LBi, LBj, kout), 1, dt2d);
+            F->ubar_bry, &zeta(LBi, LBj, know), F->zeta_bry, &zeta(LBi, LBj, kout), 1, dt2d, &vbar(LBi, LBj, know));
   bc_corners(b, GT_U, &ubar(LBi, LBj, kout), 1);
 }
 
@@ -258,7 +276,7 @@ void o_v2dbc(OARGS, int kout)
   o_know(p, s, &know, &dt2d);
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_VBAR, o_lbc(p, SIDES[q], LBV_VBAR), &vbar(LBi, LBj, kout), &vbar(LBi, LBj, know),
-            F->vbar_bry, &zeta(LBi, LBj, know), F->zeta_bry, &zeta(LBi, LBj, kout), 1, dt2d);
+            F->vbar_bry, &zeta(LBi, LBj, know), F->zeta_bry, &zeta(LBi, LBj, kout), 1, dt2d, &ubar(LBi, LBj, know));
   bc_corners(b, GT_V, &vbar(LBi, LBj, kout), 1);
 }
 
@@ -267,7 +285,7 @@ void o_u3dbc(OARGS, int nout)
   ORACLE_PROLOGUE
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_U, o_lbc(p, SIDES[q], LBV_U), &u(LBi, LBj, 1, nout), &u(LBi, LBj, 1, s->nstp),
-            F->u_bry, NULL, NULL, NULL, N, 0.0);
+            F->u_bry, NULL, NULL, NULL, N, 0.0, NULL);
   bc_corners(b, GT_U, &u(LBi, LBj, 1, nout), N);
 }
 
@@ -276,7 +294,7 @@ void o_v3dbc(OARGS, int nout)
   ORACLE_PROLOGUE
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_V, o_lbc(p, SIDES[q], LBV_V), &v(LBi, LBj, 1, nout), &v(LBi, LBj, 1, s->nstp),
-            F->v_bry, NULL, NULL, NULL, N, 0.0);
+            F->v_bry, NULL, NULL, NULL, N, 0.0, NULL);
   bc_corners(b, GT_V, &v(LBi, LBj, 1, nout), N);
 }
 
@@ -285,7 +303,7 @@ void o_t3dbc(OARGS, int nout, int itrc)
   ORACLE_PROLOGUE
   for (int q = 0; q < 4; q++)
     bc_edge(b, p, F, SIDES[q], LBV_T, o_lbc(p, SIDES[q], LBV_T), &t(LBi, LBj, 1, nout, itrc), &t(LBi, LBj, 1, s->nstp, itrc),
-            F->t_bry + (long)(itrc - 1) * n3r, NULL, NULL, NULL, N, 0.0);
+            F->t_bry + (long)(itrc - 1) * n3r, NULL, NULL, NULL, N, 0.0, NULL);
   bc_corners(b, GT_R, &t(LBi, LBj, 1, nout, itrc), N);
 }
 

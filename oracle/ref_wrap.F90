@@ -876,6 +876,7 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   USE mod_grid
   USE mod_ocean
   USE mod_boundary
+  USE mod_forces
   USE zetabc_mod, ONLY : zetabc_tile
   USE u2dbc_mod,  ONLY : u2dbc_tile
   USE v2dbc_mod,  ONLY : v2dbc_tile
@@ -890,7 +891,7 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   TYPE(stepidx_t), INTENT(in) :: s
   TYPE(fields_t), INTENT(in) :: F
   INTEGER(c_int) :: rc
-  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT, sd, v, code, side(4), ivar, i, k, it
+  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT, sd, v, code, side(4), ivar, i, k, it, eff4(6,4)
   INTEGER :: IminS, ImaxS, JminS, JmaxS, Jstr, Jend, Istr, Iend
   REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:), a5(:,:,:,:,:)
   ng = 1; tile = 0
@@ -942,11 +943,19 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
         LBC(side(sd), ivar, ng)%Chapman_explicit = code == 8
         LBC(side(sd), ivar, ng)%nudging = code == 7                 ! "RadNud"
         LBC(side(sd), ivar, ng)%nested = .FALSE.
-        LBC(side(sd), ivar, ng)%reduced = .FALSE.
+        LBC(side(sd), ivar, ng)%reduced = code == 10
         LBC(side(sd), ivar, ng)%Shchepetkin = code == 9
         LBC(side(sd), ivar, ng)%acquire = .FALSE.
       END DO
+      eff4(v, sd) = code
     END DO
+  END DO
+  !  boundary data of the free surface are "acquired" on a side whose free-surface condition is clamped or nudged, or
+  !  whose ubar / vbar condition is Flather or Shchepetkin (inp_decode.F:1620-1655; no FSOBC_REDUCED): the reduced-
+  !  physics condition then takes its pressure gradient from them (u2dbc_im.F:395-405)
+  DO sd = 1, 4
+    LBC(side(sd), isFsur, ng)%acquire = eff4(1,sd) == 3 .OR. eff4(1,sd) == 7 .OR. eff4(2,sd) == 5 .OR. eff4(2,sd) == 9 &
+ &                                      .OR. eff4(3,sd) == 5 .OR. eff4(3,sd) == 9
   END DO
   ! nudging coefficients of RadNud edges (constant ones: no climatology nudging coefficients)
   LnudgeM2CLM(ng) = .FALSE.; LnudgeM3CLM(ng) = .FALSE.
@@ -985,6 +994,10 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); OCEAN(ng)%t = a5
   CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
   CALL c_f_pointer (F%Zt_avg1, a2, (/ni,nj/));  COUPLING(ng)%Zt_avg1 = a2
+  CALL c_f_pointer (F%sustr, a2, (/ni,nj/));    FORCES(ng)%sustr = a2          ! (the reduced-physics condition)
+  CALL c_f_pointer (F%svstr, a2, (/ni,nj/));    FORCES(ng)%svstr = a2
+  CALL c_f_pointer (F%bustr, a2, (/ni,nj/));    FORCES(ng)%bustr = a2
+  CALL c_f_pointer (F%bvstr, a2, (/ni,nj/));    FORCES(ng)%bvstr = a2
   ! ---- boundary data: edge vectors from the rows of the *_bry fields ----
   IF (.NOT. associated(BOUNDARY(ng)%zeta_south)) THEN
     allocate ( BOUNDARY(ng)%zeta_south(LBi:UBi), BOUNDARY(ng)%zeta_north(LBi:UBi) )

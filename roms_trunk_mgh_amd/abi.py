@@ -23,7 +23,7 @@ ADV = {"C2": 0, "C4": 1, "A4": 2, "U3": 3, "SU3": 4, "SPLINES": 5,
        "MPDATA": 6, "HSIMT": 7}
 PGF = {"DJ_GRADPS": 0, "STANDARD": 1, "WJ_GRADP": 2, "PJ_GRADP": 3}         # enum roms_pgf (prsgrd.F:16-26)
 LBC_PERIODIC, LBC_CLOSED, LBC_GRADIENT, LBC_CLAMPED, LBC_CHAPMAN_IMPLICIT, LBC_FLATHER, LBC_RADIATION = range(7)
-LBC = {"Per": 0, "Clo": 1, "Gra": 2, "Cla": 3, "Cha": 4, "Fla": 5, "Rad": 6, "RadNud": 7, "Che": 8, "Shc": 9}      # the keywords of roms_*.in
+LBC = {"Per": 0, "Clo": 1, "Gra": 2, "Cla": 3, "Cha": 4, "Fla": 5, "Rad": 6, "RadNud": 7, "Che": 8, "Shc": 9, "Red": 10}      # the keywords of roms_*.in
 LBV = {"zeta": 0, "ubar": 1, "vbar": 2, "u": 3, "v": 4, "t": 5}
 LBS = {"west": 0, "east": 1, "south": 2, "north": 3}
 

@@ -34,7 +34,7 @@ int check_lbc()
       }
       bool ok = c == LBC_CLOSED || c == LBC_GRADIENT || c == LBC_CLAMPED || c == LBC_RADIATION || c == LBC_RADIATION_NUDGING;
       if (v == LBV_ZETA) ok = ok || c == LBC_CHAPMAN_IMPLICIT || c == LBC_CHAPMAN_EXPLICIT;
-      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER || c == LBC_SHCHEPETKIN;
+      if (v == LBV_VBAR || v == LBV_UBAR) ok = ok || c == LBC_FLATHER || c == LBC_SHCHEPETKIN || c == LBC_REDUCED;
       if (!ok) return roms_fail("check_lbc", "lateral boundary condition not implemented for this variable");
     }
   }
@@ -70,6 +70,8 @@ struct BcArgs {
   const double *D;       // boundary data of this variable (or nullptr)
   const double *Z, *Zb;  // Flather, Shchepetkin (ubar, vbar): zeta(know), zeta_bry
   const double *Zn;      // Shchepetkin: zeta at the level being written
+  const double *T;       // reduced physics: the other barotropic component at know
+  int acquire[4];        // reduced physics: boundary data of the free surface exist on the side (inp_decode.F:1620-1655)
   int var;               // enum roms_lbc_var; -1 = bc_w3d (gradient, no mask)
   int code[4];           // enum roms_lbc on the western / eastern / southern / northern edge
   int nk, masked;
@@ -186,6 +188,19 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
     }
     x = hi ? 0.5 * ((1.0 - Cn) * a.Xold[B] + Cn * a.Xold[P1] + bry_val + cff1 * (Zx - a.Zb[qo]))
            : 0.5 * ((1.0 - Cn) * a.Xold[B] + Cn * a.Xold[P1] + bry_val - cff1 * (Zx - a.Zb[qo]));
+  } else if (code == LBC_REDUCED && normal) {       // u2dbc_im.F:392-432, :740-780; v2dbc_im.F:394-436, :743-785
+    const double *pmn = we ? c->F.pm : c->F.pn;
+    const long un = we ? 1 : ni, lo = B - un, qi = hi ? lo : B, qo = hi ? B : lo;
+    double bry_pgr, bry_cor = 0.0;
+    if (a.acquire[side]) bry_pgr = hi ? -p.g * (a.Zb[qo] - a.Z[qi]) * 0.5 * pmn[qi] : -p.g * (a.Z[qi] - a.Zb[qo]) * 0.5 * pmn[qi];
+    else bry_pgr = -p.g * (a.Z[B] - a.Z[lo]) * 0.5 * (pmn[lo] + pmn[B]);
+    if (p.uv_cor) {
+      bry_cor = 0.125 * (a.T[lo] + a.T[lo + st] + a.T[B] + a.T[B + st]) * (c->F.f[lo] + c->F.f[B]);
+      if (!we) bry_cor = -bry_cor;
+    }
+    const double cff = 1.0 / (0.5 * (c->F.h[lo] + a.Z[lo] + c->F.h[B] + a.Z[B]));
+    const double bry_str = cff * ((we ? c->F.sustr : c->F.svstr)[B] - (we ? c->F.bustr : c->F.bvstr)[B]);
+    x = a.Xold[B] + a.dt2d * (bry_pgr + bry_cor + bry_str);
   } else if (code == LBC_FLATHER && normal) {       // u2dbc_im.F:214-300, v2dbc_im.F:216-286 (bry_val = boundary data)
     const long qa = B - (we ? 1 : ni), qc = B;      // the two rho-points around the velocity point, lower index first
     const double bry_val = a.D[B];
@@ -193,7 +208,7 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
     const double Cn = sqrt(p.g * cff);
     const double zb = a.Zb[hi ? qc : qa];
     x = hi ? bry_val + Cn * (0.5 * (a.Z[qa] + a.Z[qc]) - zb) : bry_val - Cn * (0.5 * (a.Z[qa] + a.Z[qc]) - zb);
-  } else if (code == LBC_FLATHER || code == LBC_SHCHEPETKIN) {   // tangential component, Chapman type: u2dbc_im.F:912-932, v2dbc_im.F:886-906
+  } else if (code == LBC_FLATHER || code == LBC_SHCHEPETKIN || code == LBC_REDUCED) {   // tangential component, Chapman type: u2dbc_im.F:912-932, v2dbc_im.F:886-906
     const double *pmn = we ? c->F.pm : c->F.pn;
     const double cff = a.dt2d * 0.5 * (pmn[P1 - st] + pmn[P1]);
     const double cff1 = sqrt(p.g * 0.5 * (c->F.h[P1 - st] + a.Z[P1 - st] + c->F.h[P1] + a.Z[P1]));
@@ -291,11 +306,23 @@ static void bc_know(const roms_step_idx_t *s, int *know, double *dt2d)
   else { *know = s->kstp; *dt2d = dtfast; }
 }
 
+// boundary data of the free surface are "acquired" on a side whose free-surface condition is clamped or nudged or whose
+// ubar / vbar condition is Flather or Shchepetkin (inp_decode.F:1620-1655, no FSOBC_REDUCED)
+static void bc_acquire(BcArgs &a)
+{
+  for (int sd = 0; sd < 4; sd++) {
+    const int zc = lbc_code(g_ctx.p, sd, LBV_ZETA), uc = lbc_code(g_ctx.p, sd, LBV_UBAR), vc = lbc_code(g_ctx.p, sd, LBV_VBAR);
+    a.acquire[sd] = zc == LBC_CLAMPED || zc == LBC_RADIATION_NUDGING || uc == LBC_FLATHER || uc == LBC_SHCHEPETKIN ||
+                    vc == LBC_FLATHER || vc == LBC_SHCHEPETKIN;
+  }
+}
+
 static bool needs_know(const BcArgs &a)
 {
   for (int sd = 0; sd < 4; sd++)
     if (a.code[sd] == LBC_RADIATION || a.code[sd] == LBC_RADIATION_NUDGING || a.code[sd] == LBC_FLATHER ||
-        a.code[sd] == LBC_CHAPMAN_IMPLICIT || a.code[sd] == LBC_CHAPMAN_EXPLICIT || a.code[sd] == LBC_SHCHEPETKIN)
+        a.code[sd] == LBC_CHAPMAN_IMPLICIT || a.code[sd] == LBC_CHAPMAN_EXPLICIT || a.code[sd] == LBC_SHCHEPETKIN ||
+        a.code[sd] == LBC_REDUCED)
       return true;
   return false;
 }
@@ -322,6 +349,8 @@ int bc_u2d(int kout, const roms_step_idx_t *s)
   a.Z = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
   a.Zb = g_ctx.dev[FID_zeta_bry];
   a.Zn = g_ctx.dev[FID_zeta] + (long)(kout - 1) * nij_host();
+  a.T = g_ctx.dev[FID_vbar] + (long)(know - 1) * nij_host();
+  bc_acquire(a);
   a.dt2d = dt2d;
   return edge_bc(a);
 }
@@ -336,6 +365,8 @@ int bc_v2d(int kout, const roms_step_idx_t *s)
   a.Zn = g_ctx.dev[FID_zeta] + (long)(kout - 1) * nij_host();
   a.Z = g_ctx.dev[FID_zeta] + (long)(know - 1) * nij_host();
   a.Zb = g_ctx.dev[FID_zeta_bry];
+  a.T = g_ctx.dev[FID_ubar] + (long)(know - 1) * nij_host();
+  bc_acquire(a);
   a.dt2d = dt2d;
   return edge_bc(a);
 }

@@ -18,8 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
 
 CONFIGS = [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)]
-TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Che", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]),
-         "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
+TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Che", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Red", "RedAcq", "Rad", "RadNud"]),
+         "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Red", "RedAcq", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
          "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad", "RadNud"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad", "RadNud"])}
 
 
@@ -58,7 +58,9 @@ def cases(st0):
                 st = st0.copy()
                 st.p = type(st0.p).from_buffer_copy(st0.p)
                 for sd in ("south", "north"):
-                    st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+                    st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC["Red" if code == "RedAcq" else code]
+                    if code == "RedAcq":         # reduced physics with free-surface boundary data (zeta clamped)
+                        st.p.lbc[abi.LBS[sd]][abi.LBV["zeta"]] = abi.LBC["Cla"]
                     st.p.obc_out[abi.LBS[sd]][abi.LBV[var]] = 2.0e-4          # RadNud: passive / active nudging (1/s)
                     st.p.obc_in[abi.LBS[sd]][abi.LBV[var]] = 1.5e-3
                 nout = s.knew if kind in ("zetabc", "u2dbc", "v2dbc") else s.nnew

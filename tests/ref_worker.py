@@ -158,8 +158,8 @@ def main_bc(config, mask=None, rad2d=False):
             row = a[:, j - b.LBj]
             row += 1.0e-3 * (1.0 + np.abs(row)) * rng.standard_normal(row.shape)
     out = {"masking": int(st0.p.masking), "cases": {}}
-    table = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Che", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]),
-             "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
+    table = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Che", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Red", "RedAcq", "Rad", "RadNud"]),
+             "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Red", "RedAcq", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
              "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad", "RadNud"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad", "RadNud"])}
     steps = [util.step_idx(iic=5, iif=1, pred=1, kstp=1, krhs=1, knew=3), util.step_idx(iic=5, iif=3, pred=1, kstp=2, krhs=1, knew=3),
              util.step_idx(iic=5, iif=3, pred=0, kstp=1, krhs=3, knew=2)]
@@ -170,7 +170,9 @@ def main_bc(config, mask=None, rad2d=False):
                 for st in (st_r, st_o):
                     st.p = type(st0.p).from_buffer_copy(st0.p)
                     for sd in ("south", "north"):
-                        st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+                        st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC["Red" if code == "RedAcq" else code]
+                        if code == "RedAcq":     # reduced physics with free-surface boundary data (zeta clamped)
+                            st.p.lbc[abi.LBS[sd]][abi.LBV["zeta"]] = abi.LBC["Cla"]
                         st.p.obc_out[abi.LBS[sd]][abi.LBV[var]] = 2.0e-4      # RadNud: passive / active nudging (1/s)
                         st.p.obc_in[abi.LBS[sd]][abi.LBV[var]] = 1.5e-3
                 nout = s.knew if kind in ("zetabc", "u2dbc", "v2dbc") else s.nnew
@@ -206,8 +208,8 @@ def basin_state(config, mask=None):
     return st0
 
 
-BC_TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Che", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]),
-            "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
+BC_TABLE = {"zetabc": ("zeta", ["Clo", "Gra", "Cla", "Cha", "Che", "Rad", "RadNud"]), "u2dbc": ("ubar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Red", "RedAcq", "Rad", "RadNud"]),
+            "v2dbc": ("vbar", ["Clo", "Gra", "Cla", "Fla", "Shc", "Red", "RedAcq", "Rad", "RadNud"]), "u3dbc": ("u", ["Clo", "Gra", "Cla", "Rad", "RadNud"]),
             "v3dbc": ("v", ["Clo", "Gra", "Cla", "Rad", "RadNud"]), "t3dbc": ("t", ["Clo", "Gra", "Cla", "Rad", "RadNud"])}
 
 
@@ -224,7 +226,9 @@ def basin_cases(st0):
                 st = st0.copy()
                 st.p = type(st0.p).from_buffer_copy(st0.p)
                 for sd in ("west", "east", "south", "north"):
-                    st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC[code]
+                    st.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC["Red" if code == "RedAcq" else code]
+                    if code == "RedAcq":
+                        st.p.lbc[abi.LBS[sd]][abi.LBV["zeta"]] = abi.LBC["Cla"]
                     st.p.obc_out[abi.LBS[sd]][abi.LBV[var]] = 2.0e-4          # RadNud: passive / active nudging (1/s)
                     st.p.obc_in[abi.LBS[sd]][abi.LBV[var]] = 1.5e-3
                 nout = s.knew if kind in ("zetabc", "u2dbc", "v2dbc") else s.nnew

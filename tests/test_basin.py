@@ -22,7 +22,10 @@ OPEN = {"zeta": "Cha", "ubar": "Fla", "vbar": "Fla", "u": "Rad", "v": "Rad", "t"
 # 2-D ones as well, so that every routine's nudging branch runs)
 RADNUD = {v: "RadNud" for v in OPEN}
 CHE_SHC = {"zeta": "Che", "ubar": "Shc", "vbar": "Shc", "u": "Rad", "v": "Rad", "t": "Rad"}
-TABLES = {True: OPEN, "radnud": RADNUD, "che_shc": CHE_SHC}
+# reduced physics for the barotropic velocity with a clamped free surface (its boundary data give the pressure gradient)
+CLA_RED = {"zeta": "Cla", "ubar": "Red", "vbar": "Red", "u": "Rad", "v": "Rad", "t": "Rad"}
+CHA_RED = {"zeta": "Cha", "ubar": "Red", "vbar": "Red", "u": "Gra", "v": "Gra", "t": "Gra"}
+TABLES = {True: OPEN, "radnud": RADNUD, "che_shc": CHE_SHC, "cla_red": CLA_RED, "cha_red": CHA_RED}
 
 
 def _open_all(st, table=OPEN):
@@ -57,7 +60,8 @@ def _state(config, kernel, open_edges):
 
 
 @pytest.mark.parametrize("config", CONFIGS)
-@pytest.mark.parametrize("open_edges", [False, True, "radnud", "che_shc"], ids=["closed", "open", "radnud", "che_shc"])
+@pytest.mark.parametrize("open_edges", [False, True, "radnud", "che_shc", "cla_red", "cha_red"],
+                         ids=["closed", "open", "radnud", "che_shc", "cla_red", "cha_red"])
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_hip_kernels_on_a_basin(config, kernel, open_edges):
     import oracle

@@ -161,7 +161,7 @@ def test_hip_reproduces_masked_reference_vectors(config):
 
 @pytest.mark.parametrize("config,mask", [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)])
 def test_oracle_reproduces_reference_boundary_conditions(config, mask):
-    """The boundary rows the reference's zetabc / u2dbc / v2dbc / u3dbc / v3dbc / t3dbc _tile left (78 cases:
+    """The boundary rows the reference's zetabc / u2dbc / v2dbc / u3dbc / v3dbc / t3dbc _tile left (90 cases:
     closed, gradient, clamped, Chapman implicit, Flather, radiation; tests/golden/make_golden_bc.py) vs the oracle."""
     import importlib.util
     import sys
@@ -181,7 +181,7 @@ def test_oracle_reproduces_reference_boundary_conditions(config, mask):
         oracle.Oracle(st).bc(kind, s, nout, itrc)
         assert np.array_equal(mg.rows(st, var), g[key]), key
         n += 1
-    assert n == 78
+    assert n == 90
 
 
 @pytest.mark.parametrize("config,mask", [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)])
@@ -423,7 +423,7 @@ def test_oracle_reproduces_reference_boundary_conditions_on_a_basin(config, mask
         assert np.array_equal(cols, g[k + "__cols"]) and np.array_equal(rows, g[k + "__rows"]), key
         assert sha == str(g[k + "__sha256"]), key
         n += 1
-    assert n == 78
+    assert n == 90
 
 
 @pytest.mark.parametrize("mask", [None, "island"])
