@@ -117,6 +117,8 @@ typedef struct roms_params {
   double weight1[ROMS_MAXFAST];      /* weight(1,1:2*ndtfast,ng)             */
   double weight2[ROMS_MAXFAST];      /* weight(2,1:2*ndtfast,ng)             */
   int    Vtransform;                 /* set_depth.F:82                       */
+  int    limit_bstress;              /* LIMIT_BSTRESS: the bottom stress may only slow the bottom velocity down to zero
+                                      * within a step, set_vbc.F:533-540, :562-567 (sits in the alignment gap before hc) */
   double hc;
   double sc_r[ROMS_MAXN + 1], Cs_r[ROMS_MAXN + 1];   /* index 1..N           */
   double sc_w[ROMS_MAXN + 1], Cs_w[ROMS_MAXN + 1];   /* index 0..N           */

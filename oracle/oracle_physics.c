@@ -76,6 +76,21 @@ int oracle_set_vbc(OARGS)
     free(wrk_);
 #undef wrk
   } else return 8;
+  if (p->limit_bstress) {           /* LIMIT_BSTRESS, :533-540 and the same four lines after each law (:562-567 ...) */
+    const double cff = 0.75 / p->dt;
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = IstrU; i <= Iend; i++) {
+        const double cff3 = cff * 0.5 * (Hz(i - 1, j, 1) + Hz(i, j, 1));
+        const double bs = F->bustr[I2(i, j)];
+        F->bustr[I2(i, j)] = copysign(1.0, bs) * MIN(fabs(bs), fabs(u(i, j, 1, nrhs)) * cff3);
+      }
+    for (int j = JstrV; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        const double cff3 = cff * 0.5 * (Hz(i, j - 1, 1) + Hz(i, j, 1));
+        const double bs = F->bvstr[I2(i, j)];
+        F->bvstr[I2(i, j)] = copysign(1.0, bs) * MIN(fabs(bs), fabs(v(i, j, 1, nrhs)) * cff3);
+      }
+  }
   /* boundary conditions + periodic / tile exchange, :472-500 */
   /* bc_u2d_tile / bc_v2d_tile with isBu2d = isUbar, isBv2d = isVbar (bc_2d.F:184, :386; mod_ncparam.F:1229) */
   o_bc_generic(b, p, F, GT_U, LBV_UBAR, F->bustr, 1);

@@ -33,7 +33,7 @@ MODULE ref_wrap_types
     REAL(c_double) :: dt, dtfast, g, rho0, gamma2, lambda
     INTEGER(c_int) :: ndtfast, nfast
     REAL(c_double) :: weight1(256), weight2(256)
-    INTEGER(c_int) :: Vtransform
+    INTEGER(c_int) :: Vtransform, limit_bstress
     REAL(c_double) :: hc
     REAL(c_double) :: sc_r(65), Cs_r(65), sc_w(65), Cs_w(65)
     INTEGER(c_int) :: Hadv(16), Vadv(16)

@@ -80,7 +80,7 @@ class Params(C.Structure):
         ("ndtfast", C.c_int), ("nfast", C.c_int),
         ("weight1", C.c_double * ROMS_MAXFAST),
         ("weight2", C.c_double * ROMS_MAXFAST),
-        ("Vtransform", C.c_int),
+        ("Vtransform", C.c_int), ("limit_bstress", C.c_int),
         ("hc", C.c_double),
         ("sc_r", C.c_double * (ROMS_MAXN + 1)), ("Cs_r", C.c_double * (ROMS_MAXN + 1)),
         ("sc_w", C.c_double * (ROMS_MAXN + 1)), ("Cs_w", C.c_double * (ROMS_MAXN + 1)),

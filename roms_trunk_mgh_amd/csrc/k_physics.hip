@@ -37,12 +37,24 @@ k_set_vbc(const RomsDev *__restrict__ c, int nrhs)
   // bottom stress, :380-470 (k = 1 is the first plane of u, v)
   const bool on_u = i >= b.IstrU && i <= b.Iend && j >= b.Jstr && j <= b.Jend;
   const bool on_v = i >= b.Istr && i <= b.Iend && j >= b.JstrV && j <= b.Jend;
+  // LIMIT_BSTRESS, set_vbc.F:533-540, :562-567: the stress may only slow the bottom velocity down to zero within a step
+  const gcd_t Hz1 = (gcd_t)c->F.Hz;
+  auto lim_u = [&](double bs) {
+    if (!p.limit_bstress) return bs;
+    const double cff3 = (0.75 / p.dt) * 0.5 * (Hz1[a - 1] + Hz1[a]);
+    return copysign(1.0, bs) * fmin(fabs(bs), fabs(u[a]) * cff3);
+  };
+  auto lim_v = [&](double bs) {
+    if (!p.limit_bstress) return bs;
+    const double cff3 = (0.75 / p.dt) * 0.5 * (Hz1[a - ni] + Hz1[a]);
+    return copysign(1.0, bs) * fmin(fabs(bs), fabs(v[a]) * cff3);
+  };
   if (p.uv_drag == 2) {
     const gcd_t r2 = (gcd_t)(c->F.rdrag2);
     if (on_u) {
       const double cff1 = 0.25 * (v[a] + v[a + ni] + v[a - 1] + v[a - 1 + ni]);
       const double cff2 = sqrt(u[a] * u[a] + cff1 * cff1);
-      const double bu = 0.5 * (r2[a - 1] + r2[a]) * u[a] * cff2;
+      const double bu = lim_u(0.5 * (r2[a - 1] + r2[a]) * u[a] * cff2);
       GF(bustr)[a] = bu;
       if (b.south_edge && !b.NSperiodic && j == b.Jstr) GF(bustr)[a - ni] = p.gamma2 * bu;   // bc_u2d_tile
       if (b.north_edge && !b.NSperiodic && j == b.Jend) GF(bustr)[a + ni] = p.gamma2 * bu;
@@ -50,7 +62,7 @@ k_set_vbc(const RomsDev *__restrict__ c, int nrhs)
     if (on_v) {
       const double cff1 = 0.25 * (u[a] + u[a + 1] + u[a - ni] + u[a + 1 - ni]);
       const double cff2 = sqrt(cff1 * cff1 + v[a] * v[a]);
-      GF(bvstr)[a] = 0.5 * (r2[a - ni] + r2[a]) * v[a] * cff2;
+      GF(bvstr)[a] = lim_v(0.5 * (r2[a - ni] + r2[a]) * v[a] * cff2);
     }
   } else if (p.uv_drag == 3) {      // UV_LOGDRAG, set_vbc.F:542-580
     const gcd_t zr = (gcd_t)c->F.z_r, zw = (gcd_t)c->F.z_w, zo = (gcd_t)c->F.ZoBot;
@@ -63,7 +75,7 @@ k_set_vbc(const RomsDev *__restrict__ c, int nrhs)
     if (on_u) {
       const double cff1 = 0.25 * (v[a] + v[a + ni] + v[a - 1] + v[a - 1 + ni]);
       const double cff2 = sqrt(u[a] * u[a] + cff1 * cff1);
-      const double bu = 0.5 * (cd(a - 1) + cd(a)) * u[a] * cff2;
+      const double bu = lim_u(0.5 * (cd(a - 1) + cd(a)) * u[a] * cff2);
       GF(bustr)[a] = bu;
       if (b.south_edge && !b.NSperiodic && j == b.Jstr) GF(bustr)[a - ni] = p.gamma2 * bu;   // bc_u2d_tile
       if (b.north_edge && !b.NSperiodic && j == b.Jend) GF(bustr)[a + ni] = p.gamma2 * bu;
@@ -71,17 +83,17 @@ k_set_vbc(const RomsDev *__restrict__ c, int nrhs)
     if (on_v) {
       const double cff1 = 0.25 * (u[a] + u[a + 1] + u[a - ni] + u[a + 1 - ni]);
       const double cff2 = sqrt(cff1 * cff1 + v[a] * v[a]);
-      GF(bvstr)[a] = 0.5 * (cd(a - ni) + cd(a)) * v[a] * cff2;
+      GF(bvstr)[a] = lim_v(0.5 * (cd(a - ni) + cd(a)) * v[a] * cff2);
     }
   } else {
     const gcd_t r1 = (gcd_t)(c->F.rdrag);
     if (on_u) {
-      const double bu = 0.5 * (r1[a - 1] + r1[a]) * u[a];
+      const double bu = lim_u(0.5 * (r1[a - 1] + r1[a]) * u[a]);
       GF(bustr)[a] = bu;
       if (b.south_edge && !b.NSperiodic && j == b.Jstr) GF(bustr)[a - ni] = p.gamma2 * bu;
       if (b.north_edge && !b.NSperiodic && j == b.Jend) GF(bustr)[a + ni] = p.gamma2 * bu;
     }
-    if (on_v) GF(bvstr)[a] = 0.5 * (r1[a - ni] + r1[a]) * v[a];
+    if (on_v) GF(bvstr)[a] = lim_v(0.5 * (r1[a - ni] + r1[a]) * v[a]);
   }
   // bc_v2d_tile, closed walls: normal component zero on the wall rows
   if (i >= b.Istr && i <= b.Iend && !b.NSperiodic) {

@@ -369,6 +369,30 @@ def logdrag_state(config="UPWELLING"):
     return st
 
 
+def main_limbs(config):
+    """set_vbc with LIMIT_BSTRESS (set_vbc.F:533-567; the application built with -DLIMIT_BSTRESS): a strong drag so
+    that the limit is reached at part of the points."""
+    import oracle
+    import util
+    from oracle import ref
+    st0 = util.prepared_state(config, overrides={"limit_bstress": 1})
+    st0["rdrag"] *= 25.0 * (1.0 + 3.0 * np.linspace(0.0, 1.0, st0["rdrag"].shape[0]))[:, None]
+    st0["rdrag2"] *= 4000.0
+    s = util.step_idx()
+    st_r, st_o, st_n = st0.copy(), st0.copy(), st0.copy()
+    st_n.p = type(st0.p).from_buffer_copy(st0.p)
+    st_n.p.limit_bstress = 0
+    ref.Ref(st_r).physics("set_vbc", s)
+    oracle.Oracle(st_o).call("set_vbc", s)
+    oracle.Oracle(st_n).call("set_vbc", s)
+    names = ["bustr", "bvstr"]
+    out = {"set_vbc": {"diffs": {n: util.max_rel_diff(st_o[n], st_r[n]) for n in names},
+                       "changed": [n for n in names if not np.array_equal(st_r[n], st0[n])]},
+           "frac_limited": float((st_o.interior("bustr") != st_n.interior("bustr")).mean())}
+    out["set_vbc"]["max_rel_diff"] = max(out["set_vbc"]["diffs"].values())
+    print(json.dumps(out))
+
+
 def main_logdrag(config):
     """set_vbc with UV_LOGDRAG (set_vbc.F:542-580): reference Fortran (UPWELLING with UV_LOGDRAG in the place of
     UV_LDRAG) vs C oracle; LOG comes from two math libraries, the relative difference is reported."""
@@ -570,6 +594,8 @@ if __name__ == "__main__":
                      basin=sys.argv[2] == "physics_basin")
     elif len(sys.argv) > 2 and sys.argv[2] == "basin":
         main(sys.argv[1], basin=True)
+    elif len(sys.argv) > 2 and sys.argv[2] == "limbs":
+        main_limbs(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "logdrag":
         main_logdrag(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] in ("iso", "iso_closed", "iso_open", "iso_mask", "iso_mask_open"):

@@ -405,3 +405,31 @@ def test_set_vbc_log_layer_drag():
     for n in ("bustr", "bvstr", "stflx", "btflx"):
         assert util.max_rel_diff(st_h[n], st_o[n]) <= 1e-14, n
     assert util.max_rel_diff(st_o["bustr"], st0["bustr"]) > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,drag", [("UPWELLING", 1), ("BENCHMARK_TINY", 2), ("UPWELLING", 3)])
+def test_set_vbc_limited_bottom_stress(config, drag):
+    """LIMIT_BSTRESS (roms_params_t.limit_bstress) with each of the three drag laws: HIP vs oracle."""
+    import oracle
+    from roms_trunk_mgh_amd import hip
+    st0 = util.prepared_state(config, overrides={"limit_bstress": 1, "uv_drag": drag})
+    st0["rdrag"] *= 60.0
+    st0["rdrag2"] *= 4000.0
+    st0["ZoBot"][:] = 0.6 * (st0["z_r"][:, :, 0] - st0["z_w"][:, :, 0])
+    st_o, st_h = st0.copy(), st0.copy()
+    s = util.step_idx()
+    oracle.Oracle(st_o).call("set_vbc", s)
+    h = hip.RomsHip(st_h)
+    try:
+        h.call("set_vbc", s)
+        h.to_host()
+    finally:
+        h.close()
+    for n in ("bustr", "bvstr"):
+        assert util.max_rel_diff(st_h[n], st_o[n]) <= (1e-14 if drag == 3 else 0.0), n
+    st_n = st0.copy()
+    st_n.p = type(st0.p).from_buffer_copy(st0.p)
+    st_n.p.limit_bstress = 0
+    oracle.Oracle(st_n).call("set_vbc", s)
+    assert util.max_rel_diff(st_n["bustr"], st_o["bustr"]) > 1e-3        # the limit is reached somewhere
