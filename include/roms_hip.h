@@ -126,6 +126,8 @@ typedef struct roms_params {
   int    lbc_west, lbc_east, lbc_south, lbc_north;   /* enum roms_lbc        */
   /* equation of state */
   int    nonlin_eos;                 /* 1 = NONLIN_EOS (rho_eos.F:111)       */
+  int    eminusp;                    /* EMINUSP: bulk_flux also sets evap = LHeat / Hlv and the surface salt flux
+                                      * stflux(isalt) = (evap - rain) / rhow, bulk_flux.F:883-899 (alignment gap before R0) */
   double R0, T0, S0, Tcoef, Scoef;   /* linear EOS (rho_eos.F:576)           */
   /* CPP-derived option switches of the application header */
   int    uv_adv, uv_cor, uv_vis2, curvgrid, var_rho_2d;

@@ -138,7 +138,7 @@ int oracle_bulk_flux(OARGS)
 {
   ORACLE_PROLOGUE
   if (o_check_lbc(b, p)) return 8;
-  const int nrhs = s->nrhs, itemp = 1, IterMax = 3, mk = p->masking;
+  const int nrhs = s->nrhs, itemp = 1, isalt = 2, IterMax = 3, mk = p->masking;
   /* mod_scalars.F:431-444, :1415-1421 */
   const double Cp = 3985.0, StefBo = 5.67E-8, emmiss = 0.97, rhow = 1000.0, vonKar = 0.41;
   const double blk_Cpa = 1004.67, blk_Cpw = 4000.0, blk_Rgas = 287.1, blk_Zabl = 600.0, blk_beta = 1.2;
@@ -148,6 +148,7 @@ int oracle_bulk_flux(OARGS)
   const double eps = 1.0E-20, r3 = 1.0 / 3.0;
   (void)rhow;
   double *Taux_ = walloc(nis * njs), *Tauy_ = walloc(nis * njs), *LHeat_ = walloc(nis * njs);
+  double *Hlv_ = walloc(nis * njs);                                    /* (the reference keeps Hlv(i,j) too, :175) */
   double *SHeat_ = walloc(nis * njs), *LRad_ = walloc(nis * njs);
 #define Taux(i,j)  Taux_[WS2(i,j)]
 #define Tauy(i,j)  Tauy_[WS2(i,j)]
@@ -190,6 +191,7 @@ int oracle_bulk_flux(OARGS)
       const double rhoAir = PairM * 100.0 / (blk_Rgas * TairK * (1.0 + 0.61 * Q));
       const double VisAir = 1.326E-5 * (1.0 + TairC * (6.542E-3 + TairC * (8.301E-6 - 4.84E-9 * TairC)));
       const double Hlv = (2.501 - 0.00237 * TseaC) * 1.0E+6;
+      Hlv_[WS2(i, j)] = Hlv;
       /* first guesses, :536-600 */
       double Wgus = 0.5;
       double delW = sqrt(Wmag * Wmag + Wgus * Wgus);
@@ -271,6 +273,13 @@ int oracle_bulk_flux(OARGS)
       shflx(i, j) = -SHeat(i, j) * Hscale;
       stflux(i, j, itemp) = (srflx(i, j) + lrflx(i, j) + lhflx(i, j) + shflx(i, j));
       if (mk) stflux(i, j, itemp) = stflux(i, j, itemp) * rmask(i, j);        /* :877 */
+      if (p->eminusp) {                                                       /* EMINUSP, :883-899 */
+        const double cffw = 1.0 / rhow;
+        F->evap[I2(i, j)] = LHeat(i, j) / Hlv_[WS2(i, j)];
+        if (mk) F->evap[I2(i, j)] = F->evap[I2(i, j)] * rmask(i, j);
+        stflux(i, j, isalt) = cffw * (F->evap[I2(i, j)] - rain(i, j));
+        if (mk) stflux(i, j, isalt) = stflux(i, j, isalt) * rmask(i, j);
+      }
     }
   const double cffs = 0.5 / rho0;
   for (int j = JstrR; j <= JendR; j++)
@@ -287,9 +296,13 @@ int oracle_bulk_flux(OARGS)
   o_exchange2d(b, GT_R, F->lhflx);
   o_exchange2d(b, GT_R, F->shflx);
   o_exchange2d(b, GT_R, &stflux(LBi, LBj, itemp));
+  if (p->eminusp) {                                                     /* bulk_flux.F:945-952 */
+    o_exchange2d(b, GT_R, F->evap);
+    o_exchange2d(b, GT_R, &stflux(LBi, LBj, isalt));
+  }
   o_exchange2d(b, GT_U, F->sustr);
   o_exchange2d(b, GT_V, F->svstr);
-  free(Taux_); free(Tauy_); free(LHeat_); free(SHeat_); free(LRad_);
+  free(Taux_); free(Tauy_); free(LHeat_); free(SHeat_); free(LRad_); free(Hlv_);
   return 0;
 }
 

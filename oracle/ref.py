@@ -30,6 +30,8 @@ class Ref:
             app += "_ISO"                                                  # ... and MIX_ISO_TS as the tracer mixing choice
         elif state.p.ts_dif4 or state.p.uv_vis4:
             app += "_DIF4"                                                 # built with TS_DIF4 and UV_VIS4 added
+        if state.p.eminusp:
+            app += "_EMP"                                                  # built with -DEMINUSP
         if state.p.limit_bstress:
             app += "_LIMBS"                                                # built with -DLIMIT_BSTRESS
         if state.p.radiation_2d:

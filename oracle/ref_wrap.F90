@@ -38,7 +38,7 @@ MODULE ref_wrap_types
     REAL(c_double) :: sc_r(65), Cs_r(65), sc_w(65), Cs_w(65)
     INTEGER(c_int) :: Hadv(16), Vadv(16)
     INTEGER(c_int) :: lbc_west, lbc_east, lbc_south, lbc_north
-    INTEGER(c_int) :: nonlin_eos
+    INTEGER(c_int) :: nonlin_eos, eminusp
     REAL(c_double) :: R0, T0, S0, Tcoef, Scoef
     INTEGER(c_int) :: uv_adv, uv_cor, uv_vis2, curvgrid, var_rho_2d
     INTEGER(c_int) :: ts_dif2, mix_geo_ts, mix_s_ts, salinity, lmd_nonlocal, solar_source
@@ -537,6 +537,9 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   CALL c_f_pointer (F%lrflx, a2, (/ni,nj/));    a2 = FORCES(ng)%lrflx
   CALL c_f_pointer (F%lhflx, a2, (/ni,nj/));    a2 = FORCES(ng)%lhflx
   CALL c_f_pointer (F%shflx, a2, (/ni,nj/));    a2 = FORCES(ng)%shflx
+#ifdef EMINUSP
+  CALL c_f_pointer (F%evap, a2, (/ni,nj/));     a2 = FORCES(ng)%evap
+#endif
   CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akv
   CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/));   a4 = MIXING(ng)%Akt
   CALL c_f_pointer (F%ghats, a4, (/ni,nj,NN+1,INT(b%NAT)/)); a4 = MIXING(ng)%ghats

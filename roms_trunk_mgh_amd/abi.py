@@ -87,7 +87,7 @@ class Params(C.Structure):
         ("Hadv", C.c_int * ROMS_MAXNT), ("Vadv", C.c_int * ROMS_MAXNT),
         ("lbc_west", C.c_int), ("lbc_east", C.c_int),
         ("lbc_south", C.c_int), ("lbc_north", C.c_int),
-        ("nonlin_eos", C.c_int),
+        ("nonlin_eos", C.c_int), ("eminusp", C.c_int),
         ("R0", C.c_double), ("T0", C.c_double), ("S0", C.c_double),
         ("Tcoef", C.c_double), ("Scoef", C.c_double),
         ("uv_adv", C.c_int), ("uv_cor", C.c_int), ("uv_vis2", C.c_int),

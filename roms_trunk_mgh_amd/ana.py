@@ -214,6 +214,7 @@ def make_params(cfg, NT):
     # set_vbc.F: BENCHMARK and SEAMOUNT have UV_QDRAG (rdrg2 = 3.0d-03), UPWELLING UV_LDRAG (rdrg = 3.0d-04)
     p.uv_drag = int(cfg.get("uv_drag", 1 if cfg["app"] == "UPWELLING" else 2))      # 3 = UV_LOGDRAG
     p.limit_bstress = int(cfg.get("limit_bstress", 0))
+    p.eminusp = int(cfg.get("eminusp", 0))
     p.Cdb_min, p.Cdb_max = 1.0e-6, 0.5                                  # mod_scalars.F:747-748
     p.blk_ZQ = p.blk_ZT = p.blk_ZW = 10.0       # roms_*.in:382-384
     return p

@@ -264,6 +264,15 @@ k_bulk_flux(const RomsDev *__restrict__ c, int nrhs, double *__restrict__ Taux, 
     double stf = (GF(srflx)[a] + lr + lh + sh);
     if (masking) stf = stf * mr;
     GF(stflux)[a] = stf;
+    if (p.eminusp) {                               // EMINUSP, bulk_flux.F:883-899 (rhow = 1000, mod_scalars.F:437)
+      const double cffw = 1.0 / 1000.0;
+      double ev = LHeat / Hlv;
+      if (masking) ev = ev * mr;
+      GF(evap)[a] = ev;
+      double sf = cffw * (ev - rn);
+      if (masking) sf = sf * mr;
+      GF(stflux)[a + nij] = sf;
+    }
   }
 }
 
@@ -384,6 +393,10 @@ extern "C" int roms_hip_bulk_flux(const roms_step_idx_t *s)
   halo_exchange2d(GT_R, g_ctx.dev[FID_lhflx]);
   halo_exchange2d(GT_R, g_ctx.dev[FID_shflx]);
   halo_exchange2d(GT_R, g_ctx.dev[FID_stflux]);        // first plane = itemp
+  if (g_ctx.p.eminusp) {                               // bulk_flux.F:945-952
+    halo_exchange2d(GT_R, g_ctx.dev[FID_evap]);
+    halo_exchange2d(GT_R, g_ctx.dev[FID_stflux] + (long)(g_ctx.b.UBi - g_ctx.b.LBi + 1) * (g_ctx.b.UBj - g_ctx.b.LBj + 1));
+  }
   halo_exchange2d(GT_U, g_ctx.dev[FID_sustr]);
   halo_exchange2d(GT_V, g_ctx.dev[FID_svstr]);
   return halo_batch_end();

@@ -59,7 +59,7 @@ MODULE roms_hip_mod
     REAL(c_double) :: sc_r(65), Cs_r(65), sc_w(65), Cs_w(65)
     INTEGER(c_int) :: Hadv(16), Vadv(16)
     INTEGER(c_int) :: lbc_west, lbc_east, lbc_south, lbc_north
-    INTEGER(c_int) :: nonlin_eos
+    INTEGER(c_int) :: nonlin_eos, eminusp
     REAL(c_double) :: R0, T0, S0, Tcoef, Scoef
     INTEGER(c_int) :: uv_adv, uv_cor, uv_vis2, curvgrid, var_rho_2d
     INTEGER(c_int) :: ts_dif2, mix_geo_ts, mix_s_ts, salinity, lmd_nonlocal, solar_source

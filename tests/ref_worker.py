@@ -369,6 +369,27 @@ def logdrag_state(config="UPWELLING"):
     return st
 
 
+def main_emp(config, mask=None):
+    """bulk_flux with EMINUSP (bulk_flux.F:883-899; BENCHMARK built with -DEMINUSP): evap and the surface salt flux."""
+    import oracle
+    import util
+    from oracle import ref
+    st0 = util.prepared_state(config, overrides={"eminusp": 1}, mask=mask)
+    st0["rain"] += 2.0e-5
+    s = util.step_idx()
+    st_r, st_o = st0.copy(), st0.copy()
+    ref.Ref(st_r).physics("bulk_flux", s)
+    oracle.Oracle(st_o).call("bulk_flux", s)
+    names = ["evap", "stflux", "lhflx", "sustr"]
+    out = {"masking": int(st0.p.masking),
+           "bulk_flux": {"diffs": {n: util.max_rel_diff(st_o[n], st_r[n]) for n in names},
+                         "changed": [n for n in names if not np.array_equal(st_r[n], st0[n])],
+                         "amax_evap": float(np.abs(st_r["evap"]).max()),
+                         "amax_saltflux": float(np.abs(st_r["stflux"][:, :, 1]).max())}}
+    out["bulk_flux"]["max_rel_diff"] = max(out["bulk_flux"]["diffs"].values())
+    print(json.dumps(out))
+
+
 def main_limbs(config):
     """set_vbc with LIMIT_BSTRESS (set_vbc.F:533-567; the application built with -DLIMIT_BSTRESS): a strong drag so
     that the limit is reached at part of the points."""
@@ -594,6 +615,8 @@ if __name__ == "__main__":
                      basin=sys.argv[2] == "physics_basin")
     elif len(sys.argv) > 2 and sys.argv[2] == "basin":
         main(sys.argv[1], basin=True)
+    elif len(sys.argv) > 2 and sys.argv[2] in ("emp", "emp_mask"):
+        main_emp(sys.argv[1], mask="island" if sys.argv[2] == "emp_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] == "limbs":
         main_limbs(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "logdrag":

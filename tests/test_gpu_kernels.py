@@ -433,3 +433,24 @@ def test_set_vbc_limited_bottom_stress(config, drag):
     st_n.p.limit_bstress = 0
     oracle.Oracle(st_n).call("set_vbc", s)
     assert util.max_rel_diff(st_n["bustr"], st_o["bustr"]) > 1e-3        # the limit is reached somewhere
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mask", [None, "island"])
+def test_bulk_flux_eminusp(mask):
+    """EMINUSP (roms_params_t.eminusp): evap and the surface salt flux of bulk_flux.F:883-899, with their exchanges."""
+    import oracle
+    st0 = util.prepared_state("BENCHMARK_TINY", overrides={"eminusp": 1}, mask=mask)
+    st0["rain"] += 2.0e-5
+    st_o, st_h = st0.copy(), st0.copy()
+    s = util.step_idx()
+    oracle.Oracle(st_o).call("bulk_flux", s)
+    h = hip.RomsHip(st_h)
+    try:
+        h.call("bulk_flux", s)
+        h.to_host()
+    finally:
+        h.close()
+    diffs = util.compare_states(st_h, st_o)
+    assert all(v <= 1e-11 for v in diffs.values()), diffs
+    assert float(np.abs(st_o["evap"]).max()) > 1e-6 and util.max_rel_diff(st_o["stflux"][:, :, 1], st0["stflux"][:, :, 1]) > 1e-6
