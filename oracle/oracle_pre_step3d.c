@@ -21,7 +21,7 @@ int oracle_pre_step3d(OARGS)
     if (ha == ADV_SPLINES) return 8;
     if (va == ADV_U3) return 8;
     /* the reference lets H and V differ; MPDATA and HSIMT are restated as H+V pairs only */
-    if ((ha == ADV_HSIMT) != (va == ADV_HSIMT)) return 8;
+    if (ha == ADV_HSIMT && va != ADV_HSIMT) return 8;
     if ((ha == ADV_MPDATA) != (va == ADV_MPDATA)) return 8;
   }
   double *CF_ = walloc(nis * (N + 1)), *DC_ = walloc(nis * (N + 1)), *FC_ = walloc(nis * (N + 1));

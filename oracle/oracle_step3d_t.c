@@ -24,7 +24,9 @@ int oracle_step3d_t(OARGS)
     int ha = p->Hadv[itrc - 1], va = p->Vadv[itrc - 1];
     if (ha == ADV_SPLINES) return 8;
     if (va == ADV_U3) return 8;
-    if ((ha == ADV_HSIMT) != (va == ADV_HSIMT)) return 8;   /* restated as an H+V pair, like MPDATA */
+    /* HSIMT horizontally alone reads oHz at halo points the reference has not computed (Lhsimt needs both directions,
+     * step3d_t.F:304-305, :340-360, :445); HSIMT vertically with another horizontal scheme is a working pair */
+    if (ha == ADV_HSIMT && va != ADV_HSIMT) return 8;
     if (ha == ADV_HSIMT) Lhsimt = 1;
     /* the reference lets H and V differ; only the pair MPDATA/MPDATA is restated */
     if ((ha == ADV_MPDATA) != (va == ADV_MPDATA)) return 8;

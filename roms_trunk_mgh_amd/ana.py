@@ -385,7 +385,7 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
         cfg.update(overrides)
     NAT = cfg["NAT"]
     NT = NT or NAT
-    adv = {cfg["Hadv"], cfg["Vadv"]} | set(cfg.get("Hadv_list", [])) | set(cfg.get("Vadv_list", []))
+    adv = {cfg["Hadv"]} | set(cfg.get("Hadv_list", []))        # the horizontal schemes decide (inp_par.F:264-267)
     nghost = 3 if (adv & {"MPDATA", "HSIMT"}) or cfg.get("uv_vis4") else 2          # inp_par.F:264-278
     b = make_bounds(cfg["Lm"], cfg["Mm"], cfg["N"], NT, NAT, ntileI, ntileJ, tile,
                     EWperiodic=bool(cfg.get("EWperiodic", True)), NSperiodic=False, NghostPoints=nghost)

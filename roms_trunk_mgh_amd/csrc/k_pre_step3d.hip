@@ -53,12 +53,16 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
   const bool w_wall = b.west_edge && !b.EWperiodic && i == b.Istr;
   const bool e_wall = b.east_edge && !b.EWperiodic && i == b.Iend;
   // time-stepping weights, pre_step3d.F:586-600
-  // (MPDATA tracers use Gamma = 1/2, :557-563 and :793-799; H and V scheme are both MPDATA or neither)
+  // (upstream predictors -- MPDATA, HSIMT -- use Gamma = 1/2; the horizontal part takes the weight of the horizontal
+  // scheme, :557-563, the vertical part that of the vertical scheme, :793-799: they differ for "HSIMT vertically with
+  // another scheme horizontally")
   const double Gamma = (HADV == ADV_MPDATA) ? 0.5 : 1.0 / 6.0;
+  const double GammaV = (VADV == ADV_MPDATA) ? 0.5 : 1.0 / 6.0;
   double cff, cff1, cff2;
   if (first_step) { cff = 0.5 * dt; cff1 = 1.0; cff2 = 0.0; }
   else { cff = (1.0 - Gamma) * dt; cff1 = 0.5 + Gamma; cff2 = 0.5 - Gamma; }
   const double cpp = cff * GF(pm)[c0] * GF(pn)[c0];
+  const double cppv = (first_step ? 0.5 * dt : (1.0 - GammaV) * dt) * GF(pm)[c0] * GF(pn)[c0];
   // explicit vertical flux pieces
   const double cff3 = dt * (1.0 - p.lambda);
   const bool nonlocal = p.lmd_nonlocal && itrc <= b.NAT;
@@ -165,8 +169,8 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
       FCk = vflux<VADV>(k, N, w_k, tkm1, tk, tkp1, tkp2, cfk, cfk1);
     }
     // ---- artificial continuity, pre_step3d.F:893-915 ----
-    const double DCk = 1.0 / (hz - cpp * (hu1 - hu0 + hv1 - hv0 + (w_k - w_km1)));
-    t3v = DCk * (t3v - cpp * (FCk - FCprev));
+    const double DCk = 1.0 / (hz - cppv * (hu1 - hu0 + hv1 - hv0 + (w_k - w_km1)));
+    t3v = DCk * (t3v - cppv * (FCk - FCprev));
     t3[ck] = t3v;
     // ---- start of the corrector: explicit vertical flux, pre_step3d.F:917-1010 ----
     double FDk;
@@ -327,6 +331,13 @@ static int pre_step3d_tracers(const roms_step_idx_t *s)
       case ADV_MPDATA * 16 + ADV_MPDATA: rc = launch_pre_t<ADV_MPDATA, ADV_MPDATA>(s, it, n); break;
       // HSIMT: the predictor is the same first-order upstream step with Gamma = 1/2 (pre_step3d.F:364, :558, :730, :794)
       case ADV_HSIMT * 16 + ADV_HSIMT: rc = launch_pre_t<ADV_MPDATA, ADV_MPDATA>(s, it, n); break;
+      // HSIMT vertically with another scheme horizontally (the one working one-sided pair of the reference): the
+      // vertical predictor is the upstream step (:729-748, Gamma = 1/2 :793-799), the horizontal one the scheme's own
+      case ADV_U3 * 16 + ADV_HSIMT: rc = launch_pre_t<ADV_U3, ADV_MPDATA>(s, it, n); break;
+      case ADV_C4 * 16 + ADV_HSIMT: rc = launch_pre_t<ADV_C4, ADV_MPDATA>(s, it, n); break;
+      case ADV_SU3 * 16 + ADV_HSIMT: rc = launch_pre_t<ADV_C4, ADV_MPDATA>(s, it, n); break;
+      case ADV_A4 * 16 + ADV_HSIMT: rc = launch_pre_t<ADV_A4, ADV_MPDATA>(s, it, n); break;
+      case ADV_C2 * 16 + ADV_HSIMT: rc = launch_pre_t<ADV_C2, ADV_MPDATA>(s, it, n); break;
       default:
         return roms_fail("roms_hip_pre_step3d", "advection scheme pair not implemented (MPDATA and HSIMT only as H+V pairs)");
       }

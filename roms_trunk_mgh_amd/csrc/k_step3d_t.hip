@@ -518,6 +518,24 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   }
 }
 
+// the straight-from-memory kernel for a pair (HSIMT in the vertical with another horizontal scheme)
+template <int HADV, int VADV>
+int launch_classic(int nnew, int itrc0, int ntr)
+{
+  const roms_bounds_t &b = g_ctx.b;
+  const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
+  if (b.N > ROMS_MAXN) return roms_fail("roms_hip_step3d_t", "N > 64 not instantiated");
+  if (g_ctx.p.masking) return roms_fail("roms_hip_step3d_t", "MASKING is not built for the pair (other scheme, HSIMT)");
+  if (b.N <= 16)
+    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 16>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+  else if (b.N <= 32)
+    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+  else
+    hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 64>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+  KERNEL_CHECK("k_step3d_t");
+  return 0;
+}
+
 template <int HADV, int VADV>
 int launch_nmax(int nnew, int itrc0, int ntr)
 {
@@ -596,6 +614,12 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
         rc = launch_nmax<ADV_HSIMT, ADV_HSIMT>(s->nnew, it, n);
         break;
       }
+      // HSIMT vertically with another scheme horizontally: the straight-from-memory kernel (two ghost points suffice)
+      case ADV_U3 * 16 + ADV_HSIMT: rc = launch_classic<ADV_U3, ADV_HSIMT>(s->nnew, it, n); break;
+      case ADV_C4 * 16 + ADV_HSIMT: rc = launch_classic<ADV_C4, ADV_HSIMT>(s->nnew, it, n); break;
+      case ADV_SU3 * 16 + ADV_HSIMT: rc = launch_classic<ADV_C4, ADV_HSIMT>(s->nnew, it, n); break;
+      case ADV_A4 * 16 + ADV_HSIMT: rc = launch_classic<ADV_A4, ADV_HSIMT>(s->nnew, it, n); break;
+      case ADV_C2 * 16 + ADV_HSIMT: rc = launch_classic<ADV_C2, ADV_HSIMT>(s->nnew, it, n); break;
       case ADV_MPDATA * 16 + ADV_MPDATA:
         // multi-pass: upstream step, anti-diffusive velocities, FCT limiter, corrected step (k_mpdata.hip)
         for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q, q == 0);
