@@ -115,6 +115,7 @@ static int guarded_alloc(double **user, double **base, long n)
                        (unsigned long long *)*base, g, k_guard_bits);
     hipLaunchKernelGGL(k_fill_guard, dim3((unsigned)((g + 255) / 256)), dim3(256), 0, g_ctx.stream,
                        (unsigned long long *)(*user + n), g, k_guard_bits);
+    KERNEL_CHECK("k_fill_guard");
   }
   HIP_TRY(hipMemsetAsync(*user, 0, sizeof(double) * n, g_ctx.stream));
   return 0;
@@ -282,6 +283,8 @@ extern "C" int roms_hip_set_bounds(const roms_bounds_t *b)
   return 0;
 }
 
+static int library_default(int id, double *value);
+
 extern "C" int roms_hip_set_params(const roms_params_t *p)
 {
   if (!g_ctx.inited) return roms_fail("roms_hip_set_params", "library not initialised");
@@ -289,6 +292,21 @@ extern "C" int roms_hip_set_params(const roms_params_t *p)
   step2d_graphs_release();
   g_ctx.p = *p;
   g_ctx.hostc.p = *p;
+  // Library-kept defaults (all-water masks, zero biharmonic coefficients, ZoBot) were created under the previous
+  // parameters.  One that the new parameters no longer allow (masking switched on, uv_vis4 ...) is dropped here so
+  // that the next entry refuses the call with "field not registered" instead of running on the stale default.
+  for (int id = 0; id < FID_COUNT; id++)
+    if (g_ctx.dev[id] && !g_ctx.host[id]) {
+      double value;
+      if (!library_default(id, &value)) {
+        (void)hipStreamSynchronize(g_ctx.stream);
+        snapshot_forget(id);
+        guarded_free(&g_ctx.dev[id], &g_ctx.dev_base[id]);
+        g_ctx.count[id] = 0;
+        *(reinterpret_cast<double **>(&g_ctx.hostc.F) + id) = nullptr;
+        if (roms_rowm_is_table_field(id)) roms_rowm_invalidate();
+      }
+    }
   g_ctx.have_params = true;
   g_ctx.devc_dirty = true;
   return 0;
@@ -411,7 +429,9 @@ int roms_entry_check(const char *name)
         int rc = guarded_alloc(&g_ctx.dev[id], &g_ctx.dev_base[id], want);
         if (rc) return rc;
         std::vector<double> fill((size_t)want, value);
-        HIP_TRY(hipMemcpy(g_ctx.dev[id], fill.data(), sizeof(double) * want, hipMemcpyHostToDevice));
+        // on the library's (non-blocking) stream, behind guarded_alloc's memset of the same array
+        HIP_TRY(hipMemcpyAsync(g_ctx.dev[id], fill.data(), sizeof(double) * want, hipMemcpyHostToDevice, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
         g_ctx.host[id] = nullptr;
         g_ctx.count[id] = want;
         *(reinterpret_cast<double **>(&g_ctx.hostc.F) + id) = g_ctx.dev[id];

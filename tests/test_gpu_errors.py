@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def test_unsupported_boundary_condition_is_refused():
     st = ana.make_tile("UPWELLING", perturb=1.0)
-    st.p.lbc_south = 9                                     # no such code (enum roms_lbc ends at LBC_RADIATION_NUDGING = 7)
+    st.p.lbc_south = 99                                    # no such code (enum roms_lbc ends at LBC_REDUCED = 10)
     h = hip.RomsHip(st)
     try:
         with pytest.raises(RuntimeError) as e:
@@ -20,6 +20,17 @@ def test_unsupported_boundary_condition_is_refused():
         assert "not implemented" in str(e.value)
         with pytest.raises(RuntimeError):
             h.call("step3d_t", util.step_idx())
+    finally:
+        h.close()
+    # a valid code on a variable it is not defined for: Shchepetkin (ubar / vbar only) as the side's default, which
+    # also applies to zeta, u, v and t
+    st = ana.make_tile("UPWELLING", perturb=1.0)
+    st.p.lbc_south = abi.LBC["Shc"]
+    h = hip.RomsHip(st)
+    try:
+        with pytest.raises(RuntimeError) as e:
+            h.call("pre_step3d", util.step_idx())
+        assert "not implemented" in str(e.value)
     finally:
         h.close()
     # a condition that exists, for a variable it is not defined for: Flather on the free surface
@@ -115,5 +126,26 @@ def test_fields_of_absent_options_may_stay_unregistered():
         with pytest.raises(RuntimeError) as e:
             h.call("set_depth", util.step_idx())
         assert "field not registered: umask" in str(e.value)
+    finally:
+        h.close()
+
+
+def test_library_defaults_do_not_survive_a_parameter_change():
+    """the all-water masks the library keeps for an application without MASKING must not be used after
+    set_params switches MASKING on -- the entry has to refuse with 'field not registered'."""
+    import ctypes as C
+    st = util.prepared_state("UPWELLING")
+    h = hip.RomsHip(st, leave_unregistered=("rmask", "umask", "vmask", "pmask"))
+    try:
+        h.call("omega", util.step_idx())                   # creates the defaults under masking = 0
+        p2 = type(st.p).from_buffer_copy(st.p)
+        p2.masking = 1
+        assert h.l.roms_hip_set_params(C.byref(p2)) == 0
+        with pytest.raises(RuntimeError) as e:
+            h.call("omega", util.step_idx())
+        assert "field not registered" in str(e.value)
+        p2.masking = 0                                     # and back: usable again
+        assert h.l.roms_hip_set_params(C.byref(p2)) == 0
+        h.call("omega", util.step_idx())
     finally:
         h.close()

@@ -1,5 +1,5 @@
 """Developer tool: time single hot-path entries on a named configuration with
-the library's hipEvent timers.  Usage: python tools/bench_kernel.py BENCHMARK3 step3d_t [reps]"""
+the library's hipEvent timers.  Usage: python tools/bench_kernel.py [--lib PATH] BENCHMARK3 step3d_t [reps]"""
 import sys
 import time
 
@@ -11,6 +11,10 @@ from roms_trunk_mgh_amd import hip  # noqa: E402
 
 
 def main():
+    if "--lib" in sys.argv:                 # A/B of another build of the same ABI (python -m roms_trunk_mgh_amd._build <variant>)
+        q = sys.argv.index("--lib")
+        hip.use_library(sys.argv[q + 1])
+        del sys.argv[q:q + 2]
     config = sys.argv[1] if len(sys.argv) > 1 else "BENCHMARK3"
     kernels = sys.argv[2].split(",") if len(sys.argv) > 2 else ["step3d_t"]
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10

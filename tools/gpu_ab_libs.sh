@@ -8,8 +8,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R"
 export PYTHONPATH=$R
 for v in "$@"; do
-  if [ "$v" = base ]; then unset ROMS_HIP_LIBRARY; else export ROMS_HIP_LIBRARY=$R/roms_trunk_mgh_amd/libroms_hip_$v.so; fi
+  if [ "$v" = base ]; then LIBARG=""; else LIBARG="--lib $R/roms_trunk_mgh_amd/libroms_hip_$v.so"; fi
   echo "=== $v"
-  python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_main3d.py -m gpu -x -q -k "$FILT" 2>&1 | tail -1
-  python3 tools/bench_kernel.py $CONFIG $ENTRY 9 | grep -v "state built"
+  # the parity tests always run on the product library (no environment variable can redirect it)
+  [ "$v" = base ] && python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_main3d.py -m gpu -x -q -k "$FILT" 2>&1 | tail -1
+  python3 tools/bench_kernel.py $LIBARG $CONFIG $ENTRY 9 | grep -v "state built"
 done
