@@ -138,332 +138,456 @@ __device__ __forceinline__ double mp_div(double n, double d)
 #define DV(n, d) mp_div<FAST>((n), (d))
 
 // ------------------------------------------------- K2: Ua, Va, Wa (raw) ----
-// vertical-gradient factor C and mean vertical Courant number Wm of a face between
-// column p (offset 0) and column q (offset dq), mpdata_adiff.F:262-310 / :456-504
-template <bool FAST>
-__device__ __forceinline__ void face_CW(const gcd_t Ta, const gcd_t z_r, const gcd_t odzA, const gcd_t Wv, const gcd_t pm,
-                                        const gcd_t pn, long a2, long a, long dq, long nij, int k, int N,
-                                        double dt, double &C, double &Wm)
+// LDS-tiled and level-marching.  A workgroup of 64 x 4 threads owns the faces of 64 x 4 columns and walks from the
+// bottom level to the top.  Everything the three faces of a cell need from the cells around it is a handful of *cell
+// quantities* that the reference evaluates again and again inside every face (mpdata_adiff.F:262-560):
+//
+//   GU(i,j,k) = (Ta(i) - Ta(i-1)) * (pm(i-1) + pm(i)) [* umask(i)]      xi-gradient on the u-face of the cell
+//   GV(i,j,k) = (Ta(j) - Ta(j-1)) * (pn(j-1) + pn(j)) [* vmask(j)]      eta-gradient on its v-face
+//   HU(i,j,k) = Huon * (pm(i-1)+pm(i)) * (pn(i-1)+pn(i)) * (oHz(i-1)+oHz(i))    the Courant-number term of its u-face
+//   HV(i,j,k) = Hvom * (pm(j-1)+pm(j)) * (pn(j-1)+pn(j)) * (oHz(j-1)+oHz(j))
+//   DZ(i,j,k) = (Ta(k+1) - Ta(k)) * odz(k)                              vertical gradient on its w-face
+//   WC(i,j,k) = (W(k-1)*odz(k-1) + W(k)*odz(k)) * pm * pn               (one term at k = 1 and k = N)
+//
+// -- the same operations in the same order wherever the reference uses them, so sharing them keeps every bit.  Per
+// level each thread evaluates them once for its own column (and the first 140 threads for one column of the one-point
+// ring around the tile as well), publishes them in LDS, and after a barrier every thread combines its own values with
+// those of its W, S, E, N, NW and SE neighbours into Ua, Va and Wa.  Against the one-thread-per-cell kernel of round 2
+// (which re-derived all of this from ~150 global loads per cell) that is ~15 global loads + 28 LDS reads per cell and
+// roughly a third fewer FP64 instructions.
+//
+// LDS plane A_k (published in iteration k; two planes alive: A_k and A_k-1):
+//   at level k+1: Ta, GU, GV, HU, HV, ZU = z_r(min(k+1,N));   at level k: DZ, WC;   ZL = z_r(max(k-1,1))
+#define MPX 66
+#define MPY 6
+#define MPC (MPX * MPY)
+enum { Q_TA = 0, Q_GU, Q_GV, Q_HU, Q_HV, Q_ZU, Q_DZ, Q_WC, Q_ZL, Q_N };
+
+struct MpCol {          // level-independent part of a column
+  long a2;              // index in a 2-D array
+  long dW, dS;          // distance to the western / southern neighbour (0 where that would leave the array: value unused)
+  double PMU, PNU, PMV, PNV, pm, pn, um, vm;
+  bool ok;              // the column lies inside LBi:UBi, LBj:UBj
+};
+
+struct MpLev {          // what a thread keeps of its own column for one level
+  double Ta, GU, GV, HU, HV;        // cell quantities
+  double Hu, Hv, OHU, OHV;          // raw Huon, Hvom and the oHz sums (the face's own Courant number keeps the reference's
+                                    // association 0.125*Huon*dt*..., which is not HU)
+};
+
+template <bool MASK>
+__device__ __forceinline__ MpCol mp_column(const RomsDev *__restrict__ c, int i, int j)
 {
-  // a = index of (p,k) in rho arrays, a2 = 2-D index of p; q = p + dq
-  const long aq = a + dq, a2q = a2 + dq;
-  auto odz = [&](long x) { return odzA[x]; };                             // odz at level of x
-  const long w = a + nij, wq = aq + nij;      // W(.,.,k) of a K_3DW array = rho index + nij
-  if (k == 1) {
-    C = DV(0.25 * ((Ta[a + nij] - Ta[a]) * odz(a) + (Ta[aq + nij] - Ta[aq]) * odz(aq)) *
-               (z_r[a + nij] - z_r[a] + z_r[aq + nij] - z_r[aq]), Ta[aq] + Ta[a] + EPS_MP);
-    Wm = 0.25 * dt * (Wv[wq] * odz(aq) * pm[a2q] * pn[a2q] + Wv[w] * odz(a) * pm[a2] * pn[a2]);
-  } else if (k < N) {
-    C = DV(0.0625 *
-               ((Ta[a + nij] - Ta[a]) * odz(a) + (Ta[a] - Ta[a - nij]) * odz(a - nij) +
-                (Ta[aq + nij] - Ta[aq]) * odz(aq) + (Ta[aq] - Ta[aq - nij]) * odz(aq - nij)) *
-               (z_r[a + nij] - z_r[a - nij] + z_r[aq + nij] - z_r[aq - nij]), Ta[aq] + Ta[a] + EPS_MP);
-    Wm = 0.25 * dt *
-         ((Wv[wq - nij] * odz(aq - nij) + Wv[wq] * odz(aq)) * pm[a2q] * pn[a2q] +
-          (Wv[w] * odz(a) + Wv[w - nij] * odz(a - nij)) * pm[a2] * pn[a2]);
-  } else {
-    C = DV(0.25 * ((Ta[a] - Ta[a - nij]) * odz(a - nij) + (Ta[aq] - Ta[aq - nij]) * odz(aq - nij)) *
-               (z_r[a] - z_r[a - nij] + z_r[aq] - z_r[aq - nij]), Ta[aq] + Ta[a] + EPS_MP);
-    Wm = 0.25 * dt * (Wv[wq - nij] * odz(aq - nij) * pm[a2q] * pn[a2q] + Wv[w - nij] * odz(a - nij) * pm[a2] * pn[a2]);
-  }
+  DEV_PROLOGUE(c)
+  MpCol cc;
+  cc.ok = i >= b.LBi && i <= b.UBi && j >= b.LBj && j <= b.UBj;
+  const int ic = cc.ok ? i : b.LBi, jc = cc.ok ? j : b.LBj;
+  cc.a2 = I2(ic, jc);
+  cc.dW = ic > b.LBi ? 1 : 0;
+  cc.dS = jc > b.LBj ? ni : 0;
+  const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn;
+  cc.pm = pm[cc.a2]; cc.pn = pn[cc.a2];
+  const double pmW = pm[cc.a2 - cc.dW], pnW = pn[cc.a2 - cc.dW], pmS = pm[cc.a2 - cc.dS], pnS = pn[cc.a2 - cc.dS];
+  cc.PMU = pmW + cc.pm; cc.PNU = pnW + cc.pn;
+  cc.PMV = cc.pm + pmS; cc.PNV = cc.pn + pnS;
+  cc.um = 1.0; cc.vm = 1.0;
+  if constexpr (MASK) { cc.um = GF(umask)[cc.a2]; cc.vm = GF(vmask)[cc.a2]; }
+  return cc;
 }
 
-// One launch for the three faces (they share the Ta, Huon, Hvom, oHz loads): 208 VGPRs, two waves per SIMD.
-// The kernel is FP64-issue bound (per cell and level ~1800 VALU instructions, 49 divisions among them); one
-// launch per face raises the occupancy to 3-4 waves but repeats the shared loads and was 20 % slower.
-// MASK (MASKING applications, separate instantiations so that the unmasked kernel keeps its code): the horizontal
-// differences of the cross terms times the mask of their face (mpdata_adiff.F:288-297, :470-480, :640-660) and
-// the clamped velocities times umask / vmask / rmask (:395, :568, :801).
+struct MpF { gcd_t Ta, oHz, odz, Huon, Hvom, W, z_r; };
+
+// what plane A_k of one column needs from memory: level k+1 of Ta (own, west, south), oHz (own, west, south), Huon,
+// Hvom, z_r and level k of odz and W.  Loaded one iteration ahead (the loads are in flight while the faces of the
+// level below are evaluated: the level loop is bound by memory latency, not bytes, like k_step3d_t_pipe).
+struct MpRaw { double t1, tW, tS, o, oW, oS, hu, hv, zu, odz, w; };
+
+__device__ __forceinline__ MpRaw mp_load_raw(const MpF &f, const MpCol &cc, int k, int N, long nij)
+{
+  MpRaw r;
+  // k = N: nothing new is needed (plane A_N has no level N+1); re-read level N, the values are not used
+  const long a1 = cc.a2 + (long)(k < N ? k : N - 1) * nij;          // level k+1
+  const long a0 = cc.a2 + (long)(k >= 1 ? (k < N ? k - 1 : N - 2) : 0) * nij;   // level k (odz has levels 1..N-1)
+  r.t1 = f.Ta[a1]; r.tW = f.Ta[a1 - cc.dW]; r.tS = f.Ta[a1 - cc.dS];
+  r.o = f.oHz[a1]; r.oW = f.oHz[a1 - cc.dW]; r.oS = f.oHz[a1 - cc.dS];
+  r.hu = f.Huon[a1]; r.hv = f.Hvom[a1];
+  r.zu = f.z_r[a1];
+  r.odz = f.odz[a0];
+  r.w = f.W[a1];                                        // W(i,j,k) of a (0:N) array = rho index of level k+1
+  return r;
+}
+
+struct MpSlide { double Tk, WZm, zk, zkm1; };    // Ta(k), W(k-1)*odz(k-1), z_r(k), z_r(k-1) of a column
+
+// plane A_k of one column from its raw loads and what it carries from the level below: q[] for the LDS, L = level
+// k+1 of the column for its owner, WZk = W(k)*odz(k)
+template <bool MASK>
+__device__ __forceinline__ void mp_cellq(const MpRaw &r, const MpCol &cc, MpSlide &s, int k, int N, double q[Q_N], MpLev &L,
+                                         double &WZk)
+{
+  L.Ta = L.GU = L.GV = L.HU = L.HV = L.Hu = L.Hv = L.OHU = L.OHV = 0.0;
+  WZk = 0.0;
+  q[Q_DZ] = q[Q_WC] = q[Q_ZL] = 0.0;
+  if (k < N) {
+    L.Hu = r.hu; L.Hv = r.hv;
+    L.Ta = r.t1;
+    L.GU = (r.t1 - r.tW) * cc.PMU;
+    L.GV = (r.t1 - r.tS) * cc.PNV;
+    if constexpr (MASK) { L.GU = L.GU * cc.um; L.GV = L.GV * cc.vm; }
+    L.OHU = r.oW + r.o;
+    L.OHV = r.oS + r.o;
+    L.HU = L.Hu * cc.PMU * cc.PNU * L.OHU;
+    L.HV = L.Hv * cc.PMV * cc.PNV * L.OHV;
+    q[Q_ZU] = r.zu;
+  } else {
+    q[Q_ZU] = s.zk;
+  }
+  q[Q_TA] = L.Ta; q[Q_GU] = L.GU; q[Q_GV] = L.GV; q[Q_HU] = L.HU; q[Q_HV] = L.HV;
+  if (k >= 1) {
+    if (k < N) {
+      q[Q_DZ] = (r.t1 - s.Tk) * r.odz;
+      WZk = r.w * r.odz;
+    }
+    if (k == 1) q[Q_WC] = WZk * cc.pm * cc.pn;
+    else q[Q_WC] = (k < N ? (s.WZm + WZk) : s.WZm) * cc.pm * cc.pn;
+    q[Q_ZL] = k > 1 ? s.zkm1 : s.zk;
+  }
+  // slide to the next level
+  s.Tk = r.t1; s.WZm = WZk;
+  if (k >= 1) s.zkm1 = s.zk;
+  if (k < N) s.zk = r.zu;
+}
+
+// the nine third-order coefficients and the polynomial of one face; P = the gradient factor along the face's own
+// direction, Q, R the other two, Xp, Xq, Xr the matching first-order velocities.  SWAPBC: the eta face of the
+// reference multiplies sig_b with Xp*Xq^2 and sig_c with Xp^2*Xq (mpdata_adiff.F:556-560), the other two the
+// other way round (:376-380, :786-790).
+#define MP_SIGMA(P, Q, R, Xp, Xq, Xr, OUT, SWAPBC)                                                                    \
+  {                                                                                                                   \
+    const double PP = P * P, QQ = Q * Q, RR = R * R, PQ = P * Q, PR = P * R;                                          \
+    const double XpXp = Xp * Xp, XqXq = Xq * Xq, XrXr = Xr * Xr, XpXq = Xp * Xq, XpXr = Xp * Xr;                      \
+    const double sig_alfa = DV(1.0, 1.0 - fabs(P) + EPS_MP);                                                          \
+    const double sig_beta = DV(-P, (1.0 - fabs(P)) * (1.0 - PP) + EPS_MP);                                            \
+    const double sig_gama = DV(2.0 * fabs(PP * P), (1.0 - fabs(P)) * (1.0 - PP) * (1.0 - fabs(PP * P)) + EPS_MP);     \
+    const double sig_a = DV(-Q, (1.0 - fabs(P)) * (1.0 - fabs(PQ)) + EPS_MP);                                         \
+    const double sig_b = DV(PQ, (1.0 - fabs(P)) * (1.0 - PP * fabs(Q)) + EPS_MP) *                                    \
+                         (DV(fabs(Q), 1.0 - fabs(PQ) + EPS_MP) + DV(2.0 * P, 1.0 - PP + EPS_MP));                     \
+    const double sig_c = DV(fabs(P) * QQ, (1.0 - fabs(P)) * (1.0 - QQ * fabs(P)) * (1.0 - fabs(PQ)) + EPS_MP);        \
+    const double sig_d = DV(-R, (1.0 - fabs(P)) * (1.0 - fabs(PR)) + EPS_MP);                                         \
+    const double sig_e = DV(PR, (1.0 - fabs(P)) * (1.0 - PP * fabs(R)) + EPS_MP) *                                    \
+                         (DV(fabs(R), 1.0 - fabs(PR) + EPS_MP) + DV(2.0 * P, 1.0 - PP + EPS_MP));                     \
+    const double sig_f = DV(fabs(P) * RR, (1.0 - fabs(P)) * (1.0 - RR * fabs(P)) * (1.0 - fabs(PR)) + EPS_MP);        \
+    if (SWAPBC)                                                                                                       \
+      OUT = sig_alfa * Xp + sig_beta * XpXp + sig_gama * XpXp * Xp + sig_a * XpXq + sig_b * Xp * XqXq +               \
+            sig_c * XpXp * Xq + sig_d * XpXr + sig_e * XpXp * Xr + sig_f * Xp * XrXr;                                 \
+    else                                                                                                              \
+      OUT = sig_alfa * Xp + sig_beta * XpXp + sig_gama * XpXp * Xp + sig_a * XpXq + sig_b * XpXp * Xq +               \
+            sig_c * Xp * XqXq + sig_d * XpXr + sig_e * XpXp * Xr + sig_f * Xp * XrXr;                                 \
+  }
+
 template <bool FAST, bool MASK>
-__global__ void __launch_bounds__(BLK_X *BLK_Y)
+__global__ void __launch_bounds__(BLK_X *BLK_Y, 2)
 k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
 {
   DEV_PROLOGUE(c)
-  // union of the three ranges: i = IstrU-1 : Iendp2, j = JstrV-1 : Jendp2
-  // level fastest inside an XCD (see k_mp_ta)
-  const TileLv XB = decode_tile_level(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1, N);
-  if (!XB.valid) return;
-  const int i = b.IstrU - 1 + XB.bx * BLK_X + threadIdx.x;
-  const int j = b.JstrV - 1 + XB.by * BLK_Y + threadIdx.y;
-  if (i > b.Iendp2 || j > b.Jendp2) return;
-  const bool do_u = j <= b.Jendp1;                                  // Ua: j = JstrV-1:Jendp1, i = IstrU-1:Iendp2
-  const bool do_v = j >= b.JstrVm1 && i <= b.Iendp1;                // Va: j = JstrVm1:Jendp2, i = IstrU-1:Iendp1
-  const bool do_w = j <= b.Jendp1 && i <= b.Iendp1;                 // Wa: j = JstrV-1:Jendp1, i = IstrU-1:Iendp1
+  __shared__ double lds[2][Q_N][MPC];
+  // union of the three ranges: i = IstrU-1 : Iendp2, j = JstrV-1 : Jendp2; XCD strips of tile columns (xcd_block)
+  const Blk XB = xcd_block();
+  const int i0 = b.IstrU - 1 + XB.x * BLK_X, j0 = b.JstrV - 1 + XB.y * BLK_Y;
+  const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
+  const int tid = threadIdx.y * BLK_X + threadIdx.x;
+  const bool inr = i <= b.Iendp2 && j <= b.Jendp2;
+  const bool do_u = inr && j <= b.Jendp1;                                   // Ua: j = JstrV-1:Jendp1, i = IstrU-1:Iendp2
+  const bool do_v = inr && j >= b.JstrVm1 && i <= b.Iendp1;                 // Va: j = JstrVm1:Jendp2, i = IstrU-1:Iendp1
+  const bool do_w = inr && j <= b.Jendp1 && i <= b.Iendp1;                  // Wa: j = JstrV-1:Jendp1, i = IstrU-1:Iendp1
   const double dt = c->p.dt;
-  const gcd_t Ta = (gcd_t)m.Ta;
-  const gcd_t z_r = (gcd_t)c->F.z_r, Wv = (gcd_t)c->F.W, Hz = (gcd_t)c->F.Hz;
-  const gcd_t Huon = (gcd_t)c->F.Huon, Hvom = (gcd_t)c->F.Hvom;
-  const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn, on_v = (gcd_t)c->F.on_v, om_u = (gcd_t)c->F.om_u;
+  MpF f;
+  f.Ta = (gcd_t)m.Ta; f.oHz = (gcd_t)m.oHz; f.odz = (gcd_t)m.odz;
+  f.Huon = (gcd_t)c->F.Huon; f.Hvom = (gcd_t)c->F.Hvom; f.W = (gcd_t)c->F.W; f.z_r = (gcd_t)c->F.z_r;
   const gd_t Ua = (gd_t)m.Ua, Va = (gd_t)m.Va, Wa = (gd_t)m.Wa;
-  const long a2 = I2(i, j);
+  // own column: slot (tx+1, ty+1) of the 66 x 6 plane
+  const int so = (threadIdx.y + 1) * MPX + threadIdx.x + 1;
+  const MpCol co = mp_column<MASK>(c, i, j);
+  // ring column of this thread (the first 140 threads): rows 0 and 5, then columns 0 and 65 of rows 1..4
+  int sh = -1, ih = 0, jh = 0;
+  if (tid < 2 * MPX) { const int r = tid / MPX, x = tid - r * MPX; sh = (r ? (MPY - 1) * MPX : 0) + x; ih = i0 - 1 + x; jh = j0 - 1 + (r ? MPY - 1 : 0); }
+  else if (tid < 2 * MPX + 2 * BLK_Y) { const int q = tid - 2 * MPX, y = 1 + (q >> 1), x = (q & 1) ? MPX - 1 : 0; sh = y * MPX + x; ih = i0 - 1 + x; jh = j0 - 1 + y; }
+  MpCol ch = co;
+  if (sh >= 0) ch = mp_column<MASK>(c, ih, jh);
+  const bool halo = sh >= 0 && ch.ok;
+  // level-independent sums of the faces (mpdata_adiff.F:300, :478, :656-657)
+  const gcd_t on_v = (gcd_t)c->F.on_v, om_u = (gcd_t)c->F.om_u;
+  const long a2 = co.a2;
+  double ONV4 = 0.0, OMU4 = 0.0, OMU2 = 0.0, ONV2 = 0.0, rm = 1.0;
+  if (do_u) ONV4 = on_v[a2] + on_v[a2 + ni] + on_v[a2 - 1] + on_v[a2 - 1 + ni];
+  if (do_v) OMU4 = om_u[a2] + om_u[a2 + 1] + om_u[a2 - ni] + om_u[a2 + 1 - ni];
+  if (do_w) { OMU2 = om_u[a2 + 1] + om_u[a2]; ONV2 = on_v[a2 + ni] + on_v[a2]; }
+  if constexpr (MASK) { if (inr) rm = GF(rmask)[a2]; }
   // faces on a physical edge, mpdata_adiff.F:577-640: zero (closed) or the value of the next face inside, which the
   // thread of that face stores
   const bool v_wall_n = b.north_edge && !b.NSperiodic && j == b.Jend + 1;
   const bool u_wall_w = b.west_edge && !b.EWperiodic && i == b.Istr;
   const bool u_wall_e = b.east_edge && !b.EWperiodic && i == b.Iend + 1;
-  const gcd_t oHzA = (gcd_t)m.oHz, odzA = (gcd_t)m.odz;
-  auto oHz = [&](long x) { return oHzA[x]; };
-  const gcd_t umk = (gcd_t)c->F.umask, vmk = (gcd_t)c->F.vmask, rmk = (gcd_t)c->F.rmask;
-  auto UM = [&](double x, long q) { if constexpr (MASK) return x * umk[q]; else return x; };   // x * umask(q)
-  auto VM = [&](double x, long q) { if constexpr (MASK) return x * vmk[q]; else return x; };
-  // one thread per (i,j,k): nothing is carried from level to level, and with ~1200 FP64 instructions per
-  // cell the kernel needs every wave it can get (a k-loop per column ran at two waves per SIMD)
+  const bool u_copy_w = b.west_edge && !b.EWperiodic && i == b.Istr + 1 && !m.closed[LBS_WEST];
+  const bool u_copy_e = b.east_edge && !b.EWperiodic && i == b.Iend && !m.closed[LBS_EAST];
+  const bool v_copy_s = b.south_edge && !b.NSperiodic && j == b.Jstr + 1;
+  const bool v_copy_n = b.north_edge && !b.NSperiodic && j == b.Jend && !m.closed[LBS_NORTH];
+  // a thread without a ring column repeats its own one there (valid addresses, nothing stored): no divergent loads
+  const MpCol chh = halo ? ch : co;
+  // plane A_0: level 1
+  MpLev Lc, Ln;              // own column at level k and k+1
+  double DZm1 = 0.0;         // own DZ(k-1)
+  MpSlide so_s{0.0, 0.0, 0.0, 0.0}, sh_s{0.0, 0.0, 0.0, 0.0};
   {
-    const int k = XB.k0 + 1;
+    const MpRaw r0 = mp_load_raw(f, co, 0, N, nij), r0h = mp_load_raw(f, chh, 0, N, nij);
+    double q[Q_N], wz;
+    MpLev Lh;
+    mp_cellq<MASK>(r0, co, so_s, 0, N, q, Lc, wz);
+#pragma unroll
+    for (int e = 0; e < Q_N; e++) lds[0][e][so] = co.ok ? q[e] : 0.0;
+    mp_cellq<MASK>(r0h, chh, sh_s, 0, N, q, Lh, wz);
+    if (sh >= 0) {
+#pragma unroll
+      for (int e = 0; e < Q_N; e++) lds[0][e][sh] = halo ? q[e] : 0.0;
+    }
+  }
+  MpRaw rn = mp_load_raw(f, co, 1, N, nij), rnh = mp_load_raw(f, chh, 1, N, nij);
+  __syncthreads();
+  for (int k = 1; k <= N; k++) {
+    const int cu = k & 1, pv = cu ^ 1;
+    double qo[Q_N], WZk;
+    // ---- phase 1: plane A_k from the loads issued one iteration ago; then the loads of plane A_k+1 go out
+    {
+      double q[Q_N], wz;
+      MpLev Lh;
+      mp_cellq<MASK>(rn, co, so_s, k, N, qo, Ln, WZk);
+#pragma unroll
+      for (int e = 0; e < Q_N; e++) lds[cu][e][so] = co.ok ? qo[e] : 0.0;
+      mp_cellq<MASK>(rnh, chh, sh_s, k, N, q, Lh, wz);
+      if (sh >= 0) {
+#pragma unroll
+        for (int e = 0; e < Q_N; e++) lds[cu][e][sh] = halo ? q[e] : 0.0;
+      }
+    }
+    if (k < N) { rn = mp_load_raw(f, co, k + 1, N, nij); rnh = mp_load_raw(f, chh, k + 1, N, nij); }
+    __syncthreads();
+    // ---- phase 2: the three faces of (i,j,k)
     const long a = a2 + (long)(k - 1) * nij;
-    const double T0 = Ta[a];
+    const double T0 = Lc.Ta;
+    const double DZk = qo[Q_DZ], WCk = qo[Q_WC], ZU = qo[Q_ZU], ZL = qo[Q_ZL];
     // ---------------- XI face between (i-1,j) and (i,j) ----------------
     if (do_u) {
-      const double Tw = Ta[a - 1];
+      const int sw = so - 1, sn = so + MPX, snw = so + MPX - 1;
+      const double Tw = lds[pv][Q_TA][sw];
       double ua = 0.0;
       if (!u_wall_w && !u_wall_e && !((Tw <= 0.0) || (T0 <= 0.0) || (fabs(Tw - T0) <= EPS2_MP))) {
-        double Ck, Wk;
-        face_CW<FAST>(Ta, z_r, odzA, Wv, pm, pn, a2, a, -1, nij, k, N, dt, Ck, Wk);
-        const double A = DV(T0 - Tw, T0 + Tw + EPS_MP);
-        double B = 0.03125 *
-                   (VM((Ta[a + ni] - T0) * (pn[a2] + pn[a2 + ni]), a2 + ni) + VM((T0 - Ta[a - ni]) * (pn[a2 - ni] + pn[a2]), a2) +
-                    VM((Ta[a - 1 + ni] - Tw) * (pn[a2 - 1] + pn[a2 - 1 + ni]), a2 - 1 + ni) +
-                    VM((Tw - Ta[a - 1 - ni]) * (pn[a2 - 1 - ni] + pn[a2 - 1]), a2 - 1));
-        B = DV(B * (on_v[a2] + on_v[a2 + ni] + on_v[a2 - 1] + on_v[a2 - 1 + ni]), Tw + T0 + EPS_MP);
-        const double Um = 0.125 * Huon[a] * dt * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a - 1) + oHz(a));
-        const double Vm = 0.03125 * dt *
-                          (Hvom[a - 1] * (pm[a2 - 1] + pm[a2 - 1 - ni]) * (pn[a2 - 1] + pn[a2 - 1 - ni]) *
-                               (oHz(a - 1) + oHz(a - 1 - ni)) +
-                           Hvom[a - 1 + ni] * (pm[a2 - 1 + ni] + pm[a2 - 1]) * (pn[a2 - 1 + ni] + pn[a2 - 1]) *
-                               (oHz(a - 1 + ni) + oHz(a - 1)) +
-                           Hvom[a] * (pm[a2] + pm[a2 - ni]) * (pn[a2] + pn[a2 - ni]) * (oHz(a) + oHz(a - ni)) +
-                           Hvom[a + ni] * (pm[a2 + ni] + pm[a2]) * (pn[a2 + ni] + pn[a2]) * (oHz(a + ni) + oHz(a)));
+        const double den = Tw + T0 + EPS_MP;
+        const double zs = ZU - ZL + lds[cu][Q_ZU][sw] - lds[cu][Q_ZL][sw];
+        double Ck;
+        if (k == 1) Ck = DV(0.25 * (DZk + lds[cu][Q_DZ][sw]) * zs, den);
+        else if (k < N) Ck = DV(0.0625 * (DZk + DZm1 + lds[cu][Q_DZ][sw] + lds[pv][Q_DZ][sw]) * zs, den);
+        else Ck = DV(0.25 * (DZm1 + lds[pv][Q_DZ][sw]) * zs, den);
+        const double Wk = 0.25 * dt * (lds[cu][Q_WC][sw] + WCk);
+        const double A = DV(T0 - Tw, den);
+        double B = 0.03125 * (lds[pv][Q_GV][sn] + Lc.GV + lds[pv][Q_GV][snw] + lds[pv][Q_GV][sw]);
+        B = DV(B * ONV4, den);
+        const double Um = 0.125 * Lc.Hu * dt * co.PMU * co.PNU * Lc.OHU;
+        const double Vm = 0.03125 * dt * (lds[pv][Q_HV][sw] + lds[pv][Q_HV][snw] + Lc.HV + lds[pv][Q_HV][sn]);
         const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
         const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
         const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
-        const double AA = A * A, BB = B * B, CC = Ck * Ck, AB = A * B, AC = A * Ck;
-        const double XX = X * X, YY = Y * Y, ZZ = Z * Z, XY = X * Y, XZ = X * Z;
-        const double sig_alfa = DV(1.0, 1.0 - fabs(A) + EPS_MP);
-        const double sig_beta = DV(-A, (1.0 - fabs(A)) * (1.0 - AA) + EPS_MP);
-        const double sig_gama = DV(2.0 * fabs(AA * A), (1.0 - fabs(A)) * (1.0 - AA) * (1.0 - fabs(AA * A)) + EPS_MP);
-        const double sig_a = DV(-B, (1.0 - fabs(A)) * (1.0 - fabs(AB)) + EPS_MP);
-        const double sig_b = DV(AB, (1.0 - fabs(A)) * (1.0 - AA * fabs(B)) + EPS_MP) *
-                             (DV(fabs(B), 1.0 - fabs(AB) + EPS_MP) + DV(2.0 * A, 1.0 - AA + EPS_MP));
-        const double sig_c = DV(fabs(A) * BB, (1.0 - fabs(A)) * (1.0 - BB * fabs(A)) * (1.0 - fabs(AB)) + EPS_MP);
-        const double sig_d = DV(-Ck, (1.0 - fabs(A)) * (1.0 - fabs(AC)) + EPS_MP);
-        const double sig_e = DV(AC, (1.0 - fabs(A)) * (1.0 - AA * fabs(Ck)) + EPS_MP) *
-                             (DV(fabs(Ck), 1.0 - fabs(AC) + EPS_MP) + DV(2.0 * A, 1.0 - AA + EPS_MP));
-        const double sig_f = DV(fabs(A) * CC, (1.0 - fabs(A)) * (1.0 - CC * fabs(A)) * (1.0 - fabs(AC)) + EPS_MP);
-        const double u0 = sig_alfa * X + sig_beta * XX + sig_gama * XX * X + sig_a * XY + sig_b * XX * Y +
-                          sig_c * X * YY + sig_d * XZ + sig_e * XX * Z + sig_f * X * ZZ;
+        double u0;
+        MP_SIGMA(A, B, Ck, X, Y, Z, u0, false)
         ua = fmin(fabs(u0), 1.0 * fabs(Um)) * copysign(1.0, u0);
-        ua = UM(ua, a2);
+        if constexpr (MASK) ua = ua * co.um;
       }
       if (u_wall_w) { if (m.closed[LBS_WEST]) Ua[a] = 0.0; }
       else if (u_wall_e) { if (m.closed[LBS_EAST]) Ua[a] = 0.0; }
       else {
         Ua[a] = ua;
-        if (b.west_edge && !b.EWperiodic && i == b.Istr + 1 && !m.closed[LBS_WEST]) Ua[a - 1] = ua;
-        if (b.east_edge && !b.EWperiodic && i == b.Iend && !m.closed[LBS_EAST]) Ua[a + 1] = ua;
+        if (u_copy_w) Ua[a - 1] = ua;
+        if (u_copy_e) Ua[a + 1] = ua;
       }
     }
     // ---------------- ETA face between (i,j-1) and (i,j) ----------------
     if (do_v) {
-      const double Ts = Ta[a - ni];
+      const int ss = so - MPX, se = so + 1, sse = so - MPX + 1;
+      const double Ts = lds[pv][Q_TA][ss];
       double va = 0.0;
       if (!v_wall_n && !((Ts <= 0.0) || (T0 <= 0.0) || (fabs(Ts - T0) <= EPS2_MP))) {
-        double Ck, Wk;
-        face_CW<FAST>(Ta, z_r, odzA, Wv, pm, pn, a2, a, -ni, nij, k, N, dt, Ck, Wk);
-        double A = 0.03125 *
-                   (UM((Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]), a2 + 1) + UM((T0 - Ta[a - 1]) * (pm[a2 - 1] + pm[a2]), a2) +
-                    UM((Ta[a + 1 - ni] - Ts) * (pm[a2 + 1 - ni] + pm[a2 - ni]), a2 + 1 - ni) +
-                    UM((Ts - Ta[a - 1 - ni]) * (pm[a2 - 1 - ni] + pm[a2 - ni]), a2 - ni));
-        A = DV(A * (om_u[a2] + om_u[a2 + 1] + om_u[a2 - ni] + om_u[a2 + 1 - ni]), Ts + T0 + EPS_MP);
-        const double B = DV(T0 - Ts, T0 + Ts + EPS_MP);
-        const double Um = 0.03125 * dt *
-                          (Huon[a + 1] * (pm[a2 + 1] + pm[a2]) * (pn[a2 + 1] + pn[a2]) * (oHz(a + 1) + oHz(a)) +
-                           Huon[a + 1 - ni] * (pm[a2 + 1 - ni] + pm[a2 - ni]) * (pn[a2 + 1 - ni] + pn[a2 - ni]) *
-                               (oHz(a + 1 - ni) + oHz(a - ni)) +
-                           Huon[a] * (pm[a2 - 1] + pm[a2]) * (pn[a2 - 1] + pn[a2]) * (oHz(a - 1) + oHz(a)) +
-                           Huon[a - ni] * (pm[a2 - 1 - ni] + pm[a2 - ni]) * (pn[a2 - 1 - ni] + pn[a2 - ni]) *
-                               (oHz(a - 1 - ni) + oHz(a - ni)));
-        const double Vm = 0.125 * Hvom[a] * dt * (pn[a2 - ni] + pn[a2]) * (pm[a2 - ni] + pm[a2]) * (oHz(a - ni) + oHz(a));
+        const double den = Ts + T0 + EPS_MP;
+        const double zs = ZU - ZL + lds[cu][Q_ZU][ss] - lds[cu][Q_ZL][ss];
+        double Ck;
+        if (k == 1) Ck = DV(0.25 * (DZk + lds[cu][Q_DZ][ss]) * zs, den);
+        else if (k < N) Ck = DV(0.0625 * (DZk + DZm1 + lds[cu][Q_DZ][ss] + lds[pv][Q_DZ][ss]) * zs, den);
+        else Ck = DV(0.25 * (DZm1 + lds[pv][Q_DZ][ss]) * zs, den);
+        const double Wk = 0.25 * dt * (lds[cu][Q_WC][ss] + WCk);
+        double A = 0.03125 * (lds[pv][Q_GU][se] + Lc.GU + lds[pv][Q_GU][sse] + lds[pv][Q_GU][ss]);
+        A = DV(A * OMU4, den);
+        const double B = DV(T0 - Ts, den);
+        const double Um = 0.03125 * dt * (lds[pv][Q_HU][se] + lds[pv][Q_HU][sse] + Lc.HU + lds[pv][Q_HU][ss]);
+        const double Vm = 0.125 * Lc.Hv * dt * co.PNV * co.PMV * Lc.OHV;
         const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
         const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
         const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
-        const double AA = A * A, BB = B * B, CC = Ck * Ck, AB = A * B, BC = B * Ck;
-        const double XX = X * X, YY = Y * Y, ZZ = Z * Z, XY = X * Y, YZ = Y * Z;
-        const double sig_alfa = DV(1.0, 1.0 - fabs(B) + EPS_MP);
-        const double sig_beta = DV(-B, (1.0 - fabs(B)) * (1.0 - BB) + EPS_MP);
-        const double sig_gama = DV(2.0 * fabs(BB * B), (1.0 - fabs(B)) * (1.0 - BB) * (1.0 - fabs(BB * B)) + EPS_MP);
-        const double sig_a = DV(-A, (1.0 - fabs(B)) * (1.0 - fabs(AB)) + EPS_MP);
-        const double sig_b = DV(AB, (1.0 - fabs(B)) * (1.0 - BB * fabs(A)) + EPS_MP) *
-                             (DV(fabs(A), 1.0 - fabs(AB) + EPS_MP) + DV(2.0 * B, 1.0 - BB + EPS_MP));
-        const double sig_c = DV(fabs(B) * AA, (1.0 - fabs(B)) * (1.0 - AA * fabs(B)) * (1.0 - fabs(AB)) + EPS_MP);
-        const double sig_d = DV(-Ck, (1.0 - fabs(B)) * (1.0 - fabs(BC)) + EPS_MP);
-        const double sig_e = DV(BC, (1.0 - fabs(B)) * (1.0 - BB * fabs(Ck)) + EPS_MP) *
-                             (DV(fabs(Ck), 1.0 - fabs(BC) + EPS_MP) + DV(2.0 * B, 1.0 - BB + EPS_MP));
-        const double sig_f = DV(fabs(B) * CC, (1.0 - fabs(B)) * (1.0 - CC * fabs(B)) * (1.0 - fabs(BC)) + EPS_MP);
-        const double v0 = sig_alfa * Y + sig_beta * YY + sig_gama * YY * Y + sig_a * XY + sig_b * Y * XX +
-                          sig_c * YY * X + sig_d * YZ + sig_e * YY * Z + sig_f * Y * ZZ;
+        double v0;
+        MP_SIGMA(B, A, Ck, Y, X, Z, v0, true)
         va = fmin(fabs(v0), 1.0 * fabs(Vm)) * copysign(1.0, v0);
-        va = VM(va, a2);
+        if constexpr (MASK) va = va * co.vm;
       }
       if (v_wall_n) { if (m.closed[LBS_NORTH]) Va[a] = 0.0; }
       else {
         Va[a] = va;
         // southern edge: Va(i,Jstr) (:612-625); row Jstr is below this kernel's Va range
-        if (b.south_edge && !b.NSperiodic && j == b.Jstr + 1) Va[a - ni] = m.closed[LBS_SOUTH] ? 0.0 : va;
-        if (b.north_edge && !b.NSperiodic && j == b.Jend && !m.closed[LBS_NORTH]) Va[a + ni] = va;
+        if (v_copy_s) Va[a - ni] = m.closed[LBS_SOUTH] ? 0.0 : va;
+        if (v_copy_n) Va[a + ni] = va;
       }
     }
     // ---------------- W face between levels k and k+1 ----------------
     if (do_w) {
       const long aw = a + nij;                 // Wa(i,j,k) in a (0:N) array
       if (k == 1) Wa[a2] = 0.0;                // Wa(i,j,0)
-      if (k == N) { Wa[aw] = 0.0; return; }    // Wa(i,j,N)
-      const double Tu = Ta[a + nij];
-      double wa = 0.0;
-      if (!((T0 <= 0.0) || (Tu <= 0.0) || (fabs(T0 - Tu) <= EPS2_MP))) {
-        const double Ck = DV(Tu - T0, Tu + T0 + EPS_MP);
-        double A = 0.0625 *
-                   (UM((Ta[a + 1 + nij] - Tu) * (pm[a2 + 1] + pm[a2]), a2 + 1) + UM((Tu - Ta[a - 1 + nij]) * (pm[a2] + pm[a2 - 1]), a2) +
-                    UM((Ta[a + 1] - T0) * (pm[a2 + 1] + pm[a2]), a2 + 1) + UM((T0 - Ta[a - 1]) * (pm[a2] + pm[a2 - 1]), a2));
-        double B = 0.0625 *
-                   (VM((Ta[a + ni + nij] - Tu) * (pn[a2 + ni] + pn[a2]), a2 + ni) + VM((Tu - Ta[a - ni + nij]) * (pn[a2] + pn[a2 - ni]), a2) +
-                    VM((Ta[a + ni] - T0) * (pn[a2 + ni] + pn[a2]), a2 + ni) + VM((T0 - Ta[a - ni]) * (pn[a2] + pn[a2 - ni]), a2));
-        A = DV(A * (om_u[a2 + 1] + om_u[a2]), Tu + T0 + EPS_MP);
-        B = DV(B * (on_v[a2 + ni] + on_v[a2]), Tu + T0 + EPS_MP);
-        const double Um = 0.03125 * dt *
-                          (Huon[a] * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a) + oHz(a - 1)) +
-                           Huon[a + nij] * (pm[a2] + pm[a2 - 1]) * (pn[a2] + pn[a2 - 1]) * (oHz(a + nij) + oHz(a - 1 + nij)) +
-                           Huon[a + 1] * (pm[a2] + pm[a2 + 1]) * (pn[a2] + pn[a2 + 1]) * (oHz(a) + oHz(a + 1)) +
-                           Huon[a + 1 + nij] * (pm[a2] + pm[a2 + 1]) * (pn[a2] + pn[a2 + 1]) *
-                               (oHz(a + nij) + oHz(a + 1 + nij)));
-        const double Vm = 0.03125 * dt *
-                          (Hvom[a] * (pm[a2] + pm[a2 - ni]) * (pn[a2] + pn[a2 - ni]) * (oHz(a) + oHz(a - ni)) +
-                           Hvom[a + nij] * (pm[a2] + pm[a2 - ni]) * (pn[a2] + pn[a2 - ni]) * (oHz(a + nij) + oHz(a - ni + nij)) +
-                           Hvom[a + ni] * (pm[a2] + pm[a2 + ni]) * (pn[a2] + pn[a2 + ni]) * (oHz(a) + oHz(a + ni)) +
-                           Hvom[a + ni + nij] * (pm[a2] + pm[a2 + ni]) * (pn[a2] + pn[a2 + ni]) *
-                               (oHz(a + nij) + oHz(a + ni + nij)));
-        const double Wk = Wv[aw] * odzA[a] * pm[a2] * pn[a2] * dt;
-        const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
-        const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
-        const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
-        const double AA = A * A, BB = B * B, CC = Ck * Ck, AC = A * Ck, BC = B * Ck;
-        const double XX = X * X, YY = Y * Y, ZZ = Z * Z, XZ = X * Z, YZ = Y * Z;
-        const double sig_alfa = DV(1.0, 1.0 - fabs(Ck) + EPS_MP);
-        const double sig_beta = DV(-Ck, (1.0 - fabs(Ck)) * (1.0 - CC) + EPS_MP);
-        const double sig_gama = DV(2.0 * fabs(CC * Ck), (1.0 - fabs(Ck)) * (1.0 - CC) * (1.0 - fabs(CC * Ck)) + EPS_MP);
-        const double sig_a = DV(-B, (1.0 - fabs(Ck)) * (1.0 - fabs(BC)) + EPS_MP);
-        const double sig_b = DV(BC, (1.0 - fabs(Ck)) * (1.0 - CC * fabs(B)) + EPS_MP) *
-                             (DV(fabs(B), 1.0 - fabs(BC) + EPS_MP) + DV(2.0 * Ck, 1.0 - CC + EPS_MP));
-        const double sig_c = DV(fabs(Ck) * BB, (1.0 - fabs(Ck)) * (1.0 - B * B * fabs(Ck)) * (1.0 - fabs(BC)) + EPS_MP);
-        const double sig_d = DV(-A, (1.0 - fabs(Ck)) * (1.0 - fabs(AC)) + EPS_MP);
-        const double sig_e = DV(AC, (1.0 - fabs(Ck)) * (1.0 - CC * fabs(A)) + EPS_MP) *
-                             (DV(fabs(A), 1.0 - fabs(AC) + EPS_MP) + DV(2.0 * Ck, 1.0 - CC + EPS_MP));
-        const double sig_f = DV(fabs(Ck) * AA, (1.0 - fabs(Ck)) * (1.0 - AA * fabs(Ck)) * (1.0 - fabs(AC)) + EPS_MP);
-        const double w0 = sig_alfa * Z + sig_beta * ZZ + sig_gama * ZZ * Z + sig_a * YZ + sig_b * ZZ * Y +
-                          sig_c * Z * YY + sig_d * XZ + sig_e * ZZ * X + sig_f * Z * XX;
-        wa = fmin(fabs(w0), 1.0 * fabs(Wk)) * copysign(1.0, w0);
-        if constexpr (MASK) wa = wa * rmk[a2];
+      if (k == N) Wa[aw] = 0.0;                // Wa(i,j,N)
+      else {
+        const int se = so + 1, sn = so + MPX;
+        const double Tu = Ln.Ta;
+        double wa = 0.0;
+        if (!((T0 <= 0.0) || (Tu <= 0.0) || (fabs(T0 - Tu) <= EPS2_MP))) {
+          const double den = Tu + T0 + EPS_MP;
+          const double Ck = DV(Tu - T0, den);
+          double A = 0.0625 * (lds[cu][Q_GU][se] + Ln.GU + lds[pv][Q_GU][se] + Lc.GU);
+          double B = 0.0625 * (lds[cu][Q_GV][sn] + Ln.GV + lds[pv][Q_GV][sn] + Lc.GV);
+          A = DV(A * OMU2, den);
+          B = DV(B * ONV2, den);
+          const double Um = 0.03125 * dt * (Lc.HU + Ln.HU + lds[pv][Q_HU][se] + lds[cu][Q_HU][se]);
+          const double Vm = 0.03125 * dt * (Lc.HV + Ln.HV + lds[pv][Q_HV][sn] + lds[cu][Q_HV][sn]);
+          const double Wk = WZk * co.pm * co.pn * dt;
+          const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
+          const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
+          const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
+          double w0;
+          MP_SIGMA(Ck, B, A, Z, Y, X, w0, false)
+          wa = fmin(fabs(w0), 1.0 * fabs(Wk)) * copysign(1.0, w0);
+          if constexpr (MASK) wa = wa * rm;
+        }
+        Wa[aw] = wa;
       }
-      Wa[aw] = wa;
     }
+    Lc = Ln;
+    DZm1 = DZk;
+    __syncthreads();        // the plane of iteration k-1 is overwritten next
   }
 }
 
 #undef DV
 
-// ------------------------------------------------------ K3: beta_up/dn ----
+// --------------- K3: FCT limiter, limited transports, update, tridiagonal ----
+// mpdata_adiff.F:842-1100 (beta_up / beta_dn, the limited Ua, Va, Wa) + step3d_t.F:1235-1316 (corrected advection of
+// Ta) + :1431-1501 (classic tridiagonal vertical diffusion) in ONE level-marching kernel: the limiter factors of a
+// level live in LDS only (66 x (TY+2) cells: the tile and a one-cell ring, evaluated by the tile's threads), so
+// beta_up / beta_dn are never written to memory, and Ta, Ua, Va, Wa are read once instead of twice.
+//   iteration k:  beta(k) of own + ring cell -> LDS | barrier | limited horizontal fluxes of level k (neighbours'
+//                 beta from LDS), limited vertical flux through the face below (own beta(k-1), beta(k)), which
+//                 completes level k-1: forward elimination of the tridiagonal for k-1.
 // MASK: every term of the extrema times mask_up = rmask (land values out of Tmax) / mask_dn = 1 on water, 1e20 on
-// land (out of Tmin) of its column, mpdata_adiff.F:826-835.
+// land (out of Tmin) of its column (mpdata_adiff.F:826-835); the limited transports times umask / vmask / rmask
+// (:991, :1006, :1022) and the new tracer times rmask (step3d_t.F:1586-1596).
+struct MpBeta { double up, dn; };
+
+// beta_up, beta_dn of cell (index a2, level k) straight from memory (ring cells)
 template <bool MASK>
-__global__ void __launch_bounds__(BLK_X *BLK_Y)
-k_mp_beta(const RomsDev *__restrict__ c, MpArgs m)
+__device__ __forceinline__ MpBeta mp_beta_cell(const RomsDev *__restrict__ c, const MpArgs &m, gcd_t t3, long a2, int k, int N,
+                                               long ni, long nij)
 {
-  DEV_PROLOGUE(c)
-  const TileLv XB = decode_tile_level(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1, N);
-  if (!XB.valid) return;
-  const int i = b.IstrU - 1 + XB.bx * BLK_X + threadIdx.x;
-  const int j = b.JstrV - 1 + XB.by * BLK_Y + threadIdx.y;
-  if (i > b.Iendp1 || j > b.Jendp1) return;
   const gcd_t Ta = (gcd_t)m.Ta, Ua = (gcd_t)m.Ua, Va = (gcd_t)m.Va, Wa = (gcd_t)m.Wa;
-  const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (m.itrc - 1)) * n3r);
-  const gd_t bup = (gd_t)m.bup, bdn = (gd_t)m.bdn;
-  const long a2 = I2(i, j);
-  {
-    const int k = XB.k0 + 1;                                     // one thread per (i,j,k)
-    const long a = a2 + (long)(k - 1) * nij;
-    const long aw = a + nij;                                     // Wa(i,j,k); Wa(i,j,k-1) = Wa[a]
-    const double T0 = Ta[a], Tw = Ta[a - 1], Te = Ta[a + 1], Ts = Ta[a - ni], Tn = Ta[a + ni];
-    double Tmax, Tmin;
-    if constexpr (!MASK) {
-      Tmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
-                            t3[a - ni]), Tn), t3[a + ni]);
-      Tmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
-                            t3[a - ni]), Tn), t3[a + ni]);
-      if (k > 1) {
-        Tmax = fmax(fmax(Tmax, Ta[a - nij]), t3[a - nij]);
-        Tmin = fmin(fmin(Tmin, Ta[a - nij]), t3[a - nij]);
-      }
-      if (k < N) {
-        Tmax = fmax(fmax(Tmax, Ta[a + nij]), t3[a + nij]);
-        Tmin = fmin(fmin(Tmin, Ta[a + nij]), t3[a + nij]);
-      }
-    } else {
-      const gcd_t rmk = (gcd_t)c->F.rmask;
-      const double Large = 1.0E+20;
-      auto mdn = [&](double r) { return fmax(1.0, fmin(Large, (1.0 - r) * Large)); };
-      const double mu0 = rmk[a2], md0 = mdn(mu0);
-      Tmax = T0 * mu0;
-      Tmin = T0 * md0;
-      auto take = [&](double mu, double md, double x) { Tmax = fmax(Tmax, x * mu); Tmin = fmin(Tmin, x * md); };
-      take(mu0, md0, t3[a]);
-      const long dq[4] = {-1, 1, -(long)ni, (long)ni};
-      const double Tq[4] = {Tw, Te, Ts, Tn};
+  const long a = a2 + (long)(k - 1) * nij;
+  const long aw = a + nij;                                     // Wa(i,j,k); Wa(i,j,k-1) = Wa[a]
+  const double T0 = Ta[a], Tw = Ta[a - 1], Te = Ta[a + 1], Ts = Ta[a - ni], Tn = Ta[a + ni];
+  double Tmax, Tmin;
+  if constexpr (!MASK) {
+    Tmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
+                          t3[a - ni]), Tn), t3[a + ni]);
+    Tmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
+                          t3[a - ni]), Tn), t3[a + ni]);
+    if (k > 1) {
+      Tmax = fmax(fmax(Tmax, Ta[a - nij]), t3[a - nij]);
+      Tmin = fmin(fmin(Tmin, Ta[a - nij]), t3[a - nij]);
+    }
+    if (k < N) {
+      Tmax = fmax(fmax(Tmax, Ta[a + nij]), t3[a + nij]);
+      Tmin = fmin(fmin(Tmin, Ta[a + nij]), t3[a + nij]);
+    }
+  } else {
+    const gcd_t rmk = (gcd_t)c->F.rmask;
+    const double Large = 1.0E+20;
+    auto mdn = [&](double r) { return fmax(1.0, fmin(Large, (1.0 - r) * Large)); };
+    const double mu0 = rmk[a2], md0 = mdn(mu0);
+    Tmax = T0 * mu0;
+    Tmin = T0 * md0;
+    auto take = [&](double mu, double md, double x) { Tmax = fmax(Tmax, x * mu); Tmin = fmin(Tmin, x * md); };
+    take(mu0, md0, t3[a]);
+    const long dq[4] = {-1, 1, -(long)ni, (long)ni};
+    const double Tq[4] = {Tw, Te, Ts, Tn};
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const double mu = rmk[a2 + dq[q]], md = mdn(mu);
-        take(mu, md, Tq[q]);
-        take(mu, md, t3[a + dq[q]]);
-      }
-      if (k > 1) { take(mu0, md0, Ta[a - nij]); take(mu0, md0, t3[a - nij]); }
-      if (k < N) { take(mu0, md0, Ta[a + nij]); take(mu0, md0, t3[a + nij]); }
+    for (int q = 0; q < 4; q++) {
+      const double mu = rmk[a2 + dq[q]], md = mdn(mu);
+      take(mu, md, Tq[q]);
+      take(mu, md, t3[a + dq[q]]);
     }
-    const double ua0 = Ua[a], ua1 = Ua[a + 1], va0 = Va[a], va1 = Va[a + ni];
-    double cff1 = Tw * fmax(0.0, ua0) - Te * fmin(0.0, ua1) + Ts * fmax(0.0, va0) - Tn * fmin(0.0, va1);
-    double cff2 = T0 * fmax(0.0, ua1) - T0 * fmin(0.0, ua0) + T0 * fmax(0.0, va1) - T0 * fmin(0.0, va0);
-    if (k == 1) {
-      cff1 = cff1 - Ta[a + nij] * fmin(0.0, Wa[aw]);
-      cff2 = cff2 + T0 * fmax(0.0, Wa[aw]);
-    } else if (k < N) {
-      cff1 = cff1 + Ta[a - nij] * fmax(0.0, Wa[a]) - Ta[a + nij] * fmin(0.0, Wa[aw]);
-      cff2 = cff2 + T0 * fmax(0.0, Wa[aw]) - T0 * fmin(0.0, Wa[a]);
-    } else {
-      cff1 = cff1 + Ta[a - nij] * fmax(0.0, Wa[a]);
-      cff2 = cff2 - T0 * fmin(0.0, Wa[a]);
-    }
-    bup[a] = (Tmax - T0) / (cff1 + EPS_MP);
-    bdn[a] = (T0 - Tmin) / (cff2 + EPS_MP);
+    if (k > 1) { take(mu0, md0, Ta[a - nij]); take(mu0, md0, t3[a - nij]); }
+    if (k < N) { take(mu0, md0, Ta[a + nij]); take(mu0, md0, t3[a + nij]); }
   }
+  const double ua0 = Ua[a], ua1 = Ua[a + 1], va0 = Va[a], va1 = Va[a + ni];
+  double cff1 = Tw * fmax(0.0, ua0) - Te * fmin(0.0, ua1) + Ts * fmax(0.0, va0) - Tn * fmin(0.0, va1);
+  double cff2 = T0 * fmax(0.0, ua1) - T0 * fmin(0.0, ua0) + T0 * fmax(0.0, va1) - T0 * fmin(0.0, va0);
+  if (k == 1) {
+    cff1 = cff1 - Ta[a + nij] * fmin(0.0, Wa[aw]);
+    cff2 = cff2 + T0 * fmax(0.0, Wa[aw]);
+  } else if (k < N) {
+    cff1 = cff1 + Ta[a - nij] * fmax(0.0, Wa[a]) - Ta[a + nij] * fmin(0.0, Wa[aw]);
+    cff2 = cff2 + T0 * fmax(0.0, Wa[aw]) - T0 * fmin(0.0, Wa[a]);
+  } else {
+    cff1 = cff1 + Ta[a - nij] * fmax(0.0, Wa[a]);
+    cff2 = cff2 - T0 * fmin(0.0, Wa[a]);
+  }
+  MpBeta r;
+  r.up = (Tmax - T0) / (cff1 + EPS_MP);
+  r.dn = (T0 - Tmin) / (cff2 + EPS_MP);
+  return r;
 }
 
-// -------------------------- K4: limited transports, update, tridiagonal ----
-// MASK: the limited transports times umask / vmask / rmask (mpdata_adiff.F:991, :1006, :1022) and the new tracer
-// times rmask (step3d_t.F:1586-1596).
-template <int NMAX, bool MASK>
-__global__ void __launch_bounds__(BLK_X *BLK_Y)
+template <int TY, bool MASK>
+__global__ void __launch_bounds__(BLK_X *TY)
 k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
 {
   DEV_PROLOGUE(c)
+  constexpr int PY = TY + 2, PC = MPX * PY;
+  __shared__ double lb[2][2][PC];           // [plane][beta_up / beta_dn][cell of the 66 x (TY+2) tile]
   const Blk XB = xcd_block();
-  const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
-  const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
-  if (i > b.Iend || j > b.Jend) return;
+  const int i0 = b.Istr + XB.x * BLK_X, j0 = b.Jstr + XB.y * TY;
+  const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
+  const int tid = threadIdx.y * BLK_X + threadIdx.x;
+  const bool own = i <= b.Iend && j <= b.Jend;
   const double dt = c->p.dt;
   const gcd_t Ta = (gcd_t)m.Ta, Ua = (gcd_t)m.Ua, Va = (gcd_t)m.Va, Wa = (gcd_t)m.Wa;
-  const gcd_t bup = (gcd_t)m.bup, bdn = (gcd_t)m.bdn;
   const gcd_t Hz = (gcd_t)c->F.Hz, z_r = (gcd_t)c->F.z_r;
+  const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (m.itrc - 1)) * n3r);
   const int ltrc = m.itrc < b.NAT ? m.itrc : b.NAT;
   const gcd_t Akt = (gcd_t)(c->F.Akt + (long)(ltrc - 1) * n3w);
   const gd_t tn = (gd_t)(c->F.t + ((long)(m.nnew - 1) + 3L * (m.itrc - 1)) * n3r);
-  const long a2 = I2(i, j);
+  const int so = (threadIdx.y + 1) * MPX + threadIdx.x + 1;
+  // ring cell of this thread: rows 0 and TY+1, then columns 0 and 65 of rows 1..TY.  beta exists on
+  // IstrU-1:Iendp1 x JstrV-1:Jendp1 (mpdata_adiff.F:842); ring cells outside it (physical walls) carry zeros,
+  // their faces take the wall rule below.
+  int sh = -1, ih = 0, jh = 0;
+  if (tid < 2 * MPX) { const int r = tid / MPX, x = tid - r * MPX; sh = (r ? (PY - 1) * MPX : 0) + x; ih = i0 - 1 + x; jh = j0 - 1 + (r ? PY - 1 : 0); }
+  else if (tid < 2 * MPX + 2 * TY) { const int q = tid - 2 * MPX, y = 1 + (q >> 1), x = (q & 1) ? MPX - 1 : 0; sh = y * MPX + x; ih = i0 - 1 + x; jh = j0 - 1 + y; }
+  const bool halo = sh >= 0 && ih >= b.IstrU - 1 && ih <= b.Iendp1 && jh >= b.JstrV - 1 && jh <= b.Jendp1;
+  const long a2h = halo ? I2(ih, jh) : 0;
+  // the tile's own slots beyond Iend / Jend (partial workgroups) still owe their beta to the last own column / row
+  const bool cellb = i <= b.Iendp1 && j <= b.Jendp1;
+  const long a2 = cellb ? I2(i, j) : I2(b.Istr, b.Jstr);
   const double cffa = 1.0 / dt;                                   // mpdata_adiff.F:254
   const double cpp = dt * GF(pm)[a2] * GF(pn)[a2];
   const double omu0 = GF(om_u)[a2], omu1 = GF(om_u)[a2 + 1], onv0 = GF(on_v)[a2], onv1 = GF(on_v)[a2 + ni];
@@ -475,104 +599,126 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
   const bool v1_wall = b.north_edge && !b.NSperiodic && j == b.Jend;       // Va(i,Jend+1)
   const bool u0_wall = b.west_edge && !b.EWperiodic && i == b.Istr;        // Ua(Istr,j)
   const bool u1_wall = b.east_edge && !b.EWperiodic && i == b.Iend;        // Ua(Iend+1,j)
-  auto lim_u = [&](long x, double om) {       // limited Ua at index x (face between x-1 and x), :1034-1040
-    const double cff1 = fmin(fmin(bdn[x - 1], bup[x]), 1.0);
-    const double cff2 = fmin(fmin(bup[x - 1], bdn[x]), 1.0);
-    return (cff1 * fmax(0.0, Ua[x]) + cff2 * fmin(0.0, Ua[x])) * cffa * om;
-  };
-  auto lim_v = [&](long x, double on) {       // :1042-1049
-    const double cff1 = fmin(fmin(bdn[x - ni], bup[x]), 1.0);
-    const double cff2 = fmin(fmin(bup[x - ni], bdn[x]), 1.0);
-    return (cff1 * fmax(0.0, Va[x]) + cff2 * fmin(0.0, Va[x])) * cffa * on;
-  };
   double um0 = 1.0, um1 = 1.0, vm0 = 1.0, vm1 = 1.0, rm0 = 1.0;
   if constexpr (MASK) {
     um0 = GF(umask)[a2]; um1 = GF(umask)[a2 + 1]; vm0 = GF(vmask)[a2]; vm1 = GF(vmask)[a2 + ni]; rm0 = GF(rmask)[a2];
   }
-  double DCm[NMAX + 1];      // right-hand side / solution
-  double CFm[NMAX + 1];
-  double FCm1 = 0.0;         // corrected vertical flux through the bottom face
-#pragma unroll
-  for (int k = 1; k <= NMAX; k++) {
-    if (k <= N) {
-      const long a = a2 + (long)(k - 1) * nij;
-      const double T0 = Ta[a], hz = Hz[a];
-      double u0 = lim_u(a, omu0), u1 = lim_u(a + 1, omu1);
-      double v0 = lim_v(a, onv0), v1 = lim_v(a + ni, onv1);
-      if constexpr (MASK) { u0 = u0 * um0; u1 = u1 * um1; v0 = v0 * vm0; v1 = v1 * vm1; }
-      {
-        const double u0i = u0, u1i = u1, v0i = v0, v1i = v1;
-        if (u0_wall) u0 = m.closed[LBS_WEST] ? 0.0 : u1i;
-        if (u1_wall) u1 = m.closed[LBS_EAST] ? 0.0 : u0i;
-        if (v0_wall) v0 = m.closed[LBS_SOUTH] ? 0.0 : v1i;
-        if (v1_wall) v1 = m.closed[LBS_NORTH] ? 0.0 : v0i;
-      }
-      // corrected horizontal fluxes, step3d_t.F:1238-1255
-      const double FXi = (fmax(u0, 0.0) * Ta[a - 1] + fmin(u0, 0.0) * T0) * 0.5 * (hz + Hz[a - 1]) * onu0;
-      const double FXip1 = (fmax(u1, 0.0) * T0 + fmin(u1, 0.0) * Ta[a + 1]) * 0.5 * (Hz[a + 1] + hz) * onu1;
-      const double FEj = (fmax(v0, 0.0) * Ta[a - ni] + fmin(v0, 0.0) * T0) * 0.5 * (hz + Hz[a - ni]) * omv0;
-      const double FEjp1 = (fmax(v1, 0.0) * T0 + fmin(v1, 0.0) * Ta[a + ni]) * 0.5 * (Hz[a + ni] + hz) * omv1;
-      const double cff1 = cpp * (FXip1 - FXi);
-      const double cff2 = cpp * (FEjp1 - FEj);
-      const double cff3 = cff1 + cff2;
-      double tv = T0 * hz - cff3;                                 // :1265
-      // corrected vertical flux through the top face, :1281-1290 with the limited Wa (:1051-1060)
-      double FCk = 0.0;
-      if (k < N) {
-        const long aw = a + nij;
-        const double c1 = fmin(fmin(bdn[a], bup[a + nij]), 1.0);
-        const double c2 = fmin(fmin(bup[a], bdn[a + nij]), 1.0);
-        double w = (c1 * fmax(0.0, Wa[aw]) + c2 * fmin(0.0, Wa[aw])) * cffa * omn * (z_r[a + nij] - z_r[a]);
-        if constexpr (MASK) w = w * rm0;
-        FCk = fmax(w, 0.0) * T0 + fmin(w, 0.0) * Ta[a + nij];
-      }
-      tv = tv - cpp * (FCk - FCm1);                               // :1305 (m Tunits)
-      FCm1 = FCk;
-      DCm[k] = tv;
-    }
-  }
-  // classic tridiagonal, step3d_t.F:1431-1501
   const double cfl = -dt * c->p.lambda;
-  double FCprev = 0.0;       // FC(k-1)
-  double CFprev = 0.0, DCprev = 0.0;
-#pragma unroll
-  for (int k = 1; k <= NMAX; k++) {
-    if (k <= N) {
+  // The eliminated right-hand side DC(k) is parked in t(nnew) itself and CF(k) in a scratch array (the round-2
+  // beta_up storage): a rolled level loop with a few dozen live registers instead of two N-long register arrays
+  // under full unrolling.  The back substitution reads them again in reverse order, a workgroup's own 2 x 30 x 4 KB
+  // straight after writing them.
+  const gd_t CFg = (gd_t)m.bup;
+  // carried from level to level (own column)
+  double bup_p = 0.0, bdn_p = 0.0;   // beta(k-1)
+  double T_p = 0.0;                  // Ta(k-1)
+  double tvh_p = 0.0;                // Ta*Hz - horizontal divergence of level k-1
+  double hz_p = 0.0, zr_p = 0.0;     // Hz(k-1), z_r(k-1)
+  double FCadv_pp = 0.0;             // limited advective flux through the face below level k-1
+  double FCd_pp = 0.0;               // diffusion coefficient FC(k-2) of the tridiagonal
+  double CF_pp = 0.0, DC_pp = 0.0;   // CF(k-2), DC(k-2) after elimination
+  for (int k = 1; k <= N + 1; k++) {
+    {
       const long a = a2 + (long)(k - 1) * nij;
-      double FCk = 0.0;
-      if (k < N) {
-        const double cff1 = 1.0 / (z_r[a + nij] - z_r[a]);
-        FCk = cfl * cff1 * Akt[a + nij];                          // Akt(i,j,k)
+      double bup = 0.0, bdn = 0.0, T0 = 0.0, tvh = 0.0, hz = 0.0, zr = 0.0, FCadv_p = 0.0;
+      if (k <= N) {
+        // ---- beta(k): own and ring cell
+        MpBeta bo{0.0, 0.0};
+        if (cellb) bo = mp_beta_cell<MASK>(c, m, t3, a2, k, N, ni, nij);
+        bup = bo.up; bdn = bo.dn;
+        const int pl = k & 1;
+        lb[pl][0][so] = bup; lb[pl][1][so] = bdn;
+        if (sh >= 0) {
+          MpBeta bh{0.0, 0.0};
+          if (halo) bh = mp_beta_cell<MASK>(c, m, t3, a2h, k, N, ni, nij);
+          lb[pl][0][sh] = bh.up; lb[pl][1][sh] = bh.dn;
+        }
+        __syncthreads();
+        if (own) {
+          // ---- limited horizontal transports of level k (mpdata_adiff.F:1034-1049) and corrected fluxes
+          const double bupW = lb[pl][0][so - 1], bdnW = lb[pl][1][so - 1], bupE = lb[pl][0][so + 1], bdnE = lb[pl][1][so + 1];
+          const double bupS = lb[pl][0][so - MPX], bdnS = lb[pl][1][so - MPX], bupN = lb[pl][0][so + MPX], bdnN = lb[pl][1][so + MPX];
+          const double ua0 = Ua[a], ua1 = Ua[a + 1], va0 = Va[a], va1 = Va[a + ni];
+          T0 = Ta[a]; hz = Hz[a]; zr = z_r[a];
+          double u0 = (fmin(fmin(bdnW, bup), 1.0) * fmax(0.0, ua0) + fmin(fmin(bupW, bdn), 1.0) * fmin(0.0, ua0)) * cffa * omu0;
+          double u1 = (fmin(fmin(bdn, bupE), 1.0) * fmax(0.0, ua1) + fmin(fmin(bup, bdnE), 1.0) * fmin(0.0, ua1)) * cffa * omu1;
+          double v0 = (fmin(fmin(bdnS, bup), 1.0) * fmax(0.0, va0) + fmin(fmin(bupS, bdn), 1.0) * fmin(0.0, va0)) * cffa * onv0;
+          double v1 = (fmin(fmin(bdn, bupN), 1.0) * fmax(0.0, va1) + fmin(fmin(bup, bdnN), 1.0) * fmin(0.0, va1)) * cffa * onv1;
+          if constexpr (MASK) { u0 = u0 * um0; u1 = u1 * um1; v0 = v0 * vm0; v1 = v1 * vm1; }
+          {
+            const double u0i = u0, u1i = u1, v0i = v0, v1i = v1;
+            if (u0_wall) u0 = m.closed[LBS_WEST] ? 0.0 : u1i;
+            if (u1_wall) u1 = m.closed[LBS_EAST] ? 0.0 : u0i;
+            if (v0_wall) v0 = m.closed[LBS_SOUTH] ? 0.0 : v1i;
+            if (v1_wall) v1 = m.closed[LBS_NORTH] ? 0.0 : v0i;
+          }
+          // corrected horizontal fluxes, step3d_t.F:1238-1255
+          const double FXi = (fmax(u0, 0.0) * Ta[a - 1] + fmin(u0, 0.0) * T0) * 0.5 * (hz + Hz[a - 1]) * onu0;
+          const double FXip1 = (fmax(u1, 0.0) * T0 + fmin(u1, 0.0) * Ta[a + 1]) * 0.5 * (Hz[a + 1] + hz) * onu1;
+          const double FEj = (fmax(v0, 0.0) * Ta[a - ni] + fmin(v0, 0.0) * T0) * 0.5 * (hz + Hz[a - ni]) * omv0;
+          const double FEjp1 = (fmax(v1, 0.0) * T0 + fmin(v1, 0.0) * Ta[a + ni]) * 0.5 * (Hz[a + ni] + hz) * omv1;
+          const double cff1 = cpp * (FXip1 - FXi);
+          const double cff2 = cpp * (FEjp1 - FEj);
+          const double cff3 = cff1 + cff2;
+          tvh = T0 * hz - cff3;                                     // :1265
+          // limited vertical transport through the face between k-1 and k (:1051-1060), corrected flux :1281-1290
+          if (k > 1) {
+            const double c1 = fmin(fmin(bdn_p, bup), 1.0);
+            const double c2 = fmin(fmin(bup_p, bdn), 1.0);
+            const double wa = Wa[a];                                // Wa(i,j,k-1)
+            double w = (c1 * fmax(0.0, wa) + c2 * fmin(0.0, wa)) * cffa * omn * (zr - zr_p);
+            if constexpr (MASK) w = w * rm0;
+            FCadv_p = fmax(w, 0.0) * T_p + fmin(w, 0.0) * T0;
+          }
+        }
       }
-      const double BCk = Hz[a] - FCk - FCprev;
-      if (k == 1) {
-        const double cff = 1.0 / BCk;
-        CFm[1] = cff * FCk;
-        DCm[1] = cff * DCm[1];
-      } else if (k < N) {
-        const double cff = 1.0 / (BCk - FCprev * CFprev);
-        CFm[k] = cff * FCk;
-        DCm[k] = cff * (DCm[k] - FCprev * DCprev);
-      } else {
-        DCm[k] = (DCm[k] - FCprev * DCprev) / (BCk - FCprev * CFprev);
+      // ---- level kk = k-1 is complete: vertical advection (:1305), forward elimination of the classic
+      //      tridiagonal (step3d_t.F:1431-1501)
+      if (own && k > 1) {
+        const int kk = k - 1;
+        const double tv = tvh_p - cpp * (FCadv_p - FCadv_pp);
+        double FCd = 0.0;
+        if (kk < N) {
+          const double cff1 = 1.0 / (zr - zr_p);
+          FCd = cfl * cff1 * Akt[a];                                // Akt(i,j,kk)
+        }
+        const double BC = hz_p - FCd - FCd_pp;
+        double CFk = 0.0, DCk;
+        if (kk == 1) {
+          const double cff = 1.0 / BC;
+          CFk = cff * FCd;
+          DCk = cff * tv;
+        } else if (kk < N) {
+          const double cff = 1.0 / (BC - FCd_pp * CF_pp);
+          CFk = cff * FCd;
+          DCk = cff * (tv - FCd_pp * DC_pp);
+        } else {
+          DCk = (tv - FCd_pp * DC_pp) / (BC - FCd_pp * CF_pp);
+        }
+        tn[a - nij] = DCk;
+        CFg[a - nij] = CFk;
+        CF_pp = CFk;
+        DC_pp = DCk;
+        FCd_pp = FCd;
+        FCadv_pp = FCadv_p;
       }
-      CFprev = CFm[k < N ? k : 1];
-      DCprev = DCm[k];
-      FCprev = FCk;
+      bup_p = bup; bdn_p = bdn; T_p = T0; tvh_p = tvh; hz_p = hz; zr_p = zr;
     }
   }
-  double up = 0.0;
-#pragma unroll
-  for (int k = NMAX; k >= 1; k--) {
-    if (k <= N) {
-      const long a = a2 + (long)(k - 1) * nij;
-      double v;
-      if (k == N) v = DCm[k];
-      else v = DCm[k] - CFm[k] * up;
-      up = v;
-      if constexpr (MASK) v = v * rm0;
-      tn[a] = v;
-    }
+  if (!own) return;
+  // back substitution; DC_pp = DC(N) is the top value.  A lane reads back only what it stored itself.
+  double up = DC_pp;
+  {
+    double v = up;
+    if constexpr (MASK) v = v * rm0;
+    tn[a2 + (long)(N - 1) * nij] = v;
+  }
+  for (int k = N - 1; k >= 1; k--) {
+    const long a = a2 + (long)(k - 1) * nij;
+    double v = tn[a] - CFg[a] * up;
+    up = v;
+    if constexpr (MASK) v = v * rm0;
+    tn[a] = v;
   }
 }
 
@@ -583,7 +729,6 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
 {
   const roms_bounds_t &b = g_ctx.b;
   if (b.NghostPoints != 3) return roms_fail("roms_hip_step3d_t", "MPDATA needs NghostPoints = 3 (inp_par.F:266-278)");
-  if (b.N > ROMS_MAXN) return roms_fail("roms_hip_step3d_t", "N > 64 not instantiated");
   int rc;
   const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
   // three-point footprint: refresh the ghost points of t(nnew) first, step3d_t.F:369-386
@@ -608,25 +753,18 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
   }
   KERNEL_CHECK("k_mp_ta");
   {
-    dim3 g3 = grid_tile_level(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1, b.N);
+    dim3 g3 = grid2d(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1);
     void (*kern)(const RomsDev *, MpArgs) = g_ctx.p.masking ? (g_ctx.p.mpdata_fast ? k_mp_adiff<true, true> : k_mp_adiff<false, true>)
                                 : (g_ctx.p.mpdata_fast ? k_mp_adiff<true, false> : k_mp_adiff<false, false>);
     hipLaunchKernelGGL(kern, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
   }
   KERNEL_CHECK("k_mp_adiff");
-  {
-    dim3 g3 = grid_tile_level(b.Iendp1 - (b.IstrU - 1) + 1, b.Jendp1 - (b.JstrV - 1) + 1, b.N);
-    void (*beta)(const RomsDev *, MpArgs) = g_ctx.p.masking ? k_mp_beta<true> : k_mp_beta<false>;
-    hipLaunchKernelGGL(beta, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
-  }
-  KERNEL_CHECK("k_mp_beta");
-  const dim3 g = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
+  constexpr int UTY = 8;                 // rows per workgroup of the fused limiter + update kernel
+  const dim3 g((unsigned)((b.Iend - b.Istr + 1 + BLK_X - 1) / BLK_X), (unsigned)((b.Jend - b.Jstr + 1 + UTY - 1) / UTY), 1);
   const bool mk = g_ctx.p.masking != 0;
   void (*upd)(const RomsDev *, MpArgs);
-  if (b.N <= 16) upd = mk ? k_mp_update<16, true> : k_mp_update<16, false>;
-  else if (b.N <= 32) upd = mk ? k_mp_update<32, true> : k_mp_update<32, false>;
-  else upd = mk ? k_mp_update<ROMS_MAXN, true> : k_mp_update<ROMS_MAXN, false>;
-  hipLaunchKernelGGL(upd, g, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+  upd = mk ? k_mp_update<UTY, true> : k_mp_update<UTY, false>;
+  hipLaunchKernelGGL(upd, g, dim3(BLK_X, UTY, 1), 0, g_ctx.stream, g_ctx.devc, m);
   KERNEL_CHECK("k_mp_update");
   return 0;
 }
