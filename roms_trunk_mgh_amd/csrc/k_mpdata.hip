@@ -117,25 +117,18 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
   }
 }
 
-// Quotient n/d.  Exact variant: the IEEE division of the reference (bit-identical results).  FAST variant
-// (roms_params_t.mpdata_fast): n times a reciprocal from v_rcp_f64 refined by two Newton steps (explicit FMAs,
-// within ~1 ulp of 1/d) -- one reciprocal per distinct denominator, the compiler merges the three quotients of
-// a face that share the tracer sum.  The IEEE division costs ~30 VALU instructions on gfx950, the refined
-// reciprocal 5, and this kernel evaluates 49 quotients per cell; validated against the oracle at the north-star
-// bound (1e-10 relative RMS after 100 steps, tests/test_gpu_mpdata.py).
-template <bool FAST>
-__device__ __forceinline__ double mp_div(double n, double d)
+// Reciprocal of the FAST variant (roms_params_t.mpdata_fast): v_rcp_f64 refined by one Newton step (explicit FMAs) --
+// one reciprocal per distinct denominator, the compiler merges the quotients of a face that share one.  The IEEE
+// division costs ~11 FP64 instructions on gfx950 (two of them quarter rate) and this kernel evaluates 45 quotients
+// per cell; validated against the oracle at the north-star bound (1e-10 relative RMS after 100 steps,
+// tests/test_gpu_mpdata.py).  The exact variant divides as the reference does (bit-identical results).
+__device__ __forceinline__ double mp_rcp(double d)
 {
-  if constexpr (FAST) {
-    double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    return n * r;
-  } else {
-    return n / d;
-  }
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  return r;
 }
-#define DV(n, d) mp_div<FAST>((n), (d))
 
 // ------------------------------------------------- K2: Ua, Va, Wa (raw) ----
 // LDS-tiled and level-marching.  A workgroup of 64 x 4 threads owns the faces of 64 x 4 columns and walks from the
@@ -263,7 +256,7 @@ __device__ __forceinline__ void mp_cellq(const MpRaw &r, const MpCol &cc, MpSlid
 // direction, Q, R the other two, Xp, Xq, Xr the matching first-order velocities.  SWAPBC: the eta face of the
 // reference multiplies sig_b with Xp*Xq^2 and sig_c with Xp^2*Xq (mpdata_adiff.F:556-560), the other two the
 // other way round (:376-380, :786-790).
-#define MP_SIGMA(P, Q, R, Xp, Xq, Xr, OUT, SWAPBC)                                                                    \
+#define MP_SIGMA_EXACT(P, Q, R, Xp, Xq, Xr, OUT, SWAPBC)                                                                    \
   {                                                                                                                   \
     const double PP = P * P, QQ = Q * Q, RR = R * R, PQ = P * Q, PR = P * R;                                          \
     const double XpXp = Xp * Xp, XqXq = Xq * Xq, XrXr = Xr * Xr, XpXq = Xp * Xq, XpXr = Xp * Xr;                      \
@@ -278,6 +271,53 @@ __device__ __forceinline__ void mp_cellq(const MpRaw &r, const MpCol &cc, MpSlid
     const double sig_e = DV(PR, (1.0 - fabs(P)) * (1.0 - PP * fabs(R)) + EPS_MP) *                                    \
                          (DV(fabs(R), 1.0 - fabs(PR) + EPS_MP) + DV(2.0 * P, 1.0 - PP + EPS_MP));                     \
     const double sig_f = DV(fabs(P) * RR, (1.0 - fabs(P)) * (1.0 - RR * fabs(P)) * (1.0 - fabs(PR)) + EPS_MP);        \
+    if (SWAPBC)                                                                                                       \
+      OUT = sig_alfa * Xp + sig_beta * XpXp + sig_gama * XpXp * Xp + sig_a * XpXq + sig_b * Xp * XqXq +               \
+            sig_c * XpXp * Xq + sig_d * XpXr + sig_e * XpXp * Xr + sig_f * Xp * XrXr;                                 \
+    else                                                                                                              \
+      OUT = sig_alfa * Xp + sig_beta * XpXp + sig_gama * XpXp * Xp + sig_a * XpXq + sig_b * XpXp * Xq +               \
+            sig_c * Xp * XqXq + sig_d * XpXr + sig_e * XpXp * Xr + sig_f * Xp * XrXr;                                 \
+  }
+
+// FAST variant: the twelve denominators of a face are inverted together (prefix products, ONE refined reciprocal,
+// then the individual inverses by back-multiplication: 33 multiplications instead of eleven more reciprocals).
+// Every denominator carries the reference's +eps and lies in [1e-18, ~2], so the product stays in range.
+template <int NQ>
+__device__ __forceinline__ void mp_batch_rcp(const double (&d)[NQ], double (&inv)[NQ])
+{
+  double pre[NQ];
+  pre[0] = d[0];
+#pragma unroll
+  for (int q = 1; q < NQ; q++) pre[q] = pre[q - 1] * d[q];
+  double r = mp_rcp(pre[NQ - 1]);
+#pragma unroll
+  for (int q = NQ - 1; q >= 1; q--) {
+    inv[q] = r * pre[q - 1];
+    r = r * d[q];
+  }
+  inv[0] = r;
+}
+#define MP_SIGMA_FAST(P, Q, R, Xp, Xq, Xr, OUT, SWAPBC)                                                               \
+  {                                                                                                                   \
+    const double PP = P * P, QQ = Q * Q, RR = R * R, PQ = P * Q, PR = P * R;                                          \
+    const double XpXp = Xp * Xp, XqXq = Xq * Xq, XrXr = Xr * Xr, XpXq = Xp * Xq, XpXr = Xp * Xr;                      \
+    const double omP = 1.0 - fabs(P), omPP = 1.0 - PP, omPQ = 1.0 - fabs(PQ), omPR = 1.0 - fabs(PR);                  \
+    const double dd[12] = {omP + EPS_MP, omP * omPP + EPS_MP, omP * omPP * (1.0 - fabs(PP * P)) + EPS_MP,             \
+                           omP * omPQ + EPS_MP, omP * (1.0 - PP * fabs(Q)) + EPS_MP, omPQ + EPS_MP, omPP + EPS_MP,    \
+                           omP * (1.0 - QQ * fabs(P)) * omPQ + EPS_MP, omP * omPR + EPS_MP,                           \
+                           omP * (1.0 - PP * fabs(R)) + EPS_MP, omPR + EPS_MP,                                        \
+                           omP * (1.0 - RR * fabs(P)) * omPR + EPS_MP};                                               \
+    double iv[12];                                                                                                    \
+    mp_batch_rcp<12>(dd, iv);                                                                                         \
+    const double sig_alfa = iv[0];                                                                                    \
+    const double sig_beta = -P * iv[1];                                                                               \
+    const double sig_gama = 2.0 * fabs(PP * P) * iv[2];                                                               \
+    const double sig_a = -Q * iv[3];                                                                                  \
+    const double sig_b = PQ * iv[4] * (fabs(Q) * iv[5] + 2.0 * P * iv[6]);                                            \
+    const double sig_c = fabs(P) * QQ * iv[7];                                                                        \
+    const double sig_d = -R * iv[8];                                                                                  \
+    const double sig_e = PR * iv[9] * (fabs(R) * iv[10] + 2.0 * P * iv[6]);                                           \
+    const double sig_f = fabs(P) * RR * iv[11];                                                                       \
     if (SWAPBC)                                                                                                       \
       OUT = sig_alfa * Xp + sig_beta * XpXp + sig_gama * XpXp * Xp + sig_a * XpXq + sig_b * Xp * XqXq +               \
             sig_c * XpXp * Xq + sig_d * XpXr + sig_e * XpXp * Xr + sig_f * Xp * XrXr;                                 \
@@ -376,111 +416,25 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
     const long a = a2 + (long)(k - 1) * nij;
     const double T0 = Lc.Ta;
     const double DZk = qo[Q_DZ], WCk = qo[Q_WC], ZU = qo[Q_ZU], ZL = qo[Q_ZL];
-    // ---------------- XI face between (i-1,j) and (i,j) ----------------
-    if (do_u) {
-      const int sw = so - 1, sn = so + MPX, snw = so + MPX - 1;
-      const double Tw = lds[pv][Q_TA][sw];
-      double ua = 0.0;
-      if (!u_wall_w && !u_wall_e && !((Tw <= 0.0) || (T0 <= 0.0) || (fabs(Tw - T0) <= EPS2_MP))) {
-        const double den = Tw + T0 + EPS_MP;
-        const double zs = ZU - ZL + lds[cu][Q_ZU][sw] - lds[cu][Q_ZL][sw];
-        double Ck;
-        if (k == 1) Ck = DV(0.25 * (DZk + lds[cu][Q_DZ][sw]) * zs, den);
-        else if (k < N) Ck = DV(0.0625 * (DZk + DZm1 + lds[cu][Q_DZ][sw] + lds[pv][Q_DZ][sw]) * zs, den);
-        else Ck = DV(0.25 * (DZm1 + lds[pv][Q_DZ][sw]) * zs, den);
-        const double Wk = 0.25 * dt * (lds[cu][Q_WC][sw] + WCk);
-        const double A = DV(T0 - Tw, den);
-        double B = 0.03125 * (lds[pv][Q_GV][sn] + Lc.GV + lds[pv][Q_GV][snw] + lds[pv][Q_GV][sw]);
-        B = DV(B * ONV4, den);
-        const double Um = 0.125 * Lc.Hu * dt * co.PMU * co.PNU * Lc.OHU;
-        const double Vm = 0.03125 * dt * (lds[pv][Q_HV][sw] + lds[pv][Q_HV][snw] + Lc.HV + lds[pv][Q_HV][sn]);
-        const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
-        const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
-        const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
-        double u0;
-        MP_SIGMA(A, B, Ck, X, Y, Z, u0, false)
-        ua = fmin(fabs(u0), 1.0 * fabs(Um)) * copysign(1.0, u0);
-        if constexpr (MASK) ua = ua * co.um;
-      }
-      if (u_wall_w) { if (m.closed[LBS_WEST]) Ua[a] = 0.0; }
-      else if (u_wall_e) { if (m.closed[LBS_EAST]) Ua[a] = 0.0; }
-      else {
-        Ua[a] = ua;
-        if (u_copy_w) Ua[a - 1] = ua;
-        if (u_copy_e) Ua[a + 1] = ua;
-      }
-    }
-    // ---------------- ETA face between (i,j-1) and (i,j) ----------------
-    if (do_v) {
-      const int ss = so - MPX, se = so + 1, sse = so - MPX + 1;
-      const double Ts = lds[pv][Q_TA][ss];
-      double va = 0.0;
-      if (!v_wall_n && !((Ts <= 0.0) || (T0 <= 0.0) || (fabs(Ts - T0) <= EPS2_MP))) {
-        const double den = Ts + T0 + EPS_MP;
-        const double zs = ZU - ZL + lds[cu][Q_ZU][ss] - lds[cu][Q_ZL][ss];
-        double Ck;
-        if (k == 1) Ck = DV(0.25 * (DZk + lds[cu][Q_DZ][ss]) * zs, den);
-        else if (k < N) Ck = DV(0.0625 * (DZk + DZm1 + lds[cu][Q_DZ][ss] + lds[pv][Q_DZ][ss]) * zs, den);
-        else Ck = DV(0.25 * (DZm1 + lds[pv][Q_DZ][ss]) * zs, den);
-        const double Wk = 0.25 * dt * (lds[cu][Q_WC][ss] + WCk);
-        double A = 0.03125 * (lds[pv][Q_GU][se] + Lc.GU + lds[pv][Q_GU][sse] + lds[pv][Q_GU][ss]);
-        A = DV(A * OMU4, den);
-        const double B = DV(T0 - Ts, den);
-        const double Um = 0.03125 * dt * (lds[pv][Q_HU][se] + lds[pv][Q_HU][sse] + Lc.HU + lds[pv][Q_HU][ss]);
-        const double Vm = 0.125 * Lc.Hv * dt * co.PNV * co.PMV * Lc.OHV;
-        const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
-        const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
-        const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
-        double v0;
-        MP_SIGMA(B, A, Ck, Y, X, Z, v0, true)
-        va = fmin(fabs(v0), 1.0 * fabs(Vm)) * copysign(1.0, v0);
-        if constexpr (MASK) va = va * co.vm;
-      }
-      if (v_wall_n) { if (m.closed[LBS_NORTH]) Va[a] = 0.0; }
-      else {
-        Va[a] = va;
-        // southern edge: Va(i,Jstr) (:612-625); row Jstr is below this kernel's Va range
-        if (v_copy_s) Va[a - ni] = m.closed[LBS_SOUTH] ? 0.0 : va;
-        if (v_copy_n) Va[a + ni] = va;
-      }
-    }
-    // ---------------- W face between levels k and k+1 ----------------
-    if (do_w) {
-      const long aw = a + nij;                 // Wa(i,j,k) in a (0:N) array
-      if (k == 1) Wa[a2] = 0.0;                // Wa(i,j,0)
-      if (k == N) Wa[aw] = 0.0;                // Wa(i,j,N)
-      else {
-        const int se = so + 1, sn = so + MPX;
-        const double Tu = Ln.Ta;
-        double wa = 0.0;
-        if (!((T0 <= 0.0) || (Tu <= 0.0) || (fabs(T0 - Tu) <= EPS2_MP))) {
-          const double den = Tu + T0 + EPS_MP;
-          const double Ck = DV(Tu - T0, den);
-          double A = 0.0625 * (lds[cu][Q_GU][se] + Ln.GU + lds[pv][Q_GU][se] + Lc.GU);
-          double B = 0.0625 * (lds[cu][Q_GV][sn] + Ln.GV + lds[pv][Q_GV][sn] + Lc.GV);
-          A = DV(A * OMU2, den);
-          B = DV(B * ONV2, den);
-          const double Um = 0.03125 * dt * (Lc.HU + Ln.HU + lds[pv][Q_HU][se] + lds[cu][Q_HU][se]);
-          const double Vm = 0.03125 * dt * (Lc.HV + Ln.HV + lds[pv][Q_HV][sn] + lds[cu][Q_HV][sn]);
-          const double Wk = WZk * co.pm * co.pn * dt;
-          const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Ck * Um * Wk;
-          const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Ck * Vm * Wk;
-          const double Z = (fabs(Wk) - Wk * Wk) * Ck - A * Um * Wk - B * Vm * Wk;
-          double w0;
-          MP_SIGMA(Ck, B, A, Z, Y, X, w0, false)
-          wa = fmin(fabs(w0), 1.0 * fabs(Wk)) * copysign(1.0, w0);
-          if constexpr (MASK) wa = wa * rm;
-        }
-        Wa[aw] = wa;
-      }
+    if constexpr (FAST) {
+#pragma clang fp contract(fast)
+#define DV(n, d) ((n) * mp_rcp(d))
+#define MP_SIGMA MP_SIGMA_FAST
+#include "k_mpdata_faces.inc"
+#undef MP_SIGMA
+#undef DV
+    } else {
+#define DV(n, d) ((n) / (d))
+#define MP_SIGMA MP_SIGMA_EXACT
+#include "k_mpdata_faces.inc"
+#undef MP_SIGMA
+#undef DV
     }
     Lc = Ln;
     DZm1 = DZk;
     __syncthreads();        // the plane of iteration k-1 is overwritten next
   }
 }
-
-#undef DV
 
 // --------------- K3: FCT limiter, limited transports, update, tridiagonal ----
 // mpdata_adiff.F:842-1100 (beta_up / beta_dn, the limited Ua, Va, Wa) + step3d_t.F:1235-1316 (corrected advection of
@@ -495,67 +449,83 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
 // (:991, :1006, :1022) and the new tracer times rmask (step3d_t.F:1586-1596).
 struct MpBeta { double up, dn; };
 
-// beta_up, beta_dn of cell (index a2, level k) straight from memory (ring cells)
-template <bool MASK>
-__device__ __forceinline__ MpBeta mp_beta_cell(const RomsDev *__restrict__ c, const MpArgs &m, gcd_t t3, long a2, int k, int N,
-                                               long ni, long nij)
+// what beta(k) of a column needs from memory beyond what the column carries from the levels below: level k+1 of Ta
+// and t3, the four horizontal neighbours of Ta and t3 at level k, the anti-diffusive velocities of the cell's faces
+struct MpBRaw { double Tup, t3up, Tw, Te, Ts, Tn, t3w, t3e, t3s, t3n, ua0, ua1, va0, va1, wa; };
+struct MpBSlide { double T0, Tdn, t30, t3dn, wadn; };     // Ta(k), Ta(k-1), t3(k), t3(k-1), Wa(k-1)
+
+__device__ __forceinline__ MpBRaw mp_load_braw(gcd_t Ta, gcd_t t3, gcd_t Ua, gcd_t Va, gcd_t Wa, long a2, int k, int N, long ni,
+                                               long nij)
 {
-  const gcd_t Ta = (gcd_t)m.Ta, Ua = (gcd_t)m.Ua, Va = (gcd_t)m.Va, Wa = (gcd_t)m.Wa;
-  const long a = a2 + (long)(k - 1) * nij;
-  const long aw = a + nij;                                     // Wa(i,j,k); Wa(i,j,k-1) = Wa[a]
-  const double T0 = Ta[a], Tw = Ta[a - 1], Te = Ta[a + 1], Ts = Ta[a - ni], Tn = Ta[a + ni];
+  MpBRaw r;
+  const long a = a2 + (long)(k <= N ? k - 1 : N - 1) * nij;      // level k (k = N+1: nothing new is needed, values unused)
+  const long au = k < N ? a + nij : a;
+  r.Tup = Ta[au]; r.t3up = t3[au];
+  r.Tw = Ta[a - 1]; r.Te = Ta[a + 1]; r.Ts = Ta[a - ni]; r.Tn = Ta[a + ni];
+  r.t3w = t3[a - 1]; r.t3e = t3[a + 1]; r.t3s = t3[a - ni]; r.t3n = t3[a + ni];
+  r.ua0 = Ua[a]; r.ua1 = Ua[a + 1]; r.va0 = Va[a]; r.va1 = Va[a + ni];
+  r.wa = Wa[a + nij];                                              // Wa(i,j,k)
+  return r;
+}
+
+// beta_up, beta_dn of level k of a column (mpdata_adiff.F:842-990), then slide the column to level k+1.
+// mu0, muq[]: mask_up = rmask of the column and of its W, E, S, N neighbours (MASK only); mask_dn follows from it
+template <bool MASK>
+__device__ __forceinline__ MpBeta mp_beta(const MpBRaw &r, MpBSlide &s, int k, int N, double mu0, const double muq[4])
+{
+  const double T0 = s.T0, Tw = r.Tw, Te = r.Te, Ts = r.Ts, Tn = r.Tn;
   double Tmax, Tmin;
   if constexpr (!MASK) {
-    Tmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
-                          t3[a - ni]), Tn), t3[a + ni]);
-    Tmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(Tw, t3[a - 1]), T0), t3[a]), Te), t3[a + 1]), Ts),
-                          t3[a - ni]), Tn), t3[a + ni]);
+    Tmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(Tw, r.t3w), T0), s.t30), Te), r.t3e), Ts), r.t3s), Tn), r.t3n);
+    Tmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(Tw, r.t3w), T0), s.t30), Te), r.t3e), Ts), r.t3s), Tn), r.t3n);
     if (k > 1) {
-      Tmax = fmax(fmax(Tmax, Ta[a - nij]), t3[a - nij]);
-      Tmin = fmin(fmin(Tmin, Ta[a - nij]), t3[a - nij]);
+      Tmax = fmax(fmax(Tmax, s.Tdn), s.t3dn);
+      Tmin = fmin(fmin(Tmin, s.Tdn), s.t3dn);
     }
     if (k < N) {
-      Tmax = fmax(fmax(Tmax, Ta[a + nij]), t3[a + nij]);
-      Tmin = fmin(fmin(Tmin, Ta[a + nij]), t3[a + nij]);
+      Tmax = fmax(fmax(Tmax, r.Tup), r.t3up);
+      Tmin = fmin(fmin(Tmin, r.Tup), r.t3up);
     }
   } else {
-    const gcd_t rmk = (gcd_t)c->F.rmask;
     const double Large = 1.0E+20;
-    auto mdn = [&](double r) { return fmax(1.0, fmin(Large, (1.0 - r) * Large)); };
-    const double mu0 = rmk[a2], md0 = mdn(mu0);
+    auto mdn = [&](double rr) { return fmax(1.0, fmin(Large, (1.0 - rr) * Large)); };
+    const double md0 = mdn(mu0);
     Tmax = T0 * mu0;
     Tmin = T0 * md0;
     auto take = [&](double mu, double md, double x) { Tmax = fmax(Tmax, x * mu); Tmin = fmin(Tmin, x * md); };
-    take(mu0, md0, t3[a]);
-    const long dq[4] = {-1, 1, -(long)ni, (long)ni};
-    const double Tq[4] = {Tw, Te, Ts, Tn};
+    take(mu0, md0, s.t30);
+    const double Tq[4] = {Tw, Te, Ts, Tn}, t3q[4] = {r.t3w, r.t3e, r.t3s, r.t3n};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const double mu = rmk[a2 + dq[q]], md = mdn(mu);
-      take(mu, md, Tq[q]);
-      take(mu, md, t3[a + dq[q]]);
+      const double md = mdn(muq[q]);
+      take(muq[q], md, Tq[q]);
+      take(muq[q], md, t3q[q]);
     }
-    if (k > 1) { take(mu0, md0, Ta[a - nij]); take(mu0, md0, t3[a - nij]); }
-    if (k < N) { take(mu0, md0, Ta[a + nij]); take(mu0, md0, t3[a + nij]); }
+    if (k > 1) { take(mu0, md0, s.Tdn); take(mu0, md0, s.t3dn); }
+    if (k < N) { take(mu0, md0, r.Tup); take(mu0, md0, r.t3up); }
   }
-  const double ua0 = Ua[a], ua1 = Ua[a + 1], va0 = Va[a], va1 = Va[a + ni];
-  double cff1 = Tw * fmax(0.0, ua0) - Te * fmin(0.0, ua1) + Ts * fmax(0.0, va0) - Tn * fmin(0.0, va1);
-  double cff2 = T0 * fmax(0.0, ua1) - T0 * fmin(0.0, ua0) + T0 * fmax(0.0, va1) - T0 * fmin(0.0, va0);
+  double cff1 = Tw * fmax(0.0, r.ua0) - Te * fmin(0.0, r.ua1) + Ts * fmax(0.0, r.va0) - Tn * fmin(0.0, r.va1);
+  double cff2 = T0 * fmax(0.0, r.ua1) - T0 * fmin(0.0, r.ua0) + T0 * fmax(0.0, r.va1) - T0 * fmin(0.0, r.va0);
   if (k == 1) {
-    cff1 = cff1 - Ta[a + nij] * fmin(0.0, Wa[aw]);
-    cff2 = cff2 + T0 * fmax(0.0, Wa[aw]);
+    cff1 = cff1 - r.Tup * fmin(0.0, r.wa);
+    cff2 = cff2 + T0 * fmax(0.0, r.wa);
   } else if (k < N) {
-    cff1 = cff1 + Ta[a - nij] * fmax(0.0, Wa[a]) - Ta[a + nij] * fmin(0.0, Wa[aw]);
-    cff2 = cff2 + T0 * fmax(0.0, Wa[aw]) - T0 * fmin(0.0, Wa[a]);
+    cff1 = cff1 + s.Tdn * fmax(0.0, s.wadn) - r.Tup * fmin(0.0, r.wa);
+    cff2 = cff2 + T0 * fmax(0.0, r.wa) - T0 * fmin(0.0, s.wadn);
   } else {
-    cff1 = cff1 + Ta[a - nij] * fmax(0.0, Wa[a]);
-    cff2 = cff2 - T0 * fmin(0.0, Wa[a]);
+    cff1 = cff1 + s.Tdn * fmax(0.0, s.wadn);
+    cff2 = cff2 - T0 * fmin(0.0, s.wadn);
   }
-  MpBeta r;
-  r.up = (Tmax - T0) / (cff1 + EPS_MP);
-  r.dn = (T0 - Tmin) / (cff2 + EPS_MP);
-  return r;
+  MpBeta o;
+  o.up = (Tmax - T0) / (cff1 + EPS_MP);
+  o.dn = (T0 - Tmin) / (cff2 + EPS_MP);
+  s.Tdn = s.T0; s.T0 = r.Tup; s.t3dn = s.t30; s.t30 = r.t3up; s.wadn = r.wa;
+  return o;
 }
+
+// LDS slots of the update kernel: the level's Ta, t3, Hz, Ua, Va of every cell of the 66 x (TY+2) tile (two
+// planes, alternating) and its beta_up / beta_dn (one plane)
+enum { S_T = 0, S_T3, S_HZ, S_UA, S_VA, S_N };
 
 template <int TY, bool MASK>
 __global__ void __launch_bounds__(BLK_X *TY)
@@ -563,7 +533,8 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
 {
   DEV_PROLOGUE(c)
   constexpr int PY = TY + 2, PC = MPX * PY;
-  __shared__ double lb[2][2][PC];           // [plane][beta_up / beta_dn][cell of the 66 x (TY+2) tile]
+  __shared__ double lr[2][S_N][PC];
+  __shared__ double lb[2][PC];              // beta_up / beta_dn
   const Blk XB = xcd_block();
   const int i0 = b.Istr + XB.x * BLK_X, j0 = b.Jstr + XB.y * TY;
   const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
@@ -577,22 +548,37 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
   const gcd_t Akt = (gcd_t)(c->F.Akt + (long)(ltrc - 1) * n3w);
   const gd_t tn = (gd_t)(c->F.t + ((long)(m.nnew - 1) + 3L * (m.itrc - 1)) * n3r);
   const int so = (threadIdx.y + 1) * MPX + threadIdx.x + 1;
-  // ring cell of this thread: rows 0 and TY+1, then columns 0 and 65 of rows 1..TY.  beta exists on
-  // IstrU-1:Iendp1 x JstrV-1:Jendp1 (mpdata_adiff.F:842); ring cells outside it (physical walls) carry zeros,
-  // their faces take the wall rule below.
-  int sh = -1, ih = 0, jh = 0;
-  if (tid < 2 * MPX) { const int r = tid / MPX, x = tid - r * MPX; sh = (r ? (PY - 1) * MPX : 0) + x; ih = i0 - 1 + x; jh = j0 - 1 + (r ? PY - 1 : 0); }
-  else if (tid < 2 * MPX + 2 * TY) { const int q = tid - 2 * MPX, y = 1 + (q >> 1), x = (q & 1) ? MPX - 1 : 0; sh = y * MPX + x; ih = i0 - 1 + x; jh = j0 - 1 + y; }
-  const bool halo = sh >= 0 && ih >= b.IstrU - 1 && ih <= b.Iendp1 && jh >= b.JstrV - 1 && jh <= b.Jendp1;
-  const long a2h = halo ? I2(ih, jh) : 0;
-  // the tile's own slots beyond Iend / Jend (partial workgroups) still owe their beta to the last own column / row
-  const bool cellb = i <= b.Iendp1 && j <= b.Jendp1;
-  const long a2 = cellb ? I2(i, j) : I2(b.Istr, b.Jstr);
+  // ring cell of this thread: rows 0 and TY+1, then columns 0 and 65 of rows 1..TY; od = the side on which its
+  // neighbour lies outside the tile (0 W, 1 E, 2 S, 3 N).  The four corners are nobody's W/E/S/N neighbour.
+  // beta exists on IstrU-1:Iendp1 x JstrV-1:Jendp1 (mpdata_adiff.F:842); cells outside it carry zeros, their faces
+  // take the wall rule below.
+  int sh = -1, ih = 0, jh = 0, od = 0;
+  bool corner = false;
+  if (tid < 2 * MPX) {
+    const int r = tid / MPX, x = tid - r * MPX;
+    sh = (r ? (PY - 1) * MPX : 0) + x; ih = i0 - 1 + x; jh = j0 - 1 + (r ? PY - 1 : 0);
+    od = r ? 3 : 2; corner = x == 0 || x == MPX - 1;
+  } else if (tid < 2 * MPX + 2 * TY) {
+    const int q = tid - 2 * MPX, y = 1 + (q >> 1), x = (q & 1) ? MPX - 1 : 0;
+    sh = y * MPX + x; ih = i0 - 1 + x; jh = j0 - 1 + y;
+    od = (q & 1) ? 1 : 0;
+  }
+  const bool ring = sh >= 0;
+  const bool inarr = i <= b.UBi && j <= b.UBj;                                   // own slot inside the arrays
+  const bool cellb = i <= b.Iendp1 && j <= b.Jendp1;                             // ... and a cell with a beta
+  const bool harr = ring && ih >= b.LBi && ih <= b.UBi && jh >= b.LBj && jh <= b.UBj;
+  const bool halo = harr && !corner && ih >= b.IstrU - 1 && ih <= b.Iendp1 && jh >= b.JstrV - 1 && jh <= b.Jendp1;
+  const long a2 = inarr ? I2(i, j) : I2(b.Istr, b.Jstr);
+  const long a2h = harr ? I2(ih, jh) : a2;
+  // ring cell: its neighbour outside the tile, and the faces Ua(i+1) / Va(j+1) (memory; 0 offset where there is no beta)
+  const long oq[4] = {-1, 1, -(long)ni, (long)ni};
+  const long aout = halo ? oq[od] : 0, au1 = halo ? 1 : 0, av1 = halo ? ni : 0;
   const double cffa = 1.0 / dt;                                   // mpdata_adiff.F:254
-  const double cpp = dt * GF(pm)[a2] * GF(pn)[a2];
-  const double omu0 = GF(om_u)[a2], omu1 = GF(om_u)[a2 + 1], onv0 = GF(on_v)[a2], onv1 = GF(on_v)[a2 + ni];
-  const double onu0 = GF(on_u)[a2], onu1 = GF(on_u)[a2 + 1], omv0 = GF(om_v)[a2], omv1 = GF(om_v)[a2 + ni];
-  const double omn = GF(omn)[a2];
+  const long a2c = cellb ? a2 : I2(b.Istr, b.Jstr);               // 2-D constants of the own cell
+  const double cpp = dt * GF(pm)[a2c] * GF(pn)[a2c];
+  const double omu0 = GF(om_u)[a2c], omu1 = GF(om_u)[a2c + 1], onv0 = GF(on_v)[a2c], onv1 = GF(on_v)[a2c + ni];
+  const double onu0 = GF(on_u)[a2c], onu1 = GF(on_u)[a2c + 1], omv0 = GF(om_v)[a2c], omv1 = GF(om_v)[a2c + ni];
+  const double omn = GF(omn)[a2c];
   // physical edges of the limited transports, mpdata_adiff.F:1031-1100: zero (closed) or the limited transport of the
   // next face inside -- the other face of this cell
   const bool v0_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;       // Va(i,Jstr)
@@ -600,8 +586,17 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
   const bool u0_wall = b.west_edge && !b.EWperiodic && i == b.Istr;        // Ua(Istr,j)
   const bool u1_wall = b.east_edge && !b.EWperiodic && i == b.Iend;        // Ua(Iend+1,j)
   double um0 = 1.0, um1 = 1.0, vm0 = 1.0, vm1 = 1.0, rm0 = 1.0;
+  double muq[4] = {1.0, 1.0, 1.0, 1.0}, muh[4] = {1.0, 1.0, 1.0, 1.0}, mu0h = 1.0;
   if constexpr (MASK) {
-    um0 = GF(umask)[a2]; um1 = GF(umask)[a2 + 1]; vm0 = GF(vmask)[a2]; vm1 = GF(vmask)[a2 + ni]; rm0 = GF(rmask)[a2];
+    um0 = GF(umask)[a2c]; um1 = GF(umask)[a2c + 1]; vm0 = GF(vmask)[a2c]; vm1 = GF(vmask)[a2c + ni]; rm0 = GF(rmask)[a2c];
+    const gcd_t rmk = (gcd_t)c->F.rmask;
+    const long a2hc = halo ? a2h : a2c;
+    mu0h = rmk[a2hc];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      muq[q] = rmk[a2c + oq[q]];
+      muh[q] = rmk[a2hc + oq[q]];
+    }
   }
   const double cfl = -dt * c->p.lambda;
   // The eliminated right-hand side DC(k) is parked in t(nnew) itself and CF(k) in a scratch array (the round-2
@@ -609,7 +604,31 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
   // under full unrolling.  The back substitution reads them again in reverse order, a workgroup's own 2 x 30 x 4 KB
   // straight after writing them.
   const gd_t CFg = (gd_t)m.bup;
-  // carried from level to level (own column)
+  // per level from memory -- own column: the level above of Ta and t3, the cell's own faces, Hz, z_r, Akt;
+  // ring column: the same without z_r / Akt, plus the neighbour outside the tile and the far faces
+  struct ORaw { double Tup, t3up, ua0, va0, wa, hz, zr, akt; };
+  struct RRaw { double Tup, t3up, ua0, ua1, va0, va1, wa, hz, Tout, t3out; };
+  auto load_own = [&](int k) {
+    ORaw r;
+    const long a = a2 + (long)(k <= N ? k - 1 : N - 1) * nij;      // k = N+1: nothing new is needed
+    const long au = k < N ? a + nij : a;
+    r.Tup = Ta[au]; r.t3up = t3[au];
+    r.ua0 = Ua[a]; r.va0 = Va[a]; r.wa = Wa[a + nij];              // Wa(i,j,k)
+    r.hz = Hz[a]; r.zr = z_r[a]; r.akt = Akt[a];                   // Akt(i,j,k-1)
+    return r;
+  };
+  auto load_ring = [&](int k) {
+    RRaw r;
+    const long a = a2h + (long)(k <= N ? k - 1 : N - 1) * nij;
+    const long au = k < N ? a + nij : a;
+    r.Tup = Ta[au]; r.t3up = t3[au];
+    r.ua0 = Ua[a]; r.ua1 = Ua[a + au1]; r.va0 = Va[a]; r.va1 = Va[a + av1]; r.wa = Wa[a + nij];
+    r.hz = Hz[a];
+    r.Tout = Ta[a + aout]; r.t3out = t3[a + aout];
+    return r;
+  };
+  // carried from level to level
+  MpBSlide so_s{Ta[a2], 0.0, t3[a2], 0.0, 0.0}, sh_s{Ta[a2h], 0.0, t3[a2h], 0.0, 0.0};
   double bup_p = 0.0, bdn_p = 0.0;   // beta(k-1)
   double T_p = 0.0;                  // Ta(k-1)
   double tvh_p = 0.0;                // Ta*Hz - horizontal divergence of level k-1
@@ -617,93 +636,125 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
   double FCadv_pp = 0.0;             // limited advective flux through the face below level k-1
   double FCd_pp = 0.0;               // diffusion coefficient FC(k-2) of the tridiagonal
   double CF_pp = 0.0, DC_pp = 0.0;   // CF(k-2), DC(k-2) after elimination
+  // loads of level 1; from then on the loads of level k+1 are in flight while level k is evaluated
+  ORaw po = load_own(1);
+  RRaw pr;
+  if (ring) pr = load_ring(1);
+#pragma unroll 1
   for (int k = 1; k <= N + 1; k++) {
-    {
-      const long a = a2 + (long)(k - 1) * nij;
-      double bup = 0.0, bdn = 0.0, T0 = 0.0, tvh = 0.0, hz = 0.0, zr = 0.0, FCadv_p = 0.0;
-      if (k <= N) {
-        // ---- beta(k): own and ring cell
-        MpBeta bo{0.0, 0.0};
-        if (cellb) bo = mp_beta_cell<MASK>(c, m, t3, a2, k, N, ni, nij);
-        bup = bo.up; bdn = bo.dn;
-        const int pl = k & 1;
-        lb[pl][0][so] = bup; lb[pl][1][so] = bdn;
-        if (sh >= 0) {
-          MpBeta bh{0.0, 0.0};
-          if (halo) bh = mp_beta_cell<MASK>(c, m, t3, a2h, k, N, ni, nij);
-          lb[pl][0][sh] = bh.up; lb[pl][1][sh] = bh.dn;
+    const long a = a2 + (long)(k - 1) * nij;
+    double bup = 0.0, bdn = 0.0, T0 = 0.0, tvh = 0.0, hz = 0.0, zr = po.zr, FCadv_p = 0.0;
+    const double akt = po.akt;
+    if (k <= N) {
+      const ORaw co = po;
+      const int pl = k & 1;
+      T0 = so_s.T0;
+      hz = co.hz;
+      const double wadn = so_s.wadn;
+      // ---- publish level k of the own and the ring cell
+      lr[pl][S_T][so] = T0; lr[pl][S_T3][so] = so_s.t30; lr[pl][S_HZ][so] = hz; lr[pl][S_UA][so] = co.ua0; lr[pl][S_VA][so] = co.va0;
+      RRaw cr;
+      if (ring) {
+        cr = pr;
+        lr[pl][S_T][sh] = sh_s.T0; lr[pl][S_T3][sh] = sh_s.t30; lr[pl][S_HZ][sh] = cr.hz; lr[pl][S_UA][sh] = cr.ua0; lr[pl][S_VA][sh] = cr.va0;
+      }
+      // the loads of level k+1 go out before the barrier
+      po = load_own(k + 1);
+      if (ring) pr = load_ring(k + 1);
+      __syncthreads();
+      // ---- beta(k): own cell from the tile in LDS, ring cell with its outer neighbour from memory
+      MpBRaw rb;
+      rb.Tup = co.Tup; rb.t3up = co.t3up; rb.wa = co.wa;
+      rb.Tw = lr[pl][S_T][so - 1]; rb.Te = lr[pl][S_T][so + 1]; rb.Ts = lr[pl][S_T][so - MPX]; rb.Tn = lr[pl][S_T][so + MPX];
+      rb.t3w = lr[pl][S_T3][so - 1]; rb.t3e = lr[pl][S_T3][so + 1]; rb.t3s = lr[pl][S_T3][so - MPX]; rb.t3n = lr[pl][S_T3][so + MPX];
+      rb.ua0 = co.ua0; rb.ua1 = lr[pl][S_UA][so + 1]; rb.va0 = co.va0; rb.va1 = lr[pl][S_VA][so + MPX];
+      const double hzW = lr[pl][S_HZ][so - 1], hzE = lr[pl][S_HZ][so + 1], hzS = lr[pl][S_HZ][so - MPX], hzN = lr[pl][S_HZ][so + MPX];
+      MpBeta bo = mp_beta<MASK>(rb, so_s, k, N, rm0, muq);
+      if (!cellb) bo.up = bo.dn = 0.0;
+      bup = bo.up; bdn = bo.dn;
+      lb[0][so] = bup; lb[1][so] = bdn;
+      if (ring) {
+        MpBRaw rh;
+        const int sW = od == 0 ? sh : sh - 1, sE = od == 1 ? sh : sh + 1, sS = od == 2 ? sh : sh - MPX, sN = od == 3 ? sh : sh + MPX;
+        rh.Tup = cr.Tup; rh.t3up = cr.t3up; rh.wa = cr.wa;
+        rh.Tw = lr[pl][S_T][sW]; rh.Te = lr[pl][S_T][sE]; rh.Ts = lr[pl][S_T][sS]; rh.Tn = lr[pl][S_T][sN];
+        rh.t3w = lr[pl][S_T3][sW]; rh.t3e = lr[pl][S_T3][sE]; rh.t3s = lr[pl][S_T3][sS]; rh.t3n = lr[pl][S_T3][sN];
+        if (od == 0) { rh.Tw = cr.Tout; rh.t3w = cr.t3out; }
+        else if (od == 1) { rh.Te = cr.Tout; rh.t3e = cr.t3out; }
+        else if (od == 2) { rh.Ts = cr.Tout; rh.t3s = cr.t3out; }
+        else { rh.Tn = cr.Tout; rh.t3n = cr.t3out; }
+        rh.ua0 = cr.ua0; rh.ua1 = cr.ua1; rh.va0 = cr.va0; rh.va1 = cr.va1;
+        const MpBeta bh = mp_beta<MASK>(rh, sh_s, k, N, mu0h, muh);
+        lb[0][sh] = halo ? bh.up : 0.0; lb[1][sh] = halo ? bh.dn : 0.0;
+      }
+      __syncthreads();
+      {
+        // ---- limited horizontal transports of level k (mpdata_adiff.F:1034-1049) and corrected fluxes
+        const double bupW = lb[0][so - 1], bdnW = lb[1][so - 1], bupE = lb[0][so + 1], bdnE = lb[1][so + 1];
+        const double bupS = lb[0][so - MPX], bdnS = lb[1][so - MPX], bupN = lb[0][so + MPX], bdnN = lb[1][so + MPX];
+        const double ua0 = rb.ua0, ua1 = rb.ua1, va0 = rb.va0, va1 = rb.va1;
+        double u0 = (fmin(fmin(bdnW, bup), 1.0) * fmax(0.0, ua0) + fmin(fmin(bupW, bdn), 1.0) * fmin(0.0, ua0)) * cffa * omu0;
+        double u1 = (fmin(fmin(bdn, bupE), 1.0) * fmax(0.0, ua1) + fmin(fmin(bup, bdnE), 1.0) * fmin(0.0, ua1)) * cffa * omu1;
+        double v0 = (fmin(fmin(bdnS, bup), 1.0) * fmax(0.0, va0) + fmin(fmin(bupS, bdn), 1.0) * fmin(0.0, va0)) * cffa * onv0;
+        double v1 = (fmin(fmin(bdn, bupN), 1.0) * fmax(0.0, va1) + fmin(fmin(bup, bdnN), 1.0) * fmin(0.0, va1)) * cffa * onv1;
+        if constexpr (MASK) { u0 = u0 * um0; u1 = u1 * um1; v0 = v0 * vm0; v1 = v1 * vm1; }
+        {
+          const double u0i = u0, u1i = u1, v0i = v0, v1i = v1;
+          if (u0_wall) u0 = m.closed[LBS_WEST] ? 0.0 : u1i;
+          if (u1_wall) u1 = m.closed[LBS_EAST] ? 0.0 : u0i;
+          if (v0_wall) v0 = m.closed[LBS_SOUTH] ? 0.0 : v1i;
+          if (v1_wall) v1 = m.closed[LBS_NORTH] ? 0.0 : v0i;
         }
-        __syncthreads();
-        if (own) {
-          // ---- limited horizontal transports of level k (mpdata_adiff.F:1034-1049) and corrected fluxes
-          const double bupW = lb[pl][0][so - 1], bdnW = lb[pl][1][so - 1], bupE = lb[pl][0][so + 1], bdnE = lb[pl][1][so + 1];
-          const double bupS = lb[pl][0][so - MPX], bdnS = lb[pl][1][so - MPX], bupN = lb[pl][0][so + MPX], bdnN = lb[pl][1][so + MPX];
-          const double ua0 = Ua[a], ua1 = Ua[a + 1], va0 = Va[a], va1 = Va[a + ni];
-          T0 = Ta[a]; hz = Hz[a]; zr = z_r[a];
-          double u0 = (fmin(fmin(bdnW, bup), 1.0) * fmax(0.0, ua0) + fmin(fmin(bupW, bdn), 1.0) * fmin(0.0, ua0)) * cffa * omu0;
-          double u1 = (fmin(fmin(bdn, bupE), 1.0) * fmax(0.0, ua1) + fmin(fmin(bup, bdnE), 1.0) * fmin(0.0, ua1)) * cffa * omu1;
-          double v0 = (fmin(fmin(bdnS, bup), 1.0) * fmax(0.0, va0) + fmin(fmin(bupS, bdn), 1.0) * fmin(0.0, va0)) * cffa * onv0;
-          double v1 = (fmin(fmin(bdn, bupN), 1.0) * fmax(0.0, va1) + fmin(fmin(bup, bdnN), 1.0) * fmin(0.0, va1)) * cffa * onv1;
-          if constexpr (MASK) { u0 = u0 * um0; u1 = u1 * um1; v0 = v0 * vm0; v1 = v1 * vm1; }
-          {
-            const double u0i = u0, u1i = u1, v0i = v0, v1i = v1;
-            if (u0_wall) u0 = m.closed[LBS_WEST] ? 0.0 : u1i;
-            if (u1_wall) u1 = m.closed[LBS_EAST] ? 0.0 : u0i;
-            if (v0_wall) v0 = m.closed[LBS_SOUTH] ? 0.0 : v1i;
-            if (v1_wall) v1 = m.closed[LBS_NORTH] ? 0.0 : v0i;
-          }
-          // corrected horizontal fluxes, step3d_t.F:1238-1255
-          const double FXi = (fmax(u0, 0.0) * Ta[a - 1] + fmin(u0, 0.0) * T0) * 0.5 * (hz + Hz[a - 1]) * onu0;
-          const double FXip1 = (fmax(u1, 0.0) * T0 + fmin(u1, 0.0) * Ta[a + 1]) * 0.5 * (Hz[a + 1] + hz) * onu1;
-          const double FEj = (fmax(v0, 0.0) * Ta[a - ni] + fmin(v0, 0.0) * T0) * 0.5 * (hz + Hz[a - ni]) * omv0;
-          const double FEjp1 = (fmax(v1, 0.0) * T0 + fmin(v1, 0.0) * Ta[a + ni]) * 0.5 * (Hz[a + ni] + hz) * omv1;
-          const double cff1 = cpp * (FXip1 - FXi);
-          const double cff2 = cpp * (FEjp1 - FEj);
-          const double cff3 = cff1 + cff2;
-          tvh = T0 * hz - cff3;                                     // :1265
-          // limited vertical transport through the face between k-1 and k (:1051-1060), corrected flux :1281-1290
-          if (k > 1) {
-            const double c1 = fmin(fmin(bdn_p, bup), 1.0);
-            const double c2 = fmin(fmin(bup_p, bdn), 1.0);
-            const double wa = Wa[a];                                // Wa(i,j,k-1)
-            double w = (c1 * fmax(0.0, wa) + c2 * fmin(0.0, wa)) * cffa * omn * (zr - zr_p);
-            if constexpr (MASK) w = w * rm0;
-            FCadv_p = fmax(w, 0.0) * T_p + fmin(w, 0.0) * T0;
-          }
+        // corrected horizontal fluxes, step3d_t.F:1238-1255
+        const double FXi = (fmax(u0, 0.0) * rb.Tw + fmin(u0, 0.0) * T0) * 0.5 * (hz + hzW) * onu0;
+        const double FXip1 = (fmax(u1, 0.0) * T0 + fmin(u1, 0.0) * rb.Te) * 0.5 * (hzE + hz) * onu1;
+        const double FEj = (fmax(v0, 0.0) * rb.Ts + fmin(v0, 0.0) * T0) * 0.5 * (hz + hzS) * omv0;
+        const double FEjp1 = (fmax(v1, 0.0) * T0 + fmin(v1, 0.0) * rb.Tn) * 0.5 * (hzN + hz) * omv1;
+        const double cff1 = cpp * (FXip1 - FXi);
+        const double cff2 = cpp * (FEjp1 - FEj);
+        const double cff3 = cff1 + cff2;
+        tvh = T0 * hz - cff3;                                     // :1265
+        // limited vertical transport through the face between k-1 and k (:1051-1060), corrected flux :1281-1290
+        if (k > 1) {
+          const double c1 = fmin(fmin(bdn_p, bup), 1.0);
+          const double c2 = fmin(fmin(bup_p, bdn), 1.0);
+          double w = (c1 * fmax(0.0, wadn) + c2 * fmin(0.0, wadn)) * cffa * omn * (zr - zr_p);
+          if constexpr (MASK) w = w * rm0;
+          FCadv_p = fmax(w, 0.0) * T_p + fmin(w, 0.0) * T0;
         }
       }
-      // ---- level kk = k-1 is complete: vertical advection (:1305), forward elimination of the classic
-      //      tridiagonal (step3d_t.F:1431-1501)
-      if (own && k > 1) {
-        const int kk = k - 1;
-        const double tv = tvh_p - cpp * (FCadv_p - FCadv_pp);
-        double FCd = 0.0;
-        if (kk < N) {
-          const double cff1 = 1.0 / (zr - zr_p);
-          FCd = cfl * cff1 * Akt[a];                                // Akt(i,j,kk)
-        }
-        const double BC = hz_p - FCd - FCd_pp;
-        double CFk = 0.0, DCk;
-        if (kk == 1) {
-          const double cff = 1.0 / BC;
-          CFk = cff * FCd;
-          DCk = cff * tv;
-        } else if (kk < N) {
-          const double cff = 1.0 / (BC - FCd_pp * CF_pp);
-          CFk = cff * FCd;
-          DCk = cff * (tv - FCd_pp * DC_pp);
-        } else {
-          DCk = (tv - FCd_pp * DC_pp) / (BC - FCd_pp * CF_pp);
-        }
-        tn[a - nij] = DCk;
-        CFg[a - nij] = CFk;
-        CF_pp = CFk;
-        DC_pp = DCk;
-        FCd_pp = FCd;
-        FCadv_pp = FCadv_p;
-      }
-      bup_p = bup; bdn_p = bdn; T_p = T0; tvh_p = tvh; hz_p = hz; zr_p = zr;
     }
+    // ---- level kk = k-1 is complete: vertical advection (:1305), forward elimination of the classic
+    //      tridiagonal (step3d_t.F:1431-1501)
+    if (own && k > 1) {
+      const int kk = k - 1;
+      const double tv = tvh_p - cpp * (FCadv_p - FCadv_pp);
+      double FCd = 0.0;
+      if (kk < N) {
+        const double cff1 = 1.0 / (zr - zr_p);
+        FCd = cfl * cff1 * akt;                                   // Akt(i,j,kk)
+      }
+      const double BC = hz_p - FCd - FCd_pp;
+      double CFk = 0.0, DCk;
+      if (kk == 1) {
+        const double cff = 1.0 / BC;
+        CFk = cff * FCd;
+        DCk = cff * tv;
+      } else if (kk < N) {
+        const double cff = 1.0 / (BC - FCd_pp * CF_pp);
+        CFk = cff * FCd;
+        DCk = cff * (tv - FCd_pp * DC_pp);
+      } else {
+        DCk = (tv - FCd_pp * DC_pp) / (BC - FCd_pp * CF_pp);
+      }
+      tn[a - nij] = DCk;
+      CFg[a - nij] = CFk;
+      CF_pp = CFk;
+      DC_pp = DCk;
+      FCd_pp = FCd;
+      FCadv_pp = FCadv_p;
+    }
+    bup_p = bup; bdn_p = bdn; T_p = T0; tvh_p = tvh; hz_p = hz; zr_p = zr;
   }
   if (!own) return;
   // back substitution; DC_pp = DC(N) is the top value.  A lane reads back only what it stored itself.
@@ -713,7 +764,8 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
     if constexpr (MASK) v = v * rm0;
     tn[a2 + (long)(N - 1) * nij] = v;
   }
-  for (int k = N - 1; k >= 1; k--) {
+#pragma unroll 8
+  for (int k = N - 1; k >= 1; k--) {       // the loads do not depend on `up`: eight levels in flight
     const long a = a2 + (long)(k - 1) * nij;
     double v = tn[a] - CFg[a] * up;
     up = v;
