@@ -59,16 +59,35 @@ def pmc_traffic(config, gpus):
     """HBM-side bytes per launch of the roofline kernel, from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).  Counters
     cannot be read from inside the bench; the figure holds for the configuration it was measured on
-    (whole grid on one GPU) and is null otherwise."""
+    (whole grid on one GPU) and is null otherwise.  Returns (bytes, source): `source` names the profile
+    directory and the commit of the kernel source the counters were taken on, so that a figure that is
+    older than the kernel shows."""
     if gpus != 1:
-        return None
+        return None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             k = json.load(f)[config]
         k = k.get("step3d_t") or k["k_step3d_t_pipe"]
-        return float(k["fetch_bytes"] + k["write_bytes"])
+        src = {"profile": "profiles/" + str(k.get("round")), "kernel_commit": k.get("commit"),
+               "kernel_source_sha16": k.get("source_sha16"), "kernel_source_sha16_now": kernel_source_sha(config)}
+        src["stale"] = bool(src["kernel_source_sha16"] and src["kernel_source_sha16"] != src["kernel_source_sha16_now"])
+        return float(k["fetch_bytes"] + k["write_bytes"]), src
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+
+
+def kernel_source_sha(config):
+    """sha256 (16 hex digits) of the source file of the roofline kernel of `config`."""
+    import hashlib
+    name = "k_mpdata.hip" if config.endswith("_MPDATA") else "k_step3d_t.hip"
+    h = hashlib.sha256()
+    for fn in (name, "k_mpdata_faces.inc") if name == "k_mpdata.hip" else (name,):
+        try:
+            with open(os.path.join(ROOT, "roms_trunk_mgh_amd", "csrc", fn), "rb") as f:
+                h.update(f.read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -257,6 +276,67 @@ def halo_selftest(be, st, rank):
     return bad
 
 
+def run_config5(args, device, steps=6, warmup=2):
+    """BASELINE.json configuration 5 -- BENCHMARK3 + 4 passive tracers, all six advected with MPDATA -- on one
+    GPU: the whole step with the reciprocal-sharing k_mp_adiff (roms_params_t.mpdata_fast = 1, as
+    `--config BENCHMARK3_MPDATA` times it) and step3d_t alone with both variants (mpdata_fast = 0 is the one
+    that is bit-identical to the oracle)."""
+    import ctypes as C
+    from roms_trunk_mgh_amd import hip, main3d
+    config = "BENCHMARK3_MPDATA"
+    st = make_tile(config, perturb=1.0)
+    st.p.mpdata_fast = 1
+    be = hip.RomsHip(st, rank=0, device=device)
+    try:
+        m = main3d.Main3D(be, physics=args.physics, diagnostics=args.physics)
+        m.initial()
+        for _ in range(warmup):
+            m.step()
+        be.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.step()
+        be.sync()
+        wall = time.perf_counter() - t0
+
+        def step3d_t_ms(fast):
+            p2 = type(st.p).from_buffer_copy(st.p)
+            p2.mpdata_fast = fast
+            be._chk(be.l.roms_hip_set_params(C.byref(p2)), "set_params")
+            be.timing(False)
+            m.step()
+            be.timing(True)
+            v = []
+            for _ in range(4):
+                m.step()
+                v.append(be.last_ms("step3d_t"))
+            be.timing(False)
+            return sum(v) / len(v)
+        t_fast = step3d_t_ms(1)
+        t_exact = step3d_t_ms(0)
+        import numpy as np
+        be.to_host(["t"])
+        ok = bool(np.isfinite(st["t"]).all())
+    finally:
+        be.close()
+    b = st.b
+    cells = (b.Iend - b.Istr + 1) * (b.Jend - b.Jstr + 1) * b.N
+    comp = 8.0 * (4 * b.NT + 4) * cells
+    multi = 8.0 * (12 * b.NT + 6) * cells
+    traffic, src = pmc_traffic(config, 1)
+    return {"workload": f"{config} {b.Lm}x{b.Mm}x{b.N} NT={b.NT}, all tracers MPDATA, "
+                        + ("bulk fluxes + KPP + diagnostics every step" if args.physics else "fixed forcing"),
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall / steps,
+            "value": steps * st.p.dt / 86400.0 / wall, "unit": "simulated-days/s", "mpdata_fast": 1,
+            "step3d_t_ms": t_fast, "step3d_t_ms_exact": t_exact,
+            "frac": comp / (t_fast * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_exact": comp / (t_exact * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "multipass_frac": multi / (t_fast * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes": comp, "multipass_bytes": multi,
+            "multipass_note": "8*(12*NT+6) B/cell, the round-2 definition (Ta, Ua, Va, Wa, beta_up, beta_dn materialised); "
+                              "since round 3 beta_up / beta_dn stay in LDS",
+            "traffic": traffic, "traffic_source": src, "finite": ok}
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         a = sys.argv[2:]
@@ -279,6 +359,9 @@ def main():
                     help="N = 1 only: hand the library an RCCL id so that the tile is its own western / eastern neighbour "
                          "and every periodic exchange of the step travels through pack -> ncclSend/ncclRecv -> unpack "
                          "(what a tile of an N-GPU run executes, measured on one GPU; not the headline configuration)")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the extra leg of the default run: BENCHMARK3_MPDATA (BASELINE.json configuration 5) timed "
+                         "after the headline configuration and reported under the key config5")
     ap.add_argument("--no-physics", dest="physics", action="store_false",
                     help="keep the outputs of bulk_flux + set_vbc fixed instead of recomputing them on the "
                          "device every step (SURVEY 8f-1); default: recompute, as the reference's step does")
@@ -517,11 +600,12 @@ def main():
                if args.physics else "fixed inputs", "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok}
         if notes:
             cfg["notes"] = notes
-        roof = {"kernel": ("k_mp_ta + k_mp_adiff + k_mp_beta + k_mp_update per tracer (step3d_t_tile, MPDATA)" if mpdata
+        roof = {"kernel": ("k_mp_ta + k_mp_adiff + k_mp_update per tracer (step3d_t_tile, MPDATA)" if mpdata
                            else "k_step3d_t_pipe (step3d_t_tile)"),
                 "bound": "hbm", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.config, args.gpus), "traffic_unit": "bytes/launch",
+                "traffic": pmc_traffic(args.config, args.gpus)[0], "traffic_unit": "bytes/launch",
+                "traffic_source": pmc_traffic(args.config, args.gpus)[1],
                 "avg_ms": t_ms, "algorithmic_bytes": alg_bytes,
                 "measured_peak": measured_peak,
                 "measured_peak_note": "streaming copy k_calib_stream, 8 B read + 8 B written per double, one 3-D field"}
@@ -536,6 +620,12 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": cfg, "roofline": roof, "kernel_ms": per_kernel,
         }
+        if args.gpus == 1 and args.config == "BENCHMARK3" and not args.no_config5 and not args.loopback:
+            # BASELINE.json configuration 5 on the same box, after the headline run (its own state and context)
+            try:
+                out["config5"] = run_config5(args, device)
+            except Exception as e:            # the headline line must not depend on this leg
+                out["config5"] = {"error": repr(e)}
         if not args.no_cpu_baseline and args.gpus == 1:
             # the GPU boxes of this pool report every core of the host (256) but give a one-GPU job a share of
             # 16 (their process guard and memory cap are sized for that): the baseline uses that share

@@ -219,33 +219,23 @@ template <bool MASK>
 __device__ __forceinline__ void mp_cellq(const MpRaw &r, const MpCol &cc, MpSlide &s, int k, int N, double q[Q_N], MpLev &L,
                                          double &WZk)
 {
-  L.Ta = L.GU = L.GV = L.HU = L.HV = L.Hu = L.Hv = L.OHU = L.OHV = 0.0;
-  WZk = 0.0;
-  q[Q_DZ] = q[Q_WC] = q[Q_ZL] = 0.0;
-  if (k < N) {
-    L.Hu = r.hu; L.Hv = r.hv;
-    L.Ta = r.t1;
-    L.GU = (r.t1 - r.tW) * cc.PMU;
-    L.GV = (r.t1 - r.tS) * cc.PNV;
-    if constexpr (MASK) { L.GU = L.GU * cc.um; L.GV = L.GV * cc.vm; }
-    L.OHU = r.oW + r.o;
-    L.OHV = r.oS + r.o;
-    L.HU = L.Hu * cc.PMU * cc.PNU * L.OHU;
-    L.HV = L.Hv * cc.PMV * cc.PNV * L.OHV;
-    q[Q_ZU] = r.zu;
-  } else {
-    q[Q_ZU] = s.zk;
-  }
+  // level k+1 (at k = N the raw loads repeat level N: those values are never used -- there is no W face above level N)
+  L.Hu = r.hu; L.Hv = r.hv;
+  L.Ta = r.t1;
+  L.GU = (r.t1 - r.tW) * cc.PMU;
+  L.GV = (r.t1 - r.tS) * cc.PNV;
+  if constexpr (MASK) { L.GU = L.GU * cc.um; L.GV = L.GV * cc.vm; }
+  L.OHU = r.oW + r.o;
+  L.OHV = r.oS + r.o;
+  L.HU = L.Hu * cc.PMU * cc.PNU * L.OHU;
+  L.HV = L.Hv * cc.PMV * cc.PNV * L.OHV;
+  q[Q_ZU] = k < N ? r.zu : s.zk;
   q[Q_TA] = L.Ta; q[Q_GU] = L.GU; q[Q_GV] = L.GV; q[Q_HU] = L.HU; q[Q_HV] = L.HV;
-  if (k >= 1) {
-    if (k < N) {
-      q[Q_DZ] = (r.t1 - s.Tk) * r.odz;
-      WZk = r.w * r.odz;
-    }
-    if (k == 1) q[Q_WC] = WZk * cc.pm * cc.pn;
-    else q[Q_WC] = (k < N ? (s.WZm + WZk) : s.WZm) * cc.pm * cc.pn;
-    q[Q_ZL] = k > 1 ? s.zkm1 : s.zk;
-  }
+  // level k (DZ and WZk are not used at k = N, nothing of this at k = 0)
+  q[Q_DZ] = (r.t1 - s.Tk) * r.odz;
+  WZk = r.w * r.odz;
+  q[Q_WC] = (k == 1 ? WZk : (k < N ? (s.WZm + WZk) : s.WZm)) * cc.pm * cc.pn;
+  q[Q_ZL] = k > 1 ? s.zkm1 : s.zk;
   // slide to the next level
   s.Tk = r.t1; s.WZm = WZk;
   if (k >= 1) s.zkm1 = s.zk;
@@ -332,9 +322,11 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
 {
   DEV_PROLOGUE(c)
   __shared__ double lds[2][Q_N][MPC];
-  // union of the three ranges: i = IstrU-1 : Iendp2, j = JstrV-1 : Jendp2; XCD strips of tile columns (xcd_block)
-  const Blk XB = xcd_block();
-  const int i0 = b.IstrU - 1 + XB.x * BLK_X, j0 = b.JstrV - 1 + XB.y * BLK_Y;
+  // union of the three ranges: i = IstrU-1 : Iendp2, j = JstrV-1 : Jendp2.  Each XCD walks its own strip of tile
+  // columns row by row (decode_tile_tracer), so the ring columns two neighbouring tiles both read meet in one L2
+  const TileTr XB = decode_tile_tracer(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1, 1);
+  if (!XB.valid) return;
+  const int i0 = b.IstrU - 1 + XB.bx * BLK_X, j0 = b.JstrV - 1 + XB.by * BLK_Y;
   const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
   const int tid = threadIdx.y * BLK_X + threadIdx.x;
   const bool inr = i <= b.Iendp2 && j <= b.Jendp2;
@@ -385,11 +377,11 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
     MpLev Lh;
     mp_cellq<MASK>(r0, co, so_s, 0, N, q, Lc, wz);
 #pragma unroll
-    for (int e = 0; e < Q_N; e++) lds[0][e][so] = co.ok ? q[e] : 0.0;
+    for (int e = 0; e < Q_N; e++) lds[0][e][so] = q[e];
     mp_cellq<MASK>(r0h, chh, sh_s, 0, N, q, Lh, wz);
     if (sh >= 0) {
 #pragma unroll
-      for (int e = 0; e < Q_N; e++) lds[0][e][sh] = halo ? q[e] : 0.0;
+      for (int e = 0; e < Q_N; e++) lds[0][e][sh] = q[e];
     }
   }
   MpRaw rn = mp_load_raw(f, co, 1, N, nij), rnh = mp_load_raw(f, chh, 1, N, nij);
@@ -403,11 +395,11 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
       MpLev Lh;
       mp_cellq<MASK>(rn, co, so_s, k, N, qo, Ln, WZk);
 #pragma unroll
-      for (int e = 0; e < Q_N; e++) lds[cu][e][so] = co.ok ? qo[e] : 0.0;
+      for (int e = 0; e < Q_N; e++) lds[cu][e][so] = qo[e];
       mp_cellq<MASK>(rnh, chh, sh_s, k, N, q, Lh, wz);
       if (sh >= 0) {
 #pragma unroll
-        for (int e = 0; e < Q_N; e++) lds[cu][e][sh] = halo ? q[e] : 0.0;
+        for (int e = 0; e < Q_N; e++) lds[cu][e][sh] = q[e];
       }
     }
     if (k < N) { rn = mp_load_raw(f, co, k + 1, N, nij); rnh = mp_load_raw(f, chh, k + 1, N, nij); }
@@ -805,13 +797,16 @@ int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
   }
   KERNEL_CHECK("k_mp_ta");
   {
-    dim3 g3 = grid2d(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1);
+    dim3 g3 = grid_tile_tracer(b.Iendp2 - (b.IstrU - 1) + 1, b.Jendp2 - (b.JstrV - 1) + 1, 1);
     void (*kern)(const RomsDev *, MpArgs) = g_ctx.p.masking ? (g_ctx.p.mpdata_fast ? k_mp_adiff<true, true> : k_mp_adiff<false, true>)
                                 : (g_ctx.p.mpdata_fast ? k_mp_adiff<true, false> : k_mp_adiff<false, false>);
     hipLaunchKernelGGL(kern, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
   }
   KERNEL_CHECK("k_mp_adiff");
-  constexpr int UTY = 8;                 // rows per workgroup of the fused limiter + update kernel
+#ifndef MP_UTY
+#define MP_UTY 8
+#endif
+  constexpr int UTY = MP_UTY;            // rows per workgroup of the fused limiter + update kernel
   const dim3 g((unsigned)((b.Iend - b.Istr + 1 + BLK_X - 1) / BLK_X), (unsigned)((b.Jend - b.Jstr + 1 + UTY - 1) / UTY), 1);
   const bool mk = g_ctx.p.masking != 0;
   void (*upd)(const RomsDev *, MpArgs);

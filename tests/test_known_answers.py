@@ -238,3 +238,380 @@ def test_tracer_wave_in_uniform_flow_u3(kind):
         assert abs(out[mode][0] / (-lam.real) - 1.0) < 3.0e-2, (out[mode][0], -lam.real)
     order = math.log2(out[2][0] / out[1][0])
     assert 3.8 < order < 4.05, (order, out)
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 3: the terms the four cases above leave unconstrained
+# ------------------------------------------------------------------------------------------------
+def _c4_symbol(theta):
+    """Fourth-order centred flux form: face value (7/12)(S[i] + S[i+1]) - (1/12)(S[i-1] + S[i+2])."""
+    e = complex(math.cos(theta), math.sin(theta))
+    face = (7.0 / 12.0) * (1.0 + e) - (1.0 / 12.0) * (1.0 / e + e * e)
+    return -(1.0 - 1.0 / e) * face
+
+
+def _c2_symbol(theta):
+    """Second-order centred flux form: face value (S[i] + S[i+1]) / 2."""
+    e = complex(math.cos(theta), math.sin(theta))
+    return -(1.0 - 1.0 / e) * 0.5 * (1.0 + e)
+
+
+def _wave_run(kind, scheme, mode, U=0.5, A=1.0, dt=100.0, nsteps=120, vadv="C4"):
+    """The passive tracer wave of test_tracer_wave_in_uniform_flow_u3 with another horizontal scheme; returns
+    (damping rate, phase speed, wavenumber, theta, dx, final field, initial field)."""
+    st = _channel(dt, 20)
+    ov = dict(Hadv=scheme, Vadv=vadv)
+    st = ana.make_tile("UPWELLING", perturb=0.0, overrides=dict(dt=dt, ndtfast=20, theta_s=0.0, theta_b=0.0, **ov))
+    st2 = _channel(dt, 20)
+    for name in ("h", "f", "fomn", "t", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx", "srflx", "Akv", "Akt", "zeta",
+                 "ubar", "vbar", "u", "v", "Zt_avg1"):
+        if st[name].shape == st2[name].shape:
+            st[name][:] = st2[name]
+        else:                                              # three ghost points (HSIMT / MPDATA): rebuild the flat channel
+            st[name][:] = {"h": H0, "Akv": 1.0e-5, "Akt": 1.0e-6}.get(name, 0.0)
+    st["t"][:, :, :, :, 0] = 14.0
+    st.p.Scoef = 0.0
+    b = st.b
+    dx = 1.0 / float(st["pm"][3, 3])
+    theta = 2.0 * math.pi * mode / b.Lm
+    xr = (np.arange(b.LBi, b.UBi + 1) - 0.5) * dx
+    k = theta / dx
+    S = 35.0 + A * np.cos(k * xr)
+    st["t"][:, :, :, :, 1] = S[:, None, None, None]
+    st["u"][:] = U
+    st["ubar"][:] = U
+    be = _backend(kind, st)
+    m = main3d.Main3D(be)
+    m.initial()
+    m.run(nsteps)
+    if kind == "hip":
+        be.to_host()
+        be.close()
+    T = nsteps * dt
+    Si = st.interior("t")[:, :, :, m.s.nnew - 1, 1]
+    xi = xr[st.I(b.Istr, b.Iend)]
+    assert float(np.abs(st.interior("u")[..., m.s.nnew - 1] - U).max()) < 1e-9
+    assert float(np.abs(Si - Si[:, :1, :1]).max()) < 1e-9
+    s1 = Si[:, 3, 5] - 35.0
+    c = 2.0 * np.mean(s1 * np.cos(k * xi)), 2.0 * np.mean(s1 * np.sin(k * xi))
+    amp, phase = math.hypot(*c), math.atan2(c[1], c[0])
+    phase += 2.0 * math.pi * round((k * U * T - phase) / (2.0 * math.pi))      # the branch next to k U T
+    return -math.log(amp / A) / T, phase / (k * T), k, theta, dx, s1, A * np.cos(k * xi)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("scheme", ["C2", "C4"])
+def test_tracer_wave_centred_schemes(kind, scheme):
+    """The centred flux forms have purely imaginary symbols: the wave keeps its amplitude and travels at the scheme's
+    own phase speed, U sin(theta)/theta (C2) and U (8 sin(theta) - sin(2 theta)) / (6 theta) (C4) -- constrains the
+    1/2 and the 7/12, -1/12 weights of the C2 / C4 branches of pre_step3d.F:330-420 and step3d_t.F:596-700 (a wrong
+    weight changes the speed at first order in theta^2)."""
+    U = 0.5
+    sym = _c2_symbol if scheme == "C2" else _c4_symbol
+    errs = {}
+    for mode in (2, 4):
+        rate, cph, k, theta, dx, _, _ = _wave_run(kind, scheme, mode, U=U)
+        lam = sym(theta) * U / dx
+        assert abs(lam.real) < 1e-12 * abs(lam.imag)
+        c_scheme = -lam.imag / k
+        errs[mode] = 1.0 - c_scheme / U                      # the scheme's own dispersion
+        assert abs(cph / c_scheme - 1.0) < 2.0e-4, (scheme, mode, cph, c_scheme)
+        # no damping beyond the time stepping's (third order in U k dt) and the tiny explicit diffusion
+        assert abs(rate) < 3.0e-8, (scheme, mode, rate)
+    # the dispersion the run was checked against is the scheme's formal order: 2 (C2) or 4 (C4)
+    order = math.log2(errs[4] / errs[2])
+    assert (1.9 < order < 2.1) if scheme == "C2" else (3.8 < order < 4.1), (scheme, order)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_tracer_wave_akima(kind):
+    """A4 (Akima): harmonic instead of arithmetic means of the slopes in the fourth-order correction; on a smooth
+    wave both agree to leading order, so the wave travels at U up to fourth-order dispersion (much better than
+    C2's sin(theta)/theta) and is not damped away from its extrema -- constrains the A4 branches' 1/2 and 1/6
+    (pre_step3d.F, step3d_t.F) without leaning on the harmonic mean's exact form."""
+    U = 0.5
+    rate, cph, k, theta, dx, _, _ = _wave_run(kind, "A4", 2, U=U)
+    c2 = -(_c2_symbol(theta) * U / dx).imag / k
+    assert abs(cph / U - 1.0) < 0.1 * abs(c2 / U - 1.0), (cph, c2)
+    assert abs(rate) < 2.0e-6
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_tracer_wave_hsimt_is_monotone(kind):
+    """HSIMT (Wu and Zhu 2010) is a TVD scheme: the translated wave never leaves the range of the initial one and
+    its total variation does not grow; it still travels at U."""
+    U = 0.5
+    rate, cph, k, theta, dx, s1, s0 = _wave_run(kind, "HSIMT", 2, U=U, vadv="HSIMT")
+    assert s1.max() <= s0.max() + 1e-12 and s1.min() >= s0.min() - 1e-12
+    tv = lambda s: float(np.abs(np.diff(np.concatenate([s, s[:1]]))).sum())
+    assert tv(s1) <= tv(s0) * (1.0 + 1e-12)
+    assert abs(cph / U - 1.0) < 5.0e-3, cph
+    assert 0.0 < rate < 2.0e-6, rate
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_mpdata_translates_a_positive_blob(kind):
+    """MPDATA (Smolarkiewicz): a positive blob in a uniform current stays positive, keeps its content, creates no
+    new maximum (the FCT limiter of mpdata_adiff.F:842-1100), moves with the current, and -- the point of the
+    anti-diffusive step -- spreads far less than under the first-order upstream step it corrects, whose numerical
+    diffusivity is U dx (1 - U dt/dx) / 2."""
+    U, dt, nsteps = 0.5, 100.0, 120
+    st = ana.make_tile("UPWELLING", perturb=0.0,
+                       overrides=dict(dt=dt, ndtfast=20, theta_s=0.0, theta_b=0.0, Hadv="MPDATA", Vadv="MPDATA"))
+    assert st.b.NghostPoints == 3
+    st["h"][:] = H0
+    st["f"][:] = 0.0
+    st["fomn"][:] = 0.0
+    for name in ("sustr", "svstr", "bustr", "bvstr", "stflx", "btflx", "srflx", "zeta", "vbar", "v", "Zt_avg1"):
+        st[name][:] = 0.0
+    st["Akv"][:] = 1.0e-5
+    st["Akt"][:] = 1.0e-6
+    st["t"][:, :, :, :, 0] = 14.0
+    st.p.Scoef = 0.0
+    b = st.b
+    dx = 1.0 / float(st["pm"][3, 3])
+    xr = (np.arange(b.LBi, b.UBi + 1) - 0.5) * dx
+    L = b.Lm * dx
+    x0, sig = 0.3 * L, 3.0 * dx
+    d = (xr - x0 + 0.5 * L) % L - 0.5 * L
+    S = 1.0 + np.exp(-0.5 * (d / sig) ** 2)                 # positive background, so the Courant-number guards do not switch
+    st["t"][:, :, :, :, 1] = S[:, None, None, None]
+    st["u"][:] = U
+    st["ubar"][:] = U
+    be = _backend(kind, st)
+    m = main3d.Main3D(be)
+    m.initial()
+    m.run(nsteps)
+    if kind == "hip":
+        be.to_host()
+        be.close()
+    T = nsteps * dt
+    Si = st.interior("t")[:, :, :, m.s.nnew - 1, 1]
+    assert float(np.abs(Si - Si[:, :1, :1]).max()) < 1e-9
+    s1 = Si[:, 3, 5]
+    s0 = S[st.I(b.Istr, b.Iend)]
+    xi = xr[st.I(b.Istr, b.Iend)]
+    assert s1.min() >= 1.0 - 1e-12 and s1.max() <= s0.max() + 1e-12            # no new extrema
+    assert abs(s1.sum() / s0.sum() - 1.0) < 1e-12                              # content
+    # centre and spread of the blob above its background (periodic first and second moments)
+    def moments(s):
+        w = s - 1.0
+        ang = 2.0 * math.pi * xi / L
+        cx, sx = float((w * np.cos(ang)).sum()), float((w * np.sin(ang)).sum())
+        xc = (math.atan2(sx, cx) % (2.0 * math.pi)) * L / (2.0 * math.pi)
+        dd = (xi - xc + 0.5 * L) % L - 0.5 * L
+        return xc, float((w * dd * dd).sum() / w.sum())
+    xc0, var0 = moments(s0)
+    xc1, var1 = moments(s1)
+    shift = (xc1 - xc0) % L
+    assert abs(shift / (U * T) - 1.0) < 5.0e-3, (shift, U * T)
+    K_upstream = 0.5 * U * dx * (1.0 - U * dt / dx)
+    assert var1 - var0 < 0.15 * (2.0 * K_upstream * T), (var1 - var0, 2.0 * K_upstream * T)
+    assert var1 > var0 - 1e-9
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_overturning_cell_lifts_a_stratified_tracer(kind):
+    """Vertical velocity and vertical tracer advection.  A weak overturning cell u = U0 sin(kx) cos(m(z+h)) (zero
+    vertical mean, homogeneous fluid: no pressure force, it changes only on the advective time scale L/U0) has
+    w = -(U0 k/m) cos(kx) sin(m(z+h)).  A passive tracer with a uniform vertical gradient G and no horizontal
+    gradient then obeys dS/dt = -w G: after a short time S - S0 = (U0 k G/m) cos(kx) sin(m(z+h)) t.  Constrains
+    omega.F:151-212 (W from the divergence of Huon, Hvom and the removal of its barotropic part), the vertical
+    advection of pre_step3d.F:619-915 and step3d_t.F:1100-1200 (C4 fluxes, the artificial-continuity term, the
+    Hz-weighted update) -- a wrong sign, weight or a missing 1/Hz shows at first order."""
+    U0, G = 1.0e-2, 1.0e-2
+    dt, nsteps = 100.0, 30
+    st = _channel(dt, 20)
+    st.p.Scoef = 0.0
+    b = st.b
+    be = _backend(kind, st)
+    m = main3d.Main3D(be)
+    m.initial()
+    if kind == "hip":
+        be.to_host(["z_r"])
+    dx = 1.0 / float(st["pm"][3, 3])
+    k = 2.0 * math.pi / (b.Lm * dx)
+    mz = math.pi / H0
+    xu = (np.arange(b.LBi, b.UBi + 1) - 1.0) * dx              # u-points
+    xr = (np.arange(b.LBi, b.UBi + 1) - 0.5) * dx
+    z = st["z_r"]
+    st["u"][:] = (U0 * np.sin(k * xu)[:, None, None] * np.cos(mz * (z + H0)))[..., None]
+    st["t"][:, :, :, :, 1] = (35.0 + G * z)[..., None]
+    if kind == "hip":
+        be.to_device(["u", "t"])
+    S0 = st["t"][:, :, :, 0, 1].copy()
+    m.run(nsteps)
+    if kind == "hip":
+        be.to_host()
+        be.close()
+    T = nsteps * dt
+    I, J = st.I(b.Istr, b.Iend), st.J(b.Jstr + 10, b.Jend - 10)     # away from the walls (v = 0 there, not in between)
+    dS = (st["t"][:, :, :, m.s.nnew - 1, 1] - S0)[I, J, :]
+    want = (U0 * k * G / mz) * np.cos(k * xr[I])[:, None, None] * np.sin(mz * (z[I, J, :] + H0)) * T
+    scale = float(np.abs(want).max())
+    assert scale > 1e-6
+    # the whole pattern: amplitude within half a per cent (second order in the layer thickness, first order in
+    # U0 k T -- the cell advects itself and the tracer it has lifted)
+    proj = float((dS * want).sum() / (want * want).sum())
+    assert abs(proj - 1.0) < 5.0e-3, proj
+    # point by point away from the bottom and the surface; the two levels next to either boundary use the
+    # reference's one-sided fourth-order weights (1/2, 7/12, -1/12), which are not exact for a linear profile
+    kin = slice(2, b.N - 2)
+    err = float(np.abs(dS[:, :, kin] - want[:, :, kin]).max())
+    assert err < 1.5e-2 * scale, err / scale
+    # ... where the answer is still right to the size of that known defect, and of the right sign
+    assert float(np.abs(dS - want).max()) < 6.0e-2 * scale
+
+
+def _ab3_root(z):
+    """Principal root of the third-order Adams-Bashforth scheme y(n+1) = y(n) + z (23/12 y(n) - 16/12 y(n-1) +
+    5/12 y(n-2)) for y' = lambda y, z = lambda dt -- the time stepping of the 3-D momentum equations
+    (Shchepetkin and McWilliams 2005; the reference starts it with one Euler and one AB2 step)."""
+    r = np.roots([1.0, -(1.0 + 23.0 / 12.0 * z), 16.0 / 12.0 * z, -5.0 / 12.0 * z])
+    return complex(r[np.argmin(np.abs(r - np.exp(z)))])
+
+
+def _quick_symbol(theta):
+    """As _u3_symbol with the curvature weight 1/8 instead of 1/6: the face value is the parabola through the two
+    upstream points and the downstream one evaluated AT the face (Leonard's QUICK; the reference's momentum
+    advection with its default upstream bias Gadv = -1/4), where the tracers' 1/6 makes the cell AVERAGE third
+    order."""
+    e = complex(math.cos(theta), math.sin(theta))
+    face = 0.5 * (1.0 + e) - (e - 2.0 + 1.0 / e) / 8.0
+    return -(1.0 - 1.0 / e) * face
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_momentum_wave_in_uniform_flow(kind):
+    """Horizontal momentum advection.  A weak cross-channel velocity wave v' = a cos(kx) cos(m(z+h)) with zero
+    vertical mean (so nothing barotropic, no pressure force in a homogeneous fluid) in a uniform current U is
+    translated and damped as the symbol of the upstream-biased parabolic face interpolation says (curvature weight
+    1/8: phase speed U (1 - theta^2/24 ...), damping (U/dx) theta^4/16 ...) --
+    constrains the momentum fluxes of rhs3d.F:596-900 (the Gadv = -1/4 curvature terms of UFx/VFx, the upstream
+    selection by the sign of Huon), the AB3 weights of step3d_uv.F:303-315 and pre_step3d.F:985-986 (the expected
+    phase speed and damping are those of the AB3 root of the spatial symbol: a mis-weighted combination shows at
+    O((U k dt)^2)) and the coupling step that must leave a zero-mean profile alone."""
+    U, a = 0.5, 1.0e-3
+    dt, nsteps, Mm = 100.0, 30, 240
+    out = {}
+    for mode in (1, 2):
+        # a long channel: where the wave meets the walls (v = 0 there) the initial state is not balanced and sheds a
+        # weak barotropic signal that crosses 120 km in 31 steps; the row in the middle is measured before that
+        st = ana.make_tile("UPWELLING", perturb=0.0,
+                           overrides=dict(dt=dt, ndtfast=20, theta_s=0.0, theta_b=0.0, visc2=0.0, Mm=Mm))
+        st["h"][:] = H0
+        st["f"][:] = 0.0
+        st["fomn"][:] = 0.0
+        st["t"][:, :, :, :, 0] = 14.0
+        st["t"][:, :, :, :, 1] = 35.0
+        for name in ("sustr", "svstr", "bustr", "bvstr", "stflx", "btflx", "srflx", "zeta", "ubar", "vbar", "u", "v", "Zt_avg1",
+                     "visc2_r", "visc2_p"):
+            st[name][:] = 0.0
+        st["Akv"][:] = 1.0e-7
+        st["Akt"][:] = 1.0e-6
+        b = st.b
+        assert b.Mm == Mm
+        be = _backend(kind, st)
+        m = main3d.Main3D(be)
+        m.initial()
+        if kind == "hip":
+            be.to_host(["z_r"])
+        dx = 1.0 / float(st["pm"][3, 3])
+        theta = 2.0 * math.pi * mode / b.Lm
+        k = theta / dx
+        mz = math.pi / H0
+        xr = (np.arange(b.LBi, b.UBi + 1) - 0.5) * dx            # v-points share x with the rho-points
+        prof = np.cos(mz * (st["z_r"] + H0))
+        v0 = a * np.cos(k * xr)[:, None, None] * prof
+        jj = np.arange(b.LBj, b.UBj + 1)
+        v0[:, (jj <= b.Jstr) | (jj >= b.Jend + 1), :] = 0.0       # the walls
+        st["v"][:] = v0[..., None]
+        st["u"][:] = U
+        st["ubar"][:] = U
+        if kind == "hip":
+            be.to_device(["u", "v", "ubar"])
+        jm = b.Mm // 2 - b.LBj
+        I = st.I(b.Istr, b.Iend)
+        xi = xr[I]
+        p1 = prof[I, jm, :]
+
+        def wave():
+            if kind == "hip":
+                be.to_host(["v"])
+            vi = st["v"][I, jm, :, m.s.nnew - 1]
+            amp_x = (vi * p1).sum(axis=1) / (p1 * p1).sum(axis=1)       # projection on the vertical mode, per column
+            c = 2.0 * np.mean(amp_x * np.cos(k * xi)), 2.0 * np.mean(amp_x * np.sin(k * xi))
+            return math.hypot(*c), math.atan2(c[1], c[0])
+        n1 = 5                        # past the Euler / AB2 start-up steps, which change the amplitude once by O((U k dt)^2)
+        m.run(n1)
+        amp1, ph1 = wave()
+        m.run(nsteps - n1)
+        amp, phase = wave()
+        if kind == "hip":
+            be.to_host()
+            be.close()
+        T = (nsteps - n1) * dt
+        phase -= ph1
+        phase += 2.0 * math.pi * round((k * U * T - phase) / (2.0 * math.pi))
+        g = _ab3_root(_quick_symbol(theta) * U / dx * dt)                # space and time discretisation together
+        out[mode] = -math.log(amp / amp1) / T
+        assert abs(phase / T / (-math.atan2(g.imag, g.real) / dt) - 1.0) < 2.0e-5, (mode, phase / T)
+        assert abs(out[mode] / (-math.log(abs(g)) / dt) - 1.0) < 4.0e-2, (mode, out[mode], -math.log(abs(g)) / dt)
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_baroclinic_inertial_oscillation(kind):
+    """Coriolis term and the time stepping of the 3-D momentum equations.  A horizontally uniform velocity with
+    zero vertical mean, (u, v) = a cos(m(z+h)) (1, 0), in a homogeneous rotating fluid turns as
+    u + i v = a exp(-i f t) away from the walls.  The frequency measured at two time steps must converge to f
+    faster than second order, and frequency and amplitude must follow the principal root of the third-order
+    Adams-Bashforth scheme with the weights 23/12, -16/12, 5/12 (step3d_uv.F:303-315, pre_step3d.F:985-986): decay
+    (3/8)(f dt)^4 per step, where AB2 weights would grow -- constrains sign and size of fomn in rhs3d.F:467-505 as
+    well."""
+    f0, a = -5.0e-4, 1.0e-3                     # f dt = 0.15 and 0.075: the scheme's own error is what is measured
+    errs = {}
+    for dt in (300.0, 150.0):
+        nsteps = int(round(4.0 * 2.0 * math.pi / abs(f0) / dt))
+        st = ana.make_tile("UPWELLING", perturb=0.0, overrides=dict(dt=dt, ndtfast=30, theta_s=0.0, theta_b=0.0, visc2=0.0))
+        st2 = _channel(dt, 30, f0=f0)
+        for name in ("h", "f", "fomn", "t", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx", "srflx", "Akv", "Akt", "zeta",
+                     "ubar", "vbar", "u", "v", "Zt_avg1"):
+            st[name][:] = st2[name]
+        st["visc2_r"][:] = 0.0
+        st["visc2_p"][:] = 0.0
+        st["Akv"][:] = 1.0e-7
+        b = st.b
+        be = _backend(kind, st)
+        m = main3d.Main3D(be)
+        m.initial()
+        if kind == "hip":
+            be.to_host(["z_r"])
+        prof = np.cos(math.pi / H0 * (st["z_r"] + H0))
+        st["u"][:] = (a * prof)[..., None]
+        if kind == "hip":
+            be.to_device(["u"])
+        i0, j0 = b.Lm // 2 - b.LBi, b.Mm // 2 - b.LBj
+        p1 = prof[i0, j0, :]
+        series = []
+        for _ in range(nsteps):
+            m.step()
+            if kind == "hip":
+                be.to_host(["u", "v"])
+            lev = m.s.nnew - 1
+            uu = float((st["u"][i0, j0, :, lev] * p1).sum() / (p1 * p1).sum())
+            vv = float((0.5 * (st["v"][i0, j0, :, lev] + st["v"][i0, j0 + 1, :, lev]) * p1).sum() / (p1 * p1).sum())
+            series.append(complex(uu, vv))
+        if kind == "hip":
+            be.close()
+        series = np.array(series) / a
+        n1 = 10                                                  # past the Euler / AB2 start-up steps
+        t = dt * np.arange(n1 + 1, nsteps + 1)
+        ph = np.unwrap(np.angle(series[n1:]))
+        w_fit = np.polyfit(t, ph, 1)[0]                           # u + i v = exp(-i f t): d(phase)/dt = -f
+        errs[dt] = abs(w_fit / (-f0) - 1.0)
+        g = _ab3_root(-1j * f0 * dt)
+        # frequency and amplitude follow the AB3 root: |g| = 1 - (3/8)(f dt)^4, arg g = -f dt (1 + O((f dt)^4))
+        assert abs(w_fit / (math.atan2(g.imag, g.real) / dt) - 1.0) < 1.0e-5, (dt, w_fit)
+        decay = -math.log(abs(series[-1]) / abs(series[n1])) / (nsteps - 1 - n1)
+        assert abs(decay / (-math.log(abs(g))) - 1.0) < 5.0e-2, (dt, decay, -math.log(abs(g)))
+        assert errs[dt] < 2.0e-3, (dt, w_fit, -f0)
+    order = math.log2(errs[300.0] / errs[150.0])
+    assert order > 2.6, (order, errs)
