@@ -359,6 +359,9 @@ def main():
                     help="N = 1 only: hand the library an RCCL id so that the tile is its own western / eastern neighbour "
                          "and every periodic exchange of the step travels through pack -> ncclSend/ncclRecv -> unpack "
                          "(what a tile of an N-GPU run executes, measured on one GPU; not the headline configuration)")
+    ap.add_argument("--graph-exchanges", choices=["auto", "on", "off"], default="auto",
+                    help="several tiles over RCCL: replay LOOP_2D with its exchanges as one hipGraph (roms_hip_graph_exchanges); "
+                         "auto = in --loopback only")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the extra leg of the default run: BENCHMARK3_MPDATA (BASELINE.json configuration 5) timed "
                          "after the headline configuration and reported under the key config5")
@@ -508,6 +511,8 @@ def main():
         t_ = torch.tensor([1 if transport == "rccl" else 0], dtype=torch.int32)
         dist.all_reduce(t_, op=dist.ReduceOp.SUM)
         rccl_ranks = int(t_.item())
+    if args.graph_exchanges != "auto":
+        be.graph_exchanges(args.graph_exchanges == "on")
     m = main3d.Main3D(be, physics=args.physics, diagnostics=args.physics)      # NINFO == 1 (roms_benchmark3.in:257)
     if world > 1 and args.physics:
         # diag.F:398-420: the tile-local results are reduced over the ranks every time (mp_reduce / mp_reduce2)
@@ -573,6 +578,7 @@ def main():
     cal.sort()
     measured_peak = 16.0 * ncal / (cal[len(cal) // 2] * 1e-3) / 1e9
     be.timing(False)
+    graph_state = be.graph_exchanges_state()      # 1: LOOP_2D ran as one hipGraph with its exchanges inside (loopback / opt-in)
     tile_cells = (b.Iend - b.Istr + 1) * (b.Jend - b.Jstr + 1) * b.N
     alg_bytes = 8.0 * (4 * b.NT + 4) * tile_cells          # SURVEY.md section 8d (compulsory traffic)
     t_ms = per_kernel.get("step3d_t", float("nan"))
@@ -595,7 +601,7 @@ def main():
                            + ("analytic atmospheric forcing, bulk fluxes + KPP + diagnostics every step"
                               if args.physics else "fixed forcing / mixing fields"),
                "tiling": f"{ntI}x{ntJ}", "halo_transport": transport, "rccl_ranks": rccl_ranks,
-               "halo_selftest": selftest,
+               "halo_selftest": selftest, "graph_exchanges": graph_state,
                "per_step_physics": "ana_srflux+bulk_flux+set_vbc+lmd_vmix (KPP)+wvelocity+diag (NINFO=1) on device"
                if args.physics else "fixed inputs", "dt_s": dt, "ndtfast": st.p.ndtfast, "finite": ok}
         if notes:

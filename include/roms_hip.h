@@ -291,6 +291,15 @@ int roms_hip_diag(const roms_step_idx_t *s, double *out12);
  * stream without returning to the host).  indx1 is mod_stepping's indx1(ng), updated on return. */
 int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1);
 
+/* Several tiles over RCCL: replay LOOP_2D as ONE hipGraph that contains the compute launches, the pack / unpack
+ * launches and the ncclSend / ncclRecv groups of its 2*nfast+1 calls (RCCL enqueues its kernels on the capturing
+ * stream).  Every rank of the communicator must switch it on before its first roms_hip_step2d_loop, since all of
+ * them then capture once and replay the same sequence; off by default between ranks, always tried in loopback.  If
+ * the stack refuses the capture the loop keeps running eagerly.  state: 0 = eager, 1 = graph in use, -1 = capture was
+ * tried and refused.  (the reference's loop is step2d_LF_AM3.h:509-590 per call.) */
+int roms_hip_graph_exchanges(int on);
+int roms_hip_graph_exchanges_state(void);
+
 /* mp_exchange2d/3d/4d (ROMS/Utility/mp_exchange.F:290/1413/2753) together
  * with the periodic exchange_*_tile (exchange_2d.F:229, exchange_3d.F:259) on
  * whole registered fields; level = 1-based trailing index (time level or

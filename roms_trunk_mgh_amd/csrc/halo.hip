@@ -318,6 +318,22 @@ extern "C" int roms_hip_halo_plan(const roms_bounds_t *b, int rank, int *out)
   return 0;
 }
 
+static void ensure_neigh();
+
+// hipGraph capture of a loop with exchanges inside (k_step2d.hip): possible with the RCCL transport only (the relay
+// synchronises the stream), and the message buffers must exist before the capture starts.
+bool halo_rccl_capturable() { return g_ctx.nccl_comm != nullptr && g_relay == nullptr; }
+int halo_reserve_buffers()
+{
+  ensure_neigh();
+  if (!g_have_plan) { g_plan = make_plan(g_ctx.b, g_neigh); g_have_plan = true; }
+  long smax = 0, rmax = 0;
+  for (int m = 0; m < g_plan.nsend; m++) smax += (long)g_plan.send[m].wi * g_plan.send[m].wj;
+  for (int m = 0; m < g_plan.nrecv; m++) rmax += (long)g_plan.recv[m].wi * g_plan.recv[m].wj;
+  const long planes = (long)HALO_MAX_ITEMS * (g_ctx.b.N + 1);       // the largest batch: eight 3-D W-type fields
+  return ensure_buffers((size_t)((smax > rmax ? smax : rmax) * planes));
+}
+
 // One exchange = a list of fields (each nk planes) whose ghost points travel in ONE message per
 // neighbour: every RCCL group costs a fixed latency, and the barotropic loop alone issues
 // dozens of exchanges per step.
@@ -404,6 +420,24 @@ static int exchange_all(const HaloItem *items, int nitems)
   return 0;
 }
 
+static void ensure_neigh()
+{
+  const roms_bounds_t &b = g_ctx.b;
+  if (!g_have_neigh) {
+    int v[12];
+    roms_hip_tile_neighbors(g_ctx.rank, b.ntileI, b.ntileJ, b.NghostPoints, b.NghostPoints,
+                            b.EWperiodic, b.NSperiodic, v);
+    g_neigh = Neigh{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]};
+    if (g_ctx.loopback && b.EWperiodic) {
+      // the tile is its own W and E neighbour; it is west-most and east-most at once, so both halves of
+      // the Nghost+1 rule (mp_exchange.F:155-187) apply
+      g_neigh.Wtile = g_neigh.Etile = g_ctx.rank;
+      if (b.NghostPoints != 3) g_neigh.GrecvW = g_neigh.GsendE = b.NghostPoints + 1;
+    }
+    g_have_neigh = true;
+  }
+}
+
 static int halo_run(const HaloItem *items, int nitems)
 {
   const roms_bounds_t &b = g_ctx.b;
@@ -432,19 +466,7 @@ static int halo_run(const HaloItem *items, int nitems)
     KERNEL_CHECK("k_periodic_multi");
     return 0;
   }
-  if (!g_have_neigh) {
-    int v[12];
-    roms_hip_tile_neighbors(g_ctx.rank, b.ntileI, b.ntileJ, b.NghostPoints, b.NghostPoints,
-                            b.EWperiodic, b.NSperiodic, v);
-    g_neigh = Neigh{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]};
-    if (g_ctx.loopback && b.EWperiodic) {
-      // the tile is its own W and E neighbour; it is west-most and east-most at once, so both halves of
-      // the Nghost+1 rule (mp_exchange.F:155-187) apply
-      g_neigh.Wtile = g_neigh.Etile = g_ctx.rank;
-      if (b.NghostPoints != 3) g_neigh.GrecvW = g_neigh.GsendE = b.NghostPoints + 1;
-    }
-    g_have_neigh = true;
-  }
+  ensure_neigh();
   // a periodic direction held by ONE tile row/column is a local copy
   if (b.EWperiodic && b.ntileI == 1 && !g_ctx.loopback) {
     for (int f = 0; f < nitems; f++) {

@@ -396,9 +396,28 @@ static int step2d_loop_body(roms_step_idx_t *s, int *indx1)
 // tiles the loop contains host-side transport calls and runs eagerly.
 struct LoopGraph { hipGraphExec_t exec; int indx1_out; roms_step_idx_t s_out; };
 static std::map<int, LoopGraph> g_loop_graphs;
+static int g_graph_exchanges = 2;            // roms_hip_graph_exchanges: 0 never, 1 always, 2 (default) in loopback only
+static bool g_rccl_graph_failed = false;     // the capture of the transport failed once on this stack: stay eager
+bool halo_rccl_capturable();                  // halo.hip: RCCL transport in use, message plan and buffers can be fixed
+int halo_reserve_buffers();                   // halo.hip: allocate the message buffers for the largest exchange now
+
+extern "C" int roms_hip_graph_exchanges(int on)
+{
+  g_graph_exchanges = on ? 1 : 0;
+  step2d_graphs_release();
+  return 0;
+}
+// 0 = LOOP_2D runs eagerly on several tiles, 1 = replayed as one hipGraph with the exchanges inside, -1 = the capture
+// was tried and refused by this stack
+extern "C" int roms_hip_graph_exchanges_state(void)
+{
+  if (g_rccl_graph_failed) return -1;
+  return g_loop_graphs.empty() ? 0 : 1;
+}
 
 void step2d_graphs_release()
 {
+  g_rccl_graph_failed = false;
   for (auto &kv : g_loop_graphs)
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   g_loop_graphs.clear();
@@ -413,15 +432,34 @@ extern "C" int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1)
   ScopedTimer tm("step2d_loop");
   const roms_bounds_t &b = g_ctx.b;
   const bool one_tile = b.ntileI * b.ntileJ == 1 && !g_ctx.loopback;
-  if (!one_tile) return step2d_loop_body(s, indx1);
+  // Several tiles over RCCL: the loop's launches AND its ncclSend / ncclRecv groups are captured too (RCCL enqueues
+  // its kernels on the capturing stream), so that a replay is one hipGraphLaunch for 59 compute launches, 59 packs,
+  // 59 transport kernels and 59 unpacks.  Loopback (one tile that is its own neighbour) always tries it; between
+  // ranks it is opt-in (roms_hip_graph_exchanges), because every rank must capture and replay the same sequence.
+  // If the capture fails on this stack the loop runs eagerly from then on.
+  const bool rccl_graph = !one_tile && halo_rccl_capturable() && !g_rccl_graph_failed &&
+                          (g_graph_exchanges == 1 || (g_graph_exchanges == 2 && g_ctx.loopback));
+  if (!one_tile && !rccl_graph) return step2d_loop_body(s, indx1);
   const int phase = s->iic == s->ntfirst ? 0 : (s->iic == s->ntfirst + 1 ? 1 : 2);
   const int key = ((*indx1 * 4 + s->nstp) * 4 + s->nnew) * 4 + phase;
   auto it = g_loop_graphs.find(key);
   if (it == g_loop_graphs.end()) {
     hipGraph_t graph = nullptr;
+    const roms_step_idx_t s_in = *s;
+    const int indx1_in = *indx1;
+    if (rccl_graph && (rc = halo_reserve_buffers())) return rc;       // no allocation inside a capture
     HIP_TRY(hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeThreadLocal));
     rc = step2d_loop_body(s, indx1);
     const hipError_t e = hipStreamEndCapture(g_ctx.stream, &graph);
+    if (rccl_graph && (rc || e != hipSuccess)) {
+      // this stack does not capture the transport: remember it and run the loop the ordinary way
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      g_rccl_graph_failed = true;
+      *s = s_in;
+      *indx1 = indx1_in;
+      return step2d_loop_body(s, indx1);
+    }
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return roms_fail("roms_hip_step2d_loop: hipStreamEndCapture", hipGetErrorString(e));
     LoopGraph lg{nullptr, *indx1, *s};

@@ -146,6 +146,14 @@ MODULE roms_hip_mod
     INTEGER(c_int) FUNCTION roms_hip_check_guards () BIND(C, name='roms_hip_check_guards')
       IMPORT :: c_int
     END FUNCTION roms_hip_check_guards
+    ! LOOP_2D with its RCCL exchanges as one hipGraph (several tiles; every rank switches it on before the first loop)
+    INTEGER(c_int) FUNCTION roms_hip_graph_exchanges (on) BIND(C, name='roms_hip_graph_exchanges')
+      IMPORT :: c_int
+      INTEGER(c_int), VALUE :: on
+    END FUNCTION roms_hip_graph_exchanges
+    INTEGER(c_int) FUNCTION roms_hip_graph_exchanges_state () BIND(C, name='roms_hip_graph_exchanges_state')
+      IMPORT :: c_int
+    END FUNCTION roms_hip_graph_exchanges_state
     INTEGER(c_int) FUNCTION roms_hip_sync_all_to_host () BIND(C, name='roms_hip_sync_all_to_host')
       IMPORT :: c_int
     END FUNCTION roms_hip_sync_all_to_host

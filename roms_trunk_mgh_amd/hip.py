@@ -40,7 +40,8 @@ DECLARED_SYMBOLS = (
      "roms_hip_step2d_loop", "roms_hip_exchange", "roms_hip_timing_enable",
      "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay", "roms_hip_diag",
      "roms_hip_snapshot_begin", "roms_hip_snapshot_end", "roms_hip_halo_plan",
-     "roms_hip_ana_srflux", "roms_hip_check_guards", "roms_hip_row_metrics_state"] + ["roms_hip_" + e for e in ENTRIES])
+     "roms_hip_ana_srflux", "roms_hip_check_guards", "roms_hip_row_metrics_state",
+     "roms_hip_graph_exchanges", "roms_hip_graph_exchanges_state"] + ["roms_hip_" + e for e in ENTRIES])
 
 
 _DP = C.POINTER(C.c_double)
@@ -233,6 +234,14 @@ class RomsHip:
         """roms_hip_row_metrics_state: 0 not examined, 1 metric arrays independent of i (row table), 2 not."""
         self.l.roms_hip_row_metrics_state.restype = C.c_int
         return int(self.l.roms_hip_row_metrics_state())
+
+    def graph_exchanges(self, on=True):
+        """Several tiles over RCCL: replay LOOP_2D with its exchanges as one hipGraph (roms_hip.h)."""
+        self._chk(self.l.roms_hip_graph_exchanges(int(on)), "graph_exchanges")
+
+    def graph_exchanges_state(self):
+        self.l.roms_hip_graph_exchanges_state.restype = C.c_int
+        return int(self.l.roms_hip_graph_exchanges_state())
 
     def check_guards(self):
         """Raise if a kernel stored outside one of the device arrays (roms_hip_check_guards)."""

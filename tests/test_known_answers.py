@@ -310,7 +310,7 @@ def test_tracer_wave_centred_schemes(kind, scheme):
     sym = _c2_symbol if scheme == "C2" else _c4_symbol
     errs = {}
     for mode in (2, 4):
-        rate, cph, k, theta, dx, _, _ = _wave_run(kind, scheme, mode, U=U)
+        rate, cph, k, theta, dx, _, _ = _wave_run(kind, scheme, mode, U=U, vadv=scheme)      # the pairs the library builds
         lam = sym(theta) * U / dx
         assert abs(lam.real) < 1e-12 * abs(lam.imag)
         c_scheme = -lam.imag / k
@@ -330,7 +330,7 @@ def test_tracer_wave_akima(kind):
     C2's sin(theta)/theta) and is not damped away from its extrema -- constrains the A4 branches' 1/2 and 1/6
     (pre_step3d.F, step3d_t.F) without leaning on the harmonic mean's exact form."""
     U = 0.5
-    rate, cph, k, theta, dx, _, _ = _wave_run(kind, "A4", 2, U=U)
+    rate, cph, k, theta, dx, _, _ = _wave_run(kind, "A4", 2, U=U, vadv="A4")
     c2 = -(_c2_symbol(theta) * U / dx).imag / k
     assert abs(cph / U - 1.0) < 0.1 * abs(c2 / U - 1.0), (cph, c2)
     assert abs(rate) < 2.0e-6
