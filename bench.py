@@ -361,7 +361,7 @@ def main():
                          "(what a tile of an N-GPU run executes, measured on one GPU; not the headline configuration)")
     ap.add_argument("--graph-exchanges", choices=["auto", "on", "off"], default="auto",
                     help="several tiles over RCCL: replay LOOP_2D with its exchanges as one hipGraph (roms_hip_graph_exchanges); "
-                         "auto = in --loopback only")
+                         "auto = the library's default (off: measured slower in wall time on this stack)")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the extra leg of the default run: BENCHMARK3_MPDATA (BASELINE.json configuration 5) timed "
                          "after the headline configuration and reported under the key config5")

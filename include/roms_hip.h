@@ -294,7 +294,8 @@ int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1);
 /* Several tiles over RCCL: replay LOOP_2D as ONE hipGraph that contains the compute launches, the pack / unpack
  * launches and the ncclSend / ncclRecv groups of its 2*nfast+1 calls (RCCL enqueues its kernels on the capturing
  * stream).  Every rank of the communicator must switch it on before its first roms_hip_step2d_loop, since all of
- * them then capture once and replay the same sequence; off by default between ranks, always tried in loopback.  If
+ * them then capture once and replay the same sequence.  Off by default: on this stack the replay shortens the loop's
+ * device time (BENCHMARK1 tile, loopback: 1.85 -> 1.65 ms) but lengthens the step's wall time (3.05 -> 3.64 ms).  If
  * the stack refuses the capture the loop keeps running eagerly.  state: 0 = eager, 1 = graph in use, -1 = capture was
  * tried and refused.  (the reference's loop is step2d_LF_AM3.h:509-590 per call.) */
 int roms_hip_graph_exchanges(int on);

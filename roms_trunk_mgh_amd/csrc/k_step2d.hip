@@ -396,7 +396,7 @@ static int step2d_loop_body(roms_step_idx_t *s, int *indx1)
 // tiles the loop contains host-side transport calls and runs eagerly.
 struct LoopGraph { hipGraphExec_t exec; int indx1_out; roms_step_idx_t s_out; };
 static std::map<int, LoopGraph> g_loop_graphs;
-static int g_graph_exchanges = 2;            // roms_hip_graph_exchanges: 0 never, 1 always, 2 (default) in loopback only
+static int g_graph_exchanges = 0;            // roms_hip_graph_exchanges: 0 (default) never, 1 always, 2 in loopback only
 static bool g_rccl_graph_failed = false;     // the capture of the transport failed once on this stack: stay eager
 bool halo_rccl_capturable();                  // halo.hip: RCCL transport in use, message plan and buffers can be fixed
 int halo_reserve_buffers();                   // halo.hip: allocate the message buffers for the largest exchange now
@@ -432,11 +432,12 @@ extern "C" int roms_hip_step2d_loop(roms_step_idx_t *s, int *indx1)
   ScopedTimer tm("step2d_loop");
   const roms_bounds_t &b = g_ctx.b;
   const bool one_tile = b.ntileI * b.ntileJ == 1 && !g_ctx.loopback;
-  // Several tiles over RCCL: the loop's launches AND its ncclSend / ncclRecv groups are captured too (RCCL enqueues
+  // Several tiles over RCCL: the loop's launches AND its ncclSend / ncclRecv groups can be captured too (RCCL enqueues
   // its kernels on the capturing stream), so that a replay is one hipGraphLaunch for 59 compute launches, 59 packs,
-  // 59 transport kernels and 59 unpacks.  Loopback (one tile that is its own neighbour) always tries it; between
-  // ranks it is opt-in (roms_hip_graph_exchanges), because every rank must capture and replay the same sequence.
-  // If the capture fails on this stack the loop runs eagerly from then on.
+  // 59 transport kernels and 59 unpacks.  Opt-in (roms_hip_graph_exchanges): measured in loopback on BENCHMARK1
+  // (ROCm 7.2, RCCL of this image) the loop's device time drops from 1.85 to 1.65 ms but the step's wall time RISES
+  // from 3.05 to 3.64 ms -- replaying what RCCL records besides its kernels costs more on the host than the eager
+  // calls.  Every rank must capture and replay the same sequence.  If the capture fails the loop runs eagerly.
   const bool rccl_graph = !one_tile && halo_rccl_capturable() && !g_rccl_graph_failed &&
                           (g_graph_exchanges == 1 || (g_graph_exchanges == 2 && g_ctx.loopback));
   if (!one_tile && !rccl_graph) return step2d_loop_body(s, indx1);
