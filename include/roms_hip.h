@@ -33,7 +33,7 @@ extern "C" {
 /* ------------------------------------------------------------------ */
 enum roms_kind {
   K_2D = 0, K_2D_T2, K_2D_T3, K_2D_NT,
-  K_3DR, K_3DW, K_3DR_T2, K_3DW_T2, K_3DW_NAT, K_4DT, K_3DR_NT
+  K_3DR, K_3DW, K_3DR_T2, K_3DW_T2, K_3DW_NAT, K_4DT, K_3DR_NT, K_3DW_T3
 };
 
 enum roms_field_id {
@@ -167,7 +167,18 @@ typedef struct roms_params {
   /* UV_LOGDRAG (uv_drag = 3): limits of the drag coefficient of the logarithmic bottom layer, roms_*.in Cdb_min /
    * Cdb_max (mod_scalars.F:747-748); the roughness length is the field ZoBot */
   double Cdb_min, Cdb_max;
+  /* GLS_MIXING: the generic length-scale closure of Umlauf and Burchard (2003) as gls_prestep.F / gls_corstep.F build
+   * it (main3d.F:564-567, :790-793); the parameter sets of roms_*.in (GLS_P ... GLS_SIGP: k-kl = Mellor-Yamada 2.5,
+   * k-epsilon, k-omega, gen) select the closure.  gls_stability: enum roms_gls_stab (the CPP choice GALPERIN (none),
+   * KANTHA_CLAYSON, CANUTO_A, CANUTO_B); gls_n2s2_horavg = N2S2_HORAVG; gls_ri_splines = RI_SPLINES (the shear from
+   * parabolic splines); the third-order upstream advection of tke / gls (neither K_C2ADVECTION nor K_C4ADVECTION).
+   * CRAIG_BANNER, CHARNOK, ZOS_HSIG, TKE_WAVEDISS are not built.  Akk_bak, Akp_bak: background diffusivities of
+   * tke and gls; Zos: surface roughness (m), mod_scalars.F. */
+  int    gls_mixing, gls_stability, gls_n2s2_horavg, gls_ri_splines;
+  double gls_p, gls_m, gls_n, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp, gls_Kmin, gls_Pmin;
+  double Akk_bak, Akp_bak, Zos;
 } roms_params_t;
+enum roms_gls_stab { GLS_GALPERIN = 0, GLS_KANTHA_CLAYSON = 1, GLS_CANUTO_A = 2, GLS_CANUTO_B = 3 };
 
 /* Time-level indices = mod_stepping.F (nstp,nnew,nrhs,kstp,krhs,knew) and
  * mod_scalars.F (iic, iif, ntfirst, PREDICTOR_2D_STEP); see
@@ -277,6 +288,12 @@ int roms_hip_lmd_vmix(const roms_step_idx_t *s);
  * hour that caldate (ROMS/Utility/dateclock.F:73) returns for tdays(ng) -- the host passes those two numbers --
  * with the cloud and water-vapour corrections from cloud, Tair, Hair.  Writes srflx. */
 int roms_hip_ana_srflux(double yday, double hour);
+/* gls_prestep(ng,tile)             ROMS/Nonlinear/gls_prestep.F:23   (main3d.F:567, after rhs3d)
+ * gls_corstep(ng,tile)             ROMS/Nonlinear/gls_corstep.F:27   (main3d.F:793, after omega and before step3d_t)
+ * with tkebc_tile (tkebc_im.F:50: closed and gradient edges).  GLS_MIXING applications only: these two replace
+ * lmd_vmix as the source of Akv / Akt. */
+int roms_hip_gls_prestep(const roms_step_idx_t *s);
+int roms_hip_gls_corstep(const roms_step_idx_t *s);
 /* wvelocity(ng,tile,nstp)          ROMS/Nonlinear/wvelocity.F:27     (main3d.F:475; writes wvel) */
 int roms_hip_wvelocity(const roms_step_idx_t *s);
 /* diag(ng,tile)                    ROMS/Nonlinear/diag.F:31          (main3d.F:314), the tile-local part

@@ -17,7 +17,9 @@
 #                                 (= the application plus TS_DIF4 and UV_VIS4), UPWELLING_MASK_DIF4; UPWELLING_ISO, SEAMOUNT_ISO,
 #                                 UPWELLING_MASK_ISO (= the _DIF4 options with MIX_ISO_TS as the tracer mixing choice); UPWELLING_LOGDRAG
 #                                 (UV_LOGDRAG instead of UV_LDRAG); UPWELLING_PJ, SEAMOUNT_PJ (PJ_GRADP: prsgrd40.h); UPWELLING_RAD2D,
-#                                 UPWELLING_MASK_RAD2D, BENCHMARK_RAD2D (+ -DRADIATION_2D)
+#                                 UPWELLING_MASK_RAD2D, BENCHMARK_RAD2D (+ -DRADIATION_2D); UPWELLING_GLS, UPWELLING_MASK_GLS
+#                                 (GLS_MIXING + KANTHA_CLAYSON + N2S2_HORAVG + RI_SPLINES instead of ANA_VMIX), BENCHMARK_GLS
+#                                 (GLS_MIXING + CANUTO_A instead of the KPP block): gls_prestep.F, gls_corstep.F, tkebc_im.F
 #
 # This is the reference's own recipe (makefile:207, Compilers/Linux-gfortran.mk:
 # 43-44: cpp -P -traditional then the Fortran compiler), serial build (no
@@ -43,6 +45,7 @@ FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iouni
  Nonlinear/zetabc Nonlinear/u2dbc_im Nonlinear/v2dbc_im Nonlinear/u3dbc_im Nonlinear/v3dbc_im Nonlinear/t3dbc_im
  Nonlinear/ini_fields
  Nonlinear/bc_3d Utility/shapiro Nonlinear/lmd_swfrac Nonlinear/lmd_skpp Nonlinear/lmd_vmix
+ Nonlinear/tkebc_im Nonlinear/gls_prestep Nonlinear/gls_corstep
 
  Utility/stats Functionals/analytical Nonlinear/wvelocity Nonlinear/diag Utility/set_scoord Utility/metrics"
 
@@ -60,12 +63,14 @@ build_app () {
   case $TAG in *_RAD2D) XDEF="$XDEF -DRADIATION_2D";; esac
   case $TAG in *_LIMBS) XDEF="$XDEF -DLIMIT_BSTRESS";; esac
   case $TAG in *_EMP) XDEF="$XDEF -DEMINUSP";; esac              # BENCHMARK[_MASK]_EMP: + EMINUSP (bulk_flux.F:883-899)      # <APP>_LIMBS: + LIMIT_BSTRESS (set_vbc.F:533-567)
-  case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_PJ) VAR=pj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; *_LOGDRAG) VAR=logdrag; WDEF="-DREF_LOGDRAG";; esac
+  case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_PJ) VAR=pj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; *_LOGDRAG) VAR=logdrag; WDEF="-DREF_LOGDRAG";; *_GLS) VAR=gls; WDEF="-DREF_GLS";; esac
   local hdr=$(echo $APP | tr A-Z a-z).h
   # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
   [ "$APP" = UPWELLING ] && hdr=upwelling_$VAR.h
   # SEAMOUNT: same numerics without ANA_DIAG, whose ana_diag.h does not compile (see ref_headers/seamount_nodiag.h)
   [ "$APP" = SEAMOUNT ] && hdr=seamount_$VAR.h
+  # BENCHMARK_GLS: benchmark.h with the KPP block replaced by GLS_MIXING + CANUTO_A (ref_headers/benchmark_gls.h)
+  [ "$APP" = BENCHMARK ] && [ "$VAR" = gls ] && hdr=benchmark_gls.h
   local D=$OUT/$TAG
   if [ -f $D/libref.so ] && [ $D/libref.so -nt $HERE/ref_wrap.F90 ] && [ $D/libref.so -nt $HERE/build_ref.sh ]; then
     return 0
@@ -93,7 +98,7 @@ build_app () {
   echo "[$TAG] built $D/libref.so"
 }
 
-for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ UPWELLING_RAD2D UPWELLING_MASK_RAD2D BENCHMARK_RAD2D UPWELLING_LIMBS BENCHMARK_LIMBS BENCHMARK_EMP BENCHMARK_MASK_EMP}; do
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ UPWELLING_RAD2D UPWELLING_MASK_RAD2D BENCHMARK_RAD2D UPWELLING_LIMBS BENCHMARK_LIMBS BENCHMARK_EMP BENCHMARK_MASK_EMP UPWELLING_GLS UPWELLING_MASK_GLS BENCHMARK_GLS}; do
   build_app $app &
 done
 wait

@@ -208,6 +208,8 @@ int oracle_rhs3d(OARGS);
 int oracle_step2d(OARGS);
 int oracle_step3d_uv(OARGS);
 int oracle_step3d_t(OARGS);
+int oracle_gls_prestep(OARGS);     /* oracle_gls.c: gls_prestep.F:66 */
+int oracle_gls_corstep(OARGS);     /* gls_corstep.F:101 */
 int oracle_ini_zeta(OARGS);        /* ini_fields.F:836 */
 int oracle_ini_fields(OARGS);      /* ini_fields.F:106 */
 int oracle_step2d_loop(const roms_bounds_t *b, const roms_params_t *p, roms_step_idx_t *s,

@@ -36,6 +36,8 @@ class Ref:
             app += "_LIMBS"                                                # built with -DLIMIT_BSTRESS
         if state.p.radiation_2d:
             app += "_RAD2D"                                                # built with -DRADIATION_2D
+        if state.p.gls_mixing:
+            app += "_GLS"                                                  # GLS_MIXING builds (ref_headers/*_gls.h)
         self.l = C.CDLL(lib_path(app))
         self.st = state
         self.l.ref_abi_sizeof.argtypes = [C.c_int]
@@ -106,6 +108,15 @@ class Ref:
         rc = self.l.ref_physics(kid, C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))
         if rc != 0:
             raise RuntimeError(f"ref_physics {kernel} rc={rc}")
+
+    def gls(self, kernel, s):
+        """gls_prestep / gls_corstep through the reference's own module procedures (GLS builds only: ref_gls)."""
+        kid = {"gls_prestep": 1, "gls_corstep": 2}[kernel]
+        self.l.ref_gls.argtypes = [C.c_int, C.POINTER(abi.Bounds), C.POINTER(abi.Params), C.POINTER(abi.StepIdx),
+                                   C.POINTER(abi.Fields)]
+        rc = self.l.ref_gls(kid, C.byref(self.st.b), C.byref(self.st.p), C.byref(s), C.byref(self.F))
+        if rc != 0:
+            raise RuntimeError(f"ref_gls {kernel} rc={rc}")
 
     def diagnostics(self, kernel, s, workdir="."):
         """wvelocity (writes wvel) or diag through the reference's own module procedures.  diag keeps no

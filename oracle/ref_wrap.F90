@@ -53,6 +53,9 @@ MODULE ref_wrap_types
     INTEGER(c_int) :: ts_dif4, uv_vis4
     INTEGER(c_int) :: mix_iso_ts, radiation_2d
     REAL(c_double) :: Cdb_min, Cdb_max
+    INTEGER(c_int) :: gls_mixing, gls_stability, gls_n2s2_horavg, gls_ri_splines
+    REAL(c_double) :: gls_p, gls_m, gls_n, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp, gls_Kmin, gls_Pmin
+    REAL(c_double) :: Akk_bak, Akp_bak, Zos
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -73,6 +76,7 @@ MODULE ref_wrap_types
     TYPE(c_ptr) :: zeta_bry, ubar_bry, vbar_bry, u_bry, v_bry, t_bry
     TYPE(c_ptr) :: visc4_p, visc4_r, diff4
     TYPE(c_ptr) :: ZoBot
+    TYPE(c_ptr) :: tke, gls, Lscale, Akk, Akp
   END TYPE fields_t
   LOGICAL, SAVE :: have_boundary = .FALSE.      ! allocate_boundary is done once per process
 END MODULE ref_wrap_types
@@ -757,7 +761,7 @@ FUNCTION ref_ana (kernel, b, p, F, cfg, scout) BIND(C, name='ref_ana') RESULT(rc
     CALL c_f_pointer (F%svstr, a2, (/ni,nj/));   a2 = FORCES(ng)%svstr
     CALL c_f_pointer (F%stflux, a3, (/ni,nj,NTT/)); a3 = FORCES(ng)%stflux
 # endif
-# ifdef UPWELLING
+# if defined UPWELLING && !defined REF_GLS
     !  ANA_VMIX: analytic vertical mixing coefficients on the z_w of F (ana_vmix.h)
     CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); GRID(ng)%z_w = a3
     CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
@@ -1068,3 +1072,111 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   a4 = OCEAN(ng)%v
   CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); a5 = OCEAN(ng)%t
 END FUNCTION ref_bc
+
+!-----------------------------------------------------------------------
+!  GLS_MIXING (builds with -DREF_GLS: ref_headers/upwelling_gls.h, benchmark_gls.h): kernel 1 = gls_prestep
+!  (gls_prestep.F:23), 2 = gls_corstep (gls_corstep.F:27), as main3d.F:567 / :793 call them.  The closure
+!  parameters of roms_*.in (GLS_P ... GLS_SIGP, AKK_BAK, AKP_BAK, ZOS) come from the params block; the stability
+!  constants are what initialize_scalars (ref_setup) computed.  LBC(:,isMtke,ng) = the tracers' table (closed or
+!  gradient: tkebc_im.F treats both alike).
+#ifdef REF_GLS
+FUNCTION ref_gls (kernel, b, p, s, F) BIND(C, name='ref_gls') RESULT(rc)
+  USE ref_wrap_types
+  USE mod_param
+  USE mod_scalars
+  USE mod_ncparam
+  USE mod_stepping
+  USE mod_grid
+  USE mod_ocean
+  USE mod_mixing
+  USE mod_forces
+  USE mod_boundary, ONLY : allocate_boundary
+  USE gls_prestep_mod, ONLY : gls_prestep
+  USE gls_corstep_mod, ONLY : gls_corstep
+  INTEGER(c_int), VALUE :: kernel
+  TYPE(bounds_t), INTENT(in) :: b
+  TYPE(params_t), INTENT(in) :: p
+  TYPE(stepidx_t), INTENT(in) :: s
+  TYPE(fields_t), INTENT(in) :: F
+  INTEGER(c_int) :: rc
+  INTEGER :: ng, tile, LBi, UBi, LBj, UBj, ni, nj, NN, NTT, sd, code, it
+  INTEGER :: side4(4)
+  REAL(c_double), POINTER :: a2(:,:), a3(:,:,:), a4(:,:,:,:)
+  ng = 1; tile = 0
+  LBi = b%LBi; UBi = b%UBi; LBj = b%LBj; UBj = b%UBj
+  ni = UBi-LBi+1; nj = UBj-LBj+1; NN = b%N; NTT = b%NT
+  rc = 0
+  IF (.NOT. have_boundary) THEN
+    CALL allocate_boundary (ng)
+    have_boundary = .TRUE.
+  END IF
+  nstp(ng) = s%nstp; nnew(ng) = s%nnew; nrhs(ng) = s%nrhs
+  iic(ng) = s%iic; ntfirst(ng) = s%ntfirst
+  dt(ng) = p%dt; g = p%g; rho0 = p%rho0
+  gls_p(ng) = p%gls_p; gls_m(ng) = p%gls_m; gls_n(ng) = p%gls_n; gls_cmu0(ng) = p%gls_cmu0
+  gls_c1(ng) = p%gls_c1; gls_c2(ng) = p%gls_c2; gls_c3m(ng) = p%gls_c3m; gls_c3p(ng) = p%gls_c3p
+  gls_sigk(ng) = p%gls_sigk; gls_sigp(ng) = p%gls_sigp; gls_Kmin(ng) = p%gls_Kmin; gls_Pmin(ng) = p%gls_Pmin
+  Akk_bak(ng) = p%Akk_bak; Akp_bak(ng) = p%Akp_bak; Akv_bak(ng) = p%Akv_bak; Zos(ng) = p%Zos
+  DO it = 1, INT(b%NAT)
+    Akt_bak(it,ng) = p%Akt_bak(it)
+  END DO
+  !  LBC(:,isMtke,ng): index 6 (= isTvar(1), free in this build: initialize_ncparam has not run)
+  isMtke = 6
+  side4 = (/ iwest, ieast, isouth, inorth /)
+  DO sd = 1, 4
+    code = p%lbc(6, sd)
+    IF (code == 0) THEN
+      SELECT CASE (sd)
+      CASE (1); code = p%lbc_west
+      CASE (2); code = p%lbc_east
+      CASE (3); code = p%lbc_south
+      CASE (4); code = p%lbc_north
+      END SELECT
+    END IF
+    LBC(side4(sd), isMtke, ng)%closed = code == 1
+    LBC(side4(sd), isMtke, ng)%gradient = code == 2
+    LBC(side4(sd), isMtke, ng)%radiation = .FALSE.
+    LBC(side4(sd), isMtke, ng)%periodic = code == 0
+  END DO
+  CALL c_f_pointer (F%pm, a2, (/ni,nj/));       GRID(ng)%pm = a2
+  CALL c_f_pointer (F%pn, a2, (/ni,nj/));       GRID(ng)%pn = a2
+  CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
+  CALL c_f_pointer (F%Huon, a3, (/ni,nj,NN/));  GRID(ng)%Huon = a3
+  CALL c_f_pointer (F%Hvom, a3, (/ni,nj,NN/));  GRID(ng)%Hvom = a3
+  CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
+  CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); GRID(ng)%z_w = a3
+  CALL c_f_pointer (F%ZoBot, a2, (/ni,nj/));    GRID(ng)%ZoBot = a2
+#ifdef MASKING
+  CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
+  CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
+  CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
+#endif
+  CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   OCEAN(ng)%u = a4
+  CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   OCEAN(ng)%v = a4
+  CALL c_f_pointer (F%W, a3, (/ni,nj,NN+1/));   OCEAN(ng)%W = a3
+  CALL c_f_pointer (F%bustr, a2, (/ni,nj/));    FORCES(ng)%bustr = a2
+  CALL c_f_pointer (F%bvstr, a2, (/ni,nj/));    FORCES(ng)%bvstr = a2
+  CALL c_f_pointer (F%sustr, a2, (/ni,nj/));    FORCES(ng)%sustr = a2
+  CALL c_f_pointer (F%svstr, a2, (/ni,nj/));    FORCES(ng)%svstr = a2
+  CALL c_f_pointer (F%bvf, a3, (/ni,nj,NN+1/)); MIXING(ng)%bvf = a3
+  CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); MIXING(ng)%Akv = a3
+  CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/)); MIXING(ng)%Akt = a4
+  CALL c_f_pointer (F%Akk, a3, (/ni,nj,NN+1/)); MIXING(ng)%Akk = a3
+  CALL c_f_pointer (F%Akp, a3, (/ni,nj,NN+1/)); MIXING(ng)%Akp = a3
+  CALL c_f_pointer (F%Lscale, a3, (/ni,nj,NN+1/)); MIXING(ng)%Lscale = a3
+  CALL c_f_pointer (F%tke, a4, (/ni,nj,NN+1,3/)); MIXING(ng)%tke = a4
+  CALL c_f_pointer (F%gls, a4, (/ni,nj,NN+1,3/)); MIXING(ng)%gls = a4
+  SELECT CASE (kernel)
+  CASE (1); CALL gls_prestep (ng, tile)
+  CASE (2); CALL gls_corstep (ng, tile)
+  CASE DEFAULT; rc = 2
+  END SELECT
+  CALL c_f_pointer (F%tke, a4, (/ni,nj,NN+1,3/)); a4 = MIXING(ng)%tke
+  CALL c_f_pointer (F%gls, a4, (/ni,nj,NN+1,3/)); a4 = MIXING(ng)%gls
+  CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akv
+  CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/)); a4 = MIXING(ng)%Akt
+  CALL c_f_pointer (F%Akk, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akk
+  CALL c_f_pointer (F%Akp, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akp
+  CALL c_f_pointer (F%Lscale, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Lscale
+END FUNCTION ref_gls
+#endif

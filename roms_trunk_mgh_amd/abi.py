@@ -16,11 +16,12 @@ ROMS_MAXNT = 16
 ROMS_MAXFAST = 256
 
 KINDS = ["K_2D", "K_2D_T2", "K_2D_T3", "K_2D_NT", "K_3DR", "K_3DW",
-         "K_3DR_T2", "K_3DW_T2", "K_3DW_NAT", "K_4DT", "K_3DR_NT"]
+         "K_3DR_T2", "K_3DW_T2", "K_3DW_NAT", "K_4DT", "K_3DR_NT", "K_3DW_T3"]
 
 # enum roms_adv (T_ADV logical records, ROMS/Modules/mod_param.F:382-394)
 ADV = {"C2": 0, "C4": 1, "A4": 2, "U3": 3, "SU3": 4, "SPLINES": 5,
        "MPDATA": 6, "HSIMT": 7}
+GLS_STAB = {"GALPERIN": 0, "KANTHA_CLAYSON": 1, "CANUTO_A": 2, "CANUTO_B": 3}            # enum roms_gls_stab
 PGF = {"DJ_GRADPS": 0, "STANDARD": 1, "WJ_GRADP": 2, "PJ_GRADP": 3}         # enum roms_pgf (prsgrd.F:16-26)
 LBC_PERIODIC, LBC_CLOSED, LBC_GRADIENT, LBC_CLAMPED, LBC_CHAPMAN_IMPLICIT, LBC_FLATHER, LBC_RADIATION = range(7)
 LBC = {"Per": 0, "Clo": 1, "Gra": 2, "Cla": 3, "Cha": 4, "Fla": 5, "Rad": 6, "RadNud": 7, "Che": 8, "Shc": 9, "Red": 10}      # the keywords of roms_*.in
@@ -50,6 +51,7 @@ def trailing_shape(kind, N, NT, NAT):
         "K_2D": (), "K_2D_T2": (2,), "K_2D_T3": (3,), "K_2D_NT": (NT,),
         "K_3DR": (N,), "K_3DW": (N + 1,), "K_3DR_T2": (N, 2),
         "K_3DW_T2": (N + 1, 2), "K_3DW_NAT": (N + 1, NAT), "K_4DT": (N, 3, NT), "K_3DR_NT": (N, NT),
+        "K_3DW_T3": (N + 1, 3),
     }[kind]
 
 
@@ -104,6 +106,11 @@ class Params(C.Structure):
         ("obc_out", (C.c_double * 6) * 4), ("obc_in", (C.c_double * 6) * 4),
         ("ts_dif4", C.c_int), ("uv_vis4", C.c_int), ("mix_iso_ts", C.c_int), ("radiation_2d", C.c_int),
         ("Cdb_min", C.c_double), ("Cdb_max", C.c_double),
+        ("gls_mixing", C.c_int), ("gls_stability", C.c_int), ("gls_n2s2_horavg", C.c_int), ("gls_ri_splines", C.c_int),
+        ("gls_p", C.c_double), ("gls_m", C.c_double), ("gls_n", C.c_double), ("gls_cmu0", C.c_double),
+        ("gls_c1", C.c_double), ("gls_c2", C.c_double), ("gls_c3m", C.c_double), ("gls_c3p", C.c_double),
+        ("gls_sigk", C.c_double), ("gls_sigp", C.c_double), ("gls_Kmin", C.c_double), ("gls_Pmin", C.c_double),
+        ("Akk_bak", C.c_double), ("Akp_bak", C.c_double), ("Zos", C.c_double),
     ]
 
 

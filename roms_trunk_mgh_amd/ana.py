@@ -217,7 +217,28 @@ def make_params(cfg, NT):
     p.eminusp = int(cfg.get("eminusp", 0))
     p.Cdb_min, p.Cdb_max = 1.0e-6, 0.5                                  # mod_scalars.F:747-748
     p.blk_ZQ = p.blk_ZT = p.blk_ZW = 10.0       # roms_*.in:382-384
+    # GLS_MIXING: cfg["gls"] = one of the parameter sets of roms_*.in (roms_upwelling.in:352-364, :1862-1874);
+    # cfg["gls_stability"] = GALPERIN | KANTHA_CLAYSON | CANUTO_A | CANUTO_B (the CPP choice of the application)
+    if cfg.get("gls"):
+        p.gls_mixing = 1
+        (p.gls_p, p.gls_m, p.gls_n, p.gls_Kmin, p.gls_Pmin, p.gls_cmu0, p.gls_c1, p.gls_c2, p.gls_c3m, p.gls_c3p,
+         p.gls_sigk, p.gls_sigp) = GLS_SETS[cfg["gls"]]
+        p.gls_stability = abi.GLS_STAB[cfg.get("gls_stability", "KANTHA_CLAYSON")]
+        p.gls_n2s2_horavg = int(cfg.get("gls_n2s2_horavg", 1))
+        p.gls_ri_splines = int(cfg.get("gls_ri_splines", 1))
+        p.Akk_bak = p.Akp_bak = 5.0e-6              # AKK_BAK, AKP_BAK (roms_upwelling.in)
+        p.Zos = 0.02                                # Zos (roms_upwelling.in:378)
     return p
+
+
+# GLS_P, GLS_M, GLS_N, GLS_Kmin, GLS_Pmin, GLS_CMU0, GLS_C1, GLS_C2, GLS_C3M, GLS_C3P, GLS_SIGK, GLS_SIGP
+# (the table of roms_upwelling.in:1862-1874)
+GLS_SETS = {
+    "k-kl":      (0.0, 1.0, 1.0, 5.0e-6, 5.0e-6, 0.5544, 0.9, 0.52, 2.5, 1.0, 1.96, 1.96),
+    "k-epsilon": (3.0, 1.5, -1.0, 7.6e-6, 1.0e-12, 0.5477, 1.44, 1.92, -0.4, 1.0, 1.0, 1.30),
+    "k-omega":   (-1.0, 0.5, -1.0, 7.6e-6, 1.0e-12, 0.5477, 0.555, 0.833, -0.6, 1.0, 2.0, 2.0),
+    "gen":       (2.0, 1.0, -0.67, 1.0e-8, 1.0e-8, 0.5544, 1.0, 1.22, 0.1, 1.0, 0.8, 1.07),
+}
 
 
 def _grid_global(cfg, b, st):
@@ -476,6 +497,16 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
         A["Hair"][:] = 0.7
         A["rain"][:] = 1.0e-5
         A["cloud"][:] = 0.4
+    if p.gls_mixing:
+        # mod_mixing.F initialize_mixing: tke = gls_Kmin, gls = gls_Pmin, Akk / Akp / Akv / Akt = background; a smooth
+        # `perturb` on top so that no stencil coefficient of the closure multiplies a constant field in the tests
+        wob = 1.0 + perturb * 0.5 * (1.0 + bump[:, :, None] * np.cos(math.pi * np.arange(N + 1) / N)[None, None, :])
+        for lev in range(3):
+            A["tke"][:, :, :, lev] = p.gls_Kmin * wob * (1.0 + 0.1 * lev * perturb)
+            A["gls"][:, :, :, lev] = p.gls_Pmin * wob * (1.0 + 0.07 * lev * perturb)
+        A["Akk"][:] = p.Akk_bak * wob
+        A["Akp"][:] = p.Akp_bak * wob
+        A["Lscale"][:] = perturb * 0.3 * wob
     st.z_r0, st.z_w0 = z_r, z_w
     # land/sea masks: all water unless asked for (MASKING applications); mask = "island" -> island_mask()
     for name in ("rmask", "umask", "vmask", "pmask"):

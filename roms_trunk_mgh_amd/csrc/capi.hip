@@ -38,6 +38,7 @@ long roms_field_count(int kind, const roms_bounds_t &b)
   case K_3DW_NAT: return nij * (b.N + 1) * b.NAT;
   case K_4DT:     return nij * b.N * 3 * b.NT;
   case K_3DR_NT:  return nij * b.N * b.NT;
+  case K_3DW_T3:  return nij * (b.N + 1) * 3;
   }
   return -1;
 }
@@ -411,7 +412,8 @@ static int library_default(int id, double *value)
     *value = 1.0; return !p.masking;
   case FID_visc4_p: case FID_visc4_r: *value = 0.0; return !p.uv_vis4;
   case FID_diff4: *value = 0.0; return !p.ts_dif4;
-  case FID_ZoBot: *value = 1.0; return p.uv_drag != 3;
+  case FID_ZoBot: *value = 1.0; return p.uv_drag != 3 && !p.gls_mixing;
+  case FID_tke: case FID_gls: case FID_Lscale: case FID_Akk: case FID_Akp: *value = 0.0; return !p.gls_mixing;
   default: return 0;
   }
 }

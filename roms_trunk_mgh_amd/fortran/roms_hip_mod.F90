@@ -74,6 +74,11 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: ts_dif4, uv_vis4            ! TS_DIF4, UV_VIS4 (biharmonic mixing)
     INTEGER(c_int) :: mix_iso_ts, radiation_2d    ! MIX_ISO_TS, RADIATION_2D
     REAL(c_double) :: Cdb_min, Cdb_max            ! UV_LOGDRAG limits
+    !  GLS_MIXING (gls_prestep.F, gls_corstep.F): switch, stability functions (0 Galperin, 1 KANTHA_CLAYSON,
+    !  2 CANUTO_A, 3 CANUTO_B), N2S2_HORAVG, RI_SPLINES; the closure parameters of roms_*.in
+    INTEGER(c_int) :: gls_mixing, gls_stability, gls_n2s2_horavg, gls_ri_splines
+    REAL(c_double) :: gls_p, gls_m, gls_n, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp, gls_Kmin, gls_Pmin
+    REAL(c_double) :: Akk_bak, Akp_bak, Zos
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)
@@ -101,7 +106,8 @@ MODULE roms_hip_mod
  &    FID_shflx=80, FID_evap=81, FID_hsbl=82, FID_rdrag=83, FID_wvel=84, FID_lonr=85, FID_latr=86,   &
  &    FID_rmask=87, FID_umask=88, FID_vmask=89, FID_pmask=90, FID_zeta_bry=91, FID_ubar_bry=92,   &
  &    FID_vbar_bry=93, FID_u_bry=94, FID_v_bry=95, FID_t_bry=96,                                  &
- &    FID_visc4_p=97, FID_visc4_r=98, FID_diff4=99, FID_ZoBot=100
+ &    FID_visc4_p=97, FID_visc4_r=98, FID_diff4=99, FID_ZoBot=100,                             &
+ &    FID_tke=101, FID_gls=102, FID_Lscale=103, FID_Akk=104, FID_Akp=105
 
   INTERFACE
     INTEGER(c_int) FUNCTION roms_hip_init (rank, ntileI, ntileJ, device_id, uid)            &
@@ -257,6 +263,15 @@ MODULE roms_hip_mod
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
     END FUNCTION
+    !  GLS_MIXING: gls_prestep (main3d.F:567) and gls_corstep (main3d.F:793)
+    INTEGER(c_int) FUNCTION roms_hip_gls_prestep (s) BIND(C, name='roms_hip_gls_prestep')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
+    INTEGER(c_int) FUNCTION roms_hip_gls_corstep (s) BIND(C, name='roms_hip_gls_corstep')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
     !  tile-local part of diag_tile; out12 = my_volume, my_avgke, my_avgpe, my_maxspeed, my_maxrho,
     !  my_max_C, my_max_Cu, my_max_Cv, my_max_Cw, my_max_Ci, my_max_Cj, my_max_Ck (diag.F:190-290)
     INTEGER(c_int) FUNCTION roms_hip_diag (s, out12) BIND(C, name='roms_hip_diag')
@@ -274,7 +289,7 @@ MODULE roms_hip_mod
   PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
   PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc, roms_hip_lmd_vmix
   PUBLIC :: roms_hip_ana_srflux, roms_hip_wvelocity, roms_hip_diag, roms_hip_snapshot_begin, roms_hip_snapshot_end
-  PUBLIC :: roms_hip_ini_zeta, roms_hip_ini_fields
+  PUBLIC :: roms_hip_ini_zeta, roms_hip_ini_fields, roms_hip_gls_prestep, roms_hip_gls_corstep
   PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
 
 CONTAINS

@@ -15,10 +15,12 @@ against either backend (`hip.RomsHip` = the product, or the CPU oracle in tests)
     main3d.F:467-475  lmd_vmix (physics=True; else fixed mixing inputs); omega; wvelocity (diagnostics=True)
     main3d.F:489      set_zeta
     main3d.F:563      rhs3d
+    main3d.F:567      gls_prestep                      (GLS_MIXING applications)
     main3d.F:592-700  LOOP_2D (predictor/corrector step2d)
     main3d.F:736      set_depth
     main3d.F:762      step3d_uv
     main3d.F:789      omega
+    main3d.F:793      gls_corstep                      (GLS_MIXING applications)
     main3d.F:814      step3d_t
     main3d.F:914      iic += 1
 """
@@ -104,10 +106,15 @@ class Main3D:
             be.call("wvelocity", s)
         be.call("set_zeta", s)
         be.call("rhs3d", s)
+        gls = bool(be.st.p.gls_mixing)
+        if gls:                               # main3d.F:564-567
+            be.call("gls_prestep", s)
         self.indx1 = be.step2d_loop(s, self.indx1)
         be.call("set_depth", s)
         be.call("step3d_uv", s)
         be.call("omega", s)
+        if gls:                               # main3d.F:790-793
+            be.call("gls_corstep", s)
         be.call("step3d_t", s)
         self.iic += 1
 

@@ -489,6 +489,41 @@ def main_physics(config, mask=None, basin=False):
     print(json.dumps(out))
 
 
+def main_gls(config, mask=None, basin=False):
+    """gls_prestep_tile and gls_corstep_tile (with tkebc_tile): reference Fortran (the GLS builds) vs C oracle, for the
+    four parameter sets of roms_*.in and both start-up branches.  The closure raises to real powers (pow of either
+    build's math library): relative difference reported."""
+    import oracle
+    import util
+    from oracle import ref
+    out = {"cases": {}}
+    names = ["tke", "gls", "Akv", "Akt", "Akk", "Akp", "Lscale"]
+    for gset in ("k-epsilon", "k-kl", "k-omega", "gen"):
+        st0 = util.gls_state(config, gls=gset, mask=mask, basin=basin)
+        out["masking"], out["EWperiodic"] = int(st0.p.masking), int(st0.b.EWperiodic)
+        for kernel in ("gls_prestep", "gls_corstep"):
+            for iic in (1, 5):
+                s = util.step_idx(iic=iic)
+                st_r, st_o = st0.copy(), st0.copy()
+                if kernel == "gls_corstep":                 # as gls_prestep leaves the nnew level: Hz-weighted
+                    for st in (st_r, st_o):
+                        hzw = np.zeros_like(st["Akv"])
+                        hzw[:, :, 1:-1] = 0.5 * (st["Hz"][:, :, :-1] + st["Hz"][:, :, 1:])
+                        hzw[:, :, 0] = hzw[:, :, 1]
+                        hzw[:, :, -1] = hzw[:, :, -2]
+                        for n in ("tke", "gls"):
+                            st[n][:, :, :, s.nnew - 1] = hzw * st[n][:, :, :, s.nstp - 1]
+                ref.Ref(st_r).gls(kernel, s)
+                oracle.Oracle(st_o).call(kernel, s)
+                diffs = {n: util.max_rel_diff(st_o[n], st_r[n]) for n in names}
+                changed = [n for n in names if not np.array_equal(st_r[n], st0[n])]
+                out["cases"][f"{gset}/{kernel}/iic{iic}"] = {
+                    "max_rel_diff": max(diffs.values()), "diffs": diffs, "changed": changed,
+                    "finite": bool(all(np.isfinite(st_r[n]).all() for n in names)),
+                    "amax": {n: float(np.abs(st_r[n]).max()) for n in names}}
+    print(json.dumps(out))
+
+
 def main_diag(config):
     """wvelocity (bit for bit on wvel and on the exchanged DU_avg1/DV_avg1) and diag (the reference keeps
     only its printed report: compared at the printed 7 digits) -- reference Fortran vs C oracle."""
@@ -608,6 +643,8 @@ if __name__ == "__main__":
     RAD2D = len(sys.argv) > 3 and sys.argv[3] == "rad2d"      # the builds with -DRADIATION_2D (bc, bc4 modes)
     if len(sys.argv) > 2 and sys.argv[2] == "ana":
         main_ana(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] in ("gls", "gls_mask", "gls_basin"):
+        main_gls(sys.argv[1], mask="island" if sys.argv[2] == "gls_mask" else None, basin=sys.argv[2] == "gls_basin")
     elif len(sys.argv) > 2 and sys.argv[2] == "diag":
         main_diag(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] in ("physics", "physics_mask", "physics_basin"):

@@ -118,6 +118,53 @@ def kpp_state(config="BENCHMARK_TINY", mask=None):
     return st
 
 
+GLS_BUILDS = {   # the CPP choices of the two GLS reference builds (oracle/ref_headers/upwelling_gls.h, benchmark_gls.h)
+    "UPWELLING": dict(gls_stability="KANTHA_CLAYSON", gls_n2s2_horavg=1, gls_ri_splines=1),
+    "BENCHMARK": dict(gls_stability="CANUTO_A", gls_n2s2_horavg=0, gls_ri_splines=0),
+}
+
+
+def gls_state(config, gls="k-epsilon", mask=None, basin=False, extra=None):
+    """prepared_state of a GLS_MIXING application with the CPP choices of the matching reference build, made into a
+    meaningful input of gls_prestep / gls_corstep: bvf from the (pinned) oracle rho_eos with both signs of the
+    stratification, energetic tke / gls at the three time levels, diffusivities above their backgrounds, W as omega
+    left it (prepared_state)."""
+    import oracle
+    from roms_trunk_mgh_amd import ana as _ana
+    ov = dict(GLS_BUILDS[_ana.CONFIGS[config]["app"]], gls=gls)
+    if basin:
+        ov["EWperiodic"] = False
+    if extra:
+        ov.update(extra)
+    st = prepared_state(config, mask=mask, overrides=ov)
+    oracle.Oracle(st).call("rho_eos", step_idx())
+    b, p = st.b, st.p
+    ii = np.arange(b.LBi, b.UBi + 1, dtype=np.float64)[:, None, None]
+    jj = np.arange(b.LBj, b.UBj + 1, dtype=np.float64)[None, :, None]
+    kk = (np.arange(0, b.N + 1, dtype=np.float64) / b.N)[None, None, :]
+    wob = 1.0 + 0.5 * np.sin(2.0 * math.pi * 2 * (ii - 0.5) / b.Lm) * np.cos(math.pi * (jj - 0.5) / b.Mm) * (0.4 + kk)
+    # unstable patches: the sign of the stratification selects gls_c3m / gls_c3p and the length-scale limiter
+    st["bvf"][:] = np.where(np.sin(2.0 * math.pi * 3 * (ii - 0.5) / b.Lm) > 0.8, -0.3 * np.abs(st["bvf"]) - 1.0e-7, st["bvf"] + 1.0e-6 * wob)
+    for lev in range(3):
+        st["tke"][:, :, :, lev] = 2.0e-4 * wob * (1.0 + 0.05 * lev) * (0.2 + kk * (1.0 - kk) * 4.0)
+        ls = 0.5 + 3.0 * kk * (1.0 - kk) * 4.0 * wob                      # a length scale (m)
+        st["gls"][:, :, :, lev] = np.maximum((p.gls_cmu0 ** p.gls_p) * st["tke"][:, :, :, lev] ** p.gls_m * ls ** p.gls_n
+                                             * (1.0 + 0.03 * lev), p.gls_Pmin)
+    st["Lscale"][:] = 0.5 + 2.0 * kk * (1.0 - kk) * 4.0 * wob
+    st["Akv"][:] = p.Akv_bak + 2.0e-3 * wob * kk * (1.0 - kk) * 4.0
+    for it in range(b.NAT):
+        st["Akt"][:, :, :, it] = p.Akt_bak[it] + 1.5e-3 * wob * kk * (1.0 - kk) * 4.0 * (1.0 + 0.1 * it)
+    st["Akk"][:] = p.Akk_bak + st["Akv"] / p.gls_sigk
+    st["Akp"][:] = p.Akp_bak + st["Akv"] / p.gls_sigp
+    st["ZoBot"][:] = 0.02 * (1.0 + 0.3 * wob[:, :, 0])
+    if mask is not None:
+        for name in ("tke", "gls"):
+            st[name] *= st["rmask"][:, :, None, None]
+        st["sustr"] *= st["umask"]
+        st["svstr"] *= st["vmask"]
+    return st
+
+
 def hz_weighted_tnew(st, nnew=2):
     """pre_step3d leaves t(nnew) multiplied by Hz; reproduce that for isolated
     step3d_t tests."""
