@@ -429,7 +429,9 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   USE set_vbc_mod,   ONLY : set_vbc
 #ifdef BENCHMARK
   USE bulk_flux_mod, ONLY : bulk_flux
+# ifndef REF_GLS
   USE lmd_vmix_mod,  ONLY : lmd_vmix
+# endif
 #endif
   INTEGER(c_int), VALUE :: kernel
   TYPE(bounds_t), INTENT(in) :: b
@@ -512,21 +514,27 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   CALL c_f_pointer (F%lhflx, a2, (/ni,nj/));    FORCES(ng)%lhflx = a2
   CALL c_f_pointer (F%shflx, a2, (/ni,nj/));    FORCES(ng)%shflx = a2
   !  lmd_vmix (LMD_MIXING + LMD_SKPP): uniform Jerlov water type WTYPE = 1 (roms_benchmark*.in:392)
+# ifndef REF_GLS
   MIXING(ng)%Jwtype = 1.0_r8
+# endif
   iic(ng) = s%iic; ntstart(ng) = s%ntfirst
   CALL c_f_pointer (F%f, a2, (/ni,nj/));        GRID(ng)%f = a2
   CALL c_f_pointer (F%pden, a3, (/ni,nj,NN/));  OCEAN(ng)%pden = a3
   CALL c_f_pointer (F%bvf, a3, (/ni,nj,NN+1/)); MIXING(ng)%bvf = a3
   CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); MIXING(ng)%Akv = a3
   CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/));   MIXING(ng)%Akt = a4
+# ifndef REF_GLS
   CALL c_f_pointer (F%ghats, a4, (/ni,nj,NN+1,INT(b%NAT)/)); MIXING(ng)%ghats = a4
   CALL c_f_pointer (F%hsbl, a2, (/ni,nj/));     MIXING(ng)%hsbl = a2
+# endif
 #endif
   SELECT CASE (kernel)
   CASE (1); CALL set_vbc (ng, tile)
 #ifdef BENCHMARK
   CASE (2); CALL bulk_flux (ng, tile)
+# ifndef REF_GLS
   CASE (3); CALL lmd_vmix (ng, tile)
+# endif
 #endif
   CASE DEFAULT; rc = 2
   END SELECT
@@ -546,8 +554,10 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
 #endif
   CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akv
   CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/));   a4 = MIXING(ng)%Akt
+# ifndef REF_GLS
   CALL c_f_pointer (F%ghats, a4, (/ni,nj,NN+1,INT(b%NAT)/)); a4 = MIXING(ng)%ghats
   CALL c_f_pointer (F%hsbl, a2, (/ni,nj/));     a2 = MIXING(ng)%hsbl
+# endif
 #endif
 END FUNCTION ref_physics
 

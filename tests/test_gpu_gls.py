@@ -1,0 +1,117 @@
+"""-m gpu: the generic length-scale closure (GLS / MY25), HIP vs CPU oracle through the C ABI.
+The oracle's gls_prestep / gls_corstep / tkebc are pinned bit for bit against the reference's GLS builds
+(tests/test_ref_pinning.py, tests/test_golden.py)."""
+import numpy as np
+import pytest
+
+import util
+from roms_trunk_mgh_amd import ana, hip, main3d
+from roms_trunk_mgh_amd.state import rel_rms
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11          # of each field's maximum: the device pow() differs from glibc's in the last place
+NAMES = ["tke", "gls", "Akv", "Akt", "Akk", "Akp", "Lscale"]
+
+
+def _hz_weight(st, s):
+    hzw = np.zeros_like(st["Akv"])
+    hzw[:, :, 1:-1] = 0.5 * (st["Hz"][:, :, :-1] + st["Hz"][:, :, 1:])
+    hzw[:, :, 0] = hzw[:, :, 1]
+    hzw[:, :, -1] = hzw[:, :, -2]
+    for n in ("tke", "gls"):
+        st[n][:, :, :, s.nnew - 1] = hzw * st[n][:, :, :, s.nstp - 1]
+
+
+@pytest.mark.parametrize("config,mask,basin", [("UPWELLING", None, False), ("UPWELLING", "island", False),
+                                               ("UPWELLING", None, True), ("BENCHMARK_TINY", None, False)])
+@pytest.mark.parametrize("gset", ["k-epsilon", "k-kl", "k-omega", "gen"])
+@pytest.mark.parametrize("kernel", ["gls_prestep", "gls_corstep"])
+def test_gls_kernels_vs_oracle(config, mask, basin, gset, kernel):
+    import oracle
+    for iic in (1, 5):
+        st0 = util.gls_state(config, gls=gset, mask=mask, basin=basin)
+        s = util.step_idx(iic=iic)
+        if kernel == "gls_corstep":
+            _hz_weight(st0, s)
+        st_o, st_h = st0.copy(), st0.copy()
+        oracle.Oracle(st_o).call(kernel, s)
+        h = hip.RomsHip(st_h)
+        try:
+            h.call(kernel, s)
+            h.to_host()
+        finally:
+            h.close()
+        for n in NAMES:
+            scale = max(float(np.abs(st_o[n]).max()), 1e-300)
+            d = float(np.abs(st_h[n] - st_o[n]).max()) / scale
+            assert d <= TOL, (n, iic, d)
+        changed = ["tke", "gls"] if kernel == "gls_prestep" else NAMES
+        assert all(not np.array_equal(st_o[n], st0[n]) for n in changed)
+
+
+@pytest.mark.parametrize("extra", [dict(gls_stability="GALPERIN"), dict(gls_stability="CANUTO_B"),
+                                   dict(gls_n2s2_horavg=0), dict(gls_ri_splines=0)],
+                         ids=["galperin", "canuto_b", "no_horavg", "plain_shear"])
+def test_gls_other_options_vs_oracle(extra):
+    """The option combinations no reference build of this repository covers are at least HIP = oracle."""
+    import oracle
+    st0 = util.gls_state("UPWELLING", gls="k-epsilon", extra=extra)
+    s = util.step_idx(iic=5)
+    _hz_weight(st0, s)
+    st_o, st_h = st0.copy(), st0.copy()
+    oracle.Oracle(st_o).call("gls_corstep", s)
+    h = hip.RomsHip(st_h)
+    try:
+        h.call("gls_corstep", s)
+        h.to_host()
+    finally:
+        h.close()
+    for n in NAMES:
+        scale = max(float(np.abs(st_o[n]).max()), 1e-300)
+        assert float(np.abs(st_h[n] - st_o[n]).max()) / scale <= TOL, n
+
+
+@pytest.mark.parametrize("config,gset,stab", [("UPWELLING", "k-epsilon", "KANTHA_CLAYSON"), ("UPWELLING", "k-kl", "KANTHA_CLAYSON"),
+                                              ("BENCHMARK_TINY", "gen", "CANUTO_A")])
+def test_100_steps_with_gls(config, gset, stab):
+    """The whole step with the closure in it (main3d.F:567, :793): 100 steps, north-star bound 1e-10 relative RMS on
+    the prognostic fields and the same bound on tke, gls, Akv."""
+    import oracle
+    ov = dict(gls=gset, gls_stability=stab)
+    st_o = ana.make_tile(config, perturb=1.0, overrides=ov)
+    st_h = st_o.copy()
+    mo = main3d.Main3D(oracle.Oracle(st_o), physics=True)
+    mo.initial()
+    mo.run(100)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be, physics=True)
+        mh.initial()
+        mh.run(100)
+        be.to_host()
+    finally:
+        be.close()
+    s = mo.s
+    out = {"zeta": rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], 1e-3)}
+    for name in ("u", "v"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], 1e-4)
+    for it in range(st_o.b.NT):
+        out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
+    for name in ("tke", "gls"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], 1e-12)
+    out["Akv"] = rel_rms(st_h.interior("Akv"), st_o.interior("Akv"), 1e-8)
+    assert np.isfinite(st_h["t"]).all() and np.isfinite(st_h["tke"]).all()
+    assert all(v <= 1e-10 for v in out.values()), out
+    # the closure did something: the wind-driven surface layer mixes far above the background
+    assert float(st_o.interior("Akv").max()) > 50.0 * st_o.p.Akv_bak
+
+
+def test_gls_without_the_switch_is_refused():
+    st = util.prepared_state("UPWELLING")
+    h = hip.RomsHip(st)
+    try:
+        with pytest.raises(RuntimeError) as e:
+            h.call("gls_corstep", util.step_idx())
+        assert "gls_mixing" in str(e.value)
+    finally:
+        h.close()
