@@ -157,7 +157,7 @@ def _cpu_mpi_worker(config, nsteps, physics, tiling=None, outdir=None):
         bq = st.b
         np.savez(os.path.join(outdir, f"tile{rank}.npz"),
                  bounds=np.array([bq.Istr, bq.Iend, bq.Jstr, bq.Jend, bq.LBi, bq.LBj]),
-                 **{k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz")})
+                 **{k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke")})
     if rank == 0:
         print("CPUBASE " + json.dumps({"wall": wall, "dt": st.p.dt, "tiling": f"{ntI}x{ntJ}", "ranks": world,
                                        "finite": ok}), flush=True)

@@ -68,6 +68,9 @@ def checksum(st):
             continue
         if name == "ZoBot":                      # the roughness length of UV_LOGDRAG joined later as well
             continue
+        # and the fields of the GLS closure (all zero in an application without GLS_MIXING)
+        if name in ("tke", "gls", "Lscale", "Akk", "Akp") and not st.p.gls_mixing:
+            continue
         h.update(np.ascontiguousarray(st.arr[name]).tobytes())
     return h.hexdigest()
 

@@ -28,6 +28,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
         kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:
         kw.setdefault("overrides", {})["EWperiodic"] = False
+    if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
+        kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)
     b = st.b
     ndev = torch.cuda.device_count()
@@ -50,7 +52,7 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
     m.run(nsteps)
     be.to_host()
     be.close()
-    out = {k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz")}
+    out = {k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke")}
     if "slim" in opts:      # full-size grids: only the newest time level of the 3-D prognostic fields
         lev = m.s.nnew - 1
         out["u"], out["v"], out["t"] = st["u"][:, :, :, lev], st["v"][:, :, :, lev], st["t"][:, :, :, lev, :]

@@ -51,7 +51,7 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
     lib.oracle_set_exchange_hook(HOOK(0))
     np.savez(os.path.join(outdir, f"tile{rank}.npz"),
              bounds=np.array([b.Istr, b.Iend, b.Jstr, b.Jend, b.LBi, b.LBj]),
-             **{k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz")})
+             **{k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke")})
     dist.barrier()
     dist.destroy_process_group()
 

@@ -39,6 +39,8 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:
         kw.setdefault("overrides", {})["EWperiodic"] = False
+    if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
+        kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     st = ana.make_tile(config, perturb=1.0, **kw)
     be = hip.RomsHip(st)
     m = main3d.Main3D(be, physics=("physics" in opts), diagnostics=("physics" in opts))
@@ -63,6 +65,9 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "UPWELLING", "basin"), (2, 1, "BENCHMARK_TINY", "basin+physics"),
                                                     # MPDATA on a basin with land, across tile edges
                                                     (2, 2, "BENCHMARK_TINY", "mpdata+basin+mask"),
+                                                    # the GLS closure: smoothed shear, five-point advection of tke / gls and
+                                                    # the Akv / Akt edge rule of gls_corstep.F across tile edges
+                                                    (2, 2, "UPWELLING", "gls"), (2, 1, "BENCHMARK_TINY", "gls+basin+mask"),
                                                     # biharmonic mixing across tile edges
                                                     (2, 2, "BENCHMARK_TINY", "dif4"), (2, 2, "BENCHMARK_TINY", "dif4+basin+mask"),
                                                     # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
@@ -91,7 +96,7 @@ def test_tiled_hip_equals_single_hip(tmp_path, ntI, ntJ, config, variant):
     for r in range(world):
         d = np.load(os.path.join(tmp_path, f"tile{r}.npz"))
         Istr, Iend, Jstr, Jend, LBi, LBj = [int(x) for x in d["bounds"]]
-        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz"):
+        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke"):
             a = d[name]
             ni, nj = a.shape[0], a.shape[1]
             i0, j0 = LBi - rb.LBi, LBj - rb.LBj

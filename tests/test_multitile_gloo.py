@@ -55,6 +55,9 @@ def _single(config, nsteps, variant=""):
                                                     # corners, the edge rule of Ua / Va, masks -- across tile edges
                                                     (2, 2, "BENCHMARK_TINY", "mpdata+basin+mask"),
                                                     (2, 2, "BENCHMARK_TINY", "hsimt+basin+mask"),
+                                                    # the GLS closure across tile edges (smoothed shear, five-point advection of
+                                                    # tke / gls, the Akv / Akt edge rule of gls_corstep.F)
+                                                    (2, 2, "UPWELLING", "gls"), (2, 1, "BENCHMARK_TINY", "gls+basin+mask"),
                                                     # biharmonic mixing: the first operator's one-point-wider range
                                                     # and its edge rule across tile edges, channel and basin
                                                     (2, 2, "BENCHMARK_TINY", "dif4"), (2, 2, "BENCHMARK_TINY", "dif4+basin+mask")])
@@ -73,7 +76,7 @@ def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     for r in range(world):
         d = np.load(os.path.join(tmp_path, f"tile{r}.npz"))
         Istr, Iend, Jstr, Jend, LBi, LBj = [int(x) for x in d["bounds"]]
-        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz"):
+        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke"):
             a = d[name]
             ni, nj = a.shape[0], a.shape[1]
             # whole allocated tile (owned + ghost points) against the same index range of the single-tile run
@@ -108,7 +111,7 @@ def test_mpi_baseline_layer_equals_single(tmp_path, ntI, ntJ, config):
     for q in range(world):
         d = np.load(os.path.join(tmp_path, f"tile{q}.npz"))
         Istr, Iend, Jstr, Jend, LBi, LBj = [int(x) for x in d["bounds"]]
-        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz"):
+        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke"):
             a = d[name]
             ni, nj = a.shape[0], a.shape[1]
             i0, j0 = LBi - rb.LBi, LBj - rb.LBj
