@@ -177,6 +177,13 @@ typedef struct roms_params {
   int    gls_mixing, gls_stability, gls_n2s2_horavg, gls_ri_splines;
   double gls_p, gls_m, gls_n, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp, gls_Kmin, gls_Pmin;
   double Akk_bak, Akp_bak, Zos;
+  /* WET_DRY (wetdry.F, step2d_LF_AM3.h:729-755, :863-866, :2123-2160 ...): cells whose total depth falls to Dcrit
+   * (roms_*.in DCRIT, m) are masked out of the barotropic and baroclinic stepping.  The wet/dry masks are fields
+   * (pmask_wet ... vmask_full); roms_hip_wetdry initialises them (initial.F:438-466), every step2d call updates
+   * them.  With wet_dry the barotropic step takes the general launch sequence (flux, free surface, masks,
+   * momentum). */
+  int    wet_dry, wet_dry_pad_;
+  double Dcrit;
 } roms_params_t;
 enum roms_gls_stab { GLS_GALPERIN = 0, GLS_KANTHA_CLAYSON = 1, GLS_CANUTO_A = 2, GLS_CANUTO_B = 3 };
 
@@ -294,6 +301,10 @@ int roms_hip_ana_srflux(double yday, double hour);
  * lmd_vmix as the source of Akv / Akt. */
 int roms_hip_gls_prestep(const roms_step_idx_t *s);
 int roms_hip_gls_corstep(const roms_step_idx_t *s);
+/* wetdry(ng,tile,Tindex,.TRUE.)    ROMS/Nonlinear/wetdry.F:17 -> wetdry_ini_tile (:395): the initial wet/dry masks
+ * from zeta, ubar, vbar of time level Tindex = s->kstp (initial.F:438-466; WET_DRY applications).  The per-call
+ * update wetdry_tile (:93) runs inside roms_hip_step2d. */
+int roms_hip_wetdry(const roms_step_idx_t *s);
 /* wvelocity(ng,tile,nstp)          ROMS/Nonlinear/wvelocity.F:27     (main3d.F:475; writes wvel) */
 int roms_hip_wvelocity(const roms_step_idx_t *s);
 /* diag(ng,tile)                    ROMS/Nonlinear/diag.F:31          (main3d.F:314), the tile-local part

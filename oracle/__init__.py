@@ -17,7 +17,7 @@ _LIB = None
 KERNELS = ["set_massflux", "omega", "set_zeta", "set_depth", "rho_eos", "pre_step3d",
            "prsgrd", "t3dmix2", "rhs3d_tile", "uv3dmix2", "rhs3d", "step2d",
            "step3d_uv", "step3d_t", "bulk_flux", "set_vbc", "lmd_vmix", "wvelocity", "ini_zeta", "ini_fields",
-           "t3dmix4", "uv3dmix4", "gls_prestep", "gls_corstep"]
+           "t3dmix4", "uv3dmix4", "gls_prestep", "gls_corstep", "wetdry"]
 
 
 def build(force=False):

@@ -152,6 +152,15 @@
 #define umask(i,j)    F->umask[I2(i,j)]
 #define vmask(i,j)    F->vmask[I2(i,j)]
 #define pmask(i,j)    F->pmask[I2(i,j)]
+#define pmask_wet(i,j)     F->pmask_wet[I2(i,j)]
+#define rmask_wet(i,j)     F->rmask_wet[I2(i,j)]
+#define umask_wet(i,j)     F->umask_wet[I2(i,j)]
+#define vmask_wet(i,j)     F->vmask_wet[I2(i,j)]
+#define rmask_wet_avg(i,j) F->rmask_wet_avg[I2(i,j)]
+#define pmask_full(i,j)    F->pmask_full[I2(i,j)]
+#define rmask_full(i,j)    F->rmask_full[I2(i,j)]
+#define umask_full(i,j)    F->umask_full[I2(i,j)]
+#define vmask_full(i,j)    F->vmask_full[I2(i,j)]
 #define zeta_bry(i,j) F->zeta_bry[I2(i,j)]
 #define ubar_bry(i,j) F->ubar_bry[I2(i,j)]
 #define vbar_bry(i,j) F->vbar_bry[I2(i,j)]
@@ -210,6 +219,16 @@ int oracle_step3d_uv(OARGS);
 int oracle_step3d_t(OARGS);
 int oracle_gls_prestep(OARGS);     /* oracle_gls.c: gls_prestep.F:66 */
 int oracle_gls_corstep(OARGS);     /* gls_corstep.F:101 */
+int oracle_wetdry(OARGS);          /* oracle_wetdry.c: wetdry.F:17 with Linitialize (wetdry_ini_tile, :395) */
+void o_wetdry(OARGS);              /* wetdry_tile, wetdry.F:93 (called by step2d) */
+/* the factor of the barotropic / boundary wet-dry rule, e.g. step2d_LF_AM3.h:2124-2126: 1 on a face between two wet
+ * cells (mask 2), 0 between two dry ones (0), and on a one-sided face (mask +-1) 1 only for flow out of the wet cell */
+static inline double o_wet_factor(double mask_wet, double vel)
+{
+  const double cff5 = fabs(fabs(mask_wet) - 1.0);
+  const double cff6 = 0.5 + copysign(0.5, vel) * mask_wet;
+  return 0.5 * mask_wet * cff5 + cff6 * (1.0 - cff5);
+}
 int oracle_ini_zeta(OARGS);        /* ini_fields.F:836 */
 int oracle_ini_fields(OARGS);      /* ini_fields.F:106 */
 int oracle_step2d_loop(const roms_bounds_t *b, const roms_params_t *p, roms_step_idx_t *s,

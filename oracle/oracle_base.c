@@ -195,7 +195,10 @@ int oracle_set_depth(OARGS)
   const double hc = p->hc;
   if (p->Vtransform == 1) {
     for (int j = JstrT; j <= JendT; j++) {
-      for (int i = IstrT; i <= IendT; i++) z_w(i, j, 0) = -h(i, j);
+      for (int i = IstrT; i <= IendT; i++) {
+        if (p->wet_dry && h(i, j) == 0.0) h(i, j) = 1.0E-14;      /* WET_DRY, set_depth.F:168-172 / :216-220: h itself is changed */
+        z_w(i, j, 0) = -h(i, j);
+      }
       for (int k = 1; k <= N; k++) {
         double cff_r = hc * (p->sc_r[k] - p->Cs_r[k]);
         double cff_w = hc * (p->sc_w[k] - p->Cs_w[k]);
@@ -213,7 +216,10 @@ int oracle_set_depth(OARGS)
     }
   } else {
     for (int j = JstrT; j <= JendT; j++) {
-      for (int i = IstrT; i <= IendT; i++) z_w(i, j, 0) = -h(i, j);
+      for (int i = IstrT; i <= IendT; i++) {
+        if (p->wet_dry && h(i, j) == 0.0) h(i, j) = 1.0E-14;      /* WET_DRY, set_depth.F:168-172 / :216-220: h itself is changed */
+        z_w(i, j, 0) = -h(i, j);
+      }
       for (int k = 1; k <= N; k++) {
         double cff_r = hc * p->sc_r[k], cff_w = hc * p->sc_w[k];
         double cff1_r = p->Cs_r[k], cff1_w = p->Cs_w[k];

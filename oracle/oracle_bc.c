@@ -140,7 +140,8 @@ static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_f
         const long lo = B - (e.we ? 1 : ni), qi = e.hi ? lo : B, qo = e.hi ? B : lo;
         const double Co = 1.0 / (2.0 + sqrt(2.0));              /* mod_scalars.F:4175 */
         const double bry_val = D[B];
-        const double cff = 0.5 * (F->h[lo] + F->h[B]);
+        /* WET_DRY: the total depth instead of the resting one, u2dbc_im.F:331-340, :679-688; v2dbc_im.F:333, :682 */
+        const double cff = p->wet_dry ? 0.5 * (F->h[lo] + Z[lo] + F->h[B] + Z[B]) : 0.5 * (F->h[lo] + F->h[B]);
         const double cff1 = sqrt(p->g / cff);
         const double Cn = dt2d * cff1 * cff * 0.5 * (pmn[lo] + pmn[B]);
         double Zx = (0.5 + Cn) * Z[qi] + (0.5 - Cn) * Z[qo];
@@ -190,6 +191,12 @@ static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_f
         x = normal ? 0.0 : (gtype == GT_R ? Xk[P1] : p->gamma2 * Xk[P1]);
       }
       if (mk && !(normal && code == LBC_CLOSED)) x = x * mask[B];
+      /* WET_DRY, 3-D momentum: the wet/dry mask after every land/sea-mask product (u3dbc_im.F:174 ... :681,
+       * v3dbc_im.F:174 ... :681) -- but for u on a southern gradient edge, whose block tests a symbol that no header
+       * defines (u3dbc_im.F:496) */
+      if (p->wet_dry && (var == LBV_U || var == LBV_V) && !(normal && code == LBC_CLOSED) &&
+          !(var == LBV_U && side == LBS_SOUTH && code == LBC_GRADIENT))
+        x = x * (var == LBV_U ? F->umask_wet : F->vmask_wet)[B];
       Xk[B] = x;
     }
   }
@@ -256,6 +263,26 @@ void o_zetabc(OARGS, int kout)
     bc_edge(b, p, F, SIDES[q], LBV_ZETA, o_lbc(p, SIDES[q], LBV_ZETA), &zeta(LBi, LBj, kout), &zeta(LBi, LBj, know),
             F->zeta_bry, &zeta(LBi, LBj, know), F->zeta_bry, NULL, 1, dt2d, NULL);
   bc_corners(b, GT_R, &zeta(LBi, LBj, kout), 1);
+  if (p->wet_dry) {
+    /* WET_DRY, zetabc.F:733-827: the water level of every boundary point (and corner) stays above the bed */
+    const double eps = 1.0E-20, cff = p->Dcrit - eps;
+#define RAISE(i, j) if (zeta(i, j, kout) <= (p->Dcrit - h(i, j))) zeta(i, j, kout) = cff - h(i, j)
+    if (!EWperiodic) {
+      if (west_edge) for (int j = Jstr; j <= Jend; j++) { RAISE(Istr - 1, j); }
+      if (east_edge) for (int j = Jstr; j <= Jend; j++) { RAISE(Iend + 1, j); }
+    }
+    if (!NSperiodic) {
+      if (south_edge) for (int i = Istr; i <= Iend; i++) { RAISE(i, Jstr - 1); }
+      if (north_edge) for (int i = Istr; i <= Iend; i++) { RAISE(i, Jend + 1); }
+    }
+    if (!(EWperiodic || NSperiodic)) {
+      if (south_edge && west_edge) { RAISE(Istr - 1, Jstr - 1); }
+      if (south_edge && east_edge) { RAISE(Iend + 1, Jstr - 1); }
+      if (north_edge && west_edge) { RAISE(Istr - 1, Jend + 1); }
+      if (north_edge && east_edge) { RAISE(Iend + 1, Jend + 1); }
+    }
+#undef RAISE
+  }
 }
 
 void o_u2dbc(OARGS, int kout)
@@ -267,6 +294,25 @@ void o_u2dbc(OARGS, int kout)
     bc_edge(b, p, F, SIDES[q], LBV_UBAR, o_lbc(p, SIDES[q], LBV_UBAR), &ubar(LBi, LBj, kout), &ubar(LBi, LBj, know),
             F->ubar_bry, &zeta(LBi, LBj, know), F->zeta_bry, &zeta(LBi, LBj, kout), 1, dt2d, &vbar(LBi, LBj, know));
   bc_corners(b, GT_U, &ubar(LBi, LBj, kout), 1);
+  if (p->wet_dry) {
+    /* WET_DRY, u2dbc_im.F:1176-1293 (ranges as written: IstrU on the southern edge, Istr on the northern one) */
+#define WETBC(i, j) ubar(i, j, kout) = ubar(i, j, kout) * o_wet_factor(umask_wet(i, j), ubar(i, j, kout))
+    if (!EWperiodic) {
+      if (west_edge) for (int j = Jstr; j <= Jend; j++) { WETBC(Istr, j); }
+      if (east_edge) for (int j = Jstr; j <= Jend; j++) { WETBC(Iend + 1, j); }
+    }
+    if (!NSperiodic) {
+      if (south_edge) for (int i = IstrU; i <= Iend; i++) { WETBC(i, Jstr - 1); }
+      if (north_edge) for (int i = Istr; i <= Iend; i++) { WETBC(i, Jend + 1); }
+    }
+    if (!(EWperiodic || NSperiodic)) {
+      if (south_edge && west_edge) { WETBC(Istr, Jstr - 1); }
+      if (south_edge && east_edge) { WETBC(Iend + 1, Jstr - 1); }
+      if (north_edge && west_edge) { WETBC(Istr, Jend + 1); }
+      if (north_edge && east_edge) { WETBC(Iend + 1, Jend + 1); }
+    }
+#undef WETBC
+  }
 }
 
 void o_v2dbc(OARGS, int kout)
@@ -278,6 +324,28 @@ void o_v2dbc(OARGS, int kout)
     bc_edge(b, p, F, SIDES[q], LBV_VBAR, o_lbc(p, SIDES[q], LBV_VBAR), &vbar(LBi, LBj, kout), &vbar(LBi, LBj, know),
             F->vbar_bry, &zeta(LBi, LBj, know), F->zeta_bry, &zeta(LBi, LBj, kout), 1, dt2d, &ubar(LBi, LBj, know));
   bc_corners(b, GT_V, &vbar(LBi, LBj, kout), 1);
+  if (p->wet_dry) {
+    /* WET_DRY, v2dbc_im.F:1169-1287.  As written, the western edge takes its factor from the boundary point
+     * (Istr-1,j) and applies it to the first INTERIOR point (Istr,j), :1180-1185. */
+#define WETBC(i, j) vbar(i, j, kout) = vbar(i, j, kout) * o_wet_factor(vmask_wet(i, j), vbar(i, j, kout))
+    if (!EWperiodic) {
+      if (west_edge)
+        for (int j = JstrV; j <= Jend; j++)
+          vbar(Istr, j, kout) = vbar(Istr, j, kout) * o_wet_factor(vmask_wet(Istr - 1, j), vbar(Istr - 1, j, kout));
+      if (east_edge) for (int j = JstrV; j <= Jend; j++) { WETBC(Iend + 1, j); }
+    }
+    if (!NSperiodic) {
+      if (south_edge) for (int i = Istr; i <= Iend; i++) { WETBC(i, Jstr); }
+      if (north_edge) for (int i = Istr; i <= Iend; i++) { WETBC(i, Jend + 1); }
+    }
+    if (!(EWperiodic || NSperiodic)) {
+      if (south_edge && west_edge) { WETBC(Istr - 1, Jstr); }
+      if (south_edge && east_edge) { WETBC(Iend + 1, Jstr); }
+      if (north_edge && west_edge) { WETBC(Istr - 1, Jend + 1); }
+      if (north_edge && east_edge) { WETBC(Iend + 1, Jend + 1); }
+    }
+#undef WETBC
+  }
 }
 
 void o_u3dbc(OARGS, int nout)

@@ -3,7 +3,7 @@
  * ini_zeta_tile and ini_fields_tile (ROMS/Nonlinear/ini_fields.F:836-1137, :106-777), the two initialisation
  * routines main3d calls on the first time step (main3d.F:269-283) before the first set_massflux: they load the
  * other time levels from the initial state, apply the MASKING multiplies and the lateral boundary conditions, and
- * derive ubar, vbar from the vertical integral of u, v.  SOLVE3D, no PERFECT_RESTART, no WET_DRY, no sediment.
+ * derive ubar, vbar from the vertical integral of u, v.  SOLVE3D, no PERFECT_RESTART, no sediment; WET_DRY: the wet-mask products and the Dcrit floor of zeta.
  * Pinned against the reference's own routines (tests/test_ref_pinning.py, oracle/ref_wrap.F90 ref_bc kinds 7, 8).
  */
 #include "oracle.h"
@@ -35,6 +35,7 @@ int oracle_ini_zeta(OARGS)
     for (int i = Imin; i <= Imax; i++) {
       double cff1 = zeta(i, j, kstp);
       if (p->masking) cff1 = cff1 * rmask(i, j);
+      if (p->wet_dry && cff1 <= (p->Dcrit - h(i, j))) cff1 = p->Dcrit - h(i, j);   /* WET_DRY, ini_fields.F:951-957 */
       zeta(i, j, kstp) = cff1;
       zeta(i, j, knew) = cff1;
     }
@@ -44,6 +45,7 @@ int oracle_ini_zeta(OARGS)
   }
   o_exchange2d(b, GT_R, &zeta(LBi, LBj, kstp));
   if (knew != kstp) o_exchange2d(b, GT_R, &zeta(LBi, LBj, knew));
+  if (p->wet_dry) o_exchange2d(b, GT_R, F->rmask_wet);                             /* :1020-1024, :1060-1066 */
   /* fast-time averaged free surface, :1062-1080 */
   for (int j = JstrT; j <= JendT; j++)
     for (int i = IstrT; i <= IendT; i++) Zt_avg1(i, j) = zeta(i, j, kstp);
@@ -65,6 +67,7 @@ int oracle_ini_fields(OARGS)
       for (int i = IstrM; i <= IendB; i++) {
         double cff1 = u(i, j, k, nstp);
         if (mk) cff1 = cff1 * umask(i, j);
+        if (p->wet_dry) cff1 = cff1 * umask_wet(i, j);            /* WET_DRY, ini_fields.F:292 / :307 / :398 / :423 */
         u(i, j, k, nstp) = cff1;
         u(i, j, k, nnew) = cff1;
       }
@@ -72,6 +75,7 @@ int oracle_ini_fields(OARGS)
         for (int i = IstrB; i <= IendB; i++) {
           double cff2 = v(i, j, k, nstp);
           if (mk) cff2 = cff2 * vmask(i, j);
+          if (p->wet_dry) cff2 = cff2 * vmask_wet(i, j);            /* WET_DRY, ini_fields.F:292 / :307 / :398 / :423 */
           v(i, j, k, nstp) = cff2;
           v(i, j, k, nnew) = cff2;
         }
@@ -97,6 +101,7 @@ int oracle_ini_fields(OARGS)
       const double cff1 = 1.0 / DC0;
       double cff2 = CF0 * cff1;
       if (mk) cff2 = cff2 * umask(i, j);
+      if (p->wet_dry) cff2 = cff2 * umask_wet(i, j);            /* WET_DRY, ini_fields.F:292 / :307 / :398 / :423 */
       ubar(i, j, kstp) = cff2;
       ubar(i, j, knew) = cff2;
     }
@@ -111,6 +116,7 @@ int oracle_ini_fields(OARGS)
         const double cff1 = 1.0 / DC0;
         double cff2 = CF0 * cff1;
         if (mk) cff2 = cff2 * vmask(i, j);
+        if (p->wet_dry) cff2 = cff2 * vmask_wet(i, j);            /* WET_DRY, ini_fields.F:292 / :307 / :398 / :423 */
         vbar(i, j, kstp) = cff2;
         vbar(i, j, knew) = cff2;
       }

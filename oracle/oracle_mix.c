@@ -36,6 +36,7 @@ static int t3dmix2_geo(OARGS)
           for (int i = Istr; i <= Iend + 1; i++) {
             cff = 0.5 * (pm(i, j) + pm(i - 1, j));
             if (p->masking) cff = cff * umask(i, j);                                  /* MASKING, t3dmix2_geo.h:228 */
+            if (p->wet_dry) cff = cff * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
             dZdx(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i - 1, j, k + 1));
             dTdx(i, j, k2) = cff * (t(i, j, k + 1, nrhs, itrc) - t(i - 1, j, k + 1, nrhs, itrc));
           }
@@ -43,6 +44,7 @@ static int t3dmix2_geo(OARGS)
           for (int i = Istr; i <= Iend; i++) {
             cff = 0.5 * (pn(i, j) + pn(i, j - 1));
             if (p->masking) cff = cff * vmask(i, j);                                  /* MASKING, t3dmix2_geo.h:260 */
+            if (p->wet_dry) cff = cff * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
             dZde(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i, j - 1, k + 1));
             dTde(i, j, k2) = cff * (t(i, j, k + 1, nrhs, itrc) - t(i, j - 1, k + 1, nrhs, itrc));
           }
@@ -132,12 +134,14 @@ static int t3dmix2_s(OARGS)
           cff = 0.25 * (diff2(i, j, itrc) + diff2(i - 1, j, itrc)) * pmon_u(i, j);
           FX(i, j) = cff * (Hz(i, j, k) + Hz(i - 1, j, k)) * (t(i, j, k, nrhs, itrc) - t(i - 1, j, k, nrhs, itrc));
           if (p->masking) FX(i, j) = FX(i, j) * umask(i, j);                          /* MASKING, t3dmix2_s.h:235 */
+          if (p->wet_dry) FX(i, j) = FX(i, j) * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
         }
       for (int j = Jstr; j <= Jend + 1; j++)
         for (int i = Istr; i <= Iend; i++) {
           cff = 0.25 * (diff2(i, j, itrc) + diff2(i, j - 1, itrc)) * pnom_v(i, j);
           FE(i, j) = cff * (Hz(i, j, k) + Hz(i, j - 1, k)) * (t(i, j, k, nrhs, itrc) - t(i, j - 1, k, nrhs, itrc));
           if (p->masking) FE(i, j) = FE(i, j) * vmask(i, j);                          /* MASKING, t3dmix2_s.h:275 */
+          if (p->wet_dry) FE(i, j) = FE(i, j) * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
         }
       for (int j = Jstr; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
@@ -188,6 +192,7 @@ int oracle_uv3dmix2(OARGS)
               (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * v(i, j, k, nrhs) - (pn(i - 1, j - 1) + pn(i - 1, j)) * v(i - 1, j, k, nrhs)) +
                pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * u(i, j, k, nrhs) - (pm(i - 1, j - 1) + pm(i, j - 1)) * u(i, j - 1, k, nrhs)));
         if (p->masking) cff = cff * pmask(i, j);                                      /* MASKING, uv3dmix2_s.h:272 */
+        if (p->wet_dry) cff = cff * pmask_wet(i, j);           /* WET_DRY: the next block of the same file */
         UFe(i, j) = om_p(i, j) * om_p(i, j) * visc2_p(i, j) * cff;
         VFx(i, j) = on_p(i, j) * on_p(i, j) * visc2_p(i, j) * cff;
       }

@@ -45,12 +45,14 @@ static int t3dmix4_s(OARGS)
         for (int i = Imin; i <= Imax + 1; i++) {
           cff = 0.25 * (diff4(i, j, itrc) + diff4(i - 1, j, itrc)) * pmon_u(i, j);
           if (p->masking) cff = cff * umask(i, j);
+          if (p->wet_dry) cff = cff * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
           FX(i, j) = cff * (Hz(i, j, k) + Hz(i - 1, j, k)) * (t(i, j, k, nrhs, itrc) - t(i - 1, j, k, nrhs, itrc));
         }
       for (int j = Jmin; j <= Jmax + 1; j++)
         for (int i = Imin; i <= Imax; i++) {
           cff = 0.25 * (diff4(i, j, itrc) + diff4(i, j - 1, itrc)) * pnom_v(i, j);
           if (p->masking) cff = cff * vmask(i, j);
+          if (p->wet_dry) cff = cff * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
           FE(i, j) = cff * (Hz(i, j, k) + Hz(i, j - 1, k)) * (t(i, j, k, nrhs, itrc) - t(i, j - 1, k, nrhs, itrc));
         }
       for (int j = Jmin; j <= Jmax; j++)
@@ -85,12 +87,14 @@ static int t3dmix4_s(OARGS)
           cff = 0.25 * (diff4(i, j, itrc) + diff4(i - 1, j, itrc)) * pmon_u(i, j);
           FX(i, j) = cff * (Hz(i, j, k) + Hz(i - 1, j, k)) * (LapT(i, j) - LapT(i - 1, j));
           if (p->masking) FX(i, j) = FX(i, j) * umask(i, j);
+          if (p->wet_dry) FX(i, j) = FX(i, j) * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
         }
       for (int j = Jstr; j <= Jend + 1; j++)
         for (int i = Istr; i <= Iend; i++) {
           cff = 0.25 * (diff4(i, j, itrc) + diff4(i, j - 1, itrc)) * pnom_v(i, j);
           FE(i, j) = cff * (Hz(i, j, k) + Hz(i, j - 1, k)) * (LapT(i, j) - LapT(i, j - 1));
           if (p->masking) FE(i, j) = FE(i, j) * vmask(i, j);
+          if (p->wet_dry) FE(i, j) = FE(i, j) * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
         }
       for (int j = Jstr; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
@@ -141,6 +145,7 @@ static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const r
         for (int i = i0; i <= i1 + 1; i++) {
           cff = 0.5 * (pm(i, j) + pm(i - 1, j));
           if (p->masking) cff = cff * umask(i, j);
+          if (p->wet_dry) cff = cff * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
           dZdx(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i - 1, j, k + 1));
           dTdx(i, j, k2) = cff * (S(i, j, k + 1) - S(i - 1, j, k + 1));
         }
@@ -148,6 +153,7 @@ static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const r
         for (int i = i0; i <= i1; i++) {
           cff = 0.5 * (pn(i, j) + pn(i, j - 1));
           if (p->masking) cff = cff * vmask(i, j);
+          if (p->wet_dry) cff = cff * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
           dZde(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i, j - 1, k + 1));
           dTde(i, j, k2) = cff * (S(i, j, k + 1) - S(i, j - 1, k + 1));
         }
@@ -269,6 +275,7 @@ static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_
         for (int i = i0; i <= i1 + 1; i++) {
           cff = 0.5 * (pm(i, j) + pm(i - 1, j));
           if (p->masking) cff = cff * umask(i, j);
+          if (p->wet_dry) cff = cff * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
           dRdx(i, j, k2) = cff * (pden(i, j, k + 1) - pden(i - 1, j, k + 1));
           dTdx(i, j, k2) = cff * (S(i, j, k + 1) - S(i - 1, j, k + 1));
         }
@@ -276,6 +283,7 @@ static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_
         for (int i = i0; i <= i1; i++) {
           cff = 0.5 * (pn(i, j) + pn(i, j - 1));
           if (p->masking) cff = cff * vmask(i, j);
+          if (p->wet_dry) cff = cff * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
           dRde(i, j, k2) = cff * (pden(i, j, k + 1) - pden(i, j - 1, k + 1));
           dTde(i, j, k2) = cff * (S(i, j, k + 1) - S(i, j - 1, k + 1));
         }
@@ -491,6 +499,7 @@ int oracle_uv3dmix4(OARGS)
               (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * v(i, j, k, nrhs) - (pn(i - 1, j - 1) + pn(i - 1, j)) * v(i - 1, j, k, nrhs)) +
                pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * u(i, j, k, nrhs) - (pm(i - 1, j - 1) + pm(i, j - 1)) * u(i, j - 1, k, nrhs)));
         if (p->masking) cff = cff * pmask(i, j);
+        if (p->wet_dry) cff = cff * pmask_wet(i, j);           /* WET_DRY: the next block of the same file */
         UFe(i, j) = om_p(i, j) * om_p(i, j) * visc4_p(i, j) * cff;
         VFx(i, j) = on_p(i, j) * on_p(i, j) * visc4_p(i, j) * cff;
       }
@@ -563,6 +572,7 @@ int oracle_uv3dmix4(OARGS)
               (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * LapV(i, j) - (pn(i - 1, j - 1) + pn(i - 1, j)) * LapV(i - 1, j)) +
                pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * LapU(i, j) - (pm(i - 1, j - 1) + pm(i, j - 1)) * LapU(i, j - 1)));
         if (p->masking) cff = cff * pmask(i, j);
+        if (p->wet_dry) cff = cff * pmask_wet(i, j);           /* WET_DRY: the next block of the same file */
         UFe(i, j) = om_p(i, j) * om_p(i, j) * visc4_p(i, j) * cff;
         VFx(i, j) = on_p(i, j) * on_p(i, j) * visc4_p(i, j) * cff;
       }

@@ -174,6 +174,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
                       sig_c * X * YY + sig_d * XZ + sig_e * XX * Z + sig_f * X * ZZ;
           Ua(i, j, k) = MIN(fabs(ua), fac * fabs(Um)) * copysign(1.0, ua);
           if (mk) Ua(i, j, k) = Ua(i, j, k) * umask(i, j);                    /* :395 */
+          if (p->wet_dry) Ua(i, j, k) = Ua(i, j, k) * umask_wet(i, j);           /* WET_DRY: the next block */
         }
       }
   }
@@ -266,6 +267,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
                       sig_c * YY * X + sig_d * YZ + sig_e * YY * Z + sig_f * Y * ZZ;
           Va(i, j, k) = MIN(fabs(va), fac * fabs(Vm)) * copysign(1.0, va);
           if (mk) Va(i, j, k) = Va(i, j, k) * vmask(i, j);                    /* :568 */
+          if (p->wet_dry) Va(i, j, k) = Va(i, j, k) * vmask_wet(i, j);           /* WET_DRY: the next block */
         }
       }
   }
@@ -356,6 +358,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
                       sig_c * Z * YY + sig_d * XZ + sig_e * ZZ * X + sig_f * Z * XX;
           Wa(i, j, k) = MIN(fabs(wa), fac * fabs(Wk)) * copysign(1.0, wa);
           if (mk) Wa(i, j, k) = Wa(i, j, k) * rmask(i, j);                    /* :801 */
+          if (p->wet_dry) Wa(i, j, k) = Wa(i, j, k) * rmask_wet(i, j);           /* WET_DRY: the next block */
         }
       }
     for (int i = IstrU - 1; i <= Iendp1; i++) {
@@ -428,6 +431,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
         const double cff2 = MIN(MIN(beta_up(i - 1, j, k), beta_dn(i, j, k)), 1.0);
         Ua(i, j, k) = (cff1 * MAX(0.0, Ua(i, j, k)) + cff2 * MIN(0.0, Ua(i, j, k))) * cff * om_u(i, j);
         if (mk) Ua(i, j, k) = Ua(i, j, k) * umask(i, j);                      /* :991 */
+        if (p->wet_dry) Ua(i, j, k) = Ua(i, j, k) * umask_wet(i, j);           /* WET_DRY: the next block */
       }
     for (int j = JstrV; j <= Jendp1; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -435,6 +439,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
         const double cff2 = MIN(MIN(beta_up(i, j - 1, k), beta_dn(i, j, k)), 1.0);
         Va(i, j, k) = (cff1 * MAX(0.0, Va(i, j, k)) + cff2 * MIN(0.0, Va(i, j, k))) * cff * on_v(i, j);
         if (mk) Va(i, j, k) = Va(i, j, k) * vmask(i, j);                      /* :1006 */
+        if (p->wet_dry) Va(i, j, k) = Va(i, j, k) * vmask_wet(i, j);           /* WET_DRY: the next block */
       }
     if (k < N)
       for (int j = Jstr; j <= Jend; j++)
@@ -444,6 +449,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
           Wa(i, j, k) = (cff1 * MAX(0.0, Wa(i, j, k)) + cff2 * MIN(0.0, Wa(i, j, k))) * cff * omn(i, j) *
                         (z_r(i, j, k + 1) - z_r(i, j, k));
           if (mk) Wa(i, j, k) = Wa(i, j, k) * rmask(i, j);                    /* :1022 */
+          if (p->wet_dry) Wa(i, j, k) = Wa(i, j, k) * rmask_wet(i, j);           /* WET_DRY: the next block */
         }
   }
 

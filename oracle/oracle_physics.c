@@ -175,6 +175,7 @@ int oracle_bulk_flux(OARGS)
                    (cff1 * (0.39 - 0.05 * sqrt(vap_p)) * (1.0 - 0.6823 * cloud(i, j) * cloud(i, j)) +
                     cff2 * 4.0 * (TseaK - TairK));
       if (mk) LRad(i, j) = LRad(i, j) * rmask(i, j);                          /* MASKING, bulk_flux.F:486 */
+      if (p->wet_dry) LRad(i, j) = LRad(i, j) * rmask_wet(i, j);           /* WET_DRY: the next block */
       /* specific humidities, :486-520 */
       cff = (1.0007 + 3.46E-6 * PairM) * 6.1121 * exp(17.502 * TairC / (240.97 + TairC));
       const double Qair = 0.62197 * (cff / (PairM - 0.378 * cff));
@@ -252,17 +253,21 @@ int oracle_bulk_flux(OARGS)
       const double Hsr = rain(i, j) * wet_bulb * blk_Cpw * ((TseaC - TairC) + (Qsea - Q) * Hlv / blk_Cpa);
       SHeat(i, j) = (Hs + Hsr);
       if (mk) SHeat(i, j) = SHeat(i, j) * rmask(i, j);                        /* :790 */
+      if (p->wet_dry) SHeat(i, j) = SHeat(i, j) * rmask_wet(i, j);           /* WET_DRY: the next block */
       const double Hl = -Hlv * rhoAir * Wstar * Qstar;
       const double upvel = -1.61 * Wstar * Qstar - (1.0 + 1.61 * Q) * Wstar * Tstar / TairK;
       const double Hlw = rhoAir * Hlv * upvel * Q;
       LHeat(i, j) = (Hl + Hlw);
       if (mk) LHeat(i, j) = LHeat(i, j) * rmask(i, j);                        /* :809 */
+      if (p->wet_dry) LHeat(i, j) = LHeat(i, j) * rmask_wet(i, j);           /* WET_DRY: the next block */
       const double Taur = 0.85 * rain(i, j) * Wmag;
       cff = rhoAir * Cd * Wspeed;
       Taux(i, j) = (cff * Ua + Taur * copysign(1.0, Ua));
       if (mk) Taux(i, j) = Taux(i, j) * rmask(i, j);                          /* :824 */
+      if (p->wet_dry) Taux(i, j) = Taux(i, j) * rmask_wet(i, j);           /* WET_DRY: the next block */
       Tauy(i, j) = (cff * Va + Taur * copysign(1.0, Va));
       if (mk) Tauy(i, j) = Tauy(i, j) * rmask(i, j);                          /* :831 */
+      if (p->wet_dry) Tauy(i, j) = Tauy(i, j) * rmask_wet(i, j);           /* WET_DRY: the next block */
     }
   /* kinematic fluxes, :790-860 */
   Hscale = 1.0 / (rho0 * Cp);
@@ -273,12 +278,15 @@ int oracle_bulk_flux(OARGS)
       shflx(i, j) = -SHeat(i, j) * Hscale;
       stflux(i, j, itemp) = (srflx(i, j) + lrflx(i, j) + lhflx(i, j) + shflx(i, j));
       if (mk) stflux(i, j, itemp) = stflux(i, j, itemp) * rmask(i, j);        /* :877 */
+      if (p->wet_dry) stflux(i, j, itemp) = stflux(i, j, itemp) * rmask_wet(i, j);           /* WET_DRY: the next block */
       if (p->eminusp) {                                                       /* EMINUSP, :883-899 */
         const double cffw = 1.0 / rhow;
         F->evap[I2(i, j)] = LHeat(i, j) / Hlv_[WS2(i, j)];
         if (mk) F->evap[I2(i, j)] = F->evap[I2(i, j)] * rmask(i, j);
+        if (p->wet_dry) F->evap[I2(i, j)] = F->evap[I2(i, j)] * rmask_wet(i, j);           /* WET_DRY: the next block */
         stflux(i, j, isalt) = cffw * (F->evap[I2(i, j)] - rain(i, j));
         if (mk) stflux(i, j, isalt) = stflux(i, j, isalt) * rmask(i, j);
+        if (p->wet_dry) stflux(i, j, isalt) = stflux(i, j, isalt) * rmask_wet(i, j);           /* WET_DRY: the next block */
       }
     }
   const double cffs = 0.5 / rho0;
@@ -286,11 +294,13 @@ int oracle_bulk_flux(OARGS)
     for (int i = Istr; i <= IendR; i++) {
       F->sustr[I2(i, j)] = cffs * (Taux(i - 1, j) + Taux(i, j));
       if (mk) F->sustr[I2(i, j)] = F->sustr[I2(i, j)] * umask(i, j);          /* :908 */
+      if (p->wet_dry) F->sustr[I2(i, j)] = F->sustr[I2(i, j)] * umask_wet(i, j);           /* WET_DRY: the next block */
     }
   for (int j = Jstr; j <= JendR; j++)
     for (int i = IstrR; i <= IendR; i++) {
       F->svstr[I2(i, j)] = cffs * (Tauy(i, j - 1) + Tauy(i, j));
       if (mk) F->svstr[I2(i, j)] = F->svstr[I2(i, j)] * vmask(i, j);          /* :919 */
+      if (p->wet_dry) F->svstr[I2(i, j)] = F->svstr[I2(i, j)] * vmask_wet(i, j);           /* WET_DRY: the next block */
     }
   o_exchange2d(b, GT_R, F->lrflx);
   o_exchange2d(b, GT_R, F->lhflx);

@@ -244,7 +244,7 @@ int oracle_pre_step3d(OARGS)
             FC(i, k) = FC(i, k) - dt * Akt(i, j, k, itrc) * ghats(i, j, k, itrc);
       if (p->solar_source && itrc == itemp)
         for (int k = 1; k <= N - 1; k++)
-          for (int i = Istr; i <= Iend; i++) FC(i, k) = FC(i, k) + dt * srflx(i, j) * swdk(i, j, k);
+          for (int i = Istr; i <= Iend; i++) FC(i, k) = FC(i, k) + dt * srflx(i, j) * (p->wet_dry ? rmask_wet(i, j) : 1.0) * swdk(i, j, k);   /* WET_DRY, :876 */
       for (int i = Istr; i <= Iend; i++) {
         FC(i, 0) = dt * btflx(i, j, itrc);
         FC(i, N) = dt * stflx(i, j, itrc);

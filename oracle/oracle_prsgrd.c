@@ -108,7 +108,29 @@ static int oracle_prsgrd40(OARGS)
   return 0;
 }
 
+static int o_prsgrd_any(OARGS);
+
+/* WET_DRY: every variant multiplies the term it has just stored by the wet/dry mask of the face (prsgrd32.h:346,
+ * :410; prsgrd31.h:223 ... :350; prsgrd40.h:229, :259) -- one pass over the same ranges after the variant */
 int oracle_prsgrd(OARGS)
+{
+  /* PJ_GRADP with WET_DRY does not compile in the reference (prsgrd40.h:98-100 passes umask_wet, vmask_wet to a
+   * routine that never declares them): refused, as the library does */
+  if (p->wet_dry && p->pgf == PGF_PJ_GRADP) return 8;
+  const int rc = o_prsgrd_any(b, p, s, F);
+  if (rc || !p->wet_dry) return rc;
+  ORACLE_PROLOGUE
+  const int nrhs = s->nrhs;
+  for (int k = 1; k <= N; k++) {
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = IstrU; i <= Iend; i++) ru(i, j, k, nrhs) = ru(i, j, k, nrhs) * umask_wet(i, j);
+    for (int j = JstrV; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) rv(i, j, k, nrhs) = rv(i, j, k, nrhs) * vmask_wet(i, j);
+  }
+  return 0;
+}
+
+static int o_prsgrd_any(OARGS)
 {
   if (p->pgf == PGF_PJ_GRADP) return oracle_prsgrd40(b, p, s, F);
   if (p->pgf != PGF_DJ_GRADPS) {

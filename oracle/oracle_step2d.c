@@ -103,6 +103,7 @@ int oracle_step2d(OARGS)
     o_exchange2d(b, GT_U, F->DU_avg1);
     o_exchange2d(b, GT_V, F->DV_avg1);
   }
+  if (p->wet_dry) o_wetdry(b, p, s, F);                 /* WET_DRY: the new wet/dry masks, :729-749 */
   if (iif > nfast) { FREE_ALL return 0; }
 
   /* free-surface step, :770-929 */
@@ -154,7 +155,11 @@ int oracle_step2d(OARGS)
       }
   }
   for (int j = Jstr; j <= Jend; j++)
-    for (int i = Istr; i <= Iend; i++) zeta(i, j, knew) = zeta_new(i, j);
+    for (int i = Istr; i <= Iend; i++) {
+      zeta(i, j, knew) = zeta_new(i, j);
+      /* WET_DRY && MASKING, :863-866: the total depth of a land cell stays at Dcrit */
+      if (p->wet_dry && p->masking) zeta(i, j, knew) = zeta(i, j, knew) + (p->Dcrit - h(i, j)) * (1.0 - rmask(i, j));
+    }
   if (PREDICTOR) {
     for (int j = Jstr; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) rzeta(i, j, krhs) = rhs_zeta(i, j);
@@ -301,6 +306,7 @@ int oracle_step2d(OARGS)
               (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * vbar(i, j, krhs) - (pn(i - 1, j - 1) + pn(i - 1, j)) * vbar(i - 1, j, krhs)) +
                pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * ubar(i, j, krhs) - (pm(i - 1, j - 1) + pm(i, j - 1)) * ubar(i, j - 1, krhs)));
         if (p->masking) cff = cff * pmask(i, j);                                        /* MASKING, :1433 */
+        if (p->wet_dry) cff = cff * pmask_wet(i, j);                                    /* WET_DRY, :1436/:1512/:1707 */
         UFe(i, j) = om_p(i, j) * om_p(i, j) * cff;
         VFx(i, j) = on_p(i, j) * on_p(i, j) * cff;
       }
@@ -343,6 +349,7 @@ int oracle_step2d(OARGS)
               (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * vbar(i, j, krhs) - (pn(i - 1, j - 1) + pn(i - 1, j)) * vbar(i - 1, j, krhs)) +
                pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * ubar(i, j, krhs) - (pm(i - 1, j - 1) + pm(i, j - 1)) * ubar(i, j - 1, krhs)));
         if (p->masking) cff = cff * pmask(i, j);
+        if (p->wet_dry) cff = cff * pmask_wet(i, j);                                    /* WET_DRY, :1436/:1512/:1707 */
         UFe(i, j) = om_p(i, j) * om_p(i, j) * cff;
         VFx(i, j) = on_p(i, j) * on_p(i, j) * cff;
       }
@@ -412,6 +419,7 @@ int oracle_step2d(OARGS)
               (pmon_p(i, j) * ((pn(i, j - 1) + pn(i, j)) * LapV(i, j) - (pn(i - 1, j - 1) + pn(i - 1, j)) * LapV(i - 1, j)) +
                pnom_p(i, j) * ((pm(i - 1, j) + pm(i, j)) * LapU(i, j) - (pm(i - 1, j - 1) + pm(i, j - 1)) * LapU(i, j - 1)));
         if (p->masking) cff = cff * pmask(i, j);
+        if (p->wet_dry) cff = cff * pmask_wet(i, j);                                    /* WET_DRY, :1436/:1512/:1707 */
         UFe(i, j) = om_p(i, j) * om_p(i, j) * cff;
         VFx(i, j) = on_p(i, j) * on_p(i, j) * cff;
       }
@@ -497,6 +505,15 @@ int oracle_step2d(OARGS)
         fac = 1.0 / (Dnew(i, j) + Dnew(i - 1, j));
         ubar(i, j, knew) = (ubar(i, j, kstp) * (Dstp(i, j) + Dstp(i - 1, j)) + cff * cff1 * rhs_ubar(i, j)) * fac;
         if (p->masking) ubar(i, j, knew) = ubar(i, j, knew) * umask(i, j);      /* MASKING, :2120/:2175 */
+        if (p->wet_dry) {                                                        /* WET_DRY, :2123-2135 ... */
+          const double cff7 = o_wet_factor(umask_wet(i, j), ubar(i, j, knew));
+          ubar(i, j, knew) = ubar(i, j, knew) * cff7;
+          rhs_ubar(i, j) = rhs_ubar(i, j) * cff7;
+          if (iif == 1 && PREDICTOR) {                                           /* FIRST_2D_STEP only, :2129-2133 */
+            rufrc(i, j) = rufrc(i, j) * cff7;
+            ru(i, j, 0, nstp) = rufrc(i, j);
+          }
+        }
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -504,6 +521,15 @@ int oracle_step2d(OARGS)
         fac = 1.0 / (Dnew(i, j) + Dnew(i, j - 1));
         vbar(i, j, knew) = (vbar(i, j, kstp) * (Dstp(i, j) + Dstp(i, j - 1)) + cff * cff1 * rhs_vbar(i, j)) * fac;
         if (p->masking) vbar(i, j, knew) = vbar(i, j, knew) * vmask(i, j);      /* MASKING, :2145/:2194 */
+        if (p->wet_dry) {                                                        /* WET_DRY, :2123-2135 ... */
+          const double cff7 = o_wet_factor(vmask_wet(i, j), vbar(i, j, knew));
+          vbar(i, j, knew) = vbar(i, j, knew) * cff7;
+          rhs_vbar(i, j) = rhs_vbar(i, j) * cff7;
+          if (iif == 1 && PREDICTOR) {                                           /* FIRST_2D_STEP only, :2129-2133 */
+            rvfrc(i, j) = rvfrc(i, j) * cff7;
+            rv(i, j, 0, nstp) = rvfrc(i, j);
+          }
+        }
       }
   } else {
     cff1 = 0.5 * dtfast * 5.0 / 12.0;
@@ -516,6 +542,11 @@ int oracle_step2d(OARGS)
         ubar(i, j, knew) = (ubar(i, j, kstp) * (Dstp(i, j) + Dstp(i - 1, j)) +
                             cff * (cff1 * rhs_ubar(i, j) + cff2 * rubar(i, j, kstp) - cff3 * rubar(i, j, ptsk))) * fac;
         if (p->masking) ubar(i, j, knew) = ubar(i, j, knew) * umask(i, j);      /* MASKING, :2120/:2175 */
+        if (p->wet_dry) {                                                        /* WET_DRY, :2123-2135 ... */
+          const double cff7 = o_wet_factor(umask_wet(i, j), ubar(i, j, knew));
+          ubar(i, j, knew) = ubar(i, j, knew) * cff7;
+          rhs_ubar(i, j) = rhs_ubar(i, j) * cff7;
+        }
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -524,6 +555,11 @@ int oracle_step2d(OARGS)
         vbar(i, j, knew) = (vbar(i, j, kstp) * (Dstp(i, j) + Dstp(i, j - 1)) +
                             cff * (cff1 * rhs_vbar(i, j) + cff2 * rvbar(i, j, kstp) - cff3 * rvbar(i, j, ptsk))) * fac;
         if (p->masking) vbar(i, j, knew) = vbar(i, j, knew) * vmask(i, j);      /* MASKING, :2145/:2194 */
+        if (p->wet_dry) {                                                        /* WET_DRY, :2123-2135 ... */
+          const double cff7 = o_wet_factor(vmask_wet(i, j), vbar(i, j, knew));
+          vbar(i, j, knew) = vbar(i, j, knew) * cff7;
+          rhs_vbar(i, j) = rhs_vbar(i, j) * cff7;
+        }
       }
   }
   if (PREDICTOR) {

@@ -85,6 +85,10 @@ int oracle_step3d_uv(OARGS)
       for (int i = IstrU; i <= Iend; i++) {
         u(i, j, k, nnew) = u(i, j, k, nnew) - DC(i, 0);
         if (p->masking) u(i, j, k, nnew) = u(i, j, k, nnew) * umask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+        if (p->wet_dry) {                                                        /* WET_DRY, step3d_uv.F:561-564 / :894-897 */
+          u(i, j, k, nnew) = u(i, j, k, nnew) * umask_wet(i, j);
+          ru(i, j, k, nrhs) = ru(i, j, k, nrhs) * umask_wet(i, j);
+        }
       }
 
     /* ---- v, step3d_uv.F:620-860 ---- */
@@ -144,6 +148,10 @@ int oracle_step3d_uv(OARGS)
         for (int i = Istr; i <= Iend; i++) {
           v(i, j, k, nnew) = v(i, j, k, nnew) - DC(i, 0);
           if (p->masking) v(i, j, k, nnew) = v(i, j, k, nnew) * vmask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+          if (p->wet_dry) {                                                        /* WET_DRY, step3d_uv.F:561-564 / :894-897 */
+            v(i, j, k, nnew) = v(i, j, k, nnew) * vmask_wet(i, j);
+            rv(i, j, k, nrhs) = rv(i, j, k, nrhs) * vmask_wet(i, j);
+          }
         }
     }
   }
@@ -166,16 +174,19 @@ int oracle_step3d_uv(OARGS)
       DC(i, 0) = 1.0 / DC(i, 0);
       CF(i, 0) = DC(i, 0) * (CF(i, 0) - DU_avg1(i, j));
       ubar(i, j, 1) = DC(i, 0) * DU_avg1(i, j);
+      if (p->wet_dry) ubar(i, j, 1) = ubar(i, j, 1) * umask_wet(i, j);                /* WET_DRY, step3d_uv.F:1042-1044 */
       ubar(i, j, 2) = ubar(i, j, 1);
     }
     if (!EWperiodic) {
       if (west_edge) for (int k = 1; k <= N; k++) {
         u(Istr, j, k, nnew) = u(Istr, j, k, nnew) - CF(Istr, 0);
         if (p->masking) u(Istr, j, k, nnew) = u(Istr, j, k, nnew) * umask(Istr, j);               /* :1081-1084 */
+        if (p->wet_dry) u(Istr, j, k, nnew) = u(Istr, j, k, nnew) * umask_wet(Istr, j);   /* WET_DRY, the next block */
       }
       if (east_edge) for (int k = 1; k <= N; k++) {
         u(Iend + 1, j, k, nnew) = u(Iend + 1, j, k, nnew) - CF(Iend + 1, 0);
         if (p->masking) u(Iend + 1, j, k, nnew) = u(Iend + 1, j, k, nnew) * umask(Iend + 1, j);   /* :1108-1111 */
+        if (p->wet_dry) u(Iend + 1, j, k, nnew) = u(Iend + 1, j, k, nnew) * umask_wet(Iend + 1, j);   /* WET_DRY, the next block */
       }
     }
     if (!NSperiodic) {
@@ -184,12 +195,14 @@ int oracle_step3d_uv(OARGS)
           for (int i = IstrU; i <= Iend; i++) {
             u(i, j, k, nnew) = u(i, j, k, nnew) - CF(i, 0);
             if (p->masking) u(i, j, k, nnew) = u(i, j, k, nnew) * umask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+            if (p->wet_dry) u(i, j, k, nnew) = u(i, j, k, nnew) * umask_wet(i, j);   /* WET_DRY, the next block */
           }
       if (j == Mm + 1)
         for (int k = 1; k <= N; k++)
           for (int i = IstrU; i <= Iend; i++) {
             u(i, j, k, nnew) = u(i, j, k, nnew) - CF(i, 0);
             if (p->masking) u(i, j, k, nnew) = u(i, j, k, nnew) * umask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+            if (p->wet_dry) u(i, j, k, nnew) = u(i, j, k, nnew) * umask_wet(i, j);   /* WET_DRY, the next block */
           }
     }
     for (int k = N; k >= 1; k--)
@@ -214,16 +227,19 @@ int oracle_step3d_uv(OARGS)
         DC(i, 0) = 1.0 / DC(i, 0);
         CF(i, 0) = DC(i, 0) * (CF(i, 0) - DV_avg1(i, j));
         vbar(i, j, 1) = DC(i, 0) * DV_avg1(i, j);
+        if (p->wet_dry) vbar(i, j, 1) = vbar(i, j, 1) * vmask_wet(i, j);              /* WET_DRY, step3d_uv.F:1255-1257 */
         vbar(i, j, 2) = vbar(i, j, 1);
       }
       if (!EWperiodic) {
         if (west_edge) for (int k = 1; k <= N; k++) {
           v(Istr - 1, j, k, nnew) = v(Istr - 1, j, k, nnew) - CF(Istr - 1, 0);
           if (p->masking) v(Istr - 1, j, k, nnew) = v(Istr - 1, j, k, nnew) * vmask(Istr - 1, j);   /* :1297-1301 */
+          if (p->wet_dry) v(Istr - 1, j, k, nnew) = v(Istr - 1, j, k, nnew) * vmask_wet(Istr - 1, j);   /* WET_DRY, the next block */
         }
         if (east_edge) for (int k = 1; k <= N; k++) {
           v(Iend + 1, j, k, nnew) = v(Iend + 1, j, k, nnew) - CF(Iend + 1, 0);
           if (p->masking) v(Iend + 1, j, k, nnew) = v(Iend + 1, j, k, nnew) * vmask(Iend + 1, j);
+          if (p->wet_dry) v(Iend + 1, j, k, nnew) = v(Iend + 1, j, k, nnew) * vmask_wet(Iend + 1, j);   /* WET_DRY, the next block */
         }
       }
       if (!NSperiodic) {
@@ -232,12 +248,14 @@ int oracle_step3d_uv(OARGS)
             for (int i = Istr; i <= Iend; i++) {
               v(i, j, k, nnew) = v(i, j, k, nnew) - CF(i, 0);
               if (p->masking) v(i, j, k, nnew) = v(i, j, k, nnew) * vmask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+              if (p->wet_dry) v(i, j, k, nnew) = v(i, j, k, nnew) * vmask_wet(i, j);   /* WET_DRY, the next block */
             }
         if (j == Mm + 1)
           for (int k = 1; k <= N; k++)
             for (int i = Istr; i <= Iend; i++) {
               v(i, j, k, nnew) = v(i, j, k, nnew) - CF(i, 0);
               if (p->masking) v(i, j, k, nnew) = v(i, j, k, nnew) * vmask(i, j);      /* MASKING, step3d_uv.F:558/:891/:1137/:1166/:1355/:1384 */
+              if (p->wet_dry) v(i, j, k, nnew) = v(i, j, k, nnew) * vmask_wet(i, j);   /* WET_DRY, the next block */
             }
       }
       for (int k = N; k >= 1; k--)

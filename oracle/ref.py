@@ -23,6 +23,8 @@ def available(app):
 class Ref:
     def __init__(self, state):
         app = state.cfg["app"] + ("_MASK" if state.p.masking else "")      # <APP>_MASK: built with -DMASKING
+        if state.p.wet_dry:
+            app += "_WET"                                                  # <APP>_MASK_WET...: built with -DWET_DRY as well
         app += {0: "", 1: "_PG31", 2: "_WJ", 3: "_PJ"}[int(state.p.pgf)]   # prsgrd31.h builds (plain / WJ_GRADP), prsgrd40.h
         if state.p.uv_drag == 3:
             app += "_LOGDRAG"                                              # UV_LOGDRAG instead of the application's law

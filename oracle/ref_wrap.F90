@@ -56,6 +56,8 @@ MODULE ref_wrap_types
     INTEGER(c_int) :: gls_mixing, gls_stability, gls_n2s2_horavg, gls_ri_splines
     REAL(c_double) :: gls_p, gls_m, gls_n, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp, gls_Kmin, gls_Pmin
     REAL(c_double) :: Akk_bak, Akp_bak, Zos
+    INTEGER(c_int) :: wet_dry, wet_dry_pad_
+    REAL(c_double) :: Dcrit
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -77,6 +79,7 @@ MODULE ref_wrap_types
     TYPE(c_ptr) :: visc4_p, visc4_r, diff4
     TYPE(c_ptr) :: ZoBot
     TYPE(c_ptr) :: tke, gls, Lscale, Akk, Akp
+    TYPE(c_ptr) :: pmask_wet, rmask_wet, umask_wet, vmask_wet, rmask_wet_avg, pmask_full, rmask_full, umask_full, vmask_full
   END TYPE fields_t
   LOGICAL, SAVE :: have_boundary = .FALSE.      ! allocate_boundary is done once per process
 END MODULE ref_wrap_types
@@ -306,6 +309,13 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
   CALL c_f_pointer (F%pmask, a2, (/ni,nj/));    GRID(ng)%pmask = a2
 #endif
+#ifdef WET_DRY
+  CALL c_f_pointer (F%rmask_wet, a2, (/ni,nj/)); GRID(ng)%rmask_wet = a2
+  CALL c_f_pointer (F%umask_wet, a2, (/ni,nj/)); GRID(ng)%umask_wet = a2
+  CALL c_f_pointer (F%vmask_wet, a2, (/ni,nj/)); GRID(ng)%vmask_wet = a2
+  CALL c_f_pointer (F%pmask_wet, a2, (/ni,nj/)); GRID(ng)%pmask_wet = a2
+  Dcrit(ng) = p%Dcrit
+#endif
   CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
   CALL c_f_pointer (F%Huon, a3, (/ni,nj,NN/));  GRID(ng)%Huon = a3
   CALL c_f_pointer (F%Hvom, a3, (/ni,nj,NN/));  GRID(ng)%Hvom = a3
@@ -479,6 +489,13 @@ FUNCTION ref_physics (kernel, b, p, s, F) BIND(C, name='ref_physics') RESULT(rc)
   CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
   CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
   CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
+#endif
+#ifdef WET_DRY
+  CALL c_f_pointer (F%rmask_wet, a2, (/ni,nj/)); GRID(ng)%rmask_wet = a2
+  CALL c_f_pointer (F%umask_wet, a2, (/ni,nj/)); GRID(ng)%umask_wet = a2
+  CALL c_f_pointer (F%vmask_wet, a2, (/ni,nj/)); GRID(ng)%vmask_wet = a2
+  CALL c_f_pointer (F%pmask_wet, a2, (/ni,nj/)); GRID(ng)%pmask_wet = a2
+  Dcrit(ng) = p%Dcrit
 #endif
 #if defined BENCHMARK || defined SEAMOUNT
   CALL c_f_pointer (F%rdrag2, a2, (/ni,nj/));   GRID(ng)%rdrag2 = a2
@@ -869,9 +886,19 @@ FUNCTION ref_mpdata_adiff (b, p, F, oHz, t3, Ta, Ua, Va, Wa) BIND(C, name='ref_m
   CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
   CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
 #endif
+#ifdef WET_DRY
+  CALL c_f_pointer (F%rmask_wet, a2, (/ni,nj/)); GRID(ng)%rmask_wet = a2
+  CALL c_f_pointer (F%umask_wet, a2, (/ni,nj/)); GRID(ng)%umask_wet = a2
+  CALL c_f_pointer (F%vmask_wet, a2, (/ni,nj/)); GRID(ng)%vmask_wet = a2
+  CALL c_f_pointer (F%pmask_wet, a2, (/ni,nj/)); GRID(ng)%pmask_wet = a2
+  Dcrit(ng) = p%Dcrit
+#endif
   CALL mpdata_adiff_tile (ng, tile, LBi, UBi, LBj, UBj, IminS, ImaxS, JminS, JmaxS,   &
 #ifdef MASKING
  &                        GRID(ng)%rmask, GRID(ng)%umask, GRID(ng)%vmask, &
+#endif
+#ifdef WET_DRY
+ &                        GRID(ng)%rmask_wet, GRID(ng)%umask_wet, GRID(ng)%vmask_wet, &
 #endif
  &                        GRID(ng)%pm, GRID(ng)%pn, GRID(ng)%omn, GRID(ng)%om_u, GRID(ng)%on_v, &
  &                        GRID(ng)%z_r, poHz, GRID(ng)%Huon, GRID(ng)%Hvom, OCEAN(ng)%W, &
@@ -1002,6 +1029,13 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
   CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
   CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
+#endif
+#ifdef WET_DRY
+  CALL c_f_pointer (F%rmask_wet, a2, (/ni,nj/)); GRID(ng)%rmask_wet = a2
+  CALL c_f_pointer (F%umask_wet, a2, (/ni,nj/)); GRID(ng)%umask_wet = a2
+  CALL c_f_pointer (F%vmask_wet, a2, (/ni,nj/)); GRID(ng)%vmask_wet = a2
+  CALL c_f_pointer (F%pmask_wet, a2, (/ni,nj/)); GRID(ng)%pmask_wet = a2
+  Dcrit(ng) = p%Dcrit
 #endif
   CALL c_f_pointer (F%zeta, a3, (/ni,nj,3/));   OCEAN(ng)%zeta = a3
   CALL c_f_pointer (F%ubar, a3, (/ni,nj,3/));   OCEAN(ng)%ubar = a3
@@ -1160,6 +1194,13 @@ FUNCTION ref_gls (kernel, b, p, s, F) BIND(C, name='ref_gls') RESULT(rc)
   CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
   CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
   CALL c_f_pointer (F%vmask, a2, (/ni,nj/));    GRID(ng)%vmask = a2
+#endif
+#ifdef WET_DRY
+  CALL c_f_pointer (F%rmask_wet, a2, (/ni,nj/)); GRID(ng)%rmask_wet = a2
+  CALL c_f_pointer (F%umask_wet, a2, (/ni,nj/)); GRID(ng)%umask_wet = a2
+  CALL c_f_pointer (F%vmask_wet, a2, (/ni,nj/)); GRID(ng)%vmask_wet = a2
+  CALL c_f_pointer (F%pmask_wet, a2, (/ni,nj/)); GRID(ng)%pmask_wet = a2
+  Dcrit(ng) = p%Dcrit
 #endif
   CALL c_f_pointer (F%u, a4, (/ni,nj,NN,2/));   OCEAN(ng)%u = a4
   CALL c_f_pointer (F%v, a4, (/ni,nj,NN,2/));   OCEAN(ng)%v = a4

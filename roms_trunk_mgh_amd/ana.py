@@ -228,6 +228,9 @@ def make_params(cfg, NT):
         p.gls_ri_splines = int(cfg.get("gls_ri_splines", 1))
         p.Akk_bak = p.Akp_bak = 5.0e-6              # AKK_BAK, AKP_BAK (roms_upwelling.in)
         p.Zos = 0.02                                # Zos (roms_upwelling.in:378)
+    # WET_DRY: DCRIT of roms_*.in (0.10 m in every input script of the reference, e.g. roms_upwelling.in)
+    p.wet_dry = int(cfg.get("wet_dry", 0))
+    p.Dcrit = float(cfg.get("Dcrit", 0.10))
     return p
 
 
@@ -291,6 +294,13 @@ def _grid_global(cfg, b, st):
     A["pm"][:] = pm
     A["pn"][:] = pn
     A["f"][:] = f
+    if cfg.get("beach"):
+        # WET_DRY test bathymetry (no application header of the reference has one that fits a 3-D channel): the
+        # northern side shoals to a beach whose shoreline (h = 0) meanders around row Mm - 3.5 -- 0.25 m per row near
+        # the shoreline, bed above the resting level (h < 0) beyond it; a function of the global indices only
+        d = (Mm - 3.5 - jj) + 1.5 * np.sin(2.0 * math.pi * (ii - 0.5) / Lm)
+        hb = np.where(d > 0.0, 0.25 * d + 0.15 * d * d, 0.25 * d)
+        h = np.minimum(h, hb * ones)
     A["h"][:] = h
     # ---- metrics.F ----
     A["om_r"][:] = 1.0 / pm
@@ -421,7 +431,9 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
     jj = np.arange(b.LBj, b.UBj + 1, dtype=np.float64)[None, :]
     # smooth doubly-varying bump, periodic in i
     bump = np.sin(2.0 * math.pi * (ii - 0.5) / Lm * 3.0) * np.sin(math.pi * (jj - 0.5) / Mm * 2.0)
-    zeta0 = perturb * 0.05 * bump
+    zeta0 = perturb * cfg.get("zeta_amp", 0.05) * bump
+    if p.wet_dry:                            # an initial state consistent with the bed: total depth >= Dcrit
+        zeta0 = np.maximum(zeta0, p.Dcrit - A["h"])
     # closed walls: zero-gradient ghost rows for zeta (zetabc.F closed branches)
     for k in range(3):
         A["zeta"][:, :, k] = zeta0
@@ -514,6 +526,12 @@ def make_tile(config, ntileI=1, ntileJ=1, tile=0, NT=None, overrides=None,
     p.masking = 0
     # pressure-gradient algorithm (prsgrd.F:16-26): the three application headers define DJ_GRADPS
     p.pgf = abi.PGF[cfg.get("pgf", "DJ_GRADPS")]
+    if p.wet_dry and mask is None:           # WET_DRY needs MASKING (wetdry.F:325 reads rmask unconditionally): all water
+        set_masks(st, np.ones((st.ni, st.nj)))
+    for name in ("pmask_wet", "rmask_wet", "umask_wet", "vmask_wet", "pmask_full", "rmask_full", "umask_full",
+                 "vmask_full"):
+        A[name][:] = 1.0                      # all wet until initial.F's wetdry call (main3d.initial) sets them
+    A["rmask_wet_avg"][:] = 0.0
     if mask == "island":
         set_masks(st, island_mask(cfg, b))
         # masked initial state, as the reference's ini_fields / ana_initial leave it

@@ -414,6 +414,8 @@ static int library_default(int id, double *value)
   case FID_diff4: *value = 0.0; return !p.ts_dif4;
   case FID_ZoBot: *value = 1.0; return p.uv_drag != 3 && !p.gls_mixing;
   case FID_tke: case FID_gls: case FID_Lscale: case FID_Akk: case FID_Akp: *value = 0.0; return !p.gls_mixing;
+  case FID_pmask_wet: case FID_rmask_wet: case FID_umask_wet: case FID_vmask_wet: case FID_rmask_wet_avg:
+  case FID_pmask_full: case FID_rmask_full: case FID_umask_full: case FID_vmask_full: *value = 1.0; return !p.wet_dry;
   default: return 0;
   }
 }

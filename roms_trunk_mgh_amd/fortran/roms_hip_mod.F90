@@ -79,6 +79,9 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: gls_mixing, gls_stability, gls_n2s2_horavg, gls_ri_splines
     REAL(c_double) :: gls_p, gls_m, gls_n, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp, gls_Kmin, gls_Pmin
     REAL(c_double) :: Akk_bak, Akp_bak, Zos
+    !  WET_DRY: switch and the critical depth Dcrit (m)
+    INTEGER(c_int) :: wet_dry, wet_dry_pad_
+    REAL(c_double) :: Dcrit
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)
@@ -107,7 +110,9 @@ MODULE roms_hip_mod
  &    FID_rmask=87, FID_umask=88, FID_vmask=89, FID_pmask=90, FID_zeta_bry=91, FID_ubar_bry=92,   &
  &    FID_vbar_bry=93, FID_u_bry=94, FID_v_bry=95, FID_t_bry=96,                                  &
  &    FID_visc4_p=97, FID_visc4_r=98, FID_diff4=99, FID_ZoBot=100,                             &
- &    FID_tke=101, FID_gls=102, FID_Lscale=103, FID_Akk=104, FID_Akp=105
+ &    FID_tke=101, FID_gls=102, FID_Lscale=103, FID_Akk=104, FID_Akp=105,                      &
+ &    FID_pmask_wet=106, FID_rmask_wet=107, FID_umask_wet=108, FID_vmask_wet=109, FID_rmask_wet_avg=110,   &
+ &    FID_pmask_full=111, FID_rmask_full=112, FID_umask_full=113, FID_vmask_full=114
 
   INTERFACE
     INTEGER(c_int) FUNCTION roms_hip_init (rank, ntileI, ntileJ, device_id, uid)            &
@@ -263,6 +268,11 @@ MODULE roms_hip_mod
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
     END FUNCTION
+    !  WET_DRY: the initial wet/dry masks (wetdry with Linitialize, initial.F:438-466)
+    INTEGER(c_int) FUNCTION roms_hip_wetdry (s) BIND(C, name='roms_hip_wetdry')
+      IMPORT :: c_int, roms_step_idx_t
+      TYPE(roms_step_idx_t), INTENT(in) :: s
+    END FUNCTION
     !  GLS_MIXING: gls_prestep (main3d.F:567) and gls_corstep (main3d.F:793)
     INTEGER(c_int) FUNCTION roms_hip_gls_prestep (s) BIND(C, name='roms_hip_gls_prestep')
       IMPORT :: c_int, roms_step_idx_t
@@ -289,7 +299,7 @@ MODULE roms_hip_mod
   PUBLIC :: roms_hip_set_depth, roms_hip_rhs3d, roms_hip_step2d, roms_hip_step2d_loop
   PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc, roms_hip_lmd_vmix
   PUBLIC :: roms_hip_ana_srflux, roms_hip_wvelocity, roms_hip_diag, roms_hip_snapshot_begin, roms_hip_snapshot_end
-  PUBLIC :: roms_hip_ini_zeta, roms_hip_ini_fields, roms_hip_gls_prestep, roms_hip_gls_corstep
+  PUBLIC :: roms_hip_ini_zeta, roms_hip_ini_fields, roms_hip_gls_prestep, roms_hip_gls_corstep, roms_hip_wetdry
   PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
 
 CONTAINS

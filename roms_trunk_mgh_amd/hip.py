@@ -29,7 +29,7 @@ def use_library(path):
 ENTRIES = ["set_massflux", "rho_eos", "omega", "set_zeta", "set_depth", "rhs3d",
            "pre_step3d", "prsgrd", "t3dmix2", "rhs3d_tile", "uv3dmix2", "step2d",
            "step3d_uv", "step3d_t", "bulk_flux", "set_vbc", "lmd_vmix", "wvelocity", "ini_zeta", "ini_fields",
-           "t3dmix4", "uv3dmix4", "gls_prestep", "gls_corstep"]
+           "t3dmix4", "uv3dmix4", "gls_prestep", "gls_corstep", "wetdry"]
 
 # every symbol include/roms_hip.h declares
 DECLARED_SYMBOLS = (

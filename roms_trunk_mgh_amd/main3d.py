@@ -68,6 +68,9 @@ class Main3D:
         set_depth, set_massflux, omega, rho_eos on the initial state."""
         s = self.s
         s.nstp, s.nnew, s.nrhs = 1, 2, 1
+        if self.be.st.p.wet_dry:              # initial.F:438-466: the wet/dry masks of the initial state (Tindex = 1)
+            s.kstp = 1
+            self.be.call("wetdry", s)
         for k in ("set_depth", "set_massflux", "omega", "rho_eos"):
             self.be.call(k, s)
 

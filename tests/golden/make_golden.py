@@ -71,6 +71,9 @@ def checksum(st):
         # and the fields of the GLS closure (all zero in an application without GLS_MIXING)
         if name in ("tke", "gls", "Lscale", "Akk", "Akp") and not st.p.gls_mixing:
             continue
+        # and the wet/dry masks (all one in an application without WET_DRY)
+        if (name.endswith("_wet") or name.endswith("_full") or name == "rmask_wet_avg") and not st.p.wet_dry:
+            continue
         h.update(np.ascontiguousarray(st.arr[name]).tobytes())
     return h.hexdigest()
 

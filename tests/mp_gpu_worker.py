@@ -28,6 +28,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
         kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:
         kw.setdefault("overrides", {})["EWperiodic"] = False
+    if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
+        kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)
@@ -52,7 +54,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
     m.run(nsteps)
     be.to_host()
     be.close()
-    out = {k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke")}
+    out = {k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke", "rmask_wet", "umask_wet",
+                                 "vmask_wet", "pmask_wet", "rmask_wet_avg")}
     if "slim" in opts:      # full-size grids: only the newest time level of the 3-D prognostic fields
         lev = m.s.nnew - 1
         out["u"], out["v"], out["t"] = st["u"][:, :, :, lev], st["v"][:, :, :, lev], st["t"][:, :, :, lev, :]

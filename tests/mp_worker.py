@@ -30,6 +30,10 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
         kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:                  # no periodic direction
         kw.setdefault("overrides", {})["EWperiodic"] = False
+    if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
+        kw.setdefault("overrides", {})["gls"] = "k-epsilon"
+    if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
+        kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb, **kw)
     b = st.b
     ni, nj = st.ni, st.nj
@@ -51,7 +55,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
     lib.oracle_set_exchange_hook(HOOK(0))
     np.savez(os.path.join(outdir, f"tile{rank}.npz"),
              bounds=np.array([b.Istr, b.Iend, b.Jstr, b.Jend, b.LBi, b.LBj]),
-             **{k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke")})
+             **{k: st[k] for k in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke", "rmask_wet", "umask_wet",
+                                 "vmask_wet", "pmask_wet", "rmask_wet_avg")})
     dist.barrier()
     dist.destroy_process_group()
 

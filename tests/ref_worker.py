@@ -21,6 +21,9 @@ def main(config, mask=None, pgf=0, basin=False):
         ov["EWperiodic"] = False
     st0 = util.prepared_state(config, overrides=ov, mask=mask)
     st0.p.pgf = pgf                      # 1, 2: the reference built with prsgrd31.h (plain / WJ_GRADP)
+    if util.WET:                         # set_depth.F:168-172: a bed at the resting level is lifted by 1e-14
+        st0["h"][7 - st0.b.LBi, 9 - st0.b.LBj] = 0.0
+        st0["h"][12 - st0.b.LBi, 3 - st0.b.LBj] = 0.0
     out = {"pgf": int(st0.p.pgf), "EWperiodic": int(st0.b.EWperiodic)}
     r = ref.Ref(st0.copy())
     bb = r.bounds()
@@ -137,6 +140,21 @@ def main_iso(config, basin=None, mask=None):
     print(json.dumps(out))
 
 
+def shallow_edges(st):
+    """WET_DRY boundary-condition cases: a bed so shallow on stretches of the boundary rows / columns (and the two rows
+    inside) that the boundary free surface falls below Dcrit - h there (zetabc.F:733-827) while h + zeta stays
+    positive for the Chapman / Flather / Shchepetkin square roots."""
+    b = st.b
+    h = st["h"]
+    ii = np.arange(b.LBi, b.UBi + 1)[:, None] * np.ones((1, st.nj), dtype=int)
+    jj = np.arange(b.LBj, b.UBj + 1)[None, :] * np.ones((st.ni, 1), dtype=int)
+    edge = (jj <= b.Jstr + 1) | (jj >= b.Jend - 1)
+    if not b.EWperiodic:
+        edge |= (ii <= b.Istr + 1) | (ii >= b.Iend - 1)
+    stretch = ((ii // 5) % 2 == 0) & ((jj // 4) % 3 != 1)
+    h[edge & stretch] = 0.16               # zeta of prepared_state lies within +-0.13: 0 < h + zeta, zeta <= Dcrit - h on a part
+
+
 def main_bc(config, mask=None, rad2d=False):
     """The six lateral boundary-condition routines on the S/N edges, every condition the library offers, for the
     three states of the barotropic stepping (first, predictor, corrector): reference Fortran vs C oracle."""
@@ -145,6 +163,8 @@ def main_bc(config, mask=None, rad2d=False):
     from oracle import ref
     from roms_trunk_mgh_amd import abi
     st0 = util.prepared_state(config, mask=mask)
+    if util.WET:
+        shallow_edges(st0)
     st0.p.radiation_2d = int(rad2d)
     rng = np.random.default_rng(11)
     for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
@@ -192,6 +212,8 @@ def basin_state(config, mask=None):
     satisfy none of the conditions already."""
     import util
     st0 = util.prepared_state(config, overrides={"EWperiodic": False}, mask=mask)
+    if util.WET:
+        shallow_edges(st0)
     rng = np.random.default_rng(17)
     for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
         st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
@@ -283,6 +305,8 @@ def ini_cases(config, mask):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from make_golden_bc import input_state
     st0 = input_state(config, mask)
+    if util.WET:
+        shallow_edges(st0)
     rng = np.random.default_rng(23)
     st0["u"][:, :, :, 0] += 0.01 * rng.standard_normal(st0["u"][:, :, :, 0].shape)      # so that ubar, vbar change
     st0["v"][:, :, :, 0] += 0.01 * rng.standard_normal(st0["v"][:, :, :, 0].shape)
@@ -640,6 +664,10 @@ GRID2D = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", 
 
 
 if __name__ == "__main__":
+    if sys.argv[-1] == "wet":                  # ... wet: the same comparison on a WET_DRY state against the _WET builds
+        import util as _util
+        _util.WET = True
+        sys.argv.pop()
     RAD2D = len(sys.argv) > 3 and sys.argv[3] == "rad2d"      # the builds with -DRADIATION_2D (bc, bc4 modes)
     if len(sys.argv) > 2 and sys.argv[2] == "ana":
         main_ana(sys.argv[1])

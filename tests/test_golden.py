@@ -532,3 +532,86 @@ def test_analytic_setup_reproduces_reference_fields(config):
     own = (st.I(b.Istr, b.Iend), st.J(b.Jstr, b.Jend))
     want, got = g["ana__T0"][own], st["t"][:, :, :, 0, 0][own]
     assert float(np.abs(got - want).max()) <= 4e-16 * float(np.abs(want).max())
+
+
+def _wet_mod():
+    import sys
+    gd = os.path.join(HERE, "golden")
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    import make_golden_wet as mw
+    return mw
+
+
+def _wet_check(config, backend, tol, only=None):
+    mw = _wet_mod()
+    g = np.load(os.path.join(HERE, "golden", f"ref_wet_{config}_MASK.npz"))
+    seen = 0
+    for label, st, s, op in mw.kernel_cases(config):
+        if only is not None and not only(label):
+            continue
+        st0 = st.copy()
+        backend(st, s, op)
+        res = mw.results(st, st0, label)
+        want_keys = {k for k in g.files if k.startswith(label + "/")}
+        assert set(res) == want_keys, (label, sorted(set(res) ^ want_keys))
+        for k, v in res.items():
+            want = g[k]
+            if k.endswith("_sha256"):
+                if tol == 0.0:
+                    assert str(v) == str(want), k
+            else:
+                scale = max(float(np.abs(want).max()), 1e-300)
+                assert float(np.abs(v - want).max()) <= tol * scale, (k, float(np.abs(v - want).max()) / scale)
+        seen += 1
+    assert seen
+
+
+@pytest.mark.parametrize("config", ["UPWELLING", "BENCHMARK_TINY"])
+def test_oracle_reproduces_reference_wet_dry_kernels(config):
+    """WET_DRY: set_depth, prsgrd32 / prsgrd31, t3dmix2 (s / geo), uv3dmix2, t3dmix4, uv3dmix4, bulk_flux, ini_zeta +
+    ini_fields of the reference built with -DWET_DRY (tests/golden/make_golden_wet.py) vs the oracle, bit for bit."""
+    import oracle
+
+    def run(st, s, op):
+        o = oracle.Oracle(st)
+        if op == "ini":
+            o.call("ini_zeta", s)
+            o.call("ini_fields", s)
+        else:
+            o.call(op.split(":")[-1], s)
+    _wet_check(config, run, 0.0)
+
+
+def test_oracle_reproduces_reference_wet_dry_boundary_conditions():
+    """WET_DRY blocks of zetabc.F (:733-827), u2dbc_im.F (:331, :679, :1176-1293), v2dbc_im.F (:333, :682, :1169-1287),
+    u3dbc_im.F, v3dbc_im.F on a basin with shallow stretches along the edges: SHA-256 of the reference's outputs."""
+    import oracle
+    mw = _wet_mod()
+    g = np.load(os.path.join(HERE, "golden", "ref_wet_bc_UPWELLING_MASK.npz"))
+    n = 0
+    for label, kind, var, st, s, nout, itrc in mw.bc_cases("UPWELLING"):
+        oracle.Oracle(st).bc(kind, s, nout, itrc)
+        assert mw.sha(st[var]) == str(g[f"{label}/{var}_sha256"]), label
+        n += 1
+    assert n == len(g.files)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["UPWELLING", "BENCHMARK_TINY"])
+def test_hip_reproduces_reference_wet_dry_kernels(config):
+    """The same vectors against the HIP path (bit for bit but for bulk_flux, whose exp / log come from another libm)."""
+    from roms_trunk_mgh_amd import hip
+
+    def run(st, s, op):
+        h = hip.RomsHip(st)
+        try:
+            if op == "ini":
+                h.call("ini_zeta", s)
+                h.call("ini_fields", s)
+            else:
+                h.call(op.split(":")[-1], s)
+            h.to_host()
+        finally:
+            h.close()
+    _wet_check(config, run, 1e-12)

@@ -39,6 +39,8 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:
         kw.setdefault("overrides", {})["EWperiodic"] = False
+    if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
+        kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     st = ana.make_tile(config, perturb=1.0, **kw)
@@ -68,6 +70,9 @@ def _single(config, nsteps, variant=""):
                                                     # the GLS closure: smoothed shear, five-point advection of tke / gls and
                                                     # the Akv / Akt edge rule of gls_corstep.F across tile edges
                                                     (2, 2, "UPWELLING", "gls"), (2, 1, "BENCHMARK_TINY", "gls+basin+mask"),
+                                                    # WET_DRY: masks, their fast-time sum and the drying shoreline across
+                                                    # tile edges
+                                                    (2, 2, "UPWELLING", "wet"), (2, 2, "UPWELLING", "wet+basin+mask"),
                                                     # biharmonic mixing across tile edges
                                                     (2, 2, "BENCHMARK_TINY", "dif4"), (2, 2, "BENCHMARK_TINY", "dif4+basin+mask"),
                                                     # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
@@ -96,7 +101,8 @@ def test_tiled_hip_equals_single_hip(tmp_path, ntI, ntJ, config, variant):
     for r in range(world):
         d = np.load(os.path.join(tmp_path, f"tile{r}.npz"))
         Istr, Iend, Jstr, Jend, LBi, LBj = [int(x) for x in d["bounds"]]
-        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke"):
+        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke", "rmask_wet", "umask_wet",
+                     "vmask_wet", "pmask_wet", "rmask_wet_avg"):
             a = d[name]
             ni, nj = a.shape[0], a.shape[1]
             i0, j0 = LBi - rb.LBi, LBj - rb.LBj

@@ -36,6 +36,10 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:                  # no periodic direction
         kw.setdefault("overrides", {})["EWperiodic"] = False
+    if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
+        kw.setdefault("overrides", {})["gls"] = "k-epsilon"
+    if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
+        kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
     st = ana.make_tile(config, perturb=1.0, **kw)
     m = main3d.Main3D(oracle.Oracle(st))
     m.initial()
@@ -58,6 +62,9 @@ def _single(config, nsteps, variant=""):
                                                     # the GLS closure across tile edges (smoothed shear, five-point advection of
                                                     # tke / gls, the Akv / Akt edge rule of gls_corstep.F)
                                                     (2, 2, "UPWELLING", "gls"), (2, 1, "BENCHMARK_TINY", "gls+basin+mask"),
+                                                    # WET_DRY: the wet/dry masks, their fast-time sum and the drying
+                                                    # shoreline across tile edges; with land and on a basin
+                                                    (2, 2, "UPWELLING", "wet"), (2, 2, "UPWELLING", "wet+basin+mask"),
                                                     # biharmonic mixing: the first operator's one-point-wider range
                                                     # and its edge rule across tile edges, channel and basin
                                                     (2, 2, "BENCHMARK_TINY", "dif4"), (2, 2, "BENCHMARK_TINY", "dif4+basin+mask")])
@@ -76,7 +83,8 @@ def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     for r in range(world):
         d = np.load(os.path.join(tmp_path, f"tile{r}.npz"))
         Istr, Iend, Jstr, Jend, LBi, LBj = [int(x) for x in d["bounds"]]
-        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke"):
+        for name in ("zeta", "ubar", "vbar", "u", "v", "t", "Huon", "W", "Hz", "Akv", "tke", "rmask_wet", "umask_wet",
+                     "vmask_wet", "pmask_wet", "rmask_wet_avg"):
             a = d[name]
             ni, nj = a.shape[0], a.shape[1]
             # whole allocated tile (owned + ghost points) against the same index range of the single-tile run
@@ -84,7 +92,7 @@ def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
             want = ref[name][i0:i0 + ni, j0:j0 + nj]
             own = (slice(Istr - LBi, Iend - LBi + 1), slice(Jstr - LBj, Jend - LBj + 1))
             assert np.array_equal(a[own], want[own]), (name, r, float(np.abs(a[own] - want[own]).max()))
-            if name in ("zeta", "t", "Hz", "W"):      # rho-type: every ghost point is defined
+            if name in ("zeta", "t", "Hz", "W", "rmask_wet"):      # rho-type: every ghost point is defined
                 # (not the reference's spare padding column/row of even-sized grids, Im=Lm+1/Jm=Mm+1)
                 iv = min(ni, rb.Lm + rb.NghostPoints - LBi + 1)
                 jv = min(nj, rb.Mm + 1 - LBj + 1)

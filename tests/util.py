@@ -13,12 +13,61 @@ def step_idx(iic=3, ntfirst=1, nstp=1, nnew=2, nrhs=1, kstp=1, krhs=1, knew=2, i
                        krhs=krhs, knew=knew, iif=iif, predictor_2d_step=pred)
 
 
-def prepared_state(config, seed=1, NT=None, overrides=None, oracle_backend=None, mask=None):
+# WET = True (set by tests/ref_worker.py "... wet" and by the WET_DRY tests): prepared_state builds a WET_DRY state --
+# wet_dry = 1 and synthetic wet/dry masks of the general (fast-step) kind, which hold every value the reference's
+# wetdry_mask_tile can produce (0, 1, 2 and -1 / 1 on one-sided faces)
+WET = False
+
+
+def synthetic_wet_masks(st, seed=5):
+    """Wet/dry masks from a seeded rho-point flag (dry blobs, single dry cells, dry stretches along the edges) by the
+    rules of wetdry.F:563-716 restated on whole arrays; independent of the oracle's loops."""
+    b = st.b
+    rng = np.random.default_rng(seed)
+    ii = np.arange(b.LBi, b.UBi + 1, dtype=np.float64)[:, None]
+    jj = np.arange(b.LBj, b.UBj + 1, dtype=np.float64)[None, :]
+    iw = np.mod(ii - 1.0, b.Lm) + 1.0 if b.EWperiodic else ii
+    wd = np.ones((st.ni, st.nj))
+    for ic, jc, r in ((0.3 * b.Lm, 0.7 * b.Mm, 3.2), (0.8 * b.Lm, 0.25 * b.Mm, 2.4), (0.55 * b.Lm, b.Mm + 0.5, 4.0),
+                      (0.15 * b.Lm, 0.5, 3.0), (1.0, 0.5 * b.Mm, 2.5), (b.Lm, 0.8 * b.Mm, 2.2)):
+        wd[(iw - ic) ** 2 + (jj - jc) ** 2 <= r * r] = 0.0
+    glob = rng.random((b.Lm + 8, b.Mm + 8)) < 0.03            # lone dry cells: a function of the global indices
+    wd[glob[(iw.astype(int) + 3) % (b.Lm + 8), (jj.astype(int) + 3) % (b.Mm + 8)]] = 0.0
+    wd *= st["rmask"]
+    m, s = slice(0, -1), slice(1, None)
+    um = np.zeros_like(wd)
+    vm = np.zeros_like(wd)
+    um[s, :] = wd[m, :] + wd[s, :]
+    um[s, :] = np.where(um[s, :] == 1.0, wd[m, :] - wd[s, :], um[s, :])
+    vm[:, s] = wd[:, m] + wd[:, s]
+    vm[:, s] = np.where(vm[:, s] == 1.0, wd[:, m] - wd[:, s], vm[:, s])
+    a, bq, c, d = wd[m, s] > 0.5, wd[s, s] > 0.5, wd[m, m] > 0.5, wd[s, m] > 0.5
+    nwet = a.astype(int) + bq.astype(int) + c.astype(int) + d.astype(int)
+    side = (a & c & ~bq & ~d) | (bq & d & ~a & ~c) | (a & bq & ~c & ~d) | (c & d & ~a & ~bq)
+    pm = np.zeros_like(wd)
+    pm[s, s] = np.where(nwet >= 3, 1.0, np.where((nwet == 2) & side, 2.0, 0.0))
+    st["rmask_wet"][:] = wd
+    st["umask_wet"][:] = um
+    st["vmask_wet"][:] = vm
+    st["pmask_wet"][:] = pm
+    st["rmask_full"][:] = wd * st["rmask"]
+    st["umask_full"][:] = um * st["umask"]
+    st["vmask_full"][:] = vm * st["vmask"]
+    st["pmask_full"][:] = np.maximum(pm * st["pmask"], 2.0)
+    return wd
+
+
+def prepared_state(config, seed=1, NT=None, overrides=None, oracle_backend=None, mask=None, wet=None):
     """A tile state with non-trivial velocities, fluxes, RHS terms and tracers at
     all time levels.  Deterministic (seeded).  mask = "island": a MASKING grid (ana.island_mask); the
     prognostic fields are then zero on land, as the reference keeps them."""
     import oracle
+    wet = WET if wet is None else wet
+    if wet:
+        overrides = dict(overrides or {}, wet_dry=1)
     st = ana.make_tile(config, perturb=1.0, NT=NT, overrides=overrides, mask=mask)
+    if wet:
+        synthetic_wet_masks(st)
     b = st.b
     rng = np.random.default_rng(seed)
     Lm, Mm, N = b.Lm, b.Mm, b.N
