@@ -177,7 +177,8 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
     const long lo = B - (we ? 1 : ni), qi = hi ? lo : B, qo = hi ? B : lo;     // rho-points inside / outside
     const double Co = 1.0 / (2.0 + sqrt(2.0));      // mod_scalars.F:4175
     const double bry_val = a.D[B];
-    const double cff = 0.5 * (c->F.h[lo] + c->F.h[B]);
+    // WET_DRY: the total depth instead of the resting one (u2dbc_im.F:331-340, :679-688; v2dbc_im.F:333, :682)
+    const double cff = p.wet_dry ? 0.5 * (c->F.h[lo] + a.Z[lo] + c->F.h[B] + a.Z[B]) : 0.5 * (c->F.h[lo] + c->F.h[B]);
     const double cff1 = sqrt(p.g / cff);
     const double Cn = a.dt2d * cff1 * cff * 0.5 * (pmn[lo] + pmn[B]);
     double Zx = (0.5 + Cn) * a.Z[qi] + (0.5 - Cn) * a.Z[qo];
@@ -228,7 +229,58 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
     const double *M = utype ? c->F.umask : (vtype ? c->F.vmask : c->F.rmask);
     x = x * M[B];
   }
+  // WET_DRY, 3-D momentum: the wet/dry mask after every land/sea-mask product of u3dbc_im.F / v3dbc_im.F (:174 ...
+  // :681) -- but for u on a southern gradient edge, whose block tests a symbol no header defines (u3dbc_im.F:496)
+  if (p.wet_dry && a.masked == 1 && (a.var == LBV_U || a.var == LBV_V) && !(normal && code == LBC_CLOSED) &&
+      !(a.var == LBV_U && side == LBS_SOUTH && code == LBC_GRADIENT))
+    x = x * (a.var == LBV_U ? c->F.umask_wet : c->F.vmask_wet)[B];
   X[B] = x;
+}
+
+// WET_DRY: what zetabc.F:733-827, u2dbc_im.F:1176-1293 and v2dbc_im.F:1169-1287 do after their edges and corners.
+// One thread per boundary point; blockIdx.y = 0..3 the edges (ranges as written in the reference), 4 the corners.
+//   zeta: a boundary free surface at or below Dcrit - h is lifted to (Dcrit - 1e-20) - h
+//   ubar / vbar: times the wet/dry factor of the boundary face.  As written, the northern edge of ubar starts at Istr
+//   where the southern one starts at IstrU, and the western edge of vbar takes its factor from the boundary point
+//   (Istr-1,j) and applies it to the first interior point (Istr,j).
+__global__ void k_wet_bc2d(const RomsDev *__restrict__ c, double *__restrict__ X, int var)
+{
+  DEV_PROLOGUE(c)
+  const roms_params_t &p = c->p;
+  const int side = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ew = !b.EWperiodic, ns = !b.NSperiodic;
+  int i, j, it, jt;                                    // (i,j): the point whose mask and value decide; (it,jt): the target
+  if (side == 4) {
+    if (!(ew && ns) || t >= 4) return;
+    const bool south = t < 2, west = (t & 1) == 0;
+    if (!((south ? b.south_edge : b.north_edge) && (west ? b.west_edge : b.east_edge))) return;
+    if (var == LBV_UBAR && !south && west) return;     // (Istr,Jend+1): the northern edge's range holds it already
+    i = west ? (var == LBV_UBAR ? b.Istr : b.Istr - 1) : b.Iend + 1;
+    j = south ? (var == LBV_VBAR ? b.Jstr : b.Jstr - 1) : b.Jend + 1;
+    it = i; jt = j;
+  } else if (side <= LBS_EAST) {
+    if (!ew || !(side == LBS_WEST ? b.west_edge : b.east_edge)) return;
+    j = (var == LBV_VBAR ? b.JstrV : b.Jstr) + t;
+    if (j > b.Jend) return;
+    i = side == LBS_EAST ? b.Iend + 1 : (var == LBV_UBAR ? b.Istr : b.Istr - 1);
+    it = (var == LBV_VBAR && side == LBS_WEST) ? b.Istr : i;       // v2dbc_im.F:1180-1185
+    jt = j;
+  } else {
+    if (!ns || !(side == LBS_SOUTH ? b.south_edge : b.north_edge)) return;
+    i = ((var == LBV_UBAR && side == LBS_SOUTH) ? b.IstrU : b.Istr) + t;
+    if (i > b.Iend) return;
+    j = side == LBS_NORTH ? b.Jend + 1 : (var == LBV_VBAR ? b.Jstr : b.Jstr - 1);
+    it = i; jt = j;
+  }
+  const long q = I2(i, j), qt = I2(it, jt);
+  if (var == LBV_ZETA) {
+    const double eps = 1.0E-20, cff = p.Dcrit - eps;
+    if (X[q] <= (p.Dcrit - c->F.h[q])) X[q] = cff - c->F.h[q];
+  } else {
+    const double *W = var == LBV_UBAR ? c->F.umask_wet : c->F.vmask_wet;
+    X[qt] = X[qt] * wet_factor(W[q], X[q]);
+  }
 }
 
 // corners when neither direction is periodic, e.g. zetabc.F:699-731: the mean of the two neighbouring boundary
@@ -261,6 +313,10 @@ static int edge_bc(BcArgs a)
     const int gtype = (a.var == LBV_UBAR || a.var == LBV_U) ? GT_U : (a.var == LBV_VBAR || a.var == LBV_V) ? GT_V : GT_R;
     hipLaunchKernelGGL(k_corner_bc, dim3((a.nk + 63) / 64, 4), dim3(64), 0, g_ctx.stream, g_ctx.devc, a.X, gtype, a.nk);
     KERNEL_CHECK("k_corner_bc");
+  }
+  if (g_ctx.p.wet_dry && a.masked == 1 && a.var >= LBV_ZETA && a.var <= LBV_VBAR) {
+    hipLaunchKernelGGL(k_wet_bc2d, dim3((nmax + 255) / 256, 5), dim3(256), 0, g_ctx.stream, g_ctx.devc, a.X, a.var);
+    KERNEL_CHECK("k_wet_bc2d");
   }
   return 0;
 }
@@ -541,7 +597,11 @@ k_set_depth(const RomsDev *__restrict__ c)
   if (i > b.IendT || j > b.JendT) return;
   const roms_params_t &p = c->p;
   const double hc = p.hc;
-  const double hwater = GF(h)[I2(i, j)];
+  double hwater = GF(h)[I2(i, j)];
+  if (p.wet_dry && hwater == 0.0) {                 // WET_DRY, set_depth.F:168-172 / :216-220: h itself is changed
+    hwater = 1.0E-14;
+    GF(h)[I2(i, j)] = hwater;
+  }
   const double zt = GF(Zt_avg1)[I2(i, j)];
   const gd_t z_w = (gd_t)(c->F.z_w);
   const gd_t z_r = (gd_t)(c->F.z_r);

@@ -21,6 +21,7 @@ __global__ void k_ini_zeta(const RomsDev *__restrict__ c, IniArgs a)
   if (i >= a.i0 && i <= a.i1 && j >= a.j0 && j <= a.j1) {
     double cff1 = c->F.zeta[q + (long)(a.kstp - 1) * nij];
     if (c->p.masking) cff1 = cff1 * c->F.rmask[q];
+    if (c->p.wet_dry && cff1 <= (c->p.Dcrit - c->F.h[q])) cff1 = c->p.Dcrit - c->F.h[q];   // WET_DRY, ini_fields.F:951-957
     c->F.zeta[q + (long)(a.kstp - 1) * nij] = cff1;
     c->F.zeta[q + (long)(a.knew - 1) * nij] = cff1;
   }
@@ -41,7 +42,7 @@ __global__ void k_ini_3d(const RomsDev *__restrict__ c, IniArgs a)
   if (i > b.IendB || j > b.JendB) return;
   const bool mk = c->p.masking != 0;
   const long q = I2(i, j);
-  const double mu = mk ? c->F.umask[q] : 1.0, mv = mk ? c->F.vmask[q] : 1.0, mr = mk ? c->F.rmask[q] : 1.0;
+  const double mu = mk ? umaskw(c, q) : 1.0, mv = mk ? vmaskw(c, q) : 1.0, mr = mk ? c->F.rmask[q] : 1.0;   // (+ WET_DRY, ini_fields.F:292, :307)
   const bool do_u = i >= b.IstrM, do_v = j >= b.JstrM;
   for (int k = 1; k <= N; k++) {
     const long q3 = I3(i, j, k);
@@ -84,7 +85,7 @@ __global__ void k_ini_bar(const RomsDev *__restrict__ c, IniArgs a)
     }
     const double cff1 = 1.0 / DC0;
     double cff2 = CF0 * cff1;
-    if (mk) cff2 = cff2 * c->F.umask[q];
+    if (mk) cff2 = cff2 * umaskw(c, q);               // (+ WET_DRY, ini_fields.F:398)
     c->F.ubar[q + (long)(a.kstp - 1) * nij] = cff2;
     c->F.ubar[q + (long)(a.knew - 1) * nij] = cff2;
   }
@@ -97,7 +98,7 @@ __global__ void k_ini_bar(const RomsDev *__restrict__ c, IniArgs a)
     }
     const double cff1 = 1.0 / DC0;
     double cff2 = CF0 * cff1;
-    if (mk) cff2 = cff2 * c->F.vmask[q];
+    if (mk) cff2 = cff2 * vmaskw(c, q);               // (+ WET_DRY, ini_fields.F:423)
     c->F.vbar[q + (long)(a.kstp - 1) * nij] = cff2;
     c->F.vbar[q + (long)(a.knew - 1) * nij] = cff2;
   }

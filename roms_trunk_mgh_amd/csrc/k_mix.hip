@@ -84,8 +84,8 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   double mx0 = 0.5 * (pm[c0] + pm[c0 - 1]), mx1 = 0.5 * (pm[c0 + 1] + pm[c0]);
   double my0 = 0.5 * (pn[c0] + pn[c0 - ni]), my1 = 0.5 * (pn[c0 + ni] + pn[c0]);
   if (c->p.masking) {                                     // MASKING, t3dmix2_geo.h:228, :260
-    mx0 = mx0 * c->F.umask[c0]; mx1 = mx1 * c->F.umask[c0 + 1];
-    my0 = my0 * c->F.vmask[c0]; my1 = my1 * c->F.vmask[c0 + ni];
+    mx0 = mx0 * umaskw(c, c0); mx1 = mx1 * umaskw(c, c0 + 1);          // (+ WET_DRY, :231, :263)
+    my0 = my0 * vmaskw(c, c0); my1 = my1 * vmaskw(c, c0 + ni);
   }
   const double cfx0 = 0.25 * (d2[c0] + d2[c0 - 1]) * c->F.on_u[c0];
   const double cfx1 = 0.25 * (d2[c0 + 1] + d2[c0]) * c->F.on_u[c0 + 1];
@@ -225,8 +225,9 @@ k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
   const double cfe1 = 0.25 * (d2[c0 + ni] + d2[c0]) * c->F.pnom_v[c0 + ni];
   const double cdt = c->p.dt * c->F.pm[c0] * c->F.pn[c0];
   const bool masking = c->p.masking != 0;                 // MASKING, t3dmix2_s.h:235, :275
-  const double um0 = masking ? c->F.umask[c0] : 1.0, um1 = masking ? c->F.umask[c0 + 1] : 1.0;
-  const double vm0 = masking ? c->F.vmask[c0] : 1.0, vm1 = masking ? c->F.vmask[c0 + ni] : 1.0;
+  // (WET_DRY: times the wet/dry mask of the face, the block after each MASKING block of t3dmix2_s.h / t3dmix4_s.h)
+  const double um0 = masking ? umaskw(c, c0) : 1.0, um1 = masking ? umaskw(c, c0 + 1) : 1.0;
+  const double vm0 = masking ? vmaskw(c, c0) : 1.0, vm1 = masking ? vmaskw(c, c0 + ni) : 1.0;
   for (int k = 1; k <= N; k++) {
     const long ck = c0 + (long)(k - 1) * nij;
     const double t0 = T[ck], h0 = Hz[ck];
@@ -265,8 +266,9 @@ k_t3dmix4_s(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   double cfe0 = 0.25 * (d4[c0] + d4[c0 - ni]) * c->F.pnom_v[c0];
   double cfe1 = 0.25 * (d4[c0 + ni] + d4[c0]) * c->F.pnom_v[c0 + ni];
   const bool masking = c->p.masking != 0;
-  const double um0 = masking ? c->F.umask[c0] : 1.0, um1 = masking ? c->F.umask[c0 + 1] : 1.0;
-  const double vm0 = masking ? c->F.vmask[c0] : 1.0, vm1 = masking ? c->F.vmask[c0 + ni] : 1.0;
+  // (WET_DRY: times the wet/dry mask of the face, the block after each MASKING block of t3dmix2_s.h / t3dmix4_s.h)
+  const double um0 = masking ? umaskw(c, c0) : 1.0, um1 = masking ? umaskw(c, c0 + 1) : 1.0;
+  const double vm0 = masking ? vmaskw(c, c0) : 1.0, vm1 = masking ? vmaskw(c, c0 + ni) : 1.0;
   if (MODE == 1 && masking) {                            // the first operator masks the coefficient, :296, :326
     cfx0 = cfx0 * um0; cfx1 = cfx1 * um1; cfe0 = cfe0 * vm0; cfe1 = cfe1 * vm1;
   }

@@ -162,7 +162,7 @@ enum { Q_TA = 0, Q_GU, Q_GV, Q_HU, Q_HV, Q_ZU, Q_DZ, Q_WC, Q_ZL, Q_N };
 struct MpCol {          // level-independent part of a column
   long a2;              // index in a 2-D array
   long dW, dS;          // distance to the western / southern neighbour (0 where that would leave the array: value unused)
-  double PMU, PNU, PMV, PNV, pm, pn, um, vm;
+  double PMU, PNU, PMV, PNV, pm, pn, um, vm, umw, vmw;
   bool ok;              // the column lies inside LBi:UBi, LBj:UBj
 };
 
@@ -187,8 +187,10 @@ __device__ __forceinline__ MpCol mp_column(const RomsDev *__restrict__ c, int i,
   const double pmW = pm[cc.a2 - cc.dW], pnW = pn[cc.a2 - cc.dW], pmS = pm[cc.a2 - cc.dS], pnS = pn[cc.a2 - cc.dS];
   cc.PMU = pmW + cc.pm; cc.PNU = pnW + cc.pn;
   cc.PMV = cc.pm + pmS; cc.PNV = cc.pn + pnS;
-  cc.um = 1.0; cc.vm = 1.0;
-  if constexpr (MASK) { cc.um = GF(umask)[cc.a2]; cc.vm = GF(vmask)[cc.a2]; }
+  cc.um = 1.0; cc.vm = 1.0; cc.umw = 1.0; cc.vmw = 1.0;
+  // umw / vmw: the face masks of the limited velocities, times the wet/dry mask under WET_DRY (mpdata_adiff.F:394-399,
+  // :567-572); um / vm: the land/sea masks alone, as the gradients of the cross terms take them
+  if constexpr (MASK) { cc.um = GF(umask)[cc.a2]; cc.vm = GF(vmask)[cc.a2]; cc.umw = umaskw(c, cc.a2); cc.vmw = vmaskw(c, cc.a2); }
   return cc;
 }
 
@@ -356,7 +358,7 @@ k_mp_adiff(const RomsDev *__restrict__ c, MpArgs m)
   if (do_u) ONV4 = on_v[a2] + on_v[a2 + ni] + on_v[a2 - 1] + on_v[a2 - 1 + ni];
   if (do_v) OMU4 = om_u[a2] + om_u[a2 + 1] + om_u[a2 - ni] + om_u[a2 + 1 - ni];
   if (do_w) { OMU2 = om_u[a2 + 1] + om_u[a2]; ONV2 = on_v[a2 + ni] + on_v[a2]; }
-  if constexpr (MASK) { if (inr) rm = GF(rmask)[a2]; }
+  if constexpr (MASK) { if (inr) rm = rmaskw(c, a2); }           // Wa's mask (+ WET_DRY, mpdata_adiff.F:800-805)
   // faces on a physical edge, mpdata_adiff.F:577-640: zero (closed) or the value of the next face inside, which the
   // thread of that face stores
   const bool v_wall_n = b.north_edge && !b.NSperiodic && j == b.Jend + 1;
@@ -578,10 +580,13 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
   const bool v1_wall = b.north_edge && !b.NSperiodic && j == b.Jend;       // Va(i,Jend+1)
   const bool u0_wall = b.west_edge && !b.EWperiodic && i == b.Istr;        // Ua(Istr,j)
   const bool u1_wall = b.east_edge && !b.EWperiodic && i == b.Iend;        // Ua(Iend+1,j)
-  double um0 = 1.0, um1 = 1.0, vm0 = 1.0, vm1 = 1.0, rm0 = 1.0;
+  double um0 = 1.0, um1 = 1.0, vm0 = 1.0, vm1 = 1.0, rm0 = 1.0, rw0 = 1.0;
   double muq[4] = {1.0, 1.0, 1.0, 1.0}, muh[4] = {1.0, 1.0, 1.0, 1.0}, mu0h = 1.0;
   if constexpr (MASK) {
-    um0 = GF(umask)[a2c]; um1 = GF(umask)[a2c + 1]; vm0 = GF(vmask)[a2c]; vm1 = GF(vmask)[a2c + ni]; rm0 = GF(rmask)[a2c];
+    // the masks of the limited transports (:991, :1006, :1022), times the wet/dry masks under WET_DRY (:993, :1008, :1024);
+    // rm0 alone for the extrema and for the new tracer
+    um0 = umaskw(c, a2c); um1 = umaskw(c, a2c + 1); vm0 = vmaskw(c, a2c); vm1 = vmaskw(c, a2c + ni); rm0 = GF(rmask)[a2c];
+    rw0 = rmaskw(c, a2c);
     const gcd_t rmk = (gcd_t)c->F.rmask;
     const long a2hc = halo ? a2h : a2c;
     mu0h = rmk[a2hc];
@@ -712,7 +717,7 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
           const double c1 = fmin(fmin(bdn_p, bup), 1.0);
           const double c2 = fmin(fmin(bup_p, bdn), 1.0);
           double w = (c1 * fmax(0.0, wadn) + c2 * fmin(0.0, wadn)) * cffa * omn * (zr - zr_p);
-          if constexpr (MASK) w = w * rm0;
+          if constexpr (MASK) w = w * rw0;
           FCadv_p = fmax(w, 0.0) * T_p + fmin(w, 0.0) * T0;
         }
       }

@@ -167,7 +167,7 @@ k_bulk_flux(const RomsDev *__restrict__ c, int nrhs, double *__restrict__ Taux, 
   double cff1 = cff2 * TairK;
   // MASKING (bulk_flux.F:486, :790, :809, :824, :831, :877): the five fluxes and stflux times rmask; mr = 1 without
   const bool masking = c->p.masking != 0;
-  const double mr = masking ? (double)GF(rmask)[a] : 1.0;
+  const double mr = masking ? rmaskw(c, a) : 1.0;               // (+ WET_DRY: the block after each of them)
   double LRad = -emmiss * StefBo *
                 (cff1 * (0.39 - 0.05 * sqrt(vap_p)) * (1.0 - 0.6823 * cl * cl) + cff2 * 4.0 * (TseaK - TairK));
   if (masking) LRad = LRad * mr;
@@ -289,11 +289,11 @@ k_bulk_stress(const RomsDev *__restrict__ c, const double *__restrict__ Taux, co
   const bool masking = c->p.masking != 0;                          // bulk_flux.F:908, :919
   if (i >= b.Istr) {
     const double su = cff * (Taux[a - 1] + Taux[a]);
-    GF(sustr)[a] = masking ? su * GF(umask)[a] : su;
+    GF(sustr)[a] = masking ? su * umaskw(c, a) : su;          // (+ WET_DRY, :911)
   }
   if (j >= b.Jstr) {
     const double sv = cff * (Tauy[a - ni] + Tauy[a]);
-    GF(svstr)[a] = masking ? sv * GF(vmask)[a] : sv;
+    GF(svstr)[a] = masking ? sv * vmaskw(c, a) : sv;          // (+ WET_DRY, :922)
   }
 }
 

@@ -70,6 +70,8 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
   const gcd_t ghats = (gcd_t)(c->F.ghats + (long)((itrc <= b.NAT ? itrc : 1) - 1) * n3w);
   const gcd_t AktN = (gcd_t)(c->F.Akt + (long)((itrc <= b.NAT ? itrc : 1) - 1) * n3w);   // Akt(..,itrc) of the non-local term
   const double srf = GF(srflx)[c0];
+  // dt*srflx [*rmask_wet under WET_DRY, pre_step3d.F:873-878] -- the product the reference forms first, left to right
+  const double dsrf = c->p.wet_dry ? (dt * srf) * GF(rmask_wet)[c0] : dt * srf;
   const double zwN = z_w[c0 + (long)N * nij];
   const double fac1 = -1.0 / p.swfrac_mu1, fac2 = -1.0 / p.swfrac_mu2, fac3 = p.swfrac_r1;
 
@@ -190,7 +192,7 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
       if (solar) {
         const double Z = zwN - z_w[ck + nij];
         const double swdk = exp(Z * fac1) * fac3 + exp(Z * fac2) * (1.0 - fac3);
-        FDk = FDk + dt * srf * swdk;
+        FDk = FDk + dsrf * swdk;
       }
     }
     tn[ck] = hz * tk + (FDk - FDprev);

@@ -118,11 +118,13 @@ k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrh
     const double dZx0 = harm_inv(aux_0, aux_p1, eps), dZxm = harm_inv(aux_m1, aux_0, eps);
     const double dRx0 = harm_inv(FC_0, FC_p1, eps), dRxm = harm_inv(FC_m1, FC_0, eps);
     const gd_t ru = (gd_t)(c->F.ru + (long)(nrhs - 1) * n3w);
-    ru[I3W(i, j, k)] = GF(on_u)[I2(i, j)] * 0.5 * (hz0 + Hz[ck - 1]) *
+    double r = GF(on_u)[I2(i, j)] * 0.5 * (hz0 + Hz[ck - 1]) *
         (P[ck - 1] - P0 -
          HalfGRho * ((r0 + rm1) * (z0 - zm1) -
                      OneFifth * ((dRx0 - dRxm) * (z0 - zm1 - OneTwelfth * (dZx0 + dZxm)) -
                                  (dZx0 - dZxm) * (r0 - rm1 - OneTwelfth * (dRx0 + dRxm)))));
+    if (c->p.wet_dry) r = r * GF(umask_wet)[I2(i, j)];      // WET_DRY, prsgrd32.h:346-348
+    ru[I3W(i, j, k)] = r;
   }
   if (j >= b.JstrV) {
     const double rm1 = rho[ck - ni], rp1 = rho[ck + ni];
@@ -141,11 +143,13 @@ k_prsgrd_uv(const RomsDev *__restrict__ c, const double *__restrict__ P, int nrh
     const double dZx0 = harm_inv(aux_0, aux_p1, eps), dZxm = harm_inv(aux_m1, aux_0, eps);
     const double dRx0 = harm_inv(FC_0, FC_p1, eps), dRxm = harm_inv(FC_m1, FC_0, eps);
     const gd_t rv = (gd_t)(c->F.rv + (long)(nrhs - 1) * n3w);
-    rv[I3W(i, j, k)] = GF(om_v)[I2(i, j)] * 0.5 * (hz0 + Hz[ck - ni]) *
+    double r = GF(om_v)[I2(i, j)] * 0.5 * (hz0 + Hz[ck - ni]) *
         (P[ck - ni] - P0 -
          HalfGRho * ((r0 + rm1) * (z0 - zm1) -
                      OneFifth * ((dRx0 - dRxm) * (z0 - zm1 - OneTwelfth * (dZx0 + dZxm)) -
                                  (dZx0 - dZxm) * (r0 - rm1 - OneTwelfth * (dRx0 + dRxm)))));
+    if (c->p.wet_dry) r = r * GF(vmask_wet)[I2(i, j)];      // WET_DRY, prsgrd32.h:410-412
+    rv[I3W(i, j, k)] = r;
   }
 }
 
@@ -169,6 +173,9 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y) k_prsgrd31(const RomsDev *__rest
   const double fac1 = 0.5 * g / rho0, fac2 = 1000.0 * g / rho0, fac3 = 0.25 * g / rho0;
   const long a = I2(i, j), aw = do_u ? a - 1 : a, as = do_v ? a - ni : a;   // neighbours only where they are used
   const double onu = GF(on_u)[a], omv = GF(om_v)[a];
+  // WET_DRY: each stored term times the wet/dry mask of its face (prsgrd31.h:223, :269, :304, :350)
+  const bool wet = c->p.wet_dry != 0;
+  const double uw = wet ? (double)GF(umask_wet)[a] : 1.0, vw = wet ? (double)GF(vmask_wet)[a] : 1.0;
   // surface level, :196-226 and :276-306
   long q = a + (long)(N - 1) * nij, qw = aw + (long)(N - 1) * nij, qs = as + (long)(N - 1) * nij;
   double r1 = rho[q], z1 = z_r[q], r1w = rho[qw], z1w = z_r[qw], r1s = rho[qs], z1s = z_r[qs];
@@ -183,8 +190,8 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y) k_prsgrd31(const RomsDev *__rest
     phie = fac1 * (r1 - r1s) * cff1e;
     phie = phie + (fac2 + fac1 * (r1 + r1s)) * (zw0 - zws);
     const double hz = Hz[q];
-    if (do_u) ru[I3W(i, j, N)] = -0.5 * (hz + Hz[qw]) * phix * onu;
-    if (do_v) rv[I3W(i, j, N)] = -0.5 * (hz + Hz[qs]) * phie * omv;
+    if (do_u) { const double r = -0.5 * (hz + Hz[qw]) * phix * onu; ru[I3W(i, j, N)] = wet ? r * uw : r; }
+    if (do_v) { const double r = -0.5 * (hz + Hz[qs]) * phie * omv; rv[I3W(i, j, N)] = wet ? r * vw : r; }
   }
   // interior: differentiate, then integrate downwards, :232-268 and :312-352
   auto jac = [&](double rk1, double rk1m, double rk, double rkm, double zk1, double zk1m, double zk, double zkm) {
@@ -213,8 +220,8 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y) k_prsgrd31(const RomsDev *__rest
     const double hz = Hz[q], hzw = Hz[qw], hzs = Hz[qs];
     phix = phix + jac(r1, r1w, r0, r0w, z1, z1w, z0, z0w);
     phie = phie + jac(r1, r1s, r0, r0s, z1, z1s, z0, z0s);
-    if (do_u) ru[I3W(i, j, k)] = -0.5 * (hz + hzw) * phix * onu;
-    if (do_v) rv[I3W(i, j, k)] = -0.5 * (hz + hzs) * phie * omv;
+    if (do_u) { const double r = -0.5 * (hz + hzw) * phix * onu; ru[I3W(i, j, k)] = wet ? r * uw : r; }
+    if (do_v) { const double r = -0.5 * (hz + hzs) * phie * omv; rv[I3W(i, j, k)] = wet ? r * vw : r; }
     r1 = r0; z1 = z0; r1w = r0w; z1w = z0w; r1s = r0s; z1s = z0s;
   }
 }
@@ -270,6 +277,9 @@ extern "C" int roms_hip_prsgrd(const roms_step_idx_t *s)
   ScopedTimer tm("prsgrd");
   const roms_bounds_t &b = g_ctx.b;
   if (g_ctx.p.pgf == PGF_PJ_GRADP) {
+    // the reference does not compile PJ_GRADP with WET_DRY (prsgrd40.h:98-100 passes umask_wet, vmask_wet to a
+    // routine that does not declare them): refused
+    if (g_ctx.p.wet_dry) return roms_fail("roms_hip_prsgrd", "PJ_GRADP with WET_DRY does not exist in the reference");
     hipLaunchKernelGGL(k_prsgrd40, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
                        g_ctx.devc, s->nrhs);
     KERNEL_CHECK("k_prsgrd40");

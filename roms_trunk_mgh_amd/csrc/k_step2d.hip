@@ -236,8 +236,112 @@ __device__ __forceinline__ void zeta_point(const RomsDev *__restrict__ c, const 
     zw = cff5 * zn + cff4 * zk[a];
   }
   if (write_scratch) { zeta_new[o] = zn; zwrk[o] = zw; }
-  if (write_zeta) GF(zeta)[o + (long)(s.knew - 1) * nij] = zn;
+  // WET_DRY && MASKING, :863-866: the shared array (not zeta_new) keeps the total depth of a land cell at Dcrit
+  if (write_zeta)
+    GF(zeta)[o + (long)(s.knew - 1) * nij] = (p.wet_dry && p.masking) ? zn + (p.Dcrit - GF(h)[a]) * (1.0 - GF(rmask)[a]) : zn;
   if (write_rzeta && s.predictor) GF(rzeta)[o + (long)(s.krhs - 1) * nij] = rhs;
+}
+
+// ---------------------------------------------------------------------------
+// WET_DRY: wetdry_tile (wetdry.F:93-393), called by every step2d with zeta(:,:,kstp) after the fast-time averaging
+// (step2d_LF_AM3.h:729-749), and wetdry_ini_tile (:395-561).  One thread per point of (IstrR:IendR,JstrR:JendR); the
+// rho-point flag "sea and total depth above Dcrit" (:190-200) of the point and of its three lower neighbours is
+// evaluated in registers (the reference's private array `wetdry`), so the masks need no second pass:
+//   mode 0  a fast step (iif <= nfast): wetdry_mask_tile (:563-716) -- u / v masks 2 / 0 / +-1, and the running sum
+//           rmask_wet_avg (:214-227; `first` = the first predictor of the loop: the sum starts)
+//   mode 1  after the loop (iif = nfast+1): the flag is AINT(rmask_wet_avg / (2 nfast)), wetdry_avg_mask_tile
+//           (:734-917) with DU_avg1, DV_avg1, and the full masks (:325-345)
+//   mode 2  wetdry_ini_tile: the flag from zeta(Tindex), wetdry_avg_mask_tile with ubar, vbar(Tindex), full masks
+// The caller exchanges the masks afterwards, as the reference does.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k2d_wetdry(const RomsDev *__restrict__ c, int mode, int first, int kstp)
+{
+  DEV_PROLOGUE(c)
+  const int i = b.IstrR + blockIdx.x * BLK_X + threadIdx.x;
+  const int j = b.JstrR + blockIdx.y * BLK_Y + threadIdx.y;
+  if (i > b.IendR || j > b.JendR) return;
+  const roms_params_t &p = c->p;
+  const long a = I2(i, j);
+  const gcd_t zk = (gcd_t)(c->F.zeta + (long)(kstp - 1) * nij);
+  const gcd_t h = (gcd_t)c->F.h, rmask = (gcd_t)c->F.rmask, avg = (gcd_t)c->F.rmask_wet_avg;
+  const double eps = 1.0E-10;
+  const double cffa = 1.0 / (double)(2 * p.nfast);
+  auto flag = [&](long q) -> double {
+    if (mode == 1) return trunc(avg[q] * cffa);
+    double w = 1.0;
+    if (p.masking) w = w * rmask[q];
+    if ((zk[q] + h[q]) <= (p.Dcrit + eps)) w = 0.0;
+    return w;
+  };
+  const bool inU = i >= b.Istr, inV = j >= b.Jstr;       // i-1 / j-1 exist in the flag's range (Istr-1:IendR,Jstr-1:JendR)
+  const double w0 = flag(a);
+  const double wW = inU ? flag(a - 1) : 0.0, wS = inV ? flag(a - ni) : 0.0, wSW = (inU && inV) ? flag(a - 1 - ni) : 0.0;
+  GF(rmask_wet)[a] = w0;
+  if (mode == 0) GF(rmask_wet_avg)[a] = first ? w0 : GF(rmask_wet_avg)[a] + w0;
+  double um = 0.0, vm = 0.0;
+  if (inU) {
+    double cff1 = wW + w0;
+    if (cff1 == 1.0) cff1 = wW - w0;
+    um = cff1;
+    if (mode != 0) {
+      const double DU = mode == 1 ? (double)GF(DU_avg1)[a] : (double)GF(ubar)[a + (long)(kstp - 1) * nij];
+      const double cff5 = fabs(fabs(cff1) - 1.0);
+      const double cff6 = 0.5 + copysign(0.5, DU) * cff1;
+      um = 0.5 * cff1 * cff5 + cff6 * (1.0 - cff5);
+      if (DU == 0.0 && (wW + w0) <= 1.0) um = 0.0;       // catch lone ponds
+    }
+    GF(umask_wet)[a] = um;
+  }
+  if (inV) {
+    double cff1 = wS + w0;
+    if (cff1 == 1.0) cff1 = wS - w0;
+    vm = cff1;
+    if (mode != 0) {
+      const double DV = mode == 1 ? (double)GF(DV_avg1)[a] : (double)GF(vbar)[a + (long)(kstp - 1) * nij];
+      const double cff5 = fabs(fabs(cff1) - 1.0);
+      const double cff6 = 0.5 + copysign(0.5, DV) * cff1;
+      vm = 0.5 * cff1 * cff5 + cff6 * (1.0 - cff5);
+      if (DV == 0.0 && (wS + w0) <= 1.0) vm = 0.0;
+    }
+    GF(vmask_wet)[a] = vm;
+  }
+  double pw = 0.0;
+  if (inU && inV) {
+    // :631-683: 1 with four or three wet neighbours, 2 with two on the same side, 0 otherwise
+    const bool A = wW > 0.5, B = w0 > 0.5, C = wSW > 0.5, D = wS > 0.5;      // (i-1,j) (i,j) (i-1,j-1) (i,j-1)
+    const int n = (int)A + (int)B + (int)C + (int)D;
+    if (n >= 3) pw = 1.0;
+    else if (n == 2 && !((A && D) || (B && C))) pw = 2.0;
+    GF(pmask_wet)[a] = pw;
+  }
+  if (mode != 0) {                                       // :325-345 / :478-498 (as written: pmask_full is never below 2)
+    GF(rmask_full)[a] = w0 * rmask[a];
+    if (inU) GF(umask_full)[a] = um * GF(umask)[a];
+    if (inV) GF(vmask_full)[a] = vm * GF(vmask)[a];
+    if (inU && inV) GF(pmask_full)[a] = fmax(pw * GF(pmask)[a], 2.0);
+  }
+}
+
+static int wetdry_launch(int mode, int first, int kstp)
+{
+  const roms_bounds_t &b = g_ctx.b;
+  hipLaunchKernelGGL(k2d_wetdry, grid2d(b.IendR - b.IstrR + 1, b.JendR - b.JstrR + 1), block2d(), 0, g_ctx.stream,
+                     g_ctx.devc, mode, first, kstp);
+  KERNEL_CHECK("k2d_wetdry");
+  halo_batch_begin();
+  halo_exchange2d(GT_P, g_ctx.dev[FID_pmask_wet]);
+  halo_exchange2d(GT_R, g_ctx.dev[FID_rmask_wet]);
+  halo_exchange2d(GT_U, g_ctx.dev[FID_umask_wet]);
+  halo_exchange2d(GT_V, g_ctx.dev[FID_vmask_wet]);
+  if (mode == 0) halo_exchange2d(GT_R, g_ctx.dev[FID_rmask_wet_avg]);
+  else {
+    halo_exchange2d(GT_P, g_ctx.dev[FID_pmask_full]);
+    halo_exchange2d(GT_R, g_ctx.dev[FID_rmask_full]);
+    halo_exchange2d(GT_U, g_ctx.dev[FID_umask_full]);
+    halo_exchange2d(GT_V, g_ctx.dev[FID_vmask_full]);
+  }
+  return halo_batch_end();
 }
 
 // DUon/DVom scratch already holds the exchanged fluxes of barotropic level g_flux_lev (left there by the
@@ -263,7 +367,8 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   // whose boundary conditions are separate launches)
   const bool walls = lbc2d_all_closed();
   // (UV_VIS4: the biharmonic term is a pass of its own in front of the momentum kernel -- general path only)
-  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.loopback && walls && !p.uv_vis4;
+  // (WET_DRY: the masks are a pass of their own between the averages and the free surface -- general path only)
+  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.loopback && walls && !p.uv_vis4 && !p.wet_dry;
   if (sm) {
     if (s.iif <= p.nfast) {
       // ONE launch: free surface, fast-time averages and momentum (k2d_mom_lds<true>)
@@ -302,7 +407,7 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
     if ((rc = halo_batch_end())) return rc;
   }
   g_flux_ready = false;
-  if (in_loop && multi && walls && s.iif <= p.nfast && !p.uv_vis4) {
+  if (in_loop && multi && walls && s.iif <= p.nfast && !p.uv_vis4 && !p.wet_dry) {
     // ONE compute launch + ONE exchange per call
     s.sm = 3;
     if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, nullptr, nullptr, DUnext, DVnext))) return rc;
@@ -330,6 +435,8 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
     halo_exchange2d(GT_V, g_ctx.dev[FID_DV_avg1]);
     if ((rc = halo_batch_end())) return rc;
   }
+  // WET_DRY: the new wet/dry masks, :729-749 (after the averages and their exchange, before the return below)
+  if (p.wet_dry && (rc = wetdry_launch(s.iif <= p.nfast ? 0 : 1, s.iif == 1 && s.predictor, s.kstp))) return rc;
   if (s.iif > p.nfast) return 0;
   if ((rc = bc_zeta(s.knew, si))) return rc;
   if (p.uv_vis4 && (rc = roms_launch_step2d_visc4(s.krhs))) return rc;
@@ -345,6 +452,17 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
 }
 
 }  // namespace
+
+// wetdry(ng, tile, Tindex, .TRUE.): the masks of the initial state (initial.F:438-466), Tindex = s->kstp
+extern "C" int roms_hip_wetdry(const roms_step_idx_t *s)
+{
+  int rc = roms_entry_check("roms_hip_wetdry");
+  if (rc) return rc;
+  if (!g_ctx.p.wet_dry) return 0;
+  if (s->kstp < 1 || s->kstp > 3) return roms_fail("roms_hip_wetdry", "kstp (the time index of the initial state) outside 1..3");
+  ScopedTimer tm("wetdry");
+  return wetdry_launch(2, 0, s->kstp);
+}
 
 extern "C" int roms_hip_step2d(const roms_step_idx_t *s)
 {

@@ -148,7 +148,9 @@ __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S
 // of k2d_zeta_sm are done here as well -- zeta_new and zwrk are evaluated from the staged DUon/DVom
 // tiles for the (65 x 5) points this workgroup's momentum stencil touches and kept in LDS, so one
 // step2d call is ONE launch and the zeta_new/zwrk scratch round trip disappears.
-template <bool FUSED, bool ROWM = false, bool ROWH = false>
+// WET (general path only): the WET_DRY blocks -- pmask_wet in the viscous stress (:1436-1438), the wet/dry factor of
+// the new velocity, of the right-hand side and, in the first predictor, of rufrc / ru(:,:,0,nstp) (:2123-2135 ...).
+template <bool FUSED, bool ROWM = false, bool ROWH = false, bool WET = false>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon, const double *__restrict__ DVom,
             const double *__restrict__ zeta_new, const double *__restrict__ zwrk, double *__restrict__ DUnext,
@@ -385,6 +387,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       const double cffp = HT(visc2_p, q, jq) * Dp * 0.5 *
              (MT(pmon_p, q, jq) * ((MT(pn, q - ni, jq - 1) + MT(pn, q, jq)) * sV[tq] - (MT(pn, q - 1 - ni, jq - 1) + MT(pn, q - 1, jq)) * sV[tq - 1]) +
               MT(pnom_p, q, jq) * ((MT(pm, q - 1, jq) + MT(pm, q, jq)) * sU[tq] - (MT(pm, q - 1 - ni, jq - 1) + MT(pm, q - ni, jq - 1)) * sU[tq - TP]));
+      if constexpr (WET) return (masking ? cffp * GF(pmask)[q] : cffp) * GF(pmask_wet)[q];   // WET_DRY, :1436
       return masking ? cffp * GF(pmask)[q] : cffp;              // MASKING, :1433
     };
     const double sr0 = str_r(a, j, t), sp0 = str_p(a, j, t);
@@ -414,6 +417,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     if (do_v) rhs_v = rhs_v - c->ws2[23][a];
   }
   // ---- coupling between 2-D and 3-D equations, :1884-2065 ----
+  double rf_u = 0.0, rf_v = 0.0;                        // rufrc / rvfrc of the first predictor (WET: scaled below)
   if (s.iif == 1 && s.predictor) {
     // never source-mapped (step2d_impl), so owner is always true here
     const gd_t ru_s = (gd_t)(c->F.ru + (long)(s.nstp - 1) * n3w);
@@ -427,6 +431,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       else rhs_u = rhs_u + (23.0 / 12.0) * rf - (16.0 / 12.0) * ru_n[a] + (5.0 / 12.0) * ru_s[a];
       GF(rufrc)[a] = rf;
       ru_s[a] = rf;
+      rf_u = rf;
     }
     if (do_v) {
       const double rf = GF(rvfrc)[a] - rhs_v;
@@ -435,6 +440,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       else rhs_v = rhs_v + (23.0 / 12.0) * rf - (16.0 / 12.0) * rv_n[a] + (5.0 / 12.0) * rv_s[a];
       GF(rvfrc)[a] = rf;
       rv_s[a] = rf;
+      rf_v = rf;
     }
   } else {
     if (do_u) rhs_u = rhs_u + GF(rufrc)[a];
@@ -460,6 +466,16 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
                cff * (a1 * rhs_u + a2 * GF(rubar)[a + (long)(s.kstp - 1) * nij] -
                       a3 * GF(rubar)[a + (long)(ptsk - 1) * nij])) * fc;
     if (masking) un = un * GF(umask)[a];               // MASKING, :2120 / :2175
+    if constexpr (WET) {                               // WET_DRY, :2123-2135 / :2178-2184 / :2225-2231
+      const double cff7 = wet_factor(GF(umask_wet)[a], un);
+      un = un * cff7;
+      rhs_u = rhs_u * cff7;
+      if (s.iif == 1 && s.predictor) {                 // FIRST_2D_STEP and predictor, :2129-2133
+        const double rf = rf_u * cff7;
+        GF(rufrc)[a] = rf;
+        ((gd_t)(c->F.ru + (long)(s.nstp - 1) * n3w))[a] = rf;
+      }
+    }
     put(ubn, o, un);
     if (s.predictor && owner) GF(rubar)[a + (long)(s.krhs - 1) * nij] = rhs_u;
     const double un_s = masking ? (p.gamma2 * un) * GF(umask)[a - ni] : p.gamma2 * un;   // wall rows (u2dbc)
@@ -493,6 +509,16 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
                cff * (a1 * rhs_v + a2 * GF(rvbar)[a + (long)(s.kstp - 1) * nij] -
                       a3 * GF(rvbar)[a + (long)(ptsk - 1) * nij])) * fc;
     if (masking) vn = vn * GF(vmask)[a];               // MASKING, :2145 / :2194
+    if constexpr (WET) {                               // WET_DRY, :2148-2160 / :2197-2203 / :2246-2252
+      const double cff7 = wet_factor(GF(vmask_wet)[a], vn);
+      vn = vn * cff7;
+      rhs_v = rhs_v * cff7;
+      if (s.iif == 1 && s.predictor) {
+        const double rf = rf_v * cff7;
+        GF(rvfrc)[a] = rf;
+        ((gd_t)(c->F.rv + (long)(s.nstp - 1) * n3w))[a] = rf;
+      }
+    }
     put(vbn, o, vn);
     if (s.predictor && owner) GF(rvbar)[a + (long)(s.krhs - 1) * nij] = rhs_v;
     if constexpr (FUSED) {
@@ -633,7 +659,10 @@ int roms_launch_k2d_mom_lds(const int *s10, const double *DUon, const double *DV
     else
       hipLaunchKernelGGL((k2d_mom_lds<true, false>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
                          g_ctx.devc, s, DUon, DVom, (const double *)nullptr, (const double *)nullptr, DUnext, DVnext);
-  } else
+  } else if (g_ctx.p.wet_dry)
+    hipLaunchKernelGGL((k2d_mom_lds<false, false, false, true>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                       g_ctx.devc, s, DUon, DVom, zeta_new, zwrk, (double *)nullptr, (double *)nullptr);
+  else
     hipLaunchKernelGGL((k2d_mom_lds<false, false>), grid2d(nx, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc, s,
                        DUon, DVom, zeta_new, zwrk, (double *)nullptr, (double *)nullptr);
   KERNEL_CHECK("k2d_mom_lds");

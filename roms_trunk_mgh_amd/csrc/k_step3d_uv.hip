@@ -27,9 +27,9 @@ namespace {
 // One momentum column.  off = 1 (u: neighbour i-1) or ni (v: neighbour j-1).
 template <int NMAX>
 __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
-                                          gd_t vel, gcd_t rhs,
+                                          gd_t vel, gd_t rhs,
                                           double dc0, double metric, double Davg1,
-                                          gd_t Hflx, gd_t bar, double Davg2, bool masking, double msk)
+                                          gd_t Hflx, gd_t bar, double Davg2, bool masking, double msk, bool wet, double wmsk)
 {
   const gcd_t Akv = (gcd_t)(c->F.Akv);
   const gcd_t Hz = (gcd_t)(c->F.Hz);
@@ -104,7 +104,8 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
     if (k <= N) {
       const long ck = c0 + (long)(k - 1) * nij;
       double uv = un[k] - corr;
-      if (masking) uv = uv * msk;                 // MASKING, step3d_uv.F:558 / :891
+      if (masking) uv = uv * msk;                 // MASKING, step3d_uv.F:558 / :891 (msk: times the wet/dry mask, :561 / :894)
+      if (wet) rhs[ck + nij] = rhs[ck + nij] * wmsk;   // WET_DRY, step3d_uv.F:563 / :896: ru / rv(nrhs) as well
       vel[ck] = uv;
       un[k] = uv;
       const double dck = cffm * (Hz[ck] + Hz[ck - off]);
@@ -113,7 +114,8 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
     }
   }
   DC0 = 1.0 / DC0;
-  const double bv = DC0 * Davg1;
+  double bv = DC0 * Davg1;
+  if (wet) bv = bv * wmsk;                        // WET_DRY, step3d_uv.F:1042-1044 / :1255-1257
   bar[c0] = bv;
   bar[c0 + nij] = bv;
   double FC0 = 0.0;
@@ -142,20 +144,20 @@ k_uv_column(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
   if (i > b.Iend || j > b.Jend) return;
   const long c0 = I2(i, j);
   const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn;
-  const bool masking = c->p.masking != 0;
+  const bool masking = c->p.masking != 0, wet = c->p.wet_dry != 0;
   // blockIdx.z selects the component so that both columns do not share VGPRs
   if (XB.z == 0) {
     if (i < b.IstrU) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - 1]) * (pn[c0] + pn[c0 - 1]);
-    uv_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), (gcd_t)(c->F.ru + (long)(nrhs - 1) * n3w), dc0,
+    uv_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), (gd_t)(c->F.ru + (long)(nrhs - 1) * n3w), dc0,
                     GF(on_u)[c0], GF(DU_avg1)[c0], GF(Huon), GF(ubar), GF(DU_avg2)[c0], masking,
-                    masking ? (double)GF(umask)[c0] : 1.0);
+                    masking ? umaskw(c, c0) : 1.0, wet, wet ? (double)GF(umask_wet)[c0] : 1.0);
   } else {
     if (j < b.JstrV) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - ni]) * (pn[c0] + pn[c0 - ni]);
-    uv_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), (gcd_t)(c->F.rv + (long)(nrhs - 1) * n3w), dc0,
+    uv_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), (gd_t)(c->F.rv + (long)(nrhs - 1) * n3w), dc0,
                     GF(om_v)[c0], GF(DV_avg1)[c0], GF(Hvom), GF(vbar), GF(DV_avg2)[c0], masking,
-                    masking ? (double)GF(vmask)[c0] : 1.0);
+                    masking ? vmaskw(c, c0) : 1.0, wet, wet ? (double)GF(vmask_wet)[c0] : 1.0);
   }
 }
 
@@ -164,7 +166,7 @@ template <int NMAX>
 __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
                                               gd_t vel, gd_t Hflx,
                                               gd_t bar, double metric, double Davg1, double Davg2,
-                                              bool fix_mean, bool masking, double msk)
+                                              bool fix_mean, bool masking, double msk, bool wet, double wmsk)
 {
   const gcd_t Hz = (gcd_t)(c->F.Hz);
   const double cff = 0.5 * metric;
@@ -184,7 +186,8 @@ __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, lon
   }
   DC0 = 1.0 / DC0;
   CF0 = DC0 * (CF0 - Davg1);
-  const double bv = DC0 * Davg1;
+  double bv = DC0 * Davg1;
+  if (wet) bv = bv * wmsk;                                // WET_DRY, step3d_uv.F:1042-1044 / :1255-1257
   bar[c0] = bv;
   bar[c0 + nij] = bv;
   double FC0 = 0.0;
@@ -196,7 +199,7 @@ __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, lon
       double uv = vel[ck];
       if (fix_mean) {                                     // boundary rows, :1087-1110
         uv = uv - CF0;
-        if (masking) uv = uv * msk;                       // MASKING, :1137 / :1166 / :1355 / :1384
+        if (masking) uv = uv * msk;                       // MASKING, :1137 / :1166 / :1355 / :1384 (msk: times the wet/dry mask)
         vel[ck] = uv;
       }
       const double h = 0.5 * (Hflx[ck] + uv * dck);
@@ -225,7 +228,7 @@ k_uv_couple(const RomsDev *__restrict__ c, int nnew)
   if (i > b.IendT || j > b.JendT) return;
   const long c0 = I2(i, j);
   const bool ns_wall = !b.NSperiodic;
-  const bool masking = c->p.masking != 0;
+  const bool masking = c->p.masking != 0, wet = c->p.wet_dry != 0;
   // columns stepped by k_uv_column were coupled there
   const bool inner = i <= b.Iend && j >= b.Jstr && j <= b.Jend;
   if (XB.z == 0) {
@@ -236,14 +239,16 @@ k_uv_couple(const RomsDev *__restrict__ c, int nnew)
     const bool fix = (ns_wall && (j == 0 || j == b.Mm + 1) && i >= b.IstrU && i <= b.Iend) ||
                      (!b.EWperiodic && ((b.west_edge && i == b.Istr) || (b.east_edge && i == b.Iend + 1)));
     couple_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), GF(Huon), GF(ubar), GF(on_u)[c0],
-                        GF(DU_avg1)[c0], GF(DU_avg2)[c0], fix, masking, masking ? (double)GF(umask)[c0] : 1.0);
+                        GF(DU_avg1)[c0], GF(DU_avg2)[c0], fix, masking, masking ? umaskw(c, c0) : 1.0, wet,
+                        wet ? (double)GF(umask_wet)[c0] : 1.0);
   } else {
     if (inner && i >= b.Istr && j >= b.JstrV) return;
     if (j < b.Jstr) return;
     const bool fix = (ns_wall && (j == 1 || j == b.Mm + 1) && i >= b.Istr && i <= b.Iend) ||
                      (!b.EWperiodic && ((b.west_edge && i == b.Istr - 1) || (b.east_edge && i == b.Iend + 1)));
     couple_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), GF(Hvom), GF(vbar), GF(om_v)[c0],
-                        GF(DV_avg1)[c0], GF(DV_avg2)[c0], fix, masking, masking ? (double)GF(vmask)[c0] : 1.0);
+                        GF(DV_avg1)[c0], GF(DV_avg2)[c0], fix, masking, masking ? vmaskw(c, c0) : 1.0, wet,
+                        wet ? (double)GF(vmask_wet)[c0] : 1.0);
   }
 }
 

@@ -44,7 +44,7 @@ __device__ __forceinline__ PsiC psi_coef(const RomsDev *__restrict__ c, long q, 
   o.d = pm[q - 1 - ni] + pm[q - ni];
   o.k_e = c->F.om_p[q] * c->F.om_p[q] * visc_p[q];
   o.k_x = c->F.on_p[q] * c->F.on_p[q] * visc_p[q];
-  o.mask = c->p.masking ? c->F.pmask[q] : 1.0;
+  o.mask = c->p.masking ? pmaskw(c, q) : 1.0;               // (+ WET_DRY, uv3dmix2_s.h:275, uv3dmix4_s.h:334, :560)
   return o;
 }
 __device__ __forceinline__ double stress_r(const RhoC &m, const double *__restrict__ u, const double *__restrict__ v,
@@ -271,7 +271,7 @@ k2d_visc4_first(const RomsDev *__restrict__ c, int krhs, Uv4 A)
     const double cff = c->F.visc4_p[q] * 0.5 *
            (c->F.pmon_p[q] * ((pn[q - ni] + pn[q]) * v[q] - (pn[q - 1 - ni] + pn[q - 1]) * v[q - 1]) +
             c->F.pnom_p[q] * ((pm[q - 1] + pm[q]) * u[q] - (pm[q - 1 - ni] + pm[q - ni]) * u[q - ni]));
-    return msk ? cff * c->F.pmask[q] : cff;
+    return msk ? cff * pmaskw(c, q) : cff;                  // (+ WET_DRY, step2d_LF_AM3.h:1512, :1707)
   };
   const double sr0 = str_r(a), sp0 = str_p(a);
   if (do_u) {
@@ -312,7 +312,7 @@ k2d_visc4_second(const RomsDev *__restrict__ c, int krhs, Uv4 A, double *__restr
     const double cff = c->F.visc4_p[q] * Dp * 0.5 *
            (c->F.pmon_p[q] * ((pn[q - ni] + pn[q]) * v[q] - (pn[q - 1 - ni] + pn[q - 1]) * v[q - 1]) +
             c->F.pnom_p[q] * ((pm[q - 1] + pm[q]) * u[q] - (pm[q - 1 - ni] + pm[q - ni]) * u[q - ni]));
-    return msk ? cff * c->F.pmask[q] : cff;
+    return msk ? cff * pmaskw(c, q) : cff;                  // (+ WET_DRY, step2d_LF_AM3.h:1512, :1707)
   };
   const double sr0 = str_r(a), sp0 = str_p(a);
   if (do_u) {

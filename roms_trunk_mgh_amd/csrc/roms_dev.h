@@ -131,6 +131,32 @@ typedef double __attribute__((address_space(1))) *gd_t;
 // field `name` of the constant block as a global-address-space pointer (device code with `c` in scope)
 #define GF(name) ((gd_t)c->F.name)
 
+// WET_DRY: the land/sea mask of a point times its wet/dry mask.  Wherever the reference multiplies by the wet/dry mask
+// directly after the land/sea mask (x = x*umask; x = x*umask_wet -- every WET_DRY block of the mixing, bulk-flux,
+// MPDATA, step3d_uv and ini_fields files) the two small-integer factors combine exactly, signed zeros included:
+// x*(m*w) == (x*m)*w bit for bit for m in {0,1}, w in {-1,0,1,2}.  Callers hold `c`; without WET_DRY this is the
+// land/sea mask alone.
+#define ROMS_MASKW(name)                                                                                  \
+  __device__ __forceinline__ double name##w(const RomsDev *__restrict__ c, long q)                       \
+  {                                                                                                       \
+    double m = ((gcd_t)c->F.name)[q];                                                                     \
+    if (c->p.wet_dry) m = m * ((gcd_t)c->F.name##_wet)[q];                                                \
+    return m;                                                                                             \
+  }
+ROMS_MASKW(rmask)
+ROMS_MASKW(umask)
+ROMS_MASKW(vmask)
+ROMS_MASKW(pmask)
+#undef ROMS_MASKW
+// the factor of the barotropic wet/dry rule (step2d_LF_AM3.h:2124-2126, u2dbc_im.F:1183-1187): 1 on a face between
+// two wet cells (mask 2), 0 between two dry ones, and on a one-sided face (+-1) 1 only for flow out of the wet cell
+__device__ __forceinline__ double wet_factor(double mask_wet, double vel)
+{
+  const double cff5 = fabs(fabs(mask_wet) - 1.0);
+  const double cff6 = 0.5 + copysign(0.5, vel) * mask_wet;
+  return 0.5 * mask_wet * cff5 + cff6 * (1.0 - cff5);
+}
+
 #define I2(i,j)    ((long)((i) - LBi) + (long)((j) - LBj) * ni)
 #define I3(i,j,k)  (I2(i,j) + (long)((k) - 1) * nij)
 #define I3W(i,j,k) (I2(i,j) + (long)(k) * nij)
