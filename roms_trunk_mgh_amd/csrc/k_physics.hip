@@ -406,10 +406,14 @@ extern "C" int roms_hip_bulk_flux(const roms_step_idx_t *s)
 // lmd_vmix = lmd_vmix_tile + lmd_skpp_tile + lmd_finish_tile (ROMS/Nonlinear/lmd_vmix.F:99/465,
 // lmd_skpp.F:98, lmd_swfrac.F:6): K-profile vertical mixing with the BENCHMARK option set (LMD_RIMIX
 // + RI_SPLINES, LMD_CONVEC, LMD_SKPP, LMD_NONLOCAL, SALINITY; uniform Jerlov water type).
-// Column-local: one thread per (i,j), two sweeps.  Upward: the forward recurrences of the three splines
-// (u, v, pden) go to the 3-D device scratch ([level][i,j], coalesced).  Downward: their back-substitution
-// is fused with the Richardson-number mixing, the bulk Richardson function and the boundary-layer depth
-// search, so no other profile is stored; the buoyancy-flux profile is recomputed (two exp) where used.
+// Column-local: one thread per (i,j), three sweeps.  Upward: the forward recurrences of the three splines
+// (u, v, pden), of which only every sixth level is kept (registers).  Downward, segment by segment: the
+// recurrences of a segment are re-run from its checkpoint into LDS and their back-substitution is fused with
+// the Richardson-number mixing, the bulk Richardson function and the boundary-layer depth search, so no profile
+// goes to device memory but the shear function nu_sx (parked in Akv); the buoyancy-flux profile is recomputed
+// (two exp) where used.  Upward again: the boundary-layer profiles, the convective adjustment, the final Akv, Akt.
+// Per column and level 4 + 4 + 2 + 3 array reads from memory (4 more from cache) and 6 writes -- the earlier version
+// (forward values of all levels in scratch) read 18 and wrote 11.
 // =================================================================================================
 namespace {
 
@@ -440,13 +444,22 @@ __device__ __forceinline__ void wscale(double Ustar, double sigma, double Bf, do
   }
 }
 
-struct LmdScratch { double *FC, *dU, *dV, *dR, *Bf; };
+// The forward recurrences of the three splines are NOT stored per level: the upward sweep keeps only their values at
+// every LMD_SEG-th level (checkpoints, in registers); the downward sweep takes the column segment by segment from the
+// top, re-runs the recurrence of a segment from its checkpoint and consumes it in descending order.  Same operations
+// in the same order as a single upward sweep, so the same bits -- without the 4 x (N-1) scratch stores and loads per
+// column of the earlier version.  All three sweeps load a whole segment (LMD_SEG levels of every input) before they
+// compute it: a wave has a dozen memory round trips per column instead of one per level and sweep (the kernel was
+// waiting on memory for 72 % of its wave-cycles, SQ_WAIT_ANY, with one level's loads in flight).
+#define LMD_SEG 5
 
-__global__ void __launch_bounds__(BLK_X *BLK_Y)
-k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg, double Vtc)
+template <int NMAX>
+__global__ void __launch_bounds__(BLK_X *BLK_Y, 2)
+k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, double lmd_Cg, double Vtc)
 {
   DEV_PROLOGUE(c)
   const roms_params_t &p = c->p;
+  constexpr int MS = (NMAX - 1 + LMD_SEG - 1) / LMD_SEG;        // segments of W-levels 1..NMAX-1
   const Blk XB = xcd_block();
   const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
   const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
@@ -456,36 +469,50 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   const double lmd_Ri0 = 0.7, lmd_bvfcon = -2.0E-5, lmd_nu0c = 0.01, lmd_nu0m = 10.0E-4, lmd_nu0s = 10.0E-4;
   const double lmd_Ric = 0.3, lmd_cekman = 0.7, lmd_cmonob = 1.0, lmd_epsilon = 0.1;
   const double gorho0 = g / p.rho0;
-  const gcd_t Hz = (gcd_t)c->F.Hz, rho = (gcd_t)c->F.rho, pden = (gcd_t)c->F.pden, bvf = (gcd_t)c->F.bvf;
+  const gcd_t Hz = (gcd_t)c->F.Hz, pden = (gcd_t)c->F.pden, bvf = (gcd_t)c->F.bvf;
   const gcd_t z_w = (gcd_t)c->F.z_w;
   const gcd_t u = (gcd_t)(c->F.u + (long)(nstp - 1) * n3r), v = (gcd_t)(c->F.v + (long)(nstp - 1) * n3r);
   const gd_t Akv = (gd_t)c->F.Akv, AkT = (gd_t)c->F.Akt, AkS = (gd_t)(c->F.Akt + n3w);
   const gd_t ghT = (gd_t)c->F.ghats, ghS = (gd_t)(c->F.ghats + n3w);
-  const gd_t FC = (gd_t)w.FC, dU = (gd_t)w.dU, dV = (gd_t)w.dV, dR = (gd_t)w.dR;
   auto r3i = [&](int k) { return a + (long)(k - 1) * nij; };     // rho-type level k = 1..N
   auto w3i = [&](int k) { return a + (long)k * nij; };           // W-type level k = 0..N
 
-  // ---------- one upward sweep: spline recurrences of u, v (lmd_vmix_tile :205-225 = lmd_skpp_tile
-  // :345-365) and of pden; only these forward values go to scratch ----------
-  // (software-pipelined: the six loads of level k+2 are issued before level k is computed)
+  // the inputs of rho-levels k0+1 .. k0+SEG+1 (clamped to N: the clamped ones are loaded but not used)
+  struct Lev { double hz, ua, ub, va, vb, pd; };
+  auto load_seg = [&](int k0, Lev (&L)[LMD_SEG + 1]) {
+#pragma unroll
+    for (int t = 0; t <= LMD_SEG; t++) {
+      const long q = r3i(min(k0 + 1 + t, N));
+      L[t].hz = Hz[q]; L[t].ua = u[q]; L[t].ub = u[q + 1]; L[t].va = v[q]; L[t].vb = v[q + ni]; L[t].pd = pden[q];
+    }
+  };
+  // one level of the spline recurrences of u, v (lmd_vmix_tile :205-225 = lmd_skpp_tile :345-365) and of pden:
+  // from the values of level k-1 (FCm ...) and the inputs of rho-levels k (A) and k+1 (B)
+#define LMD_FWD(A, B, fck, duk, dvk, drk)                                             \
+      const double cff = 1.0 / (2.0 * B.hz + A.hz * (2.0 - FCm));                     \
+      const double fck = cff * B.hz;                                                  \
+      const double duk = cff * (3.0 * (B.ua - A.ua + B.ub - A.ub) - A.hz * dUm);      \
+      const double dvk = cff * (3.0 * (B.va - A.va + B.vb - A.vb) - A.hz * dVm);      \
+      const double drk = cff * (6.0 * (B.pd - A.pd) - A.hz * dRm);
+
+  // ---------- upward sweep: the recurrences, keeping their values at levels 0, SEG, 2 SEG ... only ----------
+  double ckF[MS], ckU[MS], ckV[MS], ckR[MS];
   {
     double FCm = 0.0, dUm = 0.0, dVm = 0.0, dRm = 0.0;
-    long q = r3i(1);
-    double hz = Hz[q], ua = u[q], ub = u[q + 1], va = v[q], vb = v[q + ni], pd = pden[q];
-    q = r3i(N >= 2 ? 2 : 1);
-    double hz1 = Hz[q], ua1 = u[q], ub1 = u[q + 1], va1 = v[q], vb1 = v[q + ni], pd1 = pden[q];
-    for (int k = 1; k <= N - 1; k++) {
-      q = r3i(k + 2 <= N ? k + 2 : N);
-      const double hz2 = Hz[q], ua2 = u[q], ub2 = u[q + 1], va2 = v[q], vb2 = v[q + ni], pd2 = pden[q];
-      const double cff = 1.0 / (2.0 * hz1 + hz * (2.0 - FCm));
-      const double fck = cff * hz1;
-      const double duk = cff * (3.0 * (ua1 - ua + ub1 - ub) - hz * dUm);
-      const double dvk = cff * (3.0 * (va1 - va + vb1 - vb) - hz * dVm);
-      const double drk = cff * (6.0 * (pd1 - pd) - hz * dRm);
-      FC[w3i(k)] = fck; dU[w3i(k)] = duk; dV[w3i(k)] = dvk; dR[w3i(k)] = drk;
-      FCm = fck; dUm = duk; dVm = dvk; dRm = drk;
-      hz = hz1; ua = ua1; ub = ub1; va = va1; vb = vb1; pd = pd1;
-      hz1 = hz2; ua1 = ua2; ub1 = ub2; va1 = va2; vb1 = vb2; pd1 = pd2;
+#pragma unroll
+    for (int m = 0; m < MS; m++) {
+      ckF[m] = FCm; ckU[m] = dUm; ckV[m] = dVm; ckR[m] = dRm;
+      if (m * LMD_SEG + 1 <= N - 1) {
+        Lev L[LMD_SEG + 1];
+        load_seg(m * LMD_SEG, L);
+#pragma unroll
+        for (int t = 0; t < LMD_SEG; t++) {
+          if (m * LMD_SEG + 1 + t <= N - 1) {
+            LMD_FWD(L[t], L[t + 1], fck, duk, dvk, drk)
+            FCm = fck; dUm = duk; dVm = dvk; dRm = drk;
+          }
+        }
+      }
     }
   }
 
@@ -518,82 +545,128 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
   auto bflux = [&](int k, double &gT, double &gS) { return bflux_z(z_w[w3i(k)], gT, gS); };
   { double gT, gS; bflux(N, gT, gS); ghT[w3i(N)] = gT; ghS[w3i(N)] = gS; }
 
-  // ---------- one downward sweep: back-substitution of the three splines fused with (a) the shear /
+  // ---------- downward sweep, segment by segment: back-substitution of the three splines fused with (a) the shear /
   // Richardson-number mixing of lmd_vmix_tile (:240-300) and (b) the bulk Richardson function and the
   // boundary-layer depth search of lmd_skpp_tile (:380-470) ----------
   const double cff1 = 1.0 / 3.0, cff2 = 1.0 / 6.0;
   int ksbl = 1;
   {
-    // inputs of iteration k: rho-type level k (hz, pd, ua/ub = u(i), u(i+1), va/vb = v(j), v(j+1)) and
-    // W-type level k-1 (fc, dr, du, dv: forward spline values; bvm, zwm); software-pipelined, the twelve
-    // loads of iteration k-1 are issued before iteration k is computed
-    long q = r3i(N), qw = w3i(N > 1 ? N - 1 : 1), qz = w3i(N - 1);
-    double hz = Hz[q], pd = pden[q], ua = u[q], ub = u[q + 1], va = v[q], vb = v[q + ni];
-    double fc = FC[qw], dr = dR[qw], du = dU[qw], dv = dV[qw], bvm = bvf[qz], zwm = z_w[qz];
-    double bvk = 0.0, zwk = zwN;                                 // W-type level k (bvf(N) is not used)
-    const double Rref = pd + hz * (cff1 * 0.0 + cff2 * dr);      // final: x(N) = 0
-    const double Uref = 0.5 * (ua + ub) + hz * (cff1 * 0.0 + cff2 * du);
-    const double Vref = 0.5 * (va + vb) + hz * (cff1 * 0.0 + cff2 * dv);
+    double Rref = 0.0, Uref = 0.0, Vref = 0.0;
     double dRk = 0.0, dUk = 0.0, dVk = 0.0;                      // final values at level k (k = N: 0)
     double FCk = 0.0;                                            // FC(i,N) = 0
+    double bvk = 0.0, zwk = zwN;                                 // W-type level k (bvf(N) is not used)
     hsbl = z_w[w3i(1)];
-    for (int k = N; k >= 1; k--) {
-      q = r3i(k > 1 ? k - 1 : 1); qw = w3i(k > 2 ? k - 2 : 1); qz = w3i(k > 2 ? k - 2 : 0);
-      const double n_hz = Hz[q], n_pd = pden[q], n_ua = u[q], n_ub = u[q + 1], n_va = v[q], n_vb = v[q + ni];
-      const double n_fc = FC[qw], n_dr = dR[qw], n_du = dU[qw], n_dv = dV[qw], n_bvm = bvf[qz], n_zwm = z_w[qz];
-      // final spline derivatives at level k-1
-      double dRm = 0.0, dUm = 0.0, dVm = 0.0;
-      if (k - 1 >= 1) {
-        dRm = dr - fc * dRk;
-        dUm = du - fc * dUk;
-        dVm = dv - fc * dVk;
+    const int mtop = (N - 2) / LMD_SEG;                          // the segment of W-level N-1
+    for (int m = mtop; m >= 0; m--) {
+      const int k0 = m * LMD_SEG;                                // this segment: W-levels k0+1 .. min(k0+SEG, N-1)
+      // everything the segment reads, in flight together: rho-levels k0+1 .. k0+SEG+1, bvf and z_w of W-levels
+      // k0 .. k0+SEG (iteration k works on W-level k-1)
+      double bvW[LMD_SEG + 1], zwW[LMD_SEG + 1];
+#pragma unroll
+      for (int t = 0; t <= LMD_SEG; t++) {
+        const long qz = w3i(min(k0 + t, N - 1));
+        bvW[t] = bvf[qz]; zwW[t] = z_w[qz];
       }
-      // (a) interior mixing at W-level k
-      if (k <= N - 1) {
-        const double epsv = 1.0E-14;
-        double shear2 = dUk * dUk + dVk * dVk;
-        const double bv = bvk;
-        const double Rig = bv / (shear2 + epsv);
-        double cff = fmin(1.0, fmax(0.0, Rig) / lmd_Ri0);
-        double nu_sx = 1.0 - cff * cff;
-        nu_sx = nu_sx * nu_sx * nu_sx;
-        shear2 = bv / (Rig + epsv);
-        cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
-        nu_sx = cff * nu_sx;
-        cff = 1.0 / sqrt(fmax(bv, 1.0E-7));
-        const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
-        Akv[w3i(k)] = lmd_iwm + lmd_nu0m * nu_sx;
-        // Akt(itemp) = Akt(isalt) here (lmd_vmix.F:296-297): one store; the sweeps below read AkT for both and the
-        // last one writes the final AkS of every interior level
-        AkT[w3i(k)] = lmd_iws + lmd_nu0s * nu_sx;
+      // re-run the recurrences of the segment from its checkpoint
+      double fF[LMD_SEG], fU[LMD_SEG], fV[LMD_SEG], fR[LMD_SEG];
+      double hzA[LMD_SEG + 1], pdA[LMD_SEG + 1], umA[LMD_SEG + 1], vmA[LMD_SEG + 1];     // what the iterations need of L
+      {
+        Lev L[LMD_SEG + 1];
+        load_seg(k0, L);
+        double FCm = ckF[0], dUm = ckU[0], dVm = ckV[0], dRm = ckR[0];
+#pragma unroll
+        for (int t = 1; t < MS; t++)
+          if (m == t) { FCm = ckF[t]; dUm = ckU[t]; dVm = ckV[t]; dRm = ckR[t]; }
+#pragma unroll
+        for (int t = 0; t < LMD_SEG; t++) {
+          fF[t] = 0.0; fU[t] = 0.0; fV[t] = 0.0; fR[t] = 0.0;
+          if (k0 + 1 + t <= N - 1) {
+            LMD_FWD(L[t], L[t + 1], fck, duk, dvk, drk)
+            fF[t] = fck; fU[t] = duk; fV[t] = dvk; fR[t] = drk;
+            FCm = fck; dUm = duk; dVm = dvk; dRm = drk;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t <= LMD_SEG; t++) {
+          hzA[t] = L[t].hz; pdA[t] = L[t].pd; umA[t] = 0.5 * (L[t].ua + L[t].ub); vmA[t] = 0.5 * (L[t].va + L[t].vb);
+        }
       }
-      // (b) bulk Richardson function at W-level k-1
-      const double depth = zwN - zwm;
-      double gT, gS;
-      const double bf = bflux_z(zwm, gT, gS);
-      if (k - 1 == 0) { ghT[w3i(0)] = gT; ghS[w3i(0)] = gS; }
-      const double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
-      double wmk, wsk;
-      wscale(Ustar, sigma, bf, wmk, wsk);
-      const double Rk = pd - hz * (cff1 * dRm + cff2 * dRk);
-      const double Uk = 0.5 * (ua + ub) - hz * (cff1 * dUm + cff2 * dUk);
-      const double Vk = 0.5 * (va + vb) - hz * (cff1 * dVm + cff2 * dVk);
-      const double Ritop = -gorho0 * (Rref - Rk) * depth;
-      const double Ribot = (Uref - Uk) * (Uref - Uk) + (Vref - Vk) * (Vref - Vk) +
-                           Vtc * depth * wsk * sqrt(fabs(bvm));
-      const double FCkm1 = Ritop - lmd_Ric * Ribot;
-      // boundary-layer depth: first level (from the top, k = N..2) where the function turns positive
-      if (k >= 2 && ksbl == 1 && FCkm1 > 0.0) {
-        hsbl = (zwk * FCkm1 - zwm * FCk) / (FCkm1 - FCk);
-        ksbl = k;
+      // iteration k (rho-level k = L[k-k0-1], forward values and bvf / z_w of W-level k-1) for k = k0+SEG+1 .. k0+2;
+      // the lowest segment also runs k = 1, which has no level below
+#pragma unroll
+      for (int t = LMD_SEG; t >= 0; t--) {
+        const int k = k0 + 1 + t;
+        if (k <= N && (t >= 1 || m == 0)) {
+          const double hz = hzA[t], pd = pdA[t], um = umA[t], vm = vmA[t];
+          const int tw = t >= 1 ? t - 1 : 0;                     // slot of the forward values of W-level k-1
+          const double fc = fF[tw], du = fU[tw], dv = fV[tw], dr = fR[tw];
+          const double bvm = bvW[t], zwm = zwW[t];
+          if (k == N) {                                          // the reference values at the surface: x(N) = 0
+            Rref = pd + hz * (cff1 * 0.0 + cff2 * dr);
+            Uref = um + hz * (cff1 * 0.0 + cff2 * du);
+            Vref = vm + hz * (cff1 * 0.0 + cff2 * dv);
+          }
+          // final spline derivatives at level k-1
+          double dRm = 0.0, dUm = 0.0, dVm = 0.0;
+          if (k - 1 >= 1) {
+            dRm = dr - fc * dRk;
+            dUm = du - fc * dUk;
+            dVm = dv - fc * dVk;
+          }
+          // (a) interior mixing at W-level k: only the shear function nu_sx is kept (in Akv); the last sweep forms
+          // Akv and Akt from it and from bvf, which it reads anyway (lmd_vmix.F:286-297)
+          if (k <= N - 1) {
+            const double epsv = 1.0E-14;
+            double shear2 = dUk * dUk + dVk * dVk;
+            const double bv = bvk;
+            const double Rig = bv / (shear2 + epsv);
+            double cff = fmin(1.0, fmax(0.0, Rig) / lmd_Ri0);
+            double nu_sx = 1.0 - cff * cff;
+            nu_sx = nu_sx * nu_sx * nu_sx;
+            shear2 = bv / (Rig + epsv);
+            cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
+            nu_sx = cff * nu_sx;
+            Akv[w3i(k)] = nu_sx;
+          }
+          // (b) bulk Richardson function at W-level k-1 -- until the boundary-layer depth is found: the levels below
+          // it cannot change hsbl / ksbl any more (the search keeps the first crossing from the top)
+          if (ksbl == 1) {
+            const double depth = zwN - zwm;
+            double gT, gS;
+            const double bf = bflux_z(zwm, gT, gS);
+            if (k - 1 == 0) { ghT[w3i(0)] = gT; ghS[w3i(0)] = gS; }
+            const double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
+            double wmk, wsk;
+            wscale(Ustar, sigma, bf, wmk, wsk);
+            const double Rk = pd - hz * (cff1 * dRm + cff2 * dRk);
+            const double Uk = um - hz * (cff1 * dUm + cff2 * dUk);
+            const double Vk = vm - hz * (cff1 * dVm + cff2 * dVk);
+            const double Ritop = -gorho0 * (Rref - Rk) * depth;
+            const double Ribot = (Uref - Uk) * (Uref - Uk) + (Vref - Vk) * (Vref - Vk) +
+                                 Vtc * depth * wsk * sqrt(fabs(bvm));
+            const double FCkm1 = Ritop - lmd_Ric * Ribot;
+            // boundary-layer depth: first level (from the top, k = N..2) where the function turns positive
+            if (k >= 2 && FCkm1 > 0.0) {
+              hsbl = (zwk * FCkm1 - zwm * FCk) / (FCkm1 - FCk);
+              ksbl = k;
+            }
+            FCk = FCkm1;
+          } else if (k - 1 == 0) {                               // the non-local flux shape at the bottom (:320-338)
+            double gT, gS;
+            bflux_z(zwm, gT, gS);
+            ghT[w3i(0)] = gT; ghS[w3i(0)] = gS;
+          }
+          dRk = dRm; dUk = dUm; dVk = dVm;
+          bvk = bvm; zwk = zwm;
+        }
       }
-      FCk = FCkm1;
-      dRk = dRm; dUk = dUm; dVk = dVm;
-      bvk = bvm; zwk = zwm;
-      hz = n_hz; pd = n_pd; ua = n_ua; ub = n_ub; va = n_va; vb = n_vb;
-      fc = n_fc; dr = n_dr; du = n_du; dv = n_dv; bvm = n_bvm; zwm = n_zwm;
     }
   }
+#undef LMD_FWD
+  // the interior mixing coefficients of (a) at W-level k from the stored shear function: the same expressions
+  // as lmd_vmix.F:286-297
+  auto akv_a = [&](double nu_sx, double bv) { return 1.0E-6 * (1.0 / sqrt(fmax(bv, 1.0E-7))) + lmd_nu0m * nu_sx; };
+  auto akt_a = [&](double nu_sx, double bv) { return 1.0E-7 * (1.0 / sqrt(fmax(bv, 1.0E-7))) + lmd_nu0s * nu_sx; };
   // buoyancy flux at the boundary-layer depth; MASKING: depth and flux times rmask (:562, :574 and :669, :681)
   auto bfsfc_at = [&](double hs) {
     double zgrid = zwN - hs;
@@ -616,9 +689,16 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
     if (b.south_edge && j == b.Jstr) GF(hsbl)[a - ni] = hsbl;
     if (b.north_edge && j == b.Jend) GF(hsbl)[a + ni] = hsbl;
   }
+  // ksbl = the first k from the top (N..2) with z_w(k-1) < hsbl (lmd_skpp.F:640-650); LMD_SEG levels per round trip
   ksbl = 1;
-  for (int k = N; k >= 2; k--)
-    if ((ksbl == 1) && (z_w[w3i(k - 1)] < hsbl)) ksbl = k;
+  for (int kt = N; kt >= 2 && ksbl == 1; kt -= LMD_SEG) {
+    double zc[LMD_SEG];
+#pragma unroll
+    for (int t = 0; t < LMD_SEG; t++) zc[t] = z_w[w3i(max(kt - t - 1, 0))];
+#pragma unroll
+    for (int t = 0; t < LMD_SEG; t++)
+      if ((ksbl == 1) && (kt - t >= 2) && (zc[t] < hsbl)) ksbl = kt - t;
+  }
   Bfsfc = bfsfc_at(hsbl);
   sl_dpth = lmd_epsilon * (zwN - hsbl);
   double wm, ws;
@@ -634,18 +714,22 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
     const double cff = 1.0 / (z_w[w3i(k)] - z_w[w3i(k - 1)]);
     const double cff_dn = cff * (hsbl - z_w[w3i(k - 1)]);
     const double cff_up = cff * (z_w[w3i(k)] - hsbl);
-    double K_bl = cff_dn * Akv[w3i(k)] + cff_up * Akv[w3i(k - 1)];
-    double dK_bl = cff * (Akv[w3i(k)] - Akv[w3i(k - 1)]);
+    // Akv / Akt of (a) at the two levels around the boundary-layer depth (level N keeps the array's own values)
+    const double bv_k = bvf[w3i(k)], bv_m = bvf[w3i(k - 1)], nu_k = Akv[w3i(k)], nu_m = Akv[w3i(k - 1)];
+    const double akv_k = (k <= N - 1) ? akv_a(nu_k, bv_k) : nu_k, akv_m = akv_a(nu_m, bv_m);
+    const double akt_k = (k <= N - 1) ? akt_a(nu_k, bv_k) : (double)AkT[w3i(k)], akt_m = akt_a(nu_m, bv_m);
+    double K_bl = cff_dn * akv_k + cff_up * akv_m;
+    double dK_bl = cff * (akv_k - akv_m);
     Gm1 = K_bl / (zbl * wm + eps);
     if (masking) Gm1 = Gm1 * mr;                                 // :754
     dGm1dS = fmin(0.0, -dK_bl / (wm + eps) - K_bl * f1);
-    K_bl = cff_dn * AkT[w3i(k)] + cff_up * AkT[w3i(k - 1)];
-    dK_bl = cff * (AkT[w3i(k)] - AkT[w3i(k - 1)]);
+    K_bl = cff_dn * akt_k + cff_up * akt_m;
+    dK_bl = cff * (akt_k - akt_m);
     Gt1 = K_bl / (zbl * ws + eps);
     if (masking) Gt1 = Gt1 * mr;                                 // :765
     dGt1dS = fmin(0.0, -dK_bl / (ws + eps) - K_bl * f1);
-    // salinity: interior levels hold the temperature values (see above); level N was not touched
-    const double aks_k = (k <= N - 1) ? AkT[w3i(k)] : AkS[w3i(k)], aks_km1 = AkT[w3i(k - 1)];
+    // salinity: Akt(isalt) = Akt(itemp) at the interior levels (lmd_vmix.F:296-297); level N was not touched
+    const double aks_k = (k <= N - 1) ? akt_k : (double)AkS[w3i(k)], aks_km1 = akt_m;
     K_bl = cff_dn * aks_k + cff_up * aks_km1;
     dK_bl = cff * (aks_k - aks_km1);
     Gs1 = K_bl / (zbl * ws + eps);
@@ -667,44 +751,53 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, LmdScratch w, double lmd_Cg,
     Gs1 = Gt1;
     dGs1dS = dGt1dS;
   }
-  long q3 = w3i(1);
-  double n_akv = Akv[q3], n_akt = AkT[q3], n_zw = z_w[q3], n_bv = bvf[q3];
-  for (int k = 1; k <= N - 1; k++) {
-    double akv = n_akv, akt = n_akt, aks = n_akt;
-    const double zwk = n_zw, bvk = n_bv;
-    q3 = w3i(k + 1 <= N - 1 ? k + 1 : k);                      // next level, in flight during this one
-    n_akv = Akv[q3]; n_akt = AkT[q3]; n_zw = z_w[q3]; n_bv = bvf[q3];
-    if (k > ksbl) {
-      const double depth = zwN - zwk;
-      double gT, gS;
-      const double bf = bflux_z(zwk, gT, gS);
-      double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
-      double wmk, wsk;
-      wscale(Ustar, sigma, bf, wmk, wsk);
-      sigma = depth / (zbl + eps);
-      if (masking) sigma = sigma * mr;                           // :866
-      const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
-      const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
-      const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
-      const double Gs = a1 + a2 * Gs1 + a3 * dGs1dS;
-      akv = depth * wmk * (1.0 + sigma * Gm);
-      akt = depth * wsk * (1.0 + sigma * Gt);
-      aks = depth * wsk * (1.0 + sigma * Gs);
-      const double cff = lmd_Cg * (1.0 - (0.5 + copysign(0.5, bf))) / (zbl * wsk + eps);
-      ghT[w3i(k)] = cff * gT;
-      ghS[w3i(k)] = cff * gS;
-    } else {
-      ghT[w3i(k)] = 0.0;
-      ghS[w3i(k)] = 0.0;
+  // ---------- upward again, LMD_SEG levels at a time: boundary-layer profiles, convective adjustment, final values ----------
+  for (int kb = 1; kb <= N - 1; kb += LMD_SEG) {
+    double nuA[LMD_SEG], zwA[LMD_SEG], bvA[LMD_SEG];
+#pragma unroll
+    for (int t = 0; t < LMD_SEG; t++) {
+      const long q3 = w3i(min(kb + t, N - 1));
+      nuA[t] = Akv[q3]; zwA[t] = z_w[q3]; bvA[t] = bvf[q3];
     }
-    // lmd_finish_tile: convective mixing where the stratification is unstable (lmd_vmix.F:520-540)
-    double cff = fmax(bvk, lmd_bvfcon);
-    cff = fmin(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
-    double nu_sxc = 1.0 - cff * cff;
-    nu_sxc = nu_sxc * nu_sxc * nu_sxc;
-    Akv[w3i(k)] = akv + lmd_nu0c * nu_sxc;
-    AkT[w3i(k)] = akt + lmd_nu0c * nu_sxc;
-    AkS[w3i(k)] = aks + lmd_nu0c * nu_sxc;
+#pragma unroll
+    for (int t = 0; t < LMD_SEG; t++) {
+      const int k = kb + t;
+      if (k <= N - 1) {
+        const double zwk = zwA[t], bvk = bvA[t];
+        double akv = akv_a(nuA[t], bvk), akt = akt_a(nuA[t], bvk), aks = akt;
+        if (k > ksbl) {
+          const double depth = zwN - zwk;
+          double gT, gS;
+          const double bf = bflux_z(zwk, gT, gS);
+          double sigma = (bf < 0.0) ? fmin(sl_dpth, depth) : depth;
+          double wmk, wsk;
+          wscale(Ustar, sigma, bf, wmk, wsk);
+          sigma = depth / (zbl + eps);
+          if (masking) sigma = sigma * mr;                         // :866
+          const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
+          const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
+          const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
+          const double Gs = a1 + a2 * Gs1 + a3 * dGs1dS;
+          akv = depth * wmk * (1.0 + sigma * Gm);
+          akt = depth * wsk * (1.0 + sigma * Gt);
+          aks = depth * wsk * (1.0 + sigma * Gs);
+          const double cff = lmd_Cg * (1.0 - (0.5 + copysign(0.5, bf))) / (zbl * wsk + eps);
+          ghT[w3i(k)] = cff * gT;
+          ghS[w3i(k)] = cff * gS;
+        } else {
+          ghT[w3i(k)] = 0.0;
+          ghS[w3i(k)] = 0.0;
+        }
+        // lmd_finish_tile: convective mixing where the stratification is unstable (lmd_vmix.F:520-540)
+        double cff = fmax(bvk, lmd_bvfcon);
+        cff = fmin(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
+        double nu_sxc = 1.0 - cff * cff;
+        nu_sxc = nu_sxc * nu_sxc * nu_sxc;
+        Akv[w3i(k)] = akv + lmd_nu0c * nu_sxc;
+        AkT[w3i(k)] = akt + lmd_nu0c * nu_sxc;
+        AkS[w3i(k)] = aks + lmd_nu0c * nu_sxc;
+      }
+    }
   }
 }
 
@@ -759,14 +852,15 @@ extern "C" int roms_hip_lmd_vmix(const roms_step_idx_t *s)
   const long n3w = nij * (b.N + 1);
   {
     ScopedTimer tm("lmd_vmix");
-    LmdScratch w{g_ctx.hostc.ws3[1], g_ctx.hostc.ws3[2], g_ctx.hostc.ws3[3], g_ctx.hostc.ws3[4], g_ctx.hostc.ws3[5]};
     // run-time constants of mod_scalars.F:4330 (lmd_Cg) and lmd_skpp.F:300 (Vtc), evaluated on the host
     const double vonKar = 0.41, lmd_Cstar = 10.0, lmd_Cv = 1.25, lmd_Ric = 0.3, lmd_betaT = -0.2, lmd_cs = 98.96,
                  lmd_epsilon = 0.1;
     const double lmd_Cg = lmd_Cstar * vonKar * pow(lmd_cs * vonKar * lmd_epsilon, 1.0 / 3.0);
     const double Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);
-    hipLaunchKernelGGL(k_lmd_vmix, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream, g_ctx.devc,
-                       s->nstp, w, lmd_Cg, Vtc);
+    const dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
+    if (b.N <= 32) hipLaunchKernelGGL(k_lmd_vmix<32>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, lmd_Cg, Vtc);
+    else if (b.N <= ROMS_MAXN) hipLaunchKernelGGL(k_lmd_vmix<ROMS_MAXN>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nstp, lmd_Cg, Vtc);
+    else return roms_fail("roms_hip_lmd_vmix", "N > 64 not instantiated");
     KERNEL_CHECK("k_lmd_vmix");
     const int nj = b.Jend - b.Jstr + 1, ni_ = b.Iend - b.Istr + 1;
     if (b.west_edge || b.east_edge)
