@@ -37,9 +37,13 @@ enum { RM_pm = 0, RM_pn, RM_on_u, RM_om_v, RM_fomn, RM_dndx, RM_dmde, RM_pmon_r,
        RM_h, RM_visc2_r, RM_visc2_p, RM_COUNT };
 #define RM_FIRST_GROUP RM_h
 
+// the row table is read-only for every kernel that uses it (k_rowm_build wrote it in an earlier launch): constant
+// address space, so that a load with a wave-uniform row index is a scalar load (s_load_dwordx2 through the scalar
+// cache) instead of a vector load that occupies the memory pipeline and a VGPR pair per value
+typedef const double __attribute__((address_space(4))) *ccd_t;
 template <bool ROWM>
 struct Met {
-  gcd_t tab;      // RM_COUNT rows of nj doubles
+  ccd_t tab;      // RM_COUNT rows of nj doubles
   int nj, LBj;
   // element q (flat index, row jr) of metric array A
   __device__ __forceinline__ double get(gcd_t A, int f, long q, int jr) const
@@ -158,8 +162,8 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
 {
   DEV_PROLOGUE(c)
   const roms_params_t &p = c->p;
-  const Met<ROWM> met{(gcd_t)c->rowm, (int)nj, LBj};
-  const Met<ROWH> meth{(gcd_t)c->rowm, (int)nj, LBj};
+  const Met<ROWM> met{(ccd_t)c->rowm, (int)nj, LBj};
+  const Met<ROWH> meth{(ccd_t)c->rowm, (int)nj, LBj};
   // DUnext != nullptr (FUSED on several tiles, inside LOOP_2D): the closed-wall conditions are applied here
   // and DUon/DVom of the NEXT call (level knew) are left in DUnext/DVnext on the points this tile owns,
   // so that one exchange per call moves everything the next call needs
@@ -176,7 +180,10 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const int ilast = ghost_threads ? (b.Lm + b.NghostPoints) : b.Iend;
   const Blk XB = xcd_block();
   const int it0 = ibase + XB.x * BLK_X, j0 = b.Jstr + XB.y * BLK_Y;
-  const int it = it0 + threadIdx.x, j = j0 + threadIdx.y;
+  // a wave is one row of the tile (BLK_X = 64 = the wave size): its row index is a scalar, so that the row-table
+  // metrics of the momentum phase (MT / HT with row j, j-1, j+1) are scalar loads, not 64 lanes reading one address
+  static_assert(BLK_X == 64, "one wave per tile row");
+  const int it = it0 + threadIdx.x, j = j0 + __builtin_amdgcn_readfirstlane(threadIdx.y);
   const gcd_t ubk = (gcd_t)(c->F.ubar + (long)(s.krhs - 1) * nij);
   const gcd_t vbk = (gcd_t)(c->F.vbar + (long)(s.krhs - 1) * nij);
   const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
