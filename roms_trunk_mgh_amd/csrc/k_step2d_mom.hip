@@ -43,12 +43,12 @@ enum { RM_pm = 0, RM_pn, RM_on_u, RM_om_v, RM_fomn, RM_dndx, RM_dmde, RM_pmon_r,
 typedef const double __attribute__((address_space(4))) *ccd_t;
 template <bool ROWM>
 struct Met {
-  ccd_t tab;      // RM_COUNT rows of nj doubles
+  ccd_t tab;      // nj rows of RM_COUNT doubles
   int nj, LBj;
   // element q (flat index, row jr) of metric array A
   __device__ __forceinline__ double get(gcd_t A, int f, long q, int jr) const
   {
-    if constexpr (ROWM) return tab[f * nj + (jr - LBj)];
+    if constexpr (ROWM) return tab[(jr - LBj) * RM_COUNT + f];   // [row][field]: one row's values lie together
     else return A[q];
   }
 };
@@ -148,6 +148,39 @@ __device__ __forceinline__ void zeta_eval(const RomsDev *__restrict__ c, const S
   }
 }
 
+// The same with the point's inputs already in registers (the fused kernel issues these loads before its first barrier):
+// zs_a = zeta(kstp), zk_a = zeta(krhs), rz_k / rz_p = rzeta(kstp) / rzeta(ptsk), rm = rmask (1 without MASKING)
+__device__ __forceinline__ void zeta_eval_pre(const roms_params_t &p, const S2 &s, const double rhs, const double pmn_a,
+                                              const double pn_a, const double zs_a, const double zk_a, const double rz_k,
+                                              const double rz_p, const double rm, const bool masking, double &zn,
+                                              double &zw)
+{
+  const double dtfast = p.dtfast;
+  if (s.iif == 1) {
+    const double cff1 = dtfast;
+    zn = zs_a + pmn_a * pn_a * cff1 * rhs;
+    if (masking) zn = zn * rm;
+    zw = 0.5 * (zs_a + zn);
+  } else if (s.predictor) {
+    const double cff1 = 2.0 * dtfast;
+    const double cff4 = 4.0 / 25.0;
+    const double cff5 = 1.0 - 2.0 * cff4;
+    zn = zs_a + pmn_a * pn_a * cff1 * rhs;
+    if (masking) zn = zn * rm;
+    zw = cff5 * zk_a + cff4 * (zs_a + zn);
+  } else {
+    const double cff1 = dtfast * 5.0 / 12.0;
+    const double cff2 = dtfast * 8.0 / 12.0;
+    const double cff3 = dtfast * 1.0 / 12.0;
+    const double cff4 = 2.0 / 5.0;
+    const double cff5 = 1.0 - cff4;
+    const double cff = cff1 * rhs;
+    zn = zs_a + pmn_a * pn_a * (cff + cff2 * rz_k - cff3 * rz_p);
+    if (masking) zn = zn * rm;
+    zw = cff5 * zn + cff4 * zk_a;
+  }
+}
+
 // FUSED (single tile, source-mapped calls only): the free-surface step and the fast-time averaging
 // of k2d_zeta_sm are done here as well -- zeta_new and zwrk are evaluated from the staged DUon/DVom
 // tiles for the (65 x 5) points this workgroup's momentum stencil touches and kept in LDS, so one
@@ -187,6 +220,59 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   const gcd_t ubk = (gcd_t)(c->F.ubar + (long)(s.krhs - 1) * nij);
   const gcd_t vbk = (gcd_t)(c->F.vbar + (long)(s.krhs - 1) * nij);
   const gcd_t zk = (gcd_t)(c->F.zeta + (long)(s.krhs - 1) * nij);
+  // ---- FUSED: every global value the later phases need is requested now, so that the kernel waits for memory once
+  // instead of once per phase (staging, free surface, momentum): the free-surface inputs of this thread's (up to two)
+  // tile points and the momentum inputs of its own point ----
+  constexpr int ZW = BLK_X + 1, ZH = BLK_Y + 1;
+  constexpr int ZIT = (ZW * ZH + BLK_X * BLK_Y - 1) / (BLK_X * BLK_Y);
+  double z_zs[ZIT], z_zk[ZIT], z_rk[ZIT], z_rp[ZIT], z_rm[ZIT];
+  double q_rhoA0 = 0.0, q_rhoS0 = 0.0, q_rhoAw = 0.0, q_rhoSw = 0.0, q_rhoAs = 0.0, q_rhoSs = 0.0;
+  double q_zs0 = 0.0, q_zsw = 0.0, q_zss = 0.0, q_ruf = 0.0, q_rvf = 0.0, q_us = 0.0, q_vs = 0.0;
+  double q_rubk = 0.0, q_rubp = 0.0, q_rvbk = 0.0, q_rvbp = 0.0;
+  double q_Zt = 0.0, q_DU1 = 0.0, q_DU2 = 0.0, q_DV1 = 0.0, q_DV2 = 0.0, q_zkr = 0.0;
+  if constexpr (FUSED) {
+    const int tid = threadIdx.y * BLK_X + threadIdx.x;
+    const gcd_t zsq = (gcd_t)(c->F.zeta + (long)(s.kstp - 1) * nij);
+    const bool am3z = !(s.iif == 1 || s.predictor);
+#pragma unroll
+    for (int r = 0; r < ZIT; r++) {
+      const int q = tid + r * BLK_X * BLK_Y;
+      z_zs[r] = 0.0; z_zk[r] = 0.0; z_rk[r] = 0.0; z_rp[r] = 0.0; z_rm[r] = 1.0;
+      if (q < ZW * ZH) {
+        const int li = 1 + q % ZW, lj = 1 + q / ZW;
+        int gi = it0 - 2 + li, gj = j0 - 2 + lj;
+        if (s.sm) gi = wrap_i(b, gi);
+        else gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
+        gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
+        const long gq = I2(gi, gj);
+        z_zs[r] = zsq[gq];
+        z_zk[r] = zk[gq];
+        if (am3z) {
+          z_rk[r] = GF(rzeta)[gq + (long)(s.kstp - 1) * nij];
+          z_rp[r] = GF(rzeta)[gq + (long)(3 - s.kstp - 1) * nij];
+        }
+        if (p.masking) z_rm[r] = GF(rmask)[gq];
+      }
+    }
+    if (it <= ilast && j <= b.Jend) {
+      const int isrc = ghost_threads ? wrap_i(b, it) : it;
+      const long a = I2(isrc, j), o = I2(it, j);
+      const gcd_t rhoA = (gcd_t)(c->F.rhoA), rhoS = (gcd_t)(c->F.rhoS);
+      q_rhoA0 = rhoA[a]; q_rhoS0 = rhoS[a]; q_rhoAw = rhoA[a - 1]; q_rhoSw = rhoS[a - 1];
+      q_rhoAs = rhoA[a - ni]; q_rhoSs = rhoS[a - ni];
+      q_zs0 = zsq[a]; q_zsw = zsq[a - 1]; q_zss = zsq[a - ni];
+      q_ruf = GF(rufrc)[a]; q_rvf = GF(rvfrc)[a];
+      q_us = GF(ubar)[a + (long)(s.kstp - 1) * nij]; q_vs = GF(vbar)[a + (long)(s.kstp - 1) * nij];
+      if (am3z) {
+        q_rubk = GF(rubar)[a + (long)(s.kstp - 1) * nij]; q_rubp = GF(rubar)[a + (long)(3 - s.kstp - 1) * nij];
+        q_rvbk = GF(rvbar)[a + (long)(s.kstp - 1) * nij]; q_rvbp = GF(rvbar)[a + (long)(3 - s.kstp - 1) * nij];
+      }
+      if (!(s.predictor && s.iif == 1)) {              // the running sums of the fast-time averages (:614-682)
+        q_DU2 = GF(DU_avg2)[o]; q_DV2 = GF(DV_avg2)[o];
+        if (s.predictor) { q_Zt = GF(Zt_avg1)[o]; q_DU1 = GF(DU_avg1)[o]; q_DV1 = GF(DV_avg1)[o]; q_zkr = zk[o]; }
+      }
+    }
+  }
   // ---- stage the stencil fields (target coordinates it0-2.., j0-2..) ----
   {
     const int tid = threadIdx.y * BLK_X + threadIdx.x;
@@ -220,20 +306,24 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   if constexpr (FUSED) {
     // free surface at tile points li = 1..BLK_X+1, lj = 1..BLK_Y+1 (targets it0-1.., j0-1..)
     const int tid = threadIdx.y * BLK_X + threadIdx.x;
-    constexpr int ZW = BLK_X + 1, ZH = BLK_Y + 1;
-    for (int q = tid; q < ZW * ZH; q += BLK_X * BLK_Y) {
-      const int li = 1 + q % ZW, lj = 1 + q / ZW;
-      const int e = lj * TP + li;
-      int gi = it0 - 2 + li, gj = j0 - 2 + lj;
-      if (s.sm) gi = wrap_i(b, gi);
-      else gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
-      gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
-      const double rhs = (sDU[e] - sDU[e + 1]) + (sDV[e] - sDV[e + TP]);
-      double zn, zw;
-      const long gq = I2(gi, gj);
-      zeta_eval(c, s, rhs, gq, nij, MT(pm, gq, gj), MT(pn, gq, gj), zn, zw);
-      sZn[e] = zn;
-      sZw[e] = zw;
+#pragma unroll
+    for (int r = 0; r < ZIT; r++) {
+      const int q = tid + r * BLK_X * BLK_Y;
+      if (q < ZW * ZH) {
+        const int li = 1 + q % ZW, lj = 1 + q / ZW;
+        const int e = lj * TP + li;
+        int gi = it0 - 2 + li, gj = j0 - 2 + lj;
+        if (s.sm) gi = wrap_i(b, gi);
+        else gi = gi < b.LBi ? b.LBi : (gi > b.UBi ? b.UBi : gi);
+        gj = gj < b.LBj ? b.LBj : (gj > b.UBj ? b.UBj : gj);
+        const double rhs = (sDU[e] - sDU[e + 1]) + (sDV[e] - sDV[e + TP]);
+        double zn, zw;
+        const long gq = I2(gi, gj);
+        zeta_eval_pre(p, s, rhs, MT(pm, gq, gj), MT(pn, gq, gj), z_zs[r], z_zk[r], z_rk[r], z_rp[r], z_rm[r],
+                      p.masking != 0, zn, zw);
+        sZn[e] = zn;
+        sZw[e] = zw;
+      }
     }
     __syncthreads();
   }
@@ -299,7 +389,27 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const bool in_i = it >= b.IstrR && it <= b.IendR;
     if (in_i) {
       const bool inU = it >= b.Istr;
-      average(o, t, inU, true);
+      // the thread's own point, with the running sums requested at the top of the kernel (same expressions as `average`)
+      if (s.predictor && iif == 1) {
+        const double cff2 = (-1.0 / 12.0) * p.weight2[iif];
+        GF(Zt_avg1)[o] = 0.0;
+        if (inU) { GF(DU_avg1)[o] = 0.0; GF(DU_avg2)[o] = cff2 * sDU[t]; }
+        GF(DV_avg1)[o] = 0.0; GF(DV_avg2)[o] = cff2 * sDV[t];
+      } else if (s.predictor) {
+        const double cff1 = p.weight1[iif - 2];
+        const double cff2 = (8.0 / 12.0) * p.weight2[iif - 1] - (1.0 / 12.0) * p.weight2[iif];
+        GF(Zt_avg1)[o] = q_Zt + cff1 * q_zkr;
+        if (inU) {
+          GF(DU_avg1)[o] = q_DU1 + cff1 * sDU[t];
+          GF(DU_avg2)[o] = q_DU2 + cff2 * sDU[t];
+        }
+        GF(DV_avg1)[o] = q_DV1 + cff1 * sDV[t];
+        GF(DV_avg2)[o] = q_DV2 + cff2 * sDV[t];
+      } else {
+        const double cff2 = (iif == 1) ? p.weight2[iif - 1] : (5.0 / 12.0) * p.weight2[iif - 1];
+        if (inU) GF(DU_avg2)[o] = q_DU2 + cff2 * sDU[t];
+        GF(DV_avg2)[o] = q_DV2 + cff2 * sDV[t];
+      }
       if (j == b.Jstr && b.JstrR < b.Jstr) average(o - ni, t - TP, inU, false);   // row JstrR = Jstr-1
       if (j == b.Jend && b.JendR > b.Jend) average(o + ni, t + TP, inU, true);    // row JendR = Jend+1
     }
@@ -314,25 +424,28 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
   // resting depth at the point, its western and its southern neighbour (rows j, j, j-1: always inside the array)
   const double h0 = HT(h, a, j), hw = HT(h, a - 1, j), hs = HT(h, a - ni, j - 1);
   const double zw0 = FUSED ? sZw[t] : zwrk[a];
-  const double gz0 = (fac + rhoS[a]) * zw0, gz20 = gz0 * zw0, gsa0 = zw0 * (rhoS[a] - rhoA[a]);
+  const double rS0 = FUSED ? q_rhoS0 : (double)rhoS[a], rA0 = FUSED ? q_rhoA0 : (double)rhoA[a];
+  const double gz0 = (fac + rS0) * zw0, gz20 = gz0 * zw0, gsa0 = zw0 * (rS0 - rA0);
   const double cg = 0.5 * p.g, c3 = 1.0 / 3.0;
   double rhs_u = 0.0, rhs_v = 0.0;
   if (do_u) {
     const long q = a - 1;
     const double zw = FUSED ? sZw[t - 1] : zwrk[q];
-    const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
+    const double rSq = FUSED ? q_rhoSw : (double)rhoS[q], rAq = FUSED ? q_rhoAw : (double)rhoA[q];
+    const double gz = (fac + rSq) * zw, gz2 = gz * zw, gsa = zw * (rSq - rAq);
     rhs_u = cg * MT(on_u, a, j) *
             ((hw + h0) * (gz - gz0) +
-             (hw - h0) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
+             (hw - h0) * (gsa + gsa0 + c3 * (rAq - rA0) * (zw - zw0)) +
              (gz2 - gz20));
   }
   if (do_v) {
     const long q = a - ni;
     const double zw = FUSED ? sZw[t - TP] : zwrk[q];
-    const double gz = (fac + rhoS[q]) * zw, gz2 = gz * zw, gsa = zw * (rhoS[q] - rhoA[q]);
+    const double rSq = FUSED ? q_rhoSs : (double)rhoS[q], rAq = FUSED ? q_rhoAs : (double)rhoA[q];
+    const double gz = (fac + rSq) * zw, gz2 = gz * zw, gsa = zw * (rSq - rAq);
     rhs_v = cg * MT(om_v, a, j) *
             ((hs + h0) * (gz - gz0) +
-             (hs - h0) * (gsa + gsa0 + c3 * (rhoA[q] - rhoA[a]) * (zw - zw0)) +
+             (hs - h0) * (gsa + gsa0 + c3 * (rAq - rA0) * (zw - zw0)) +
              (gz2 - gz20));
   }
   // ---- advection, :1079-1283 ----
@@ -432,7 +545,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const gcd_t ru_n = (gcd_t)(c->F.ru + (long)(s.nnew - 1) * n3w);
     const gcd_t rv_n = (gcd_t)(c->F.rv + (long)(s.nnew - 1) * n3w);
     if (do_u) {
-      const double rf = GF(rufrc)[a] - rhs_u;
+      const double rf = (FUSED ? q_ruf : (double)GF(rufrc)[a]) - rhs_u;
       if (s.iic == s.ntfirst) rhs_u = rhs_u + rf;
       else if (s.iic == s.ntfirst + 1) rhs_u = rhs_u + 1.5 * rf - 0.5 * ru_n[a];
       else rhs_u = rhs_u + (23.0 / 12.0) * rf - (16.0 / 12.0) * ru_n[a] + (5.0 / 12.0) * ru_s[a];
@@ -441,7 +554,7 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       rf_u = rf;
     }
     if (do_v) {
-      const double rf = GF(rvfrc)[a] - rhs_v;
+      const double rf = (FUSED ? q_rvf : (double)GF(rvfrc)[a]) - rhs_v;
       if (s.iic == s.ntfirst) rhs_v = rhs_v + rf;
       else if (s.iic == s.ntfirst + 1) rhs_v = rhs_v + 1.5 * rf - 0.5 * rv_n[a];
       else rhs_v = rhs_v + (23.0 / 12.0) * rf - (16.0 / 12.0) * rv_n[a] + (5.0 / 12.0) * rv_s[a];
@@ -450,12 +563,12 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
       rf_v = rf;
     }
   } else {
-    if (do_u) rhs_u = rhs_u + GF(rufrc)[a];
-    if (do_v) rhs_v = rhs_v + GF(rvfrc)[a];
+    if (do_u) rhs_u = rhs_u + (FUSED ? q_ruf : (double)GF(rufrc)[a]);
+    if (do_v) rhs_v = rhs_v + (FUSED ? q_rvf : (double)GF(rvfrc)[a]);
   }
   // ---- time step, :2098-2255 ----
   const double dtfast = p.dtfast;
-  const double Dn0 = (FUSED ? sZn[t] : zeta_new[a]) + h0, Dst0 = zs[a] + h0;
+  const double Dn0 = (FUSED ? sZn[t] : zeta_new[a]) + h0, Dst0 = (FUSED ? q_zs0 : (double)zs[a]) + h0;
   const int ptsk = 3 - s.kstp;
   const bool am3 = !(s.iif == 1 || s.predictor);
   const double c1 = (s.iif == 1) ? 0.5 * dtfast : dtfast;
@@ -466,12 +579,13 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const long q = a - 1;
     const double cff = (MT(pm, a, j) + MT(pm, q, j)) * (MT(pn, a, j) + MT(pn, q, j));
     const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - 1] : zeta_new[q]) + hw));
-    const double us = GF(ubar)[a + (long)(s.kstp - 1) * nij];
+    const double us = FUSED ? q_us : (double)GF(ubar)[a + (long)(s.kstp - 1) * nij];
+    const double zsq = FUSED ? q_zsw : (double)zs[q];
     double un;
-    if (!am3) un = (us * (Dst0 + (zs[q] + hw)) + cff * c1 * rhs_u) * fc;
-    else un = (us * (Dst0 + (zs[q] + hw)) +
-               cff * (a1 * rhs_u + a2 * GF(rubar)[a + (long)(s.kstp - 1) * nij] -
-                      a3 * GF(rubar)[a + (long)(ptsk - 1) * nij])) * fc;
+    if (!am3) un = (us * (Dst0 + (zsq + hw)) + cff * c1 * rhs_u) * fc;
+    else un = (us * (Dst0 + (zsq + hw)) +
+               cff * (a1 * rhs_u + a2 * (FUSED ? q_rubk : (double)GF(rubar)[a + (long)(s.kstp - 1) * nij]) -
+                      a3 * (FUSED ? q_rubp : (double)GF(rubar)[a + (long)(ptsk - 1) * nij]))) * fc;
     if (masking) un = un * GF(umask)[a];               // MASKING, :2120 / :2175
     if constexpr (WET) {                               // WET_DRY, :2123-2135 / :2178-2184 / :2225-2231
       const double cff7 = wet_factor(GF(umask_wet)[a], un);
@@ -509,12 +623,13 @@ k2d_mom_lds(const RomsDev *__restrict__ c, S2 s, const double *__restrict__ DUon
     const long q = a - ni;
     const double cff = (MT(pm, a, j) + MT(pm, q, j - 1)) * (MT(pn, a, j) + MT(pn, q, j - 1));
     const double fc = 1.0 / (Dn0 + ((FUSED ? sZn[t - TP] : zeta_new[q]) + hs));
-    const double vs = GF(vbar)[a + (long)(s.kstp - 1) * nij];
+    const double vs = FUSED ? q_vs : (double)GF(vbar)[a + (long)(s.kstp - 1) * nij];
+    const double zsq = FUSED ? q_zss : (double)zs[q];
     double vn;
-    if (!am3) vn = (vs * (Dst0 + (zs[q] + hs)) + cff * c1 * rhs_v) * fc;
-    else vn = (vs * (Dst0 + (zs[q] + hs)) +
-               cff * (a1 * rhs_v + a2 * GF(rvbar)[a + (long)(s.kstp - 1) * nij] -
-                      a3 * GF(rvbar)[a + (long)(ptsk - 1) * nij])) * fc;
+    if (!am3) vn = (vs * (Dst0 + (zsq + hs)) + cff * c1 * rhs_v) * fc;
+    else vn = (vs * (Dst0 + (zsq + hs)) +
+               cff * (a1 * rhs_v + a2 * (FUSED ? q_rvbk : (double)GF(rvbar)[a + (long)(s.kstp - 1) * nij]) -
+                      a3 * (FUSED ? q_rvbp : (double)GF(rvbar)[a + (long)(ptsk - 1) * nij]))) * fc;
     if (masking) vn = vn * GF(vmask)[a];               // MASKING, :2145 / :2194
     if constexpr (WET) {                               // WET_DRY, :2148-2160 / :2197-2203 / :2246-2252
       const double cff7 = wet_factor(GF(vmask_wet)[a], vn);
@@ -558,7 +673,7 @@ __global__ void k_rowm_build(const RomsDev *__restrict__ c, double *__restrict__
                                      c->F.om_p, c->F.on_p, c->F.h, c->F.visc2_r, c->F.visc2_p};
   const double *a = A[f];
   if (!a) {                           // array not registered: never read by a kernel either
-    if (threadIdx.x == 0) tab[(long)f * nj + jr] = 0.0;
+    if (threadIdx.x == 0) tab[(long)jr * RM_COUNT + f] = 0.0;
     return;
   }
   // the columns a kernel can read: the tile's own and two on either side (ghost columns; the reference's padding
@@ -569,7 +684,7 @@ __global__ void k_rowm_build(const RomsDev *__restrict__ c, double *__restrict__
   bool differs = false;
   for (int i = i0 + (int)threadIdx.x; i <= i1; i += (int)blockDim.x) differs |= row[i] != v0;
   if (differs) atomicOr(flag + (f >= RM_FIRST_GROUP ? 1 : 0), 1);     // one flag per group
-  if (threadIdx.x == 0) tab[(long)f * nj + jr] = a[(long)jr * ni + (b.Istr - LBi)];
+  if (threadIdx.x == 0) tab[(long)jr * RM_COUNT + f] = a[(long)jr * ni + (b.Istr - LBi)];
 }
 
 }  // namespace
