@@ -182,7 +182,11 @@ typedef struct roms_params {
    * (pmask_wet ... vmask_full); roms_hip_wetdry initialises them (initial.F:438-466), every step2d call updates
    * them.  With wet_dry the barotropic step takes the general launch sequence (flux, free surface, masks,
    * momentum). */
-  int    wet_dry, wet_dry_pad_;
+  int    wet_dry;
+  /* LuvSrc(ng) .or. LwSrc(ng) (mod_scalars.F; point sources / sinks of mod_sources.F).  The library holds no source
+   * table: with a non-zero value every entry refuses to run (error text "point sources"), so that a river application
+   * cannot lose its sources silently; 0 = the application has none. */
+  int    point_sources;
   double Dcrit;
 } roms_params_t;
 enum roms_gls_stab { GLS_GALPERIN = 0, GLS_KANTHA_CLAYSON = 1, GLS_CANUTO_A = 2, GLS_CANUTO_B = 3 };

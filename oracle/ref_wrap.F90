@@ -56,7 +56,7 @@ MODULE ref_wrap_types
     INTEGER(c_int) :: gls_mixing, gls_stability, gls_n2s2_horavg, gls_ri_splines
     REAL(c_double) :: gls_p, gls_m, gls_n, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp, gls_Kmin, gls_Pmin
     REAL(c_double) :: Akk_bak, Akp_bak, Zos
-    INTEGER(c_int) :: wet_dry, wet_dry_pad_
+    INTEGER(c_int) :: wet_dry, point_sources
     REAL(c_double) :: Dcrit
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t

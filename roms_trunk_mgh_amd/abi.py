@@ -111,7 +111,7 @@ class Params(C.Structure):
         ("gls_c1", C.c_double), ("gls_c2", C.c_double), ("gls_c3m", C.c_double), ("gls_c3p", C.c_double),
         ("gls_sigk", C.c_double), ("gls_sigp", C.c_double), ("gls_Kmin", C.c_double), ("gls_Pmin", C.c_double),
         ("Akk_bak", C.c_double), ("Akp_bak", C.c_double), ("Zos", C.c_double),
-        ("wet_dry", C.c_int), ("wet_dry_pad_", C.c_int), ("Dcrit", C.c_double),
+        ("wet_dry", C.c_int), ("point_sources", C.c_int), ("Dcrit", C.c_double),
     ]
 
 

@@ -427,6 +427,8 @@ int roms_entry_check(const char *name)
   if (!g_ctx.have_bounds || !g_ctx.have_params) return roms_fail(name, "bounds/params not set");
   // WET_DRY exists only with MASKING in the reference (wetdry.F:325-345 reads rmask ... vmask unconditionally)
   if (g_ctx.p.wet_dry && !g_ctx.p.masking) return roms_fail(name, "wet_dry = 1 needs masking = 1");
+  // mod_sources.F: the library has no source table -- never run a river application without its rivers
+  if (g_ctx.p.point_sources) return roms_fail(name, "point sources (LuvSrc / LwSrc) are not implemented: keep this application on the host path");
   for (int id = 0; id < FID_COUNT; id++)
     if (!g_ctx.dev[id]) {
       double value;

@@ -40,15 +40,22 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
   double hzk_m1 = 0.0, ohz_m1 = 0.0, ak_m2 = 0.0;
   double ak_m1 = 0.5 * (Akv[c0 - off] + Akv[c0]);           // AK(0)
   double sumH = 0.0;
+  // the six inputs of level k+1 are requested before level k is computed (the kernel waits for memory on 85 % of its
+  // wave-cycles otherwise: a level's loads sit behind the `k <= N` test of its own block)
+  double n_aA = Akv[c0 + nij - off], n_aB = Akv[c0 + nij], n_hA = Hz[c0 - off], n_hB = Hz[c0], n_v = vel[c0], n_r = rhs[c0 + nij];
 #pragma unroll
   for (int k = 1; k <= NMAX; k++) {
     if (k <= N) {
-      const long ck = c0 + (long)(k - 1) * nij;
-      const double ak_0 = 0.5 * (Akv[ck + nij - off] + Akv[ck + nij]);   // AK(k)
-      const double hzk = 0.5 * (Hz[ck - off] + Hz[ck]);
+      const double aA = n_aA, aB = n_aB, hA = n_hA, hB = n_hB, v0 = n_v, r0 = n_r;
+      if (k + 1 <= N) {
+        const long cn = c0 + (long)k * nij;
+        n_aA = Akv[cn + nij - off]; n_aB = Akv[cn + nij]; n_hA = Hz[cn - off]; n_hB = Hz[cn]; n_v = vel[cn]; n_r = rhs[cn + nij];
+      }
+      const double ak_0 = 0.5 * (aA + aB);   // AK(k)
+      const double hzk = 0.5 * (hA + hB);
       const double ohz = 1.0 / hzk;
-      double uv = vel[ck];
-      uv = uv + dc0 * rhs[ck + nij];
+      double uv = v0;
+      uv = uv + dc0 * r0;
       uv = uv * ohz;
       un[k] = uv;
       if (k >= 2) {
@@ -134,7 +141,7 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
 }
 
 template <int NMAX>
-__global__ void __launch_bounds__(BLK_X *BLK_Y)
+__global__ void __launch_bounds__(BLK_X *BLK_Y, (NMAX <= 32 ? 2 : 1))      // two waves per SIMD where the level arrays allow it
 k_uv_column(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
 {
   DEV_PROLOGUE(c)

@@ -47,13 +47,13 @@ __device__ __forceinline__ PsiC psi_coef(const RomsDev *__restrict__ c, long q, 
   o.mask = c->p.masking ? pmaskw(c, q) : 1.0;               // (+ WET_DRY, uv3dmix2_s.h:275, uv3dmix4_s.h:334, :560)
   return o;
 }
-__device__ __forceinline__ double stress_r(const RhoC &m, const double *__restrict__ u, const double *__restrict__ v,
-                                           const double *__restrict__ Hz, long rk, long ni)
+// (u, v, Hz through the global address space: generic pointers made these flat loads, which tie up the LDS / scalar
+// counter as well and cannot be issued past it)
+__device__ __forceinline__ double stress_r(const RhoC &m, gcd_t u, gcd_t v, gcd_t Hz, long rk, long ni)
 {
   return Hz[rk] * 0.5 * (m.pmon * (m.e1 * u[rk + 1] - m.e0 * u[rk]) - m.pnom * (m.n1 * v[rk + ni] - m.n0 * v[rk]));
 }
-__device__ __forceinline__ double stress_p(const PsiC &m, const double *__restrict__ u, const double *__restrict__ v,
-                                           const double *__restrict__ Hz, long qk, long ni, bool msk)
+__device__ __forceinline__ double stress_p(const PsiC &m, gcd_t u, gcd_t v, gcd_t Hz, long qk, long ni, bool msk)
 {
   const double cff = 0.125 * (Hz[qk - 1] + Hz[qk] + Hz[qk - 1 - ni] + Hz[qk - ni]) *
                      (m.pmon * (m.a * v[qk] - m.b * v[qk - 1]) + m.pnom * (m.c * u[qk] - m.d * u[qk - ni]));
@@ -75,13 +75,13 @@ k_uv3dmix2_v2(const RomsDev *__restrict__ c, int nrhs, int nnew, const double *_
   const bool do_u = i >= b.IstrU, do_v = j >= b.JstrV;
   const bool msk = c->p.masking != 0;
   const double dt = c->p.dt;
-  const double *__restrict__ u = BIH ? lapU : c->F.u + (long)(nrhs - 1) * n3r;
-  const double *__restrict__ v = BIH ? lapV : c->F.v + (long)(nrhs - 1) * n3r;
+  const gcd_t u = (gcd_t)(BIH ? lapU : c->F.u + (long)(nrhs - 1) * n3r);
+  const gcd_t v = (gcd_t)(BIH ? lapV : c->F.v + (long)(nrhs - 1) * n3r);
   const double *__restrict__ visc_r = BIH ? c->F.visc4_r : c->F.visc2_r;
   const double *__restrict__ visc_p = BIH ? c->F.visc4_p : c->F.visc2_p;
-  const double *__restrict__ Hz = c->F.Hz;
-  double *__restrict__ un = c->F.u + (long)(nnew - 1) * n3r;
-  double *__restrict__ vn = c->F.v + (long)(nnew - 1) * n3r;
+  const gcd_t Hz = (gcd_t)c->F.Hz;
+  const gd_t un = (gd_t)(c->F.u + (long)(nnew - 1) * n3r);
+  const gd_t vn = (gd_t)(c->F.v + (long)(nnew - 1) * n3r);
   const long a = I2(i, j);
   const double *pm = c->F.pm, *pn = c->F.pn;
   const double cu = dt * 0.25 * (pm[a - 1] + pm[a]) * (pn[a - 1] + pn[a]);

@@ -79,8 +79,8 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: gls_mixing, gls_stability, gls_n2s2_horavg, gls_ri_splines
     REAL(c_double) :: gls_p, gls_m, gls_n, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp, gls_Kmin, gls_Pmin
     REAL(c_double) :: Akk_bak, Akp_bak, Zos
-    !  WET_DRY: switch and the critical depth Dcrit (m)
-    INTEGER(c_int) :: wet_dry, wet_dry_pad_
+    !  WET_DRY: switch and the critical depth Dcrit (m); point_sources: LuvSrc.or.LwSrc (refused when non-zero)
+    INTEGER(c_int) :: wet_dry, point_sources
     REAL(c_double) :: Dcrit
   END TYPE roms_params_t
 

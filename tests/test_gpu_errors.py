@@ -149,3 +149,19 @@ def test_library_defaults_do_not_survive_a_parameter_change():
         h.call("omega", util.step_idx())
     finally:
         h.close()
+
+
+def test_point_sources_are_refused():
+    """An application with rivers (LuvSrc / LwSrc) must not run without them: every entry fails with a message."""
+    import util
+    from roms_trunk_mgh_amd import hip
+    st = util.prepared_state("UPWELLING")
+    st.p.point_sources = 1
+    h = hip.RomsHip(st)
+    try:
+        for entry in ("step2d", "step3d_t", "omega"):
+            with pytest.raises(RuntimeError) as e:
+                h.call(entry, util.step_idx())
+            assert "point sources" in str(e.value)
+    finally:
+        h.close()
