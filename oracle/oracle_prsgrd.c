@@ -26,6 +26,7 @@ static int oracle_prsgrd31(OARGS)
         const int im = i - di, jm = j - dj;
         double cff1 = z_w(i, j, N) - z_r(i, j, N) + z_w(im, jm, N) - z_r(im, jm, N);
         double ph = fac1 * (rho(i, j, N) - rho(im, jm, N)) * cff1;
+        if (p->atm_press) ph = ph + (100.0 / p->rho0) * (F->Pair[I2(i, j)] - F->Pair[I2(im, jm)]);   /* ATM_PRESS, prsgrd31.h:213-215, :294-296 */
         ph = ph + (fac2 + fac1 * (rho(i, j, N) + rho(im, jm, N))) * (z_w(i, j, N) - z_w(im, jm, N));
         phi[i - IminS] = ph;
         const double r = -0.5 * (Hz(i, j, N) + Hz(im, jm, N)) * ph * (dir ? om_v(i, j) : on_u(i, j));
@@ -72,7 +73,10 @@ static int oracle_prsgrd40(OARGS)
 #define FXk(i,j,k) FX_[WS3(i,j,k)]
 #define Pk(i,j,k) P_[WS2(i,j) + (long)(k) * nis * njs]
   for (int j = JstrV - 1; j <= Jend; j++) {
-    for (int i = IstrU - 1; i <= Iend; i++) Pk(i, j, N) = 0.0;
+    for (int i = IstrU - 1; i <= Iend; i++) {
+      Pk(i, j, N) = 0.0;
+      if (p->atm_press) Pk(i, j, N) = Pk(i, j, N) + (100.0 / g) * (F->Pair[I2(i, j)] - 1013.25);   /* ATM_PRESS, prsgrd40.h:187-196 */
+    }
     for (int k = N; k >= 1; k--)
       for (int i = IstrU - 1; i <= Iend; i++) {
         Pk(i, j, k - 1) = Pk(i, j, k) + Hz(i, j, k) * rho(i, j, k);
@@ -178,6 +182,10 @@ static int o_prsgrd_any(OARGS)
     for (int i = IstrU - 1; i <= Iend; i++) {
       cff1 = 1.0 / (z_r(i, j, N) - z_r(i, j, N - 1));
       cff2 = 0.5 * (rho(i, j, N) - rho(i, j, N - 1)) * (z_w(i, j, N) - z_r(i, j, N)) * cff1;
+      if (p->atm_press)                                                  /* ATM_PRESS, prsgrd32.h:229-232, :264-266 */
+        P(i, j, N) = g * z_w(i, j, N) + (100.0 / rho0) * (F->Pair[I2(i, j)] - 1013.25) +
+                     GRho * (rho(i, j, N) + cff2) * (z_w(i, j, N) - z_r(i, j, N));
+      else
       P(i, j, N) = g * z_w(i, j, N) + GRho * (rho(i, j, N) + cff2) * (z_w(i, j, N) - z_r(i, j, N));
     }
     for (int k = N - 1; k >= 1; k--)

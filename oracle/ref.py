@@ -25,6 +25,8 @@ class Ref:
         app = state.cfg["app"] + ("_MASK" if state.p.masking else "")      # <APP>_MASK: built with -DMASKING
         if state.p.wet_dry:
             app += "_WET"                                                  # <APP>_MASK_WET...: built with -DWET_DRY as well
+        if state.p.atm_press:
+            app += "_ATM"                                                  # built with -DATM_PRESS as well
         app += {0: "", 1: "_PG31", 2: "_WJ", 3: "_PJ"}[int(state.p.pgf)]   # prsgrd31.h builds (plain / WJ_GRADP), prsgrd40.h
         if state.p.uv_drag == 3:
             app += "_LOGDRAG"                                              # UV_LOGDRAG instead of the application's law

@@ -58,6 +58,7 @@ MODULE ref_wrap_types
     REAL(c_double) :: Akk_bak, Akp_bak, Zos
     INTEGER(c_int) :: wet_dry, point_sources
     REAL(c_double) :: Dcrit
+    INTEGER(c_int) :: atm_press, atm_press_pad_
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -259,6 +260,9 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   USE set_zeta_mod,     ONLY : set_zeta
   USE rho_eos_mod,      ONLY : rho_eos
   USE prsgrd_mod,       ONLY : prsgrd
+#ifdef ATM_PRESS
+  USE mod_forces
+#endif
   USE t3dmix2_mod,      ONLY : t3dmix2
   USE uv3dmix2_mod,     ONLY : uv3dmix2
 #ifdef REF_DIF4
@@ -303,6 +307,9 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   CALL c_f_pointer (F%pnom_p, a2, (/ni,nj/));   GRID(ng)%pnom_p = a2
   CALL c_f_pointer (F%pmon_u, a2, (/ni,nj/));   GRID(ng)%pmon_u = a2
   CALL c_f_pointer (F%pnom_v, a2, (/ni,nj/));   GRID(ng)%pnom_v = a2
+#ifdef ATM_PRESS
+  CALL c_f_pointer (F%Pair, a2, (/ni,nj/));     FORCES(ng)%Pair = a2
+#endif
 #ifdef MASKING
   CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
   CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2

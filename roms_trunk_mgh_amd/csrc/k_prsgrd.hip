@@ -55,7 +55,11 @@ k_prsgrd_P(const RomsDev *__restrict__ c, double *__restrict__ P)
   {
     const double cff1 = 1.0 / (zr_k1 - zr_k);
     const double cff2 = 0.5 * (rho_k1 - rho_k) * (zwN - zr_k1) * cff1;
-    P[c0 + (long)(N - 1) * nij] = g * zwN + GRho * (rho_k1 + cff2) * (zwN - zr_k1);
+    // ATM_PRESS (prsgrd32.h:229-232, :264-266): + (100 / rho0) (Pair - 1 atm), Pair in mb
+    if (c->p.atm_press)
+      P[c0 + (long)(N - 1) * nij] = g * zwN + (100.0 / c->p.rho0) * (GF(Pair)[c0] - 1013.25) + GRho * (rho_k1 + cff2) * (zwN - zr_k1);
+    else
+      P[c0 + (long)(N - 1) * nij] = g * zwN + GRho * (rho_k1 + cff2) * (zwN - zr_k1);
   }
   double Pk1 = P[c0 + (long)(N - 1) * nij];
   // limited slopes at level N: harm(raw(N), raw(N-1)) with raw(N)=raw(N-1)
@@ -185,9 +189,13 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y) k_prsgrd31(const RomsDev *__rest
   {
     const double cff1 = zw0 - z1 + zww - z1w;
     phix = fac1 * (r1 - r1w) * cff1;
+    const bool atm = c->p.atm_press != 0;                       // ATM_PRESS, prsgrd31.h:213-215, :294-296
+    const double fpa = 100.0 / rho0, pa0 = atm ? (double)GF(Pair)[a] : 0.0;
+    if (atm) phix = phix + fpa * (pa0 - GF(Pair)[aw]);
     phix = phix + (fac2 + fac1 * (r1 + r1w)) * (zw0 - zww);
     const double cff1e = zw0 - z1 + zws - z1s;
     phie = fac1 * (r1 - r1s) * cff1e;
+    if (atm) phie = phie + fpa * (pa0 - GF(Pair)[as]);
     phie = phie + (fac2 + fac1 * (r1 + r1s)) * (zw0 - zws);
     const double hz = Hz[q];
     if (do_u) { const double r = -0.5 * (hz + Hz[qw]) * phix * onu; ru[I3W(i, j, N)] = wet ? r * uw : r; }
@@ -243,6 +251,10 @@ __global__ void __launch_bounds__(BLK_X *BLK_Y) k_prsgrd40(const RomsDev *__rest
   const double dzx = zw[aw + (long)N * nij] - zw[a + (long)N * nij];      // z_w(i-1,j,N) - z_w(i,j,N)
   const double dze = zw[as + (long)N * nij] - zw[a + (long)N * nij];
   double P0 = 0.0, Pw = 0.0, Ps = 0.0;        // P(.,.,k) of the three columns
+  if (c->p.atm_press) {                       // ATM_PRESS, prsgrd40.h:187-196: P(N) = (100 / g) (Pair - 1 atm)
+    const double fpa = 100.0 / c->p.g;
+    P0 = P0 + fpa * (GF(Pair)[a] - 1013.25); Pw = Pw + fpa * (GF(Pair)[aw] - 1013.25); Ps = Ps + fpa * (GF(Pair)[as] - 1013.25);
+  }
   double FCx = 0.0, FCe = 0.0;                // FC(i,k) of the two components
   for (int k = N; k >= 1; k--) {
     const long q = a + (long)(k - 1) * nij, qw = aw + (long)(k - 1) * nij, qs = as + (long)(k - 1) * nij;

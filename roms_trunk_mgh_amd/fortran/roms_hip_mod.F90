@@ -82,6 +82,8 @@ MODULE roms_hip_mod
     !  WET_DRY: switch and the critical depth Dcrit (m); point_sources: LuvSrc.or.LwSrc (refused when non-zero)
     INTEGER(c_int) :: wet_dry, point_sources
     REAL(c_double) :: Dcrit
+    !  ATM_PRESS: Pair (mb) in the baroclinic pressure gradient
+    INTEGER(c_int) :: atm_press, atm_press_pad_
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)

@@ -12,14 +12,26 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main(config, mask=None, pgf=0, basin=False):
+def atm_pressure(st):
+    """A surface air-pressure field (mb) with gradients in both directions, for the ATM_PRESS cases."""
+    b = st.b
+    ii = np.arange(b.LBi, b.UBi + 1, dtype=np.float64)[:, None]
+    jj = np.arange(b.LBj, b.UBj + 1, dtype=np.float64)[None, :]
+    st["Pair"][:] = 1013.25 + 6.0 * np.sin(2.0 * np.pi * 2.0 * (ii - 0.5) / b.Lm) * np.cos(np.pi * (jj - 0.5) / b.Mm) + 0.02 * jj
+
+
+def main(config, mask=None, pgf=0, basin=False, atm=False):
     import oracle
     import util
     from oracle import ref
     ov = {"tnu2": 300.0, "visc2": 800.0} if config != "SEAMOUNT" else {"tnu2": 300.0}
     if basin:                                # no periodic direction: western / eastern edges closed as well
         ov["EWperiodic"] = False
+    if atm:                                  # ATM_PRESS builds (oracle/_ref/<APP>_ATM...)
+        ov["atm_press"] = 1
     st0 = util.prepared_state(config, overrides=ov, mask=mask)
+    if atm:
+        atm_pressure(st0)
     st0.p.pgf = pgf                      # 1, 2: the reference built with prsgrd31.h (plain / WJ_GRADP)
     if util.WET:                         # set_depth.F:168-172: a bed at the resting level is lifted by 1e-14
         st0["h"][7 - st0.b.LBi, 9 - st0.b.LBj] = 0.0
@@ -698,6 +710,8 @@ if __name__ == "__main__":
         main_mpdata(sys.argv[1], mask="island" if "mask" in sys.argv[2] else None, basin=sys.argv[2].split("_")[-1])
     elif len(sys.argv) > 2 and sys.argv[2] == "mask":
         main(sys.argv[1], mask="island")
+    elif len(sys.argv) > 2 and sys.argv[2] in ("atm", "atm_pg31", "atm_pj"):
+        main(sys.argv[1], pgf={"atm": 0, "atm_pg31": 1, "atm_pj": 3}[sys.argv[2]], atm=True)
     elif len(sys.argv) > 2 and sys.argv[2] in ("pg31", "wj", "pj"):
         main(sys.argv[1], pgf={"pg31": 1, "wj": 2, "pj": 3}[sys.argv[2]])
     elif len(sys.argv) > 2 and sys.argv[2] in ("ini", "ini_mask"):

@@ -615,3 +615,49 @@ def test_hip_reproduces_reference_wet_dry_kernels(config):
         finally:
             h.close()
     _wet_check(config, run, 1e-12)
+
+
+def _atm_check(backend, tol):
+    import sys
+    gd = os.path.join(HERE, "golden")
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    import make_golden_atm as ma
+    g = np.load(os.path.join(gd, "ref_atm_UPWELLING.npz"))
+    for variant in ma.VARIANTS:
+        st, s = ma.prepare(variant)
+        st_off = st.copy()
+        st_off.p = type(st.p).from_buffer_copy(st.p)
+        backend(st, s)
+        for k, v in ma.results(st, variant).items():
+            want = g[k]
+            if k.endswith("_sha256"):
+                if tol == 0.0:
+                    assert str(v) == str(want), k
+            else:
+                scale = max(float(np.abs(want).max()), 1e-300)
+                assert float(np.abs(v - want).max()) <= tol * scale, k
+        # the air-pressure term matters
+        st_off.p.atm_press = 0
+        backend(st_off, s)
+        assert not np.array_equal(st_off["ru"], st["ru"]) and not np.array_equal(st_off["rv"], st["rv"])
+
+
+def test_oracle_reproduces_reference_atm_press():
+    """ATM_PRESS: prsgrd32 / prsgrd31 / prsgrd40 of the reference built with the option (make_golden_atm.py)."""
+    import oracle
+    _atm_check(lambda st, s: oracle.Oracle(st).call("prsgrd", s), 0.0)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_reference_atm_press():
+    from roms_trunk_mgh_amd import hip
+
+    def run(st, s):
+        h = hip.RomsHip(st)
+        try:
+            h.call("prsgrd", s)
+            h.to_host()
+        finally:
+            h.close()
+    _atm_check(run, 1e-13)

@@ -164,12 +164,16 @@ def test_100_steps_hsimt():
 
 # ---- HSIMT in the vertical with another scheme in the horizontal: of the four one-sided pairs with MPDATA / HSIMT the
 # only one that is a working configuration of the reference ----
-@pytest.mark.parametrize("hadv", ["U3", "C4", "A4"])
+@pytest.mark.parametrize("hadv", ["U3", "C4", "SU3", "A4", "C2"])
 @pytest.mark.parametrize("kernel", ["pre_step3d", "step3d_t"])
-def test_vertical_hsimt_with_another_horizontal_scheme(hadv, kernel):
+@pytest.mark.parametrize("basin", [False, True])
+def test_vertical_hsimt_with_another_horizontal_scheme(hadv, kernel, basin):
     import oracle
     for config in ("BENCHMARK_TINY", "UPWELLING"):
-        st0 = util.prepared_state(config, overrides={"Hadv": hadv, "Vadv": "HSIMT"})
+        ov = {"Hadv": hadv, "Vadv": "HSIMT"}
+        if basin:                        # no periodic direction: the western / eastern wall rule of the horizontal scheme
+            ov["EWperiodic"] = False
+        st0 = util.prepared_state(config, overrides=ov)
         assert st0.b.NghostPoints == 2
         if kernel == "step3d_t":
             util.hz_weighted_tnew(st0)
