@@ -190,8 +190,9 @@ typedef struct roms_params {
   double Dcrit;
   /* ATM_PRESS (prsgrd32.h:229-232, :264-266; prsgrd31.h:196-198, :213-215, :294-296; prsgrd40.h:187-196): the
    * atmospheric surface pressure Pair (mb, FID_Pair) in the baroclinic pressure gradient (inverse barometer).
-   * PRESS_COMPENSATE (the same term in the Flather condition, u2dbc_im.F:264) is not built. */
-  int    atm_press, atm_press_pad_;
+   * press_compensate = PRESS_COMPENSATE (with ATM_PRESS): the same term in the Flather value of the normal barotropic
+   * velocity (u2dbc_im.F:264-272, :612-620; v2dbc_im.F:266, :615). */
+  int    atm_press, press_compensate;
 } roms_params_t;
 enum roms_gls_stab { GLS_GALPERIN = 0, GLS_KANTHA_CLAYSON = 1, GLS_CANUTO_A = 2, GLS_CANUTO_B = 3 };
 

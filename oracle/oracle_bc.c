@@ -178,6 +178,11 @@ static void bc_edge(const roms_bounds_t *b, const roms_params_t *p, const roms_f
         const double cff = 1.0 / (0.5 * (F->h[qa] + Z[qa] + F->h[qc] + Z[qc]));
         const double Cn = sqrt(p->g * cff);
         const double zb = Zb[e.hi ? qc : qa];                   /* zeta_west(j) = the rho boundary point */
+        if (p->atm_press && p->press_compensate) {             /* ATM_PRESS && PRESS_COMPENSATE, u2dbc_im.F:264-272, :612-620 */
+          const double OneAtm = 1013.25, fac = 100.0 / (p->g * p->rho0);
+          const double zm = 0.5 * (Z[qa] + Z[qc] + fac * (F->Pair[qa] + F->Pair[qc] - 2.0 * OneAtm));
+          x = e.hi ? bry_val + Cn * (zm - zb) : bry_val - Cn * (zm - zb);
+        } else
         x = e.hi ? bry_val + Cn * (0.5 * (Z[qa] + Z[qc]) - zb) : bry_val - Cn * (0.5 * (Z[qa] + Z[qc]) - zb);
       } else if (code == LBC_FLATHER || code == LBC_SHCHEPETKIN || code == LBC_REDUCED) {   /* tangential: u2dbc_im.F:912-932, v2dbc_im.F:886-906 */
         const double cff = dt2d * 0.5 * (pmn[P1 - e.st] + pmn[P1]);

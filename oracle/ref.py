@@ -27,6 +27,8 @@ class Ref:
             app += "_WET"                                                  # <APP>_MASK_WET...: built with -DWET_DRY as well
         if state.p.atm_press:
             app += "_ATM"                                                  # built with -DATM_PRESS as well
+            if state.p.press_compensate:
+                app += "_PC"                                               # ... and -DPRESS_COMPENSATE
         app += {0: "", 1: "_PG31", 2: "_WJ", 3: "_PJ"}[int(state.p.pgf)]   # prsgrd31.h builds (plain / WJ_GRADP), prsgrd40.h
         if state.p.uv_drag == 3:
             app += "_LOGDRAG"                                              # UV_LOGDRAG instead of the application's law

@@ -58,7 +58,7 @@ MODULE ref_wrap_types
     REAL(c_double) :: Akk_bak, Akp_bak, Zos
     INTEGER(c_int) :: wet_dry, point_sources
     REAL(c_double) :: Dcrit
-    INTEGER(c_int) :: atm_press, atm_press_pad_
+    INTEGER(c_int) :: atm_press, press_compensate
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor
@@ -1052,6 +1052,9 @@ FUNCTION ref_bc (kind, b, p, s, F, nout, itrc) BIND(C, name='ref_bc') RESULT(rc)
   CALL c_f_pointer (F%t, a5, (/ni,nj,NN,3,NTT/)); OCEAN(ng)%t = a5
   CALL c_f_pointer (F%Hz, a3, (/ni,nj,NN/));    GRID(ng)%Hz = a3
   CALL c_f_pointer (F%Zt_avg1, a2, (/ni,nj/));  COUPLING(ng)%Zt_avg1 = a2
+#ifdef ATM_PRESS
+  CALL c_f_pointer (F%Pair, a2, (/ni,nj/));     FORCES(ng)%Pair = a2           ! (PRESS_COMPENSATE in the Flather value)
+#endif
   CALL c_f_pointer (F%sustr, a2, (/ni,nj/));    FORCES(ng)%sustr = a2          ! (the reduced-physics condition)
   CALL c_f_pointer (F%svstr, a2, (/ni,nj/));    FORCES(ng)%svstr = a2
   CALL c_f_pointer (F%bustr, a2, (/ni,nj/));    FORCES(ng)%bustr = a2

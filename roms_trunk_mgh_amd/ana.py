@@ -230,6 +230,7 @@ def make_params(cfg, NT):
         p.Zos = 0.02                                # Zos (roms_upwelling.in:378)
     # WET_DRY: DCRIT of roms_*.in (0.10 m in every input script of the reference, e.g. roms_upwelling.in)
     p.atm_press = int(cfg.get("atm_press", 0))       # ATM_PRESS: Pair in the baroclinic pressure gradient
+    p.press_compensate = int(cfg.get("press_compensate", 0))   # ... and (PRESS_COMPENSATE) in the Flather value
     p.wet_dry = int(cfg.get("wet_dry", 0))
     p.Dcrit = float(cfg.get("Dcrit", 0.10))
     return p

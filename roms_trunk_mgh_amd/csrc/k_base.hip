@@ -208,6 +208,11 @@ __global__ void k_edge_bc(const RomsDev *__restrict__ c, BcArgs a)
     const double cff = 1.0 / (0.5 * (c->F.h[qa] + a.Z[qa] + c->F.h[qc] + a.Z[qc]));
     const double Cn = sqrt(p.g * cff);
     const double zb = a.Zb[hi ? qc : qa];
+    if (p.atm_press && p.press_compensate) {         // ATM_PRESS && PRESS_COMPENSATE, u2dbc_im.F:264-272, :612-620
+      const double OneAtm = 1013.25, fac = 100.0 / (p.g * p.rho0);
+      const double zm = 0.5 * (a.Z[qa] + a.Z[qc] + fac * (c->F.Pair[qa] + c->F.Pair[qc] - 2.0 * OneAtm));
+      x = hi ? bry_val + Cn * (zm - zb) : bry_val - Cn * (zm - zb);
+    } else
     x = hi ? bry_val + Cn * (0.5 * (a.Z[qa] + a.Z[qc]) - zb) : bry_val - Cn * (0.5 * (a.Z[qa] + a.Z[qc]) - zb);
   } else if (code == LBC_FLATHER || code == LBC_SHCHEPETKIN || code == LBC_REDUCED) {   // tangential component, Chapman type: u2dbc_im.F:912-932, v2dbc_im.F:886-906
     const double *pmn = we ? c->F.pm : c->F.pn;

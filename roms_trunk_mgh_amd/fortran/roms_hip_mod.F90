@@ -83,7 +83,7 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: wet_dry, point_sources
     REAL(c_double) :: Dcrit
     !  ATM_PRESS: Pair (mb) in the baroclinic pressure gradient
-    INTEGER(c_int) :: atm_press, atm_press_pad_
+    INTEGER(c_int) :: atm_press, press_compensate
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)

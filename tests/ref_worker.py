@@ -167,7 +167,7 @@ def shallow_edges(st):
     h[edge & stretch] = 0.16               # zeta of prepared_state lies within +-0.13: 0 < h + zeta, zeta <= Dcrit - h on a part
 
 
-def main_bc(config, mask=None, rad2d=False):
+def main_bc(config, mask=None, rad2d=False, pc=False):
     """The six lateral boundary-condition routines on the S/N edges, every condition the library offers, for the
     three states of the barotropic stepping (first, predictor, corrector): reference Fortran vs C oracle."""
     import oracle
@@ -178,6 +178,9 @@ def main_bc(config, mask=None, rad2d=False):
     if util.WET:
         shallow_edges(st0)
     st0.p.radiation_2d = int(rad2d)
+    if pc:
+        st0.p.atm_press = st0.p.press_compensate = 1
+        atm_pressure(st0)
     rng = np.random.default_rng(11)
     for name in ("zeta_bry", "ubar_bry", "vbar_bry", "u_bry", "v_bry"):
         st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
@@ -269,13 +272,16 @@ def basin_cases(st0):
                 yield f"{kind}:{code}:{q}", kind, var, st, s, nout, st0.b.NT
 
 
-def main_bc4(config, mask=None, rad2d=False):
+def main_bc4(config, mask=None, rad2d=False, pc=False):
     """The six boundary-condition routines on a basin (four physical edges + corners): reference vs oracle."""
     import oracle
     import util
     from oracle import ref
     st0 = basin_state(config, mask)
     st0.p.radiation_2d = int(rad2d)
+    if pc:
+        st0.p.atm_press = st0.p.press_compensate = 1
+        atm_pressure(st0)
     out = {"masking": int(st0.p.masking), "EWperiodic": int(st0.b.EWperiodic), "cases": {}, "radiation_2d": int(rad2d)}
     bb = ref.Ref(st0.copy()).bounds()
     mine = st0.b.as_dict()
@@ -680,6 +686,7 @@ if __name__ == "__main__":
         import util as _util
         _util.WET = True
         sys.argv.pop()
+    PC = len(sys.argv) > 3 and sys.argv[3] == "pc"            # ATM_PRESS + PRESS_COMPENSATE builds (bc, bc4 modes)
     RAD2D = len(sys.argv) > 3 and sys.argv[3] == "rad2d"      # the builds with -DRADIATION_2D (bc, bc4 modes)
     if len(sys.argv) > 2 and sys.argv[2] == "ana":
         main_ana(sys.argv[1])
@@ -717,8 +724,8 @@ if __name__ == "__main__":
     elif len(sys.argv) > 2 and sys.argv[2] in ("ini", "ini_mask"):
         main_ini(sys.argv[1], mask="island" if sys.argv[2] == "ini_mask" else None)
     elif len(sys.argv) > 2 and sys.argv[2] in ("bc4", "bc4_mask"):
-        main_bc4(sys.argv[1], mask="island" if sys.argv[2] == "bc4_mask" else None, rad2d=RAD2D)
+        main_bc4(sys.argv[1], mask="island" if sys.argv[2] == "bc4_mask" else None, rad2d=RAD2D, pc=PC)
     elif len(sys.argv) > 2 and sys.argv[2] in ("bc", "bc_mask"):
-        main_bc(sys.argv[1], mask="island" if sys.argv[2] == "bc_mask" else None, rad2d=RAD2D)
+        main_bc(sys.argv[1], mask="island" if sys.argv[2] == "bc_mask" else None, rad2d=RAD2D, pc=PC)
     else:
         main(sys.argv[1])

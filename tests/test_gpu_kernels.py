@@ -454,3 +454,35 @@ def test_bulk_flux_eminusp(mask):
     diffs = util.compare_states(st_h, st_o)
     assert all(v <= 1e-11 for v in diffs.values()), diffs
     assert float(np.abs(st_o["evap"]).max()) > 1e-6 and util.max_rel_diff(st_o["stflux"][:, :, 1], st0["stflux"][:, :, 1]) > 1e-6
+
+
+@pytest.mark.parametrize("iif,pred", [(1, 1), (5, 1), (5, 0)])
+def test_step2d_flather_with_press_compensate(iif, pred):
+    """ATM_PRESS + PRESS_COMPENSATE: the air-pressure term in the Flather value (u2dbc_im.F:264-272; pinned in the
+    oracle against the reference built with both options), one barotropic call on a basin with Chapman / Flather edges."""
+    import oracle
+    from roms_trunk_mgh_amd import abi
+    import ref_worker
+    st0 = util.prepared_state("UPWELLING", overrides={"EWperiodic": False, "atm_press": 1, "press_compensate": 1})
+    ref_worker.atm_pressure(st0)
+    for sd in ("west", "east", "south", "north"):
+        st0.p.lbc[abi.LBS[sd]][abi.LBV["zeta"]] = abi.LBC["Cha"]
+        st0.p.lbc[abi.LBS[sd]][abi.LBV["ubar"]] = abi.LBC["Fla"]
+        st0.p.lbc[abi.LBS[sd]][abi.LBV["vbar"]] = abi.LBC["Fla"]
+    rng = np.random.default_rng(4)
+    for name in ("zeta_bry", "ubar_bry", "vbar_bry"):
+        st0[name][:] = 1.0e-2 * rng.standard_normal(st0[name].shape)
+    s = _idx2d(iif, pred, 7)
+    st_o, st_h, st_n = st0.copy(), st0.copy(), st0.copy()
+    st_n.p = type(st0.p).from_buffer_copy(st0.p)
+    st_n.p.press_compensate = 0
+    oracle.Oracle(st_o).call("step2d", s)
+    oracle.Oracle(st_n).call("step2d", s)
+    h = hip.RomsHip(st_h)
+    try:
+        h.call("step2d", s)
+        h.to_host()
+    finally:
+        h.close()
+    assert not util.compare_states(st_h, st_o)
+    assert not np.array_equal(st_o["ubar"], st_n["ubar"]) and not np.array_equal(st_o["vbar"], st_n["vbar"])
