@@ -211,12 +211,15 @@ struct PackArgs {
   int i0[HALO_MAX_MSGS], j0[HALO_MAX_MSGS], wi[HALO_MAX_MSGS], wj[HALO_MAX_MSGS];
   long off[HALO_MAX_MSGS];      // start of message m in buf (doubles)
   double *buf;
+  int LBi, LBj;                 // array origin and pitches: in the kernel arguments, so that the kernel does not
+  long ni, nij;                 // wait for a load from the constant block before it can form its first address
 };
 // All fields of a batch and all messages of an exchange in ONE launch (a step on several tiles issues
 // ~70 exchanges; with a launch per field and side the host could not feed the GPU).
-__global__ void k_pack_multi(const RomsDev *__restrict__ c, PackArgs a)
+__global__ void k_pack_multi(const RomsDev *__restrict__, PackArgs a)
 {
-  DEV_PROLOGUE(c)
+  const int LBi = a.LBi, LBj = a.LBj;
+  const long ni = a.ni, nij = a.nij;
   const int m = blockIdx.z;
   const int wi = a.wi[m], cnt = wi * a.wj[m];
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,6 +351,9 @@ static int exchange_all(const HaloItem *items, int nitems)
   for (int f = 0; f < nitems; f++) nktot += items[f].nk;
   PackArgs pa;
   pa.n = nitems; pa.nktot = (int)nktot;
+  pa.LBi = g_ctx.b.LBi; pa.LBj = g_ctx.b.LBj;
+  pa.ni = g_ctx.b.UBi - g_ctx.b.LBi + 1;
+  pa.nij = pa.ni * (long)(g_ctx.b.UBj - g_ctx.b.LBj + 1);
   {
     int koff = 0;
     for (int f = 0; f < nitems; f++) { pa.A[f] = items[f].A; pa.koff[f] = koff; koff += items[f].nk; }
