@@ -615,3 +615,44 @@ def test_baroclinic_inertial_oscillation(kind):
         assert errs[dt] < 2.0e-3, (dt, w_fit, -f0)
     order = math.log2(errs[300.0] / errs[150.0])
     assert order > 2.6, (order, errs)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_inverse_barometer_is_a_state_of_rest(kind):
+    """ATM_PRESS: under an air-pressure pattern the ocean at rest has the free surface of the inverse barometer,
+    g' zeta + (100 / rho0) (Pair - P0) = const with g' = g (1 + rho'/rho0) (the surface pressure of prsgrd32.h:264-269:
+    g z_w + 100/rho0 (Pair - 1 atm) + g/rho0 rho' (z_w - z_r)).  Started there, the channel stays at rest through the
+    baroclinic pressure gradient, the 2-D/3-D coupling and the barotropic loop; started from a flat surface it does
+    not -- so the term is there, with this sign and this factor."""
+    dt, ndtfast = 300.0, 30
+    st = _channel(dt, ndtfast)
+    st.p.atm_press = 1
+    b = st.b
+    kx = 2.0 * math.pi / (b.Lm * (1.0 / float(st["pm"][3, 3])))
+    x = (np.arange(b.LBi, b.UBi + 1) - 0.5) / float(st["pm"][3, 3])
+    dp = 8.0                                             # mb
+    pair = 1013.25 + dp * np.cos(kx * x)[:, None] * np.ones((1, st.nj))
+    st["Pair"][:] = pair
+    rho_anom = st.p.R0 - st.p.R0 * st.p.Tcoef * (14.0 - st.p.T0) - 1000.0
+    g_eff = G * (1.0 + rho_anom / st.p.rho0)
+    z0 = -(100.0 / st.p.rho0) * (pair - 1013.25) / g_eff
+    amp = 100.0 * dp / (st.p.rho0 * g_eff)               # ~8 cm
+    out = {}
+    for case, zini in (("ib", z0), ("flat", 0.0 * z0)):
+        s2 = st.copy()
+        for lev in range(3):
+            s2["zeta"][:, :, lev] = zini
+        s2["Zt_avg1"][:] = zini
+        be = _backend(kind, s2)
+        m = main3d.Main3D(be)
+        m.initial()
+        m.run(20)
+        if kind == "hip":
+            be.to_host()
+            be.close()
+        out[case] = (float(np.abs(s2.interior("u")[..., m.s.nnew - 1]).max()),
+                     float(np.abs(s2.interior("Zt_avg1") - zini[s2.I(b.Istr, b.Iend), s2.J(b.Jstr, b.Jend)]).max()))
+    c0 = math.sqrt(g_eff * H0)
+    u_scale = amp * c0 / H0                              # the velocity a free adjustment of this surface would reach
+    assert out["ib"][0] < 1.0e-3 * u_scale and out["ib"][1] < 1.0e-3 * amp, (out, u_scale, amp)
+    assert out["flat"][0] > 0.2 * u_scale, (out, u_scale)
