@@ -29,17 +29,22 @@ template <int NMAX>
 __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
                                           gd_t vel, gd_t rhs,
                                           double dc0, double metric, double Davg1,
-                                          gd_t Hflx, gd_t bar, double Davg2, bool masking, double msk, bool wet, double wmsk)
+                                          gd_t Hflx, gd_t bar, double Davg2, bool masking, double msk, bool wet, double wmsk,
+                                          double *__restrict__ un)
 {
+  // un[k * UN_S]: the velocity column, in LDS ([level][thread]) -- the registers it occupied hold hs[k] = Hz(k) +
+  // Hz(k) of the neighbour, the one input all four sweeps need: the sweeps after the first read Hz no more (15 -> 9
+  // loads per level; the mean and the final sweep have no load to wait for at all)
+  constexpr int UN_S = BLK_X * BLK_Y;
   const gcd_t Akv = (gcd_t)(c->F.Akv);
   const gcd_t Hz = (gcd_t)(c->F.Hz);
   const double dt = c->p.dt;
-  double un[NMAX + 1], CF[NMAX + 1], DC[NMAX + 1];
+  double hs[NMAX + 1], CF[NMAX + 1], DC[NMAX + 1];
   CF[0] = 0.0;
   DC[0] = 0.0;
   double hzk_m1 = 0.0, ohz_m1 = 0.0, ak_m2 = 0.0;
   double ak_m1 = 0.5 * (Akv[c0 - off] + Akv[c0]);           // AK(0)
-  double sumH = 0.0;
+  double sumH = 0.0, un_prev = 0.0;
   // the six inputs of level k+1 are requested before level k is computed (the kernel waits for memory on 85 % of its
   // wave-cycles otherwise: a level's loads sit behind the `k <= N` test of its own block)
   double n_aA = Akv[c0 + nij - off], n_aB = Akv[c0 + nij], n_hA = Hz[c0 - off], n_hB = Hz[c0], n_v = vel[c0], n_r = rhs[c0 + nij];
@@ -52,12 +57,14 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
         n_aA = Akv[cn + nij - off]; n_aB = Akv[cn + nij]; n_hA = Hz[cn - off]; n_hB = Hz[cn]; n_v = vel[cn]; n_r = rhs[cn + nij];
       }
       const double ak_0 = 0.5 * (aA + aB);   // AK(k)
-      const double hzk = 0.5 * (hA + hB);
+      hs[k] = hA + hB;
+      const double hzk = 0.5 * hs[k];
       const double ohz = 1.0 / hzk;
       double uv = v0;
       uv = uv + dc0 * r0;
       uv = uv * ohz;
-      un[k] = uv;
+      un[k * UN_S] = uv;
+      const double un_k = uv;
       if (k >= 2) {
         const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
         const double fc = c6 * hzk_m1 - dt * ak_m2 * ohz_m1;
@@ -65,9 +72,10 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
         const double bc = c3 * (hzk_m1 + hzk) + dt * ak_m1 * (ohz_m1 + ohz);
         const double cff = 1.0 / (bc - fc * CF[k - 2]);
         CF[k - 1] = cff * cf;
-        DC[k - 1] = cff * (un[k] - un[k - 1] - fc * DC[k - 2]);
+        DC[k - 1] = cff * (un_k - un_prev - fc * DC[k - 2]);
       }
       sumH = (k == 1) ? hzk : sumH + hzk;
+      un_prev = un_k;
       hzk_m1 = hzk; ohz_m1 = ohz; ak_m2 = ak_m1; ak_m1 = ak_0;
     }
   }
@@ -83,10 +91,9 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
         const double ak = 0.5 * (Akv[c0 + (long)kk * nij - off] + Akv[c0 + (long)kk * nij]);
         dcA = dc * ak;
       }
-      const long ck = c0 + (long)kk * nij;           // level kk+1
-      const double hzk = 0.5 * (Hz[ck - off] + Hz[ck]);
+      const double hzk = 0.5 * hs[kk + 1];           // level kk+1
       const double ohz = 1.0 / hzk;
-      un[kk + 1] = un[kk + 1] + dt * ohz * (dcA_up - dcA);
+      un[(kk + 1) * UN_S] = un[(kk + 1) * UN_S] + dt * ohz * (dcA_up - dcA);
       dcA_up = dcA;
     }
   }
@@ -95,9 +102,8 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
 #pragma unroll
   for (int k = 1; k <= NMAX; k++) {
     if (k <= N) {
-      const long ck = c0 + (long)(k - 1) * nij;
-      const double hzk = 0.5 * (Hz[ck - off] + Hz[ck]);
-      sumU = (k == 1) ? un[k] * hzk : sumU + un[k] * hzk;
+      const double hzk = 0.5 * hs[k];
+      sumU = (k == 1) ? un[k * UN_S] * hzk : sumU + un[k * UN_S] * hzk;
     }
   }
   const double cff1 = 1.0 / (sumH * metric);
@@ -110,12 +116,12 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
   for (int k = 1; k <= NMAX; k++) {
     if (k <= N) {
       const long ck = c0 + (long)(k - 1) * nij;
-      double uv = un[k] - corr;
+      double uv = un[k * UN_S] - corr;
       if (masking) uv = uv * msk;                 // MASKING, step3d_uv.F:558 / :891 (msk: times the wet/dry mask, :561 / :894)
       if (wet) rhs[ck + nij] = rhs[ck + nij] * wmsk;   // WET_DRY, step3d_uv.F:563 / :896: ru / rv(nrhs) as well
       vel[ck] = uv;
-      un[k] = uv;
-      const double dck = cffm * (Hz[ck] + Hz[ck - off]);
+      un[k * UN_S] = uv;
+      const double dck = cffm * hs[k];
       CF[k] = dck;
       DC0 = DC0 + dck;
     }
@@ -129,7 +135,7 @@ __device__ __forceinline__ void uv_column(const RomsDev *__restrict__ c, long c0
 #pragma unroll
   for (int k = NMAX; k >= 1; k--) {
     if (k <= N) {
-      const double h = 0.5 * (Hflx[c0 + (long)(k - 1) * nij] + un[k] * CF[k]);
+      const double h = 0.5 * (Hflx[c0 + (long)(k - 1) * nij] + un[k * UN_S] * CF[k]);
       DC[k] = h;
       FC0 = FC0 + h;
     }
@@ -152,19 +158,21 @@ k_uv_column(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
   const long c0 = I2(i, j);
   const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn;
   const bool masking = c->p.masking != 0, wet = c->p.wet_dry != 0;
+  __shared__ double s_un[(NMAX + 1) * BLK_X * BLK_Y];
+  double *const un = s_un + threadIdx.y * BLK_X + threadIdx.x;
   // blockIdx.z selects the component so that both columns do not share VGPRs
   if (XB.z == 0) {
     if (i < b.IstrU) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - 1]) * (pn[c0] + pn[c0 - 1]);
     uv_column<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), (gd_t)(c->F.ru + (long)(nrhs - 1) * n3w), dc0,
                     GF(on_u)[c0], GF(DU_avg1)[c0], GF(Huon), GF(ubar), GF(DU_avg2)[c0], masking,
-                    masking ? umaskw(c, c0) : 1.0, wet, wet ? (double)GF(umask_wet)[c0] : 1.0);
+                    masking ? umaskw(c, c0) : 1.0, wet, wet ? (double)GF(umask_wet)[c0] : 1.0, un);
   } else {
     if (j < b.JstrV) return;
     const double dc0 = cff * (pm[c0] + pm[c0 - ni]) * (pn[c0] + pn[c0 - ni]);
     uv_column<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), (gd_t)(c->F.rv + (long)(nrhs - 1) * n3w), dc0,
                     GF(om_v)[c0], GF(DV_avg1)[c0], GF(Hvom), GF(vbar), GF(DV_avg2)[c0], masking,
-                    masking ? vmaskw(c, c0) : 1.0, wet, wet ? (double)GF(vmask_wet)[c0] : 1.0);
+                    masking ? vmaskw(c, c0) : 1.0, wet, wet ? (double)GF(vmask_wet)[c0] : 1.0, un);
   }
 }
 
