@@ -193,6 +193,10 @@ typedef struct roms_params {
    * press_compensate = PRESS_COMPENSATE (with ATM_PRESS): the same term in the Flather value of the normal barotropic
    * velocity (u2dbc_im.F:264-272, :612-620; v2dbc_im.F:266, :615). */
   int    atm_press, press_compensate;
+  /* TS_MIX_STABILITY (t3dmix2_s.h:212-218, t3dmix2_geo.h:236-239 / :268 / :301, t3dmix2_iso.h:239 / :271 / :321, the
+   * first operator of t3dmix4_s.h:262 / :308, t3dmix4_geo.h:279 / :311 / :345, t3dmix4_iso.h:287 / :319 / :369): every
+   * tracer difference of the lateral mixing operator is 3/4 of t(nrhs)'s plus 1/4 of t(nstp)'s. */
+  int    ts_mix_stability;
 } roms_params_t;
 enum roms_gls_stab { GLS_GALPERIN = 0, GLS_KANTHA_CLAYSON = 1, GLS_CANUTO_A = 2, GLS_CANUTO_B = 3 };
 

@@ -229,6 +229,12 @@ static inline double o_wet_factor(double mask_wet, double vel)
   const double cff6 = 0.5 + copysign(0.5, vel) * mask_wet;
   return 0.5 * mask_wet * cff5 + cff6 * (1.0 - cff5);
 }
+/* TS_MIX_STABILITY: the tracer difference a - b of the lateral mixing operators, a2 - b2 the same difference of the
+ * t(nstp) level (t3dmix2_s.h:212-218 and the like sites of t3dmix2_geo/_iso.h and the first operator of t3dmix4_*.h) */
+static inline double o_tdiff(int stab, double a, double b, double a2, double b2)
+{
+  return stab ? 0.75 * (a - b) + 0.25 * (a2 - b2) : a - b;
+}
 int oracle_ini_zeta(OARGS);        /* ini_fields.F:836 */
 int oracle_ini_fields(OARGS);      /* ini_fields.F:106 */
 int oracle_step2d_loop(const roms_bounds_t *b, const roms_params_t *p, roms_step_idx_t *s,

@@ -11,7 +11,7 @@
 static int t3dmix2_geo(OARGS)
 {
   ORACLE_PROLOGUE
-  const int nrhs = s->nrhs, nnew = s->nnew;
+  const int nrhs = s->nrhs, nnew = s->nnew, nstp = s->nstp, stab = p->ts_mix_stability;
   const double dt = p->dt;
   double cff, cff1, cff2, cff3, cff4;
   const long n2 = nis * njs;
@@ -38,7 +38,8 @@ static int t3dmix2_geo(OARGS)
             if (p->masking) cff = cff * umask(i, j);                                  /* MASKING, t3dmix2_geo.h:228 */
             if (p->wet_dry) cff = cff * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
             dZdx(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i - 1, j, k + 1));
-            dTdx(i, j, k2) = cff * (t(i, j, k + 1, nrhs, itrc) - t(i - 1, j, k + 1, nrhs, itrc));
+            dTdx(i, j, k2) = cff * o_tdiff(stab, t(i, j, k + 1, nrhs, itrc), t(i - 1, j, k + 1, nrhs, itrc),   /* TS_MIX_STABILITY, :236 */
+                                     t(i, j, k + 1, nstp, itrc), t(i - 1, j, k + 1, nstp, itrc));
           }
         for (int j = Jstr; j <= Jend + 1; j++)
           for (int i = Istr; i <= Iend; i++) {
@@ -46,7 +47,8 @@ static int t3dmix2_geo(OARGS)
             if (p->masking) cff = cff * vmask(i, j);                                  /* MASKING, t3dmix2_geo.h:260 */
             if (p->wet_dry) cff = cff * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
             dZde(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i, j - 1, k + 1));
-            dTde(i, j, k2) = cff * (t(i, j, k + 1, nrhs, itrc) - t(i, j - 1, k + 1, nrhs, itrc));
+            dTde(i, j, k2) = cff * o_tdiff(stab, t(i, j, k + 1, nrhs, itrc), t(i, j - 1, k + 1, nrhs, itrc),   /* :268 */
+                                     t(i, j, k + 1, nstp, itrc), t(i, j - 1, k + 1, nstp, itrc));
           }
       }
       if (k == 0 || k == N) {
@@ -56,7 +58,8 @@ static int t3dmix2_geo(OARGS)
         for (int j = Jstr - 1; j <= Jend + 1; j++)
           for (int i = Istr - 1; i <= Iend + 1; i++) {
             cff = 1.0 / (z_r(i, j, k + 1) - z_r(i, j, k));
-            dTdz(i, j, k2) = cff * (t(i, j, k + 1, nrhs, itrc) - t(i, j, k, nrhs, itrc));
+            dTdz(i, j, k2) = cff * o_tdiff(stab, t(i, j, k + 1, nrhs, itrc), t(i, j, k, nrhs, itrc),           /* :301 */
+                                     t(i, j, k + 1, nstp, itrc), t(i, j, k, nstp, itrc));
           }
       }
       if (k > 0) {
@@ -121,7 +124,7 @@ static int t3dmix2_geo(OARGS)
 static int t3dmix2_s(OARGS)
 {
   ORACLE_PROLOGUE
-  const int nrhs = s->nrhs, nnew = s->nnew;
+  const int nrhs = s->nrhs, nnew = s->nnew, nstp = s->nstp, stab = p->ts_mix_stability;
   const double dt = p->dt;
   double cff, cff1, cff2, cff3;
   double *FE_ = walloc(nis * njs), *FX_ = walloc(nis * njs);
@@ -132,14 +135,18 @@ static int t3dmix2_s(OARGS)
       for (int j = Jstr; j <= Jend; j++)
         for (int i = Istr; i <= Iend + 1; i++) {
           cff = 0.25 * (diff2(i, j, itrc) + diff2(i - 1, j, itrc)) * pmon_u(i, j);
-          FX(i, j) = cff * (Hz(i, j, k) + Hz(i - 1, j, k)) * (t(i, j, k, nrhs, itrc) - t(i - 1, j, k, nrhs, itrc));
+          FX(i, j) = cff * (Hz(i, j, k) + Hz(i - 1, j, k)) *
+                     o_tdiff(stab, t(i, j, k, nrhs, itrc), t(i - 1, j, k, nrhs, itrc),         /* TS_MIX_STABILITY, :212 */
+                             t(i, j, k, nstp, itrc), t(i - 1, j, k, nstp, itrc));
           if (p->masking) FX(i, j) = FX(i, j) * umask(i, j);                          /* MASKING, t3dmix2_s.h:235 */
           if (p->wet_dry) FX(i, j) = FX(i, j) * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
         }
       for (int j = Jstr; j <= Jend + 1; j++)
         for (int i = Istr; i <= Iend; i++) {
           cff = 0.25 * (diff2(i, j, itrc) + diff2(i, j - 1, itrc)) * pnom_v(i, j);
-          FE(i, j) = cff * (Hz(i, j, k) + Hz(i, j - 1, k)) * (t(i, j, k, nrhs, itrc) - t(i, j - 1, k, nrhs, itrc));
+          FE(i, j) = cff * (Hz(i, j, k) + Hz(i, j - 1, k)) *
+                     o_tdiff(stab, t(i, j, k, nrhs, itrc), t(i, j - 1, k, nrhs, itrc),         /* :252 */
+                             t(i, j, k, nstp, itrc), t(i, j - 1, k, nstp, itrc));
           if (p->masking) FE(i, j) = FE(i, j) * vmask(i, j);                          /* MASKING, t3dmix2_s.h:275 */
           if (p->wet_dry) FE(i, j) = FE(i, j) * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
         }

@@ -30,7 +30,7 @@
 static int t3dmix4_s(OARGS)
 {
   ORACLE_PROLOGUE
-  const int nrhs = s->nrhs, nnew = s->nnew;
+  const int nrhs = s->nrhs, nnew = s->nnew, nstp = s->nstp, stab = p->ts_mix_stability;
   const double dt = p->dt;
   double cff, cff1, cff2, cff3;
   double *FE_ = walloc(nis * njs), *FX_ = walloc(nis * njs), *LapT_ = walloc(nis * njs);
@@ -46,14 +46,18 @@ static int t3dmix4_s(OARGS)
           cff = 0.25 * (diff4(i, j, itrc) + diff4(i - 1, j, itrc)) * pmon_u(i, j);
           if (p->masking) cff = cff * umask(i, j);
           if (p->wet_dry) cff = cff * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
-          FX(i, j) = cff * (Hz(i, j, k) + Hz(i - 1, j, k)) * (t(i, j, k, nrhs, itrc) - t(i - 1, j, k, nrhs, itrc));
+          FX(i, j) = cff * (Hz(i, j, k) + Hz(i - 1, j, k)) *
+                     o_tdiff(stab, t(i, j, k, nrhs, itrc), t(i - 1, j, k, nrhs, itrc),         /* TS_MIX_STABILITY, :262 */
+                             t(i, j, k, nstp, itrc), t(i - 1, j, k, nstp, itrc));
         }
       for (int j = Jmin; j <= Jmax + 1; j++)
         for (int i = Imin; i <= Imax; i++) {
           cff = 0.25 * (diff4(i, j, itrc) + diff4(i, j - 1, itrc)) * pnom_v(i, j);
           if (p->masking) cff = cff * vmask(i, j);
           if (p->wet_dry) cff = cff * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
-          FE(i, j) = cff * (Hz(i, j, k) + Hz(i, j - 1, k)) * (t(i, j, k, nrhs, itrc) - t(i, j - 1, k, nrhs, itrc));
+          FE(i, j) = cff * (Hz(i, j, k) + Hz(i, j - 1, k)) *
+                     o_tdiff(stab, t(i, j, k, nrhs, itrc), t(i, j - 1, k, nrhs, itrc),         /* :308 */
+                             t(i, j, k, nstp, itrc), t(i, j - 1, k, nstp, itrc));
         }
       for (int j = Jmin; j <= Jmax; j++)
         for (int i = Imin; i <= Imax; i++) {
@@ -116,7 +120,7 @@ static int t3dmix4_s(OARGS)
  * k = 1..N) on the range (i0:i1, j0:j1): :243-455 with S = t(nrhs) and out = LapT (first = 1), :577-775 with S = LapT
  * and t(nnew) = t(nnew) - dt * (...) (first = 0).  The two blocks of the reference differ in nothing else. */
 static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_step_idx_t *s, roms_fields_t *F,
-                         int itrc, const double *S_, double *out_, int i0, int i1, int j0, int j1, int first)
+                         int itrc, const double *S_, const double *S2_, double *out_, int i0, int i1, int j0, int j1, int first)
 {
   ORACLE_PROLOGUE
   const int nnew = s->nnew;
@@ -127,6 +131,8 @@ static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const r
   double *dTdz_ = walloc(2 * n2), *dTdx_ = walloc(2 * n2), *dTde_ = walloc(2 * n2);
   double *dZdx_ = walloc(2 * n2), *dZde_ = walloc(2 * n2);
 #define S(i,j,k) S_[WS3(i,j,k)]
+/* the difference S(a) - S(b); with TS_MIX_STABILITY (S2_ = t(nstp), first operator only) the weighted one */
+#define SD(ia,ja,ka,ib,jb,kb) o_tdiff(S2_ != NULL, S(ia,ja,ka), S(ib,jb,kb), S2_ ? S2_[WS3(ia,ja,ka)] : 0.0, S2_ ? S2_[WS3(ib,jb,kb)] : 0.0)
 #define OUT(i,j,k) out_[WS3(i,j,k)]
 #define FE(i,j) FE_[WS2(i,j)]
 #define FX(i,j) FX_[WS2(i,j)]
@@ -147,7 +153,7 @@ static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const r
           if (p->masking) cff = cff * umask(i, j);
           if (p->wet_dry) cff = cff * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
           dZdx(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i - 1, j, k + 1));
-          dTdx(i, j, k2) = cff * (S(i, j, k + 1) - S(i - 1, j, k + 1));
+          dTdx(i, j, k2) = cff * SD(i, j, k + 1, i - 1, j, k + 1);
         }
       for (int j = j0; j <= j1 + 1; j++)
         for (int i = i0; i <= i1; i++) {
@@ -155,7 +161,7 @@ static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const r
           if (p->masking) cff = cff * vmask(i, j);
           if (p->wet_dry) cff = cff * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
           dZde(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i, j - 1, k + 1));
-          dTde(i, j, k2) = cff * (S(i, j, k + 1) - S(i, j - 1, k + 1));
+          dTde(i, j, k2) = cff * SD(i, j, k + 1, i, j - 1, k + 1);
         }
     }
     if (k == 0 || k == N) {
@@ -165,7 +171,7 @@ static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const r
       for (int j = j0 - 1; j <= j1 + 1; j++)
         for (int i = i0 - 1; i <= i1 + 1; i++) {
           cff = 1.0 / (z_r(i, j, k + 1) - z_r(i, j, k));
-          dTdz(i, j, k2) = cff * (S(i, j, k + 1) - S(i, j, k));
+          dTdz(i, j, k2) = cff * SD(i, j, k + 1, i, j, k);
         }
     }
     if (k > 0) {
@@ -227,6 +233,7 @@ static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const r
   }
   free(FE_); free(FX_); free(FS_); free(dTdz_); free(dTdx_); free(dTde_); free(dZdx_); free(dZde_);
 #undef S
+#undef SD
 #undef OUT
 #undef FE
 #undef FX
@@ -244,7 +251,7 @@ static void rotated_pass(const roms_bounds_t *b, const roms_params_t *p, const r
  * differences of the potential density take the place of the geopotential operator's dZdx / dZde, the vertical tracer
  * difference is scaled by -1 / MAX(pden(k) - pden(k+1), eps), and MIN / MAX change places. */
 static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_step_idx_t *s, roms_fields_t *F,
-                     int itrc, const double *S_, double *out_, int i0, int i1, int j0, int j1, int mode)
+                     int itrc, const double *S_, const double *S2_, double *out_, int i0, int i1, int j0, int j1, int mode)
 {
   ORACLE_PROLOGUE
   const int nnew = s->nnew;
@@ -256,6 +263,8 @@ static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_
   double *dTdr_ = walloc(2 * n2), *dTdx_ = walloc(2 * n2), *dTde_ = walloc(2 * n2);
   double *dRdx_ = walloc(2 * n2), *dRde_ = walloc(2 * n2);
 #define S(i,j,k) S_[WS3(i,j,k)]
+/* the difference S(a) - S(b); with TS_MIX_STABILITY (S2_ = t(nstp), first operator only) the weighted one */
+#define SD(ia,ja,ka,ib,jb,kb) o_tdiff(S2_ != NULL, S(ia,ja,ka), S(ib,jb,kb), S2_ ? S2_[WS3(ia,ja,ka)] : 0.0, S2_ ? S2_[WS3(ib,jb,kb)] : 0.0)
 #define OUT(i,j,k) out_[WS3(i,j,k)]
 #define FE(i,j) FE_[WS2(i,j)]
 #define FX(i,j) FX_[WS2(i,j)]
@@ -277,7 +286,7 @@ static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_
           if (p->masking) cff = cff * umask(i, j);
           if (p->wet_dry) cff = cff * umask_wet(i, j);           /* WET_DRY: the next block of the same file */
           dRdx(i, j, k2) = cff * (pden(i, j, k + 1) - pden(i - 1, j, k + 1));
-          dTdx(i, j, k2) = cff * (S(i, j, k + 1) - S(i - 1, j, k + 1));
+          dTdx(i, j, k2) = cff * SD(i, j, k + 1, i - 1, j, k + 1);
         }
       for (int j = j0; j <= j1 + 1; j++)
         for (int i = i0; i <= i1; i++) {
@@ -285,7 +294,7 @@ static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_
           if (p->masking) cff = cff * vmask(i, j);
           if (p->wet_dry) cff = cff * vmask_wet(i, j);           /* WET_DRY: the next block of the same file */
           dRde(i, j, k2) = cff * (pden(i, j, k + 1) - pden(i, j - 1, k + 1));
-          dTde(i, j, k2) = cff * (S(i, j, k + 1) - S(i, j - 1, k + 1));
+          dTde(i, j, k2) = cff * SD(i, j, k + 1, i, j - 1, k + 1);
         }
     }
     if (k == 0 || k == N) {
@@ -296,7 +305,7 @@ static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_
         for (int i = i0 - 1; i <= i1 + 1; i++) {
           cff1 = MAX(pden(i, j, k) - pden(i, j, k + 1), eps);
           cff = -1.0 / cff1;
-          dTdr(i, j, k2) = cff * (S(i, j, k + 1) - S(i, j, k));
+          dTdr(i, j, k2) = cff * SD(i, j, k + 1, i, j, k);
           FS(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i, j, k));
         }
     }
@@ -369,6 +378,7 @@ static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_
   }
   free(FE_); free(FX_); free(FS_); free(dTdr_); free(dTdx_); free(dTde_); free(dRdx_); free(dRde_);
 #undef S
+#undef SD
 #undef OUT
 #undef FE
 #undef FX
@@ -385,15 +395,19 @@ static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_
 int oracle_t3dmix2_iso(OARGS)
 {
   ORACLE_PROLOGUE
-  const int nrhs = s->nrhs;
+  const int nrhs = s->nrhs, nstp = s->nstp;
   double *T_ = walloc(nis * njs * N);
+  double *T2_ = p->ts_mix_stability ? walloc(nis * njs * N) : NULL;      /* TS_MIX_STABILITY: t(nstp) beside t(nrhs) */
   for (int itrc = 1; itrc <= NT; itrc++) {
     for (int k = 1; k <= N; k++)
       for (int j = MAX(JminS, LBj); j <= MIN(JmaxS, UBj); j++)
-        for (int i = MAX(IminS, LBi); i <= MIN(ImaxS, UBi); i++) T_[WS3(i, j, k)] = t(i, j, k, nrhs, itrc);
-    iso_pass(b, p, s, F, itrc, T_, NULL, Istr, Iend, Jstr, Jend, 0);
+        for (int i = MAX(IminS, LBi); i <= MIN(ImaxS, UBi); i++) {
+          T_[WS3(i, j, k)] = t(i, j, k, nrhs, itrc);
+          if (T2_) T2_[WS3(i, j, k)] = t(i, j, k, nstp, itrc);
+        }
+    iso_pass(b, p, s, F, itrc, T_, T2_, NULL, Istr, Iend, Jstr, Jend, 0);
   }
-  free(T_);
+  free(T_); free(T2_);
   return 0;
 }
 
@@ -402,18 +416,22 @@ int oracle_t3dmix2_iso(OARGS)
 static int t3dmix4_rot(OARGS, int iso)
 {
   ORACLE_PROLOGUE
-  const int nrhs = s->nrhs;
+  const int nrhs = s->nrhs, nstp = s->nstp;
   const long n3s = nis * njs * N;
   double *T_ = walloc(n3s), *LapT_ = walloc(n3s);
+  double *T2_ = p->ts_mix_stability ? walloc(n3s) : NULL;               /* TS_MIX_STABILITY: t(nstp) beside t(nrhs) */
 #define LapT(i,j,k) LapT_[WS3(i,j,k)]
   FIRST_RANGE
   for (int itrc = 1; itrc <= NT; itrc++) {
     /* t(nrhs) on the private extents (the first pass reads it on Imin-1:Imax+1, Jmin-1:Jmax+1) */
     for (int k = 1; k <= N; k++)
       for (int j = MAX(JminS, LBj); j <= MIN(JmaxS, UBj); j++)
-        for (int i = MAX(IminS, LBi); i <= MIN(ImaxS, UBi); i++) T_[WS3(i, j, k)] = t(i, j, k, nrhs, itrc);
-    if (iso) iso_pass(b, p, s, F, itrc, T_, LapT_, Imin, Imax, Jmin, Jmax, 1);
-    else rotated_pass(b, p, s, F, itrc, T_, LapT_, Imin, Imax, Jmin, Jmax, 1);
+        for (int i = MAX(IminS, LBi); i <= MIN(ImaxS, UBi); i++) {
+          T_[WS3(i, j, k)] = t(i, j, k, nrhs, itrc);
+          if (T2_) T2_[WS3(i, j, k)] = t(i, j, k, nstp, itrc);
+        }
+    if (iso) iso_pass(b, p, s, F, itrc, T_, T2_, LapT_, Imin, Imax, Jmin, Jmax, 1);
+    else rotated_pass(b, p, s, F, itrc, T_, T2_, LapT_, Imin, Imax, Jmin, Jmax, 1);
     /* physical edges and corners of the first result, :457-575 */
     if (!EWperiodic) {
       if (west_edge) {
@@ -447,10 +465,10 @@ static int t3dmix4_rot(OARGS, int iso)
         if (north_edge && east_edge) LapT(Iend + 1, Jend + 1, k) = 0.5 * (LapT(Iend, Jend + 1, k) + LapT(Iend + 1, Jend, k));
       }
     }
-    if (iso) iso_pass(b, p, s, F, itrc, LapT_, NULL, Istr, Iend, Jstr, Jend, 2);
-    else rotated_pass(b, p, s, F, itrc, LapT_, NULL, Istr, Iend, Jstr, Jend, 0);
+    if (iso) iso_pass(b, p, s, F, itrc, LapT_, NULL, NULL, Istr, Iend, Jstr, Jend, 2);
+    else rotated_pass(b, p, s, F, itrc, LapT_, NULL, NULL, Istr, Iend, Jstr, Jend, 0);
   }
-  free(T_); free(LapT_);
+  free(T_); free(T2_); free(LapT_);
 #undef LapT
   return 0;
 }

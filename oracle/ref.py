@@ -32,6 +32,8 @@ class Ref:
         app += {0: "", 1: "_PG31", 2: "_WJ", 3: "_PJ"}[int(state.p.pgf)]   # prsgrd31.h builds (plain / WJ_GRADP), prsgrd40.h
         if state.p.uv_drag == 3:
             app += "_LOGDRAG"                                              # UV_LOGDRAG instead of the application's law
+        if state.p.ts_mix_stability:
+            app += "_STAB"                                                 # built with -DTS_MIX_STABILITY as well
         if state.p.mix_iso_ts:
             app += "_ISO"                                                  # ... and MIX_ISO_TS as the tracer mixing choice
         elif state.p.ts_dif4 or state.p.uv_vis4:
@@ -50,7 +52,7 @@ class Ref:
         want = [C.sizeof(abi.Bounds), C.sizeof(abi.Params), C.sizeof(abi.StepIdx), C.sizeof(abi.Fields)]
         got = [self.l.ref_abi_sizeof(i) for i in range(4)]
         if want != got:
-            raise RuntimeError(f"ref ABI mismatch python={want} fortran={got}")
+            raise RuntimeError(f"ref ABI mismatch ({app}) python={want} fortran={got}")
         self.l.ref_setup.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params)]
         rc = self.l.ref_setup(C.byref(state.b), C.byref(state.p))
         if rc != 0:

@@ -20,6 +20,16 @@ namespace {
 __device__ __forceinline__ double dmin0(double a) { return a < 0.0 ? a : 0.0; }   // MIN(a,0)
 __device__ __forceinline__ double dmax0(double a) { return a > 0.0 ? a : 0.0; }   // MAX(a,0)
 
+// The tracer difference a - b of the operators' first application; STAB (TS_MIX_STABILITY, t3dmix2_s.h:212-218,
+// t3dmix2_geo.h:236 / :268 / :301 and the like sites of t3dmix2_iso.h and of the first operator of t3dmix4_*.h): 3/4 of
+// it plus 1/4 of the same difference a2 - b2 of t(nstp)
+template <bool STAB>
+__device__ __forceinline__ double tdiff(double a, double b, double a2, double b2)
+{
+  if constexpr (STAB) return 0.75 * (a - b) + 0.25 * (a2 - b2);
+  else return a - b;
+}
+
 // The range and the edge rule of the first biharmonic operator (t3dmix4_s.h:262-275, :347-405): one point beyond the
 // tile inside the grid; outside a physical edge LapT is zero where the tracer's condition is closed, a copy of the
 // first inside value otherwise.  (The corner values the reference also sets are never read by the second operator.)
@@ -28,6 +38,7 @@ struct Lap4 {
   int i0, i1, j0, j1;           // Imin:Imax, Jmin:Jmax
   int closed[4];                // [LBS_WEST .. LBS_NORTH]
   int itrc;
+  int nstp;                     // STAB kernels: the time level of the 1/4 part
 };
 
 template <int MODE>
@@ -50,7 +61,8 @@ __device__ __forceinline__ void lap4_store(const roms_bounds_t &b, const Lap4 &L
 // ISO (MIX_ISO_TS): t3dmix2_iso.h:193-437 / t3dmix4_iso.h:262-805 -- the same sweep with the horizontal differences
 // of the potential density in the place of those of z_r, the vertical tracer difference scaled by
 // -1 / MAX(pden(k) - pden(k+1), eps), MIN and MAX exchanged, and the vertical flux times that scale times dz.
-template <int MODE, bool ISO>
+// STAB (MODE 0 / 1): TS_MIX_STABILITY -- t(nstp) is read beside t(nrhs) and every tracer difference is tdiff<true>.
+template <int MODE, bool ISO, bool STAB = false>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
 {
@@ -65,6 +77,8 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   if (i > ihi || j > jhi) return;
   const double dt = c->p.dt;
   const double *__restrict__ T = MODE == 2 ? L.lap : c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
+  static_assert(!(STAB && MODE == 2), "the second biharmonic operator acts on LapT alone");
+  const double *__restrict__ S = STAB ? c->F.t + ((long)(L.nstp - 1) + 3L * (itrc - 1)) * n3r : T;
   double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
   const double *__restrict__ z_r = ISO ? c->F.pden : c->F.z_r;      // the field whose horizontal differences give the slopes
   const double *__restrict__ zz = c->F.z_r;                          // ISO: depths of the own column
@@ -104,14 +118,17 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   // Software pipeline (cf. k_step3d_t_pipe): the 16 loads an iteration consumes -- T and z_r of level
   // k+1 at the five columns, Hz of level k at the five columns, t(nnew) of level k -- are issued one
   // iteration ahead, so their latency overlaps the arithmetic of the previous level.
-  struct LvIn { double Tm1, T01, Tp1, Ts1, Tn1, Zm1, Z01, Zp1, Zs1, Zn1, hz0, hzm, hzp, hzs, hzn, tn, zz1; };
-  const gcd_t gT = (gcd_t)T, gZ = (gcd_t)z_r, gHz = (gcd_t)Hz;
+  struct LvIn { double Tm1, T01, Tp1, Ts1, Tn1, Zm1, Z01, Zp1, Zs1, Zn1, hz0, hzm, hzp, hzs, hzn, tn, zz1;
+                double Sm1, S01, Sp1, Ss1, Sn1; };
+  const gcd_t gT = (gcd_t)T, gS = (gcd_t)S, gZ = (gcd_t)z_r, gHz = (gcd_t)Hz;
   const gd_t gtn = (gd_t)tn;
   auto load_level = [&](int k) {
     LvIn L;
     const long ck = c0 + (long)(k - 1) * nij;
     const long cu = (k < N) ? ck + nij : ck;               // level k+1 (clamped at the top; unused there)
     L.Tm1 = gT[cu - 1]; L.T01 = gT[cu]; L.Tp1 = gT[cu + 1]; L.Ts1 = gT[cu - ni]; L.Tn1 = gT[cu + ni];
+    if constexpr (STAB) { L.Sm1 = gS[cu - 1]; L.S01 = gS[cu]; L.Sp1 = gS[cu + 1]; L.Ss1 = gS[cu - ni]; L.Sn1 = gS[cu + ni]; }
+    else L.Sm1 = L.S01 = L.Sp1 = L.Ss1 = L.Sn1 = 0.0;
     L.Zm1 = gZ[cu - 1]; L.Z01 = gZ[cu]; L.Zp1 = gZ[cu + 1]; L.Zs1 = gZ[cu - ni]; L.Zn1 = gZ[cu + ni];
     L.hz0 = gHz[ck]; L.hzm = gHz[ck - 1]; L.hzp = gHz[ck + 1]; L.hzs = gHz[ck - ni]; L.hzn = gHz[ck + ni];
     L.tn = gtn[ck];
@@ -120,13 +137,15 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   };
   // values of level k carried for the vertical differences
   double Tm = T[c0 - 1], T0 = T[c0], Tp = T[c0 + 1], Ts = T[c0 - ni], Tn = T[c0 + ni];
+  double Sm = 0.0, S0 = 0.0, Sp = 0.0, Ss = 0.0, Sn = 0.0;
+  if constexpr (STAB) { Sm = S[c0 - 1]; S0 = S[c0]; Sp = S[c0 + 1]; Ss = S[c0 - ni]; Sn = S[c0 + ni]; }
   double Zm = z_r[c0 - 1], Z0 = z_r[c0], Zp = z_r[c0 + 1], Zs = z_r[c0 - ni], Zn = z_r[c0 + ni];
   double zzc = ISO ? zz[c0] : 0.0;
   // level 1 slabs (iteration k=0 of the reference)
-  zx0_b = mx0 * (Z0 - Zm); tx0_b = mx0 * (T0 - Tm);
-  zx1_b = mx1 * (Zp - Z0); tx1_b = mx1 * (Tp - T0);
-  ze0_b = my0 * (Z0 - Zs); te0_b = my0 * (T0 - Ts);
-  ze1_b = my1 * (Zn - Z0); te1_b = my1 * (Tn - T0);
+  zx0_b = mx0 * (Z0 - Zm); tx0_b = mx0 * tdiff<STAB>(T0, Tm, S0, Sm);
+  zx1_b = mx1 * (Zp - Z0); tx1_b = mx1 * tdiff<STAB>(Tp, T0, Sp, S0);
+  ze0_b = my0 * (Z0 - Zs); te0_b = my0 * tdiff<STAB>(T0, Ts, S0, Ss);
+  ze1_b = my1 * (Zn - Z0); te1_b = my1 * tdiff<STAB>(Tn, T0, Sn, S0);
   LvIn cur = load_level(1);
   for (int k = 1; k <= N; k++) {
     const long ck = c0 + (long)(k - 1) * nij;
@@ -137,17 +156,19 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
     if (k < N) {
       const double Tm1 = cur.Tm1, T01 = cur.T01, Tp1 = cur.Tp1, Ts1 = cur.Ts1, Tn1 = cur.Tn1;
       const double Zm1 = cur.Zm1, Z01 = cur.Z01, Zp1 = cur.Zp1, Zs1 = cur.Zs1, Zn1 = cur.Zn1;
-      zx0_b = mx0 * (Z01 - Zm1); tx0_b = mx0 * (T01 - Tm1);
-      zx1_b = mx1 * (Zp1 - Z01); tx1_b = mx1 * (Tp1 - T01);
-      ze0_b = my0 * (Z01 - Zs1); te0_b = my0 * (T01 - Ts1);
-      ze1_b = my1 * (Zn1 - Z01); te1_b = my1 * (Tn1 - T01);
-      { const double q = vscale(Zm, Zm1); dzm_b = q * (Tm1 - Tm); }
-      { const double q = vscale(Z0, Z01); dz0_b = q * (T01 - T0);
+      const double Sm1 = cur.Sm1, S01 = cur.S01, Sp1 = cur.Sp1, Ss1 = cur.Ss1, Sn1 = cur.Sn1;
+      zx0_b = mx0 * (Z01 - Zm1); tx0_b = mx0 * tdiff<STAB>(T01, Tm1, S01, Sm1);
+      zx1_b = mx1 * (Zp1 - Z01); tx1_b = mx1 * tdiff<STAB>(Tp1, T01, Sp1, S01);
+      ze0_b = my0 * (Z01 - Zs1); te0_b = my0 * tdiff<STAB>(T01, Ts1, S01, Ss1);
+      ze1_b = my1 * (Zn1 - Z01); te1_b = my1 * tdiff<STAB>(Tn1, T01, Sn1, S01);
+      { const double q = vscale(Zm, Zm1); dzm_b = q * tdiff<STAB>(Tm1, Tm, Sm1, Sm); }
+      { const double q = vscale(Z0, Z01); dz0_b = q * tdiff<STAB>(T01, T0, S01, S0);
         if constexpr (ISO) { fsf_b = q * (cur.zz1 - zzc); zzc = cur.zz1; } }
-      { const double q = vscale(Zp, Zp1); dzp_b = q * (Tp1 - Tp); }
-      { const double q = vscale(Zs, Zs1); dzs_b = q * (Ts1 - Ts); }
-      { const double q = vscale(Zn, Zn1); dzn_b = q * (Tn1 - Tn); }
+      { const double q = vscale(Zp, Zp1); dzp_b = q * tdiff<STAB>(Tp1, Tp, Sp1, Sp); }
+      { const double q = vscale(Zs, Zs1); dzs_b = q * tdiff<STAB>(Ts1, Ts, Ss1, Ss); }
+      { const double q = vscale(Zn, Zn1); dzn_b = q * tdiff<STAB>(Tn1, Tn, Sn1, Sn); }
       Tm = Tm1; T0 = T01; Tp = Tp1; Ts = Ts1; Tn = Tn1;
+      Sm = Sm1; S0 = S01; Sp = Sp1; Ss = Ss1; Sn = Sn1;
       Zm = Zm1; Z0 = Z01; Zp = Zp1; Zs = Zs1; Zn = Zn1;
     } else {
       dzm_b = dz0_b = dzp_b = dzs_b = dzn_b = 0.0;
@@ -204,8 +225,9 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   }
 }
 
+template <bool STAB>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
-k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
+k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew, int nstp)
 {
   DEV_PROLOGUE(c)
   const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, b.NT);
@@ -215,6 +237,7 @@ k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
   const int itrc = 1 + tt.itr;
   if (i > b.Iend || j > b.Jend) return;
   const double *__restrict__ T = c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
+  const double *__restrict__ S = STAB ? c->F.t + ((long)(nstp - 1) + 3L * (itrc - 1)) * n3r : T;   // TS_MIX_STABILITY
   double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
   const double *__restrict__ Hz = c->F.Hz;
   const double *__restrict__ d2 = c->F.diff2 + (long)(itrc - 1) * nij;
@@ -231,10 +254,12 @@ k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
   for (int k = 1; k <= N; k++) {
     const long ck = c0 + (long)(k - 1) * nij;
     const double t0 = T[ck], h0 = Hz[ck];
-    double FX0 = cfx0 * (h0 + Hz[ck - 1]) * (t0 - T[ck - 1]);
-    double FX1 = cfx1 * (Hz[ck + 1] + h0) * (T[ck + 1] - t0);
-    double FE0 = cfe0 * (h0 + Hz[ck - ni]) * (t0 - T[ck - ni]);
-    double FE1 = cfe1 * (Hz[ck + ni] + h0) * (T[ck + ni] - t0);
+    double s0 = 0.0, sm = 0.0, sp = 0.0, ss = 0.0, sn = 0.0;
+    if constexpr (STAB) { s0 = S[ck]; sm = S[ck - 1]; sp = S[ck + 1]; ss = S[ck - ni]; sn = S[ck + ni]; }
+    double FX0 = cfx0 * (h0 + Hz[ck - 1]) * tdiff<STAB>(t0, T[ck - 1], s0, sm);
+    double FX1 = cfx1 * (Hz[ck + 1] + h0) * tdiff<STAB>(T[ck + 1], t0, sp, s0);
+    double FE0 = cfe0 * (h0 + Hz[ck - ni]) * tdiff<STAB>(t0, T[ck - ni], s0, ss);
+    double FE1 = cfe1 * (Hz[ck + ni] + h0) * tdiff<STAB>(T[ck + ni], t0, sn, s0);
     if (masking) { FX0 = FX0 * um0; FX1 = FX1 * um1; FE0 = FE0 * vm0; FE1 = FE1 * vm1; }
     const double cff1 = cdt * (FX1 - FX0);
     const double cff2 = cdt * (FE1 - FE0);
@@ -243,7 +268,7 @@ k_t3dmix2_s(const RomsDev *__restrict__ c, int nrhs, int nnew)
 }
 
 // t3dmix4_s_tile, first operator (MODE 1, :281-345) and second operator with the time step (MODE 2, :407-475)
-template <int MODE>
+template <int MODE, bool STAB = false>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_t3dmix4_s(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
 {
@@ -257,6 +282,8 @@ k_t3dmix4_s(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   const int itrc = L.itrc;
   if (i > ihi || j > jhi) return;
   const double *__restrict__ T = MODE == 2 ? L.lap : c->F.t + ((long)(nrhs - 1) + 3L * (itrc - 1)) * n3r;
+  static_assert(!(STAB && MODE == 2), "the second biharmonic operator acts on LapT alone");
+  const double *__restrict__ S = STAB ? c->F.t + ((long)(L.nstp - 1) + 3L * (itrc - 1)) * n3r : T;   // TS_MIX_STABILITY
   double *__restrict__ tn = c->F.t + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r;
   const double *__restrict__ Hz = c->F.Hz;
   const double *__restrict__ d4 = c->F.diff4 + (long)(itrc - 1) * nij;
@@ -277,10 +304,12 @@ k_t3dmix4_s(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   for (int k = 1; k <= N; k++) {
     const long ck = c0 + (long)(k - 1) * nij;
     const double t0 = T[ck], h0 = Hz[ck];
-    double FX0 = cfx0 * (h0 + Hz[ck - 1]) * (t0 - T[ck - 1]);
-    double FX1 = cfx1 * (Hz[ck + 1] + h0) * (T[ck + 1] - t0);
-    double FE0 = cfe0 * (h0 + Hz[ck - ni]) * (t0 - T[ck - ni]);
-    double FE1 = cfe1 * (Hz[ck + ni] + h0) * (T[ck + ni] - t0);
+    double s0 = 0.0, sm = 0.0, sp = 0.0, ss = 0.0, sn = 0.0;
+    if constexpr (STAB) { s0 = S[ck]; sm = S[ck - 1]; sp = S[ck + 1]; ss = S[ck - ni]; sn = S[ck + ni]; }
+    double FX0 = cfx0 * (h0 + Hz[ck - 1]) * tdiff<STAB>(t0, T[ck - 1], s0, sm);
+    double FX1 = cfx1 * (Hz[ck + 1] + h0) * tdiff<STAB>(T[ck + 1], t0, sp, s0);
+    double FE0 = cfe0 * (h0 + Hz[ck - ni]) * tdiff<STAB>(t0, T[ck - ni], s0, ss);
+    double FE1 = cfe1 * (Hz[ck + ni] + h0) * tdiff<STAB>(T[ck + ni], t0, sn, s0);
     if constexpr (MODE == 1) {
       const double cff = 1.0 / h0;
       lap4_store<MODE>(b, L, ni, i, j, ck, pmn * cff * (FX1 - FX0 + FE1 - FE0));
@@ -299,13 +328,19 @@ static int t3dmix2_launch(const roms_step_idx_t *s)
 {
   const roms_bounds_t &b = g_ctx.b;
   const dim3 grid = grid_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, b.NT);
-  if (g_ctx.p.mix_iso_ts)
-    hipLaunchKernelGGL((k_t3dmix_geo<0, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, Lap4{});
-  else if (g_ctx.p.mix_geo_ts)
-    hipLaunchKernelGGL((k_t3dmix_geo<0, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, Lap4{});
-  else if (g_ctx.p.mix_s_ts)
-    hipLaunchKernelGGL(k_t3dmix2_s, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew);
-  else
+  const bool stab = g_ctx.p.ts_mix_stability != 0;       // TS_MIX_STABILITY
+  Lap4 L{};
+  L.nstp = s->nstp;
+  if (g_ctx.p.mix_iso_ts) {
+    if (stab) hipLaunchKernelGGL((k_t3dmix_geo<0, true, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+    else hipLaunchKernelGGL((k_t3dmix_geo<0, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+  } else if (g_ctx.p.mix_geo_ts) {
+    if (stab) hipLaunchKernelGGL((k_t3dmix_geo<0, false, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+    else hipLaunchKernelGGL((k_t3dmix_geo<0, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+  } else if (g_ctx.p.mix_s_ts) {
+    if (stab) hipLaunchKernelGGL(k_t3dmix2_s<true>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, s->nstp);
+    else hipLaunchKernelGGL(k_t3dmix2_s<false>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, s->nstp);
+  } else
     return roms_fail("roms_hip_t3dmix2", "no tracer mixing option (MIX_ISO_TS / MIX_GEO_TS / MIX_S_TS) selected");
   KERNEL_CHECK("k_t3dmix2");
   return 0;
@@ -329,8 +364,10 @@ extern "C" int roms_hip_t3dmix4(const roms_step_idx_t *s)
   if (!p.mix_iso_ts && !p.mix_geo_ts && !p.mix_s_ts)
     return roms_fail("roms_hip_t3dmix4", "no tracer mixing option (MIX_ISO_TS / MIX_GEO_TS / MIX_S_TS) selected");
   ScopedTimer tm("t3dmix4");
+  const bool stab = p.ts_mix_stability != 0;             // TS_MIX_STABILITY: in the first operator only
   Lap4 L;
   L.lap = g_ctx.hostc.ws3[1];
+  L.nstp = s->nstp;
   if (b.EWperiodic) { L.i0 = b.Istr - 1; L.i1 = b.Iend + 1; }
   else { L.i0 = b.Istr - 1 > 1 ? b.Istr - 1 : 1; L.i1 = b.Iend + 1 < b.Lm ? b.Iend + 1 : b.Lm; }
   if (b.NSperiodic) { L.j0 = b.Jstr - 1; L.j1 = b.Jend + 1; }
@@ -341,13 +378,16 @@ extern "C" int roms_hip_t3dmix4(const roms_step_idx_t *s)
   for (int itrc = 1; itrc <= b.NT; itrc++) {
     L.itrc = itrc;
     if (p.mix_iso_ts) {
-      hipLaunchKernelGGL((k_t3dmix_geo<1, true>), g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      if (stab) hipLaunchKernelGGL((k_t3dmix_geo<1, true, true>), g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      else hipLaunchKernelGGL((k_t3dmix_geo<1, true>), g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
       hipLaunchKernelGGL((k_t3dmix_geo<2, true>), g2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
     } else if (p.mix_geo_ts) {
-      hipLaunchKernelGGL((k_t3dmix_geo<1, false>), g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      if (stab) hipLaunchKernelGGL((k_t3dmix_geo<1, false, true>), g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      else hipLaunchKernelGGL((k_t3dmix_geo<1, false>), g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
       hipLaunchKernelGGL((k_t3dmix_geo<2, false>), g2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
     } else {
-      hipLaunchKernelGGL(k_t3dmix4_s<1>, g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      if (stab) hipLaunchKernelGGL((k_t3dmix4_s<1, true>), g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
+      else hipLaunchKernelGGL(k_t3dmix4_s<1>, g1, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
       hipLaunchKernelGGL(k_t3dmix4_s<2>, g2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, L);
     }
     KERNEL_CHECK("k_t3dmix4");

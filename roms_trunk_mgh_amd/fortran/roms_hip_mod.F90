@@ -84,6 +84,8 @@ MODULE roms_hip_mod
     REAL(c_double) :: Dcrit
     !  ATM_PRESS: Pair (mb) in the baroclinic pressure gradient
     INTEGER(c_int) :: atm_press, press_compensate
+    !  TS_MIX_STABILITY: 3/4 t(nrhs) + 1/4 t(nstp) in the lateral tracer mixing
+    INTEGER(c_int) :: ts_mix_stability
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)

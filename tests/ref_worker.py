@@ -68,6 +68,26 @@ def main(config, mask=None, pgf=0, basin=False, atm=False):
 
 
 DIF4 = {"ts_dif4": 1, "uv_vis4": 1, "tnu4": 2.0e7, "visc4": 4.0e7}
+# "... stab": the dif4 / iso comparisons against the builds with -DTS_MIX_STABILITY, t3dmix2 beside t3dmix4, with two
+# distinct time levels nrhs = 3 and nstp = 1 (the model's own sequence has nrhs = nstp there, main3d.F:191, which would
+# leave the 1/4 part untested)
+STAB = False
+
+
+def mix_step_idx():
+    import util
+    return util.step_idx(nstp=1, nnew=2, nrhs=3) if STAB else util.step_idx()
+
+
+def stab_effect(st0, st_o, k, s):
+    """How far the TS_MIX_STABILITY result lies from the plain operator's on the same state (the option has to act)."""
+    import oracle
+    import util
+    st_p = st0.copy()
+    st_p.p = type(st0.p).from_buffer_copy(st0.p)        # copy() shares the parameter block
+    st_p.p.ts_mix_stability = 0
+    oracle.Oracle(st_p).call(k, s)
+    return util.max_rel_diff(st_o["t"], st_p["t"])
 
 
 def main_dif4(config, basin=None, mask=None):
@@ -79,18 +99,20 @@ def main_dif4(config, basin=None, mask=None):
     import util
     from oracle import ref
     from roms_trunk_mgh_amd import abi
-    ov = dict(DIF4)
+    ov = dict(DIF4, ts_mix_stability=int(STAB))
+    if STAB:
+        ov["tnu2"] = 300.0                       # t3dmix2 is compared as well: a harmonic coefficient that acts
     if basin:
         ov["EWperiodic"] = False
     st0 = util.prepared_state(config, overrides=ov, mask=mask)
-    assert st0.b.NghostPoints == 3 and st0.p.ts_dif4 == 1 and st0.p.uv_vis4 == 1
+    assert st0.b.NghostPoints == 3 and st0.p.ts_dif4 == 1 and st0.p.uv_vis4 == 1 and st0.p.ts_mix_stability == int(STAB)
     if basin == "open":
         for sd in ("west", "east", "south", "north"):
             for var in ("u", "v", "t"):
                 st0.p.lbc[abi.LBS[sd]][abi.LBV[var]] = abi.LBC["Gra"]
     out = {"EWperiodic": int(st0.b.EWperiodic), "masking": int(st0.p.masking), "kernels": {}}
-    s = util.step_idx()
-    for k in ("t3dmix4", "uv3dmix4"):
+    s = mix_step_idx()
+    for k in (("t3dmix2", "t3dmix4") if STAB else ("t3dmix4", "uv3dmix4")):
         st_r, st_o = st0.copy(), st0.copy()
         ref.Ref(st_r).call(k, s)
         oracle.Oracle(st_o).call(k, s)
@@ -99,6 +121,8 @@ def main_dif4(config, basin=None, mask=None):
         out["kernels"][k] = {"max_rel_diff": max(diffs.values()) if diffs else 0.0, "fields_diff": sorted(diffs),
                              "changed": sorted(changed),
                              "change": max(util.max_rel_diff(st_r[n], st0[n]) for n in ("t", "u", "v"))}
+        if STAB:
+            out["kernels"][k]["stab_effect"] = stab_effect(st0, st_o, k, s)
     print(json.dumps(out))
 
 
@@ -109,7 +133,7 @@ def iso_state(config, basin=None, mask=None, extra=None):
     import oracle
     import util
     from roms_trunk_mgh_amd import abi
-    ov = dict(DIF4, mix_iso_ts=1, tnu2=300.0)
+    ov = dict(DIF4, mix_iso_ts=1, tnu2=300.0, ts_mix_stability=int(STAB))
     if extra:
         ov.update(extra)
     if basin:
@@ -140,7 +164,7 @@ def main_iso(config, basin=None, mask=None):
     d = st0["pden"][:, :, :-1] - st0["pden"][:, :, 1:]
     out = {"EWperiodic": int(st0.b.EWperiodic), "masking": int(st0.p.masking), "kernels": {},
            "frac_below_eps": float((d < 0.5).mean())}
-    s = util.step_idx()
+    s = mix_step_idx()
     for k in ("t3dmix2", "t3dmix4"):
         st_r, st_o = st0.copy(), st0.copy()
         ref.Ref(st_r).call(k, s)
@@ -149,6 +173,8 @@ def main_iso(config, basin=None, mask=None):
         out["kernels"][k] = {"max_rel_diff": max(diffs.values()) if diffs else 0.0, "fields_diff": sorted(diffs),
                              "changed": sorted(util.compare_states(st_r, st0)),
                              "change": util.max_rel_diff(st_r["t"], st0["t"])}
+        if STAB:
+            out["kernels"][k]["stab_effect"] = stab_effect(st0, st_o, k, s)
     print(json.dumps(out))
 
 
@@ -685,6 +711,9 @@ if __name__ == "__main__":
     if sys.argv[-1] == "wet":                  # ... wet: the same comparison on a WET_DRY state against the _WET builds
         import util as _util
         _util.WET = True
+        sys.argv.pop()
+    if sys.argv[-1] == "stab":                 # ... stab: the dif4 / iso modes against the _STAB builds
+        STAB = True
         sys.argv.pop()
     PC = len(sys.argv) > 3 and sys.argv[3] == "pc"            # ATM_PRESS + PRESS_COMPENSATE builds (bc, bc4 modes)
     RAD2D = len(sys.argv) > 3 and sys.argv[3] == "rad2d"      # the builds with -DRADIATION_2D (bc, bc4 modes)

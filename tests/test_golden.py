@@ -661,3 +661,51 @@ def test_hip_reproduces_reference_atm_press():
         finally:
             h.close()
     _atm_check(run, 1e-13)
+
+
+def _stab_check(backend, tol):
+    import sys
+    gd = os.path.join(HERE, "golden")
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    import make_golden_stab as ms
+    g = np.load(os.path.join(gd, "ref_stab.npz"))
+    for variant in ms.VARIANTS:
+        for kernel in ms.KERNELS:
+            st, s = ms.prepare(variant)
+            st_off = st.copy()
+            st_off.p = type(st.p).from_buffer_copy(st.p)
+            backend(st, s, kernel)
+            for k, v in ms.results(st, variant, kernel).items():
+                want = g[k]
+                if k.endswith("_sha256"):
+                    if tol == 0.0:
+                        assert str(v) == str(want), k
+                else:
+                    scale = max(float(np.abs(want).max()), 1e-300)
+                    assert float(np.abs(v - want).max()) <= tol * scale, k
+            # the 1/4 t(nstp) part matters
+            st_off.p.ts_mix_stability = 0
+            backend(st_off, s, kernel)
+            assert not np.array_equal(st_off["t"], st["t"]), (variant, kernel)
+
+
+def test_oracle_reproduces_reference_ts_mix_stability():
+    """TS_MIX_STABILITY: t3dmix2 / t3dmix4 along s-surfaces, geopotentials and isopycnals of the reference built with
+    the option (make_golden_stab.py), whole arrays by SHA-256."""
+    import oracle
+    _stab_check(lambda st, s, k: oracle.Oracle(st).call(k, s), 0.0)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_reference_ts_mix_stability():
+    from roms_trunk_mgh_amd import hip
+
+    def run(st, s, k):
+        h = hip.RomsHip(st)
+        try:
+            h.call(k, s)
+            h.to_host()
+        finally:
+            h.close()
+    _stab_check(run, 1e-13)

@@ -15,8 +15,8 @@ DIF4 = {"UPWELLING": {"ts_dif4": 1, "uv_vis4": 1, "tnu4": 2.0e7, "visc4": 4.0e7}
         "BENCHMARK_TINY": {"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10}}   # t3dmix4_geo, curvilinear terms
 
 
-def _state(config, variant):
-    ov = dict(DIF4[config])
+def _state(config, variant, extra=None):
+    ov = dict(DIF4[config], **(extra or {}))
     if variant in ("closed", "open"):
         ov["EWperiodic"] = False
     st = util.prepared_state(config, overrides=ov, mask="island" if variant == "mask" else None)
@@ -166,3 +166,69 @@ def test_100_steps_with_isopycnal_mixing(config, dif4):
     assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
     assert all(v <= 1e-10 for v in out.values()), out
     assert float(np.abs(st_o["pden"]).max()) > 0.0
+
+
+# ---- TS_MIX_STABILITY: 3/4 t(nrhs) + 1/4 t(nstp) in every tracer difference of the operators ----
+@pytest.mark.parametrize("config,iso", [("UPWELLING", False), ("SEAMOUNT", False), ("BENCHMARK_TINY", False),
+                                        ("UPWELLING", True), ("SEAMOUNT", True)])
+@pytest.mark.parametrize("variant", ["periodic", "open", "mask"])
+@pytest.mark.parametrize("kernel", ["t3dmix2", "t3dmix4"])
+def test_ts_mix_stability_kernels(config, iso, variant, kernel):
+    """s-surfaces (UPWELLING), geopotentials (SEAMOUNT, BENCHMARK_TINY) and isopycnals, with two distinct time levels
+    (nrhs = 3, nstp = 1) and with the model's own nrhs = nstp; the oracle is pinned against the reference built with
+    -DTS_MIX_STABILITY (tests/test_ref_pinning.py::test_ts_mix_stability_matches_reference_build)."""
+    import oracle
+    import ref_worker
+    if iso:
+        st0 = ref_worker.iso_state(config, basin=variant if variant == "open" else None,
+                                   mask="island" if variant == "mask" else None,
+                                   extra=dict(DIF4[config], ts_mix_stability=1))
+    else:
+        st0 = _state(config, variant, extra={"tnu2": 300.0, "ts_mix_stability": 1})
+    assert st0.p.ts_mix_stability == 1
+    for s in (util.step_idx(iic=5, nstp=1, nnew=2, nrhs=3), util.step_idx(iic=5)):
+        st_o, st_h, st_p = st0.copy(), st0.copy(), st0.copy()
+        oracle.Oracle(st_o).call(kernel, s)
+        st_p.p = type(st0.p).from_buffer_copy(st0.p)
+        st_p.p.ts_mix_stability = 0
+        oracle.Oracle(st_p).call(kernel, s)
+        h = hip.RomsHip(st_h)
+        try:
+            h.call(kernel, s)
+            h.to_host()
+        finally:
+            h.close()
+        assert np.array_equal(st_h["t"], st_o["t"]), util.compare_states(st_h, st_o)
+        assert util.max_rel_diff(st_o["t"], st0["t"]) > 1e-6
+        if s.nrhs != s.nstp:
+            assert util.max_rel_diff(st_o["t"], st_p["t"]) > 1e-9       # the option acts
+
+
+@pytest.mark.parametrize("config,iso", [("UPWELLING", False), ("SEAMOUNT", False), ("BENCHMARK_TINY", True)])
+def test_100_steps_with_ts_mix_stability(config, iso):
+    import oracle
+    ov = dict(DIF4[config], ts_mix_stability=1)
+    if iso:
+        ov["mix_iso_ts"] = 1
+    st_o = ana.make_tile(config, perturb=1.0 if config != "SEAMOUNT" else 0.0, overrides=ov)
+    st_h = st_o.copy()
+    assert st_o.p.ts_mix_stability == 1
+    mo = main3d.Main3D(oracle.Oracle(st_o))
+    mo.initial()
+    mo.run(100)
+    be = hip.RomsHip(st_h)
+    try:
+        mh = main3d.Main3D(be)
+        mh.initial()
+        mh.run(100)
+        be.to_host()
+    finally:
+        be.close()
+    s = mo.s
+    out = {"zeta": rel_rms(st_h.interior("zeta")[..., mo.indx1 - 1], st_o.interior("zeta")[..., mo.indx1 - 1], 1e-3)}
+    for name in ("u", "v"):
+        out[name] = rel_rms(st_h.interior(name)[..., s.nnew - 1], st_o.interior(name)[..., s.nnew - 1], 1e-4)
+    for it in range(st_o.b.NT):
+        out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
+    assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
+    assert all(v <= 1e-10 for v in out.values()), out          # north-star bound
