@@ -183,9 +183,10 @@ typedef struct roms_params {
    * them.  With wet_dry the barotropic step takes the general launch sequence (flux, free surface, masks,
    * momentum). */
   int    wet_dry;
-  /* LuvSrc(ng) .or. LwSrc(ng) (mod_scalars.F; point sources / sinks of mod_sources.F).  The library holds no source
-   * table: with a non-zero value every entry refuses to run (error text "point sources"), so that a river application
-   * cannot lose its sources silently; 0 = the application has none. */
+  /* Point sources / sinks of mod_sources.F (rivers): bit 0 = LuvSrc(ng) (transport through u- / v-faces, Dsrc = 0 / 1),
+   * bit 1 = LwSrc(ng) (volume influx at cell centres, Dsrc = 2).  With LuvSrc the table comes from roms_hip_set_sources;
+   * until it has been handed over every entry refuses to run (error text "point sources"), so that a river application
+   * cannot lose its sources silently.  LwSrc is not built: refused.  0 = the application has none. */
   int    point_sources;
   double Dcrit;
   /* ATM_PRESS (prsgrd32.h:229-232, :264-266; prsgrd31.h:196-198, :213-215, :294-296; prsgrd40.h:187-196): the
@@ -318,6 +319,14 @@ int roms_hip_gls_corstep(const roms_step_idx_t *s);
  * from zeta, ubar, vbar of time level Tindex = s->kstp (initial.F:438-466; WET_DRY applications).  The per-call
  * update wetdry_tile (:93) runs inside roms_hip_step2d. */
 int roms_hip_wetdry(const roms_step_idx_t *s);
+/* The source table SOURCES(ng) of mod_sources.F:56-80 with LuvSrc (roms_params_t.point_sources bit 0): Isrc, Jsrc (grid
+ * indices of the u- or v-face), Dsrc (0.0 = u-face, 1.0 = v-face), Qbar(Nsrc) (m3/s), Qsrc(Nsrc,N) = Qbar * Qshape as
+ * set_data.F:136-143 leaves it, Tsrc(Nsrc,N,NT) and LtracerSrc(NT); Fortran element order.  Call it after every
+ * set_data that changes them (the arrays are copied; a few kB).  The entries that consume it: step2d
+ * (step2d_LF_AM3.h:2484-2502), step3d_uv (step3d_uv.F:971-995), pre_step3d (pre_step3d.F:530-553), step3d_t
+ * (step3d_t.F:734-799), wetdry (wetdry.F:307-320, :511-524).  A source with Dsrc = 2 (LwSrc) is refused. */
+int roms_hip_set_sources(int Nsrc, const int *Isrc, const int *Jsrc, const double *Dsrc, const double *Qbar,
+                         const double *Qsrc, const double *Tsrc, const int *LtracerSrc);
 /* wvelocity(ng,tile,nstp)          ROMS/Nonlinear/wvelocity.F:27     (main3d.F:475; writes wvel) */
 int roms_hip_wvelocity(const roms_step_idx_t *s);
 /* diag(ng,tile)                    ROMS/Nonlinear/diag.F:31          (main3d.F:314), the tile-local part

@@ -47,6 +47,9 @@ def lib():
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params),
                            C.POINTER(abi.StepIdx), C.POINTER(abi.Fields)]
+        _ip, _dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        _LIB.oracle_set_sources.restype = C.c_int
+        _LIB.oracle_set_sources.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int]
         if hasattr(_LIB, "oracle_step2d_loop"):
             _LIB.oracle_step2d_loop.restype = C.c_int
             _LIB.oracle_step2d_loop.argtypes = [C.POINTER(abi.Bounds), C.POINTER(abi.Params),
@@ -65,6 +68,15 @@ class Oracle:
         self.st = state
         self.l = lib()
         self.F = state.fields_struct()
+        if getattr(state, "sources", None) is not None:
+            self.set_sources(state.sources)
+        elif hasattr(self.l, "oracle_set_sources"):
+            self.l.oracle_set_sources(0, None, None, None, None, None, None, None, 0, 0)     # the table is process-wide
+
+    def set_sources(self, src):
+        rc = self.l.oracle_set_sources(*src.c_args(), C.c_int(self.st.b.N), C.c_int(self.st.b.NT))
+        if rc != 0:
+            raise RuntimeError(f"oracle_set_sources returned {rc}")
 
     def call(self, kernel, s):
         fn = getattr(self.l, "oracle_" + kernel)

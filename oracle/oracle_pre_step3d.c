@@ -9,6 +9,7 @@
 int oracle_pre_step3d(OARGS)
 {
   ORACLE_PROLOGUE
+  if (o_src_check(p)) return 8;
   if (o_check_lbc(b, p)) return 8;
   const int nrhs = s->nrhs, nstp = s->nstp, nnew = s->nnew;
   const int iic = s->iic, ntfirst = s->ntfirst;
@@ -136,6 +137,7 @@ int oracle_pre_step3d(OARGS)
                          (t(i, j - 1, k, nstp, itrc) + t(i, j, k, nstp, itrc) - cff2 * (grad(i, j) - grad(i, j - 1)));
           }
       }
+      o_src_tflux(b, p, s, F, itrc, k, FX_, FE_, 0, 1);                          /* LuvSrc, pre_step3d.F:530-553 */
       Gamma = (ha == ADV_MPDATA || ha == ADV_HSIMT) ? 0.5 : 1.0 / 6.0;          /* pre_step3d.F:557-563 */
       if (iic == ntfirst) { cff = 0.5 * dt; cff1 = 1.0; cff2 = 0.0; }
       else { cff = (1.0 - Gamma) * dt; cff1 = 0.5 + Gamma; cff2 = 0.5 - Gamma; }

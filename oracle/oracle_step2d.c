@@ -10,6 +10,7 @@
 int oracle_step2d(OARGS)
 {
   ORACLE_PROLOGUE
+  if (o_src_check(p)) return 8;
   if (o_check_lbc(b, p)) return 8;
   const int krhs = s->krhs, kstp = s->kstp, knew = s->knew, nstp = s->nstp, nnew = s->nnew;
   const int iif = s->iif, iic = s->iic, ntfirst = s->ntfirst, nfast = p->nfast;
@@ -570,6 +571,7 @@ int oracle_step2d(OARGS)
   }
   o_u2dbc(b, p, s, F, knew);
   o_v2dbc(b, p, s, F, knew);
+  o_src_ubar(b, p, s, F, knew);                      /* LuvSrc, step2d_LF_AM3.h:2484-2502 */
   o_exchange2d(b, GT_U, &ubar(LBi, LBj, knew));
   o_exchange2d(b, GT_V, &vbar(LBi, LBj, knew));
   FREE_ALL

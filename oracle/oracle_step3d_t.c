@@ -13,6 +13,7 @@ int oracle_mpdata_adiff(const roms_bounds_t *b, const roms_params_t *p, const ro
 int oracle_step3d_t(OARGS)
 {
   ORACLE_PROLOGUE
+  if (o_src_check(p)) return 8;
   if (o_check_lbc(b, p)) return 8;
   if (!p->splines_vdiff) return 8;        /* only the SPLINES_VDIFF operator (step3d_t.F:1363-1430) is restated */
   const int nnew = s->nnew;
@@ -85,6 +86,7 @@ int oracle_step3d_t(OARGS)
             double cff1 = MAX(Hvom(i, j, k), 0.0), cff2 = MIN(Hvom(i, j, k), 0.0);
             FE(i, j) = cff1 * t(i, j - 1, k, 3, itrc) + cff2 * t(i, j, k, 3, itrc);
           }
+        o_src_tflux(b, p, s, F, itrc, k, FX_, FE_, 1, 0);                       /* LuvSrc, :734-799 */
         /* intermediate diffusive tracer Ta (m Tunits), :831-840 */
         for (int j = JstrVm2; j <= Jendp2i; j++)
           for (int i = IstrUm2; i <= Iendp2i; i++) {
@@ -273,6 +275,7 @@ int oracle_step3d_t(OARGS)
             }
           }
       }
+      o_src_tflux(b, p, s, F, itrc, k, FX_, FE_, ha == ADV_HSIMT, 0);           /* LuvSrc, :734-799 */
       /* HADV_STEPPING, step3d_t.F:831-875 */
       for (int j = Jstr; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {

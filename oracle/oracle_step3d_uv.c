@@ -10,6 +10,7 @@
 int oracle_step3d_uv(OARGS)
 {
   ORACLE_PROLOGUE
+  if (o_src_check(p)) return 8;
   if (o_check_lbc(b, p)) return 8;
   if (!p->splines_vvisc) return 8;        /* only the SPLINES_VVISC operator (step3d_uv.F:303-398) is restated */
   const int nrhs = s->nrhs, nnew = s->nnew;
@@ -159,6 +160,7 @@ int oracle_step3d_uv(OARGS)
   /* lateral BCs, step3d_uv.F:956-961 */
   o_u3dbc(b, p, s, F, nnew);
   o_v3dbc(b, p, s, F, nnew);
+  o_src_uv(b, p, s, F, nnew);                        /* LuvSrc, step3d_uv.F:971-995 */
 
   /* coupling 2-D and 3-D momentum, corrected mass fluxes, step3d_uv.F:997-1460 */
   for (int j = JstrT; j <= JendT; j++) {

@@ -7,7 +7,8 @@
  *   wd_mask         wetdry_mask_tile      wetdry.F:563   masks from a rho-point wet/dry flag
  *   wd_avg_mask     wetdry_avg_mask_tile  wetdry.F:734   masks of the baroclinic step: a one-sided face is open
  *                                                        only to flow out of its wet cell
- * No point sources (LuvSrc = .FALSE.).  Pinned against the reference's own wetdry.F (tests/test_ref_pinning.py).
+ * LuvSrc: the output masks count source faces as water (o_src_masks, oracle_sources.c).  PARITY UNPINNED: wetdry.F
+ * USEs mod_sources (netCDF) and cannot be built here; known-answer and property tests in tests/test_wetdry.py.
  */
 #include "oracle.h"
 
@@ -96,7 +97,7 @@ static void wd_avg_mask(const roms_bounds_t *b, roms_fields_t *F, const double *
 }
 
 /* the "full" masks, wetdry.F:325-345 / :478-498 (as written: pmask_full is never below 2) */
-static void wd_full(const roms_bounds_t *b, roms_fields_t *F)
+static void wd_full(OARGS)
 {
   ORACLE_PROLOGUE
   for (int j = JstrR; j <= JendR; j++)
@@ -107,6 +108,7 @@ static void wd_full(const roms_bounds_t *b, roms_fields_t *F)
     for (int i = Istr; i <= IendR; i++) umask_full(i, j) = umask_wet(i, j) * umask(i, j);
   for (int j = Jstr; j <= JendR; j++)
     for (int i = IstrR; i <= IendR; i++) vmask_full(i, j) = vmask_wet(i, j) * vmask(i, j);
+  o_src_masks(b, p, s, F);                           /* LuvSrc, wetdry.F:307-320 / :511-524 */
   o_exchange2d(b, GT_P, F->pmask_full);
   o_exchange2d(b, GT_R, F->rmask_full);
   o_exchange2d(b, GT_U, F->umask_full);
@@ -150,7 +152,7 @@ void o_wetdry(OARGS)
       for (int i = Istr - 1; i <= IendR; i++) wetdry(i, j) = trunc(rmask_wet_avg(i, j) * cff);
     wd_avg_mask(b, F, wd, F->DU_avg1, F->DV_avg1);
   }
-  if (iif > nfast) wd_full(b, F);
+  if (iif > nfast) wd_full(b, p, s, F);
   free(wd);
 }
 
@@ -162,7 +164,7 @@ int oracle_wetdry(OARGS)
   double *wd = walloc(nis * njs);
   wd_flag(b, p, F, &zeta(LBi, LBj, s->kstp), wd);
   wd_avg_mask(b, F, wd, &ubar(LBi, LBj, s->kstp), &vbar(LBi, LBj, s->kstp));
-  wd_full(b, F);
+  wd_full(b, p, s, F);
   free(wd);
   return 0;
 }

@@ -1,6 +1,7 @@
 // capi.hip -- life cycle, field registry and host<->device copies behind the
 // C ABI of include/roms_hip.h.
 #include "roms_dev.h"
+#include <algorithm>
 #include <map>
 #include <vector>
 
@@ -77,6 +78,7 @@ __global__ void __launch_bounds__(256) k_calib_stream(const double *__restrict__
   if (e < n) dst[e] = src[e];
 }
 int roms_entry_check(const char *where);
+namespace { void sources_release(); }
 extern "C" int roms_hip_calib_stream(long n)
 {
   int rc = roms_entry_check("roms_hip_calib_stream");
@@ -239,12 +241,112 @@ extern "C" int roms_hip_finalize(void)
   }
   for (int q = 0; q < 8; q++) guarded_free(&g_ctx.hostc.ws3[q], &g_ctx.ws3_base[q]);
   for (int q = 0; q < 32; q++) guarded_free(&g_ctx.hostc.ws2[q], &g_ctx.ws2_base[q]);
+  sources_release();
   if (g_ctx.devc) (void)hipFree(g_ctx.devc);
   g_ctx.devc = nullptr;
   if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
   g_ctx.inited = false;
   g_ctx.have_bounds = g_ctx.have_params = false;
+  return 0;
+}
+
+// ---- point sources (mod_sources.F), LuvSrc ----
+namespace {
+struct SrcStore {
+  int *geo = nullptr;        // device: I[n], J[n], D[n], umap[nij], vmap[nij]
+  double *val = nullptr;     // device: Qbar[n], Qsrc[n*N], Tsrc[n*N*NT]
+  int n = 0, N = 0, NT = 0;
+  long nij = 0;
+  std::vector<int> I, J, D;
+  bool given = false;
+} g_src;
+
+void sources_release()
+{
+  if (g_src.geo) (void)hipFree(g_src.geo);
+  if (g_src.val) (void)hipFree(g_src.val);
+  g_src = SrcStore{};
+  g_ctx.hostc.src = RomsSrc{};
+  g_ctx.devc_dirty = true;
+}
+}  // namespace
+
+bool roms_sources_given() { return g_src.given; }
+
+extern "C" int roms_hip_set_sources(int Nsrc, const int *Isrc, const int *Jsrc, const double *Dsrc, const double *Qbar,
+                                    const double *Qsrc, const double *Tsrc, const int *LtracerSrc)
+{
+  const char *me = "roms_hip_set_sources";
+  if (!g_ctx.inited || !g_ctx.have_bounds || !g_ctx.have_params)
+    return roms_fail(me, "roms_hip_init, roms_hip_set_bounds and roms_hip_set_params come first");
+  if (Nsrc < 0) return roms_fail(me, "Nsrc < 0");
+  if (!(g_ctx.p.point_sources & 1))
+    return roms_fail(me, "point sources: roms_params_t.point_sources bit 0 (LuvSrc) is not set");
+  if (Nsrc == 0) {
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    sources_release();
+    g_src.given = true;
+    return 0;
+  }
+  if (!Isrc || !Jsrc || !Dsrc || !Qbar || !Qsrc || !Tsrc || !LtracerSrc) return roms_fail(me, "null argument");
+  const roms_bounds_t &b = g_ctx.b;
+  const int N = b.N, NT = b.NT;
+  const long ni = b.UBi - b.LBi + 1, nij = ni * (b.UBj - b.LBj + 1);
+  std::vector<int> D(Nsrc);
+  for (int is = 0; is < Nsrc; is++) {
+    D[is] = (int)Dsrc[is];
+    if (D[is] != 0 && D[is] != 1)
+      return roms_fail(me, "point sources: a source with Dsrc = 2 (LwSrc, volume influx at a cell centre) is not implemented");
+  }
+  const bool same = g_src.geo && g_src.n == Nsrc && g_src.N == N && g_src.NT == NT && g_src.nij == nij &&
+                    std::equal(g_src.I.begin(), g_src.I.end(), Isrc) && std::equal(g_src.J.begin(), g_src.J.end(), Jsrc) &&
+                    g_src.D == D;
+  const size_t nval = (size_t)Nsrc * (1 + (size_t)N + (size_t)N * NT);
+  if (!same) {
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    step2d_graphs_release();               // captured launches hold the old table's addresses
+    sources_release();
+    const size_t ngeo = 3 * (size_t)Nsrc + 2 * (size_t)nij + 2 * (size_t)Nsrc;
+    std::vector<int> geo(ngeo, 0);
+    int *umap = geo.data() + 3 * (size_t)Nsrc, *vmap = umap + nij, *cells = vmap + nij;
+    int ncell = 0;
+    for (int is = 0; is < Nsrc; is++) {
+      geo[is] = Isrc[is]; geo[Nsrc + is] = Jsrc[is]; geo[2 * (size_t)Nsrc + is] = D[is];
+      // the face maps: the last source of a face wins, as the sequential loops of the reference leave it
+      if (Isrc[is] >= b.LBi && Isrc[is] <= b.UBi && Jsrc[is] >= b.LBj && Jsrc[is] <= b.UBj)
+        (D[is] == 0 ? umap : vmap)[(long)(Isrc[is] - b.LBi) + (long)(Jsrc[is] - b.LBj) * ni] = is + 1;
+      // the two cells of the face, where they are interior cells of this tile (each once)
+      for (int side = 0; side < 2; side++) {
+        const int ci = Isrc[is] - (D[is] == 0 ? side : 0), cj = Jsrc[is] - (D[is] == 1 ? side : 0);
+        if (ci < b.Istr || ci > b.Iend || cj < b.Jstr || cj > b.Jend) continue;
+        const int cell = (int)((long)(ci - b.LBi) + (long)(cj - b.LBj) * ni);
+        if (std::find(cells, cells + ncell, cell) == cells + ncell) cells[ncell++] = cell;
+      }
+    }
+    HIP_TRY(hipMalloc(&g_src.geo, sizeof(int) * ngeo));
+    HIP_TRY(hipMalloc(&g_src.val, sizeof(double) * (nval + (size_t)Nsrc * N)));
+    HIP_TRY(hipMemcpy(g_src.geo, geo.data(), sizeof(int) * ngeo, hipMemcpyHostToDevice));
+    g_src.n = Nsrc; g_src.N = N; g_src.NT = NT; g_src.nij = nij;
+    g_src.I.assign(Isrc, Isrc + Nsrc); g_src.J.assign(Jsrc, Jsrc + Nsrc); g_src.D = D;
+    RomsSrc &S = g_ctx.hostc.src;
+    S.n = Nsrc;
+    S.I = g_src.geo; S.J = g_src.geo + Nsrc; S.D = g_src.geo + 2 * (size_t)Nsrc;
+    S.umap = g_src.geo + 3 * (size_t)Nsrc; S.vmap = S.umap + nij;
+    S.cells = S.vmap + nij; S.ncell = ncell;
+    S.Qbar = g_src.val; S.Qsrc = g_src.val + Nsrc; S.Tsrc = g_src.val + Nsrc + (size_t)Nsrc * N;
+    S.save = g_src.val + nval;
+  }
+  // the values change with every set_data: one staged copy (a few kB), in stream order after the kernels that read the old ones
+  std::vector<double> val(nval);
+  std::copy(Qbar, Qbar + Nsrc, val.begin());
+  std::copy(Qsrc, Qsrc + (size_t)Nsrc * N, val.begin() + Nsrc);
+  std::copy(Tsrc, Tsrc + (size_t)Nsrc * N * NT, val.begin() + Nsrc + (size_t)Nsrc * N);
+  HIP_TRY(hipMemcpyAsync(g_src.val, val.data(), sizeof(double) * nval, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  for (int it = 0; it < ROMS_MAXNT; it++) g_ctx.hostc.src.ltr[it] = it < NT ? (LtracerSrc[it] != 0) : 0;
+  g_src.given = true;
+  g_ctx.devc_dirty = true;
   return 0;
 }
 
@@ -256,6 +358,7 @@ extern "C" int roms_hip_set_bounds(const roms_bounds_t *b)
     return roms_fail("roms_hip_set_bounds", "tiling differs from roms_hip_init");
   step2d_graphs_release();
   roms_rowm_release();
+  sources_release();                       // the face maps are in the old bounds' index space
   g_ctx.b = *b;
   g_ctx.hostc.b = *b;
   g_ctx.have_bounds = true;
@@ -291,6 +394,10 @@ extern "C" int roms_hip_set_params(const roms_params_t *p)
   if (!g_ctx.inited) return roms_fail("roms_hip_set_params", "library not initialised");
   if (2 * p->ndtfast > ROMS_MAXFAST) return roms_fail("roms_hip_set_params", "ndtfast too large");
   step2d_graphs_release();
+  if (!(p->point_sources & 1) && roms_sources_given()) {     // LuvSrc switched off: the kernels look at the table alone
+    (void)hipStreamSynchronize(g_ctx.stream);
+    sources_release();
+  }
   g_ctx.p = *p;
   g_ctx.hostc.p = *p;
   // Library-kept defaults (all-water masks, zero biharmonic coefficients, ZoBot) were created under the previous
@@ -427,8 +534,12 @@ int roms_entry_check(const char *name)
   if (!g_ctx.have_bounds || !g_ctx.have_params) return roms_fail(name, "bounds/params not set");
   // WET_DRY exists only with MASKING in the reference (wetdry.F:325-345 reads rmask ... vmask unconditionally)
   if (g_ctx.p.wet_dry && !g_ctx.p.masking) return roms_fail(name, "wet_dry = 1 needs masking = 1");
-  // mod_sources.F: the library has no source table -- never run a river application without its rivers
-  if (g_ctx.p.point_sources) return roms_fail(name, "point sources (LuvSrc / LwSrc) are not implemented: keep this application on the host path");
+  // mod_sources.F -- never run a river application without its rivers: LuvSrc needs the table of roms_hip_set_sources,
+  // LwSrc (volume influx at cell centres) is not built
+  if (g_ctx.p.point_sources & 2)
+    return roms_fail(name, "point sources: LwSrc (Dsrc = 2) is not implemented: keep this application on the host path");
+  if ((g_ctx.p.point_sources & 1) && !roms_sources_given())
+    return roms_fail(name, "point sources: LuvSrc is set but roms_hip_set_sources has not handed over SOURCES(ng)");
   for (int id = 0; id < FID_COUNT; id++)
     if (!g_ctx.dev[id]) {
       double value;

@@ -93,10 +93,12 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
     const double t0 = t3[a];
     // FC(k-1): the expression the level below evaluates as its FC(k)
     const double FCm1 = (k > 1) ? upstream(Wv[a], t3[a - nij], t0) : 0.0;
-    const double FXi = upstream(Huon[a], t3[a - 1], t0);
-    const double FXip1 = upstream(Huon[a + 1], t0, t3[a + 1]);
-    const double FEj = upstream(Hvom[a], t3[a - ni], t0);
-    const double FEjp1 = upstream(Hvom[a + ni], t0, t3[a + ni]);
+    double FXi = upstream(Huon[a], t3[a - 1], t0);
+    double FXip1 = upstream(Huon[a + 1], t0, t3[a + 1]);
+    double FEj = upstream(Hvom[a], t3[a - ni], t0);
+    double FEjp1 = upstream(Hvom[a + ni], t0, t3[a + ni]);
+    if (c->src.n > 0 && src_cell_any(c, c0, ni))     // LuvSrc, step3d_t.F:734-799 (on the extended range of MPDATA)
+      src_cell_fluxes<false>(c, c0, a, ni, k, m.itrc, c->F.t + (2L + 3L * (m.itrc - 1)) * n3r, FXi, FXip1, FEj, FEjp1);
     const double cff1 = cff * (FXip1 - FXi);
     const double cff2 = cff * (FEjp1 - FEj);
     const double cff3 = cff1 + cff2;

@@ -122,6 +122,7 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
     for (int k = 0; k <= NMAX; k++) if (k == 0 || k == N) spl[k] = 0.0;
   }
 
+  const bool src_cell = c->src.n > 0 && src_cell_any(c, c0, ni);      // LuvSrc: a face of this cell is a source face
   double tkm1 = 0.0, tk = ts[c0], tkp1 = (N >= 2) ? ts[c0 + nij] : 0.0, tkp2;
   double FCprev = 0.0;                                        // advective FC(k-1)
   double FDprev = dt * GF(btflx)[c0 + (long)(itrc - 1) * nij]; // diffusive FC(0)
@@ -153,10 +154,12 @@ k_pre_t(const RomsDev *__restrict__ c, int nstp, int nnew, int first_step, int i
     if (n_wall) dyp2 = dyp1;
     if (w_wall) dxm1 = dx0;
     if (e_wall) dxp2 = dxp1;
-    const double FXi = hflux<HADV>(hu0, xm1, tk, dxm1, dx0, dxp1);
-    const double FXip1 = hflux<HADV>(hu1, tk, xp1, dx0, dxp1, dxp2);
-    const double FEj = hflux<HADV>(hv0, ym1, tk, dym1, dy0, dyp1);
-    const double FEjp1 = hflux<HADV>(hv1, tk, yp1, dy0, dyp1, dyp2);
+    double FXi = hflux<HADV>(hu0, xm1, tk, dxm1, dx0, dxp1);
+    double FXip1 = hflux<HADV>(hu1, tk, xp1, dx0, dxp1, dxp2);
+    double FEj = hflux<HADV>(hv0, ym1, tk, dym1, dy0, dyp1);
+    double FEjp1 = hflux<HADV>(hv1, tk, yp1, dy0, dyp1, dyp2);
+    if (src_cell)                                    // LuvSrc, pre_step3d.F:530-553
+      src_cell_fluxes<true>(c, c0, ck, ni, k, itrc, nullptr, FXi, FXip1, FEj, FEjp1);
     const double hz = Hz[ck];
     const double tnn = tn[ck];
     double t3v = hz * (cff1 * tk + cff2 * tnn) - cpp * (FXip1 - FXi + FEjp1 - FEj);

@@ -317,8 +317,11 @@ k2d_wetdry(const RomsDev *__restrict__ c, int mode, int first, int kstp)
   }
   if (mode != 0) {                                       // :325-345 / :478-498 (as written: pmask_full is never below 2)
     GF(rmask_full)[a] = w0 * rmask[a];
-    if (inU) GF(umask_full)[a] = um * GF(umask)[a];
-    if (inV) GF(vmask_full)[a] = vm * GF(vmask)[a];
+    // (LuvSrc, wetdry.F:307-320 / :511-524: the output masks count a source face as water; the source loop of the
+    // reference runs over IstrR:IendR, JstrR:JendR, which holds every inU / inV point)
+    const bool srcs = c->src.n > 0;
+    if (inU) GF(umask_full)[a] = (srcs && c->src.umap[a] != 0) ? 1.0 : um * GF(umask)[a];
+    if (inV) GF(vmask_full)[a] = (srcs && c->src.vmap[a] != 0) ? 1.0 : vm * GF(vmask)[a];
     if (inU && inV) GF(pmask_full)[a] = fmax(pw * GF(pmask)[a], 2.0);
   }
 }
@@ -350,6 +353,30 @@ bool g_flux_ready = false;
 int g_flux_lev = 0;
 int g_flux_buf = 0;       // which scratch pair holds them
 
+// LuvSrc: ubar, vbar(knew) at the source faces = the source's transport over the face's new water column
+// (step2d_LF_AM3.h:2484-2502; after the boundary conditions, before the exchange).  One thread per source; two sources
+// on one face would race where the reference lets the later one win: the face map decides (its entry is that later one).
+__global__ void k2d_src_bar(const RomsDev *__restrict__ c, int knew)
+{
+  DEV_PROLOGUE(c)
+  const int is = blockIdx.x * blockDim.x + threadIdx.x;
+  if (is >= c->src.n) return;
+  const int i = c->src.I[is], j = c->src.J[is];
+  if (!(b.IstrR <= i && i <= b.IendR && b.JstrR <= j && j <= b.JendR)) return;
+  const long c0 = I2(i, j);
+  const double *__restrict__ zeta = c->F.zeta + (long)(knew - 1) * nij;
+  const double *__restrict__ h = c->F.h;
+  if (c->src.D[is] == 0) {
+    if (c->src.umap[c0] != is + 1) return;
+    const double cff = 1.0 / (c->F.on_u[c0] * 0.5 * (zeta[c0 - 1] + h[c0 - 1] + zeta[c0] + h[c0]));
+    c->F.ubar[c0 + (long)(knew - 1) * nij] = c->src.Qbar[is] * cff;
+  } else {
+    if (c->src.vmap[c0] != is + 1) return;
+    const double cff = 1.0 / (c->F.om_v[c0] * 0.5 * (zeta[c0 - ni] + h[c0 - ni] + zeta[c0] + h[c0]));
+    c->F.vbar[c0 + (long)(knew - 1) * nij] = c->src.Qbar[is] * cff;
+  }
+}
+
 int step2d_impl(const roms_step_idx_t *si, bool in_loop)
 {
   const roms_bounds_t &b = g_ctx.b;
@@ -368,7 +395,9 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   const bool walls = lbc2d_all_closed();
   // (UV_VIS4: the biharmonic term is a pass of its own in front of the momentum kernel -- general path only)
   // (WET_DRY: the masks are a pass of their own between the averages and the free surface -- general path only)
-  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.loopback && walls && !p.uv_vis4 && !p.wet_dry;
+  // (LuvSrc: the source faces are a launch of their own after the boundary conditions -- general path only)
+  const bool srcs = (p.point_sources & 1) != 0;
+  const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.loopback && walls && !p.uv_vis4 && !p.wet_dry && !srcs;
   if (sm) {
     if (s.iif <= p.nfast) {
       // ONE launch: free surface, fast-time averages and momentum (k2d_mom_lds<true>)
@@ -407,7 +436,7 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
     if ((rc = halo_batch_end())) return rc;
   }
   g_flux_ready = false;
-  if (in_loop && multi && walls && s.iif <= p.nfast && !p.uv_vis4 && !p.wet_dry) {
+  if (in_loop && multi && walls && s.iif <= p.nfast && !p.uv_vis4 && !p.wet_dry && !srcs) {
     // ONE compute launch + ONE exchange per call
     s.sm = 3;
     if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, nullptr, nullptr, DUnext, DVnext))) return rc;
@@ -443,6 +472,10 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, zeta_new, zwrk))) return rc;
   if ((rc = bc_u2d(s.knew, si))) return rc;
   if ((rc = bc_v2d(s.knew, si))) return rc;
+  if (srcs && g_ctx.hostc.src.n > 0) {        // LuvSrc, step2d_LF_AM3.h:2484-2502
+    hipLaunchKernelGGL(k2d_src_bar, dim3((g_ctx.hostc.src.n + 63) / 64), dim3(64), 0, g_ctx.stream, g_ctx.devc, s.knew);
+    KERNEL_CHECK("k2d_src_bar");
+  }
   halo_batch_begin();
   if (s.predictor) halo_exchange2d(GT_R, g_ctx.dev[FID_rzeta] + (long)(s.krhs - 1) * nij);
   halo_exchange2d(GT_R, g_ctx.dev[FID_zeta] + (long)(s.knew - 1) * nij);

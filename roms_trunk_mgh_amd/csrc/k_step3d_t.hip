@@ -151,6 +151,8 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   const bool e_wall = b.east_edge && !b.EWperiodic && i == b.Iend;
   const long oxm2 = w_wall ? 0 : -2, oxp2 = e_wall ? 0 : 2;
 
+  const bool src_cell = c->src.n > 0 && src_cell_any(c, c0, ni);      // LuvSrc: a face of this cell is a source face
+
   double tn[NMAX + 1], CF[NMAX + 1], DC[NMAX + 1];
   CF[0] = 0.0;
   DC[0] = 0.0;
@@ -248,6 +250,8 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
         FEj = hflux<HADV>(hv0, ym1, tk, dym1, dy0, dyp1);
         FEjp1 = hflux<HADV>(hv1, tk, yp1, dy0, dyp1, dyp2);
       }
+      if (src_cell)                                  // LuvSrc, step3d_t.F:734-799
+        src_cell_fluxes<false>(c, c0, ck, ni, k, itrc, c->F.t + (2L + 3L * (itrc - 1)) * n3r, FXi, FXip1, FEj, FEjp1);
       // ---- vertical flux through the top face of level k ----
       double FCk;
       if (k == N) FCk = 0.0;
@@ -324,7 +328,11 @@ struct LevelIn {
 // MASK (MASKING applications, a second instantiation so that the unmasked kernel keeps its registers): the
 // first differences are multiplied by umask / vmask of their face (step3d_t.F:603, :667) and the result by
 // rmask (:1586-1596); the masks are read per level (cache hits) rather than held in registers.
-template <int HADV, int VADV, int NMAX, bool MASK>
+// SRC (LuvSrc, point sources): the cells with a source face are a handful; the plain instantiation skips them (one
+// look at the face maps per column, and only when there is a table) and the SRC instantiation -- the same text plus the
+// replacement of the source faces' fluxes, step3d_t.F:734-799 -- runs over the list of those cells, grid =
+// (cells / 256, tracers of the launch).  The threads of the kernel do not cooperate, so any cell-to-thread map will do.
+template <int HADV, int VADV, int NMAX, bool MASK, bool SRC = false>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
 {
@@ -332,12 +340,23 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
   constexpr int NTH = BLK_X * BLK_Y;
   __shared__ double s_tn[NMAX * NTH];
   const int tid = threadIdx.y * BLK_X + threadIdx.x;
-  const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
-  if (!tt.valid) return;
-  const int i = b.Istr + tt.bx * BLK_X + threadIdx.x;
-  const int j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
-  const int itrc = itrc0 + tt.itr;
-  if (i > b.Iend || j > b.Jend) return;
+  int i, j, itrc;
+  if constexpr (SRC) {
+    const int q = blockIdx.x * NTH + tid;
+    if (q >= c->src.ncell) return;
+    const int cell = c->src.cells[q];
+    i = LBi + (int)(cell % ni);
+    j = LBj + (int)(cell / ni);
+    itrc = itrc0 + (int)blockIdx.y;
+  } else {
+    const TileTr tt = decode_tile_tracer(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1, ntr);
+    if (!tt.valid) return;
+    i = b.Istr + tt.bx * BLK_X + threadIdx.x;
+    j = b.Jstr + tt.by * BLK_Y + threadIdx.y;
+    itrc = itrc0 + tt.itr;
+    if (i > b.Iend || j > b.Jend) return;
+    if (c->src.n > 0 && src_cell_any(c, I2(i, j), ni)) return;      // the SRC launch steps this column
+  }
   const int ltrc = itrc < b.NAT ? itrc : b.NAT;
   const double dt = c->p.dt;
   const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (itrc - 1)) * n3r);
@@ -449,10 +468,13 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       if (n_wall) dyp2 = dyp1;
       if (w_wall) dxm1 = dx0;
       if (e_wall) dxp2 = dxp1;
-      const double FXi = hflux<HADV>(cur.hu0, cur.xm1, tk, dxm1, dx0, dxp1);
-      const double FXip1 = hflux<HADV>(cur.hu1, tk, cur.xp1, dx0, dxp1, dxp2);
-      const double FEj = hflux<HADV>(cur.hv0, cur.ym1, tk, dym1, dy0, dyp1);
-      const double FEjp1 = hflux<HADV>(cur.hv1, tk, cur.yp1, dy0, dyp1, dyp2);
+      double FXi = hflux<HADV>(cur.hu0, cur.xm1, tk, dxm1, dx0, dxp1);
+      double FXip1 = hflux<HADV>(cur.hu1, tk, cur.xp1, dx0, dxp1, dxp2);
+      double FEj = hflux<HADV>(cur.hv0, cur.ym1, tk, dym1, dy0, dyp1);
+      double FEjp1 = hflux<HADV>(cur.hv1, tk, cur.yp1, dy0, dyp1, dyp2);
+      if constexpr (SRC)                             // LuvSrc, step3d_t.F:734-799
+        src_cell_fluxes<false>(c, c0, c0 + (long)(k - 1) * nij, ni, k, itrc, c->F.t + (2L + 3L * (itrc - 1)) * n3r, FXi,
+                               FXip1, FEj, FEjp1);
       double FCk;
       if (k == N) FCk = 0.0;
       else if constexpr (VADV == ADV_SPLINES) FCk = spl[k];
@@ -567,6 +589,18 @@ int launch_nmax(int nnew, int itrc0, int ntr)
       hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 64, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
   }
   KERNEL_CHECK("k_step3d_t");
+  if constexpr (HADV != ADV_HSIMT) {
+    // LuvSrc: the cells with a source face (one instantiation serves every N: a handful of columns)
+    const int ncell = g_ctx.hostc.src.ncell;
+    if (ncell > 0) {
+      const dim3 gs((ncell + BLK_X * BLK_Y - 1) / (BLK_X * BLK_Y), ntr);
+      if (g_ctx.p.masking)
+        hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, true, true>), gs, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+      else
+        hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, false, true>), gs, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+      KERNEL_CHECK("k_step3d_t (source cells)");
+    }
+  }
   return 0;
 }
 

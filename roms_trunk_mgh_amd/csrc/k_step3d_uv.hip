@@ -176,6 +176,40 @@ k_uv_column(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
   }
 }
 
+// LuvSrc, step3d_uv.F:971-995: u, v(nnew) of a source face = the source's transport of the level over the face's area
+// (the layer thickness as the reference writes it, from z_w).  One thread per (source, level); the face map settles two
+// sources on one face the way the sequential loop of the reference does.
+// The reference sets these velocities after the boundary conditions and couples afterwards; k_uv_column has coupled its
+// columns already.  So the mass fluxes of the source faces are set aside before it runs (save = 1) and put back here
+// (save = 0), and k_uv_couple couples those columns again, from the source's velocity.
+__global__ void k_src_uv(const RomsDev *__restrict__ c, int nnew, int save)
+{
+  DEV_PROLOGUE(c)
+  const int is = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = 1 + (int)blockIdx.y;
+  if (is >= c->src.n) return;
+  const int i = c->src.I[is], j = c->src.J[is];
+  if (!(b.IstrR <= i && i <= b.IendR && b.JstrR <= j && j <= b.JendR)) return;
+  const long c0 = I2(i, j);
+  const double *__restrict__ z_w = c->F.z_w;
+  const double q = c->src.Qsrc[is + (long)c->src.n * (k - 1)];
+  const long w1 = c0 + (long)k * nij, w0 = c0 + (long)(k - 1) * nij;
+  double *__restrict__ keep = c->src.save + is + (long)c->src.n * (k - 1);
+  if (c->src.D[is] == 0) {
+    if (c->src.umap[c0] != is + 1) return;
+    if (save) { *keep = c->F.Huon[w0]; return; }
+    c->F.Huon[w0] = *keep;
+    const double cff1 = 1.0 / (c->F.on_u[c0] * 0.5 * (z_w[w1 - 1] - z_w[w0 - 1] + z_w[w1] - z_w[w0]));
+    c->F.u[(long)(nnew - 1) * n3r + c0 + (long)(k - 1) * nij] = q * cff1;
+  } else {
+    if (c->src.vmap[c0] != is + 1) return;
+    if (save) { *keep = c->F.Hvom[w0]; return; }
+    c->F.Hvom[w0] = *keep;
+    const double cff1 = 1.0 / (c->F.om_v[c0] * 0.5 * (z_w[w1 - ni] - z_w[w0 - ni] + z_w[w1] - z_w[w0]));
+    c->F.v[(long)(nnew - 1) * n3r + c0 + (long)(k - 1) * nij] = q * cff1;
+  }
+}
+
 // Coupling of one column; comp 0 = u (neighbour i-1), 1 = v (neighbour j-1).
 template <int NMAX>
 __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, long c0, long off, long nij, int N,
@@ -244,10 +278,11 @@ k_uv_couple(const RomsDev *__restrict__ c, int nnew)
   const long c0 = I2(i, j);
   const bool ns_wall = !b.NSperiodic;
   const bool masking = c->p.masking != 0, wet = c->p.wet_dry != 0;
-  // columns stepped by k_uv_column were coupled there
+  // columns stepped by k_uv_column were coupled there (but for the source faces, which k_src_uv has set since)
   const bool inner = i <= b.Iend && j >= b.Jstr && j <= b.Jend;
+  const bool srcs = c->src.n > 0;
   if (XB.z == 0) {
-    if (inner && i >= b.IstrU) return;
+    if (inner && i >= b.IstrU && !(srcs && c->src.umap[c0] != 0)) return;
     if (i < b.IstrP) return;
     // boundary points whose vertical mean is replaced after the boundary conditions: the wall rows (:1131-1190) and,
     // without E-W periodicity, the western / eastern boundary columns (:1075-1125)
@@ -257,7 +292,7 @@ k_uv_couple(const RomsDev *__restrict__ c, int nnew)
                         GF(DU_avg1)[c0], GF(DU_avg2)[c0], fix, masking, masking ? umaskw(c, c0) : 1.0, wet,
                         wet ? (double)GF(umask_wet)[c0] : 1.0);
   } else {
-    if (inner && i >= b.Istr && j >= b.JstrV) return;
+    if (inner && i >= b.Istr && j >= b.JstrV && !(srcs && c->src.vmap[c0] != 0)) return;
     if (j < b.Jstr) return;
     const bool fix = (ns_wall && (j == 1 || j == b.Mm + 1) && i >= b.Istr && i <= b.Iend) ||
                      (!b.EWperiodic && ((b.west_edge && i == b.Istr - 1) || (b.east_edge && i == b.Iend + 1)));
@@ -285,6 +320,10 @@ extern "C" int roms_hip_step3d_uv(const roms_step_idx_t *s)
   else cff = 0.25 * dt * 23.0 / 12.0;
   {
     ScopedTimer tm("step3d_uv");
+    if ((g_ctx.p.point_sources & 1) && g_ctx.hostc.src.n > 0) {      // LuvSrc: set the source faces' mass fluxes aside
+      hipLaunchKernelGGL(k_src_uv, dim3((g_ctx.hostc.src.n + 63) / 64, b.N), dim3(64), 0, g_ctx.stream, g_ctx.devc, s->nnew, 1);
+      KERNEL_CHECK("k_src_uv (save)");
+    }
     dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
     grid.z = 2;
     if (b.N <= 16) hipLaunchKernelGGL(k_uv_column<16>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
@@ -295,6 +334,10 @@ extern "C" int roms_hip_step3d_uv(const roms_step_idx_t *s)
     KERNEL_CHECK("k_uv_column");
     if ((rc = bc_u3d(s->nnew, s->nstp))) return rc;
     if ((rc = bc_v3d(s->nnew, s->nstp))) return rc;
+    if ((g_ctx.p.point_sources & 1) && g_ctx.hostc.src.n > 0) {
+      hipLaunchKernelGGL(k_src_uv, dim3((g_ctx.hostc.src.n + 63) / 64, b.N), dim3(64), 0, g_ctx.stream, g_ctx.devc, s->nnew, 0);
+      KERNEL_CHECK("k_src_uv");
+    }
     dim3 grid2 = grid2d(b.IendT - b.IstrT + 1, b.JendT - b.JstrT + 1);
     grid2.z = 2;
     if (b.N <= 16) hipLaunchKernelGGL(k_uv_couple<16>, grid2, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nnew);

@@ -14,6 +14,24 @@
 #include <string>
 #include "roms_hip.h"
 
+// The point-source table SOURCES(ng) (mod_sources.F:56-80) on the device, LuvSrc only (roms_hip_set_sources).  The two
+// face maps (nij ints: 1 + the index of the source at the u- / v-face of the point, 0 elsewhere; the last source of a
+// face wins, as the sequential loops of the reference leave it) let a kernel find "its" source without a search.
+struct RomsSrc {
+  int n;                      // Nsrc; 0 = no table
+  int ltr[ROMS_MAXNT];        // LtracerSrc(itrc)
+  const int *I, *J, *D;       // [n] Isrc, Jsrc, INT(Dsrc)
+  const double *Qbar;         // [n]
+  const double *Qsrc;         // [n * N]       is + n * (k-1)
+  const double *Tsrc;         // [n * N * NT]  is + n * ((k-1) + N * (itrc-1))
+  const int *umap, *vmap;     // [nij]
+  // the interior cells (Istr:Iend, Jstr:Jend) with a source face, as indices into the 2-D arrays: the software-pipelined
+  // tracer kernel leaves them to its SRC instantiation, which runs over this list
+  const int *cells;
+  int ncell;
+  double *save;               // [n * N] the mass fluxes of the source faces across k_uv_column (k_step3d_uv.hip)
+};
+
 struct RomsDev {
   roms_bounds_t b;
   roms_params_t p;
@@ -22,6 +40,7 @@ struct RomsDev {
   double *ws3[8];       // 3-D scratch, each nij*(N+1) doubles
   double *ws2[32];      // 2-D scratch, each nij doubles
   const double *rowm;   // row table of the i-uniform metric arrays (k_step2d_mom.hip), or nullptr
+  RomsSrc src;          // point sources (LuvSrc), n = 0 without
 };
 
 struct RomsCtx {
@@ -155,6 +174,39 @@ __device__ __forceinline__ double wet_factor(double mask_wet, double vel)
   const double cff5 = fabs(fabs(mask_wet) - 1.0);
   const double cff6 = 0.5 + copysign(0.5, vel) * mask_wet;
   return 0.5 * mask_wet * cff5 + cff6 * (1.0 - cff5);
+}
+
+// LuvSrc: the horizontal advective tracer fluxes of the four faces of cell c0 at level k (ck = its 3-D index), replaced
+// at source faces.  PRE = false: step3d_t.F:734-799 (Huon * Tsrc; without LtracerSrc and under MASKING the upstream value
+// of the wet side, T = t(:,:,:,3,itrc)); PRE = true: pre_step3d.F:530-553 (Huon * Tsrc, or zero without LtracerSrc).
+// The caller tests c->src.n (uniform) and src_cell_any() first: the body is the rare path.
+__device__ __forceinline__ bool src_cell_any(const RomsDev *__restrict__ c, long c0, long ni)
+{
+  return (c->src.umap[c0] | c->src.umap[c0 + 1] | c->src.vmap[c0] | c->src.vmap[c0 + ni]) != 0;
+}
+template <bool PRE>
+__device__ __forceinline__ void src_cell_fluxes(const RomsDev *__restrict__ c, long c0, long ck, long ni, int k, int itrc,
+                                                const double *__restrict__ T, double &FXi, double &FXip1, double &FEj,
+                                                double &FEjp1)
+{
+  const RomsSrc &S = c->src;
+  const bool ltr = S.ltr[itrc - 1] != 0;
+  const int N = c->b.N;
+  auto face = [&](int m, long cf, long ckf, long off, const double *__restrict__ H, double &Fv) {
+    if (!m) return;
+    const int is = m - 1;
+    if (ltr) Fv = H[ckf] * S.Tsrc[is + (long)S.n * ((k - 1) + (long)N * (itrc - 1))];
+    else if (PRE) Fv = 0.0;
+    else if (c->p.masking) {
+      const double r1 = c->F.rmask[cf], r0 = c->F.rmask[cf - off];
+      if (r1 == 0.0 && r0 == 1.0) Fv = H[ckf] * T[ckf - off];
+      else if (r1 == 1.0 && r0 == 0.0) Fv = H[ckf] * T[ckf];
+    }
+  };
+  face(S.umap[c0], c0, ck, 1, c->F.Huon, FXi);
+  face(S.umap[c0 + 1], c0 + 1, ck + 1, 1, c->F.Huon, FXip1);
+  face(S.vmap[c0], c0, ck, ni, c->F.Hvom, FEj);
+  face(S.vmap[c0 + ni], c0 + ni, ck + ni, ni, c->F.Hvom, FEjp1);
 }
 
 #define I2(i,j)    ((long)((i) - LBi) + (long)((j) - LBj) * ni)

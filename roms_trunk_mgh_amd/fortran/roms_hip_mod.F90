@@ -277,6 +277,15 @@ MODULE roms_hip_mod
       IMPORT :: c_int, roms_step_idx_t
       TYPE(roms_step_idx_t), INTENT(in) :: s
     END FUNCTION
+    !  LuvSrc: SOURCES(ng) of mod_sources.F (Isrc, Jsrc, Dsrc, Qbar, Qsrc, Tsrc) and LtracerSrc(:,ng) as 0 / 1;
+    !  after every set_data that changes them
+    INTEGER(c_int) FUNCTION roms_hip_set_sources (Nsrc, Isrc, Jsrc, Dsrc, Qbar, Qsrc, Tsrc, LtracerSrc)            &
+   &                        BIND(C, name='roms_hip_set_sources')
+      IMPORT :: c_int, c_double
+      INTEGER(c_int), VALUE :: Nsrc
+      INTEGER(c_int), INTENT(in) :: Isrc(*), Jsrc(*), LtracerSrc(*)
+      REAL(c_double), INTENT(in) :: Dsrc(*), Qbar(*), Qsrc(*), Tsrc(*)
+    END FUNCTION
     !  GLS_MIXING: gls_prestep (main3d.F:567) and gls_corstep (main3d.F:793)
     INTEGER(c_int) FUNCTION roms_hip_gls_prestep (s) BIND(C, name='roms_hip_gls_prestep')
       IMPORT :: c_int, roms_step_idx_t
@@ -304,6 +313,7 @@ MODULE roms_hip_mod
   PUBLIC :: roms_hip_step3d_uv, roms_hip_step3d_t, roms_hip_bulk_flux, roms_hip_set_vbc, roms_hip_lmd_vmix
   PUBLIC :: roms_hip_ana_srflux, roms_hip_wvelocity, roms_hip_diag, roms_hip_snapshot_begin, roms_hip_snapshot_end
   PUBLIC :: roms_hip_ini_zeta, roms_hip_ini_fields, roms_hip_gls_prestep, roms_hip_gls_corstep, roms_hip_wetdry
+  PUBLIC :: roms_hip_set_sources
   PUBLIC :: roms_hip_entry, roms_hip_make_idx, roms_hip_status
 
 CONTAINS

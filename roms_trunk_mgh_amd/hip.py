@@ -41,7 +41,7 @@ DECLARED_SYMBOLS = (
      "roms_hip_timing_last_ms", "roms_hip_calib_stream", "roms_hip_set_halo_relay", "roms_hip_diag",
      "roms_hip_snapshot_begin", "roms_hip_snapshot_end", "roms_hip_halo_plan",
      "roms_hip_ana_srflux", "roms_hip_check_guards", "roms_hip_row_metrics_state",
-     "roms_hip_graph_exchanges", "roms_hip_graph_exchanges_state"] + ["roms_hip_" + e for e in ENTRIES])
+     "roms_hip_graph_exchanges", "roms_hip_graph_exchanges_state", "roms_hip_set_sources"] + ["roms_hip_" + e for e in ENTRIES])
 
 
 _DP = C.POINTER(C.c_double)
@@ -82,6 +82,8 @@ def load():
     if hasattr(lib, "roms_hip_step2d_loop"):
         lib.roms_hip_step2d_loop.argtypes = [C.POINTER(abi.StepIdx), C.POINTER(C.c_int)]
     lib.roms_hip_calib_stream.argtypes = [C.c_long]
+    _ip = C.POINTER(C.c_int)
+    lib.roms_hip_set_sources.argtypes = [C.c_int, _ip, _ip, _DP, _DP, _DP, _DP, _ip]
     lib.roms_hip_set_halo_relay.argtypes = [RELAY_FN, C.c_void_p]
     if hasattr(lib, "roms_hip_tile_neighbors"):
         lib.roms_hip_tile_neighbors.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)]
@@ -142,6 +144,12 @@ class RomsHip:
             self._chk(self.l.roms_hip_register_field(abi.FIELD_ID[name], a.ctypes.data, a.size),
                       "register_field " + name)
         self._chk(self.l.roms_hip_sync_all_to_device(), "sync_all_to_device")
+        if getattr(state, "sources", None) is not None:
+            self.set_sources(state.sources)
+
+    def set_sources(self, src):
+        """SOURCES(ng) with LuvSrc (roms_trunk_mgh_amd/sources.py) -> roms_hip_set_sources"""
+        self._chk(self.l.roms_hip_set_sources(*src.c_args()), "set_sources")
 
     def _chk(self, rc, what):
         if rc != 0:

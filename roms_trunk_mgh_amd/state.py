@@ -53,7 +53,7 @@ class TileState:
         other = TileState.__new__(TileState)
         other.b, other.p, other.ni, other.nj = self.b, self.p, self.ni, self.nj
         other.arr = {k: v.copy(order="F") for k, v in self.arr.items()}
-        for extra in ("cfg", "lonr", "latr", "z_r0", "z_w0"):
+        for extra in ("cfg", "lonr", "latr", "z_r0", "z_w0", "sources"):
             if hasattr(self, extra):
                 setattr(other, extra, getattr(self, extra))
         return other

@@ -33,6 +33,9 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)
+    if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
+        import util
+        util.river_sources(st, "both" if "mask" in opts else "walls")
     b = st.b
     ndev = torch.cuda.device_count()
     if "rccl" in opts:

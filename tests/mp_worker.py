@@ -35,6 +35,9 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
     if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
         kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb, **kw)
+    if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
+        import util
+        util.river_sources(st, "both" if "mask" in opts else "walls")
     b = st.b
     ni, nj = st.ni, st.nj
     sr = halo.gloo_sendrecv(dist, torch)

@@ -151,17 +151,40 @@ def test_library_defaults_do_not_survive_a_parameter_change():
         h.close()
 
 
-def test_point_sources_are_refused():
-    """An application with rivers (LuvSrc / LwSrc) must not run without them: every entry fails with a message."""
+def test_point_sources_without_their_table_are_refused():
+    """An application with rivers must not run without them: with LuvSrc set and no roms_hip_set_sources call, or with
+    LwSrc (not built), every entry fails with a message; a table with a Dsrc = 2 source is refused as well."""
     import util
-    from roms_trunk_mgh_amd import hip
+    from roms_trunk_mgh_amd import hip, sources
     st = util.prepared_state("UPWELLING")
+    st.p = type(st.p).from_buffer_copy(st.p)
+    for flag in (1, 2, 3):
+        st.p.point_sources = flag
+        h = hip.RomsHip(st)
+        try:
+            for entry in ("step2d", "step3d_t", "omega"):
+                with pytest.raises(RuntimeError) as e:
+                    h.call(entry, util.step_idx())
+                assert "point sources" in str(e.value)
+        finally:
+            h.close()
     st.p.point_sources = 1
+    N, NT = st.b.N, st.b.NT
+    bad = sources.Sources([5], [5], [2.0], [10.0], np.full((1, N), 1.0 / N), np.zeros((1, N, NT)), np.ones(NT, dtype=np.int32))
     h = hip.RomsHip(st)
     try:
-        for entry in ("step2d", "step3d_t", "omega"):
-            with pytest.raises(RuntimeError) as e:
-                h.call(entry, util.step_idx())
-            assert "point sources" in str(e.value)
+        with pytest.raises(RuntimeError) as e:
+            h.set_sources(bad)
+        assert "LwSrc" in str(e.value)
+        # ... and a table handed to an application that has not set LuvSrc
+    finally:
+        h.close()
+    st.p.point_sources = 0
+    ok = sources.Sources([5], [5], [0.0], [10.0], np.full((1, N), 1.0 / N), np.zeros((1, N, NT)), np.ones(NT, dtype=np.int32))
+    h = hip.RomsHip(st)
+    try:
+        with pytest.raises(RuntimeError) as e:
+            h.set_sources(ok)
+        assert "point_sources" in str(e.value)
     finally:
         h.close()

@@ -15,6 +15,7 @@ import sys
 import numpy as np
 import pytest
 
+import util
 from roms_trunk_mgh_amd import ana, main3d
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -44,6 +45,8 @@ def _single(config, nsteps, variant=""):
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     st = ana.make_tile(config, perturb=1.0, **kw)
+    if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
+        util.river_sources(st, "both" if "mask" in opts else "walls")
     be = hip.RomsHip(st)
     m = main3d.Main3D(be, physics=("physics" in opts), diagnostics=("physics" in opts))
     m.initial()
@@ -75,6 +78,9 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "UPWELLING", "wet"), (2, 2, "UPWELLING", "wet+basin+mask"),
                                                     # biharmonic mixing across tile edges
                                                     (2, 2, "BENCHMARK_TINY", "dif4"), (2, 2, "BENCHMARK_TINY", "dif4+basin+mask"),
+                                                    # point sources (LuvSrc): rivers in the walls and on the island's coast
+                                                    (2, 2, "UPWELLING", "river+basin+mask"), (2, 1, "BENCHMARK_TINY", "river+physics"),
+                                                    (2, 2, "BENCHMARK_TINY", "river+mpdata+basin+mask"),
                                                     # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
                                                     # 512-column tiles of the 8-GPU run (4x1), both tile rows (2x2), the
                                                     # deferred-flux step2d path and, with six MPDATA tracers, three ghost points

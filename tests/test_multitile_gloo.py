@@ -11,6 +11,7 @@ import sys
 import numpy as np
 import pytest
 
+import util
 from roms_trunk_mgh_amd import ana, main3d
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -41,6 +42,8 @@ def _single(config, nsteps, variant=""):
     if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
         kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
     st = ana.make_tile(config, perturb=1.0, **kw)
+    if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
+        util.river_sources(st, "both" if "mask" in opts else "walls")
     m = main3d.Main3D(oracle.Oracle(st))
     m.initial()
     m.run(nsteps)
@@ -67,7 +70,11 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "UPWELLING", "wet"), (2, 2, "UPWELLING", "wet+basin+mask"),
                                                     # biharmonic mixing: the first operator's one-point-wider range
                                                     # and its edge rule across tile edges, channel and basin
-                                                    (2, 2, "BENCHMARK_TINY", "dif4"), (2, 2, "BENCHMARK_TINY", "dif4+basin+mask")])
+                                                    (2, 2, "BENCHMARK_TINY", "dif4"), (2, 2, "BENCHMARK_TINY", "dif4+basin+mask"),
+                                                    # point sources (LuvSrc): rivers in the walls and on the island's
+                                                    # coast, every rank holding the whole table; MPDATA's wider range
+                                                    (2, 2, "UPWELLING", "river+basin+mask"), (2, 1, "BENCHMARK_TINY", "river"),
+                                                    (2, 2, "BENCHMARK_TINY", "river+mpdata+basin+mask")])
 def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     nsteps = 3
     world = ntI * ntJ

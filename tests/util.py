@@ -285,3 +285,50 @@ def oracle_mpdata_adiff(st, oHz, Ta, t3):
                                  t3.ctypes.data, Ta.ctypes.data, Ua.ctypes.data, Va.ctypes.data, Wa.ctypes.data)
     assert rc == 0
     return Ta, Ua, Va, Wa
+
+
+def river_sources(st, kind="walls", same_tracer=False, seed=3):
+    """A point-source table for the state (LuvSrc; roms_trunk_mgh_amd/sources.py) and the switch in the parameters
+    (a private copy of them).  kind = "walls": faces of the closed walls -- an inflow through the southern wall, and in a
+    basin an inflow through the western wall and an outflow (a sink) through the eastern one; "coast": faces of the land
+    mask -- one u-face and one v-face with land behind them, flowing into the water.  Qshape grows towards the surface;
+    the first tracer comes with the river (LtracerSrc), the others do not -- unless same_tracer: then every tracer does,
+    with the value `same_tracer` (a river of ambient water)."""
+    from roms_trunk_mgh_amd import sources
+    b = st.b
+    N, NT = b.N, b.NT
+    # moves about a cell's volume in 250 steps; from the grid's nominal numbers, the same for every tiling
+    q0 = {"UPWELLING": 1.3e3 * 41 * 80, "SEAMOUNT": 1.3e7 * 49 * 48, "BENCHMARK": 1.0e9 * 64 * 32}[st.cfg["app"]] / (b.Lm * b.Mm)
+    I, J, D, Q = [], [], [], []
+    if kind in ("walls", "both"):
+        I.append(max(2, b.Lm // 3)); J.append(1); D.append(1.0); Q.append(q0)               # southern wall, northward
+        if not b.EWperiodic:
+            I.append(1); J.append(max(2, b.Mm // 2)); D.append(0.0); Q.append(0.7 * q0)      # western wall, eastward
+            I.append(b.Lm + 1); J.append(max(2, b.Mm // 4)); D.append(0.0); Q.append(0.4 * q0)   # eastern wall: a sink
+    if kind in ("coast", "both"):
+        # the whole grid's mask (the same faces for every tiling)
+        bg = ana.make_bounds(b.Lm, b.Mm, N, NT, b.NAT, 1, 1, 0, EWperiodic=bool(b.EWperiodic), NSperiodic=False,
+                             NghostPoints=b.NghostPoints)
+        rm = ana.island_mask(st.cfg, bg)
+        done_u = done_v = False
+        for j in range(3, b.Mm - 1):
+            for i in range(3, b.Lm - 1):
+                a, w, s = rm[i - bg.LBi, j - bg.LBj], rm[i - 1 - bg.LBi, j - bg.LBj], rm[i - bg.LBi, j - 1 - bg.LBj]
+                if not done_u and a == 1.0 and w == 0.0:
+                    I.append(i); J.append(j); D.append(0.0); Q.append(q0); done_u = True
+                elif not done_v and a == 0.0 and s == 1.0 and j > b.Mm // 2:
+                    I.append(i); J.append(j); D.append(1.0); Q.append(-0.6 * q0); done_v = True     # southward, into the water
+        assert done_u and done_v
+    n = len(I)
+    assert n > 0, kind
+    w = np.linspace(1.0, 3.0, N)
+    Qshape = np.tile(w / w.sum(), (n, 1))
+    Tsrc = np.zeros((n, N, NT))
+    rng = np.random.default_rng(seed)
+    for it in range(NT):
+        Tsrc[:, :, it] = same_tracer if same_tracer else (4.0 + 2.0 * it + 0.5 * rng.random((n, N)))
+    ltr = np.ones(NT, dtype=np.int32) if same_tracer else np.array([1] + [0] * (NT - 1), dtype=np.int32)
+    st.sources = sources.Sources(I, J, D, Q, Qshape, Tsrc, ltr)
+    st.p = type(st.p).from_buffer_copy(st.p)
+    st.p.point_sources = 1
+    return st.sources
