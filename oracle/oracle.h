@@ -236,7 +236,7 @@ static inline double o_tdiff(int stab, double a, double b, double a2, double b2)
   return stab ? 0.75 * (a - b) + 0.25 * (a2 - b2) : a - b;
 }
 /* point sources (oracle_sources.c): the table SOURCES(ng), process-wide */
-typedef struct { int n, N, NT; int ltr[ROMS_MAXNT]; int *I, *J; double *D, *Qbar, *Qsrc, *Tsrc; } o_src_t;
+typedef struct { int n, N, NT, given; int ltr[ROMS_MAXNT]; int *I, *J; double *D, *Qbar, *Qsrc, *Tsrc; } o_src_t;
 extern o_src_t o_src;
 int oracle_set_sources(int Nsrc, const int *Isrc, const int *Jsrc, const double *Dsrc, const double *Qbar,
                        const double *Qsrc, const double *Tsrc, const int *LtracerSrc, int N, int NT);
@@ -245,6 +245,9 @@ void o_src_ubar(OARGS, int knew);
 void o_src_uv(OARGS, int nnew);
 void o_src_tflux(OARGS, int itrc, int k, double *FX_, double *FE_, int wide, int pre);
 void o_src_masks(OARGS);
+void o_src_zeta(OARGS, int knew);
+void o_src_omega(OARGS, int j);
+void o_src_wtracer(OARGS, int itrc, int mpdata, int j, double *Ta_, const double *oHz_);
 int oracle_ini_zeta(OARGS);        /* ini_fields.F:836 */
 int oracle_ini_fields(OARGS);      /* ini_fields.F:106 */
 int oracle_step2d_loop(const roms_bounds_t *b, const roms_params_t *p, roms_step_idx_t *s,

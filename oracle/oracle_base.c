@@ -147,11 +147,11 @@ int oracle_set_massflux(OARGS)
   return 0;
 }
 
-/* omega_tile -- ROMS/Nonlinear/omega.F:73-229 (no point sources) */
+/* omega_tile -- ROMS/Nonlinear/omega.F:73-229 */
 int oracle_omega(OARGS)
 {
   ORACLE_PROLOGUE
-  (void)p; (void)s;
+  if (o_src_check(p)) return 8;
   double *wrk = walloc(nis);
   for (int j = Jstr; j <= Jend; j++) {
     for (int i = Istr; i <= Iend; i++) W(i, j, 0) = 0.0;
@@ -160,6 +160,7 @@ int oracle_omega(OARGS)
         W(i, j, k) = W(i, j, k - 1) -
                      (Huon(i + 1, j, k) - Huon(i, j, k) +
                       Hvom(i, j + 1, k) - Hvom(i, j, k));
+    o_src_omega(b, p, s, F, j);                      /* LwSrc, omega.F:165-190 */
     for (int i = Istr; i <= Iend; i++)
       wrk[i - IminS] = W(i, j, N) / (z_w(i, j, N) - z_w(i, j, 0));
     for (int k = N - 1; k >= 1; k--)

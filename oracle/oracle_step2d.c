@@ -166,6 +166,7 @@ int oracle_step2d(OARGS)
       for (int i = Istr; i <= Iend; i++) rzeta(i, j, krhs) = rhs_zeta(i, j);
     o_exchange2d(b, GT_R, &rzeta(LBi, LBj, krhs));
   }
+  o_src_zeta(b, p, s, F, knew);                      /* LwSrc, :890-908 */
   o_zetabc(b, p, s, F, knew);
   o_exchange2d(b, GT_R, &zeta(LBi, LBj, knew));
 

@@ -303,6 +303,7 @@ int oracle_step3d_t(OARGS)
           FC(i, 0) = 0.0;
           FC(i, N) = 0.0;
         }
+        o_src_wtracer(b, p, s, F, itrc, 1, j, Ta_, oHz_);                        /* LwSrc, :1136-1158 */
         for (int i = IstrUm2; i <= Iendp2i; i++) CF(i, 0) = dt * pm(i, j) * pn(i, j);
         for (int k = 1; k <= N; k++)
           for (int i = IstrUm2; i <= Iendp2i; i++) {
@@ -487,6 +488,11 @@ int oracle_step3d_t(OARGS)
         }
     }
   }
+
+  /* LwSrc: the tracer that comes with the volume of a cell-centred source, :1321-1360 */
+  for (int itrc = 1; itrc <= NT; itrc++)
+    if (!(p->Hadv[itrc - 1] == ADV_MPDATA && p->Vadv[itrc - 1] == ADV_MPDATA))
+      o_src_wtracer(b, p, s, F, itrc, 0, 0, NULL, oHz_);
 
   /* J_LOOP2: implicit vertical diffusion, step3d_t.F:1363-1560 */
   for (int j = Jstr; j <= Jend; j++) {

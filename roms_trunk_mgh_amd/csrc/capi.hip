@@ -281,8 +281,9 @@ extern "C" int roms_hip_set_sources(int Nsrc, const int *Isrc, const int *Jsrc, 
   if (!g_ctx.inited || !g_ctx.have_bounds || !g_ctx.have_params)
     return roms_fail(me, "roms_hip_init, roms_hip_set_bounds and roms_hip_set_params come first");
   if (Nsrc < 0) return roms_fail(me, "Nsrc < 0");
-  if (!(g_ctx.p.point_sources & 1))
-    return roms_fail(me, "point sources: roms_params_t.point_sources bit 0 (LuvSrc) is not set");
+  if (!(g_ctx.p.point_sources & 3))
+    return roms_fail(me, "point sources: neither bit of roms_params_t.point_sources (LuvSrc, LwSrc) is set");
+  const bool luv = (g_ctx.p.point_sources & 1) != 0, lw = (g_ctx.p.point_sources & 2) != 0;
   if (Nsrc == 0) {
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     sources_release();
@@ -296,8 +297,7 @@ extern "C" int roms_hip_set_sources(int Nsrc, const int *Isrc, const int *Jsrc, 
   std::vector<int> D(Nsrc);
   for (int is = 0; is < Nsrc; is++) {
     D[is] = (int)Dsrc[is];
-    if (D[is] != 0 && D[is] != 1)
-      return roms_fail(me, "point sources: a source with Dsrc = 2 (LwSrc, volume influx at a cell centre) is not implemented");
+    if (D[is] < 0 || D[is] > 2) return roms_fail(me, "point sources: Dsrc is 0 (u-face), 1 (v-face) or 2 (cell centre)");
   }
   const bool same = g_src.geo && g_src.n == Nsrc && g_src.N == N && g_src.NT == NT && g_src.nij == nij &&
                     std::equal(g_src.I.begin(), g_src.I.end(), Isrc) && std::equal(g_src.J.begin(), g_src.J.end(), Jsrc) &&
@@ -307,17 +307,20 @@ extern "C" int roms_hip_set_sources(int Nsrc, const int *Isrc, const int *Jsrc, 
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     step2d_graphs_release();               // captured launches hold the old table's addresses
     sources_release();
-    const size_t ngeo = 3 * (size_t)Nsrc + 2 * (size_t)nij + 2 * (size_t)Nsrc;
+    const size_t ngeo = 3 * (size_t)Nsrc + 3 * (size_t)nij + 2 * (size_t)Nsrc;
     std::vector<int> geo(ngeo, 0);
-    int *umap = geo.data() + 3 * (size_t)Nsrc, *vmap = umap + nij, *cells = vmap + nij;
+    int *umap = geo.data() + 3 * (size_t)Nsrc, *vmap = umap + nij, *wmap = vmap + nij, *cells = wmap + nij;
     int ncell = 0;
     for (int is = 0; is < Nsrc; is++) {
       geo[is] = Isrc[is]; geo[Nsrc + is] = Jsrc[is]; geo[2 * (size_t)Nsrc + is] = D[is];
-      // the face maps: the last source of a face wins, as the sequential loops of the reference leave it
+      // a source of a kind the application has switched off is not looked at (IF (LuvSrc) / IF (LwSrc) in the reference)
+      if (D[is] == 2 ? !lw : !luv) continue;
+      // the face / cell maps: the last source of a face wins, as the sequential loops of the reference leave it
       if (Isrc[is] >= b.LBi && Isrc[is] <= b.UBi && Jsrc[is] >= b.LBj && Jsrc[is] <= b.UBj)
-        (D[is] == 0 ? umap : vmap)[(long)(Isrc[is] - b.LBi) + (long)(Jsrc[is] - b.LBj) * ni] = is + 1;
-      // the two cells of the face, where they are interior cells of this tile (each once)
-      for (int side = 0; side < 2; side++) {
+        (D[is] == 0 ? umap : D[is] == 1 ? vmap : wmap)[(long)(Isrc[is] - b.LBi) + (long)(Jsrc[is] - b.LBj) * ni] = is + 1;
+      // the two cells of the face (the one cell of a cell-centred source), where they are interior cells of this tile
+      // (each once)
+      for (int side = 0; side < (D[is] == 2 ? 1 : 2); side++) {
         const int ci = Isrc[is] - (D[is] == 0 ? side : 0), cj = Jsrc[is] - (D[is] == 1 ? side : 0);
         if (ci < b.Istr || ci > b.Iend || cj < b.Jstr || cj > b.Jend) continue;
         const int cell = (int)((long)(ci - b.LBi) + (long)(cj - b.LBj) * ni);
@@ -333,7 +336,8 @@ extern "C" int roms_hip_set_sources(int Nsrc, const int *Isrc, const int *Jsrc, 
     S.n = Nsrc;
     S.I = g_src.geo; S.J = g_src.geo + Nsrc; S.D = g_src.geo + 2 * (size_t)Nsrc;
     S.umap = g_src.geo + 3 * (size_t)Nsrc; S.vmap = S.umap + nij;
-    S.cells = S.vmap + nij; S.ncell = ncell;
+    S.wmap = S.vmap + nij;
+    S.cells = S.wmap + nij; S.ncell = ncell;
     S.Qbar = g_src.val; S.Qsrc = g_src.val + Nsrc; S.Tsrc = g_src.val + Nsrc + (size_t)Nsrc * N;
     S.save = g_src.val + nval;
   }
@@ -394,7 +398,7 @@ extern "C" int roms_hip_set_params(const roms_params_t *p)
   if (!g_ctx.inited) return roms_fail("roms_hip_set_params", "library not initialised");
   if (2 * p->ndtfast > ROMS_MAXFAST) return roms_fail("roms_hip_set_params", "ndtfast too large");
   step2d_graphs_release();
-  if (!(p->point_sources & 1) && roms_sources_given()) {     // LuvSrc switched off: the kernels look at the table alone
+  if ((p->point_sources & 3) != (g_ctx.p.point_sources & 3) && roms_sources_given()) {   // the maps were built for the old switches
     (void)hipStreamSynchronize(g_ctx.stream);
     sources_release();
   }
@@ -534,12 +538,9 @@ int roms_entry_check(const char *name)
   if (!g_ctx.have_bounds || !g_ctx.have_params) return roms_fail(name, "bounds/params not set");
   // WET_DRY exists only with MASKING in the reference (wetdry.F:325-345 reads rmask ... vmask unconditionally)
   if (g_ctx.p.wet_dry && !g_ctx.p.masking) return roms_fail(name, "wet_dry = 1 needs masking = 1");
-  // mod_sources.F -- never run a river application without its rivers: LuvSrc needs the table of roms_hip_set_sources,
-  // LwSrc (volume influx at cell centres) is not built
-  if (g_ctx.p.point_sources & 2)
-    return roms_fail(name, "point sources: LwSrc (Dsrc = 2) is not implemented: keep this application on the host path");
-  if ((g_ctx.p.point_sources & 1) && !roms_sources_given())
-    return roms_fail(name, "point sources: LuvSrc is set but roms_hip_set_sources has not handed over SOURCES(ng)");
+  // mod_sources.F -- never run a river application without its rivers: LuvSrc / LwSrc need the table of roms_hip_set_sources
+  if ((g_ctx.p.point_sources & 3) && !roms_sources_given())
+    return roms_fail(name, "point sources: LuvSrc / LwSrc is set but roms_hip_set_sources has not handed over SOURCES(ng)");
   for (int id = 0; id < FID_COUNT; id++)
     if (!g_ctx.dev[id]) {
       double value;

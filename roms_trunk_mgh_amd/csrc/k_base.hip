@@ -543,6 +543,31 @@ k_omega(const RomsDev *__restrict__ c)
   W[I3W(i, j, N)] = 0.0;
 }
 
+// LwSrc, omega.F:165-190: W of a column with a cell-centred source, recomputed with the source's Qsrc(k) added to the
+// divergence and normalised like every other column.  One thread per source; of several sources in one cell the last
+// one's Qsrc alone enters W (the loop of the reference overwrites) -- the cell map names it.
+__global__ void k_src_omega(const RomsDev *__restrict__ c)
+{
+  DEV_PROLOGUE(c)
+  const int is = blockIdx.x * blockDim.x + threadIdx.x;
+  if (is >= c->src.n || c->src.D[is] != 2) return;
+  const int i = c->src.I[is], j = c->src.J[is];
+  if (i < b.Istr || i > b.Iend || j < b.Jstr || j > b.Jend) return;
+  if (c->src.wmap[I2(i, j)] != is + 1) return;
+  const double *__restrict__ Huon = c->F.Huon, *__restrict__ Hvom = c->F.Hvom, *__restrict__ z_w = c->F.z_w;
+  double *__restrict__ W = c->F.W;
+  double w = 0.0;
+  for (int k = 1; k <= N; k++) {
+    w = w - (Huon[I3(i + 1, j, k)] - Huon[I3(i, j, k)] + Hvom[I3(i, j + 1, k)] - Hvom[I3(i, j, k)]) +
+        c->src.Qsrc[is + (long)c->src.n * (k - 1)];
+    W[I3W(i, j, k)] = w;
+  }
+  const double zw0 = z_w[I3W(i, j, 0)];
+  const double wrk = w / (z_w[I3W(i, j, N)] - zw0);
+  for (int k = N - 1; k >= 1; k--) W[I3W(i, j, k)] = W[I3W(i, j, k)] - wrk * (z_w[I3W(i, j, k)] - zw0);
+  W[I3W(i, j, N)] = 0.0;
+}
+
 extern "C" int roms_hip_omega(const roms_step_idx_t *s)
 {
   (void)s;
@@ -556,6 +581,10 @@ extern "C" int roms_hip_omega(const roms_step_idx_t *s)
   else if (b.N <= 32) hipLaunchKernelGGL(k_omega<32>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc);
   else hipLaunchKernelGGL(k_omega<ROMS_MAXN>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc);
   KERNEL_CHECK("k_omega");
+  if ((g_ctx.p.point_sources & 2) && g_ctx.hostc.src.n > 0) {
+    hipLaunchKernelGGL(k_src_omega, dim3((g_ctx.hostc.src.n + 63) / 64), dim3(64), 0, g_ctx.stream, g_ctx.devc);
+    KERNEL_CHECK("k_src_omega");
+  }
   return bc_w3d(g_ctx.dev[FID_W]);
 }
 

@@ -97,12 +97,16 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
     double FXip1 = upstream(Huon[a + 1], t0, t3[a + 1]);
     double FEj = upstream(Hvom[a], t3[a - ni], t0);
     double FEjp1 = upstream(Hvom[a + ni], t0, t3[a + ni]);
-    if (c->src.n > 0 && src_cell_any(c, c0, ni))     // LuvSrc, step3d_t.F:734-799 (on the extended range of MPDATA)
+    const bool src_cell = c->src.n > 0 && src_cell_any(c, c0, ni);
+    if (src_cell)                                    // LuvSrc, step3d_t.F:734-799 (on the extended range of MPDATA)
       src_cell_fluxes<false>(c, c0, a, ni, k, m.itrc, c->F.t + (2L + 3L * (m.itrc - 1)) * n3r, FXi, FXip1, FEj, FEjp1);
     const double cff1 = cff * (FXip1 - FXi);
     const double cff2 = cff * (FEjp1 - FEj);
     const double cff3 = cff1 + cff2;
     double ta = tn[a] - cff3;                                   // step3d_t.F:838
+    // LwSrc, :1136-1158: on Istr:Iend+1, Jstr:Jend+1 only, not on the rest of MPDATA's extended range
+    if (src_cell && i >= b.Istr && i <= b.Iend + 1 && j >= b.Jstr && j <= b.Jend + 1)
+      ta = src_w_tracer(c, c0, k, m.itrc, cff, t0, ta);
     const double FCk = (k < N) ? upstream(Wv[a + nij], t0, t3[a + nij]) : 0.0;   // :1006-1018
     const double c1 = cff * (FCk - FCm1);
     ta = (ta - c1) * (1.0 / Hz[a]);                             // :1175

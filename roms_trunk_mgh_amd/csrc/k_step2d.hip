@@ -370,10 +370,27 @@ __global__ void k2d_src_bar(const RomsDev *__restrict__ c, int knew)
     if (c->src.umap[c0] != is + 1) return;
     const double cff = 1.0 / (c->F.on_u[c0] * 0.5 * (zeta[c0 - 1] + h[c0 - 1] + zeta[c0] + h[c0]));
     c->F.ubar[c0 + (long)(knew - 1) * nij] = c->src.Qbar[is] * cff;
-  } else {
+  } else if (c->src.D[is] == 1) {
     if (c->src.vmap[c0] != is + 1) return;
     const double cff = 1.0 / (c->F.om_v[c0] * 0.5 * (zeta[c0 - ni] + h[c0 - ni] + zeta[c0] + h[c0]));
     c->F.vbar[c0 + (long)(knew - 1) * nij] = c->src.Qbar[is] * cff;
+  }
+}
+
+// LwSrc, step2d_LF_AM3.h:890-908: the new free surface of the cells with a cell-centred source rises by the source's
+// volume over the cell's area (before zetabc).  ONE thread walks the table: sources sharing a cell add up in the
+// table's order, as in the reference.
+__global__ void k2d_src_zeta(const RomsDev *__restrict__ c, int knew)
+{
+  DEV_PROLOGUE(c)
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double *__restrict__ zeta = c->F.zeta + (long)(knew - 1) * nij;
+  for (int is = 0; is < c->src.n; is++) {
+    if (c->src.D[is] != 2) continue;
+    const int i = c->src.I[is], j = c->src.J[is];
+    if (!(b.IstrR <= i && i <= b.IendR && b.JstrR <= j && j <= b.JendR)) continue;
+    const long c0 = I2(i, j);
+    zeta[c0] = zeta[c0] + c->src.Qbar[is] * c->F.pm[c0] * c->F.pn[c0] * c->p.dtfast;
   }
 }
 
@@ -395,8 +412,8 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   const bool walls = lbc2d_all_closed();
   // (UV_VIS4: the biharmonic term is a pass of its own in front of the momentum kernel -- general path only)
   // (WET_DRY: the masks are a pass of their own between the averages and the free surface -- general path only)
-  // (LuvSrc: the source faces are a launch of their own after the boundary conditions -- general path only)
-  const bool srcs = (p.point_sources & 1) != 0;
+  // (LuvSrc / LwSrc: the source faces and cells are launches of their own -- general path only)
+  const bool srcs = (p.point_sources & 3) != 0;
   const bool sm = b.ntileI * b.ntileJ == 1 && b.EWperiodic && !b.NSperiodic && !g_ctx.loopback && walls && !p.uv_vis4 && !p.wet_dry && !srcs;
   if (sm) {
     if (s.iif <= p.nfast) {
@@ -467,12 +484,16 @@ int step2d_impl(const roms_step_idx_t *si, bool in_loop)
   // WET_DRY: the new wet/dry masks, :729-749 (after the averages and their exchange, before the return below)
   if (p.wet_dry && (rc = wetdry_launch(s.iif <= p.nfast ? 0 : 1, s.iif == 1 && s.predictor, s.kstp))) return rc;
   if (s.iif > p.nfast) return 0;
+  if ((p.point_sources & 2) && g_ctx.hostc.src.n > 0) {     // LwSrc, :890-908
+    hipLaunchKernelGGL(k2d_src_zeta, dim3(1), dim3(64), 0, g_ctx.stream, g_ctx.devc, s.knew);
+    KERNEL_CHECK("k2d_src_zeta");
+  }
   if ((rc = bc_zeta(s.knew, si))) return rc;
   if (p.uv_vis4 && (rc = roms_launch_step2d_visc4(s.krhs))) return rc;
   if ((rc = roms_launch_k2d_mom_lds((const int *)&s, DUon, DVom, zeta_new, zwrk))) return rc;
   if ((rc = bc_u2d(s.knew, si))) return rc;
   if ((rc = bc_v2d(s.knew, si))) return rc;
-  if (srcs && g_ctx.hostc.src.n > 0) {        // LuvSrc, step2d_LF_AM3.h:2484-2502
+  if ((p.point_sources & 1) && g_ctx.hostc.src.n > 0) {        // LuvSrc, step2d_LF_AM3.h:2484-2502
     hipLaunchKernelGGL(k2d_src_bar, dim3((g_ctx.hostc.src.n + 63) / 64), dim3(64), 0, g_ctx.stream, g_ctx.devc, s.knew);
     KERNEL_CHECK("k2d_src_bar");
   }

@@ -273,6 +273,7 @@ k_step3d_t(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       }
       tv = tv - cffdt * (FCk - FCprev);
       tv = tv * ohz;
+      if (src_cell) tv = src_w_tracer(c, c0, k, itrc, cffdt * ohz, tk, tv);       // LwSrc, step3d_t.F:1331-1360
       tn[k] = tv;
       FCprev = FCk;
       // ---- Thomas forward elimination for row kk = k-1, step3d_t.F:1376-1410 ----
@@ -494,6 +495,7 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
       }
       tv = tv - cffdt * (FCk - FCprev);
       tv = tv * ohz;
+      if constexpr (SRC) tv = src_w_tracer(c, c0, k, itrc, cffdt * ohz, tk, tv);   // LwSrc, step3d_t.F:1331-1360
       s_tn[(k - 1) * NTH + tid] = tv;
       FCprev = FCk;
       const double akt_0 = cur.akt;

@@ -201,7 +201,7 @@ __global__ void k_src_uv(const RomsDev *__restrict__ c, int nnew, int save)
     c->F.Huon[w0] = *keep;
     const double cff1 = 1.0 / (c->F.on_u[c0] * 0.5 * (z_w[w1 - 1] - z_w[w0 - 1] + z_w[w1] - z_w[w0]));
     c->F.u[(long)(nnew - 1) * n3r + c0 + (long)(k - 1) * nij] = q * cff1;
-  } else {
+  } else if (c->src.D[is] == 1) {
     if (c->src.vmap[c0] != is + 1) return;
     if (save) { *keep = c->F.Hvom[w0]; return; }
     c->F.Hvom[w0] = *keep;

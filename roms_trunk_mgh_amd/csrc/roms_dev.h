@@ -24,9 +24,10 @@ struct RomsSrc {
   const double *Qbar;         // [n]
   const double *Qsrc;         // [n * N]       is + n * (k-1)
   const double *Tsrc;         // [n * N * NT]  is + n * ((k-1) + N * (itrc-1))
-  const int *umap, *vmap;     // [nij]
-  // the interior cells (Istr:Iend, Jstr:Jend) with a source face, as indices into the 2-D arrays: the software-pipelined
-  // tracer kernel leaves them to its SRC instantiation, which runs over this list
+  const int *umap, *vmap;     // [nij]  (LuvSrc; all zero without)
+  const int *wmap;            // [nij]  LwSrc: 1 + the index of the last cell-centred source (Dsrc = 2) of the point
+  // the interior cells (Istr:Iend, Jstr:Jend) with a source face or a cell-centred source, as indices into the 2-D
+  // arrays: the software-pipelined tracer kernel leaves them to its SRC instantiation, which runs over this list
   const int *cells;
   int ncell;
   double *save;               // [n * N] the mass fluxes of the source faces across k_uv_column (k_step3d_uv.hip)
@@ -182,7 +183,24 @@ __device__ __forceinline__ double wet_factor(double mask_wet, double vel)
 // The caller tests c->src.n (uniform) and src_cell_any() first: the body is the rare path.
 __device__ __forceinline__ bool src_cell_any(const RomsDev *__restrict__ c, long c0, long ni)
 {
-  return (c->src.umap[c0] | c->src.umap[c0 + 1] | c->src.vmap[c0] | c->src.vmap[c0 + ni]) != 0;
+  return (c->src.umap[c0] | c->src.umap[c0 + 1] | c->src.vmap[c0] | c->src.vmap[c0 + ni] | c->src.wmap[c0]) != 0;
+}
+// LwSrc, step3d_t.F:1136-1158 / :1331-1360: the tracer that comes with the volume of the cell-centred sources of point
+// c0 at level k, added to tv (Ta before its vertical advection for MPDATA, t(nnew) after it otherwise); cff =
+// dt * pm * pn (times oHz outside MPDATA), t3k = t(i,j,k,3,itrc), the value the inflow carries without LtracerSrc.
+// Every source of the cell counts, in the order of the table (the sums of the reference's loop).
+__device__ __forceinline__ double src_w_tracer(const RomsDev *__restrict__ c, long c0, int k, int itrc, double cff,
+                                               double t3k, double tv)
+{
+  const RomsSrc &S = c->src;
+  if (S.wmap[c0] == 0) return tv;
+  const long ni = c->b.UBi - c->b.LBi + 1;
+  for (int is = 0; is < S.n; is++) {
+    if (S.D[is] != 2 || (long)(S.I[is] - c->b.LBi) + (long)(S.J[is] - c->b.LBj) * ni != c0) continue;
+    const double cff3 = S.ltr[itrc - 1] ? S.Tsrc[is + (long)S.n * ((k - 1) + (long)c->b.N * (itrc - 1))] : t3k;
+    tv = tv + cff * S.Qsrc[is + (long)S.n * (k - 1)] * cff3;
+  }
+  return tv;
 }
 template <bool PRE>
 __device__ __forceinline__ void src_cell_fluxes(const RomsDev *__restrict__ c, long c0, long ck, long ni, int k, int itrc,

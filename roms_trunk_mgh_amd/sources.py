@@ -1,4 +1,4 @@
-"""Point sources / sinks (rivers): the host-side image of SOURCES(ng) (ROMS/Modules/mod_sources.F:56-80) with LuvSrc,
+"""Point sources / sinks (rivers): the host-side image of SOURCES(ng) (ROMS/Modules/mod_sources.F:56-80) with LuvSrc / LwSrc,
 as an application's ana_psource.h or its river forcing file fills it.  A TileState carries one as `state.sources`;
 both backends hand it to their library when they are built and whenever `set_sources` is called again (the reference
 refreshes Qbar / Qsrc / Tsrc in set_data.F:124-160 every step)."""
@@ -12,8 +12,9 @@ _DP = C.POINTER(C.c_double)
 
 class Sources:
     def __init__(self, Isrc, Jsrc, Dsrc, Qbar, Qshape, Tsrc, LtracerSrc):
-        """Isrc, Jsrc: grid indices of the u-face (Dsrc = 0) or v-face (Dsrc = 1) the source flows through; Qbar (m3/s,
-        positive in the direction of increasing index); Qshape (Nsrc, N), the vertical distribution (sums to one);
+        """Isrc, Jsrc: grid indices of the u-face (Dsrc = 0) or v-face (Dsrc = 1) the source flows through, or of the
+        cell it enters (Dsrc = 2, LwSrc); Qbar (m3/s, positive in the direction of increasing index, or into the
+        cell); Qshape (Nsrc, N), the vertical distribution (sums to one);
         Tsrc (Nsrc, N, NT); LtracerSrc (NT)."""
         self.Isrc = np.ascontiguousarray(Isrc, dtype=np.int32)
         self.Jsrc = np.ascontiguousarray(Jsrc, dtype=np.int32)

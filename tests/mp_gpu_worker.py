@@ -35,7 +35,7 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)
     if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
         import util
-        util.river_sources(st, "both" if "mask" in opts else "walls")
+        util.river_sources(st, "all" if "wells" in opts else "both" if "mask" in opts else "walls")
     b = st.b
     ndev = torch.cuda.device_count()
     if "rccl" in opts:

@@ -37,7 +37,7 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=perturb, **kw)
     if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
         import util
-        util.river_sources(st, "both" if "mask" in opts else "walls")
+        util.river_sources(st, "all" if "wells" in opts else "both" if "mask" in opts else "walls")
     b = st.b
     ni, nj = st.ni, st.nj
     sr = halo.gloo_sendrecv(dist, torch)

@@ -152,8 +152,9 @@ def test_library_defaults_do_not_survive_a_parameter_change():
 
 
 def test_point_sources_without_their_table_are_refused():
-    """An application with rivers must not run without them: with LuvSrc set and no roms_hip_set_sources call, or with
-    LwSrc (not built), every entry fails with a message; a table with a Dsrc = 2 source is refused as well."""
+    """An application with rivers must not run without them: with LuvSrc or LwSrc set and no roms_hip_set_sources call
+    every entry fails with a message; a table with a Dsrc outside 0, 1, 2 is refused, and so is a table handed to an
+    application that has set neither switch."""
     import util
     from roms_trunk_mgh_amd import hip, sources
     st = util.prepared_state("UPWELLING")
@@ -170,13 +171,12 @@ def test_point_sources_without_their_table_are_refused():
             h.close()
     st.p.point_sources = 1
     N, NT = st.b.N, st.b.NT
-    bad = sources.Sources([5], [5], [2.0], [10.0], np.full((1, N), 1.0 / N), np.zeros((1, N, NT)), np.ones(NT, dtype=np.int32))
+    bad = sources.Sources([5], [5], [3.0], [10.0], np.full((1, N), 1.0 / N), np.zeros((1, N, NT)), np.ones(NT, dtype=np.int32))
     h = hip.RomsHip(st)
     try:
         with pytest.raises(RuntimeError) as e:
             h.set_sources(bad)
-        assert "LwSrc" in str(e.value)
-        # ... and a table handed to an application that has not set LuvSrc
+        assert "Dsrc" in str(e.value)
     finally:
         h.close()
     st.p.point_sources = 0

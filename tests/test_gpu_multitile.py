@@ -46,7 +46,7 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     st = ana.make_tile(config, perturb=1.0, **kw)
     if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
-        util.river_sources(st, "both" if "mask" in opts else "walls")
+        util.river_sources(st, "all" if "wells" in opts else "both" if "mask" in opts else "walls")
     be = hip.RomsHip(st)
     m = main3d.Main3D(be, physics=("physics" in opts), diagnostics=("physics" in opts))
     m.initial()
@@ -81,6 +81,7 @@ def _single(config, nsteps, variant=""):
                                                     # point sources (LuvSrc): rivers in the walls and on the island's coast
                                                     (2, 2, "UPWELLING", "river+basin+mask"), (2, 1, "BENCHMARK_TINY", "river+physics"),
                                                     (2, 2, "BENCHMARK_TINY", "river+mpdata+basin+mask"),
+                                                    (2, 2, "UPWELLING", "river+wells+basin+mask"), (2, 2, "BENCHMARK_TINY", "river+wells+mpdata"),
                                                     # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
                                                     # 512-column tiles of the 8-GPU run (4x1), both tile rows (2x2), the
                                                     # deferred-flux step2d path and, with six MPDATA tracers, three ghost points

@@ -23,6 +23,14 @@ VARIANTS = {
     "hsimt": dict(config="UPWELLING", overrides={"EWperiodic": False, "Hadv": "HSIMT", "Vadv": "HSIMT"}, mask=None,
                   kind="walls"),
     "n40": dict(config="UPWELLING", overrides={"EWperiodic": False, "N": 40}, mask=None, kind="walls"),
+    # cell-centred sources (LwSrc): alone, beside the face sources, two in one cell
+    "wells": dict(config="UPWELLING", overrides={"EWperiodic": False}, mask=None, kind="wells"),
+    "all": dict(config="UPWELLING", overrides={"EWperiodic": False}, mask="island", kind="all"),
+    "wells_dup": dict(config="BENCHMARK_TINY", overrides={}, mask=None, kind="wells_dup"),
+    "mpdata_all": dict(config="UPWELLING", overrides={"EWperiodic": False, "Hadv": "MPDATA", "Vadv": "MPDATA"},
+                       mask="island", kind="all"),
+    "hsimt_all": dict(config="UPWELLING", overrides={"EWperiodic": False, "Hadv": "HSIMT", "Vadv": "HSIMT"}, mask=None,
+                      kind="all"),
 }
 
 
@@ -33,17 +41,21 @@ def _prepared(variant):
     # the mass fluxes of the source faces as step3d_uv leaves them (prepared_state has walls and coasts at rest)
     q = src.qsrc()
     for n, (i, j, d) in enumerate(zip(src.Isrc, src.Jsrc, src.Dsrc)):
-        st["Huon" if int(d) == 0 else "Hvom"][st.I(i), st.J(j), :] = q[n]
+        if int(d) < 2:
+            st["Huon" if int(d) == 0 else "Hvom"][st.I(i), st.J(j), :] = q[n]
     return st
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
-@pytest.mark.parametrize("kernel", ["step2d", "step3d_uv", "pre_step3d", "step3d_t", "rhs3d"])
+@pytest.mark.parametrize("kernel", ["step2d", "step3d_uv", "pre_step3d", "step3d_t", "rhs3d", "omega"])
 def test_source_kernels(variant, kernel):
     import oracle
     st0 = _prepared(variant)
     if kernel == "step3d_t":
         util.hz_weighted_tnew(st0)
+    luv, lw = bool(st0.p.point_sources & 1), bool(st0.p.point_sources & 2)
+    if (kernel == "omega" and not lw) or (kernel in ("step3d_uv", "pre_step3d", "rhs3d") and not luv):
+        pytest.skip("the kernel has no block for this kind of source")
     st_o, st_h, st_n = st0.copy(), st0.copy(), st0.copy()
     preds = [(5, 1, 0)] if kernel != "step2d" else [(5, 1, 1), (5, 2, 1), (5, 2, 0)]
     be_o = oracle.Oracle(st_o)
@@ -69,7 +81,9 @@ def test_source_kernels(variant, kernel):
 
 
 @pytest.mark.parametrize("variant,physics", [("basin", False), ("channel", False), ("coast", False), ("benchmark", True),
-                                             ("seamount", False), ("mpdata", False), ("hsimt", False), ("n40", False)])
+                                             ("seamount", False), ("mpdata", False), ("hsimt", False), ("n40", False),
+                                             ("wells", False), ("all", False), ("wells_dup", True), ("mpdata_all", False),
+                                             ("hsimt_all", False)])
 def test_100_steps_with_rivers(variant, physics):
     import oracle
     v = VARIANTS[variant]
@@ -102,7 +116,9 @@ def test_100_steps_with_rivers(variant, physics):
 
 @pytest.mark.parametrize("config,overrides,mask,kind", [("UPWELLING", {}, None, "walls"), ("UPWELLING", {}, "island", "both"),
                                                         ("BENCHMARK_TINY", {}, "island", "both"),
-                                                        ("UPWELLING", {"Hadv": "MPDATA", "Vadv": "MPDATA"}, "island", "both")])
+                                                        ("UPWELLING", {"Hadv": "MPDATA", "Vadv": "MPDATA"}, "island", "both"),
+                                                        ("UPWELLING", {}, None, "wells"), ("UPWELLING", {}, "island", "all"),
+                                                        ("UPWELLING", {"Hadv": "MPDATA", "Vadv": "MPDATA"}, None, "all")])
 def test_device_river_of_ambient_water_keeps_tracers_uniform(config, overrides, mask, kind):
     """the known answers of tests/test_sources.py on the device: uniform tracers stay uniform, the basin's volume grows
     by the net discharge"""
@@ -125,8 +141,10 @@ def test_device_river_of_ambient_water_keeps_tracers_uniform(config, overrides, 
     for it in range(st.b.NT):
         t = st["t"][sl][..., mh.s.nnew - 1, it][wet]
         assert float(np.abs(t - (T0 + it)).max()) < 2e-11 * (T0 + it)
-    if kind == "walls":
-        qnet = src.Qbar[0] + src.Qbar[1] - src.Qbar[2]
+    if kind in ("walls", "wells") or (kind == "all" and not mask):
+        qnet = 0.0
+        for i, d, q in zip(src.Isrc, src.Dsrc, src.Qbar):
+            qnet += q if int(d) == 2 else (-q if i == st.b.Lm + 1 else q)
         assert abs((v1 - v0) / (qnet * st.p.dt * 28) - 1.0) < 1e-7
 
 

@@ -43,7 +43,7 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
     st = ana.make_tile(config, perturb=1.0, **kw)
     if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
-        util.river_sources(st, "both" if "mask" in opts else "walls")
+        util.river_sources(st, "all" if "wells" in opts else "both" if "mask" in opts else "walls")
     m = main3d.Main3D(oracle.Oracle(st))
     m.initial()
     m.run(nsteps)
@@ -74,7 +74,9 @@ def _single(config, nsteps, variant=""):
                                                     # point sources (LuvSrc): rivers in the walls and on the island's
                                                     # coast, every rank holding the whole table; MPDATA's wider range
                                                     (2, 2, "UPWELLING", "river+basin+mask"), (2, 1, "BENCHMARK_TINY", "river"),
-                                                    (2, 2, "BENCHMARK_TINY", "river+mpdata+basin+mask")])
+                                                    (2, 2, "BENCHMARK_TINY", "river+mpdata+basin+mask"),
+                                                    # ... and cell-centred sources (LwSrc) beside them
+                                                    (2, 2, "UPWELLING", "river+wells+basin+mask"), (2, 2, "BENCHMARK_TINY", "river+wells+mpdata")])
 def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     nsteps = 3
     world = ntI * ntJ

@@ -1,6 +1,6 @@
-"""Point sources / sinks through u- and v-faces (LuvSrc, rivers).  PARITY UNPINNED: step2d,
-step3d_uv, step3d_t, pre_step3d and wetdry USE mod_sources, which needs netCDF, so none of the reference's source blocks
-can be built here.  What stands in for the pin: the answers a river has to give --
+"""Point sources / sinks: through u- and v-faces (LuvSrc, rivers) and at cell centres (LwSrc); SURVEY.md section 8f.
+PARITY UNPINNED: step2d, step3d_uv, step3d_t, pre_step3d, omega and wetdry USE mod_sources, which needs netCDF, so none
+of the reference's source blocks can be built here.  What stands in for the pin: the answers a river has to give --
   * the volume of a closed basin grows by the net discharge times dt, step after step;
   * a river of ambient water leaves a uniform tracer uniform (every piece -- the barotropic and baroclinic velocities
     of the source faces, the corrected mass fluxes, omega, the predictor's and the corrector's tracer flux -- has to be
@@ -49,12 +49,17 @@ def _volume(st):
     return float((st["Hz"][sl].sum(axis=2) * area[sl]).sum())
 
 
-def test_basin_volume_grows_by_the_net_discharge():
-    st, src = _river_state("UPWELLING", same=14.0)
+@pytest.mark.parametrize("kind", ["walls", "wells", "all"])
+def test_basin_volume_grows_by_the_net_discharge(kind):
+    st, src = _river_state("UPWELLING", same=14.0, kind=kind)
     mo = main3d.Main3D(oracle.Oracle(st))
     mo.initial()
     mo.run(2)                                   # the forward first step has its own time centring
-    qnet = src.Qbar[0] + src.Qbar[1] - src.Qbar[2]
+    # into the basin: the wall faces of util.river_sources are south (in), west (in), east (out); a cell-centred source
+    # counts as it stands
+    qnet = 0.0
+    for i, d, q in zip(src.Isrc, src.Dsrc, src.Qbar):
+        qnet += q if int(d) == 2 else (-q if i == st.b.Lm + 1 else q)
     v = [_volume(st)]
     for _ in range(4):
         mo.run(5)
@@ -73,7 +78,12 @@ def test_basin_volume_grows_by_the_net_discharge():
     ("UPWELLING", {"Hadv": "MPDATA", "Vadv": "MPDATA"}, "island", "both", True),
     ("UPWELLING", {"Hadv": "HSIMT", "Vadv": "HSIMT"}, None, "walls", True),
     ("UPWELLING", {"Hadv": "C2", "Vadv": "C2"}, None, "walls", True),
-    ("UPWELLING", {"Hadv": "C4", "Vadv": "SPLINES"}, None, "walls", True)])
+    ("UPWELLING", {"Hadv": "C4", "Vadv": "SPLINES"}, None, "walls", True),
+    # cell-centred sources (LwSrc), alone and beside the face sources
+    ("UPWELLING", {}, None, "wells", True), ("UPWELLING", {}, "island", "all", True),
+    ("BENCHMARK_TINY", {}, None, "all", False), ("SEAMOUNT", {}, None, "wells", True),
+    ("UPWELLING", {"Hadv": "MPDATA", "Vadv": "MPDATA"}, "island", "all", True),
+    ("UPWELLING", {"Hadv": "HSIMT", "Vadv": "HSIMT"}, None, "all", True)])
 def test_a_river_of_ambient_water_keeps_tracers_uniform(config, overrides, mask, kind, basin):
     T0 = 14.0
     st, src = _river_state(config, same=T0, mask=mask, kind=kind, basin=basin, overrides=overrides)
@@ -120,15 +130,14 @@ def test_source_table_rules():
     st, src = _river_state("UPWELLING", same=14.0)
     be = oracle.Oracle(st)
     s = util.step_idx()
-    # LwSrc (Dsrc = 2) is not built
-    bad = type(src)(src.Isrc, src.Jsrc, [2.0] * src.n, src.Qbar, src.Qshape, src.Tsrc, src.LtracerSrc)
+    # Dsrc is 0, 1 or 2
+    bad = type(src)(src.Isrc, src.Jsrc, [3.0] * src.n, src.Qbar, src.Qshape, src.Tsrc, src.LtracerSrc)
     with pytest.raises(RuntimeError):
         be.set_sources(bad)
-    st.p.point_sources = 2
-    with pytest.raises(RuntimeError):
-        be.call("step2d", s)
-    # LuvSrc without a table
-    st.p.point_sources = 1
+    # LuvSrc / LwSrc without a table
     oracle.lib().oracle_set_sources(0, None, None, None, None, None, None, None, 0, 0)
-    with pytest.raises(RuntimeError):
-        be.call("step3d_t", s)
+    for flag in (1, 2, 3):
+        st.p.point_sources = flag
+        for k in ("step2d", "step3d_t", "omega"):
+            with pytest.raises(RuntimeError):
+                be.call(k, s)

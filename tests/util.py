@@ -291,7 +291,10 @@ def river_sources(st, kind="walls", same_tracer=False, seed=3):
     """A point-source table for the state (LuvSrc; roms_trunk_mgh_amd/sources.py) and the switch in the parameters
     (a private copy of them).  kind = "walls": faces of the closed walls -- an inflow through the southern wall, and in a
     basin an inflow through the western wall and an outflow (a sink) through the eastern one; "coast": faces of the land
-    mask -- one u-face and one v-face with land behind them, flowing into the water.  Qshape grows towards the surface;
+    mask -- one u-face and one v-face with land behind them, flowing into the water; "wells": cell-centred sources
+    (LwSrc, Dsrc = 2) -- three inflows and a sink; "wells_dup": two of them share a cell (the reference then counts
+    both in the free surface and the tracers but only the later one in omega -- as written, omega.F:173-190; for the
+    device-against-oracle tests); "all" = walls + wells (+ coast with a mask).  Qshape grows towards the surface;
     the first tracer comes with the river (LtracerSrc), the others do not -- unless same_tracer: then every tracer does,
     with the value `same_tracer` (a river of ambient water)."""
     from roms_trunk_mgh_amd import sources
@@ -300,12 +303,17 @@ def river_sources(st, kind="walls", same_tracer=False, seed=3):
     # moves about a cell's volume in 250 steps; from the grid's nominal numbers, the same for every tiling
     q0 = {"UPWELLING": 1.3e3 * 41 * 80, "SEAMOUNT": 1.3e7 * 49 * 48, "BENCHMARK": 1.0e9 * 64 * 32}[st.cfg["app"]] / (b.Lm * b.Mm)
     I, J, D, Q = [], [], [], []
-    if kind in ("walls", "both"):
+    if kind in ("walls", "both", "all"):
         I.append(max(2, b.Lm // 3)); J.append(1); D.append(1.0); Q.append(q0)               # southern wall, northward
         if not b.EWperiodic:
             I.append(1); J.append(max(2, b.Mm // 2)); D.append(0.0); Q.append(0.7 * q0)      # western wall, eastward
             I.append(b.Lm + 1); J.append(max(2, b.Mm // 4)); D.append(0.0); Q.append(0.4 * q0)   # eastern wall: a sink
-    if kind in ("coast", "both"):
+    if kind in ("wells", "wells_dup", "all"):
+        ci, cj = max(3, (2 * b.Lm) // 5), max(3, (2 * b.Mm) // 3)
+        second = (0, 0) if kind == "wells_dup" else (1, 2)
+        for di, dj, q in ((0, 0, 0.5 * q0), (second[0], second[1], 0.2 * q0), (3, -2, 0.3 * q0), (-4, 3, -0.25 * q0)):
+            I.append(ci + di); J.append(cj + dj); D.append(2.0); Q.append(q)
+    if kind in ("coast", "both") or (kind == "all" and st.p.masking):
         # the whole grid's mask (the same faces for every tiling)
         bg = ana.make_bounds(b.Lm, b.Mm, N, NT, b.NAT, 1, 1, 0, EWperiodic=bool(b.EWperiodic), NSperiodic=False,
                              NghostPoints=b.NghostPoints)
@@ -330,5 +338,5 @@ def river_sources(st, kind="walls", same_tracer=False, seed=3):
     ltr = np.ones(NT, dtype=np.int32) if same_tracer else np.array([1] + [0] * (NT - 1), dtype=np.int32)
     st.sources = sources.Sources(I, J, D, Q, Qshape, Tsrc, ltr)
     st.p = type(st.p).from_buffer_copy(st.p)
-    st.p.point_sources = 1
+    st.p.point_sources = (1 if any(d < 2.0 for d in D) else 0) | (2 if any(d == 2.0 for d in D) else 0)
     return st.sources
