@@ -408,12 +408,12 @@ extern "C" int roms_hip_bulk_flux(const roms_step_idx_t *s)
 // + RI_SPLINES, LMD_CONVEC, LMD_SKPP, LMD_NONLOCAL, SALINITY; uniform Jerlov water type).
 // Column-local: one thread per (i,j), three sweeps.  Upward: the forward recurrences of the three splines
 // (u, v, pden), of which only every sixth level is kept (registers).  Downward, segment by segment: the
-// recurrences of a segment are re-run from its checkpoint into LDS and their back-substitution is fused with
+// recurrences of a segment are re-run from its checkpoint (registers) and their back-substitution is fused with
 // the Richardson-number mixing, the bulk Richardson function and the boundary-layer depth search, so no profile
-// goes to device memory but the shear function nu_sx (parked in Akv); the buoyancy-flux profile is recomputed
-// (two exp) where used.  Upward again: the boundary-layer profiles, the convective adjustment, the final Akv, Akt.
-// Per column and level 4 + 4 + 2 + 3 array reads from memory (4 more from cache) and 6 writes -- the earlier version
-// (forward values of all levels in scratch) read 18 and wrote 11.
+// goes to device memory at all: the shear function nu_sx waits in LDS for the last sweep; the buoyancy-flux profile
+// is recomputed (two exp) where used.  Upward again: the boundary-layer profiles, the convective adjustment, the
+// final Akv, Akt.  Per column and level 4 + 4 + 2 + 2 array reads from memory (4 more from cache) and 5 writes -- the
+// first version (forward values of all levels in scratch) read 18 and wrote 11.
 // =================================================================================================
 namespace {
 
@@ -476,6 +476,11 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, double lmd_Cg, double Vtc)
   const gd_t ghT = (gd_t)c->F.ghats, ghS = (gd_t)(c->F.ghats + n3w);
   auto r3i = [&](int k) { return a + (long)(k - 1) * nij; };     // rho-type level k = 1..N
   auto w3i = [&](int k) { return a + (long)k * nij; };           // W-type level k = 0..N
+  // the shear function nu_sx of W-levels 1..N-1 waits in LDS ([level][thread]) for the last sweep -- it used to be
+  // parked in Akv: one field written and read back for nothing (0.13 GB each way on BENCHMARK3)
+  constexpr int NTH = BLK_X * BLK_Y;
+  __shared__ double s_nu[(NMAX - 1) * NTH];
+  double *const nu_col = s_nu + threadIdx.y * BLK_X + threadIdx.x;        // nu_col[(k - 1) * NTH], k = 1..N-1
 
   // the inputs of rho-levels k0+1 .. k0+SEG+1 (clamped to N: the clamped ones are loaded but not used)
   struct Lev { double hz, ua, ub, va, vb, pd; };
@@ -613,7 +618,7 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, double lmd_Cg, double Vtc)
             dUm = du - fc * dUk;
             dVm = dv - fc * dVk;
           }
-          // (a) interior mixing at W-level k: only the shear function nu_sx is kept (in Akv); the last sweep forms
+          // (a) interior mixing at W-level k: only the shear function nu_sx is kept (in LDS); the last sweep forms
           // Akv and Akt from it and from bvf, which it reads anyway (lmd_vmix.F:286-297)
           if (k <= N - 1) {
             const double epsv = 1.0E-14;
@@ -626,7 +631,7 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, double lmd_Cg, double Vtc)
             shear2 = bv / (Rig + epsv);
             cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
             nu_sx = cff * nu_sx;
-            Akv[w3i(k)] = nu_sx;
+            nu_col[(k - 1) * NTH] = nu_sx;
           }
           // (b) bulk Richardson function at W-level k-1 -- until the boundary-layer depth is found: the levels below
           // it cannot change hsbl / ksbl any more (the search keeps the first crossing from the top)
@@ -715,7 +720,8 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, double lmd_Cg, double Vtc)
     const double cff_dn = cff * (hsbl - z_w[w3i(k - 1)]);
     const double cff_up = cff * (z_w[w3i(k)] - hsbl);
     // Akv / Akt of (a) at the two levels around the boundary-layer depth (level N keeps the array's own values)
-    const double bv_k = bvf[w3i(k)], bv_m = bvf[w3i(k - 1)], nu_k = Akv[w3i(k)], nu_m = Akv[w3i(k - 1)];
+    const double bv_k = bvf[w3i(k)], bv_m = bvf[w3i(k - 1)];
+    const double nu_k = (k <= N - 1) ? nu_col[(k - 1) * NTH] : (double)Akv[w3i(k)], nu_m = nu_col[(k - 2) * NTH];
     const double akv_k = (k <= N - 1) ? akv_a(nu_k, bv_k) : nu_k, akv_m = akv_a(nu_m, bv_m);
     const double akt_k = (k <= N - 1) ? akt_a(nu_k, bv_k) : (double)AkT[w3i(k)], akt_m = akt_a(nu_m, bv_m);
     double K_bl = cff_dn * akv_k + cff_up * akv_m;
@@ -757,7 +763,7 @@ k_lmd_vmix(const RomsDev *__restrict__ c, int nstp, double lmd_Cg, double Vtc)
 #pragma unroll
     for (int t = 0; t < LMD_SEG; t++) {
       const long q3 = w3i(min(kb + t, N - 1));
-      nuA[t] = Akv[q3]; zwA[t] = z_w[q3]; bvA[t] = bvf[q3];
+      nuA[t] = nu_col[(min(kb + t, N - 1) - 1) * NTH]; zwA[t] = z_w[q3]; bvA[t] = bvf[q3];
     }
 #pragma unroll
     for (int t = 0; t < LMD_SEG; t++) {
