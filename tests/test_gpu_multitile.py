@@ -82,6 +82,7 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "UPWELLING", "river+basin+mask"), (2, 1, "BENCHMARK_TINY", "river+physics"),
                                                     (2, 2, "BENCHMARK_TINY", "river+mpdata+basin+mask"),
                                                     (2, 2, "UPWELLING", "river+wells+basin+mask"), (2, 2, "BENCHMARK_TINY", "river+wells+mpdata"),
+                                                    (2, 2, "UPWELLING", "river+wells+wet+basin+mask"),
                                                     # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
                                                     # 512-column tiles of the 8-GPU run (4x1), both tile rows (2x2), the
                                                     # deferred-flux step2d path and, with six MPDATA tracers, three ghost points

@@ -31,12 +31,15 @@ VARIANTS = {
                        mask="island", kind="all"),
     "hsimt_all": dict(config="UPWELLING", overrides={"EWperiodic": False, "Hadv": "HSIMT", "Vadv": "HSIMT"}, mask=None,
                       kind="all"),
+    # with WET_DRY: the general barotropic sequence carries both, the output masks count source faces as water
+    "wet_all": dict(config="UPWELLING", overrides={"EWperiodic": False, "wet_dry": 1, "beach": 1, "zeta_amp": 0.3},
+                    mask="island", kind="all"),
 }
 
 
 def _prepared(variant):
     v = VARIANTS[variant]
-    st = util.prepared_state(v["config"], overrides=v["overrides"], mask=v["mask"])
+    st = util.prepared_state(v["config"], overrides=v["overrides"], mask=v["mask"], wet=bool(v["overrides"].get("wet_dry")))
     src = util.river_sources(st, v["kind"])
     # the mass fluxes of the source faces as step3d_uv leaves them (prepared_state has walls and coasts at rest)
     q = src.qsrc()
@@ -47,14 +50,15 @@ def _prepared(variant):
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
-@pytest.mark.parametrize("kernel", ["step2d", "step3d_uv", "pre_step3d", "step3d_t", "rhs3d", "omega"])
+@pytest.mark.parametrize("kernel", ["step2d", "step3d_uv", "pre_step3d", "step3d_t", "rhs3d", "omega", "wetdry"])
 def test_source_kernels(variant, kernel):
     import oracle
     st0 = _prepared(variant)
     if kernel == "step3d_t":
         util.hz_weighted_tnew(st0)
     luv, lw = bool(st0.p.point_sources & 1), bool(st0.p.point_sources & 2)
-    if (kernel == "omega" and not lw) or (kernel in ("step3d_uv", "pre_step3d", "rhs3d") and not luv):
+    if (kernel == "omega" and not lw) or (kernel in ("step3d_uv", "pre_step3d", "rhs3d") and not luv) or \
+            (kernel == "wetdry" and not (luv and st0.p.wet_dry)):
         pytest.skip("the kernel has no block for this kind of source")
     st_o, st_h, st_n = st0.copy(), st0.copy(), st0.copy()
     preds = [(5, 1, 0)] if kernel != "step2d" else [(5, 1, 1), (5, 2, 1), (5, 2, 0)]
@@ -83,7 +87,7 @@ def test_source_kernels(variant, kernel):
 @pytest.mark.parametrize("variant,physics", [("basin", False), ("channel", False), ("coast", False), ("benchmark", True),
                                              ("seamount", False), ("mpdata", False), ("hsimt", False), ("n40", False),
                                              ("wells", False), ("all", False), ("wells_dup", True), ("mpdata_all", False),
-                                             ("hsimt_all", False)])
+                                             ("hsimt_all", False), ("wet_all", False)])
 def test_100_steps_with_rivers(variant, physics):
     import oracle
     v = VARIANTS[variant]

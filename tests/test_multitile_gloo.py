@@ -76,7 +76,8 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "UPWELLING", "river+basin+mask"), (2, 1, "BENCHMARK_TINY", "river"),
                                                     (2, 2, "BENCHMARK_TINY", "river+mpdata+basin+mask"),
                                                     # ... and cell-centred sources (LwSrc) beside them
-                                                    (2, 2, "UPWELLING", "river+wells+basin+mask"), (2, 2, "BENCHMARK_TINY", "river+wells+mpdata")])
+                                                    (2, 2, "UPWELLING", "river+wells+basin+mask"), (2, 2, "BENCHMARK_TINY", "river+wells+mpdata"),
+                                                    (2, 2, "UPWELLING", "river+wells+wet+basin+mask")])
 def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     nsteps = 3
     world = ntI * ntJ
