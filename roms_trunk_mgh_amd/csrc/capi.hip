@@ -159,7 +159,7 @@ extern "C" int roms_hip_check_guards(void)
   int rc;
   for (int id = 0; id < FID_COUNT; id++)
     if ((rc = check(k_field_name[id], -1, g_ctx.dev_base[id], g_ctx.count[id]))) return rc;
-  for (int q = 0; q < 8; q++)
+  for (int q = 0; q < ROMS_NWS3; q++)
     if ((rc = check("ws3", q, g_ctx.ws3_base[q], nij * (b.N + 1)))) return rc;
   for (int q = 0; q < 32; q++)
     if ((rc = check("ws2", q, g_ctx.ws2_base[q], nij))) return rc;
@@ -239,7 +239,7 @@ extern "C" int roms_hip_finalize(void)
     g_ctx.host[i] = nullptr;
     g_ctx.count[i] = 0;
   }
-  for (int q = 0; q < 8; q++) guarded_free(&g_ctx.hostc.ws3[q], &g_ctx.ws3_base[q]);
+  for (int q = 0; q < ROMS_NWS3; q++) guarded_free(&g_ctx.hostc.ws3[q], &g_ctx.ws3_base[q]);
   for (int q = 0; q < 32; q++) guarded_free(&g_ctx.hostc.ws2[q], &g_ctx.ws2_base[q]);
   sources_release();
   if (g_ctx.devc) (void)hipFree(g_ctx.devc);
@@ -378,7 +378,7 @@ extern "C" int roms_hip_set_bounds(const roms_bounds_t *b)
   // device scratch for the _tile routines' automatic arrays
   const long ni = b->UBi - b->LBi + 1, nij = ni * (long)(b->UBj - b->LBj + 1);
   g_ctx.guard = ((4 * ni + 31) / 32) * 32;
-  for (int q = 0; q < 8; q++) {
+  for (int q = 0; q < ROMS_NWS3; q++) {
     guarded_free(&g_ctx.hostc.ws3[q], &g_ctx.ws3_base[q]);
     int rc = guarded_alloc(&g_ctx.hostc.ws3[q], &g_ctx.ws3_base[q], nij * (b->N + 1));
     if (rc) return rc;

@@ -29,6 +29,10 @@ struct MpArgs {
   double *Ta, *Ua, *Va, *Wa, *bup, *bdn;   // scratch, module horizontal extents
   const double *oHz, *odz;                 // 1/Hz and 1/(z_r(k+1)-z_r(k)), k_mp_metrics (once per step3d_t call)
   int nnew, itrc;
+  // k_mp_ta steps nb consecutive tracers (itrc, itrc+1 ..) in one launch, Ta of tracer itrc+q -> TaB[q]: the mass fluxes
+  // and Hz (4 of the 7 arrays a tracer's upstream step reads or writes) cross the memory bus once per batch
+  double *TaB[3];
+  int nb;
   // the wall rule of the anti-diffusive velocities on a physical edge (mpdata_adiff.F:577-640, :1031-1100): zero where
   // the 3-D momentum's condition is closed (LBC(side, isBu3d = isUvel / isBv3d = isVvel)%closed), the neighbouring
   // face's value otherwise; [LBS_WEST .. LBS_NORTH]
@@ -77,39 +81,43 @@ k_mp_ta(const RomsDev *__restrict__ c, MpArgs m)
   const int j = b.JstrVm2 + XB.by * BLK_Y + threadIdx.y;
   if (i > b.Iendp2i || j > b.Jendp2i) return;
   const double dt = c->p.dt;
-  const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (m.itrc - 1)) * n3r);
-  const gcd_t tn = (gcd_t)(c->F.t + ((long)(m.nnew - 1) + 3L * (m.itrc - 1)) * n3r);
   const gcd_t Huon = (gcd_t)c->F.Huon, Hvom = (gcd_t)c->F.Hvom, Wv = (gcd_t)c->F.W, Hz = (gcd_t)c->F.Hz;
-  const gd_t Ta = (gd_t)m.Ta;
   const long c0 = I2(i, j);
   const double cff = dt * GF(pm)[c0] * GF(pn)[c0];
   const bool s_wall = b.south_edge && !b.NSperiodic && j == b.Jstr;
   const bool n_wall = b.north_edge && !b.NSperiodic && j == b.Jend;
   const bool w_wall = b.west_edge && !b.EWperiodic && i == b.Istr;
   const bool e_wall = b.east_edge && !b.EWperiodic && i == b.Iend;
-  {
-    const int k = XB.k0 + 1;                                      // one thread per (i,j,k)
-    const long a = c0 + (long)(k - 1) * nij;
+  const int k = XB.k0 + 1;                                        // one thread per (i,j,k)
+  const long a = c0 + (long)(k - 1) * nij;
+  const bool src_cell = c->src.n > 0 && src_cell_any(c, c0, ni);
+  // the transports and the thickness of the cell: the same for every tracer of the batch
+  const double hu0 = Huon[a], hu1 = Huon[a + 1], hv0 = Hvom[a], hv1 = Hvom[a + ni];
+  const double w0 = (k > 1) ? (double)Wv[a] : 0.0, w1 = (k < N) ? (double)Wv[a + nij] : 0.0, ohz = 1.0 / Hz[a];
+  for (int q = 0; q < m.nb; q++) {
+    const int itrc = m.itrc + q;
+    const gcd_t t3 = (gcd_t)(c->F.t + (2L + 3L * (itrc - 1)) * n3r);
+    const gcd_t tn = (gcd_t)(c->F.t + ((long)(m.nnew - 1) + 3L * (itrc - 1)) * n3r);
+    const gd_t Ta = (gd_t)m.TaB[q];
     const double t0 = t3[a];
     // FC(k-1): the expression the level below evaluates as its FC(k)
-    const double FCm1 = (k > 1) ? upstream(Wv[a], t3[a - nij], t0) : 0.0;
-    double FXi = upstream(Huon[a], t3[a - 1], t0);
-    double FXip1 = upstream(Huon[a + 1], t0, t3[a + 1]);
-    double FEj = upstream(Hvom[a], t3[a - ni], t0);
-    double FEjp1 = upstream(Hvom[a + ni], t0, t3[a + ni]);
-    const bool src_cell = c->src.n > 0 && src_cell_any(c, c0, ni);
+    const double FCm1 = (k > 1) ? upstream(w0, t3[a - nij], t0) : 0.0;
+    double FXi = upstream(hu0, t3[a - 1], t0);
+    double FXip1 = upstream(hu1, t0, t3[a + 1]);
+    double FEj = upstream(hv0, t3[a - ni], t0);
+    double FEjp1 = upstream(hv1, t0, t3[a + ni]);
     if (src_cell)                                    // LuvSrc, step3d_t.F:734-799 (on the extended range of MPDATA)
-      src_cell_fluxes<false>(c, c0, a, ni, k, m.itrc, c->F.t + (2L + 3L * (m.itrc - 1)) * n3r, FXi, FXip1, FEj, FEjp1);
+      src_cell_fluxes<false>(c, c0, a, ni, k, itrc, c->F.t + (2L + 3L * (itrc - 1)) * n3r, FXi, FXip1, FEj, FEjp1);
     const double cff1 = cff * (FXip1 - FXi);
     const double cff2 = cff * (FEjp1 - FEj);
     const double cff3 = cff1 + cff2;
     double ta = tn[a] - cff3;                                   // step3d_t.F:838
     // LwSrc, :1136-1158: on Istr:Iend+1, Jstr:Jend+1 only, not on the rest of MPDATA's extended range
     if (src_cell && i >= b.Istr && i <= b.Iend + 1 && j >= b.Jstr && j <= b.Jend + 1)
-      ta = src_w_tracer(c, c0, k, m.itrc, cff, t0, ta);
-    const double FCk = (k < N) ? upstream(Wv[a + nij], t0, t3[a + nij]) : 0.0;   // :1006-1018
+      ta = src_w_tracer(c, c0, k, itrc, cff, t0, ta);
+    const double FCk = (k < N) ? upstream(w1, t0, t3[a + nij]) : 0.0;   // :1006-1018
     const double c1 = cff * (FCk - FCm1);
-    ta = (ta - c1) * (1.0 / Hz[a]);                             // :1175
+    ta = (ta - c1) * ohz;                                       // :1175
     Ta[a] = ta;
     if (w_wall) Ta[a - 1] = ta;                                 // mpdata_adiff.F:160-176
     if (e_wall) Ta[a + 1] = ta;
@@ -780,51 +788,64 @@ k_mp_update(const RomsDev *__restrict__ c, MpArgs m)
 
 }  // namespace
 
-// One MPDATA tracer of step3d_t; called by roms_hip_step3d_t (k_step3d_t.hip).
-int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first)
+// The MPDATA tracers itrc0 .. itrc0+n-1 of step3d_t; called by roms_hip_step3d_t (k_step3d_t.hip).  In batches of up
+// to three: one exchange of their t(nnew), ONE upstream step for the batch (k_mp_ta; Ta -> ws3[1], [8], [9]), then per
+// tracer the anti-diffusive velocities and the limited, corrected step.
+int roms_launch_step3d_t_mpdata(int nnew, int itrc0, int n)
 {
   const roms_bounds_t &b = g_ctx.b;
   if (b.NghostPoints != 3) return roms_fail("roms_hip_step3d_t", "MPDATA needs NghostPoints = 3 (inp_par.F:266-278)");
   int rc;
   const long n3r = (long)(b.UBi - b.LBi + 1) * (b.UBj - b.LBj + 1) * b.N;
-  // three-point footprint: refresh the ghost points of t(nnew) first, step3d_t.F:369-386
-  if ((rc = halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + ((long)(nnew - 1) + 3L * (itrc - 1)) * n3r))) return rc;
-  MpArgs m;
-  m.Ta = g_ctx.hostc.ws3[1]; m.Ua = g_ctx.hostc.ws3[2]; m.Va = g_ctx.hostc.ws3[3]; m.Wa = g_ctx.hostc.ws3[4];
+  MpArgs m{};
+  m.Ua = g_ctx.hostc.ws3[2]; m.Va = g_ctx.hostc.ws3[3]; m.Wa = g_ctx.hostc.ws3[4];
   m.bup = g_ctx.hostc.ws3[5]; m.bdn = g_ctx.hostc.ws3[6];
   m.oHz = g_ctx.hostc.ws3[0]; m.odz = g_ctx.hostc.ws3[7];
-  m.nnew = nnew; m.itrc = itrc;
+  m.TaB[0] = g_ctx.hostc.ws3[1]; m.TaB[1] = g_ctx.hostc.ws3[8]; m.TaB[2] = g_ctx.hostc.ws3[9];
+  m.nnew = nnew;
   m.closed[LBS_WEST] = lbc_code(g_ctx.p, LBS_WEST, LBV_U) == LBC_CLOSED;
   m.closed[LBS_EAST] = lbc_code(g_ctx.p, LBS_EAST, LBV_U) == LBC_CLOSED;
   m.closed[LBS_SOUTH] = lbc_code(g_ctx.p, LBS_SOUTH, LBV_V) == LBC_CLOSED;
   m.closed[LBS_NORTH] = lbc_code(g_ctx.p, LBS_NORTH, LBV_V) == LBC_CLOSED;
-  if (first) {
-    hipLaunchKernelGGL(k_mp_metrics, grid2d(b.UBi - b.LBi + 1, b.UBj - b.LBj + 1), block2d(), 0, g_ctx.stream, g_ctx.devc,
-                       g_ctx.hostc.ws3[0], g_ctx.hostc.ws3[7]);
-    KERNEL_CHECK("k_mp_metrics");
-  }
-  {
-    dim3 g3 = grid_tile_level(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1, b.N);
-    hipLaunchKernelGGL(k_mp_ta, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
-  }
-  KERNEL_CHECK("k_mp_ta");
-  {
-    const dim3 g3((unsigned)((b.Iendp2 - (b.IstrU - 1) + 1 + BLK_X - 1) / BLK_X),
-                  (unsigned)((b.Jendp2 - (b.JstrV - 1) + 1 + MP_ATY - 1) / MP_ATY), 1);
-    void (*kern)(const RomsDev *, MpArgs) = g_ctx.p.masking ? (g_ctx.p.mpdata_fast ? k_mp_adiff<true, true> : k_mp_adiff<false, true>)
-                                : (g_ctx.p.mpdata_fast ? k_mp_adiff<true, false> : k_mp_adiff<false, false>);
-    hipLaunchKernelGGL(kern, g3, dim3(BLK_X, MP_ATY, 1), 0, g_ctx.stream, g_ctx.devc, m);
-  }
-  KERNEL_CHECK("k_mp_adiff");
+  hipLaunchKernelGGL(k_mp_metrics, grid2d(b.UBi - b.LBi + 1, b.UBj - b.LBj + 1), block2d(), 0, g_ctx.stream, g_ctx.devc,
+                     g_ctx.hostc.ws3[0], g_ctx.hostc.ws3[7]);
+  KERNEL_CHECK("k_mp_metrics");
 #ifndef MP_UTY
 #define MP_UTY 8
 #endif
   constexpr int UTY = MP_UTY;            // rows per workgroup of the fused limiter + update kernel
-  const dim3 g((unsigned)((b.Iend - b.Istr + 1 + BLK_X - 1) / BLK_X), (unsigned)((b.Jend - b.Jstr + 1 + UTY - 1) / UTY), 1);
   const bool mk = g_ctx.p.masking != 0;
-  void (*upd)(const RomsDev *, MpArgs);
-  upd = mk ? k_mp_update<UTY, true> : k_mp_update<UTY, false>;
-  hipLaunchKernelGGL(upd, g, dim3(BLK_X, UTY, 1), 0, g_ctx.stream, g_ctx.devc, m);
-  KERNEL_CHECK("k_mp_update");
+  for (int q0 = 0; q0 < n; q0 += 3) {
+    const int nb = n - q0 < 3 ? n - q0 : 3;
+    // three-point footprint: refresh the ghost points of t(nnew) first, step3d_t.F:369-386
+    halo_batch_begin();
+    for (int q = 0; q < nb; q++)
+      halo_exchange3d(GT_R, b.N, g_ctx.dev[FID_t] + ((long)(nnew - 1) + 3L * (itrc0 + q0 + q - 1)) * n3r);
+    if ((rc = halo_batch_end())) return rc;
+    m.itrc = itrc0 + q0;
+    m.nb = nb;
+    m.Ta = m.TaB[0];
+    {
+      dim3 g3 = grid_tile_level(b.Iendp2i - b.IstrUm2 + 1, b.Jendp2i - b.JstrVm2 + 1, b.N);
+      hipLaunchKernelGGL(k_mp_ta, g3, block2d(), 0, g_ctx.stream, g_ctx.devc, m);
+    }
+    KERNEL_CHECK("k_mp_ta");
+    for (int q = 0; q < nb; q++) {
+      m.itrc = itrc0 + q0 + q;
+      m.Ta = m.TaB[q];
+      {
+        const dim3 g3((unsigned)((b.Iendp2 - (b.IstrU - 1) + 1 + BLK_X - 1) / BLK_X),
+                      (unsigned)((b.Jendp2 - (b.JstrV - 1) + 1 + MP_ATY - 1) / MP_ATY), 1);
+        void (*kern)(const RomsDev *, MpArgs) = mk ? (g_ctx.p.mpdata_fast ? k_mp_adiff<true, true> : k_mp_adiff<false, true>)
+                                                  : (g_ctx.p.mpdata_fast ? k_mp_adiff<true, false> : k_mp_adiff<false, false>);
+        hipLaunchKernelGGL(kern, g3, dim3(BLK_X, MP_ATY, 1), 0, g_ctx.stream, g_ctx.devc, m);
+      }
+      KERNEL_CHECK("k_mp_adiff");
+      const dim3 g((unsigned)((b.Iend - b.Istr + 1 + BLK_X - 1) / BLK_X), (unsigned)((b.Jend - b.Jstr + 1 + UTY - 1) / UTY), 1);
+      void (*upd)(const RomsDev *, MpArgs) = mk ? k_mp_update<UTY, true> : k_mp_update<UTY, false>;
+      hipLaunchKernelGGL(upd, g, dim3(BLK_X, UTY, 1), 0, g_ctx.stream, g_ctx.devc, m);
+      KERNEL_CHECK("k_mp_update");
+    }
+  }
   return 0;
 }

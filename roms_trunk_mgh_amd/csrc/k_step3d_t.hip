@@ -25,7 +25,7 @@
 #include <cstdlib>
 
 int roms_entry_check(const char *name);
-int roms_launch_step3d_t_mpdata(int nnew, int itrc, int first);      // k_mpdata.hip
+int roms_launch_step3d_t_mpdata(int nnew, int itrc0, int n);         // k_mpdata.hip
 
 #include "advect.h"
 
@@ -658,7 +658,7 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
       case ADV_C2 * 16 + ADV_HSIMT: rc = launch_classic<ADV_C2, ADV_HSIMT>(s->nnew, it, n); break;
       case ADV_MPDATA * 16 + ADV_MPDATA:
         // multi-pass: upstream step, anti-diffusive velocities, FCT limiter, corrected step (k_mpdata.hip)
-        for (int q = 0; q < n && !rc; q++) rc = roms_launch_step3d_t_mpdata(s->nnew, it + q, q == 0);
+        rc = roms_launch_step3d_t_mpdata(s->nnew, it, n);
         break;
       default:
         return roms_fail("roms_hip_step3d_t", "advection scheme pair not implemented (MPDATA and HSIMT only as H+V pairs)");

@@ -17,6 +17,8 @@
 // The point-source table SOURCES(ng) (mod_sources.F:56-80) on the device, LuvSrc only (roms_hip_set_sources).  The two
 // face maps (nij ints: 1 + the index of the source at the u- / v-face of the point, 0 elsewhere; the last source of a
 // face wins, as the sequential loops of the reference leave it) let a kernel find "its" source without a search.
+#define ROMS_NWS3 10   // 3-D scratch arrays (the _tile routines' automatic arrays; MPDATA holds Ta of three tracers at a time)
+
 struct RomsSrc {
   int n;                      // Nsrc; 0 = no table
   int ltr[ROMS_MAXNT];        // LtracerSrc(itrc)
@@ -38,7 +40,7 @@ struct RomsDev {
   roms_params_t p;
   roms_fields_t F;      // device pointers
   // device scratch = the _tile routines' automatic work arrays
-  double *ws3[8];       // 3-D scratch, each nij*(N+1) doubles
+  double *ws3[ROMS_NWS3];   // 3-D scratch, each nij*(N+1) doubles
   double *ws2[32];      // 2-D scratch, each nij doubles
   const double *rowm;   // row table of the i-uniform metric arrays (k_step2d_mom.hip), or nullptr
   RomsSrc src;          // point sources (LuvSrc), n = 0 without
@@ -55,7 +57,7 @@ struct RomsCtx {
   double *dev[FID_COUNT] = {nullptr};
   double *dev_base[FID_COUNT] = {nullptr};   // start of the allocation (guard band in front of dev[])
   long count[FID_COUNT] = {0};
-  double *ws3_base[8] = {nullptr};
+  double *ws3_base[ROMS_NWS3] = {nullptr};
   double *ws2_base[32] = {nullptr};
   long guard = 0;               // doubles of guard band on either side of every mirror / scratch array
   RomsDev hostc{};            // host copy of the constant block

@@ -22,7 +22,11 @@ PROGRAM roms_hip_demo
   END TYPE fld
   TYPE(fld) :: F(0:MAXF-1)
   INTEGER(c_int8_t), ALLOCATABLE, TARGET :: bimg(:), pimg(:)
-  INTEGER(c_long) :: nb, np, nf, id, cnt
+  INTEGER(c_long) :: nb, np, nf, id, cnt, ns, nq, nt
+  !  SOURCES(ng) as set_data leaves it (mod_sources.F), when the state file carries one
+  INTEGER(c_int), ALLOCATABLE :: Isrc(:), Jsrc(:), ltr(:)
+  REAL(c_double), ALLOCATABLE :: Dsrc(:), Qbar(:), Qsrc(:), Tsrc(:)
+  INTEGER :: ios
   INTEGER :: nsteps, istep, q, iic, ntstart, exit_flag
   INTEGER(c_int) :: indx1, rc
   TYPE(roms_step_idx_t) :: s
@@ -49,6 +53,13 @@ PROGRAM roms_hip_demo
     ALLOCATE (F(id)%a(cnt))
     READ (10) F(id)%a
   END DO
+  ns = 0
+  READ (10, IOSTAT=ios) ns, nq, nt             ! optional: Nsrc, Nsrc*N, NT
+  IF (ios /= 0) ns = 0
+  IF (ns > 0) THEN
+    ALLOCATE (Isrc(ns), Jsrc(ns), Dsrc(ns), Qbar(ns), Qsrc(nq), Tsrc(nq*nt), ltr(nt))
+    READ (10) Isrc, Jsrc, Dsrc, Qbar, Qsrc, Tsrc, ltr
+  END IF
   CLOSE (10)
 
   CALL check (roms_hip_init (0_c_int, 1_c_int, 1_c_int, 0_c_int, c_null_ptr), 'init')
@@ -60,6 +71,10 @@ PROGRAM roms_hip_demo
     END IF
   END DO
   CALL check (roms_hip_sync_all_to_device (), 'sync_all_to_device')
+  !  point sources (LuvSrc / LwSrc): the table, once (a steady river; a driver calls this after every set_data)
+  IF (ns > 0) THEN
+    CALL check (roms_hip_set_sources (INT(ns, c_int), Isrc, Jsrc, Dsrc, Qbar, Qsrc, Tsrc, ltr), 'set_sources')
+  END IF
 
   !  initial.F:337-571, the part on the path
   ntstart = 1

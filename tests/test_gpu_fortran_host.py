@@ -19,8 +19,9 @@ FDIR = os.path.join(ROOT, "roms_trunk_mgh_amd", "fortran")
 
 
 @pytest.mark.skipif(shutil.which("flang") is None, reason="flang not installed")
-@pytest.mark.parametrize("config", ["UPWELLING", "BENCHMARK_TINY"])
-def test_fortran_host_equals_python_host(tmp_path, config):
+@pytest.mark.parametrize("config,river", [("UPWELLING", False), ("BENCHMARK_TINY", False), ("UPWELLING", True)])
+def test_fortran_host_equals_python_host(tmp_path, config, river):
+    """river: a basin with point sources (LuvSrc and LwSrc) -- roms_hip_set_sources through the Fortran interface"""
     nsteps = 4
     libdir = os.path.join(ROOT, "roms_trunk_mgh_amd")
     r = subprocess.run(["flang", "-c", os.path.join(FDIR, "roms_hip_mod.F90"), "-o", "m.o"], cwd=tmp_path,
@@ -29,7 +30,10 @@ def test_fortran_host_equals_python_host(tmp_path, config):
     r = subprocess.run(["flang", os.path.join(FDIR, "roms_hip_demo.F90"), "m.o", "-L" + libdir, "-lroms_hip",
                         "-Wl,-rpath," + libdir, "-o", "demo"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    st = ana.make_tile(config, perturb=1.0)
+    st = ana.make_tile(config, perturb=1.0, overrides={"EWperiodic": False} if river else None)
+    if river:
+        import util
+        src = util.river_sources(st, "all")
     # the state as the Fortran host receives it: bounds and parameter blocks as they lie in memory, then every
     # registered field in the order of include/roms_fields.def (Fortran order, as the module arrays are)
     with open(tmp_path / "state.bin", "wb") as f:
@@ -42,6 +46,14 @@ def test_fortran_host_equals_python_host(tmp_path, config):
             a = np.asfortranarray(st[name])
             f.write(struct.pack("qq", abi.FIELD_ID[name], a.size))
             f.write(a.tobytes(order="F"))
+        if river:                 # SOURCES(ng): Isrc, Jsrc, Dsrc, Qbar, Qsrc(Nsrc,N), Tsrc(Nsrc,N,NT), LtracerSrc
+            q = src.qsrc()
+            f.write(struct.pack("qqq", src.n, q.size, st.b.NT))
+            for a in (src.Isrc, src.Jsrc, src.Dsrc, src.Qbar):
+                f.write(a.tobytes())
+            f.write(q.tobytes(order="F"))
+            f.write(src.Tsrc.tobytes(order="F"))
+            f.write(src.LtracerSrc.tobytes())
     r = subprocess.run([str(tmp_path / "demo"), "state.bin", "result.bin", str(nsteps)], cwd=tmp_path,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
