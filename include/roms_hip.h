@@ -198,6 +198,10 @@ typedef struct roms_params {
    * first operator of t3dmix4_s.h:262 / :308, t3dmix4_geo.h:279 / :311 / :345, t3dmix4_iso.h:287 / :319 / :369): every
    * tracer difference of the lateral mixing operator is 3/4 of t(nrhs)'s plus 1/4 of t(nstp)'s. */
   int    ts_mix_stability;
+  /* TS_MIX_MIN_STRAT (t3dmix2_iso.h:313-316, t3dmix4_iso.h:361-364, :679-682; with MIX_ISO_TS): the density difference
+   * that scales the isopycnal slopes is at least strat_min = 0.1 kg/m3 per metre times the layer distance, in the
+   * place of the constant eps = 0.5. */
+  int    ts_mix_min_strat;
 } roms_params_t;
 enum roms_gls_stab { GLS_GALPERIN = 0, GLS_KANTHA_CLAYSON = 1, GLS_CANUTO_A = 2, GLS_CANUTO_B = 3 };
 

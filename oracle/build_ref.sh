@@ -23,7 +23,8 @@
 #                                 UPWELLING_ATM[_PG31|_PJ] (+ -DATM_PRESS: the air-pressure term of the three pressure-gradient files);
 #                                 UPWELLING_MASK_WET[_DIF4|_ISO|_PG31], BENCHMARK_MASK_WET (+ -DWET_DRY; PJ_GRADP with WET_DRY does not
 #                                 compile in the reference itself: prsgrd40.h:98-100 passes umask_wet, vmask_wet without declaring them);
-#                                 UPWELLING_STAB_DIF4, SEAMOUNT_STAB_DIF4, UPWELLING_STAB_ISO, SEAMOUNT_STAB_ISO (+ -DTS_MIX_STABILITY)
+#                                 UPWELLING_STAB_DIF4, SEAMOUNT_STAB_DIF4, UPWELLING_STAB_ISO, SEAMOUNT_STAB_ISO (+ -DTS_MIX_STABILITY);
+#                                 UPWELLING_MINSTRAT_ISO, SEAMOUNT_MINSTRAT_ISO (+ -DTS_MIX_MIN_STRAT)
 #
 # This is the reference's own recipe (makefile:207, Compilers/Linux-gfortran.mk:
 # 43-44: cpp -P -traditional then the Fortran compiler), serial build (no
@@ -74,6 +75,8 @@ build_app () {
   case $TAG in *_ATM_PC*) XDEF="$XDEF -DPRESS_COMPENSATE";; esac   # ... and the same term in the Flather value (u2dbc_im.F:264)
   # <APP>_STAB_DIF4 / _STAB_ISO: + TS_MIX_STABILITY (3/4 t(nrhs) + 1/4 t(nstp) in t3dmix2_*.h and the first operator of t3dmix4_*.h)
   case $TAG in *_STAB*) XDEF="$XDEF -DTS_MIX_STABILITY";; esac
+  # <APP>_MINSTRAT_ISO: + TS_MIX_MIN_STRAT (the slope scale of t3dmix2_iso.h / t3dmix4_iso.h bounded by a minimum stratification)
+  case $TAG in *_MINSTRAT*) XDEF="$XDEF -DTS_MIX_MIN_STRAT";; esac
   case $TAG in *_LIMBS) XDEF="$XDEF -DLIMIT_BSTRESS";; esac
   case $TAG in *_EMP) XDEF="$XDEF -DEMINUSP";; esac              # BENCHMARK[_MASK]_EMP: + EMINUSP (bulk_flux.F:883-899)      # <APP>_LIMBS: + LIMIT_BSTRESS (set_vbc.F:533-567)
   case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_PJ) VAR=pj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; *_LOGDRAG) VAR=logdrag; WDEF="-DREF_LOGDRAG";; *_GLS) VAR=gls; WDEF="-DREF_GLS";; esac
@@ -111,7 +114,7 @@ build_app () {
   echo "[$TAG] built $D/libref.so"
 }
 
-for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ UPWELLING_RAD2D UPWELLING_MASK_RAD2D BENCHMARK_RAD2D UPWELLING_LIMBS BENCHMARK_LIMBS BENCHMARK_EMP BENCHMARK_MASK_EMP UPWELLING_GLS UPWELLING_MASK_GLS BENCHMARK_GLS UPWELLING_MASK_WET BENCHMARK_MASK_WET UPWELLING_MASK_WET_DIF4 UPWELLING_MASK_WET_ISO UPWELLING_MASK_WET_PG31 UPWELLING_ATM UPWELLING_ATM_PG31 UPWELLING_ATM_PJ UPWELLING_ATM_PC UPWELLING_STAB_DIF4 SEAMOUNT_STAB_DIF4 UPWELLING_STAB_ISO SEAMOUNT_STAB_ISO}; do
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ UPWELLING_RAD2D UPWELLING_MASK_RAD2D BENCHMARK_RAD2D UPWELLING_LIMBS BENCHMARK_LIMBS BENCHMARK_EMP BENCHMARK_MASK_EMP UPWELLING_GLS UPWELLING_MASK_GLS BENCHMARK_GLS UPWELLING_MASK_WET BENCHMARK_MASK_WET UPWELLING_MASK_WET_DIF4 UPWELLING_MASK_WET_ISO UPWELLING_MASK_WET_PG31 UPWELLING_ATM UPWELLING_ATM_PG31 UPWELLING_ATM_PJ UPWELLING_ATM_PC UPWELLING_STAB_DIF4 SEAMOUNT_STAB_DIF4 UPWELLING_STAB_ISO SEAMOUNT_STAB_ISO UPWELLING_MINSTRAT_ISO SEAMOUNT_MINSTRAT_ISO}; do
   build_app $app &
 done
 wait

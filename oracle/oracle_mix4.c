@@ -303,7 +303,9 @@ static void iso_pass(const roms_bounds_t *b, const roms_params_t *p, const roms_
     } else {
       for (int j = j0 - 1; j <= j1 + 1; j++)
         for (int i = i0 - 1; i <= i1 + 1; i++) {
-          cff1 = MAX(pden(i, j, k) - pden(i, j, k + 1), eps);
+          /* TS_MIX_MIN_STRAT, t3dmix2_iso.h:313-316 / t3dmix4_iso.h:361-364, :679-682 (strat_min = 0.1) */
+          if (p->ts_mix_min_strat) cff1 = MAX(pden(i, j, k) - pden(i, j, k + 1), 0.1 * (z_r(i, j, k + 1) - z_r(i, j, k)));
+          else cff1 = MAX(pden(i, j, k) - pden(i, j, k + 1), eps);
           cff = -1.0 / cff1;
           dTdr(i, j, k2) = cff * SD(i, j, k + 1, i, j, k);
           FS(i, j, k2) = cff * (z_r(i, j, k + 1) - z_r(i, j, k));

@@ -32,6 +32,8 @@ class Ref:
         app += {0: "", 1: "_PG31", 2: "_WJ", 3: "_PJ"}[int(state.p.pgf)]   # prsgrd31.h builds (plain / WJ_GRADP), prsgrd40.h
         if state.p.uv_drag == 3:
             app += "_LOGDRAG"                                              # UV_LOGDRAG instead of the application's law
+        if state.p.ts_mix_min_strat:
+            app += "_MINSTRAT"                                             # built with -DTS_MIX_MIN_STRAT as well
         if state.p.ts_mix_stability:
             app += "_STAB"                                                 # built with -DTS_MIX_STABILITY as well
         if state.p.mix_iso_ts:

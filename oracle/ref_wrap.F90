@@ -58,7 +58,7 @@ MODULE ref_wrap_types
     REAL(c_double) :: Akk_bak, Akp_bak, Zos
     INTEGER(c_int) :: wet_dry, point_sources
     REAL(c_double) :: Dcrit
-    INTEGER(c_int) :: atm_press, press_compensate, ts_mix_stability
+    INTEGER(c_int) :: atm_press, press_compensate, ts_mix_stability, ts_mix_min_strat
   END TYPE params_t
   TYPE, BIND(C) :: stepidx_t
     INTEGER(c_int) :: iic, ntfirst, nstp, nnew, nrhs, kstp, krhs, knew, iif, predictor

@@ -112,7 +112,7 @@ class Params(C.Structure):
         ("gls_sigk", C.c_double), ("gls_sigp", C.c_double), ("gls_Kmin", C.c_double), ("gls_Pmin", C.c_double),
         ("Akk_bak", C.c_double), ("Akp_bak", C.c_double), ("Zos", C.c_double),
         ("wet_dry", C.c_int), ("point_sources", C.c_int), ("Dcrit", C.c_double),
-        ("atm_press", C.c_int), ("press_compensate", C.c_int), ("ts_mix_stability", C.c_int),
+        ("atm_press", C.c_int), ("press_compensate", C.c_int), ("ts_mix_stability", C.c_int), ("ts_mix_min_strat", C.c_int),
     ]
 
 

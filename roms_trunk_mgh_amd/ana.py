@@ -231,6 +231,7 @@ def make_params(cfg, NT):
     # WET_DRY: DCRIT of roms_*.in (0.10 m in every input script of the reference, e.g. roms_upwelling.in)
     p.atm_press = int(cfg.get("atm_press", 0))       # ATM_PRESS: Pair in the baroclinic pressure gradient
     p.press_compensate = int(cfg.get("press_compensate", 0))   # ... and (PRESS_COMPENSATE) in the Flather value
+    p.ts_mix_min_strat = int(cfg.get("ts_mix_min_strat", 0))   # TS_MIX_MIN_STRAT (with MIX_ISO_TS)
     p.ts_mix_stability = int(cfg.get("ts_mix_stability", 0))   # TS_MIX_STABILITY: 3/4 t(nrhs) + 1/4 t(nstp) in the tracer mixing
     p.wet_dry = int(cfg.get("wet_dry", 0))
     p.Dcrit = float(cfg.get("Dcrit", 0.10))

@@ -87,8 +87,11 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   const double *__restrict__ pn = c->F.pn;
   const double *__restrict__ d2 = (MODE == 0 ? c->F.diff2 : c->F.diff4) + (long)(itrc - 1) * nij;
   // the vertical scale of a column between levels k (a) and k+1 (b): 1/dz, or -1/MAX(drho, eps) (t3dmix2_iso.h:299-301)
-  auto vscale = [](double a, double b) {
-    if constexpr (ISO) return -1.0 / fmax(a - b, 0.5);
+  // (ISO with TS_MIX_MIN_STRAT, t3dmix2_iso.h:313-316: the bound of the density difference is strat_min = 0.1 times the
+  // distance dz of the two levels in that column instead of eps = 0.5)
+  const bool minstrat = ISO && c->p.ts_mix_min_strat != 0;
+  auto vscale = [minstrat](double a, double b, double dz) {
+    if constexpr (ISO) return -1.0 / fmax(a - b, minstrat ? 0.1 * dz : 0.5);
     else return 1.0 / (b - a);
   };
   auto f1 = [](double a) { if constexpr (ISO) return dmax0(a); else return dmin0(a); };
@@ -119,7 +122,8 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   // k+1 at the five columns, Hz of level k at the five columns, t(nnew) of level k -- are issued one
   // iteration ahead, so their latency overlaps the arithmetic of the previous level.
   struct LvIn { double Tm1, T01, Tp1, Ts1, Tn1, Zm1, Z01, Zp1, Zs1, Zn1, hz0, hzm, hzp, hzs, hzn, tn, zz1;
-                double Sm1, S01, Sp1, Ss1, Sn1; };
+                double Sm1, S01, Sp1, Ss1, Sn1;
+                double zzm1, zzp1, zzs1, zzn1; };          // TS_MIX_MIN_STRAT: z_r of the four neighbour columns
   const gcd_t gT = (gcd_t)T, gS = (gcd_t)S, gZ = (gcd_t)z_r, gHz = (gcd_t)Hz;
   const gd_t gtn = (gd_t)tn;
   auto load_level = [&](int k) {
@@ -133,6 +137,11 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
     L.hz0 = gHz[ck]; L.hzm = gHz[ck - 1]; L.hzp = gHz[ck + 1]; L.hzs = gHz[ck - ni]; L.hzn = gHz[ck + ni];
     L.tn = gtn[ck];
     if constexpr (ISO) L.zz1 = ((gcd_t)zz)[cu]; else L.zz1 = 0.0;
+    L.zzm1 = L.zzp1 = L.zzs1 = L.zzn1 = 0.0;
+    if (minstrat) {
+      const gcd_t gz = (gcd_t)zz;
+      L.zzm1 = gz[cu - 1]; L.zzp1 = gz[cu + 1]; L.zzs1 = gz[cu - ni]; L.zzn1 = gz[cu + ni];
+    }
     return L;
   };
   // values of level k carried for the vertical differences
@@ -141,6 +150,8 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
   if constexpr (STAB) { Sm = S[c0 - 1]; S0 = S[c0]; Sp = S[c0 + 1]; Ss = S[c0 - ni]; Sn = S[c0 + ni]; }
   double Zm = z_r[c0 - 1], Z0 = z_r[c0], Zp = z_r[c0 + 1], Zs = z_r[c0 - ni], Zn = z_r[c0 + ni];
   double zzc = ISO ? zz[c0] : 0.0;
+  double zzm = 0.0, zzp = 0.0, zzs = 0.0, zzn = 0.0;
+  if (minstrat) { zzm = zz[c0 - 1]; zzp = zz[c0 + 1]; zzs = zz[c0 - ni]; zzn = zz[c0 + ni]; }
   // level 1 slabs (iteration k=0 of the reference)
   zx0_b = mx0 * (Z0 - Zm); tx0_b = mx0 * tdiff<STAB>(T0, Tm, S0, Sm);
   zx1_b = mx1 * (Zp - Z0); tx1_b = mx1 * tdiff<STAB>(Tp, T0, Sp, S0);
@@ -161,12 +172,13 @@ k_t3dmix_geo(const RomsDev *__restrict__ c, int nrhs, int nnew, Lap4 L)
       zx1_b = mx1 * (Zp1 - Z01); tx1_b = mx1 * tdiff<STAB>(Tp1, T01, Sp1, S01);
       ze0_b = my0 * (Z01 - Zs1); te0_b = my0 * tdiff<STAB>(T01, Ts1, S01, Ss1);
       ze1_b = my1 * (Zn1 - Z01); te1_b = my1 * tdiff<STAB>(Tn1, T01, Sn1, S01);
-      { const double q = vscale(Zm, Zm1); dzm_b = q * tdiff<STAB>(Tm1, Tm, Sm1, Sm); }
-      { const double q = vscale(Z0, Z01); dz0_b = q * tdiff<STAB>(T01, T0, S01, S0);
+      { const double q = vscale(Zm, Zm1, cur.zzm1 - zzm); dzm_b = q * tdiff<STAB>(Tm1, Tm, Sm1, Sm); }
+      { const double q = vscale(Z0, Z01, cur.zz1 - zzc); dz0_b = q * tdiff<STAB>(T01, T0, S01, S0);
         if constexpr (ISO) { fsf_b = q * (cur.zz1 - zzc); zzc = cur.zz1; } }
-      { const double q = vscale(Zp, Zp1); dzp_b = q * tdiff<STAB>(Tp1, Tp, Sp1, Sp); }
-      { const double q = vscale(Zs, Zs1); dzs_b = q * tdiff<STAB>(Ts1, Ts, Ss1, Ss); }
-      { const double q = vscale(Zn, Zn1); dzn_b = q * tdiff<STAB>(Tn1, Tn, Sn1, Sn); }
+      { const double q = vscale(Zp, Zp1, cur.zzp1 - zzp); dzp_b = q * tdiff<STAB>(Tp1, Tp, Sp1, Sp); }
+      { const double q = vscale(Zs, Zs1, cur.zzs1 - zzs); dzs_b = q * tdiff<STAB>(Ts1, Ts, Ss1, Ss); }
+      { const double q = vscale(Zn, Zn1, cur.zzn1 - zzn); dzn_b = q * tdiff<STAB>(Tn1, Tn, Sn1, Sn); }
+      zzm = cur.zzm1; zzp = cur.zzp1; zzs = cur.zzs1; zzn = cur.zzn1;
       Tm = Tm1; T0 = T01; Tp = Tp1; Ts = Ts1; Tn = Tn1;
       Sm = Sm1; S0 = S01; Sp = Sp1; Ss = Ss1; Sn = Sn1;
       Zm = Zm1; Z0 = Z01; Zp = Zp1; Zs = Zs1; Zn = Zn1;

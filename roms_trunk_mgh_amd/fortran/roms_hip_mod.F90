@@ -86,6 +86,8 @@ MODULE roms_hip_mod
     INTEGER(c_int) :: atm_press, press_compensate
     !  TS_MIX_STABILITY: 3/4 t(nrhs) + 1/4 t(nstp) in the lateral tracer mixing
     INTEGER(c_int) :: ts_mix_stability
+    !  TS_MIX_MIN_STRAT: the slope scale of the isopycnal operator bounded by a minimum stratification
+    INTEGER(c_int) :: ts_mix_min_strat
   END TYPE roms_params_t
 
   !  mirrors `roms_halo_msg_t` of include/roms_hip.h (host relay of the halo exchange)

@@ -1,4 +1,5 @@
-"""Generates tests/golden/ref_stab.npz from the REFERENCE's own t3dmix2 / t3dmix4 built with -DTS_MIX_STABILITY
+"""Generates tests/golden/ref_stab.npz from the REFERENCE's own t3dmix2 / t3dmix4 built with -DTS_MIX_STABILITY (and,
+the minstrat_* variants, with -DTS_MIX_MIN_STRAT)
 (oracle/_ref/UPWELLING_STAB_DIF4, SEAMOUNT_STAB_DIF4, UPWELLING_STAB_ISO, SEAMOUNT_STAB_ISO; oracle/build_ref.sh):
 3/4 t(nrhs) + 1/4 t(nstp) in every tracer difference of t3dmix2_s.h / t3dmix2_geo.h / t3dmix2_iso.h and of the first
 operator of t3dmix4_s.h / t3dmix4_geo.h / t3dmix4_iso.h, on the states of tests/util.prepared_state and
@@ -19,21 +20,24 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-# variant -> (configuration, isopycnal)
-VARIANTS = {"s": ("UPWELLING", False), "geo": ("SEAMOUNT", False), "iso_upw": ("UPWELLING", True),
-            "iso_sea": ("SEAMOUNT", True)}
+# variant -> (configuration, isopycnal, option)
+VARIANTS = {"s": ("UPWELLING", False, "ts_mix_stability"), "geo": ("SEAMOUNT", False, "ts_mix_stability"),
+            "iso_upw": ("UPWELLING", True, "ts_mix_stability"), "iso_sea": ("SEAMOUNT", True, "ts_mix_stability"),
+            # TS_MIX_MIN_STRAT (oracle/_ref/UPWELLING_MINSTRAT_ISO, SEAMOUNT_MINSTRAT_ISO): the slope scale of the
+            # isopycnal operators bounded by strat_min * dz (t3dmix2_iso.h:313-316, t3dmix4_iso.h:361-364, :679-682)
+            "minstrat_upw": ("UPWELLING", True, "ts_mix_min_strat"), "minstrat_sea": ("SEAMOUNT", True, "ts_mix_min_strat")}
 KERNELS = ("t3dmix2", "t3dmix4")
 
 
 def prepare(variant):
     import ref_worker
     import util
-    config, iso = VARIANTS[variant]
+    config, iso, opt = VARIANTS[variant]
     if iso:
-        st = ref_worker.iso_state(config, extra={"ts_mix_stability": 1})
+        st = ref_worker.iso_state(config, extra={opt: 1})
     else:
-        st = util.prepared_state(config, overrides=dict(ref_worker.DIF4, tnu2=300.0, ts_mix_stability=1))
-    assert st.p.ts_mix_stability == 1
+        st = util.prepared_state(config, overrides=dict(ref_worker.DIF4, tnu2=300.0, **{opt: 1}))
+    assert getattr(st.p, opt) == 1
     return st, util.step_idx(nstp=1, nnew=2, nrhs=3)
 
 

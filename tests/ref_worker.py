@@ -72,6 +72,7 @@ DIF4 = {"ts_dif4": 1, "uv_vis4": 1, "tnu4": 2.0e7, "visc4": 4.0e7}
 # distinct time levels nrhs = 3 and nstp = 1 (the model's own sequence has nrhs = nstp there, main3d.F:191, which would
 # leave the 1/4 part untested)
 STAB = False
+MINSTRAT = False          # "... minstrat": the iso modes against the builds with -DTS_MIX_MIN_STRAT
 
 
 def mix_step_idx():
@@ -80,12 +81,14 @@ def mix_step_idx():
 
 
 def stab_effect(st0, st_o, k, s):
-    """How far the TS_MIX_STABILITY result lies from the plain operator's on the same state (the option has to act)."""
+    """How far the TS_MIX_STABILITY / TS_MIX_MIN_STRAT result lies from the plain operator's on the same state (the
+    option has to act)."""
     import oracle
     import util
     st_p = st0.copy()
     st_p.p = type(st0.p).from_buffer_copy(st0.p)        # copy() shares the parameter block
     st_p.p.ts_mix_stability = 0
+    st_p.p.ts_mix_min_strat = 0
     oracle.Oracle(st_p).call(k, s)
     return util.max_rel_diff(st_o["t"], st_p["t"])
 
@@ -133,7 +136,7 @@ def iso_state(config, basin=None, mask=None, extra=None):
     import oracle
     import util
     from roms_trunk_mgh_amd import abi
-    ov = dict(DIF4, mix_iso_ts=1, tnu2=300.0, ts_mix_stability=int(STAB))
+    ov = dict(DIF4, mix_iso_ts=1, tnu2=300.0, ts_mix_stability=int(STAB), ts_mix_min_strat=int(MINSTRAT))
     if extra:
         ov.update(extra)
     if basin:
@@ -173,7 +176,7 @@ def main_iso(config, basin=None, mask=None):
         out["kernels"][k] = {"max_rel_diff": max(diffs.values()) if diffs else 0.0, "fields_diff": sorted(diffs),
                              "changed": sorted(util.compare_states(st_r, st0)),
                              "change": util.max_rel_diff(st_r["t"], st0["t"])}
-        if STAB:
+        if STAB or MINSTRAT:
             out["kernels"][k]["stab_effect"] = stab_effect(st0, st_o, k, s)
     print(json.dumps(out))
 
@@ -711,6 +714,9 @@ if __name__ == "__main__":
     if sys.argv[-1] == "wet":                  # ... wet: the same comparison on a WET_DRY state against the _WET builds
         import util as _util
         _util.WET = True
+        sys.argv.pop()
+    if sys.argv[-1] == "minstrat":             # ... minstrat: the iso modes against the _MINSTRAT builds
+        MINSTRAT = True
         sys.argv.pop()
     if sys.argv[-1] == "stab":                 # ... stab: the dif4 / iso modes against the _STAB builds
         STAB = True

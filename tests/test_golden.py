@@ -684,15 +684,16 @@ def _stab_check(backend, tol):
                 else:
                     scale = max(float(np.abs(want).max()), 1e-300)
                     assert float(np.abs(v - want).max()) <= tol * scale, k
-            # the 1/4 t(nstp) part matters
+            # the option matters (the 1/4 t(nstp) part; the stratification bound)
             st_off.p.ts_mix_stability = 0
+            st_off.p.ts_mix_min_strat = 0
             backend(st_off, s, kernel)
             assert not np.array_equal(st_off["t"], st["t"]), (variant, kernel)
 
 
 def test_oracle_reproduces_reference_ts_mix_stability():
     """TS_MIX_STABILITY: t3dmix2 / t3dmix4 along s-surfaces, geopotentials and isopycnals of the reference built with
-    the option (make_golden_stab.py), whole arrays by SHA-256."""
+    the option, and TS_MIX_MIN_STRAT on the isopycnal operators (make_golden_stab.py), whole arrays by SHA-256."""
     import oracle
     _stab_check(lambda st, s, k: oracle.Oracle(st).call(k, s), 0.0)
 

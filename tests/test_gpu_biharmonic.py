@@ -232,3 +232,32 @@ def test_100_steps_with_ts_mix_stability(config, iso):
         out[f"t{it+1}"] = rel_rms(st_h.interior("t")[..., s.nnew - 1, it], st_o.interior("t")[..., s.nnew - 1, it], 1e-3)
     assert np.isfinite(st_h["t"]).all() and np.isfinite(st_o["t"]).all()
     assert all(v <= 1e-10 for v in out.values()), out          # north-star bound
+
+
+# ---- TS_MIX_MIN_STRAT: the slope scale of the isopycnal operators bounded by strat_min * dz ----
+@pytest.mark.parametrize("config", ["UPWELLING", "SEAMOUNT", "BENCHMARK_TINY"])
+@pytest.mark.parametrize("variant", ["periodic", "open", "mask"])
+@pytest.mark.parametrize("kernel", ["t3dmix2", "t3dmix4"])
+def test_ts_mix_min_strat_kernels(config, variant, kernel):
+    """the oracle is pinned against the reference built with -DTS_MIX_MIN_STRAT
+    (tests/test_ref_pinning.py::test_ts_mix_min_strat_matches_reference_build)"""
+    import oracle
+    import ref_worker
+    st0 = ref_worker.iso_state(config, basin=variant if variant == "open" else None,
+                               mask="island" if variant == "mask" else None,
+                               extra=dict(DIF4[config], ts_mix_min_strat=1))
+    assert st0.p.ts_mix_min_strat == 1
+    s = util.step_idx(iic=5)
+    st_o, st_h, st_p = st0.copy(), st0.copy(), st0.copy()
+    oracle.Oracle(st_o).call(kernel, s)
+    st_p.p = type(st0.p).from_buffer_copy(st0.p)
+    st_p.p.ts_mix_min_strat = 0
+    oracle.Oracle(st_p).call(kernel, s)
+    h = hip.RomsHip(st_h)
+    try:
+        h.call(kernel, s)
+        h.to_host()
+    finally:
+        h.close()
+    assert np.array_equal(st_h["t"], st_o["t"]), util.compare_states(st_h, st_o)
+    assert util.max_rel_diff(st_o["t"], st_p["t"]) > 1e-9           # the option acts
