@@ -91,7 +91,7 @@ void o_src_wtracer(OARGS, int itrc, int mpdata, int j, double *Ta_, const double
     if (mpdata && j != Jsrc) continue;
     for (int k = 1; k <= N; k++) {
       double cff = p->dt * pm(Isrc, Jsrc) * pn(Isrc, Jsrc);
-      if (!mpdata) cff = cff * oHz_[WS3(Isrc, Jsrc, k)];                     /* SPLINES_VDIFF, :1341-1343 */
+      if (!mpdata && p->splines_vdiff) cff = cff * oHz_[WS3(Isrc, Jsrc, k)];  /* SPLINES_VDIFF, :1341-1343 */
       const double cff3 = o_src.ltr[itrc - 1] ? TSRC(is, k, itrc) : t(Isrc, Jsrc, k, 3, itrc);
       if (mpdata) Ta_[WS3(Isrc, Jsrc, k) + (long)(itrc - 1) * n3s] = Ta_[WS3(Isrc, Jsrc, k) + (long)(itrc - 1) * n3s] + cff * QSRC(is, k) * cff3;
       else t(Isrc, Jsrc, k, nnew, itrc) = t(Isrc, Jsrc, k, nnew, itrc) + cff * QSRC(is, k) * cff3;

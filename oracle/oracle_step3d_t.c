@@ -15,7 +15,6 @@ int oracle_step3d_t(OARGS)
   ORACLE_PROLOGUE
   if (o_src_check(p)) return 8;
   if (o_check_lbc(b, p)) return 8;
-  if (!p->splines_vdiff) return 8;        /* only the SPLINES_VDIFF operator (step3d_t.F:1363-1430) is restated */
   const int nnew = s->nnew;
   const double dt = p->dt;
   const double eps = 1.0E-16;
@@ -437,7 +436,7 @@ int oracle_step3d_t(OARGS)
         for (int i = Istr; i <= Iend; i++) {
           double cff1 = CF(i, 0) * (FC(i, k) - FC(i, k - 1));
           t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) - cff1;
-          t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) * oHz(i, j, k);
+          if (p->splines_vdiff) t(i, j, k, nnew, itrc) = t(i, j, k, nnew, itrc) * oHz(i, j, k);      /* :1196-1198 */
         }
     }
   }
@@ -498,8 +497,8 @@ int oracle_step3d_t(OARGS)
   for (int j = Jstr; j <= Jend; j++) {
     for (int itrc = 1; itrc <= NT; itrc++) {
       const int ltrc = MIN(NAT, itrc);
-      if (p->Hadv[itrc - 1] == ADV_MPDATA) {
-        /* classic tridiagonal for MPDATA tracers (also under SPLINES_VDIFF), :1431-1501 */
+      if (p->Hadv[itrc - 1] == ADV_MPDATA || !p->splines_vdiff) {
+        /* classic tridiagonal: without SPLINES_VDIFF, and for MPDATA tracers under it as well, :1431-1501 */
         double cff = -dt * p->lambda;
         for (int k = 1; k <= N - 1; k++)
           for (int i = Istr; i <= Iend; i++) {

@@ -12,7 +12,6 @@ int oracle_step3d_uv(OARGS)
   ORACLE_PROLOGUE
   if (o_src_check(p)) return 8;
   if (o_check_lbc(b, p)) return 8;
-  if (!p->splines_vvisc) return 8;        /* only the SPLINES_VVISC operator (step3d_uv.F:303-398) is restated */
   const int nrhs = s->nrhs, nnew = s->nnew;
   const int iic = s->iic, ntfirst = s->ntfirst;
   const double dt = p->dt;
@@ -45,32 +44,68 @@ int oracle_step3d_uv(OARGS)
     for (int k = 1; k <= N; k++)
       for (int i = IstrU; i <= Iend; i++) {
         u(i, j, k, nnew) = u(i, j, k, nnew) + DC(i, 0) * ru(i, j, k, nrhs);
-        u(i, j, k, nnew) = u(i, j, k, nnew) * oHz(i, k);
+        if (p->splines_vvisc) u(i, j, k, nnew) = u(i, j, k, nnew) * oHz(i, k);
       }
-    cff1 = 1.0 / 6.0;
-    for (int k = 1; k <= N - 1; k++)
+    if (!p->splines_vvisc) {
+      /* the implicit vertical viscosity without SPLINES_VVISC, step3d_uv.F:400-464: a tridiagonal system for u itself */
+      cff = -p->lambda * dt / 0.5;
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = IstrU; i <= Iend; i++) {
+          cff1 = 1.0 / (z_r(i, j, k + 1) + z_r(i - 1, j, k + 1) - z_r(i, j, k) - z_r(i - 1, j, k));
+          FC(i, k) = cff * cff1 * AK(i, k);
+        }
+      for (int i = IstrU; i <= Iend; i++) { FC(i, 0) = 0.0; FC(i, N) = 0.0; }
+      for (int k = 1; k <= N; k++)
+        for (int i = IstrU; i <= Iend; i++) {
+          DC(i, k) = u(i, j, k, nnew);
+          BC(i, k) = Hzk(i, k) - FC(i, k) - FC(i, k - 1);
+        }
       for (int i = IstrU; i <= Iend; i++) {
-        FC(i, k) = cff1 * Hzk(i, k) - dt * AK(i, k - 1) * oHz(i, k);
-        CF(i, k) = cff1 * Hzk(i, k + 1) - dt * AK(i, k + 1) * oHz(i, k + 1);
+        cff = 1.0 / BC(i, 1);
+        CF(i, 1) = cff * FC(i, 1);
+        DC(i, 1) = cff * DC(i, 1);
       }
-    for (int i = IstrU; i <= Iend; i++) { CF(i, 0) = 0.0; DC(i, 0) = 0.0; }
-    cff1 = 1.0 / 3.0;
-    for (int k = 1; k <= N - 1; k++)
+      for (int k = 2; k <= N - 1; k++)
+        for (int i = IstrU; i <= Iend; i++) {
+          cff = 1.0 / (BC(i, k) - FC(i, k - 1) * CF(i, k - 1));
+          CF(i, k) = cff * FC(i, k);
+          DC(i, k) = cff * (DC(i, k) - FC(i, k - 1) * DC(i, k - 1));
+        }
       for (int i = IstrU; i <= Iend; i++) {
-        BC(i, k) = cff1 * (Hzk(i, k) + Hzk(i, k + 1)) + dt * AK(i, k) * (oHz(i, k) + oHz(i, k + 1));
-        cff = 1.0 / (BC(i, k) - FC(i, k) * CF(i, k - 1));
-        CF(i, k) = cff * CF(i, k);
-        DC(i, k) = cff * (u(i, j, k + 1, nnew) - u(i, j, k, nnew) - FC(i, k) * DC(i, k - 1));
+        DC(i, N) = (DC(i, N) - FC(i, N - 1) * DC(i, N - 1)) / (BC(i, N) - FC(i, N - 1) * CF(i, N - 1));
+        u(i, j, N, nnew) = DC(i, N);
       }
-    for (int i = IstrU; i <= Iend; i++) DC(i, N) = 0.0;
-    for (int k = N - 1; k >= 1; k--)
-      for (int i = IstrU; i <= Iend; i++) DC(i, k) = DC(i, k) - CF(i, k) * DC(i, k + 1);
-    for (int k = 1; k <= N; k++)
-      for (int i = IstrU; i <= Iend; i++) {
-        DC(i, k) = DC(i, k) * AK(i, k);
-        cff = dt * oHz(i, k) * (DC(i, k) - DC(i, k - 1));
-        u(i, j, k, nnew) = u(i, j, k, nnew) + cff;
-      }
+      for (int k = N - 1; k >= 1; k--)
+        for (int i = IstrU; i <= Iend; i++) {
+          DC(i, k) = DC(i, k) - CF(i, k) * DC(i, k + 1);
+          u(i, j, k, nnew) = DC(i, k);
+        }
+    } else {
+      cff1 = 1.0 / 6.0;
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = IstrU; i <= Iend; i++) {
+          FC(i, k) = cff1 * Hzk(i, k) - dt * AK(i, k - 1) * oHz(i, k);
+          CF(i, k) = cff1 * Hzk(i, k + 1) - dt * AK(i, k + 1) * oHz(i, k + 1);
+        }
+      for (int i = IstrU; i <= Iend; i++) { CF(i, 0) = 0.0; DC(i, 0) = 0.0; }
+      cff1 = 1.0 / 3.0;
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = IstrU; i <= Iend; i++) {
+          BC(i, k) = cff1 * (Hzk(i, k) + Hzk(i, k + 1)) + dt * AK(i, k) * (oHz(i, k) + oHz(i, k + 1));
+          cff = 1.0 / (BC(i, k) - FC(i, k) * CF(i, k - 1));
+          CF(i, k) = cff * CF(i, k);
+          DC(i, k) = cff * (u(i, j, k + 1, nnew) - u(i, j, k, nnew) - FC(i, k) * DC(i, k - 1));
+        }
+      for (int i = IstrU; i <= Iend; i++) DC(i, N) = 0.0;
+      for (int k = N - 1; k >= 1; k--)
+        for (int i = IstrU; i <= Iend; i++) DC(i, k) = DC(i, k) - CF(i, k) * DC(i, k + 1);
+      for (int k = 1; k <= N; k++)
+        for (int i = IstrU; i <= Iend; i++) {
+          DC(i, k) = DC(i, k) * AK(i, k);
+          cff = dt * oHz(i, k) * (DC(i, k) - DC(i, k - 1));
+          u(i, j, k, nnew) = u(i, j, k, nnew) + cff;
+        }
+    }
     /* replace the vertical mean with the barotropic one, step3d_uv.F:466-520 */
     for (int i = IstrU; i <= Iend; i++) { CF(i, 0) = Hzk(i, 1); DC(i, 0) = u(i, j, 1, nnew) * Hzk(i, 1); }
     for (int k = 2; k <= N; k++)
@@ -109,32 +144,68 @@ int oracle_step3d_uv(OARGS)
       for (int k = 1; k <= N; k++)
         for (int i = Istr; i <= Iend; i++) {
           v(i, j, k, nnew) = v(i, j, k, nnew) + DC(i, 0) * rv(i, j, k, nrhs);
-          v(i, j, k, nnew) = v(i, j, k, nnew) * oHz(i, k);
+          if (p->splines_vvisc) v(i, j, k, nnew) = v(i, j, k, nnew) * oHz(i, k);
         }
-      cff1 = 1.0 / 6.0;
-      for (int k = 1; k <= N - 1; k++)
+      if (!p->splines_vvisc) {
+        /* without SPLINES_VVISC, step3d_uv.F:733-797 */
+        cff = -p->lambda * dt / 0.5;
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff1 = 1.0 / (z_r(i, j, k + 1) + z_r(i, j - 1, k + 1) - z_r(i, j, k) - z_r(i, j - 1, k));
+            FC(i, k) = cff * cff1 * AK(i, k);
+          }
+        for (int i = Istr; i <= Iend; i++) { FC(i, 0) = 0.0; FC(i, N) = 0.0; }
+        for (int k = 1; k <= N; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            DC(i, k) = v(i, j, k, nnew);
+            BC(i, k) = Hzk(i, k) - FC(i, k) - FC(i, k - 1);
+          }
         for (int i = Istr; i <= Iend; i++) {
-          FC(i, k) = cff1 * Hzk(i, k) - dt * AK(i, k - 1) * oHz(i, k);
-          CF(i, k) = cff1 * Hzk(i, k + 1) - dt * AK(i, k + 1) * oHz(i, k + 1);
+          cff = 1.0 / BC(i, 1);
+          CF(i, 1) = cff * FC(i, 1);
+          DC(i, 1) = cff * DC(i, 1);
         }
-      for (int i = Istr; i <= Iend; i++) { CF(i, 0) = 0.0; DC(i, 0) = 0.0; }
-      cff1 = 1.0 / 3.0;
-      for (int k = 1; k <= N - 1; k++)
+        for (int k = 2; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff = 1.0 / (BC(i, k) - FC(i, k - 1) * CF(i, k - 1));
+            CF(i, k) = cff * FC(i, k);
+            DC(i, k) = cff * (DC(i, k) - FC(i, k - 1) * DC(i, k - 1));
+          }
         for (int i = Istr; i <= Iend; i++) {
-          BC(i, k) = cff1 * (Hzk(i, k) + Hzk(i, k + 1)) + dt * AK(i, k) * (oHz(i, k) + oHz(i, k + 1));
-          cff = 1.0 / (BC(i, k) - FC(i, k) * CF(i, k - 1));
-          CF(i, k) = cff * CF(i, k);
-          DC(i, k) = cff * (v(i, j, k + 1, nnew) - v(i, j, k, nnew) - FC(i, k) * DC(i, k - 1));
+          DC(i, N) = (DC(i, N) - FC(i, N - 1) * DC(i, N - 1)) / (BC(i, N) - FC(i, N - 1) * CF(i, N - 1));
+          v(i, j, N, nnew) = DC(i, N);
         }
-      for (int i = Istr; i <= Iend; i++) DC(i, N) = 0.0;
-      for (int k = N - 1; k >= 1; k--)
-        for (int i = Istr; i <= Iend; i++) DC(i, k) = DC(i, k) - CF(i, k) * DC(i, k + 1);
-      for (int k = 1; k <= N; k++)
-        for (int i = Istr; i <= Iend; i++) {
-          DC(i, k) = DC(i, k) * AK(i, k);
-          cff = dt * oHz(i, k) * (DC(i, k) - DC(i, k - 1));
-          v(i, j, k, nnew) = v(i, j, k, nnew) + cff;
-        }
+        for (int k = N - 1; k >= 1; k--)
+          for (int i = Istr; i <= Iend; i++) {
+            DC(i, k) = DC(i, k) - CF(i, k) * DC(i, k + 1);
+            v(i, j, k, nnew) = DC(i, k);
+          }
+      } else {
+        cff1 = 1.0 / 6.0;
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            FC(i, k) = cff1 * Hzk(i, k) - dt * AK(i, k - 1) * oHz(i, k);
+            CF(i, k) = cff1 * Hzk(i, k + 1) - dt * AK(i, k + 1) * oHz(i, k + 1);
+          }
+        for (int i = Istr; i <= Iend; i++) { CF(i, 0) = 0.0; DC(i, 0) = 0.0; }
+        cff1 = 1.0 / 3.0;
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            BC(i, k) = cff1 * (Hzk(i, k) + Hzk(i, k + 1)) + dt * AK(i, k) * (oHz(i, k) + oHz(i, k + 1));
+            cff = 1.0 / (BC(i, k) - FC(i, k) * CF(i, k - 1));
+            CF(i, k) = cff * CF(i, k);
+            DC(i, k) = cff * (v(i, j, k + 1, nnew) - v(i, j, k, nnew) - FC(i, k) * DC(i, k - 1));
+          }
+        for (int i = Istr; i <= Iend; i++) DC(i, N) = 0.0;
+        for (int k = N - 1; k >= 1; k--)
+          for (int i = Istr; i <= Iend; i++) DC(i, k) = DC(i, k) - CF(i, k) * DC(i, k + 1);
+        for (int k = 1; k <= N; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            DC(i, k) = DC(i, k) * AK(i, k);
+            cff = dt * oHz(i, k) * (DC(i, k) - DC(i, k - 1));
+            v(i, j, k, nnew) = v(i, j, k, nnew) + cff;
+          }
+      }
       for (int i = Istr; i <= Iend; i++) { CF(i, 0) = Hzk(i, 1); DC(i, 0) = v(i, j, 1, nnew) * Hzk(i, 1); }
       for (int k = 2; k <= N; k++)
         for (int i = Istr; i <= Iend; i++) {

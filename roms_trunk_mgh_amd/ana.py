@@ -205,7 +205,8 @@ def make_params(cfg, NT):
     p.salinity = int(app in ("BENCHMARK", "UPWELLING"))
     p.lmd_nonlocal = int(app == "BENCHMARK")
     p.solar_source = int(app == "BENCHMARK")
-    p.splines_vdiff = p.splines_vvisc = 1
+    p.splines_vdiff = int(cfg.get("splines_vdiff", 1))   # SPLINES_VDIFF / SPLINES_VVISC: 30 of the reference's 31 3-D applications
+    p.splines_vvisc = int(cfg.get("splines_vvisc", 1))
     for it in range(NT):
         p.Akt_bak[it] = {"BENCHMARK": 1.0e-5}.get(app, 1.0e-6)
     p.Akv_bak = {"BENCHMARK": 1.0e-4}.get(app, 1.0e-5)

@@ -333,7 +333,11 @@ struct LevelIn {
 // look at the face maps per column, and only when there is a table) and the SRC instantiation -- the same text plus the
 // replacement of the source faces' fluxes, step3d_t.F:734-799 -- runs over the list of those cells, grid =
 // (cells / 256, tracers of the launch).  The threads of the kernel do not cooperate, so any cell-to-thread map will do.
-template <int HADV, int VADV, int NMAX, bool MASK, bool SRC = false>
+// SPL = false (without SPLINES_VDIFF, step3d_t.F:1431-1501; 3 of the reference's 31 three-dimensional applications): the
+// advected tracer stays thickness-weighted (:1196-1198 is not compiled) and the implicit vertical diffusion is a
+// tridiagonal system for the tracer itself with the layer distances from z_r -- solved after the level loop from the
+// column in LDS.  Instantiated at NMAX = 64 only (one kernel serves every N, not tuned).
+template <int HADV, int VADV, int NMAX, bool MASK, bool SRC = false, bool SPL = true>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
 {
@@ -494,12 +498,12 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
         tv = tv - cff3;
       }
       tv = tv - cffdt * (FCk - FCprev);
-      tv = tv * ohz;
-      if constexpr (SRC) tv = src_w_tracer(c, c0, k, itrc, cffdt * ohz, tk, tv);   // LwSrc, step3d_t.F:1331-1360
+      if constexpr (SPL) tv = tv * ohz;
+      if constexpr (SRC) tv = src_w_tracer(c, c0, k, itrc, SPL ? cffdt * ohz : cffdt, tk, tv);   // LwSrc, step3d_t.F:1331-1360
       s_tn[(k - 1) * NTH + tid] = tv;
       FCprev = FCk;
       const double akt_0 = cur.akt;
-      if (k >= 2) {
+      if (SPL && k >= 2) {
         const double cff6 = 1.0 / 6.0, cff3r = 1.0 / 3.0;
         const double fc = cff6 * hz_m1 - dt * akt_m2 * ohz_m1;
         const double cf = cff6 * hz - dt * akt_0 * ohz;
@@ -515,6 +519,50 @@ k_step3d_t_pipe(const RomsDev *__restrict__ c, int nnew, int itrc0, int ntr)
     }
   }
 
+  if constexpr (!SPL) {
+    // the tridiagonal system of step3d_t.F:1431-1501: FC(k) = -dt lambda Akt(k) / (z_r(k+1) - z_r(k)),
+    // BC(k) = Hz(k) - FC(k) - FC(k-1), right-hand side = the advected, thickness-weighted tracer
+    const gcd_t z_r = (gcd_t)c->F.z_r;
+    const double cfl = -dt * c->p.lambda;
+    double fc_prev = 0.0;
+#pragma unroll
+    for (int k = 1; k <= NMAX; k++) {
+      if (k <= N) {
+        const long ck = c0 + (long)(k - 1) * nij;
+        double fc = 0.0;
+        if (k < N) {
+          const double cff1 = 1.0 / (z_r[ck + nij] - z_r[ck]);
+          fc = cfl * cff1 * Akt[ck + nij];
+        }
+        const double bc = Hz[ck] - fc - fc_prev;
+        const double d = s_tn[(k - 1) * NTH + tid];
+        if (k == 1) {
+          const double cff = 1.0 / bc;
+          CF[1] = cff * fc;
+          DC[1] = cff * d;
+        } else if (k < N) {
+          const double cff = 1.0 / (bc - fc_prev * CF[k - 1]);
+          CF[k] = cff * fc;
+          DC[k] = cff * (d - fc_prev * DC[k - 1]);
+        } else {
+          DC[k] = (d - fc_prev * DC[k - 1]) / (bc - fc_prev * CF[k - 1]);
+        }
+        fc_prev = fc;
+      }
+    }
+    double up = 0.0;
+#pragma unroll
+    for (int k = NMAX; k >= 1; k--) {
+      if (k <= N) {
+        const double v = (k == N) ? DC[k] : DC[k] - CF[k] * up;
+        up = v;
+        const long ck = c0 + (long)(k - 1) * nij;
+        if constexpr (MASK) tn_g[ck] = v * GF(rmask)[c0];
+        else tn_g[ck] = v;
+      }
+    }
+    return;
+  }
   // ---- back substitution + final update; Akt(kk), Hz(kk+1) prefetched two levels ahead ----
   double dcA_up = 0.0, dc_up = 0.0;
   double akA = Akt[c0 + (long)(N - 1) * nij], hzA = Hz[c0 + (long)(N - 1) * nij];
@@ -573,6 +621,11 @@ int launch_nmax(int nnew, int itrc0, int ntr)
       hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 32>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
     else
       hipLaunchKernelGGL((k_step3d_t<HADV, VADV, 64>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+  } else if (!g_ctx.p.splines_vdiff) {    // without SPLINES_VDIFF: one instantiation for every N
+    if (g_ctx.p.masking)
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, true, false, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+    else
+      hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, false, false, false>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
   } else if (g_ctx.p.masking) {           // software-pipelined kernel, land/sea masks applied
     if (b.N <= 16)
       hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, 16, true>), grid, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
@@ -596,10 +649,14 @@ int launch_nmax(int nnew, int itrc0, int ntr)
     const int ncell = g_ctx.hostc.src.ncell;
     if (ncell > 0) {
       const dim3 gs((ncell + BLK_X * BLK_Y - 1) / (BLK_X * BLK_Y), ntr);
-      if (g_ctx.p.masking)
-        hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, true, true>), gs, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
-      else
-        hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, false, true>), gs, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+      const bool spl = g_ctx.p.splines_vdiff != 0;
+      if (g_ctx.p.masking) {
+        if (spl) hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, true, true>), gs, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+        else hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, true, true, false>), gs, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+      } else {
+        if (spl) hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, false, true>), gs, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+        else hipLaunchKernelGGL((k_step3d_t_pipe<HADV, VADV, ROMS_MAXN, false, true, false>), gs, block2d(), 0, g_ctx.stream, g_ctx.devc, nnew, itrc0, ntr);
+      }
       KERNEL_CHECK("k_step3d_t (source cells)");
     }
   }
@@ -617,8 +674,10 @@ extern "C" int roms_hip_step3d_t(const roms_step_idx_t *s)
   const roms_params_t &p = g_ctx.p;
   if (b.N < 4) return roms_fail("roms_hip_step3d_t", "N < 4");
   if (!p.splines_vdiff)
-    return roms_fail("roms_hip_step3d_t", "only the spline-form implicit vertical diffusion (SPLINES_VDIFF, "
-                                          "step3d_t.F:1363-1430) is implemented");
+    for (int it = 1; it <= b.NT; it++)
+      if (p.Hadv[it - 1] == ADV_HSIMT || p.Vadv[it - 1] == ADV_HSIMT)
+        return roms_fail("roms_hip_step3d_t", "HSIMT without SPLINES_VDIFF is not built (the straight-from-memory kernel "
+                                              "carries the spline form of the vertical diffusion only)");
   {
     ScopedTimer tm("step3d_t");
     // one launch per run of consecutive tracers sharing a scheme pair (run-time

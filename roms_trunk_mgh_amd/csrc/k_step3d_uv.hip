@@ -266,6 +266,108 @@ __device__ __forceinline__ void couple_column(const RomsDev *__restrict__ c, lon
   }
 }
 
+// Without SPLINES_VVISC (step3d_uv.F:400-464, :733-797; 3 of the reference's 31 three-dimensional applications): the
+// AB3 step leaves u(nnew) thickness-weighted, and the implicit vertical viscosity is a tridiagonal system for the velocity
+// itself with the layer distances taken from z_r.  A plain column kernel (level arrays in registers / scratch, not
+// tuned like k_uv_column): solve, replace the vertical mean (:466-520), then couple_column from memory.
+template <int NMAX>
+__device__ __forceinline__ void uv_column_classic(const RomsDev *__restrict__ c, long c0, long off, long nij, int N, gd_t vel,
+                                                  gd_t rhs, double dc0, double metric, double Davg1, gd_t Hflx, gd_t bar,
+                                                  double Davg2, bool masking, double msk, bool wet, double wmsk)
+{
+  const gcd_t Akv = (gcd_t)(c->F.Akv), Hz = (gcd_t)(c->F.Hz), z_r = (gcd_t)(c->F.z_r);
+  const double dt = c->p.dt;
+  double hzk[NMAX + 1], FC[NMAX + 1], CF[NMAX + 1], DC[NMAX + 1];
+  FC[0] = 0.0;
+  const double cffv = -c->p.lambda * dt / 0.5;
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      const long ck = c0 + (long)(k - 1) * nij;
+      hzk[k] = 0.5 * (Hz[ck - off] + Hz[ck]);
+      DC[k] = vel[ck] + dc0 * rhs[ck + nij];                    // :316-318 (no division by the thickness)
+      if (k <= N - 1) {
+        const double ak = 0.5 * (Akv[ck + nij - off] + Akv[ck + nij]);      // AK(i,k)
+        const double cff1 = 1.0 / (z_r[ck + nij] + z_r[ck + nij - off] - z_r[ck] - z_r[ck - off]);
+        FC[k] = cffv * cff1 * ak;
+      } else FC[k] = 0.0;
+    }
+  }
+  // BC(k) = Hzk(k) - FC(k) - FC(k-1); forward elimination
+  {
+    const double cff = 1.0 / (hzk[1] - FC[1] - FC[0]);
+    CF[1] = cff * FC[1];
+    DC[1] = cff * DC[1];
+  }
+#pragma unroll
+  for (int k = 2; k <= NMAX - 1; k++) {
+    if (k <= N - 1) {
+      const double bc = hzk[k] - FC[k] - FC[k - 1];
+      const double cff = 1.0 / (bc - FC[k - 1] * CF[k - 1]);
+      CF[k] = cff * FC[k];
+      DC[k] = cff * (DC[k] - FC[k - 1] * DC[k - 1]);
+    }
+  }
+#pragma unroll
+  for (int k = 2; k <= NMAX; k++)
+    if (k == N) {
+      const double bc = hzk[k] - FC[k] - FC[k - 1];
+      DC[k] = (DC[k] - FC[k - 1] * DC[k - 1]) / (bc - FC[k - 1] * CF[k - 1]);
+    }
+#pragma unroll
+  for (int k = NMAX - 1; k >= 1; k--)
+    if (k <= N - 1) DC[k] = DC[k] - CF[k] * DC[k + 1];
+  // vertical mean replacement, :466-520 (sums ascend in k)
+  double sumH = 0.0, sumU = 0.0;
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      sumH = (k == 1) ? hzk[k] : sumH + hzk[k];
+      sumU = (k == 1) ? DC[k] * hzk[k] : sumU + DC[k] * hzk[k];
+    }
+  }
+  const double cff1 = 1.0 / (sumH * metric);
+  const double corr = (sumU * metric - Davg1) * cff1;
+#pragma unroll
+  for (int k = 1; k <= NMAX; k++) {
+    if (k <= N) {
+      const long ck = c0 + (long)(k - 1) * nij;
+      double uv = DC[k] - corr;
+      if (masking) uv = uv * msk;
+      if (wet) rhs[ck + nij] = rhs[ck + nij] * wmsk;
+      vel[ck] = uv;
+    }
+  }
+  couple_column<NMAX>(c, c0, off, nij, N, vel, Hflx, bar, metric, Davg1, Davg2, false, masking, msk, wet, wmsk);
+}
+
+template <int NMAX>
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_uv_column_classic(const RomsDev *__restrict__ c, int nrhs, int nnew, double cff)
+{
+  DEV_PROLOGUE(c)
+  const Blk XB = xcd_block();
+  const int i = b.Istr + XB.x * BLK_X + threadIdx.x;
+  const int j = b.Jstr + XB.y * BLK_Y + threadIdx.y;
+  if (i > b.Iend || j > b.Jend) return;
+  const long c0 = I2(i, j);
+  const gcd_t pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn;
+  const bool masking = c->p.masking != 0, wet = c->p.wet_dry != 0;
+  if (XB.z == 0) {
+    if (i < b.IstrU) return;
+    const double dc0 = cff * (pm[c0] + pm[c0 - 1]) * (pn[c0] + pn[c0 - 1]);
+    uv_column_classic<NMAX>(c, c0, 1, nij, N, (gd_t)(c->F.u + (long)(nnew - 1) * n3r), (gd_t)(c->F.ru + (long)(nrhs - 1) * n3w),
+                            dc0, GF(on_u)[c0], GF(DU_avg1)[c0], GF(Huon), GF(ubar), GF(DU_avg2)[c0], masking,
+                            masking ? umaskw(c, c0) : 1.0, wet, wet ? (double)GF(umask_wet)[c0] : 1.0);
+  } else {
+    if (j < b.JstrV) return;
+    const double dc0 = cff * (pm[c0] + pm[c0 - ni]) * (pn[c0] + pn[c0 - ni]);
+    uv_column_classic<NMAX>(c, c0, ni, nij, N, (gd_t)(c->F.v + (long)(nnew - 1) * n3r), (gd_t)(c->F.rv + (long)(nrhs - 1) * n3w),
+                            dc0, GF(om_v)[c0], GF(DV_avg1)[c0], GF(Hvom), GF(vbar), GF(DV_avg2)[c0], masking,
+                            masking ? vmaskw(c, c0) : 1.0, wet, wet ? (double)GF(vmask_wet)[c0] : 1.0);
+  }
+}
+
 template <int NMAX>
 __global__ void __launch_bounds__(BLK_X *BLK_Y)
 k_uv_couple(const RomsDev *__restrict__ c, int nnew)
@@ -309,9 +411,6 @@ extern "C" int roms_hip_step3d_uv(const roms_step_idx_t *s)
   int rc = roms_entry_check("roms_hip_step3d_uv");
   if (rc) return rc;
   if ((rc = check_lbc())) return rc;
-  if (!g_ctx.p.splines_vvisc)
-    return roms_fail("roms_hip_step3d_uv", "only the spline-form implicit vertical viscosity (SPLINES_VVISC, "
-                                           "step3d_uv.F:303-398) is implemented");
   const roms_bounds_t &b = g_ctx.b;
   const double dt = g_ctx.p.dt;
   double cff;
@@ -326,7 +425,11 @@ extern "C" int roms_hip_step3d_uv(const roms_step_idx_t *s)
     }
     dim3 grid = grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1);
     grid.z = 2;
-    if (b.N <= 16) hipLaunchKernelGGL(k_uv_column<16>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
+    if (!g_ctx.p.splines_vvisc) {           // without SPLINES_VVISC: the plain column kernel
+      if (b.N <= 32) hipLaunchKernelGGL(k_uv_column_classic<32>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
+      else if (b.N <= ROMS_MAXN) hipLaunchKernelGGL(k_uv_column_classic<ROMS_MAXN>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
+      else return roms_fail("roms_hip_step3d_uv", "N > 64 not instantiated");
+    } else if (b.N <= 16) hipLaunchKernelGGL(k_uv_column<16>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
     else if (b.N <= 32) hipLaunchKernelGGL(k_uv_column<32>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
     else if (b.N <= 48) hipLaunchKernelGGL(k_uv_column<48>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);
     else if (b.N <= ROMS_MAXN) hipLaunchKernelGGL(k_uv_column<ROMS_MAXN>, grid, block2d(), 0, g_ctx.stream, g_ctx.devc, s->nrhs, s->nnew, cff);

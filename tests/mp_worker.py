@@ -30,6 +30,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, perturb=1.0, v
         kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:                  # no periodic direction
         kw.setdefault("overrides", {})["EWperiodic"] = False
+    if "classic" in opts:                # without SPLINES_VVISC / SPLINES_VDIFF: the tridiagonal systems for u, v, t themselves
+        kw.setdefault("overrides", {}).update({"splines_vdiff": 0, "splines_vvisc": 0})
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)

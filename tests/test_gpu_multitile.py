@@ -42,6 +42,8 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {})["EWperiodic"] = False
     if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
         kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
+    if "classic" in opts:                # without SPLINES_VVISC / SPLINES_VDIFF: the tridiagonal systems for u, v, t themselves
+        kw.setdefault("overrides", {}).update({"splines_vdiff": 0, "splines_vvisc": 0})
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     st = ana.make_tile(config, perturb=1.0, **kw)
@@ -83,6 +85,8 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "BENCHMARK_TINY", "river+mpdata+basin+mask"),
                                                     (2, 2, "UPWELLING", "river+wells+basin+mask"), (2, 2, "BENCHMARK_TINY", "river+wells+mpdata"),
                                                     (2, 2, "UPWELLING", "river+wells+wet+basin+mask"),
+                                                    # without SPLINES_VVISC / SPLINES_VDIFF
+                                                    (2, 2, "UPWELLING", "classic+river+wells+basin+mask"), (2, 1, "BENCHMARK_TINY", "classic+physics"),
                                                     # BASELINE.json configurations 4 and 5 at FULL size (2048x256x30): the
                                                     # 512-column tiles of the 8-GPU run (4x1), both tile rows (2x2), the
                                                     # deferred-flux step2d path and, with six MPDATA tracers, three ghost points

@@ -37,6 +37,8 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {}).update({"ts_dif4": 1, "uv_vis4": 1, "tnu4": 1.0e10, "visc4": 2.0e10})
     if "basin" in opts:                  # no periodic direction
         kw.setdefault("overrides", {})["EWperiodic"] = False
+    if "classic" in opts:                # without SPLINES_VVISC / SPLINES_VDIFF: the tridiagonal systems for u, v, t themselves
+        kw.setdefault("overrides", {}).update({"splines_vdiff": 0, "splines_vvisc": 0})
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
@@ -77,7 +79,9 @@ def _single(config, nsteps, variant=""):
                                                     (2, 2, "BENCHMARK_TINY", "river+mpdata+basin+mask"),
                                                     # ... and cell-centred sources (LwSrc) beside them
                                                     (2, 2, "UPWELLING", "river+wells+basin+mask"), (2, 2, "BENCHMARK_TINY", "river+wells+mpdata"),
-                                                    (2, 2, "UPWELLING", "river+wells+wet+basin+mask")])
+                                                    (2, 2, "UPWELLING", "river+wells+wet+basin+mask"),
+                                                    # without SPLINES_VVISC / SPLINES_VDIFF
+                                                    (2, 2, "UPWELLING", "classic+river+wells+basin+mask"), (2, 1, "BENCHMARK_TINY", "classic")])
 def test_tiled_equals_single(tmp_path, ntI, ntJ, config, variant):
     nsteps = 3
     world = ntI * ntJ
