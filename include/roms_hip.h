@@ -173,7 +173,11 @@ typedef struct roms_params {
    * KANTHA_CLAYSON, CANUTO_A, CANUTO_B); gls_n2s2_horavg = N2S2_HORAVG; gls_ri_splines = RI_SPLINES (the shear from
    * parabolic splines); the third-order upstream advection of tke / gls (neither K_C2ADVECTION nor K_C4ADVECTION).
    * CRAIG_BANNER, CHARNOK, ZOS_HSIG, TKE_WAVEDISS are not built.  Akk_bak, Akp_bak: background diffusivities of
-   * tke and gls; Zos: surface roughness (m), mod_scalars.F. */
+   * tke and gls; Zos: surface roughness (m), mod_scalars.F.
+   * gls_mixing = 2: MY25_MIXING instead -- the same two entries are then my25_prestep (my25_prestep.F:23, the text of
+   * gls_prestep.F) and my25_corstep (my25_corstep.F:27; tke = q2, gls = q2l; Galperin et al. stability functions, Sm
+   * of Kantha and Clayson with gls_stability = GLS_KANTHA_CLAYSON; N2S2_HORAVG, RI_SPLINES as above).  Of the
+   * parameters only gls_Kmin, gls_Pmin (initial values) and Akk_bak are read; Akp and ZoBot are not used. */
   int    gls_mixing, gls_stability, gls_n2s2_horavg, gls_ri_splines;
   double gls_p, gls_m, gls_n, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp, gls_Kmin, gls_Pmin;
   double Akk_bak, Akp_bak, Zos;
@@ -316,7 +320,10 @@ int roms_hip_ana_srflux(double yday, double hour);
 /* gls_prestep(ng,tile)             ROMS/Nonlinear/gls_prestep.F:23   (main3d.F:567, after rhs3d)
  * gls_corstep(ng,tile)             ROMS/Nonlinear/gls_corstep.F:27   (main3d.F:793, after omega and before step3d_t)
  * with tkebc_tile (tkebc_im.F:50: closed and gradient edges).  GLS_MIXING applications only: these two replace
- * lmd_vmix as the source of Akv / Akt. */
+ * lmd_vmix as the source of Akv / Akt.
+ * my25_prestep(ng,tile)            ROMS/Nonlinear/my25_prestep.F:23  (main3d.F:565)
+ * my25_corstep(ng,tile)            ROMS/Nonlinear/my25_corstep.F:27  (main3d.F:791)
+ * MY25_MIXING applications bind the same two entries with roms_params_t.gls_mixing = 2. */
 int roms_hip_gls_prestep(const roms_step_idx_t *s);
 int roms_hip_gls_corstep(const roms_step_idx_t *s);
 /* wetdry(ng,tile,Tindex,.TRUE.)    ROMS/Nonlinear/wetdry.F:17 -> wetdry_ini_tile (:395): the initial wet/dry masks

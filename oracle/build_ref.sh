@@ -20,6 +20,7 @@
 #                                 UPWELLING_MASK_RAD2D, BENCHMARK_RAD2D (+ -DRADIATION_2D); UPWELLING_GLS, UPWELLING_MASK_GLS
 #                                 (GLS_MIXING + KANTHA_CLAYSON + N2S2_HORAVG + RI_SPLINES instead of ANA_VMIX), BENCHMARK_GLS
 #                                 (GLS_MIXING + CANUTO_A instead of the KPP block): gls_prestep.F, gls_corstep.F, tkebc_im.F;
+#                                 UPWELLING_MY25, UPWELLING_MASK_MY25, BENCHMARK_MY25 (MY25_MIXING: my25_prestep.F, my25_corstep.F);
 #                                 UPWELLING_ATM[_PG31|_PJ] (+ -DATM_PRESS: the air-pressure term of the three pressure-gradient files);
 #                                 UPWELLING_MASK_WET[_DIF4|_ISO|_PG31], BENCHMARK_MASK_WET (+ -DWET_DRY; PJ_GRADP with WET_DRY does not
 #                                 compile in the reference itself: prsgrd40.h:98-100 passes umask_wet, vmask_wet without declaring them);
@@ -50,7 +51,7 @@ FILES="Modules/mod_kinds Modules/mod_param Modules/mod_strings Modules/mod_iouni
  Nonlinear/zetabc Nonlinear/u2dbc_im Nonlinear/v2dbc_im Nonlinear/u3dbc_im Nonlinear/v3dbc_im Nonlinear/t3dbc_im
  Nonlinear/ini_fields
  Nonlinear/bc_3d Utility/shapiro Nonlinear/lmd_swfrac Nonlinear/lmd_skpp Nonlinear/lmd_vmix
- Nonlinear/tkebc_im Nonlinear/gls_prestep Nonlinear/gls_corstep
+ Nonlinear/tkebc_im Nonlinear/gls_prestep Nonlinear/gls_corstep Nonlinear/my25_prestep Nonlinear/my25_corstep
 
  Utility/stats Functionals/analytical Nonlinear/wvelocity Nonlinear/diag Utility/set_scoord Utility/metrics"
 
@@ -79,7 +80,7 @@ build_app () {
   case $TAG in *_MINSTRAT*) XDEF="$XDEF -DTS_MIX_MIN_STRAT";; esac
   case $TAG in *_LIMBS) XDEF="$XDEF -DLIMIT_BSTRESS";; esac
   case $TAG in *_EMP) XDEF="$XDEF -DEMINUSP";; esac              # BENCHMARK[_MASK]_EMP: + EMINUSP (bulk_flux.F:883-899)      # <APP>_LIMBS: + LIMIT_BSTRESS (set_vbc.F:533-567)
-  case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_PJ) VAR=pj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; *_LOGDRAG) VAR=logdrag; WDEF="-DREF_LOGDRAG";; *_GLS) VAR=gls; WDEF="-DREF_GLS";; esac
+  case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_PJ) VAR=pj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; *_LOGDRAG) VAR=logdrag; WDEF="-DREF_LOGDRAG";; *_GLS) VAR=gls; WDEF="-DREF_GLS";; *_MY25) VAR=my25; WDEF="-DREF_GLS -DREF_MY25";; esac
   local hdr=$(echo $APP | tr A-Z a-z).h
   # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
   [ "$APP" = UPWELLING ] && hdr=upwelling_$VAR.h
@@ -87,6 +88,9 @@ build_app () {
   [ "$APP" = SEAMOUNT ] && hdr=seamount_$VAR.h
   # BENCHMARK_GLS: benchmark.h with the KPP block replaced by GLS_MIXING + CANUTO_A (ref_headers/benchmark_gls.h)
   [ "$APP" = BENCHMARK ] && [ "$VAR" = gls ] && hdr=benchmark_gls.h
+  # <APP>[_MASK]_MY25: MY25_MIXING instead (ref_headers/upwelling_my25.h: + KANTHA_CLAYSON + N2S2_HORAVG + RI_SPLINES;
+  # benchmark_my25.h: the plain closure with the Galperin functions): my25_prestep.F, my25_corstep.F, tkebc_im.F
+  [ "$APP" = BENCHMARK ] && [ "$VAR" = my25 ] && hdr=benchmark_my25.h
   local D=$OUT/$TAG
   if [ -f $D/libref.so ] && [ $D/libref.so -nt $HERE/ref_wrap.F90 ] && [ $D/libref.so -nt $HERE/build_ref.sh ]; then
     return 0
@@ -114,7 +118,7 @@ build_app () {
   echo "[$TAG] built $D/libref.so"
 }
 
-for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ UPWELLING_RAD2D UPWELLING_MASK_RAD2D BENCHMARK_RAD2D UPWELLING_LIMBS BENCHMARK_LIMBS BENCHMARK_EMP BENCHMARK_MASK_EMP UPWELLING_GLS UPWELLING_MASK_GLS BENCHMARK_GLS UPWELLING_MASK_WET BENCHMARK_MASK_WET UPWELLING_MASK_WET_DIF4 UPWELLING_MASK_WET_ISO UPWELLING_MASK_WET_PG31 UPWELLING_ATM UPWELLING_ATM_PG31 UPWELLING_ATM_PJ UPWELLING_ATM_PC UPWELLING_STAB_DIF4 SEAMOUNT_STAB_DIF4 UPWELLING_STAB_ISO SEAMOUNT_STAB_ISO UPWELLING_MINSTRAT_ISO SEAMOUNT_MINSTRAT_ISO}; do
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ UPWELLING_RAD2D UPWELLING_MASK_RAD2D BENCHMARK_RAD2D UPWELLING_LIMBS BENCHMARK_LIMBS BENCHMARK_EMP BENCHMARK_MASK_EMP UPWELLING_GLS UPWELLING_MASK_GLS BENCHMARK_GLS UPWELLING_MY25 UPWELLING_MASK_MY25 BENCHMARK_MY25 UPWELLING_MASK_WET BENCHMARK_MASK_WET UPWELLING_MASK_WET_DIF4 UPWELLING_MASK_WET_ISO UPWELLING_MASK_WET_PG31 UPWELLING_ATM UPWELLING_ATM_PG31 UPWELLING_ATM_PJ UPWELLING_ATM_PC UPWELLING_STAB_DIF4 SEAMOUNT_STAB_DIF4 UPWELLING_STAB_ISO SEAMOUNT_STAB_ISO UPWELLING_MINSTRAT_ISO SEAMOUNT_MINSTRAT_ISO}; do
   build_app $app &
 done
 wait

@@ -291,6 +291,7 @@ int oracle_gls_corstep(OARGS)
   const double vonKar = 0.41;
   const double Gadv = 1.0 / 3.0, eps = 1.0E-10;
   const gls_const_t K = gls_constants(p->gls_stability);
+  const int my25 = (p->gls_mixing == 2);      /* MY25_MIXING: my25_corstep.F (the same routine up to the vertical terms) */
   const double gls_p = p->gls_p, gls_m = p->gls_m, gls_n = p->gls_n, gls_cmu0 = p->gls_cmu0;
   const double gls_c1 = p->gls_c1, gls_c2 = p->gls_c2, gls_c3m = p->gls_c3m, gls_c3p = p->gls_c3p;
   const double gls_sigk = p->gls_sigk, gls_sigp = p->gls_sigp, gls_Kmin = p->gls_Kmin, gls_Pmin = p->gls_Pmin;
@@ -460,9 +461,9 @@ int oracle_gls_corstep(OARGS)
       for (int i = Istr; i <= Iend; i++) {
         cff = dt * pm(i, j) * pn(i, j);
         tke(i, j, k, nnew) = tke(i, j, k, nnew) - cff * (FXK(i + 1, j) - FXK(i, j) + FEK(i, j + 1) - FEK(i, j));
-        tke(i, j, k, nnew) = MAX(tke(i, j, k, nnew), gls_Kmin);
+        if (!my25) tke(i, j, k, nnew) = MAX(tke(i, j, k, nnew), gls_Kmin);       /* my25_corstep.F:511-514 has no floor */
         gls(i, j, k, nnew) = gls(i, j, k, nnew) - cff * (FXP(i + 1, j) - FXP(i, j) + FEP(i, j + 1) - FEP(i, j));
-        gls(i, j, k, nnew) = MAX(gls(i, j, k, nnew), gls_Pmin);
+        if (!my25) gls(i, j, k, nnew) = MAX(gls(i, j, k, nnew), gls_Pmin);
       }
   }
   for (int j = Jstr; j <= Jend; j++) {
@@ -490,10 +491,94 @@ int oracle_gls_corstep(OARGS)
       for (int i = Istr; i <= Iend; i++) {
         cff = dt * pm(i, j) * pn(i, j);
         tke(i, j, k, nnew) = tke(i, j, k, nnew) - cff * (FCK(i, k + 1) - FCK(i, k));
-        tke(i, j, k, nnew) = MAX(tke(i, j, k, nnew), gls_Kmin);
+        if (!my25) tke(i, j, k, nnew) = MAX(tke(i, j, k, nnew), gls_Kmin);       /* my25_corstep.F:569-576 */
         gls(i, j, k, nnew) = gls(i, j, k, nnew) - cff * (FCP(i, k + 1) - FCP(i, k));
-        gls(i, j, k, nnew) = MAX(gls(i, j, k, nnew), gls_Pmin);
+        if (!my25) gls(i, j, k, nnew) = MAX(gls(i, j, k, nnew), gls_Pmin);
       }
+    if (my25) {
+      /* MY25_MIXING: my25_corstep.F:580-770 (Mellor and Yamada 1982 level 2.5 with the Galperin et al. 1988 stability
+       * functions; tke = q2, gls = q2l) */
+      const double my_B1 = 16.6, my_E1 = 1.8, my_E2 = 1.33, my_Gh0 = 0.0233, my_Sq = 0.2, my_lmax = 0.53, my_qmin = 1.0E-8;
+      const double my_B1p2o3 = pow(my_B1, 2.0 / 3.0);
+      cff = -0.5 * dt;
+      for (int k = 1; k <= N; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          FCK(i, k) = cff * (Akk(i, j, k) + Akk(i, j, k - 1)) / Hz(i, j, k);
+          CF(i, k) = 0.0;
+        }
+      cff3 = my_E2 / (vonKar * vonKar);
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          double strat2;
+          if ((buoy2(i, j, k) > -5.0E-5) && (buoy2(i, j, k) < 0.0)) strat2 = 0.0;
+          else strat2 = buoy2(i, j, k);
+          const double Qprod = shear2(i, j, k) * (Akv(i, j, k) - Akv_bak) - strat2 * (Akt(i, j, k, itemp) - p->Akt_bak[itemp - 1]);
+          const double Ls_unlmt = MAX(eps, gls(i, j, k, nstp) / (MAX(tke(i, j, k, nstp), eps)));
+          cff1 = 0.5 * (Hz(i, j, k) + Hz(i, j, k + 1));
+          tke(i, j, k, nnew) = tke(i, j, k, nnew) + dt * cff1 * Qprod * 2.0;
+          gls(i, j, k, nnew) = gls(i, j, k, nnew) + dt * cff1 * Qprod * my_E1 * Ls_unlmt;
+          const double Qdiss = dt * sqrt(tke(i, j, k, nstp)) / (my_B1 * Ls_unlmt);
+          cff = Ls_unlmt * (1.0 / (z_w(i, j, N) - z_w(i, j, k)) + 1.0 / (z_w(i, j, k) - z_w(i, j, 0)));
+          const double Wscale = 1.0 + cff3 * cff * cff;
+          BCK(i, k) = cff1 * (1.0 + 2.0 * Qdiss) - FCK(i, k) - FCK(i, k + 1);
+          BCP(i, k) = cff1 * (1.0 + Wscale * Qdiss) - FCK(i, k) - FCK(i, k + 1);
+        }
+      for (int i = Istr; i <= Iend; i++) {
+        const double sx = sustr(i, j) + sustr(i + 1, j), sy = svstr(i, j) + svstr(i, j + 1);
+        tke(i, j, N, nnew) = my_B1p2o3 * 0.5 * sqrt(sx * sx + sy * sy);
+        gls(i, j, N, nnew) = 0.0;
+        const double bx = bustr(i, j) + bustr(i + 1, j), by = bvstr(i, j) + bvstr(i, j + 1);
+        tke(i, j, 0, nnew) = my_B1p2o3 * 0.5 * sqrt(bx * bx + by * by);
+        gls(i, j, 0, nnew) = 0.0;
+      }
+      /* the two tridiagonal systems, eliminated from the top (:649-692) */
+      for (int i = Istr; i <= Iend; i++) {
+        cff = 1.0 / BCK(i, N - 1);
+        CF(i, N - 1) = cff * FCK(i, N - 1);
+        tke(i, j, N - 1, nnew) = cff * (tke(i, j, N - 1, nnew) - FCK(i, N) * tke(i, j, N, nnew));
+      }
+      for (int k = N - 2; k >= 1; k--)
+        for (int i = Istr; i <= Iend; i++) {
+          cff = 1.0 / (BCK(i, k) - CF(i, k + 1) * FCK(i, k + 1));
+          CF(i, k) = cff * FCK(i, k);
+          tke(i, j, k, nnew) = cff * (tke(i, j, k, nnew) - FCK(i, k + 1) * tke(i, j, k + 1, nnew));
+        }
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = Istr; i <= Iend; i++) tke(i, j, k, nnew) = tke(i, j, k, nnew) - CF(i, k) * tke(i, j, k - 1, nnew);
+      for (int i = Istr; i <= Iend; i++) {
+        cff = 1.0 / BCP(i, N - 1);
+        CF(i, N - 1) = cff * FCK(i, N - 1);
+        gls(i, j, N - 1, nnew) = cff * (gls(i, j, N - 1, nnew) - FCK(i, N) * gls(i, j, N, nnew));
+      }
+      for (int k = N - 2; k >= 1; k--)
+        for (int i = Istr; i <= Iend; i++) {
+          cff = 1.0 / (BCP(i, k) - CF(i, k + 1) * FCK(i, k + 1));
+          CF(i, k) = cff * FCK(i, k);
+          gls(i, j, k, nnew) = cff * (gls(i, j, k, nnew) - FCK(i, k + 1) * gls(i, j, k + 1, nnew));
+        }
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = Istr; i <= Iend; i++) gls(i, j, k, nnew) = gls(i, j, k, nnew) - CF(i, k) * gls(i, j, k - 1, nnew);
+      /* mixing coefficients (:699-770) */
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          tke(i, j, k, nnew) = MAX(tke(i, j, k, nnew), my_qmin);
+          gls(i, j, k, nnew) = MAX(gls(i, j, k, nnew), my_qmin);
+          const double Ls_unlmt = gls(i, j, k, nnew) / tke(i, j, k, nnew);
+          const double Ls_lmt = MIN(Ls_unlmt, my_lmax * sqrt(tke(i, j, k, nnew) / (MAX(0.0, buoy2(i, j, k)) + eps)));
+          const double Gh = MIN(my_Gh0, -buoy2(i, j, k) * Ls_lmt * Ls_lmt / tke(i, j, k, nnew));
+          cff = 1.0 - K.my_Sh2 * Gh;
+          const double Sh = K.my_Sh1 / cff;
+          double Sm;
+          if (p->gls_stability == GLS_KANTHA_CLAYSON) Sm = (K.my_B1pm1o3 + Sh * Gh * K.my_Sm4) / (1.0 - K.my_Sm2 * Gh);
+          else Sm = (K.my_Sm3 + Sh * Gh * K.my_Sm4) / (1.0 - K.my_Sm2 * Gh);
+          const double ql = 0.5 * (Ls_lmt * sqrt(tke(i, j, k, nnew)) + Lscale(i, j, k) * sqrt(tke(i, j, k, nstp)));
+          Akv(i, j, k) = Akv_bak + ql * Sm;
+          for (int itrc = 1; itrc <= NAT; itrc++) Akt(i, j, k, itrc) = p->Akt_bak[itrc - 1] + ql * Sh;
+          Akk(i, j, k) = Akk_bak + ql * my_Sq;
+          Lscale(i, j, k) = Ls_lmt;
+        }
+      continue;
+    }
     /* vertical mixing, production, dissipation (:706-800) */
     cff = -0.5 * dt;
     for (int i = Istr; i <= Iend; i++) {

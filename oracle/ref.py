@@ -46,7 +46,9 @@ class Ref:
             app += "_LIMBS"                                                # built with -DLIMIT_BSTRESS
         if state.p.radiation_2d:
             app += "_RAD2D"                                                # built with -DRADIATION_2D
-        if state.p.gls_mixing:
+        if state.p.gls_mixing == 2:
+            app += "_MY25"                                                 # MY25_MIXING builds (ref_headers/*_my25.h)
+        elif state.p.gls_mixing:
             app += "_GLS"                                                  # GLS_MIXING builds (ref_headers/*_gls.h)
         self.l = C.CDLL(lib_path(app))
         self.st = state

@@ -1132,7 +1132,8 @@ END FUNCTION ref_bc
 !  (gls_prestep.F:23), 2 = gls_corstep (gls_corstep.F:27), as main3d.F:567 / :793 call them.  The closure
 !  parameters of roms_*.in (GLS_P ... GLS_SIGP, AKK_BAK, AKP_BAK, ZOS) come from the params block; the stability
 !  constants are what initialize_scalars (ref_setup) computed.  LBC(:,isMtke,ng) = the tracers' table (closed or
-!  gradient: tkebc_im.F treats both alike).
+!  gradient: tkebc_im.F treats both alike).  With -DREF_MY25 as well (the _my25 headers of ref_headers) the two kernels are
+!  my25_prestep (my25_prestep.F:23) and my25_corstep (my25_corstep.F:27); MIXING(ng)%Akp does not exist then.
 #ifdef REF_GLS
 FUNCTION ref_gls (kernel, b, p, s, F) BIND(C, name='ref_gls') RESULT(rc)
   USE ref_wrap_types
@@ -1145,8 +1146,13 @@ FUNCTION ref_gls (kernel, b, p, s, F) BIND(C, name='ref_gls') RESULT(rc)
   USE mod_mixing
   USE mod_forces
   USE mod_boundary, ONLY : allocate_boundary
+# ifdef REF_MY25
+  USE my25_prestep_mod, ONLY : my25_prestep
+  USE my25_corstep_mod, ONLY : my25_corstep
+# else
   USE gls_prestep_mod, ONLY : gls_prestep
   USE gls_corstep_mod, ONLY : gls_corstep
+# endif
   INTEGER(c_int), VALUE :: kernel
   TYPE(bounds_t), INTENT(in) :: b
   TYPE(params_t), INTENT(in) :: p
@@ -1199,7 +1205,9 @@ FUNCTION ref_gls (kernel, b, p, s, F) BIND(C, name='ref_gls') RESULT(rc)
   CALL c_f_pointer (F%Hvom, a3, (/ni,nj,NN/));  GRID(ng)%Hvom = a3
   CALL c_f_pointer (F%z_r, a3, (/ni,nj,NN/));   GRID(ng)%z_r = a3
   CALL c_f_pointer (F%z_w, a3, (/ni,nj,NN+1/)); GRID(ng)%z_w = a3
+# ifndef REF_MY25
   CALL c_f_pointer (F%ZoBot, a2, (/ni,nj/));    GRID(ng)%ZoBot = a2
+# endif
 #ifdef MASKING
   CALL c_f_pointer (F%rmask, a2, (/ni,nj/));    GRID(ng)%rmask = a2
   CALL c_f_pointer (F%umask, a2, (/ni,nj/));    GRID(ng)%umask = a2
@@ -1223,13 +1231,20 @@ FUNCTION ref_gls (kernel, b, p, s, F) BIND(C, name='ref_gls') RESULT(rc)
   CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); MIXING(ng)%Akv = a3
   CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/)); MIXING(ng)%Akt = a4
   CALL c_f_pointer (F%Akk, a3, (/ni,nj,NN+1/)); MIXING(ng)%Akk = a3
+# ifndef REF_MY25
   CALL c_f_pointer (F%Akp, a3, (/ni,nj,NN+1/)); MIXING(ng)%Akp = a3
+# endif
   CALL c_f_pointer (F%Lscale, a3, (/ni,nj,NN+1/)); MIXING(ng)%Lscale = a3
   CALL c_f_pointer (F%tke, a4, (/ni,nj,NN+1,3/)); MIXING(ng)%tke = a4
   CALL c_f_pointer (F%gls, a4, (/ni,nj,NN+1,3/)); MIXING(ng)%gls = a4
   SELECT CASE (kernel)
+# ifdef REF_MY25
+  CASE (1); CALL my25_prestep (ng, tile)
+  CASE (2); CALL my25_corstep (ng, tile)
+# else
   CASE (1); CALL gls_prestep (ng, tile)
   CASE (2); CALL gls_corstep (ng, tile)
+# endif
   CASE DEFAULT; rc = 2
   END SELECT
   CALL c_f_pointer (F%tke, a4, (/ni,nj,NN+1,3/)); a4 = MIXING(ng)%tke
@@ -1237,7 +1252,9 @@ FUNCTION ref_gls (kernel, b, p, s, F) BIND(C, name='ref_gls') RESULT(rc)
   CALL c_f_pointer (F%Akv, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akv
   CALL c_f_pointer (F%Akt, a4, (/ni,nj,NN+1,INT(b%NAT)/)); a4 = MIXING(ng)%Akt
   CALL c_f_pointer (F%Akk, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akk
+# ifndef REF_MY25
   CALL c_f_pointer (F%Akp, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Akp
+# endif
   CALL c_f_pointer (F%Lscale, a3, (/ni,nj,NN+1/)); a3 = MIXING(ng)%Lscale
 END FUNCTION ref_gls
 #endif

@@ -220,8 +220,10 @@ def make_params(cfg, NT):
     p.blk_ZQ = p.blk_ZT = p.blk_ZW = 10.0       # roms_*.in:382-384
     # GLS_MIXING: cfg["gls"] = one of the parameter sets of roms_*.in (roms_upwelling.in:352-364, :1862-1874);
     # cfg["gls_stability"] = GALPERIN | KANTHA_CLAYSON | CANUTO_A | CANUTO_B (the CPP choice of the application)
+    # cfg["gls"] = "my25": MY25_MIXING instead (my25_prestep.F / my25_corstep.F: tke = q2, gls = q2l; of the closure's
+    # input parameters only gls_Kmin / gls_Pmin -- the initial values, mod_mixing.F:1464-1473 -- and Akk_bak are read)
     if cfg.get("gls"):
-        p.gls_mixing = 1
+        p.gls_mixing = 2 if cfg["gls"] == "my25" else 1
         (p.gls_p, p.gls_m, p.gls_n, p.gls_Kmin, p.gls_Pmin, p.gls_cmu0, p.gls_c1, p.gls_c2, p.gls_c3m, p.gls_c3p,
          p.gls_sigk, p.gls_sigp) = GLS_SETS[cfg["gls"]]
         p.gls_stability = abi.GLS_STAB[cfg.get("gls_stability", "KANTHA_CLAYSON")]
@@ -246,6 +248,7 @@ GLS_SETS = {
     "k-epsilon": (3.0, 1.5, -1.0, 7.6e-6, 1.0e-12, 0.5477, 1.44, 1.92, -0.4, 1.0, 1.0, 1.30),
     "k-omega":   (-1.0, 0.5, -1.0, 7.6e-6, 1.0e-12, 0.5477, 0.555, 0.833, -0.6, 1.0, 2.0, 2.0),
     "gen":       (2.0, 1.0, -0.67, 1.0e-8, 1.0e-8, 0.5544, 1.0, 1.22, 0.1, 1.0, 0.8, 1.07),
+    "my25":      (0.0, 1.0, 1.0, 5.0e-6, 5.0e-6, 0.5544, 0.9, 0.52, 2.5, 1.0, 1.96, 1.96),      # MY25_MIXING: the k-kl line of roms_*.in
 }
 
 

@@ -523,8 +523,9 @@ static int library_default(int id, double *value)
     *value = 1.0; return !p.masking;
   case FID_visc4_p: case FID_visc4_r: *value = 0.0; return !p.uv_vis4;
   case FID_diff4: *value = 0.0; return !p.ts_dif4;
-  case FID_ZoBot: *value = 1.0; return p.uv_drag != 3 && !p.gls_mixing;
-  case FID_tke: case FID_gls: case FID_Lscale: case FID_Akk: case FID_Akp: *value = 0.0; return !p.gls_mixing;
+  case FID_ZoBot: *value = 1.0; return p.uv_drag != 3 && p.gls_mixing != 1;      /* MY25_MIXING (2) does not read it */
+  case FID_Akp: *value = 0.0; return p.gls_mixing != 1;                               /* GLS_MIXING only, mod_mixing.F:245 */
+  case FID_tke: case FID_gls: case FID_Lscale: case FID_Akk: *value = 0.0; return !p.gls_mixing;
   case FID_pmask_wet: case FID_rmask_wet: case FID_umask_wet: case FID_vmask_wet: case FID_rmask_wet_avg:
   case FID_pmask_full: case FID_rmask_full: case FID_umask_full: case FID_vmask_full: *value = 1.0; return !p.wet_dry;
   default: return 0;

@@ -8,6 +8,9 @@
 //                          advection of tke / gls, production and dissipation, the two implicit vertical diffusion
 //                          solves, length-scale limitation, the stability functions (Galperin, Kantha-Clayson,
 //                          Canuto A / B) and Akv, Akt, Akk, Akp, Lscale
+//                          With roms_params_t.gls_mixing = 2 (MY25_MIXING) the same two entries are my25_prestep.F (the same
+//                          text as gls_prestep.F) and my25_corstep.F:96-894: no floors in the advection, the level-2.5
+//                          production / dissipation / wall-proximity terms and the Galperin stability functions
 //   tkebc_tile             ROMS/Nonlinear/tkebc_im.F:50-698, closed and gradient edges and the corners
 //
 // One thread per water column (64 x 4 columns per workgroup, i fastest), levels in a loop: the closure is a per-column
@@ -25,7 +28,7 @@ namespace {
 struct GlsConst {            // initialize_scalars, mod_scalars.F:1686-1712, :1756-1768, :4450-4490
   double Gh0, Ghcri, Ghmin, E2;
   double s0, s1, s2, s4, s5, s6, b0, b1, b2, b3, b4, b5;
-  double my_Sh1, my_Sh2, my_Sm2, my_Sm3, my_Sm4, my_B1pm1o3;
+  double my_Sh1, my_Sh2, my_Sm2, my_Sm3, my_Sm4, my_B1pm1o3, my_B1p2o3;
 };
 
 GlsConst gls_constants(int stab)
@@ -56,6 +59,7 @@ GlsConst gls_constants(int stab)
   }
   const double A1 = 0.92, A2 = 0.74, B1 = 16.6, B2 = 10.1, C1 = 0.08, C2 = 0.7, C3 = 0.2;
   c.my_B1pm1o3 = 1.0 / pow(B1, 1.0 / 3.0);
+  c.my_B1p2o3 = pow(B1, 2.0 / 3.0);
   c.my_Sm2 = 9.0 * A1 * A2;
   c.my_Sh1 = A2 * (1.0 - 6.0 * A1 / B1);
   if (stab == GLS_KANTHA_CLAYSON) {
@@ -353,6 +357,7 @@ k_gls_corstep(const RomsDev *__restrict__ c, GlsArgs A)
   const double dt = p.dt;
   const double vonKar = 0.41, Gadv = 1.0 / 3.0, eps = 1.0E-10;
   const bool mk = p.masking != 0;
+  const bool my25 = p.gls_mixing == 2;       // MY25_MIXING: my25_corstep.F, the same routine up to the vertical terms
   const double gls_p = p.gls_p, gls_m = p.gls_m, gls_n = p.gls_n, gls_cmu0 = p.gls_cmu0;
   const double gls_c1 = p.gls_c1, gls_c2 = p.gls_c2, gls_sigk = p.gls_sigk, gls_sigp = p.gls_sigp;
   const double gls_Kmin = p.gls_Kmin, gls_Pmin = p.gls_Pmin;
@@ -432,9 +437,9 @@ k_gls_corstep(const RomsDev *__restrict__ c, GlsArgs A)
     fx(i, FXK0, FXP0); fx(i + 1, FXK1, FXP1);
     fe(j, FEK0, FEP0); fe(j + 1, FEK1, FEP1);
     double tv = Tn[a2 + wk] - cdt * (FXK1 - FXK0 + FEK1 - FEK0);
-    tv = fmax(tv, gls_Kmin);
+    if (!my25) tv = fmax(tv, gls_Kmin);                  // my25_corstep.F:511-514 has no floor
     double gv = Gn[a2 + wk] - cdt * (FXP1 - FXP0 + FEP1 - FEP0);
-    gv = fmax(gv, gls_Pmin);
+    if (!my25) gv = fmax(gv, gls_Pmin);
     Tn[a2 + wk] = tv;
     Gn[a2 + wk] = gv;
   }
@@ -462,13 +467,102 @@ k_gls_corstep(const RomsDev *__restrict__ c, GlsArgs A)
       double FKhi, FPhi;
       vflux(k + 1, FKhi, FPhi);
       double tv = Tn[a2 + wk] - cdt * (FKhi - FKlo);
-      tv = fmax(tv, gls_Kmin);
+      if (!my25) tv = fmax(tv, gls_Kmin);                // my25_corstep.F:569-576
       double gv = Gn[a2 + wk] - cdt * (FPhi - FPlo);
-      gv = fmax(gv, gls_Pmin);
+      if (!my25) gv = fmax(gv, gls_Pmin);
       Tn[a2 + wk] = tv;
       Gn[a2 + wk] = gv;
       FKlo = FKhi; FPlo = FPhi;
     }
+  }
+  if (my25) {
+    // ---- MY25_MIXING, my25_corstep.F:580-770: Mellor and Yamada (1982) level 2.5 with the Galperin et al. (1988)
+    //      stability functions (Kantha and Clayson's Sm under KANTHA_CLAYSON); tke = q2, gls = q2l
+    const double my_B1 = 16.6, my_E1 = 1.8, my_E2 = 1.33, my_Gh0 = 0.0233, my_Sq = 0.2, my_lmax = 0.53, my_qmin = 1.0E-8;
+    const double *Ts = tke + Ls, *Gs = gls + Ls;
+    const long wN = a2 + (long)N * nij, w0 = a2;
+    {
+      const double cff = -0.5 * dt;
+      for (int k = 1; k <= N; k++) {
+        const long w = a2 + (long)k * nij, r = a2 + (long)(k - 1) * nij;
+        A.FCK[w] = cff * (Akk[w] + Akk[w - nij]) / Hz[r];
+      }
+    }
+    const double cff3 = my_E2 / (vonKar * vonKar);
+    const double zN = z_w[wN], z0 = z_w[w0];
+    for (int k = 1; k <= N - 1; k++) {
+      const long w = a2 + (long)k * nij, r = a2 + (long)(k - 1) * nij;
+      const double bu = A.BU[w];
+      const double strat2 = ((bu > -5.0E-5) && (bu < 0.0)) ? 0.0 : bu;
+      const double Qprod = A.SH[w] * (Akv[w] - Akv_bak) - strat2 * (Akt[w] - AktT_bak);
+      const double Ls_unlmt = fmax(eps, Gs[w] / (fmax(Ts[w], eps)));
+      const double cff1 = 0.5 * (Hz[r] + Hz[r + nij]);
+      Tn[w] = Tn[w] + dt * cff1 * Qprod * 2.0;
+      Gn[w] = Gn[w] + dt * cff1 * Qprod * my_E1 * Ls_unlmt;
+      const double Qdiss = dt * sqrt(Ts[w]) / (my_B1 * Ls_unlmt);
+      const double zk = z_w[w];
+      const double cff = Ls_unlmt * (1.0 / (zN - zk) + 1.0 / (zk - z0));
+      const double Wscale = 1.0 + cff3 * cff * cff;
+      const double FCKk = A.FCK[w], FCKk1 = A.FCK[w + nij];
+      A.BCK[w] = cff1 * (1.0 + 2.0 * Qdiss) - FCKk - FCKk1;
+      A.BCP[w] = cff1 * (1.0 + Wscale * Qdiss) - FCKk - FCKk1;
+    }
+    {
+      const double sx = c->F.sustr[a2] + c->F.sustr[a2 + 1], sy = c->F.svstr[a2] + c->F.svstr[a2 + ni];
+      const double bx = c->F.bustr[a2] + c->F.bustr[a2 + 1], by = c->F.bvstr[a2] + c->F.bvstr[a2 + ni];
+      Tn[wN] = K.my_B1p2o3 * 0.5 * sqrt(sx * sx + sy * sy);
+      Gn[wN] = 0.0;
+      Tn[w0] = K.my_B1p2o3 * 0.5 * sqrt(bx * bx + by * by);
+      Gn[w0] = 0.0;
+    }
+    // the two tridiagonal systems (:649-692): elimination from the top, substitution from the bottom
+    for (int sys = 0; sys < 2; sys++) {
+      double *X = sys == 0 ? Tn : Gn;
+      const double *BC = sys == 0 ? A.BCK : A.BCP;
+      const long wt = a2 + (long)(N - 1) * nij;
+      double cff = 1.0 / BC[wt];
+      double CFp = cff * A.FCK[wt];
+      A.CF[wt] = CFp;
+      double Xp = cff * (X[wt] - A.FCK[wN] * X[wN]);
+      X[wt] = Xp;
+      for (int k = N - 2; k >= 1; k--) {
+        const long w = a2 + (long)k * nij;
+        const double FCK1 = A.FCK[w + nij];
+        cff = 1.0 / (BC[w] - CFp * FCK1);
+        CFp = cff * A.FCK[w];
+        A.CF[w] = CFp;
+        Xp = cff * (X[w] - FCK1 * Xp);
+        X[w] = Xp;
+      }
+      double Xm = X[w0];
+      for (int k = 1; k <= N - 1; k++) {
+        const long w = a2 + (long)k * nij;
+        Xm = X[w] - A.CF[w] * Xm;
+        X[w] = Xm;
+      }
+    }
+    // mixing coefficients (:699-770)
+    for (int k = 1; k <= N - 1; k++) {
+      const long w = a2 + (long)k * nij;
+      const double tk = fmax(Tn[w], my_qmin), gk = fmax(Gn[w], my_qmin);
+      const double buoy2 = A.BU[w];
+      const double Ls_unlmt = gk / tk;
+      const double Ls_lmt = fmin(Ls_unlmt, my_lmax * sqrt(tk / (fmax(0.0, buoy2) + eps)));
+      const double Gh = fmin(my_Gh0, -buoy2 * Ls_lmt * Ls_lmt / tk);
+      const double cff = 1.0 - K.my_Sh2 * Gh;
+      const double Sh = K.my_Sh1 / cff;
+      double Sm;
+      if (p.gls_stability == GLS_KANTHA_CLAYSON) Sm = (K.my_B1pm1o3 + Sh * Gh * K.my_Sm4) / (1.0 - K.my_Sm2 * Gh);
+      else Sm = (K.my_Sm3 + Sh * Gh * K.my_Sm4) / (1.0 - K.my_Sm2 * Gh);
+      const double ql = 0.5 * (Ls_lmt * sqrt(tk) + Lscale[w] * sqrt(Ts[w]));
+      Tn[w] = tk;
+      Gn[w] = gk;
+      Akv[w] = Akv_bak + ql * Sm;
+      for (int it = 0; it < b.NAT; it++) Akt[w + (long)it * n3w] = p.Akt_bak[it] + ql * Sh;
+      Akk[w] = Akk_bak + ql * my_Sq;
+      Lscale[w] = Ls_lmt;
+    }
+    return;
   }
   // ---- vertical mixing terms, production, dissipation (:706-800)
   const double *Ts = tke + Ls, *Gs = gls + Ls;

@@ -60,21 +60,24 @@ def results(st, prefix):
     return out
 
 
-def child(config, mask):
+def child(config, mask, family="gls"):
+    """family "my25": the MY25_MIXING builds (oracle/_ref/UPWELLING_MY25, UPWELLING_MASK_MY25: KANTHA_CLAYSON +
+    N2S2_HORAVG + RI_SPLINES; BENCHMARK_MY25: the plain closure) -- my25_prestep.F, my25_corstep.F -> ref_my25_*.npz"""
     from oracle import ref
     out = {}
-    for gset in SETS:
+    for gset in (SETS if family == "gls" else ["my25"]):
         for kernel in KERNELS:
             st, s = prepare(config, gset, kernel, mask)
             ref.Ref(st).gls(kernel, s)
             out.update(results(st, f"{gset}/{kernel}"))
-    np.savez_compressed(os.path.join(HERE, f"ref_gls_{tag(config, mask)}.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, f"ref_{family}_{tag(config, mask)}.npz"), **out)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        child(sys.argv[1], None if sys.argv[2] == "-" else sys.argv[2])
+        child(sys.argv[1], None if sys.argv[2] == "-" else sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "gls")
     else:
-        for c, m in CASES:
-            subprocess.run([sys.executable, os.path.abspath(__file__), c, m or "-"], check=True)
-            print(tag(c, m), os.path.getsize(os.path.join(HERE, f"ref_gls_{tag(c, m)}.npz")) // 1024, "KiB")
+        for fam in ("gls", "my25"):
+            for c, m in CASES:
+                subprocess.run([sys.executable, os.path.abspath(__file__), c, m or "-", fam], check=True)
+                print(fam, tag(c, m), os.path.getsize(os.path.join(HERE, f"ref_{fam}_{tag(c, m)}.npz")) // 1024, "KiB")

@@ -34,6 +34,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
         kw.setdefault("overrides", {}).update({"splines_vdiff": 0, "splines_vvisc": 0})
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
+    if "my25" in opts:                   # MY25_MIXING (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
+        kw.setdefault("overrides", {})["gls"] = "my25"
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)
     if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
         import util

@@ -403,14 +403,14 @@ def test_hip_reproduces_reference_kpp_on_stratified_state(mask):
     _kpp_check(mask, run, 1e-10)
 
 
-def _gls_check(config, mask, backend, tol):
+def _gls_check(config, mask, backend, tol, family="gls"):
     import sys
     gd = os.path.join(HERE, "golden")
     if gd not in sys.path:
         sys.path.insert(0, gd)
     import make_golden_gls as mg
-    g = np.load(os.path.join(gd, f"ref_gls_{mg.tag(config, mask)}.npz"))
-    for gset in mg.SETS:
+    g = np.load(os.path.join(gd, f"ref_{family}_{mg.tag(config, mask)}.npz"))
+    for gset in (mg.SETS if family == "gls" else ["my25"]):
         for kernel in mg.KERNELS:
             st, s = mg.prepare(config, gset, kernel, mask)
             st0 = st.copy()
@@ -423,7 +423,7 @@ def _gls_check(config, mask, backend, tol):
                 else:
                     scale = max(float(np.abs(want).max()), 1e-300)
                     assert float(np.abs(v - want).max()) <= tol * scale, (k, float(np.abs(v - want).max()) / scale)
-            changed = ["tke", "gls"] if kernel == "gls_prestep" else mg.NAMES
+            changed = ["tke", "gls"] if kernel == "gls_prestep" else [n for n in mg.NAMES if family == "gls" or n != "Akp"]
             assert all(not np.array_equal(st[n], st0[n]) for n in changed), (gset, kernel)
 
 
@@ -437,6 +437,15 @@ def test_oracle_reproduces_reference_gls(config, mask):
     this host (same libm)."""
     import oracle
     _gls_check(config, mask, lambda st, k, s: oracle.Oracle(st).call(k, s), 0.0)
+
+
+@pytest.mark.parametrize("config,mask", GLS_CASES)
+def test_oracle_reproduces_reference_my25(config, mask):
+    """my25_prestep / my25_corstep of the reference's MY25_MIXING builds (Kantha-Clayson with N2S2_HORAVG and RI_SPLINES,
+    with and without MASKING; the plain closure with the Galperin functions and the plain shear) vs the oracle
+    (gls_mixing = 2): bit for bit on this host."""
+    import oracle
+    _gls_check(config, mask, lambda st, k, s: oracle.Oracle(st).call(k, s), 0.0, family="my25")
 
 
 @pytest.mark.gpu
@@ -454,6 +463,7 @@ def test_hip_reproduces_reference_gls(config, mask):
         finally:
             h.close()
     _gls_check(config, mask, run, 1e-10)
+    _gls_check(config, mask, run, 1e-10, family="my25")          # MY25_MIXING: the my25_prestep / my25_corstep vectors
 
 
 @pytest.mark.parametrize("config,mask", [("UPWELLING", None), ("UPWELLING", "island"), ("BENCHMARK_TINY", None)])

@@ -24,7 +24,7 @@ def _hz_weight(st, s):
 
 @pytest.mark.parametrize("config,mask,basin", [("UPWELLING", None, False), ("UPWELLING", "island", False),
                                                ("UPWELLING", None, True), ("BENCHMARK_TINY", None, False)])
-@pytest.mark.parametrize("gset", ["k-epsilon", "k-kl", "k-omega", "gen"])
+@pytest.mark.parametrize("gset", ["k-epsilon", "k-kl", "k-omega", "gen", "my25"])      # my25: MY25_MIXING (gls_mixing = 2)
 @pytest.mark.parametrize("kernel", ["gls_prestep", "gls_corstep"])
 def test_gls_kernels_vs_oracle(config, mask, basin, gset, kernel):
     import oracle
@@ -45,7 +45,7 @@ def test_gls_kernels_vs_oracle(config, mask, basin, gset, kernel):
             scale = max(float(np.abs(st_o[n]).max()), 1e-300)
             d = float(np.abs(st_h[n] - st_o[n]).max()) / scale
             assert d <= TOL, (n, iic, d)
-        changed = ["tke", "gls"] if kernel == "gls_prestep" else NAMES
+        changed = ["tke", "gls"] if kernel == "gls_prestep" else [n for n in NAMES if gset != "my25" or n != "Akp"]
         assert all(not np.array_equal(st_o[n], st0[n]) for n in changed)
 
 
@@ -72,7 +72,8 @@ def test_gls_other_options_vs_oracle(extra):
 
 
 @pytest.mark.parametrize("config,gset,stab", [("UPWELLING", "k-epsilon", "KANTHA_CLAYSON"), ("UPWELLING", "k-kl", "KANTHA_CLAYSON"),
-                                              ("BENCHMARK_TINY", "gen", "CANUTO_A")])
+                                              ("BENCHMARK_TINY", "gen", "CANUTO_A"),
+                                              ("UPWELLING", "my25", "KANTHA_CLAYSON"), ("BENCHMARK_TINY", "my25", "GALPERIN")])
 def test_100_steps_with_gls(config, gset, stab):
     """The whole step with the closure in it (main3d.F:567, :793): 100 steps, north-star bound 1e-10 relative RMS on
     the prognostic fields and the same bound on tke, gls, Akv."""

@@ -46,6 +46,8 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {}).update({"splines_vdiff": 0, "splines_vvisc": 0})
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
+    if "my25" in opts:                   # MY25_MIXING (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
+        kw.setdefault("overrides", {})["gls"] = "my25"
     st = ana.make_tile(config, perturb=1.0, **kw)
     if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
         util.river_sources(st, "all" if "wells" in opts else "both" if "mask" in opts else "walls")
@@ -75,6 +77,7 @@ def _single(config, nsteps, variant=""):
                                                     # the GLS closure: smoothed shear, five-point advection of tke / gls and
                                                     # the Akv / Akt edge rule of gls_corstep.F across tile edges
                                                     (2, 2, "UPWELLING", "gls"), (2, 1, "BENCHMARK_TINY", "gls+basin+mask"),
+                                                    (2, 2, "UPWELLING", "my25"), (1, 2, "BENCHMARK_TINY", "my25+basin+mask"),
                                                     # WET_DRY: masks, their fast-time sum and the drying shoreline across
                                                     # tile edges
                                                     (2, 2, "UPWELLING", "wet"), (2, 2, "UPWELLING", "wet+basin+mask"),

@@ -41,6 +41,8 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {}).update({"splines_vdiff": 0, "splines_vvisc": 0})
     if "gls" in opts:                    # GLS_MIXING (k-epsilon, Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
+    if "my25" in opts:                   # MY25_MIXING (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
+        kw.setdefault("overrides", {})["gls"] = "my25"
     if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
         kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
     st = ana.make_tile(config, perturb=1.0, **kw)
@@ -67,6 +69,7 @@ def _single(config, nsteps, variant=""):
                                                     # the GLS closure across tile edges (smoothed shear, five-point advection of
                                                     # tke / gls, the Akv / Akt edge rule of gls_corstep.F)
                                                     (2, 2, "UPWELLING", "gls"), (2, 1, "BENCHMARK_TINY", "gls+basin+mask"),
+                                                    (2, 2, "UPWELLING", "my25"), (1, 2, "BENCHMARK_TINY", "my25+basin+mask"),
                                                     # WET_DRY: the wet/dry masks, their fast-time sum and the drying
                                                     # shoreline across tile edges; with land and on a basin
                                                     (2, 2, "UPWELLING", "wet"), (2, 2, "UPWELLING", "wet+basin+mask"),

@@ -171,6 +171,10 @@ GLS_BUILDS = {   # the CPP choices of the two GLS reference builds (oracle/ref_h
     "UPWELLING": dict(gls_stability="KANTHA_CLAYSON", gls_n2s2_horavg=1, gls_ri_splines=1),
     "BENCHMARK": dict(gls_stability="CANUTO_A", gls_n2s2_horavg=0, gls_ri_splines=0),
 }
+MY25_BUILDS = {  # ... and of the MY25_MIXING builds (upwelling_my25.h, benchmark_my25.h)
+    "UPWELLING": dict(gls_stability="KANTHA_CLAYSON", gls_n2s2_horavg=1, gls_ri_splines=1),
+    "BENCHMARK": dict(gls_stability="GALPERIN", gls_n2s2_horavg=0, gls_ri_splines=0),
+}
 
 
 def gls_state(config, gls="k-epsilon", mask=None, basin=False, extra=None):
@@ -180,7 +184,7 @@ def gls_state(config, gls="k-epsilon", mask=None, basin=False, extra=None):
     left it (prepared_state)."""
     import oracle
     from roms_trunk_mgh_amd import ana as _ana
-    ov = dict(GLS_BUILDS[_ana.CONFIGS[config]["app"]], gls=gls)
+    ov = dict((MY25_BUILDS if gls == "my25" else GLS_BUILDS)[_ana.CONFIGS[config]["app"]], gls=gls)
     if basin:
         ov["EWperiodic"] = False
     if extra:
