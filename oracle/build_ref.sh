@@ -21,6 +21,8 @@
 #                                 (GLS_MIXING + KANTHA_CLAYSON + N2S2_HORAVG + RI_SPLINES instead of ANA_VMIX), BENCHMARK_GLS
 #                                 (GLS_MIXING + CANUTO_A instead of the KPP block): gls_prestep.F, gls_corstep.F, tkebc_im.F;
 #                                 UPWELLING_MY25, UPWELLING_MASK_MY25, BENCHMARK_MY25 (MY25_MIXING: my25_prestep.F, my25_corstep.F);
+#                                 UPWELLING_GEOUV, SEAMOUNT_GEOUV, UPWELLING_MASK_GEOUV, UPWELLING_MASK_WET_GEOUV (MIX_GEO_UV instead of
+#                                 MIX_S_UV: uv3dmix2_geo.h);
 #                                 UPWELLING_ATM[_PG31|_PJ] (+ -DATM_PRESS: the air-pressure term of the three pressure-gradient files);
 #                                 UPWELLING_MASK_WET[_DIF4|_ISO|_PG31], BENCHMARK_MASK_WET (+ -DWET_DRY; PJ_GRADP with WET_DRY does not
 #                                 compile in the reference itself: prsgrd40.h:98-100 passes umask_wet, vmask_wet without declaring them);
@@ -80,7 +82,7 @@ build_app () {
   case $TAG in *_MINSTRAT*) XDEF="$XDEF -DTS_MIX_MIN_STRAT";; esac
   case $TAG in *_LIMBS) XDEF="$XDEF -DLIMIT_BSTRESS";; esac
   case $TAG in *_EMP) XDEF="$XDEF -DEMINUSP";; esac              # BENCHMARK[_MASK]_EMP: + EMINUSP (bulk_flux.F:883-899)      # <APP>_LIMBS: + LIMIT_BSTRESS (set_vbc.F:533-567)
-  case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_PJ) VAR=pj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; *_LOGDRAG) VAR=logdrag; WDEF="-DREF_LOGDRAG";; *_GLS) VAR=gls; WDEF="-DREF_GLS";; *_MY25) VAR=my25; WDEF="-DREF_GLS -DREF_MY25";; esac
+  case $TAG in *_PG31) VAR=pg31;; *_WJ) VAR=wj;; *_PJ) VAR=pj;; *_DIF4) VAR=dif4; WDEF="-DREF_DIF4";; *_ISO) VAR=iso; WDEF="-DREF_DIF4";; *_LOGDRAG) VAR=logdrag; WDEF="-DREF_LOGDRAG";; *_GLS) VAR=gls; WDEF="-DREF_GLS";; *_MY25) VAR=my25; WDEF="-DREF_GLS -DREF_MY25";; *_GEOUV) VAR=geouv; WDEF="-DREF_GEOUV";; esac
   local hdr=$(echo $APP | tr A-Z a-z).h
   # UPWELLING: same numerics, output-side options off (see ref_headers/upwelling_nodiag.h)
   [ "$APP" = UPWELLING ] && hdr=upwelling_$VAR.h
@@ -118,7 +120,7 @@ build_app () {
   echo "[$TAG] built $D/libref.so"
 }
 
-for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ UPWELLING_RAD2D UPWELLING_MASK_RAD2D BENCHMARK_RAD2D UPWELLING_LIMBS BENCHMARK_LIMBS BENCHMARK_EMP BENCHMARK_MASK_EMP UPWELLING_GLS UPWELLING_MASK_GLS BENCHMARK_GLS UPWELLING_MY25 UPWELLING_MASK_MY25 BENCHMARK_MY25 UPWELLING_MASK_WET BENCHMARK_MASK_WET UPWELLING_MASK_WET_DIF4 UPWELLING_MASK_WET_ISO UPWELLING_MASK_WET_PG31 UPWELLING_ATM UPWELLING_ATM_PG31 UPWELLING_ATM_PJ UPWELLING_ATM_PC UPWELLING_STAB_DIF4 SEAMOUNT_STAB_DIF4 UPWELLING_STAB_ISO SEAMOUNT_STAB_ISO UPWELLING_MINSTRAT_ISO SEAMOUNT_MINSTRAT_ISO}; do
+for app in ${APPS:-BENCHMARK UPWELLING SEAMOUNT BENCHMARK_MASK UPWELLING_MASK UPWELLING_PG31 UPWELLING_WJ SEAMOUNT_PG31 SEAMOUNT_WJ UPWELLING_DIF4 SEAMOUNT_DIF4 UPWELLING_MASK_DIF4 UPWELLING_ISO SEAMOUNT_ISO UPWELLING_MASK_ISO UPWELLING_LOGDRAG UPWELLING_PJ SEAMOUNT_PJ UPWELLING_RAD2D UPWELLING_MASK_RAD2D BENCHMARK_RAD2D UPWELLING_LIMBS BENCHMARK_LIMBS BENCHMARK_EMP BENCHMARK_MASK_EMP UPWELLING_GLS UPWELLING_MASK_GLS BENCHMARK_GLS UPWELLING_MY25 UPWELLING_MASK_MY25 BENCHMARK_MY25 UPWELLING_GEOUV SEAMOUNT_GEOUV UPWELLING_MASK_GEOUV UPWELLING_MASK_WET_GEOUV UPWELLING_MASK_WET BENCHMARK_MASK_WET UPWELLING_MASK_WET_DIF4 UPWELLING_MASK_WET_ISO UPWELLING_MASK_WET_PG31 UPWELLING_ATM UPWELLING_ATM_PG31 UPWELLING_ATM_PJ UPWELLING_ATM_PC UPWELLING_STAB_DIF4 SEAMOUNT_STAB_DIF4 UPWELLING_STAB_ISO SEAMOUNT_STAB_ISO UPWELLING_MINSTRAT_ISO SEAMOUNT_MINSTRAT_ISO}; do
   build_app $app &
 done
 wait

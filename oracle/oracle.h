@@ -213,6 +213,7 @@ int oracle_uv3dmix4(OARGS);
 int oracle_t3dmix2_iso(OARGS);
 int oracle_rhs3d_tile(OARGS);
 int oracle_uv3dmix2(OARGS);
+int oracle_uv3dmix2_geo(OARGS);      /* uv3dmix2_geo.h (uv_vis2 = 2: MIX_GEO_UV) */
 int oracle_rhs3d(OARGS);
 int oracle_step2d(OARGS);
 int oracle_step3d_uv(OARGS);

@@ -175,6 +175,7 @@ int oracle_t3dmix2(OARGS)
 
 int oracle_uv3dmix2(OARGS)
 {
+  if (p->uv_vis2 == 2) return oracle_uv3dmix2_geo(b, p, s, F);     /* MIX_GEO_UV: oracle_uvmix_geo.c */
   ORACLE_PROLOGUE
   const int nrhs = s->nrhs, nnew = s->nnew;
   const double dt = p->dt;

@@ -46,6 +46,8 @@ class Ref:
             app += "_LIMBS"                                                # built with -DLIMIT_BSTRESS
         if state.p.radiation_2d:
             app += "_RAD2D"                                                # built with -DRADIATION_2D
+        if state.p.uv_vis2 == 2:
+            app += "_GEOUV"                                                # MIX_GEO_UV instead of MIX_S_UV (uv3dmix2_geo.h)
         if state.p.gls_mixing == 2:
             app += "_MY25"                                                 # MY25_MIXING builds (ref_headers/*_my25.h)
         elif state.p.gls_mixing:

@@ -341,7 +341,7 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   CALL c_f_pointer (F%rvfrc, a2, (/ni,nj/));    COUPLING(ng)%rvfrc = a2
   CALL c_f_pointer (F%rhoA, a2, (/ni,nj/));     COUPLING(ng)%rhoA = a2
   CALL c_f_pointer (F%rhoS, a2, (/ni,nj/));     COUPLING(ng)%rhoS = a2
-#if defined BENCHMARK || defined UPWELLING
+#if defined BENCHMARK || defined UPWELLING || defined REF_GEOUV
   CALL c_f_pointer (F%visc2_p, a2, (/ni,nj/));  MIXING(ng)%visc2_p = a2
   CALL c_f_pointer (F%visc2_r, a2, (/ni,nj/));  MIXING(ng)%visc2_r = a2
 #endif
@@ -392,7 +392,7 @@ FUNCTION ref_call (kernel, b, p, s, F) BIND(C, name='ref_call') RESULT(rc)
   CASE (4); CALL rho_eos (ng, tile, iNLM)
   CASE (5); CALL prsgrd (ng, tile)
   CASE (6); CALL t3dmix2 (ng, tile)
-#if defined BENCHMARK || defined UPWELLING
+#if defined BENCHMARK || defined UPWELLING || defined REF_GEOUV
   CASE (7); CALL uv3dmix2 (ng, tile)
 #endif
 #ifdef REF_DIF4

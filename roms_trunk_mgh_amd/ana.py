@@ -192,7 +192,7 @@ def make_params(cfg, NT):
     p.nonlin_eos = int(app == "BENCHMARK")
     # option switches of the application headers (ROMS/Include/{benchmark,upwelling,seamount}.h)
     p.uv_adv, p.uv_cor = 1, 1
-    p.uv_vis2 = int(app in ("BENCHMARK", "UPWELLING"))
+    p.uv_vis2 = int(cfg.get("uv_vis2", app in ("BENCHMARK", "UPWELLING")))     # 2 = UV_VIS2 with MIX_GEO_UV (uv3dmix2_geo.h) instead of MIX_S_UV
     p.curvgrid = int(app == "BENCHMARK")
     p.var_rho_2d = 1                      # globaldefs.h:491-495, always with SOLVE3D
     p.ts_dif2 = int(cfg.get("ts_dif2", 1))

@@ -720,3 +720,51 @@ def test_hip_reproduces_reference_ts_mix_stability():
         finally:
             h.close()
     _stab_check(run, 1e-13)
+
+
+def _geouv_check(case, backend, tol):
+    import sys
+    gd = os.path.join(HERE, "golden")
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    import make_golden_geouv as mg
+    g = np.load(os.path.join(gd, "ref_geouv.npz"))
+    st, s = mg.prepare(case)
+    st0 = st.copy()
+    backend(st, s)
+    for k, v in mg.results(st, s, case).items():
+        want = g[k]
+        if k.endswith("_sha256"):
+            if tol == 0.0:
+                assert str(v) == str(want), k
+        else:
+            scale = max(float(np.abs(want).max()), 1e-300)
+            assert float(np.abs(v - want).max()) <= tol * scale, (k, float(np.abs(v - want).max()) / scale)
+    assert all(not np.array_equal(st[n], st0[n]) for n in mg.NAMES), case
+
+
+GEOUV_CASES = ["channel", "seamount", "island", "island_wet"]
+
+
+@pytest.mark.parametrize("case", GEOUV_CASES)
+def test_oracle_reproduces_reference_uv3dmix2_geo(case):
+    """uv3dmix2_geo.h (UV_VIS2 with MIX_GEO_UV, uv_vis2 = 2) of the reference built with the option
+    (tests/golden/make_golden_geouv.py: channel, seamount, island grid, island grid with WET_DRY) vs the oracle: bit for bit."""
+    import oracle
+    _geouv_check(case, lambda st, s: oracle.Oracle(st).call("uv3dmix2", s), 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GEOUV_CASES)
+def test_hip_reproduces_reference_uv3dmix2_geo(case):
+    """k_uv3dmix2_geo against the reference's vectors directly (same operations in the same order: 1e-13)."""
+    from roms_trunk_mgh_amd import hip
+
+    def run(st, s):
+        h = hip.RomsHip(st)
+        try:
+            h.call("uv3dmix2", s)
+            h.to_host()
+        finally:
+            h.close()
+    _geouv_check(case, run, 1e-13)

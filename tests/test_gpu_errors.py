@@ -69,21 +69,6 @@ def test_unsupported_advection_pair_is_refused_and_library_stays_usable():
     assert np.array_equal(st_h["W"], st_o["W"])
 
 
-def test_non_spline_implicit_operators_are_refused():
-    """SPLINES_VDIFF / SPLINES_VVISC off: the reference then uses the classic tridiagonal operators
-    (step3d_uv.F:399-460, step3d_t.F:1431-1501), which are not restated -- an error, not another answer."""
-    for field, kernel in (("splines_vvisc", "step3d_uv"), ("splines_vdiff", "step3d_t")):
-        st = ana.make_tile("UPWELLING", perturb=1.0)
-        setattr(st.p, field, 0)
-        h = hip.RomsHip(st)
-        try:
-            with pytest.raises(RuntimeError) as e:
-                h.call(kernel, util.step_idx())
-            assert "spline-form" in str(e.value)
-        finally:
-            h.close()
-
-
 def test_snapshot_of_unknown_field_and_double_begin_are_refused():
     st = ana.make_tile("UPWELLING", perturb=1.0)
     h = hip.RomsHip(st)
