@@ -1,6 +1,6 @@
 // k_uv3dmix2.hip -- harmonic horizontal viscosity along s-surfaces,
 // uv3dmix2_s_tile (ROMS/Nonlinear/uv3dmix2_s.h:114-335); also accumulates
-// rufrc, rvfrc.  And the biharmonic one, uv3dmix4_s_tile (uv3dmix4_s.h:120-629): the first operator without the
+// rufrc, rvfrc.  Rotated to geopotentials (MIX_GEO_UV): k_uv3dmix2_geo below.  And the biharmonic one, uv3dmix4_s_tile (uv3dmix4_s.h:120-629): the first operator without the
 // layer thickness (k_uv4_first -> LapU, LapV on a range one point wider), its rule outside physical edges and at the
 // corners (k_uv4_edges, k_uv4_corners), then the harmonic kernel itself on LapU, LapV with visc4 and the sign reversed.
 //
@@ -331,6 +331,266 @@ k2d_visc4_second(const RomsDev *__restrict__ c, int krhs, Uv4 A, double *__restr
   }
 }
 
+// ---- uv3dmix2_geo_tile (ROMS/Nonlinear/uv3dmix2_geo.h:116-756; UV_VIS2 with MIX_GEO_UV, roms_params_t.uv_vis2 = 2):
+// harmonic viscosity rotated to geopotential surfaces.  The reference marches k over two-level slabs of fourteen
+// private arrays; here a workgroup owns BLK_X x BLK_Y columns and keeps the slabs of its patch (own points plus one
+// ring) in LDS, marching k upward: the slopes of z_r at u- and v-faces (their averages to rho- and psi-points, the
+// reference's dZdx_r/_p, dZde_r/_p, are formed where they are used: the same 0.5*(a + b)), the four horizontal
+// gradients, the two vertical ones, and the four horizontal fluxes of the level.  The vertical fluxes UFsx, UFse,
+// VFsx, VFse are only ever read at the point that made them and wait in registers.  Every value is the reference's
+// expression in the reference's order, evaluated on the reference's ranges for the patch taken as a tile, so the
+// result does not depend on the partition (workgroups or tiles).  Two barriers per level.
+__device__ __forceinline__ double gmin0(double a) { return a < 0.0 ? a : 0.0; }   // MIN(a, 0)
+__device__ __forceinline__ double gmax0(double a) { return a > 0.0 ? a : 0.0; }   // MAX(a, 0)
+#define GEO_W (BLK_X + 2)
+#define GEO_H (BLK_Y + 2)
+#define GEO_P (GEO_W * GEO_H)
+__global__ void __launch_bounds__(BLK_X *BLK_Y)
+k_uv3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
+{
+  DEV_PROLOGUE(c)
+  __shared__ double sUFx[GEO_P], sVFe[GEO_P], sUFe[GEO_P], sVFx[GEO_P];            // fluxes of the level
+  __shared__ double sSx[2][GEO_P], sSe[2][GEO_P];                                  // slopes at u- / v-faces
+  __shared__ double sdnUdx[2][GEO_P], sdmUde[2][GEO_P], sdnVdx[2][GEO_P], sdmVde[2][GEO_P];
+  __shared__ double sdUdz[2][GEO_P], sdVdz[2][GEO_P];
+  const Blk XB = xcd_block();
+  const int i0 = b.Istr + XB.x * BLK_X, j0 = b.Jstr + XB.y * BLK_Y;
+  // the patch as a tile
+  const int Istr = i0, Iend = (i0 + BLK_X - 1 < b.Iend) ? i0 + BLK_X - 1 : b.Iend;
+  const int Jstr = j0, Jend = (j0 + BLK_Y - 1 < b.Jend) ? j0 + BLK_Y - 1 : b.Jend;
+  const int IstrU = i0 > b.IstrU ? i0 : b.IstrU, JstrV = j0 > b.JstrV ? j0 : b.JstrV;
+  const int tid = threadIdx.y * BLK_X + threadIdx.x;
+  const bool msk = c->p.masking != 0;
+  const double dt = c->p.dt;
+  const gcd_t u = (gcd_t)(c->F.u + (long)(nrhs - 1) * n3r), v = (gcd_t)(c->F.v + (long)(nrhs - 1) * n3r);
+  const gd_t un = (gd_t)(c->F.u + (long)(nnew - 1) * n3r), vn = (gd_t)(c->F.v + (long)(nnew - 1) * n3r);
+  const gcd_t z_r = (gcd_t)c->F.z_r, Hz = (gcd_t)c->F.Hz, pm = (gcd_t)c->F.pm, pn = (gcd_t)c->F.pn;
+  const gcd_t on_r = (gcd_t)c->F.on_r, om_r = (gcd_t)c->F.om_r, on_p = (gcd_t)c->F.on_p, om_p = (gcd_t)c->F.om_p;
+  const gcd_t visc2_r = (gcd_t)c->F.visc2_r, visc2_p = (gcd_t)c->F.visc2_p;
+#define GL(i, j) (((j) - (j0 - 1)) * GEO_W + ((i) - (i0 - 1)))
+#define dZdx_p(i, j, s) (0.5 * (sSx[s][GL(i, (j) - 1)] + sSx[s][GL(i, j)]))
+#define dZde_p(i, j, s) (0.5 * (sSe[s][GL((i) - 1, j)] + sSe[s][GL(i, j)]))
+#define dZdx_r(i, j, s) (0.5 * (sSx[s][GL(i, j)] + sSx[s][GL((i) + 1, j)]))
+#define dZde_r(i, j, s) (0.5 * (sSe[s][GL(i, j)] + sSe[s][GL(i, (j) + 1)]))
+#define dnUdx(i, j, s) sdnUdx[s][GL(i, j)]
+#define dmUde(i, j, s) sdmUde[s][GL(i, j)]
+#define dnVdx(i, j, s) sdnVdx[s][GL(i, j)]
+#define dmVde(i, j, s) sdmVde[s][GL(i, j)]
+#define dUdz(i, j, s) sdUdz[s][GL(i, j)]
+#define dVdz(i, j, s) sdVdz[s][GL(i, j)]
+#define UFx(i, j) sUFx[GL(i, j)]
+#define VFe(i, j) sVFe[GL(i, j)]
+#define UFe(i, j) sUFe[GL(i, j)]
+#define VFx(i, j) sVFx[GL(i, j)]
+  // the thread's own column
+  const int io = i0 + (int)threadIdx.x, jo = j0 + (int)threadIdx.y;
+  const bool own = io <= Iend && jo <= Jend;
+  const bool do_u = own && io >= IstrU, do_v = own && jo >= JstrV;
+  double UFsx1 = 0.0, UFse1 = 0.0, VFsx1 = 0.0, VFse1 = 0.0;        // the k1 level of the vertical fluxes
+  double ruf = 0.0, rvf = 0.0;
+  const long ao = own ? I2(io, jo) : 0;
+  if (do_u) ruf = c->F.rufrc[ao];
+  if (do_v) rvf = c->F.rvfrc[ao];
+  int k1, k2 = 1;
+  for (int k = 0; k <= N; k++) {
+    k1 = k2;
+    k2 = 1 - k1;
+    // ---- phase 1: everything of level k+1 that depends on the fields alone -> slot k2
+    for (int q = tid; q < GEO_P; q += BLK_X * BLK_Y) {
+      const int i = i0 - 1 + q % GEO_W, j = j0 - 1 + q / GEO_W;
+      const long a = I2(i, j);
+      const bool inU = i >= IstrU - 1 && i <= Iend + 1 && j >= Jstr - 1 && j <= Jend + 1;     // u-face range
+      const bool inV = i >= Istr - 1 && i <= Iend + 1 && j >= JstrV - 1 && j <= Jend + 1;     // v-face range
+      const bool inR = i >= IstrU - 1 && i <= Iend && j >= JstrV - 1 && j <= Jend;            // rho range
+      const bool inP = i >= Istr && i <= Iend + 1 && j >= Jstr && j <= Jend + 1;              // psi range
+      if (k < N) {
+        const long ak = a + (long)k * nij;                                                    // level k+1
+        if (inU) {                                                                            // :303-340
+          double cff = 0.5 * (pm[a - 1] + pm[a]);
+          if (msk) cff = cff * umaskw(c, a);
+          sSx[k2][q] = cff * (z_r[ak] - z_r[ak - 1]);
+        }
+        if (inV) {
+          double cff = 0.5 * (pn[a - ni] + pn[a]);
+          if (msk) cff = cff * vmaskw(c, a);
+          sSe[k2][q] = cff * (z_r[ak] - z_r[ak - ni]);
+        }
+        if (inR) {                                                                            // :345-412
+          double cff = 0.5 * pm[a];
+          if (msk) cff = cff * rmaskw(c, a);
+          sdnUdx[k2][q] = cff * ((pn[a] + pn[a + 1]) * u[ak + 1] - (pn[a - 1] + pn[a]) * u[ak]);
+          cff = 0.5 * pn[a];
+          if (msk) cff = cff * rmaskw(c, a);
+          sdmVde[k2][q] = cff * ((pm[a] + pm[a + ni]) * v[ak + ni] - (pm[a - ni] + pm[a]) * v[ak]);
+        }
+        if (inP) {
+          double cff = 0.125 * (pn[a - 1] + pn[a] + pn[a - 1 - ni] + pn[a - ni]);
+          if (msk) cff = cff * pmaskw(c, a);
+          sdmUde[k2][q] = cff * ((pm[a - 1] + pm[a]) * u[ak] - (pm[a - 1 - ni] + pm[a - ni]) * u[ak - ni]);
+          cff = 0.125 * (pm[a - 1] + pm[a] + pm[a - 1 - ni] + pm[a - ni]);
+          if (msk) cff = cff * pmaskw(c, a);
+          sdnVdx[k2][q] = cff * ((pn[a - ni] + pn[a]) * v[ak] - (pn[a - 1 - ni] + pn[a - 1]) * v[ak - 1]);
+        }
+      }
+      if (k == 0 || k == N) {                                                                 // :414-440
+        if (inU) sdUdz[k2][q] = 0.0;
+        if (inV) sdVdz[k2][q] = 0.0;
+      } else {
+        const long ak = a + (long)k * nij, al = ak - nij;                                     // levels k+1, k
+        if (inU) {
+          const double cff = 1.0 / (0.5 * (z_r[ak - 1] - z_r[al - 1] + z_r[ak] - z_r[al]));
+          sdUdz[k2][q] = cff * (u[ak] - u[al]);
+        }
+        if (inV) {
+          const double cff = 1.0 / (0.5 * (z_r[ak - ni] - z_r[al - ni] + z_r[ak] - z_r[al]));
+          sdVdz[k2][q] = cff * (v[ak] - v[al]);
+        }
+      }
+    }
+    __syncthreads();
+    double UFsx2 = 0.0, UFse2 = 0.0, VFsx2 = 0.0, VFse2 = 0.0;       // k == N: zero (:433-440)
+    if (k > 0) {
+      // ---- phase 2: the rotated horizontal fluxes of level k (:463-541)
+      for (int q = tid; q < GEO_P; q += BLK_X * BLK_Y) {
+        const int i = i0 - 1 + q % GEO_W, j = j0 - 1 + q / GEO_W;
+        const long a = I2(i, j), ak = a + (long)(k - 1) * nij;
+        if (i >= IstrU - 1 && i <= Iend && j >= JstrV - 1 && j <= Jend) {
+          const double zx = dZdx_r(i, j, k1), ze = dZde_r(i, j, k1);
+          const double cff1 = gmin0(zx), cff2 = gmax0(zx), cff3 = gmin0(ze), cff4 = gmax0(ze);
+          double cff = Hz[ak] *
+                (on_r[a] * (dnUdx(i, j, k1) - 0.5 * pn[a] * (cff1 * (dUdz(i, j, k1) + dUdz(i + 1, j, k2)) + cff2 * (dUdz(i, j, k2) + dUdz(i + 1, j, k1)))) -
+                 om_r[a] * (dmVde(i, j, k1) - 0.5 * pm[a] * (cff3 * (dVdz(i, j, k1) + dVdz(i, j + 1, k2)) + cff4 * (dVdz(i, j, k2) + dVdz(i, j + 1, k1)))));
+          if (msk) cff = cff * rmaskw(c, a);
+          sUFx[q] = on_r[a] * on_r[a] * visc2_r[a] * cff;
+          sVFe[q] = om_r[a] * om_r[a] * visc2_r[a] * cff;
+        }
+        if (i >= Istr && i <= Iend + 1 && j >= Jstr && j <= Jend + 1) {
+          const double pm_p = 0.25 * (pm[a - 1 - ni] + pm[a - 1] + pm[a - ni] + pm[a]);
+          const double pn_p = 0.25 * (pn[a - 1 - ni] + pn[a - 1] + pn[a - ni] + pn[a]);
+          const double zx = dZdx_p(i, j, k1), ze = dZde_p(i, j, k1);
+          const double cff1 = gmin0(zx), cff2 = gmax0(zx), cff3 = gmin0(ze), cff4 = gmax0(ze);
+          double cff = 0.25 * (Hz[ak - 1] + Hz[ak] + Hz[ak - 1 - ni] + Hz[ak - ni]) *
+                (on_p[a] * (dnVdx(i, j, k1) - 0.5 * pn_p * (cff1 * (dVdz(i - 1, j, k1) + dVdz(i, j, k2)) + cff2 * (dVdz(i - 1, j, k2) + dVdz(i, j, k1)))) +
+                 om_p[a] * (dmUde(i, j, k1) - 0.5 * pm_p * (cff3 * (dUdz(i, j - 1, k1) + dUdz(i, j, k2)) + cff4 * (dUdz(i, j - 1, k2) + dUdz(i, j, k1)))));
+          if (msk) cff = cff * pmaskw(c, a);
+          sUFe[q] = om_p[a] * om_p[a] * visc2_p[a] * cff;
+          sVFx[q] = on_p[a] * on_p[a] * visc2_p[a] * cff;
+        }
+      }
+      // ---- the vertical fluxes through the top of level k, at the thread's own faces (:546-700)
+      if (k < N) {
+        const int i = io, j = jo;
+        if (do_u) {
+          const long a = ao;
+          double cff = 0.25 * (visc2_r[a - 1] + visc2_r[a]);
+          const double fac1 = cff * c->F.on_u[a], fac2 = cff * c->F.om_u[a];
+          cff = 0.5 * (pn[a - 1] + pn[a]);
+          const double dnUdz = cff * dUdz(i, j, k2);
+          const double dnVdz = cff * 0.25 * (dVdz(i - 1, j + 1, k2) + dVdz(i, j + 1, k2) + dVdz(i - 1, j, k2) + dVdz(i, j, k2));
+          cff = 0.5 * (pm[a - 1] + pm[a]);
+          const double dmUdz = cff * dUdz(i, j, k2);
+          const double dmVdz = cff * 0.25 * (dVdz(i - 1, j + 1, k2) + dVdz(i, j + 1, k2) + dVdz(i - 1, j, k2) + dVdz(i, j, k2));
+          const double xr1 = gmin0(dZdx_r(i - 1, j, k1)), xr2 = gmin0(dZdx_r(i, j, k2));
+          const double xr3 = gmax0(dZdx_r(i - 1, j, k2)), xr4 = gmax0(dZdx_r(i, j, k1));
+          const double ep1 = gmin0(dZde_p(i, j, k1)), ep2 = gmin0(dZde_p(i, j + 1, k2));
+          const double ep3 = gmax0(dZde_p(i, j, k2)), ep4 = gmax0(dZde_p(i, j + 1, k1));
+          const double xp5 = gmin0(dZdx_p(i, j, k1)), xp6 = gmin0(dZdx_p(i, j + 1, k2));
+          const double xp7 = gmax0(dZdx_p(i, j, k2)), xp8 = gmax0(dZdx_p(i, j + 1, k1));
+          const double er5 = gmin0(dZde_r(i - 1, j, k1)), er6 = gmin0(dZde_r(i, j, k2));
+          const double er7 = gmax0(dZde_r(i - 1, j, k2)), er8 = gmax0(dZde_r(i, j, k1));
+          UFsx2 = fac1 * (xr1 * (xr1 * dnUdz - dnUdx(i - 1, j, k1)) + xr2 * (xr2 * dnUdz - dnUdx(i, j, k2)) +
+                          xr3 * (xr3 * dnUdz - dnUdx(i - 1, j, k2)) + xr4 * (xr4 * dnUdz - dnUdx(i, j, k1)));
+          UFse2 = fac2 * (ep1 * (ep1 * dmUdz - dmUde(i, j, k1)) + ep2 * (ep2 * dmUdz - dmUde(i, j + 1, k2)) +
+                          ep3 * (ep3 * dmUdz - dmUde(i, j, k2)) + ep4 * (ep4 * dmUdz - dmUde(i, j + 1, k1)));
+          UFsx2 = UFsx2 +
+                  fac1 * (ep1 * (xp5 * dnVdz - dnVdx(i, j, k1)) + ep2 * (xp6 * dnVdz - dnVdx(i, j + 1, k2)) +
+                          ep3 * (xp7 * dnVdz - dnVdx(i, j, k2)) + ep4 * (xp8 * dnVdz - dnVdx(i, j + 1, k1)));
+          UFse2 = UFse2 -
+                  fac2 * (xr1 * (er5 * dmVdz - dmVde(i - 1, j, k1)) + xr2 * (er6 * dmVdz - dmVde(i, j, k2)) +
+                          xr3 * (er7 * dmVdz - dmVde(i - 1, j, k2)) + xr4 * (er8 * dmVdz - dmVde(i, j, k1)));
+        }
+        if (do_v) {
+          const long a = ao;
+          double cff = 0.25 * (visc2_r[a - ni] + visc2_r[a]);
+          const double fac1 = cff * c->F.on_v[a], fac2 = cff * c->F.om_v[a];
+          cff = 0.5 * (pn[a - ni] + pn[a]);
+          const double dnUdz = cff * 0.25 * (dUdz(i, j, k2) + dUdz(i + 1, j, k2) + dUdz(i, j - 1, k2) + dUdz(i + 1, j - 1, k2));
+          const double dnVdz = cff * dVdz(i, j, k2);
+          cff = 0.5 * (pm[a - ni] + pm[a]);
+          const double dmUdz = cff * 0.25 * (dUdz(i, j, k2) + dUdz(i + 1, j, k2) + dUdz(i, j - 1, k2) + dUdz(i + 1, j - 1, k2));
+          const double dmVdz = cff * dVdz(i, j, k2);
+          const double xp1 = gmin0(dZdx_p(i, j, k1)), xp2 = gmin0(dZdx_p(i + 1, j, k2));
+          const double xp3 = gmax0(dZdx_p(i, j, k2)), xp4 = gmax0(dZdx_p(i + 1, j, k1));
+          const double er1 = gmin0(dZde_r(i, j - 1, k1)), er2 = gmin0(dZde_r(i, j, k2));
+          const double er3 = gmax0(dZde_r(i, j - 1, k2)), er4 = gmax0(dZde_r(i, j, k1));
+          const double xr5 = gmin0(dZdx_r(i, j - 1, k1)), xr6 = gmin0(dZdx_r(i, j, k2));
+          const double xr7 = gmax0(dZdx_r(i, j - 1, k2)), xr8 = gmax0(dZdx_r(i, j, k1));
+          const double ep5 = gmin0(dZde_p(i, j, k1)), ep6 = gmin0(dZde_p(i + 1, j, k2));
+          const double ep7 = gmax0(dZde_p(i, j, k2)), ep8 = gmax0(dZde_p(i + 1, j, k1));
+          VFsx2 = fac1 * (xp1 * (xp1 * dnVdz - dnVdx(i, j, k1)) + xp2 * (xp2 * dnVdz - dnVdx(i + 1, j, k2)) +
+                          xp3 * (xp3 * dnVdz - dnVdx(i, j, k2)) + xp4 * (xp4 * dnVdz - dnVdx(i + 1, j, k1)));
+          VFse2 = fac2 * (er1 * (er1 * dmVdz - dmVde(i, j - 1, k1)) + er2 * (er2 * dmVdz - dmVde(i, j, k2)) +
+                          er3 * (er3 * dmVdz - dmVde(i, j - 1, k2)) + er4 * (er4 * dmVdz - dmVde(i, j, k1)));
+          VFsx2 = VFsx2 -
+                  fac1 * (er1 * (xr5 * dnUdz - dnUdx(i, j - 1, k1)) + er2 * (xr6 * dnUdz - dnUdx(i, j, k2)) +
+                          er3 * (xr7 * dnUdz - dnUdx(i, j - 1, k2)) + er4 * (xr8 * dnUdz - dnUdx(i, j, k1)));
+          VFse2 = VFse2 +
+                  fac2 * (xp1 * (ep5 * dmUdz - dmUde(i, j, k1)) + xp2 * (ep6 * dmUdz - dmUde(i + 1, j, k2)) +
+                          xp3 * (ep7 * dmUdz - dmUde(i, j, k2)) + xp4 * (ep8 * dmUdz - dmUde(i + 1, j, k1)));
+        }
+      }
+    }
+    __syncthreads();
+    if (k > 0) {
+      // ---- phase 3: the time step of level k; momentum is Hz*u, Hz*v here (:710-752)
+      const int i = io, j = jo;
+      const long ak = ao + (long)(k - 1) * nij;
+      if (do_u) {
+        const long a = ao;
+        const double cff = dt * 0.25 * (pm[a - 1] + pm[a]) * (pn[a - 1] + pn[a]);
+        const double cff1 = 0.5 * (pn[a - 1] + pn[a]) * (UFx(i, j) - UFx(i - 1, j));
+        const double cff2 = 0.5 * (pm[a - 1] + pm[a]) * (UFe(i, j + 1) - UFe(i, j));
+        const double cff3 = UFsx2 - UFsx1;
+        const double cff4 = UFse2 - UFse1;
+        const double cff5 = cff * (cff1 + cff2);
+        const double cff6 = dt * (cff3 + cff4);
+        ruf = ruf + cff1 + cff2 + cff3 + cff4;
+        un[ak] = un[ak] + cff5 + cff6;
+      }
+      if (do_v) {
+        const long a = ao;
+        const double cff = dt * 0.25 * (pm[a] + pm[a - ni]) * (pn[a] + pn[a - ni]);
+        const double cff1 = 0.5 * (pn[a - ni] + pn[a]) * (VFx(i + 1, j) - VFx(i, j));
+        const double cff2 = 0.5 * (pm[a - ni] + pm[a]) * (VFe(i, j) - VFe(i, j - 1));
+        const double cff3 = VFsx2 - VFsx1;
+        const double cff4 = VFse2 - VFse1;
+        const double cff5 = cff * (cff1 - cff2);
+        const double cff6 = dt * (cff3 + cff4);
+        rvf = rvf + cff1 - cff2 + cff3 + cff4;
+        vn[ak] = vn[ak] + cff5 + cff6;
+      }
+    }
+    UFsx1 = UFsx2; UFse1 = UFse2; VFsx1 = VFsx2; VFse1 = VFse2;
+  }
+  if (do_u) c->F.rufrc[ao] = ruf;
+  if (do_v) c->F.rvfrc[ao] = rvf;
+#undef GL
+#undef dZdx_p
+#undef dZde_p
+#undef dZdx_r
+#undef dZde_r
+#undef dnUdx
+#undef dmUde
+#undef dnVdx
+#undef dmVde
+#undef dUdz
+#undef dVdz
+#undef UFx
+#undef VFe
+#undef UFe
+#undef VFx
+}
+
 }  // namespace
 
 // called by step2d_impl (k_step2d.hip) in front of the momentum kernel when UV_VIS4 is set
@@ -376,6 +636,12 @@ extern "C" int roms_hip_uv3dmix2(const roms_step_idx_t *s)
   if (rc) return rc;
   ScopedTimer tm("uv3dmix2");
   const roms_bounds_t &b = g_ctx.b;
+  if (g_ctx.p.uv_vis2 == 2) {                                     // MIX_GEO_UV
+    hipLaunchKernelGGL(k_uv3dmix2_geo, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
+                       g_ctx.devc, s->nrhs, s->nnew);
+    KERNEL_CHECK("k_uv3dmix2_geo");
+    return 0;
+  }
   hipLaunchKernelGGL(k_uv3dmix2_v2<false>, grid2d(b.Iend - b.Istr + 1, b.Jend - b.Jstr + 1), block2d(), 0, g_ctx.stream,
                      g_ctx.devc, s->nrhs, s->nnew, (const double *)nullptr, (const double *)nullptr);
   KERNEL_CHECK("k_uv3dmix2_v2");

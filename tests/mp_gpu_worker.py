@@ -36,6 +36,8 @@ def run_rank(rank, world, ntI, ntJ, config, nsteps, port, outdir, variant=""):
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     if "my25" in opts:                   # MY25_MIXING (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "my25"
+    if "geouv" in opts:                  # UV_VIS2 with MIX_GEO_UV (uv3dmix2_geo.h)
+        kw.setdefault("overrides", {}).update({"uv_vis2": 2, **({"visc2": 50.0} if config == "SEAMOUNT" else {})})
     st = ana.make_tile(config, ntileI=ntI, ntileJ=ntJ, tile=rank, perturb=1.0, **kw)
     if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
         import util

@@ -48,6 +48,8 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     if "my25" in opts:                   # MY25_MIXING (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "my25"
+    if "geouv" in opts:                  # UV_VIS2 with MIX_GEO_UV (uv3dmix2_geo.h)
+        kw.setdefault("overrides", {}).update({"uv_vis2": 2, **({"visc2": 50.0} if config == "SEAMOUNT" else {})})
     st = ana.make_tile(config, perturb=1.0, **kw)
     if "river" in opts:                  # point sources (LuvSrc) in the walls and, with a mask, on the island's coast
         util.river_sources(st, "all" if "wells" in opts else "both" if "mask" in opts else "walls")
@@ -78,6 +80,8 @@ def _single(config, nsteps, variant=""):
                                                     # the Akv / Akt edge rule of gls_corstep.F across tile edges
                                                     (2, 2, "UPWELLING", "gls"), (2, 1, "BENCHMARK_TINY", "gls+basin+mask"),
                                                     (2, 2, "UPWELLING", "my25"), (1, 2, "BENCHMARK_TINY", "my25+basin+mask"),
+                                                    # UV_VIS2 rotated to geopotentials: the LDS patches of k_uv3dmix2_geo against tile edges
+                                                    (2, 2, "SEAMOUNT", "geouv"), (2, 1, "BENCHMARK_TINY", "geouv+basin+mask"), (3, 1, "BENCHMARK_TINY", "geouv+wet"),
                                                     # WET_DRY: masks, their fast-time sum and the drying shoreline across
                                                     # tile edges
                                                     (2, 2, "UPWELLING", "wet"), (2, 2, "UPWELLING", "wet+basin+mask"),

@@ -43,6 +43,8 @@ def _single(config, nsteps, variant=""):
         kw.setdefault("overrides", {})["gls"] = "k-epsilon"
     if "my25" in opts:                   # MY25_MIXING (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES)
         kw.setdefault("overrides", {})["gls"] = "my25"
+    if "geouv" in opts:                  # UV_VIS2 with MIX_GEO_UV (uv3dmix2_geo.h)
+        kw.setdefault("overrides", {}).update({"uv_vis2": 2, **({"visc2": 50.0} if config == "SEAMOUNT" else {})})
     if "wet" in opts:                    # WET_DRY on the beach bathymetry of ana.py (the shoreline crosses tile edges)
         kw.setdefault("overrides", {}).update({"wet_dry": 1, "beach": 1, "zeta_amp": 0.3})
     st = ana.make_tile(config, perturb=1.0, **kw)
@@ -70,6 +72,8 @@ def _single(config, nsteps, variant=""):
                                                     # tke / gls, the Akv / Akt edge rule of gls_corstep.F)
                                                     (2, 2, "UPWELLING", "gls"), (2, 1, "BENCHMARK_TINY", "gls+basin+mask"),
                                                     (2, 2, "UPWELLING", "my25"), (1, 2, "BENCHMARK_TINY", "my25+basin+mask"),
+                                                    # UV_VIS2 rotated to geopotentials (uv3dmix2_geo.h) across tile edges
+                                                    (2, 2, "SEAMOUNT", "geouv"),
                                                     # WET_DRY: the wet/dry masks, their fast-time sum and the drying
                                                     # shoreline across tile edges; with land and on a basin
                                                     (2, 2, "UPWELLING", "wet"), (2, 2, "UPWELLING", "wet+basin+mask"),
