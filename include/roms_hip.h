@@ -130,7 +130,8 @@ typedef struct roms_params {
                                       * stflux(isalt) = (evap - rain) / rhow, bulk_flux.F:883-899 (alignment gap before R0) */
   double R0, T0, S0, Tcoef, Scoef;   /* linear EOS (rho_eos.F:576)           */
   /* CPP-derived option switches of the application header */
-  int    uv_adv, uv_cor, uv_vis2, curvgrid, var_rho_2d;
+  int    uv_adv, uv_cor, uv_vis2, curvgrid, var_rho_2d;   /* uv_vis2: 0 = no UV_VIS2, 1 = MIX_S_UV (uv3dmix2_s.h:114),
+                                                          * 2 = MIX_GEO_UV (uv3dmix2_geo.h:116) */
   int    ts_dif2, mix_geo_ts, mix_s_ts, salinity, lmd_nonlocal, solar_source;
   int    splines_vdiff, splines_vvisc;
   double Akt_bak[ROMS_MAXNT], Akv_bak;
@@ -295,7 +296,7 @@ int roms_hip_pre_step3d(const roms_step_idx_t *s);  /* pre_step3d.F:39   */
 int roms_hip_prsgrd(const roms_step_idx_t *s);      /* prsgrd32.h:40     */
 int roms_hip_t3dmix2(const roms_step_idx_t *s);     /* t3dmix2_geo.h:23  */
 int roms_hip_rhs3d_tile(const roms_step_idx_t *s);  /* rhs3d.F:174       */
-int roms_hip_uv3dmix2(const roms_step_idx_t *s);    /* uv3dmix2_s.h:42   */
+int roms_hip_uv3dmix2(const roms_step_idx_t *s);    /* uv3dmix2_s.h:42; with uv_vis2 = 2 uv3dmix2_geo.h:42 */
 int roms_hip_t3dmix4(const roms_step_idx_t *s);     /* t3dmix4_s.h:23, t3dmix4_geo.h:23 (TS_DIF4) */
 int roms_hip_uv3dmix4(const roms_step_idx_t *s);    /* uv3dmix4_s.h:43 (UV_VIS4; three ghost points, inp_par.F:268) */
 /* step2d(ng,tile)                  ROMS/Nonlinear/step2d_LF_AM3.h:18 */
