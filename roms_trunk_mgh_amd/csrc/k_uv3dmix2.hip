@@ -391,45 +391,85 @@ k_uv3dmix2_geo(const RomsDev *__restrict__ c, int nrhs, int nnew)
   const long ao = own ? I2(io, jo) : 0;
   if (do_u) ruf = c->F.rufrc[ao];
   if (do_v) rvf = c->F.rvfrc[ao];
+  // every thread looks after at most two points of the patch (q = tid, tid + 256); what those points need from the
+  // k-independent fields for the gradients of a level -- the metric factors of the reference's expressions with their
+  // masks, formed exactly as the reference forms them -- is kept in registers across the levels.  (The factors of the
+  // flux phase as well: 282 registers, one workgroup per CU, 2.09 ms against 1.88 -- measured and left out.)
+  constexpr int NPT = (GEO_P + BLK_X * BLK_Y - 1) / (BLK_X * BLK_Y);
+  static_assert(NPT == 2, "patch points per thread");
+  long pa[NPT];
+  int flag[NPT];                                   // 1: u-face range, 2: v-face, 4: rho, 8: psi
+  double cU[NPT], cV[NPT], cR1[NPT], cR2[NPT], pnE[NPT], pnW[NPT], pmN[NPT], pmS[NPT];
+  double cP1[NPT], cP2[NPT], pmA[NPT], pmB[NPT], pnA[NPT], pnB[NPT];
+#pragma unroll
+  for (int r = 0; r < NPT; r++) {
+    const int q = tid + r * BLK_X * BLK_Y;
+    flag[r] = 0; pa[r] = 0;
+    cU[r] = cV[r] = cR1[r] = cR2[r] = pnE[r] = pnW[r] = pmN[r] = pmS[r] = 0.0;
+    cP1[r] = cP2[r] = pmA[r] = pmB[r] = pnA[r] = pnB[r] = 0.0;
+    if (q < GEO_P) {
+      const int i = i0 - 1 + q % GEO_W, j = j0 - 1 + q / GEO_W;
+      const long a = I2(i, j);
+      pa[r] = a;
+      if (i >= IstrU - 1 && i <= Iend + 1 && j >= Jstr - 1 && j <= Jend + 1) flag[r] |= 1;
+      if (i >= Istr - 1 && i <= Iend + 1 && j >= JstrV - 1 && j <= Jend + 1) flag[r] |= 2;
+      if (i >= IstrU - 1 && i <= Iend && j >= JstrV - 1 && j <= Jend) flag[r] |= 4;
+      if (i >= Istr && i <= Iend + 1 && j >= Jstr && j <= Jend + 1) flag[r] |= 8;
+      if (flag[r] & 1) {
+        double cff = 0.5 * (pm[a - 1] + pm[a]);
+        if (msk) cff = cff * umaskw(c, a);
+        cU[r] = cff;
+      }
+      if (flag[r] & 2) {
+        double cff = 0.5 * (pn[a - ni] + pn[a]);
+        if (msk) cff = cff * vmaskw(c, a);
+        cV[r] = cff;
+      }
+      if (flag[r] & 4) {
+        const double m = msk ? rmaskw(c, a) : 1.0;
+        double cff = 0.5 * pm[a];
+        if (msk) cff = cff * m;
+        cR1[r] = cff;
+        cff = 0.5 * pn[a];
+        if (msk) cff = cff * m;
+        cR2[r] = cff;
+        pnE[r] = pn[a] + pn[a + 1]; pnW[r] = pn[a - 1] + pn[a];
+        pmN[r] = pm[a] + pm[a + ni]; pmS[r] = pm[a - ni] + pm[a];
+      }
+      if (flag[r] & 8) {
+        const double m = msk ? pmaskw(c, a) : 1.0;
+        double cff = 0.125 * (pn[a - 1] + pn[a] + pn[a - 1 - ni] + pn[a - ni]);
+        if (msk) cff = cff * m;
+        cP1[r] = cff;
+        cff = 0.125 * (pm[a - 1] + pm[a] + pm[a - 1 - ni] + pm[a - ni]);
+        if (msk) cff = cff * m;
+        cP2[r] = cff;
+        pmA[r] = pm[a - 1] + pm[a]; pmB[r] = pm[a - 1 - ni] + pm[a - ni];
+        pnA[r] = pn[a - ni] + pn[a]; pnB[r] = pn[a - 1 - ni] + pn[a - 1];
+      }
+    }
+  }
   int k1, k2 = 1;
   for (int k = 0; k <= N; k++) {
     k1 = k2;
     k2 = 1 - k1;
     // ---- phase 1: everything of level k+1 that depends on the fields alone -> slot k2
-    for (int q = tid; q < GEO_P; q += BLK_X * BLK_Y) {
-      const int i = i0 - 1 + q % GEO_W, j = j0 - 1 + q / GEO_W;
-      const long a = I2(i, j);
-      const bool inU = i >= IstrU - 1 && i <= Iend + 1 && j >= Jstr - 1 && j <= Jend + 1;     // u-face range
-      const bool inV = i >= Istr - 1 && i <= Iend + 1 && j >= JstrV - 1 && j <= Jend + 1;     // v-face range
-      const bool inR = i >= IstrU - 1 && i <= Iend && j >= JstrV - 1 && j <= Jend;            // rho range
-      const bool inP = i >= Istr && i <= Iend + 1 && j >= Jstr && j <= Jend + 1;              // psi range
+#pragma unroll
+    for (int r = 0; r < NPT; r++) {
+      const int q = tid + r * BLK_X * BLK_Y;
+      const long a = pa[r];
+      const bool inU = flag[r] & 1, inV = flag[r] & 2, inR = flag[r] & 4, inP = flag[r] & 8;
       if (k < N) {
         const long ak = a + (long)k * nij;                                                    // level k+1
-        if (inU) {                                                                            // :303-340
-          double cff = 0.5 * (pm[a - 1] + pm[a]);
-          if (msk) cff = cff * umaskw(c, a);
-          sSx[k2][q] = cff * (z_r[ak] - z_r[ak - 1]);
-        }
-        if (inV) {
-          double cff = 0.5 * (pn[a - ni] + pn[a]);
-          if (msk) cff = cff * vmaskw(c, a);
-          sSe[k2][q] = cff * (z_r[ak] - z_r[ak - ni]);
-        }
+        if (inU) sSx[k2][q] = cU[r] * (z_r[ak] - z_r[ak - 1]);                                // :303-340
+        if (inV) sSe[k2][q] = cV[r] * (z_r[ak] - z_r[ak - ni]);
         if (inR) {                                                                            // :345-412
-          double cff = 0.5 * pm[a];
-          if (msk) cff = cff * rmaskw(c, a);
-          sdnUdx[k2][q] = cff * ((pn[a] + pn[a + 1]) * u[ak + 1] - (pn[a - 1] + pn[a]) * u[ak]);
-          cff = 0.5 * pn[a];
-          if (msk) cff = cff * rmaskw(c, a);
-          sdmVde[k2][q] = cff * ((pm[a] + pm[a + ni]) * v[ak + ni] - (pm[a - ni] + pm[a]) * v[ak]);
+          sdnUdx[k2][q] = cR1[r] * (pnE[r] * u[ak + 1] - pnW[r] * u[ak]);
+          sdmVde[k2][q] = cR2[r] * (pmN[r] * v[ak + ni] - pmS[r] * v[ak]);
         }
         if (inP) {
-          double cff = 0.125 * (pn[a - 1] + pn[a] + pn[a - 1 - ni] + pn[a - ni]);
-          if (msk) cff = cff * pmaskw(c, a);
-          sdmUde[k2][q] = cff * ((pm[a - 1] + pm[a]) * u[ak] - (pm[a - 1 - ni] + pm[a - ni]) * u[ak - ni]);
-          cff = 0.125 * (pm[a - 1] + pm[a] + pm[a - 1 - ni] + pm[a - ni]);
-          if (msk) cff = cff * pmaskw(c, a);
-          sdnVdx[k2][q] = cff * ((pn[a - ni] + pn[a]) * v[ak] - (pn[a - 1 - ni] + pn[a - 1]) * v[ak - 1]);
+          sdmUde[k2][q] = cP1[r] * (pmA[r] * u[ak] - pmB[r] * u[ak - ni]);
+          sdnVdx[k2][q] = cP2[r] * (pnA[r] * v[ak] - pnB[r] * v[ak - 1]);
         }
       }
       if (k == 0 || k == N) {                                                                 // :414-440
